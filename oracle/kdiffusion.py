@@ -1,0 +1,246 @@
+"""fp32 CPU restatement of the sampler layer (oracle; tests only).
+
+Third-party arithmetic restated from its published algorithm, anchored on the reference's call sites:
+  crowsonkb/k-diffusion @ ab527a9a6d347f364e3d185ba6d714e22d80cb3c (pinned modules/launch_utils.py:349-357)
+    external.DiscreteSchedule / DiscreteEpsDDPMDenoiser / CompVisDenoiser
+        -> constructed at modules/sd_samplers_kdiffusion.py:53-64
+    sampling.get_sigmas_karras, get_ancestral_step, sample_euler, sample_euler_ancestral,
+    sampling.sample_dpmpp_2m  -> selected by the table at modules/sd_samplers_kdiffusion.py:11-27
+    sampling.to_d             -> overridden in-tree at modules/sd_schedulers.py:10-15 (followed)
+  ldm "linear" beta schedule  -> configs/v1-inference.yaml:5-9, restated in-tree at
+                                 modules/models/diffusion/ddpm_edit.py:133-154
+  DDIM                        -> modules/sd_samplers_timesteps_impl.py:12-40 (in-repo; pinned by fixture)
+  DDIM timesteps              -> modules/sd_samplers_timesteps.py:86-96
+  img2img step arithmetic     -> modules/sd_samplers_common.py:22-31, sd_samplers_kdiffusion.py:134-143
+Known answers checked in tests: sigma_min 0.0291672, sigma_max 14.614641, get_sigmas(20) table,
+Karras rho=7 n=50 endpoints (hints at modules/shared_options.py:396-397).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+# ---------------------------------------------------------------------------------------------
+# DDPM schedule
+# ---------------------------------------------------------------------------------------------
+def make_alphas_cumprod(linear_start=0.00085, linear_end=0.0120, n=1000) -> torch.Tensor:
+    betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n, dtype=torch.float64) ** 2
+    alphas = 1.0 - betas.numpy()
+    return torch.tensor(np.cumprod(alphas, axis=0), dtype=torch.float32)
+
+
+def append_zero(x):
+    return torch.cat([x, x.new_zeros([1])])
+
+
+def append_dims(x, n):
+    return x[(...,) + (None,) * (n - x.ndim)]
+
+
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
+    ramp = torch.linspace(0, 1, n)
+    min_inv_rho = sigma_min ** (1 / rho)
+    max_inv_rho = sigma_max ** (1 / rho)
+    sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    return append_zero(sigmas)
+
+
+class DiscreteSchedule:
+    def __init__(self, sigmas: torch.Tensor, quantize: bool = False):
+        self.sigmas = sigmas
+        self.log_sigmas = sigmas.log()
+        self.quantize = quantize
+
+    @property
+    def sigma_min(self):
+        return self.sigmas[0]
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def get_sigmas(self, n=None):
+        if n is None:
+            return append_zero(self.sigmas.flip(0))
+        t_max = len(self.sigmas) - 1
+        t = torch.linspace(t_max, 0, n)
+        return append_zero(self.t_to_sigma(t))
+
+    def sigma_to_t(self, sigma, quantize=None):
+        quantize = self.quantize if quantize is None else quantize
+        log_sigma = sigma.log()
+        dists = log_sigma - self.log_sigmas[:, None]
+        if quantize:
+            return dists.abs().argmin(dim=0).view(sigma.shape)
+        low_idx = dists.ge(0).cumsum(dim=0).argmax(dim=0).clamp(max=self.log_sigmas.shape[0] - 2)
+        high_idx = low_idx + 1
+        low, high = self.log_sigmas[low_idx], self.log_sigmas[high_idx]
+        w = (low - log_sigma) / (low - high)
+        w = w.clamp(0, 1)
+        t = (1 - w) * low_idx + w * high_idx
+        return t.view(sigma.shape)
+
+    def t_to_sigma(self, t):
+        t = t.float()
+        low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
+        log_sigma = (1 - w) * self.log_sigmas[low_idx] + w * self.log_sigmas[high_idx]
+        return log_sigma.exp()
+
+
+class CompVisDenoiser(DiscreteSchedule):
+    """eps-prediction wrapper: denoised = x + eps(x*c_in, t(sigma)) * c_out, c_out=-sigma, c_in=1/sqrt(sigma^2+1)."""
+
+    def __init__(self, apply_model, alphas_cumprod, quantize=False):
+        super().__init__(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5, quantize)
+        self.apply_model = apply_model     # callable(x, t, cond) -> eps
+        self.sigma_data = 1.0
+
+    def get_scalings(self, sigma):
+        c_out = -sigma
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_out, c_in
+
+    def __call__(self, input, sigma, cond):
+        c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
+        eps = self.apply_model(input * c_in, self.sigma_to_t(sigma), cond)
+        return input + eps * c_out
+
+
+# ---------------------------------------------------------------------------------------------
+# CFG  (modules/sd_samplers_cfg_denoiser.py:74-82, 156-311 for the plain txt2img case:
+#       one cond per image with weight 1.0, equal token counts, batch_cond_uncond on, no mask)
+# ---------------------------------------------------------------------------------------------
+class CFGDenoiser:
+    def __init__(self, inner_model, mask=None, nmask=None, init_latent=None):
+        self.inner_model = inner_model
+        self.step = 0
+        self.mask, self.nmask, self.init_latent = mask, nmask, init_latent
+        self.mask_before_denoising = False
+
+    @staticmethod
+    def combine_denoised(x_out, conds_list, uncond_n, cond_scale):
+        denoised_uncond = x_out[-uncond_n:]
+        denoised = torch.clone(denoised_uncond)
+        for i, conds in enumerate(conds_list):
+            for cond_index, weight in conds:
+                denoised[i] += (x_out[cond_index] - denoised_uncond[i]) * (weight * cond_scale)
+        return denoised
+
+    def __call__(self, x, sigma, uncond, cond, cond_scale):
+        b = x.shape[0]
+        conds_list = [[(i, 1.0)] for i in range(b)]
+        if self.mask_before_denoising and self.mask is not None:
+            x = x * self.nmask + self.init_latent * self.mask
+        x_in = torch.cat([x, x])
+        sigma_in = torch.cat([sigma, sigma])
+        cond_in = torch.cat([cond, uncond])
+        x_out = self.inner_model(x_in, sigma_in, cond_in)
+        denoised = self.combine_denoised(x_out, conds_list, b, cond_scale)
+        if not self.mask_before_denoising and self.mask is not None:
+            denoised = denoised * self.nmask + self.init_latent * self.mask
+        self.step += 1
+        return denoised
+
+
+# ---------------------------------------------------------------------------------------------
+# samplers (noise_fn() returns the next per-image noise tensor = TorchHijack.randn_like,
+#           modules/sd_samplers_common.py:205-226)
+# ---------------------------------------------------------------------------------------------
+def to_d(x, sigma, denoised):
+    return (x - denoised) / sigma            # modules/sd_schedulers.py:10-15
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    if not eta:
+        return sigma_to, 0.0
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def sample_euler_ancestral(model, x, sigmas, extra_args, noise_fn, eta=1.0, s_noise=1.0, callback=None):
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        d = to_d(x, sigmas[i], denoised)
+        dt = sigma_down - sigmas[i]
+        x = x + d * dt
+        if sigmas[i + 1] > 0:
+            x = x + noise_fn() * s_noise * sigma_up
+    return x
+
+
+def sample_euler(model, x, sigmas, extra_args, noise_fn=None, callback=None):
+    """s_churn = 0 (reference default, modules/sd_samplers_common.py:242): sigma_hat == sigma."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        d = to_d(x, sigmas[i], denoised)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        dt = sigmas[i + 1] - sigmas[i]
+        x = x + d * dt
+    return x
+
+
+def sample_dpmpp_2m(model, x, sigmas, extra_args, noise_fn=None, callback=None):
+    s_in = x.new_ones([x.shape[0]])
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda sigma: sigma.log().neg()
+    old_denoised = None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        h = t_next - t
+        if old_denoised is None or sigmas[i + 1] == 0:
+            x = (sigma_fn(t_next) / sigma_fn(t)) * x - (-h).expm1() * denoised
+        else:
+            h_last = t - t_fn(sigmas[i - 1])
+            r = h_last / h
+            denoised_d = (1 + 1 / (2 * r)) * denoised - (1 / (2 * r)) * old_denoised
+            x = (sigma_fn(t_next) / sigma_fn(t)) * x - (-h).expm1() * denoised_d
+        old_denoised = denoised
+    return x
+
+
+def ddim_timesteps(steps: int) -> torch.Tensor:
+    """modules/sd_samplers_timesteps.py:94"""
+    return torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+
+
+def sample_ddim(model, x, timesteps, alphas_cumprod, extra_args, noise_fn, eta=0.0, callback=None):
+    """modules/sd_samplers_timesteps_impl.py:12-40.  ``model(x, t*s_in, **extra_args)`` returns eps (the CFG
+    combine of eps predictions, CFGDenoiserTimesteps); alphas_prev is float64 as in the reference (:15)."""
+    alphas = alphas_cumprod[timesteps]
+    alphas_prev = alphas_cumprod[torch.nn.functional.pad(timesteps[:-1], pad=(1, 0))].to(torch.float64)
+    sqrt_one_minus_alphas = torch.sqrt(1 - alphas)
+    sigmas = eta * np.sqrt((1 - alphas_prev.cpu().numpy()) / (1 - alphas.cpu()) * (1 - alphas.cpu() / alphas_prev.cpu().numpy()))
+    s_in = x.new_ones((x.shape[0]))
+    s_x = x.new_ones((x.shape[0], 1, 1, 1))
+    for i in range(len(timesteps) - 1):
+        index = len(timesteps) - 1 - i
+        e_t = model(x, timesteps[index].item() * s_in, **extra_args)
+        a_t = alphas[index].item() * s_x
+        a_prev = alphas_prev[index].item() * s_x
+        sigma_t = sigmas[index].item() * s_x
+        sqrt_one_minus_at = sqrt_one_minus_alphas[index].item() * s_x
+        pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+        dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
+        noise = sigma_t * noise_fn()
+        x = a_prev.sqrt() * pred_x0 + dir_xt + noise
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': 0, 'sigma_hat': 0, 'denoised': pred_x0})
+    return x
+
+
+def setup_img2img_steps(requested_steps: int, denoising_strength: float):
+    """modules/sd_samplers_common.py:22-31 with ``steps`` given (img2img_fix_steps path)."""
+    steps = int(requested_steps / min(denoising_strength, 0.999)) if denoising_strength > 0 else 0
+    t_enc = requested_steps - 1
+    return steps, t_enc

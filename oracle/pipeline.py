@@ -1,0 +1,95 @@
+"""End-to-end CPU restatement of the txt2img / img2img hot path (oracle; tests + bench cpu_baseline only).
+
+Follows the call stack in SURVEY.md section 3.1: ``StableDiffusionProcessingTxt2Img.sample``
+(modules/processing.py:1307-1346) -> ``KDiffusionSampler.sample`` (modules/sd_samplers_kdiffusion.py:190-234)
+-> k-diffusion sampler loop -> ``CFGDenoiser.forward`` (modules/sd_samplers_cfg_denoiser.py:156-311) ->
+``CompVisDenoiser`` -> UNet; then ``decode_latent_batch`` (modules/processing.py:625-672) and the uint8
+conversion (:1004-1005, :1034-1035).  Everything runs in fp32 on CPU = the reference's CI configuration
+``--use-cpu all --no-half --disable-opt-split-attention`` (.github/workflows/run_tests.yaml:44-56).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import kdiffusion as kd
+from .rng import ImageRNG
+from .unet import UNetConfig, build_unet
+from .vae import VAEConfig, build_vae, to_uint8_hwc
+
+
+class OracleModel:
+    def __init__(self, state_dict, unet_cfg: UNetConfig, vae_cfg: VAEConfig | None = None):
+        self.unet = build_unet(unet_cfg, state_dict)
+        self.vae = build_vae(vae_cfg, state_dict) if vae_cfg is not None else None
+        ac = state_dict.get("alphas_cumprod")
+        self.alphas_cumprod = ac.float() if ac is not None else kd.make_alphas_cumprod()
+
+    def apply_model(self, x, t, cond, y=None):
+        return self.unet(x, t, cond, y)
+
+
+def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, scheduler: str = "automatic"):
+    """modules/sd_samplers_kdiffusion.py:79-132 for the two schedules the configs use."""
+    if scheduler == "automatic":
+        scheduler = "karras" if sampler == "dpmpp_2m" else "uniform"
+    if scheduler == "karras":
+        return kd.get_sigmas_karras(steps, model_wrap.sigmas[0].item(), model_wrap.sigmas[-1].item())
+    return model_wrap.get_sigmas(steps)
+
+
+@torch.no_grad()
+def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
+           latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
+           y=None, uy=None, record=None):
+    """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
+    (modules/sd_samplers_kdiffusion.py:134-143)."""
+    b = len(seeds)
+    rng = ImageRNG((4, latent_hw[0], latent_hw[1]), seeds)
+    x = rng.next()
+
+    def apply_model(xi, t, c):
+        if y is not None:
+            return model.apply_model(xi, t, c, torch.cat([y, uy]))
+        return model.apply_model(xi, t, c)
+
+    if sampler == "ddim":
+        # CFGDenoiserTimesteps: inner model is apply_model on integer timesteps, CFG combines eps.
+        cfg = kd.CFGDenoiser(lambda xi, ti, ci: apply_model(xi, ti, ci))
+        cfg.mask_before_denoising = True
+        ts = kd.ddim_timesteps(steps)
+        extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
+        return kd.sample_ddim(cfg, x, ts, model.alphas_cumprod, extra, rng.next,
+                              eta=0.0 if eta is None else eta, callback=record)
+
+    wrap = kd.CompVisDenoiser(apply_model, model.alphas_cumprod)
+    cfg = kd.CFGDenoiser(wrap)
+    extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
+    if init_latent is None:
+        sigmas = get_sigmas(wrap, sampler, steps)
+        x = x * sigmas[0]
+    else:
+        total, t_enc = kd.setup_img2img_steps(steps, denoising_strength)
+        sigmas = get_sigmas(wrap, sampler, total)[total - t_enc - 1:]
+        x = init_latent + x * sigmas[0]
+    if sampler == "euler_a":
+        return kd.sample_euler_ancestral(cfg, x, sigmas, extra, rng.next, eta=1.0 if eta is None else eta,
+                                         s_noise=s_noise, callback=record)
+    if sampler == "euler":
+        return kd.sample_euler(cfg, x, sigmas, extra, callback=record)
+    if sampler == "dpmpp_2m":
+        return kd.sample_dpmpp_2m(cfg, x, sigmas, extra, callback=record)
+    raise ValueError(sampler)
+
+
+@torch.no_grad()
+def decode(model: OracleModel, latents):
+    """decode_latent_batch: one image at a time (modules/processing.py:631-632)."""
+    return torch.stack([model.vae.decode_first_stage(latents[i:i + 1])[0] for i in range(latents.shape[0])])
+
+
+@torch.no_grad()
+def txt2img(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
+            latent_hw=(64, 64), **kw):
+    lat = sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, latent_hw, **kw)
+    img = decode(model, lat)
+    return lat, img, to_uint8_hwc(img)

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures from the importable pieces of the reference (run in the authoring container,
+where /root/reference exists; the GPU box only sees the committed .npz files).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Reference files executed (loaded by path, unmodified):
+  modules/rng_philox.py                      -> philox.npz
+  modules/sub_quadratic_attention.py         -> subquad_attention.npz
+  modules/models/sd3/sd3_impls.py            -> vae_decoder.npz, vae_encoder.npz   (VAEDecoder / VAEEncoder, z_channels=4)
+  modules/sd_samplers_timesteps_impl.py      -> ddim.npz                            (ddim(), with stub modules)
+Weights / inputs are produced by ``seeded()`` below (CPU torch.Generator, N(0,1) scaled), so a fixture stores
+only seeds + the reference's outputs; tests regenerate the same inputs.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("SD_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def seeded(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32) * scale
+
+
+def seeded_module_weights(module, seed):
+    """Fill every parameter of ``module`` (in state_dict order) with seeded values; returns nothing."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.state_dict().items():
+            if p.ndim >= 2:
+                fan_in = int(np.prod(p.shape[1:]))
+                p.copy_(torch.randn(p.shape, generator=g) * fan_in ** -0.5)
+            elif name.endswith("weight"):
+                p.copy_(1.0 + 0.02 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+
+
+def gen_philox():
+    m = load_by_path("ref_rng_philox", "modules/rng_philox.py")
+    out = {}
+    cases = [(0, (3, 4), 1), (1000, (4, 8, 8), 3), (1007, (4, 16, 16), 2), (2 ** 32 + 5, (2, 5), 2), (123456789, (1, 4, 64, 64), 1)]
+    for ci, (seed, shape, draws) in enumerate(cases):
+        g = m.Generator(seed)
+        for d in range(draws):
+            out[f"c{ci}_seed{seed}_draw{d}"] = g.randn(shape)
+    out["docstring_seed0"] = np.array([[-0.92466259, -0.42534415, -2.6438457, 0.14518388],
+                                       [-0.12086647, -0.57972564, -0.62285122, -0.32838709],
+                                       [-1.07454231, -0.36314407, -1.67105067, 2.26550497]], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "philox.npz"), **out)
+    print("philox.npz", len(out))
+
+
+def gen_subquad():
+    m = load_by_path("ref_subquad", "modules/sub_quadratic_attention.py")
+    out = {}
+    for ci, (bh, n, mk, d, qc, kc) in enumerate([(4, 96, 96, 40, 32, 32), (2, 64, 77, 80, 64, 16), (3, 50, 130, 160, 16, 64)]):
+        q, k, v = seeded((bh, n, d), 10 + ci), seeded((bh, mk, d), 20 + ci), seeded((bh, mk, d), 30 + ci)
+        o = m.efficient_dot_product_attention(q, k, v, query_chunk_size=qc, kv_chunk_size=kc, use_checkpoint=False)
+        out[f"c{ci}_shape"] = np.array([bh, n, mk, d])
+        out[f"c{ci}_out"] = o.numpy()
+    np.savez_compressed(os.path.join(OUT, "subquad_attention.npz"), **out)
+    print("subquad_attention.npz")
+
+
+def gen_vae():
+    stub = types.ModuleType("modules.models.sd3.mmdit")
+    stub.MMDiT = object
+    for name in ("modules", "modules.models", "modules.models.sd3"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["modules.models.sd3.mmdit"] = stub
+    m = load_by_path("ref_sd3_impls", "modules/models/sd3/sd3_impls.py")
+    with torch.no_grad():
+        # full-size SD1.5 decoder (49,490,179 params) on an 8x8 latent, and a small one on 16x16
+        dec = m.VAEDecoder(z_channels=4)
+        seeded_module_weights(dec, 777)
+        z = seeded((1, 4, 8, 8), 778)
+        out = {"full_nparams": np.array(sum(p.numel() for p in dec.parameters())),
+               "full_out": dec(z).numpy()}
+        dec_s = m.VAEDecoder(ch=64, ch_mult=(1, 2), num_res_blocks=1, z_channels=4)
+        seeded_module_weights(dec_s, 779)
+        z = seeded((2, 4, 16, 16), 780)
+        out["small_out"] = dec_s(z).numpy()
+        np.savez_compressed(os.path.join(OUT, "vae_decoder.npz"), **out)
+        enc = m.VAEEncoder(ch=64, ch_mult=(1, 2), num_res_blocks=1, z_channels=4)
+        seeded_module_weights(enc, 781)
+        x = seeded((2, 3, 32, 32), 782)
+        np.savez_compressed(os.path.join(OUT, "vae_encoder.npz"), small_out=enc(x).numpy())
+    print("vae_decoder.npz vae_encoder.npz")
+
+
+def gen_ddim():
+    # stub the modules sd_samplers_timesteps_impl imports (k_diffusion is third-party and absent here)
+    kd = types.ModuleType("k_diffusion")
+    kds = types.ModuleType("k_diffusion.sampling")
+    kd.sampling = kds
+    sys.modules["k_diffusion"] = kd
+    sys.modules["k_diffusion.sampling"] = kds
+    for name in ("modules", "modules.models", "modules.models.diffusion"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    shared = types.ModuleType("modules.shared")
+    sys.modules["modules.shared"] = shared
+    sys.modules["modules"].shared = shared
+    unipc_pkg = types.ModuleType("modules.models.diffusion.uni_pc")
+    unipc_pkg.uni_pc = types.ModuleType("modules.models.diffusion.uni_pc.uni_pc")
+    unipc_pkg.uni_pc.UniPC = object          # only subclassed at import time, never used by ddim()
+    sys.modules["modules.models.diffusion.uni_pc"] = unipc_pkg
+    tu = load_by_path("modules.torch_utils", "modules/torch_utils.py")
+    sys.modules["modules"].torch_utils = tu
+    try:
+        import tqdm  # noqa: F401
+    except ImportError:
+        t = types.ModuleType("tqdm")
+        t.trange = lambda n, disable=None: range(n)
+        sys.modules["tqdm"] = t
+    impl = load_by_path("ref_timesteps_impl", "modules/sd_samplers_timesteps_impl.py")
+
+    betas = torch.linspace(0.00085 ** 0.5, 0.0120 ** 0.5, 1000, dtype=torch.float64) ** 2
+    alphas_cumprod = torch.tensor(np.cumprod(1.0 - betas.numpy(), axis=0), dtype=torch.float32)
+
+    class Inner2:
+        pass
+
+    class Inner1:
+        pass
+
+    class Model:
+        """model.inner_model.inner_model.alphas_cumprod as in the reference; a fixed analytic eps function."""
+        def __init__(self):
+            self.inner_model = Inner1()
+            self.inner_model.inner_model = Inner2()
+            self.inner_model.inner_model.alphas_cumprod = alphas_cumprod
+
+        def __call__(self, x, t, **kw):
+            return torch.tanh(0.7 * x + (t / 1000.0)[:, None, None, None]) * 0.9 + 0.05 * x
+
+    out = {}
+    for ci, (steps, eta) in enumerate([(20, 0.0), (7, 0.5)]):
+        noise_draws = [seeded((2, 4, 8, 8), 900 + i) for i in range(steps + 2)]
+        it = iter(noise_draws)
+
+        class TH:
+            @staticmethod
+            def randn_like(x):
+                return next(it)
+        kds.torch = TH
+        timesteps = torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+        x0 = seeded((2, 4, 8, 8), 890 + ci)
+        res = impl.ddim(Model(), x0.clone(), timesteps, extra_args={}, disable=True, eta=eta)
+        out[f"c{ci}_steps_eta"] = np.array([steps, eta])
+        out[f"c{ci}_out"] = res.numpy()
+    np.savez_compressed(os.path.join(OUT, "ddim.npz"), **out)
+    print("ddim.npz")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_philox()
+    gen_subquad()
+    gen_vae()
+    gen_ddim()
