@@ -1,0 +1,230 @@
+/* sdmi.h — C ABI of the MI355X-native Stable Diffusion hot-path engine (libsdmi.so).
+ *
+ * Drop-in boundary for ONE path of AUTOMATIC1111/stable-diffusion-webui: the txt2img/img2img UNet denoising
+ * loop + k-diffusion/DDIM sampler arithmetic + VAE decode.  The reference has no FFI of its
+ * own (it is pure Python over torch); each entry point below states the reference interface it replaces
+ * (paths relative to /root/reference).  The Python/ctypes binding a webui maintainer adds is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the engine's GPU unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it;
+ *   - return value: 0 = ok, non-zero = error; sdmi_last_error() returns a thread-local message;
+ *   - fp16 = IEEE binary16 ("half"); all accumulation is fp32; activations inside the engine are NHWC fp16;
+ *   - no torch / python types appear here.
+ */
+#ifndef SDMI_H
+#define SDMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDMI_VERSION 100
+
+enum { SDMI_F16 = 0, SDMI_F32 = 1 };
+
+typedef struct sdmi_engine sdmi_engine;
+
+int sdmi_version(void);
+const char* sdmi_last_error(void);
+/* 1 if a gfx950 device is visible to HIP, else 0 (never throws). */
+int sdmi_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Op-level entry points (boundary B2 "SdOptimization", and the units the parity tests exercise one by one).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Fused QK^T * scale -> softmax -> PV, never materialising the score matrix.
+ * Replaces: the attention math inside every CrossAttention.forward the webui can select —
+ *   modules/sd_hijack_optimizations.py:221-281 (split_cross_attention_forward, GPU default),
+ *   :508-546 (sdp), :480-503 (xformers), modules/hypernetworks/hypernetwork.py:382-407 (baseline),
+ *   algorithm twin modules/sub_quadratic_attention.py:141-215.
+ * q   [B, N, ldq]  head h at columns [h*D, (h+1)*D)            (fp16)
+ * k   [B, M, ldk]  same head layout                             (fp16)
+ * v   [B, M, ldv]  same head layout (row-major; transposed internally into `workspace`)
+ * out [B, N, ldo]                                                (fp16)
+ * workspace: at least sdmi_attention_workspace_bytes(B,H,M,D) bytes of device memory.
+ * D in {40, 64, 80, 128, 160} runs the MFMA kernel; any other D <= 512 runs the generic HIP kernel. */
+int64_t sdmi_attention_workspace_bytes(int B, int H, int M, int D);
+int sdmi_attention(const void* q, const void* k, const void* v, void* out,
+                   int B, int H, int N, int M, int D,
+                   int ldq, int ldk, int ldv, int ldo, float scale,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Same, with V already transposed by the producer: vt [B, H*D, Mpad] (row = h*D+d, Mpad = vt_ld >= M rounded up to 64,
+ * padding columns must be finite).  This is what the engine's UNet uses (its V projection writes V^T directly). */
+int sdmi_attention_vt(const void* q, const void* k, const void* vt, void* out,
+                      int B, int H, int N, int M, int D,
+                      int ldq, int ldk, int vt_ld, int ldo, float scale, int force_generic, void* stream);
+
+/* Implicit-GEMM convolution / linear layer on NHWC fp16 activations (MFMA, LDS-staged):
+ *   out[m, n] = epilogue( alpha * sum_{tap,c} A(m, tap, c) * W[n, tap*Cin + c] )
+ * Replaces the torch ops issued by ldm's ResBlock / Downsample / Upsample / SpatialTransformer / FeedForward modules
+ * (third-party; layer names pinned at extensions-builtin/Lora/networks.py:43-98; op inventory SURVEY.md 2.3 K1,K4,K7,K8).
+ * All fields are plain values / device pointers. */
+typedef struct sdmi_conv_desc {
+    const void* a0;        /* source 0, NHWC fp16 [B,Hi,Wi,c0] (pixel stride lda0 elements) */
+    const void* a1;        /* optional source 1 (channel-concatenated after source 0), or NULL */
+    const void* w;         /* packed weights fp16 [N][taps*(c0+c1)], k = tap*Cin + c, tap = ky*3+kx */
+    const void* bias;      /* fp32 [N] (or [M] when SDMI_EP_BIAS_ROW), or NULL */
+    const void* rowbias;   /* fp32 [B][N] added to every pixel of image b (ResBlock emb add), or NULL */
+    const void* resid;     /* fp16 [M][ldr] added before the store, or NULL */
+    void* out;             /* fp16 or fp32, row-major [M][ldo] or NCHW fp32 */
+    int32_t c0, c1, lda0, lda1;
+    int32_t B, Hi, Wi, Ho, Wo;
+    int32_t taps;          /* 1 or 9 */
+    int32_t stride;        /* 1 or 2 */
+    int32_t pad;           /* 1: symmetric "padding=1"; 0: none (VAE-encoder downsample pads right/bottom only) */
+    int32_t up;            /* 1: nearest x2 upsample of the source fused into the gather */
+    int32_t N;             /* output channels as packed (multiple of 64 for the MFMA kernel) */
+    int32_t n_real;        /* output channels actually stored (NCHW mode), else = N */
+    int32_t ldo, ldr;
+    int32_t flags;         /* SDMI_EP_* */
+    float alpha;
+    int32_t batch;         /* grid.z batched GEMM count (>=1) with the strides below (elements) */
+    int64_t a_bs, w_bs, o_bs, r_bs;
+    int32_t force_generic; /* 1: run the simple non-MFMA HIP kernel (debug / unsupported shapes) */
+    int32_t reserved;
+} sdmi_conv_desc;
+
+enum {
+    SDMI_EP_OUT_F32  = 1,   /* store fp32 instead of fp16 */
+    SDMI_EP_GEGLU    = 2,   /* W rows packed in (32 value | 32 gate) groups; out has N/2 columns: a*gelu(g) */
+    SDMI_EP_NCHW     = 4,   /* store fp32 NCHW [B][n_real][Ho][Wo] */
+    SDMI_EP_BIAS_ROW = 8    /* bias indexed by output row m instead of column n */
+};
+int sdmi_conv_gemm(const sdmi_conv_desc* d, void* stream);
+
+/* Repack helpers (device side, run once at load): OIHW fp16/fp32 conv weight -> [O][ky*3+kx][I(+pad)] fp16. */
+int sdmi_pack_conv_weight(const void* w_oihw, int dtype, void* out_f16, int O, int I, int kh, int kw,
+                          int O_pad, int I_pad, int geglu, void* stream);
+
+/* GroupNorm(32 groups, fp32 statistics) [+ SiLU] over NHWC fp16, optionally reading two channel-concatenated sources
+ * and writing one tensor.  Replaces ldm GroupNorm32 + SiLU (fp32 contract: modules/devices.py:284-295; SiLU forced at
+ * modules/sd_hijack.py:69) and the torch.cat of skip connections (modules/sd_hijack_unet.py:10-33). */
+int sdmi_groupnorm(const void* x0, const void* x1, int c0, int c1, const void* gamma_f32, const void* beta_f32,
+                   void* out_f16, int B, int HW, int groups, float eps, int silu,
+                   void* workspace_f32, int64_t workspace_bytes, void* stream);
+int64_t sdmi_groupnorm_workspace_bytes(int B, int HW, int groups);
+
+/* LayerNorm over the last dim of [rows, C] fp16 (fp32 statistics, eps 1e-5). */
+int sdmi_layernorm(const void* x, const void* gamma_f32, const void* beta_f32, void* out_f16,
+                   int64_t rows, int C, float eps, void* stream);
+
+/* Philox4x32-10 + Box-Muller normal draws, bit-compatible with the reference's "NV" noise source
+ * (modules/rng_philox.py:32-102): out[i] = randn(counter=[offset,0,i,0], key=seed). */
+int sdmi_philox_randn(void* out_f32, int64_t n, uint64_t seed, uint32_t offset, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sampler arithmetic (boundary B3): the elementwise work of CFGDenoiser + CompVisDenoiser + the k-diffusion /
+ * DDIM update, fused.  x is the fp32 sampler state [B,4,h,w] (NCHW, as the webui keeps it).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* x_in[r*B + b] = x[b] * c_in[b]  for r in 0..reps-1, written NCHW [reps*B, C, h, w] in out_dtype (SDMI_F16/F32).
+ * Replaces modules/sd_samplers_cfg_denoiser.py:203-205 (x_in = cat(cond copies, uncond)) + k-diffusion
+ * CompVisDenoiser's `input * c_in` + the cast to dtype_unet (modules/sd_hijack_unet.py:50). c_in_f32 may be NULL (=1). */
+int sdmi_cfg_prepare_input(const void* x_f32, const void* c_in_f32, void* x_in, int out_dtype,
+                           int B, int reps, int64_t chw, void* stream);
+
+/* denoised[b] = u + (c - u) * cond_scale  with  c = x + eps_c * c_out[b], u = x + eps_u * c_out[b]
+ * (eps = [cond(B) | uncond(B)], fp32 NCHW).  Replaces CompVisDenoiser's `input + eps * c_out` and
+ * CFGDenoiser.combine_denoised (modules/sd_samplers_cfg_denoiser.py:74-82) for one cond of weight 1 per image.
+ * mode 0: sigma-space (above);  mode 1: timestep-space (DDIM): out = eps_u + (eps_c - eps_u) * cond_scale.
+ * Optional mask blend (img2img, :174-187): out = out*nmask + init_latent*mask when mask != NULL. */
+int sdmi_cfg_combine(const void* x_f32, const void* eps_f32, const void* c_out_f32, float cond_scale, int mode,
+                     const void* mask_f32, const void* nmask_f32, const void* init_latent_f32,
+                     void* denoised_f32, int B, int64_t chw, void* stream);
+
+/* k-diffusion sample_euler_ancestral / sample_euler update (pinned k-diffusion@ab527a9; to_d per
+ * modules/sd_schedulers.py:10-15):  d=(x-den)/sigma; x+=d*(sigma_down-sigma); x+=noise*s_noise*sigma_up (if noise). */
+int sdmi_euler_step(void* x_f32, const void* denoised_f32, const void* noise_f32_or_null,
+                    float sigma, float sigma_down, float sigma_up, float s_noise, int64_t n, void* stream);
+
+/* k-diffusion sample_dpmpp_2m update: x = ratio*x - em1*(c1*den - c2*old_den)  (c2 = 0 on first/last step). */
+int sdmi_dpmpp2m_step(void* x_f32, const void* denoised_f32, const void* old_denoised_f32_or_null,
+                      float ratio, float em1, float c1, float c2, int64_t n, void* stream);
+
+/* DDIM update (modules/sd_samplers_timesteps_impl.py:30-36):
+ *   pred_x0=(x-sqrt_one_minus_at*e)/sqrt(a_t); x = sqrt(a_prev)*pred_x0 + sqrt(1-a_prev-sigma_t^2)*e + sigma_t*noise. */
+int sdmi_ddim_step(void* x_f32, const void* e_t_f32, const void* noise_f32_or_null, void* pred_x0_f32_or_null,
+                   float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, int64_t n, void* stream);
+
+/* y = a*x + b*z elementwise fp32 (x*sigmas[0]; init_latent + noise*sigma: modules/sd_samplers_kdiffusion.py:143,199). */
+int sdmi_axpby(void* y_f32, const void* x_f32, float a, const void* z_f32_or_null, float b, int64_t n, void* stream);
+
+/* clamp((x+1)/2,0,1)*255 truncated to uint8, NCHW fp32 -> NHWC uint8 (modules/processing.py:1004-1005,1034-1035). */
+int sdmi_image_to_u8(const void* img_f32_nchw, void* out_u8_nhwc, int B, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Engine (boundaries B1 "SdUnet" and B4 VAE): whole-UNet forward and whole-VAE decode on packed weights.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct sdmi_unet_config {
+    int32_t in_channels, out_channels, model_channels;
+    int32_t num_levels;
+    int32_t channel_mult[8];
+    int32_t num_res_blocks;
+    int32_t attn_level[8];          /* 1 if that level has SpatialTransformers */
+    int32_t transformer_depth[8];
+    int32_t num_heads;              /* used when num_head_channels == -1 */
+    int32_t num_head_channels;
+    int32_t context_dim;
+    int32_t adm_in_channels;        /* 0 = none */
+    int32_t reserved[4];
+} sdmi_unet_config;
+
+typedef struct sdmi_vae_config {
+    int32_t ch, num_levels;
+    int32_t ch_mult[8];
+    int32_t num_res_blocks, in_channels, out_ch, z_channels;
+    float scale_factor;
+    int32_t reserved[4];
+} sdmi_vae_config;
+
+sdmi_engine* sdmi_engine_create(int device);
+void sdmi_engine_destroy(sdmi_engine* e);
+
+/* Weight hand-over, one tensor at a time, by checkpoint key WITHOUT the "model.diffusion_model." / "first_stage_model."
+ * prefix.  Replaces the torch module tree the reference loader fills (modules/sd_models.py:410-538 load_model_weights):
+ * the caller keeps using read_state_dict (:312-329) and streams the dict here.  `data` may be a device or host pointer
+ * (on_device flag); fp16 or fp32; shape as in the checkpoint (OIHW conv / [out,in] linear). */
+int sdmi_unet_configure(sdmi_engine* e, const sdmi_unet_config* cfg);
+int sdmi_unet_load_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim,
+                          const int64_t* shape, int on_device);
+int sdmi_unet_finalize(sdmi_engine* e);            /* packs layouts; errors if a required key is missing */
+
+int sdmi_vae_configure(sdmi_engine* e, const sdmi_vae_config* cfg);
+int sdmi_vae_load_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim,
+                         const int64_t* shape, int on_device);
+int sdmi_vae_finalize(sdmi_engine* e);
+
+/* eps = UNet(x, timesteps, context[, y]).  Replaces SdUnet.forward (modules/sd_unet.py:75-83), called from the patched
+ * UNetModel.forward (modules/sd_unet.py:86-93, modules/sd_hijack.py:41-45).
+ * x [Bn, Cin, h, w] NCHW (io_dtype), timesteps [Bn] (io_dtype), context [Bn, L, context_dim] (io_dtype) or NULL to reuse
+ * the K/V projections cached by the previous call / sdmi_unet_set_context, y [Bn, adm] or NULL, out [Bn, Cout, h, w]. */
+int sdmi_unet_set_context(sdmi_engine* e, const void* context, int io_dtype, int Bn, int L, void* stream);
+int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y,
+                      void* out, int io_dtype, int Bn, int h, int w, int L, void* stream);
+
+/* image = decoder(post_quant_conv(z / scale_factor)), all B latents in one batched pass.
+ * Replaces decode_latent_batch's per-image loop (modules/processing.py:625-672) -> decode_first_stage
+ * (modules/sd_samplers_common.py:73-76) -> LatentDiffusion.decode_first_stage / AutoencoderKL.decode (third-party).
+ * z [B, 4, h, w] NCHW (io_dtype); out fp32 NCHW [B, 3, 8h, 8w] in [-1, 1] (what the caller .float()s anyway). */
+int sdmi_vae_decode(sdmi_engine* e, const void* z, int io_dtype, void* out_f32, int B, int h, int w, void* stream);
+
+/* latent moments = quant_conv(encoder(x)); x [B,3,H,W] NCHW in [-1,1]; out fp32 NCHW [B, 2*z, H/8, W/8] (mean | logvar).
+ * Replaces encode_first_stage (modules/sd_samplers_common.py:87-112 -> third-party AutoencoderKL.encode). */
+int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out_f32, int B, int H, int W, void* stream);
+
+/* Introspection for tests / bench. */
+int64_t sdmi_engine_arena_bytes(sdmi_engine* e);
+int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "use_graph", "glds" */
+
+/* Micro-benchmarks used by bench.py's roofline block (HIP-event timed inside the library; returns ms per launch). */
+int sdmi_bench_conv_gemm(const sdmi_conv_desc* d, int iters, float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMI_H */

@@ -61,7 +61,7 @@ def sdxl_base_config() -> UNetConfig:
 def tiny_config(**kw) -> UNetConfig:
     """Small SD1.x-shaped config for fast tests (channels stay multiples of 64 so the MFMA path is used)."""
     base = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(1, 2),
-                num_heads=2, transformer_depth=1, context_dim=64)
+                num_heads=-1, num_head_channels=64, transformer_depth=1, context_dim=64)
     base.update(kw)
     return UNetConfig(**base)
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build libsdmi.so for gfx950 in-tree (stable-diffusion-webui_amd/lib/libsdmi.so).  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p "$OUT" build
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -Wno-unused-result"
+pids=()
+for f in gemm.hip attention.hip norm.hip elementwise.hip; do
+  hipcc $FLAGS -c "$f" -o "build/${f%.hip}.o" & pids+=($!)
+done
+hipcc $FLAGS -x hip -c engine.cpp -o build/engine.o & pids+=($!)
+hipcc $FLAGS -x hip -c capi.cpp -o build/capi.o & pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o "$OUT/libsdmi.so"
+echo "built $OUT/libsdmi.so"

@@ -1,0 +1,306 @@
+// capi.cpp — extern "C" surface of libsdmi.so (declared in include/sdmi.h).
+#include "engine.h"
+
+namespace sdmi {
+int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, const void* y, void* out, int io_dtype,
+                 int Bn, int h, int w, int L, hipStream_t s);
+int vae_decode(sdmi_engine* e, const void* z, int io_dtype, float* out, int B, int h, int w, hipStream_t s);
+int vae_encode(sdmi_engine* e, const void* x, int io_dtype, float* out, int B, int H, int W, hipStream_t s);
+int engine_load_unet_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
+int engine_load_vae_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
+int engine_unet_finalize(sdmi_engine* e);
+int engine_vae_finalize(sdmi_engine* e);
+int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s);
+}  // namespace sdmi
+
+using namespace sdmi;
+
+#define API_GUARD_BEGIN try {
+#define API_GUARD_END                                            \
+    }                                                            \
+    catch (const std::exception& ex) {                           \
+        set_error(std::string("exception: ") + ex.what());      \
+        return 1;                                                \
+    }                                                            \
+    catch (...) {                                                \
+        set_error("unknown exception");                          \
+        return 1;                                                \
+    }
+
+extern "C" {
+
+int sdmi_version(void) { return SDMI_VERSION; }
+const char* sdmi_last_error(void) { return get_error(); }
+
+int sdmi_device_ok(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+    return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0 ? 1 : 0;
+}
+
+int64_t sdmi_attention_workspace_bytes(int B, int H, int M, int D) {
+    const int64_t mpad = (M + 63) / 64 * 64;
+    return (int64_t)B * H * D * mpad * (int64_t)sizeof(half_t);
+}
+
+int sdmi_attention_vt(const void* q, const void* k, const void* vt, void* out, int B, int H, int N, int M, int D, int ldq,
+                      int ldk, int vt_ld, int ldo, float scale, int force_generic, void* stream) {
+    API_GUARD_BEGIN
+    AttnP p{};
+    p.q = (const half_t*)q; p.k = (const half_t*)k; p.vt = (const half_t*)vt; p.out = (half_t*)out;
+    p.B = B; p.H = H; p.N = N; p.M = M; p.D = D; p.ldq = ldq; p.ldk = ldk; p.vt_ld = vt_ld; p.ldo = ldo;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    return launch_attention(p, force_generic != 0, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int N, int M, int D, int ldq,
+                   int ldk, int ldv, int ldo, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(workspace && workspace_bytes >= sdmi_attention_workspace_bytes(B, H, M, D), "attention workspace too small");
+    const int mpad = (M + 63) / 64 * 64;
+    if (launch_transpose_v((const half_t*)v, (half_t*)workspace, B, H, M, D, ldv, mpad, (hipStream_t)stream)) return 1;
+    return sdmi_attention_vt(q, k, workspace, out, B, H, N, M, D, ldq, ldk, mpad, ldo, scale, 0, stream);
+    API_GUARD_END
+}
+
+static int desc_to_p(const sdmi_conv_desc* d, GemmP* p) {
+    SDMI_REQUIRE(d != nullptr, "null descriptor");
+    *p = GemmP{};
+    p->a0 = (const half_t*)d->a0; p->a1 = (const half_t*)d->a1; p->w = (const half_t*)d->w;
+    p->bias = (const float*)d->bias; p->rowbias = (const float*)d->rowbias; p->resid = (const half_t*)d->resid;
+    p->out = d->out;
+    p->c0 = d->c0; p->c1 = d->a1 ? d->c1 : 0; p->cin = p->c0 + p->c1;
+    p->lda0 = d->lda0 ? d->lda0 : d->c0; p->lda1 = d->lda1 ? d->lda1 : d->c1;
+    p->Hi = d->Hi; p->Wi = d->Wi; p->Ho = d->Ho; p->Wo = d->Wo;
+    p->taps = d->taps; p->stride = d->stride ? d->stride : 1; p->pad = d->pad; p->up = d->up;
+    SDMI_REQUIRE(p->taps == 1 || p->taps == 9, "taps must be 1 or 9");
+    p->M = d->B * d->Ho * d->Wo; p->N = d->N; p->K = p->taps * p->cin;
+    p->ldo = d->ldo; p->ldr = d->ldr; p->ldw = p->K; p->ldrb = d->N;
+    p->rows_per_batch = d->Ho * d->Wo;
+    p->n_real = d->n_real ? d->n_real : d->N;
+    p->flags = d->flags;
+    p->alpha = d->alpha == 0.f ? 1.f : d->alpha;
+    p->a_bs = d->a_bs; p->w_bs = d->w_bs; p->o_bs = d->o_bs; p->r_bs = d->r_bs;
+    return 0;
+}
+
+int sdmi_conv_gemm(const sdmi_conv_desc* d, void* stream) {
+    API_GUARD_BEGIN
+    GemmP p;
+    if (desc_to_p(d, &p)) return 1;
+    const char* env = getenv("SDMI_NO_GLDS");
+    return launch_gemm(p, d->batch > 0 ? d->batch : 1, d->force_generic == 1, !(env && env[0] == '1') && d->force_generic != 2,
+                       (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_bench_conv_gemm(const sdmi_conv_desc* d, int iters, float* ms_out, void* stream) {
+    API_GUARD_BEGIN
+    GemmP p;
+    if (desc_to_p(d, &p)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    SDMI_CHECK_HIP(hipEventCreate(&e0));
+    SDMI_CHECK_HIP(hipEventCreate(&e1));
+    const bool glds = d->force_generic != 2;
+    for (int i = 0; i < 2; ++i)
+        if (launch_gemm(p, d->batch > 0 ? d->batch : 1, d->force_generic == 1, glds, s)) return 1;
+    SDMI_CHECK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (launch_gemm(p, d->batch > 0 ? d->batch : 1, d->force_generic == 1, glds, s)) return 1;
+    SDMI_CHECK_HIP(hipEventRecord(e1, s));
+    SDMI_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SDMI_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+    API_GUARD_END
+}
+
+int sdmi_pack_conv_weight(const void* w, int dtype, void* out, int O, int I, int kh, int kw, int O_pad, int I_pad, int geglu,
+                          void* stream) {
+    API_GUARD_BEGIN
+    return launch_pack_conv_weight(w, dtype, (half_t*)out, O, I, kh, kw, O_pad, I_pad, geglu, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int64_t sdmi_groupnorm_workspace_bytes(int B, int HW, int groups) { return groupnorm_ws_bytes(B, HW, groups); }
+
+int sdmi_groupnorm(const void* x0, const void* x1, int c0, int c1, const void* gamma, const void* beta, void* out, int B, int HW,
+                   int groups, float eps, int silu, void* ws, int64_t ws_bytes, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(ws && ws_bytes >= groupnorm_ws_bytes(B, HW, groups), "groupnorm workspace too small");
+    return launch_groupnorm((const half_t*)x0, (const half_t*)x1, c0, x1 ? c1 : 0, (const float*)gamma, (const float*)beta,
+                            (half_t*)out, B, HW, groups, eps, silu != 0, (float*)ws, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_layernorm(const void* x, const void* gamma, const void* beta, void* out, int64_t rows, int C, float eps, void* stream) {
+    API_GUARD_BEGIN
+    return launch_layernorm((const half_t*)x, (const float*)gamma, (const float*)beta, (half_t*)out, rows, C, eps, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_philox_randn(void* out, int64_t n, uint64_t seed, uint32_t offset, void* stream) {
+    API_GUARD_BEGIN
+    return launch_philox((float*)out, n, seed, offset, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_cfg_prepare_input(const void* x, const void* c_in, void* x_in, int out_dtype, int B, int reps, int64_t chw, void* stream) {
+    API_GUARD_BEGIN
+    return launch_cfg_prepare((const float*)x, (const float*)c_in, x_in, out_dtype, B, reps, chw, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_cfg_combine(const void* x, const void* eps, const void* c_out, float cond_scale, int mode, const void* mask,
+                     const void* nmask, const void* init_latent, void* den, int B, int64_t chw, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(mode == 1 || (x && c_out), "sigma-space combine needs x and c_out");
+    return launch_cfg_combine((const float*)x, (const float*)eps, (const float*)c_out, cond_scale, mode, (const float*)mask,
+                              (const float*)nmask, (const float*)init_latent, (float*)den, B, chw, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_euler_step(void* x, const void* den, const void* noise, float sigma, float sigma_down, float sigma_up, float s_noise,
+                    int64_t n, void* stream) {
+    API_GUARD_BEGIN
+    return launch_euler_step((float*)x, (const float*)den, (const float*)noise, sigma, sigma_down, sigma_up, s_noise, n,
+                             (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_dpmpp2m_step(void* x, const void* den, const void* old, float ratio, float em1, float c1, float c2, int64_t n,
+                      void* stream) {
+    API_GUARD_BEGIN
+    return launch_dpmpp2m_step((float*)x, (const float*)den, (const float*)old, ratio, em1, c1, c2, n, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_ddim_step(void* x, const void* e_t, const void* noise, void* pred_x0, float a_t, float a_prev, float sigma_t,
+                   float sqrt_one_minus_at, int64_t n, void* stream) {
+    API_GUARD_BEGIN
+    return launch_ddim_step((float*)x, (const float*)e_t, (const float*)noise, (float*)pred_x0, a_t, a_prev, sigma_t,
+                            sqrt_one_minus_at, n, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_axpby(void* y, const void* x, float a, const void* z, float b, int64_t n, void* stream) {
+    API_GUARD_BEGIN
+    return launch_axpby((float*)y, (const float*)x, a, (const float*)z, b, n, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_image_to_u8(const void* img, void* out, int B, int C, int H, int W, void* stream) {
+    API_GUARD_BEGIN
+    return launch_image_to_u8((const float*)img, (uint8_t*)out, B, C, H, W, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+sdmi_engine* sdmi_engine_create(int device) {
+    try {
+        if (hipSetDevice(device) != hipSuccess) {
+            set_error("hipSetDevice failed");
+            return nullptr;
+        }
+        sdmi_engine* e = new sdmi_engine();
+        e->device = device;
+        const char* g = getenv("SDMI_NO_GLDS");
+        if (g && g[0] == '1') e->use_glds = false;
+        const char* f = getenv("SDMI_FORCE_GENERIC");
+        if (f && f[0] == '1') e->force_generic = true;
+        return e;
+    } catch (...) {
+        set_error("engine allocation failed");
+        return nullptr;
+    }
+}
+void sdmi_engine_destroy(sdmi_engine* e) { delete e; }
+
+int sdmi_unet_configure(sdmi_engine* e, const sdmi_unet_config* cfg) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e && cfg, "null argument");
+    SDMI_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8, "num_levels out of range");
+    SDMI_REQUIRE(cfg->model_channels % 64 == 0, "model_channels must be a multiple of 64");
+    SDMI_REQUIRE(cfg->context_dim % 64 == 0, "context_dim must be a multiple of 64");
+    SDMI_REQUIRE(cfg->in_channels <= 16 && cfg->out_channels <= 64, "in_channels <= 16, out_channels <= 64");
+    e->unet.cfg = *cfg;
+    e->unet.ready = false;
+    return 0;
+    API_GUARD_END
+}
+int sdmi_unet_load_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                          int on_device) {
+    API_GUARD_BEGIN
+    return engine_load_unet_tensor(e, key, data, dtype, ndim, shape, on_device);
+    API_GUARD_END
+}
+int sdmi_unet_finalize(sdmi_engine* e) {
+    API_GUARD_BEGIN
+    return engine_unet_finalize(e);
+    API_GUARD_END
+}
+int sdmi_vae_configure(sdmi_engine* e, const sdmi_vae_config* cfg) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e && cfg, "null argument");
+    SDMI_REQUIRE(cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->ch % 64 == 0, "vae: ch % 64 == 0, 1..8 levels");
+    SDMI_REQUIRE(cfg->z_channels <= 16 && cfg->in_channels <= 16, "vae: z_channels, in_channels <= 16");
+    e->vae.cfg = *cfg;
+    e->vae.ready = false;
+    return 0;
+    API_GUARD_END
+}
+int sdmi_vae_load_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                         int on_device) {
+    API_GUARD_BEGIN
+    return engine_load_vae_tensor(e, key, data, dtype, ndim, shape, on_device);
+    API_GUARD_END
+}
+int sdmi_vae_finalize(sdmi_engine* e) {
+    API_GUARD_BEGIN
+    return engine_vae_finalize(e);
+    API_GUARD_END
+}
+
+int sdmi_unet_set_context(sdmi_engine* e, const void* context, int io_dtype, int Bn, int L, void* stream) {
+    API_GUARD_BEGIN
+    return engine_set_context(e, context, io_dtype, Bn, L, (hipStream_t)stream);
+    API_GUARD_END
+}
+int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y, void* out,
+                      int io_dtype, int Bn, int h, int w, int L, void* stream) {
+    API_GUARD_BEGIN
+    return unet_forward(e, x, timesteps, context, y, out, io_dtype, Bn, h, w, L, (hipStream_t)stream);
+    API_GUARD_END
+}
+int sdmi_vae_decode(sdmi_engine* e, const void* z, int io_dtype, void* out, int B, int h, int w, void* stream) {
+    API_GUARD_BEGIN
+    return vae_decode(e, z, io_dtype, (float*)out, B, h, w, (hipStream_t)stream);
+    API_GUARD_END
+}
+int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out, int B, int H, int W, void* stream) {
+    API_GUARD_BEGIN
+    return vae_encode(e, x, io_dtype, (float*)out, B, H, W, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int64_t sdmi_engine_arena_bytes(sdmi_engine* e) { return e ? (int64_t)e->arena.cap : 0; }
+
+int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e && name, "null argument");
+    const std::string n(name);
+    if (n == "force_generic") e->force_generic = value != 0;
+    else if (n == "glds") e->use_glds = value != 0;
+    else if (n == "use_graph") e->use_graph = value != 0;
+    else { set_error("unknown option " + n); return 1; }
+    return 0;
+    API_GUARD_END
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+// common.h — shared types and helpers for the gfx950 kernels of libsdmi.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+namespace sdmi {
+
+void set_error(const std::string& msg);
+const char* get_error();
+
+#define SDMI_CHECK_HIP(expr)                                                                       \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            ::sdmi::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+#define SDMI_REQUIRE(cond, msg)                                                                    \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            ::sdmi::set_error(std::string("requirement failed: ") + #cond + " — " + (msg));        \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// A 256-byte zeroed device buffer per device used as the source of padding lanes in LDS-direct loads.
+const half_t* zero_page();
+
+// ---- GEMM / implicit conv parameters (kernel argument, POD) -----------------------------------------------
+struct GemmP {
+    const half_t* a0;
+    const half_t* a1;
+    const half_t* w;
+    const float* bias;
+    const float* rowbias;
+    const half_t* resid;
+    void* out;
+    const half_t* zero;
+    int c0, c1, cin;
+    int lda0, lda1;
+    int Hi, Wi, Ho, Wo;
+    int taps, stride, pad, up;
+    int M, N, K;
+    int ldo, ldr;
+    int ldw;              // row stride of W (elements), normally K
+    int ldrb;             // batch stride of rowbias (elements), normally N
+    int rows_per_batch;   // Ho*Wo
+    int n_real;
+    int flags;
+    float alpha;
+    long a_bs, w_bs, o_bs, r_bs;
+};
+
+enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8 };
+
+int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s);
+
+// ---- attention --------------------------------------------------------------------------------------------
+struct AttnP {
+    const half_t* q;
+    const half_t* k;
+    const half_t* vt;
+    half_t* out;
+    int B, H, N, M, D;
+    int ldq, ldk, vt_ld, ldo;
+    float scale_log2;      // softmax scale * log2(e)
+};
+int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
+// v [B, M, ldv] (head h at h*D) -> vt [B, H*D, Mpad] (zero padded)
+int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, int ldv, int Mpad, hipStream_t s);
+
+// ---- norms ------------------------------------------------------------------------------------------------
+int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
+                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s);
+int64_t groupnorm_ws_bytes(int B, int HW, int groups);
+int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
+                     float eps, hipStream_t s);
+
+// ---- elementwise / misc -----------------------------------------------------------------------------------
+int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t offset, hipStream_t s);
+int launch_cfg_prepare(const float* x, const float* c_in, void* xin, int out_dtype, int B, int reps, int64_t chw, hipStream_t s);
+int launch_cfg_combine(const float* x, const float* eps, const float* c_out, float cond_scale, int mode,
+                       const float* mask, const float* nmask, const float* init_latent, float* den, int B,
+                       int64_t chw, hipStream_t s);
+int launch_euler_step(float* x, const float* den, const float* noise, float sigma, float sigma_down, float sigma_up,
+                      float s_noise, int64_t n, hipStream_t s);
+int launch_dpmpp2m_step(float* x, const float* den, const float* old, float ratio, float em1, float c1, float c2,
+                        int64_t n, hipStream_t s);
+int launch_ddim_step(float* x, const float* e, const float* noise, float* pred_x0, float a_t, float a_prev,
+                     float sigma_t, float somat, int64_t n, hipStream_t s);
+int launch_axpby(float* y, const float* x, float a, const float* z, float b, int64_t n, hipStream_t s);
+int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
+
+// NCHW (f16|f32) * scale -> NHWC fp16 with channels zero-padded to cpad; optional 1x1 channel mix (pqc) first.
+int launch_nchw_to_nhwc(const void* x, int dtype, half_t* out, int B, int C, int HW, int cpad, float scale,
+                        const float* mix_w, const float* mix_b, hipStream_t s);
+// fp32 NCHW -> user dtype NCHW copy
+int launch_copy_out(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
+int launch_convert_to_f16(const void* src, int dtype, half_t* dst, int64_t n, hipStream_t s);
+int launch_convert_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s);
+// sinusoidal timestep embedding (cos first): t [B] (f16|f32) -> out fp32 [B, dim]
+int launch_timestep_embedding(const void* t, int dtype, float* out, int B, int dim, hipStream_t s);
+// out[b][n] = act_out( sum_k act_in(a[b][k]) * w[n][k] + bias[n] ) (+ add[b][n]); a fp32, w fp16, out fp32
+int launch_small_linear(const float* a, const half_t* w, const float* bias, const float* add, float* out, int B,
+                        int N, int K, int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s);
+// row softmax: in fp32 [rows, cols] -> out fp16 [rows, ldo] (zero-filled up to ldo)
+int launch_softmax_rows(const float* in, half_t* out, int64_t rows, int cols, int ldo, hipStream_t s);
+// weight repack: OIHW (f16|f32) -> [O_pad][kh*kw][I_pad] fp16 (zero padded); geglu: permute output rows
+int launch_pack_conv_weight(const void* w, int dtype, half_t* out, int O, int I, int kh, int kw, int O_pad,
+                            int I_pad, int geglu, hipStream_t s);
+// fp32 vector permute for GEGLU bias
+int launch_pack_bias(const void* b, int dtype, float* out, int O, int O_pad, int geglu, hipStream_t s);
+
+}  // namespace sdmi

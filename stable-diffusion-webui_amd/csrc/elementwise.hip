@@ -1,0 +1,421 @@
+// elementwise.hip — the latency-/HBM-bound small kernels of the hot path (gfx950):
+//   * Philox4x32-10 + Box-Muller noise, bit-compatible with /root/reference/modules/rng_philox.py:32-102
+//   * CFG batch build / combine and sampler updates (fused replacements for the ~3B tiny torch kernels per step of
+//     /root/reference/modules/sd_samplers_cfg_denoiser.py:74-82,203-205 and the k-diffusion sampler loops)
+//   * layout / dtype conversion at the engine boundary, timestep embedding
+//     (/root/reference/modules/sd_hijack_unet.py:58-78), small-M linear layers (time embedding MLP), row softmax (VAE
+//     mid attention), weight repacking, final uint8 conversion (/root/reference/modules/processing.py:1004-1005,1034-1035).
+#include "common.h"
+#include <algorithm>
+
+// The sampler / RNG arithmetic mirrors separately-rounded torch / numpy ops: never contract a*b+c into an fma here.
+#pragma clang fp contract(off)
+
+namespace sdmi {
+
+static inline int ew_blocks(int64_t n, int per_thread = 1) {
+    int64_t b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, 4096));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (counter = [offset, 0, i, 0], key = seed) + Box-Muller on outputs 0/1.
+// The reference evaluates Box-Muller in float64 with float32-rounded constants (numpy promotes uint32*float32 to
+// float64) and rounds to float32 once; the same expression order is used here so results agree bit-for-bit except
+// where the device libm's double log/sin differ from the host's by more than half a float32 ulp (measured: none in
+// the golden fixtures).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void philox_randn_kernel(float* out, long n, unsigned k0i, unsigned k1i, unsigned offset) {
+    const float two_pow32_inv_f = 2.3283064e-10f;
+    const float two_pow32_inv_2pi_f = (float)(2.3283064e-10 * 6.2831855);
+    const double c1 = (double)two_pow32_inv_f, c2 = (double)two_pow32_inv_2pi_f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        unsigned c0 = offset, cc1 = 0u, c2w = (unsigned)i, c3 = 0u;
+        unsigned k0 = k0i, k1 = k1i;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53ull;
+            const unsigned long long p1 = (unsigned long long)c2w * 0xCD9E8D57ull;
+            const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+            const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+            const unsigned n0 = hi1 ^ cc1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+            c0 = n0; cc1 = lo1; c2w = n2; c3 = lo0;
+            if (r != 9) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        }
+        const double u = (double)c0 * c1 + c1 / 2;
+        const double v = (double)cc1 * c2 + c2 / 2;
+        const double sq = sqrt(-2.0 * log(u));
+        out[i] = (float)(sq * sin(v));
+    }
+}
+
+int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t offset, hipStream_t s) {
+    SDMI_REQUIRE(n < (1LL << 32), "philox stream index is 32-bit in the reference (rng_philox.py:92)");
+    hipLaunchKernelGGL(philox_randn_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, out, (long)n, (unsigned)(seed & 0xFFFFFFFFu),
+                       (unsigned)(seed >> 32), offset);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// CFG / sampler arithmetic (fp32 state)
+// ------------------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void cfg_prepare_kernel(const float* x, const float* c_in, TO* xin, int B, int reps, long chw) {
+    const long n = (long)B * chw;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / chw);
+        const float v = x[i] * (c_in ? c_in[b] : 1.0f);
+        const TO hv = (TO)v;
+        for (int r = 0; r < reps; ++r) xin[(long)r * n + i] = hv;
+    }
+}
+int launch_cfg_prepare(const float* x, const float* c_in, void* xin, int out_dtype, int B, int reps, int64_t chw, hipStream_t s) {
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(cfg_prepare_kernel<half_t>, dim3(ew_blocks((int64_t)B * chw)), dim3(256), 0, s, x, c_in, (half_t*)xin, B, reps, (long)chw);
+    else
+        hipLaunchKernelGGL(cfg_prepare_kernel<float>, dim3(ew_blocks((int64_t)B * chw)), dim3(256), 0, s, x, c_in, (float*)xin, B, reps, (long)chw);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const float* x, const float* eps, const float* c_out, float cond_scale,
+                                                         int mode, const float* mask, const float* nmask, const float* init,
+                                                         float* den, int B, long chw) {
+    const long n = (long)B * chw;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / chw);
+        const float ec = eps[i], eu = eps[n + i];
+        float d;
+        if (mode == 0) {
+            // CompVisDenoiser: denoised = input + eps * c_out, evaluated for both halves, then combine_denoised:
+            // denoised = u; denoised += (c - u) * (weight * cond_scale)
+            const float xv = x[i], co = c_out[b];
+            const float dc = xv + ec * co, du = xv + eu * co;
+            d = du + (dc - du) * cond_scale;
+        } else {
+            d = eu + (ec - eu) * cond_scale;
+        }
+        if (mask) d = d * nmask[i] + init[i] * mask[i];
+        den[i] = d;
+    }
+}
+int launch_cfg_combine(const float* x, const float* eps, const float* c_out, float cond_scale, int mode, const float* mask,
+                       const float* nmask, const float* init_latent, float* den, int B, int64_t chw, hipStream_t s) {
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(ew_blocks((int64_t)B * chw)), dim3(256), 0, s, x, eps, c_out, cond_scale, mode,
+                       mask, nmask, init_latent, den, B, (long)chw);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void euler_step_kernel(float* x, const float* den, const float* noise, float sigma,
+                                                        float sigma_down, float sigma_up, float s_noise, long n) {
+    const float dt = sigma_down - sigma;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float xv = x[i];
+        const float d = (xv - den[i]) / sigma;     // to_d
+        xv = xv + d * dt;
+        if (noise) xv = xv + noise[i] * s_noise * sigma_up;
+        x[i] = xv;
+    }
+}
+int launch_euler_step(float* x, const float* den, const float* noise, float sigma, float sigma_down, float sigma_up,
+                      float s_noise, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(euler_step_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, den, noise, sigma, sigma_down, sigma_up,
+                       s_noise, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void dpmpp2m_step_kernel(float* x, const float* den, const float* old, float ratio, float em1,
+                                                          float c1, float c2, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float dd = den[i];
+        if (old) dd = c1 * dd - c2 * old[i];       // denoised_d = (1 + 1/(2r)) * denoised - (1/(2r)) * old_denoised
+        x[i] = ratio * x[i] - em1 * dd;            // x = (sigma_next/sigma) * x - expm1(-h) * denoised_d
+    }
+}
+int launch_dpmpp2m_step(float* x, const float* den, const float* old, float ratio, float em1, float c1, float c2, int64_t n,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(dpmpp2m_step_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, den, old, ratio, em1, c1, c2, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void ddim_step_kernel(float* x, const float* e, const float* noise, float* pred_out, float a_t,
+                                                       float a_prev, float sigma_t, float somat, long n) {
+    // sd_samplers_timesteps_impl.py:25-36: `alphas_prev[index].item() * s_x` etc. are python-scalar * fp32-tensor
+    // products, so every per-step coefficient and the whole update are fp32 (the float64 of :15 only affects how the
+    // host computes a_prev / sigma_t before rounding them to fp32).
+    const float sqrt_at = sqrtf(a_t);
+    const float sqrt_aprev = sqrtf(a_prev);
+    const float dir_c = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float ev = e[i];
+        const float pred = (x[i] - somat * ev) / sqrt_at;
+        const float dir_xt = dir_c * ev;
+        float r = sqrt_aprev * pred + dir_xt;
+        r = r + (noise ? sigma_t * noise[i] : 0.0f);
+        if (pred_out) pred_out[i] = pred;
+        x[i] = r;
+    }
+}
+int launch_ddim_step(float* x, const float* e, const float* noise, float* pred_x0, float a_t, float a_prev, float sigma_t,
+                     float somat, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, e, noise, pred_x0, a_t, a_prev, sigma_t, somat,
+                       (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float* y, const float* x, float a, const float* z, float b, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = x[i] * a;
+        if (z) v = v + z[i] * b;
+        y[i] = v;
+    }
+}
+int launch_axpby(float* y, const float* x, float a, const float* z, float b, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, y, x, a, z, b, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void image_to_u8_kernel(const float* img, uint8_t* out, int C, long HW, long n) {
+    // n = B*HW*C output elements, NHWC
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long pix = (i / C) % HW;
+        const long b = i / ((long)C * HW);
+        float v = img[(b * C + c) * HW + pix];
+        v = (v + 1.0f) / 2.0f;
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        out[i] = (uint8_t)(255.f * v);              // numpy astype(uint8) truncates
+    }
+}
+int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s) {
+    const long n = (long)B * C * H * W;
+    hipLaunchKernelGGL(image_to_u8_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, img, out, C, (long)H * W, n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// boundary conversions
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* x, half_t* out, int C, long HW, int cpad, float scale,
+                                                          const float* mix_w, const float* mix_b, long npix) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+        const long b = i / HW, pix = i - b * HW;
+        float v[16];
+        for (int c = 0; c < C; ++c) v[c] = (float)x[(b * C + c) * HW + pix] * scale;
+        half_t* dst = out + i * cpad;
+        if (mix_w) {
+            // 1x1 conv over the C input channels (post_quant_conv) in fp32
+            for (int o = 0; o < C; ++o) {
+                float acc = mix_b ? mix_b[o] : 0.f;
+                for (int c = 0; c < C; ++c) acc = fmaf(mix_w[o * C + c], v[c], acc);
+                dst[o] = (half_t)acc;
+            }
+        } else {
+            for (int c = 0; c < C; ++c) dst[c] = (half_t)v[c];
+        }
+        for (int c = C; c < cpad; ++c) dst[c] = (half_t)0.f;
+    }
+}
+int launch_nchw_to_nhwc(const void* x, int dtype, half_t* out, int B, int C, int HW, int cpad, float scale, const float* mix_w,
+                        const float* mix_b, hipStream_t s) {
+    SDMI_REQUIRE(C <= 16 && cpad >= C, "nchw_to_nhwc: C <= 16");
+    const long npix = (long)B * HW;
+    if (dtype == 0)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(ew_blocks(npix)), dim3(256), 0, s, (const half_t*)x, out, C, (long)HW,
+                           cpad, scale, mix_w, mix_b, npix);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_blocks(npix)), dim3(256), 0, s, (const float*)x, out, C, (long)HW,
+                           cpad, scale, mix_w, mix_b, npix);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert_kernel(const TI* src, TO* dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (TO)src[i];
+}
+int launch_copy_out(const float* src, void* dst, int dtype, int64_t n, hipStream_t s) {
+    if (dtype == 0)
+        hipLaunchKernelGGL((convert_kernel<float, half_t>), dim3(ew_blocks(n)), dim3(256), 0, s, src, (half_t*)dst, (long)n);
+    else
+        hipLaunchKernelGGL((convert_kernel<float, float>), dim3(ew_blocks(n)), dim3(256), 0, s, src, (float*)dst, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_convert_to_f16(const void* src, int dtype, half_t* dst, int64_t n, hipStream_t s) {
+    if (dtype == 0)
+        hipLaunchKernelGGL((convert_kernel<half_t, half_t>), dim3(ew_blocks(n)), dim3(256), 0, s, (const half_t*)src, dst, (long)n);
+    else
+        hipLaunchKernelGGL((convert_kernel<float, half_t>), dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)src, dst, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_convert_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s) {
+    if (dtype == 0)
+        hipLaunchKernelGGL((convert_kernel<half_t, float>), dim3(ew_blocks(n)), dim3(256), 0, s, (const half_t*)src, dst, (long)n);
+    else
+        hipLaunchKernelGGL((convert_kernel<float, float>), dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)src, dst, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const T* t, float* out, int B, int dim) {
+    const int half = dim / 2;
+    const int n = B * half;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int b = i / half, j = i - b * half;
+        // freqs = exp(-ln(10000) * j / half) in fp32, args = t.float() * freqs  (sd_hijack_unet.py:69-73)
+        const float freq = expf(-9.210340371976184f * (float)j / (float)half);
+        const float a = (float)t[b] * freq;
+        out[(long)b * dim + j] = cosf(a);
+        out[(long)b * dim + half + j] = sinf(a);
+        if ((dim & 1) && j == 0) out[(long)b * dim + dim - 1] = 0.f;
+    }
+}
+int launch_timestep_embedding(const void* t, int dtype, float* out, int B, int dim, hipStream_t s) {
+    if (dtype == 0)
+        hipLaunchKernelGGL(timestep_embedding_kernel<half_t>, dim3(ew_blocks((int64_t)B * dim / 2)), dim3(256), 0, s, (const half_t*)t, out, B, dim);
+    else
+        hipLaunchKernelGGL(timestep_embedding_kernel<float>, dim3(ew_blocks((int64_t)B * dim / 2)), dim3(256), 0, s, (const float*)t, out, B, dim);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// one wave per output element (b, n); K is split across lanes in 8-wide fp16 vectors of the weight row
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* a, const half_t* w, const float* bias, const float* add,
+                                                          float* out, int B, int N, int K, int lda, int ldo, int silu_in,
+                                                          int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const long widx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (widx >= (long)B * N) return;
+    const int b = (int)(widx / N), n = (int)(widx - (long)b * N);
+    const float* ar = a + (long)b * lda;
+    const half_t* wr = w + (long)n * K;
+    float acc = 0.f;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const h8 wv = *reinterpret_cast<const h8*>(wr + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float av = ar[k + e];
+            if (silu_in) av = av / (1.0f + expf(-av));
+            acc = fmaf(av, (float)wv[e], acc);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[n] : 0.f);
+        if (silu_out) v = v / (1.0f + expf(-v));
+        if (add) v += add[(long)b * ldo + n];
+        out[(long)b * ldo + n] = v;
+    }
+}
+int launch_small_linear(const float* a, const half_t* w, const float* bias, const float* add, float* out, int B, int N, int K,
+                        int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s) {
+    SDMI_REQUIRE(K % 8 == 0, "small_linear: K % 8 == 0");
+    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv((int64_t)B * N, 4)), dim3(256), 0, s, a, w, bias, add, out, B, N, K, lda, ldo,
+                       silu_in ? 1 : 0, silu_out ? 1 : 0);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// row softmax over fp32 scores -> fp16 probabilities (one block per row, row re-read from L2)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, half_t* out, int cols, int ldo) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const float* src = in + row * cols;
+    half_t* dst = out + row * ldo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, src[c]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = tid; c < cols; c += 256) sum += expf(src[c] - mx);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = (red[4] + red[5]) + (red[6] + red[7]);
+    const float inv = 1.0f / sum;
+    for (int c = tid; c < ldo; c += 256) dst[c] = c < cols ? (half_t)(expf(src[c] - mx) * inv) : (half_t)0.f;
+}
+int launch_softmax_rows(const float* in, half_t* out, int64_t rows, int cols, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, cols, ldo);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight repacking (run once at load)
+// ------------------------------------------------------------------------------------------------------------
+// packed row index of output channel o under the GEGLU interleave: groups of 32 values followed by their 32 gates
+__device__ __forceinline__ int geglu_row(int o, int O) {
+    const int half = O / 2;
+    return o < half ? (o >> 5) * 64 + (o & 31) : ((o - half) >> 5) * 64 + 32 + ((o - half) & 31);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const T* w, half_t* out, int O, int I, int KK, int O_pad, int I_pad,
+                                                              int geglu) {
+    // out[row][tap][i] over (O_pad, KK, I_pad); source OIHW = w[o][i][tap]
+    const long n = (long)O_pad * KK * I_pad;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const int i = (int)(idx % I_pad);
+        const int tap = (int)((idx / I_pad) % KK);
+        const int row = (int)(idx / ((long)I_pad * KK));
+        // invert the row permutation: which source channel lands in `row`?
+        int o = row;
+        if (geglu && row < O) {
+            const int g = row >> 6, r = row & 63;
+            o = r < 32 ? g * 32 + r : O / 2 + g * 32 + (r - 32);
+        }
+        float v = 0.f;
+        if (o < O && i < I && row < O) v = (float)w[((long)o * I + i) * KK + tap];
+        out[idx] = (half_t)v;
+    }
+}
+int launch_pack_conv_weight(const void* w, int dtype, half_t* out, int O, int I, int kh, int kw, int O_pad, int I_pad, int geglu,
+                            hipStream_t s) {
+    const long n = (long)O_pad * kh * kw * I_pad;
+    SDMI_REQUIRE(!geglu || (O % 64 == 0 && O_pad == O), "GEGLU packing needs O % 64 == 0");
+    if (dtype == 0)
+        hipLaunchKernelGGL(pack_conv_weight_kernel<half_t>, dim3(ew_blocks(n)), dim3(256), 0, s, (const half_t*)w, out, O, I, kh * kw,
+                           O_pad, I_pad, geglu);
+    else
+        hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)w, out, O, I, kh * kw,
+                           O_pad, I_pad, geglu);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_bias_kernel(const T* b, float* out, int O, int O_pad, int geglu) {
+    for (int row = blockIdx.x * 256 + threadIdx.x; row < O_pad; row += gridDim.x * 256) {
+        int o = row;
+        if (geglu && row < O) {
+            const int g = row >> 6, r = row & 63;
+            o = r < 32 ? g * 32 + r : O / 2 + g * 32 + (r - 32);
+        }
+        out[row] = (row < O) ? (float)b[o] : 0.f;
+    }
+}
+int launch_pack_bias(const void* b, int dtype, float* out, int O, int O_pad, int geglu, hipStream_t s) {
+    if (dtype == 0)
+        hipLaunchKernelGGL(pack_bias_kernel<half_t>, dim3(ew_blocks(O_pad)), dim3(256), 0, s, (const half_t*)b, out, O, O_pad, geglu);
+    else
+        hipLaunchKernelGGL(pack_bias_kernel<float>, dim3(ew_blocks(O_pad)), dim3(256), 0, s, (const float*)b, out, O, O_pad, geglu);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sdmi

@@ -1,0 +1,1044 @@
+// engine.cpp — weight packing, activation arena and the UNet / VAE launch sequences of libsdmi (host side, C++).
+//
+// The UNet walk restates the constructor of ldm's UNetModel (third-party, Stability-AI/stablediffusion@cf1d67a6;
+// architecture from /root/reference/configs/v1-inference.yaml:29-44 and configs/sd_xl_inpaint.yaml:19-37; module layout
+// pinned in-tree at /root/reference/extensions-builtin/Lora/networks.py:43-98), and the forward order of
+// /root/reference/modules/sd_hijack_unet.py:83-102 (SpatialTransformer) — but as a flat sequence of HIP launches on NHWC
+// fp16 buffers: no module tree, no torch.cat (dual-source GroupNorm / GEMM), no F.interpolate (upsample fused in the conv
+// gather), no permutes (NHWC tokens == NHWC pixels), V written pre-transposed for the attention kernel.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace sdmi {
+
+// ------------------------------------------------------------------------------------------------------------
+// error string, zero page
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+const char* get_error() { return g_err.c_str(); }
+
+const half_t* zero_page() {
+    static thread_local int cached_dev = -1;
+    static thread_local half_t* cached = nullptr;
+    static std::map<int, half_t*> pages;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev == cached_dev) return cached;
+    auto it = pages.find(dev);
+    if (it == pages.end()) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        it = pages.emplace(dev, (half_t*)p).first;
+    }
+    cached_dev = dev;
+    cached = it->second;
+    return cached;
+}
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Run {
+    sdmi_engine* e;
+    hipStream_t s;
+    bool dry;
+    half_t* H(size_t n) { return (half_t*)e->arena.take(n * sizeof(half_t)); }
+    float* F(size_t n) { return (float*)e->arena.take(n * sizeof(float)); }
+};
+
+#define TRY(x)                  \
+    do {                        \
+        if ((x) != 0) return 1; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------------------
+static int dev_alloc(sdmi_engine* e, void** p, size_t bytes) {
+    SDMI_CHECK_HIP(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    e->owned.push_back(*p);
+    return 0;
+}
+
+static const RawTensor* find_raw(const std::map<std::string, RawTensor>& m, const std::string& k) {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : &it->second;
+}
+
+// pack `names` (each a conv / linear "<name>.weight" [+ ".bias"]) stacked along the output dim into one ConvW
+static int pack_stack(sdmi_engine* e, const std::map<std::string, RawTensor>& m, const std::vector<std::string>& names,
+                      bool pad64, bool geglu, ConvW* out) {
+    int cin = -1, taps = -1, total = 0;
+    bool any_bias = false;
+    for (auto& n : names) {
+        const RawTensor* w = find_raw(m, n + ".weight");
+        SDMI_REQUIRE(w != nullptr, "missing weight " + n + ".weight");
+        SDMI_REQUIRE(w->shape.size() == 2 || w->shape.size() == 4, "weight must be 2-D or 4-D: " + n);
+        const int I = (int)w->shape[1];
+        const int t = w->shape.size() == 4 ? (int)(w->shape[2] * w->shape[3]) : 1;
+        SDMI_REQUIRE(cin < 0 || (cin == I && taps == t), "stacked weights disagree in shape: " + n);
+        cin = I; taps = t;
+        total += (int)w->shape[0];
+        if (find_raw(m, n + ".bias")) any_bias = true;
+    }
+    SDMI_REQUIRE(taps == 1 || taps == 9, "only 1x1 and 3x3 kernels");
+    out->cin = cin;
+    out->cin_pad = pad64 ? rup(cin, 64) : cin;
+    out->cout = total;
+    out->n_pad = pad64 ? rup(total, 64) : total;
+    out->taps = taps;
+    out->geglu = geglu;
+    SDMI_REQUIRE(names.size() == 1 || (total == out->n_pad), "stacked outputs must be multiples of 64");
+    const size_t wn = (size_t)out->n_pad * taps * out->cin_pad;
+    TRY(dev_alloc(e, (void**)&out->w, wn * sizeof(half_t)));
+    SDMI_CHECK_HIP(hipMemset(out->w, 0, wn * sizeof(half_t)));
+    if (any_bias) {
+        TRY(dev_alloc(e, (void**)&out->b, (size_t)out->n_pad * sizeof(float)));
+        SDMI_CHECK_HIP(hipMemset(out->b, 0, (size_t)out->n_pad * sizeof(float)));
+    }
+    int row = 0;
+    for (size_t i = 0; i < names.size(); ++i) {
+        const RawTensor* w = find_raw(m, names[i] + ".weight");
+        const int O = (int)w->shape[0];
+        const int Opad = (names.size() == 1) ? out->n_pad : O;
+        const int kh = taps == 9 ? 3 : 1;
+        TRY(launch_pack_conv_weight(w->ptr, w->dtype, out->w + (size_t)row * taps * out->cin_pad, O, cin, kh, kh, Opad,
+                                    out->cin_pad, geglu ? 1 : 0, 0));
+        const RawTensor* b = find_raw(m, names[i] + ".bias");
+        if (b) TRY(launch_pack_bias(b->ptr, b->dtype, out->b + row, O, Opad, geglu ? 1 : 0, 0));
+        row += Opad;
+    }
+    return 0;
+}
+static int pack_one(sdmi_engine* e, const std::map<std::string, RawTensor>& m, const std::string& name, bool pad64,
+                    bool geglu, ConvW* out) {
+    return pack_stack(e, m, {name}, pad64, geglu, out);
+}
+static int pack_norm(sdmi_engine* e, const std::map<std::string, RawTensor>& m, const std::string& name, NormW* out) {
+    const RawTensor* g = find_raw(m, name + ".weight");
+    const RawTensor* b = find_raw(m, name + ".bias");
+    SDMI_REQUIRE(g && b, "missing norm " + name);
+    const int c = (int)g->shape[0];
+    out->c = c;
+    TRY(dev_alloc(e, (void**)&out->g, c * sizeof(float)));
+    TRY(dev_alloc(e, (void**)&out->b, c * sizeof(float)));
+    TRY(launch_convert_to_f32(g->ptr, g->dtype, out->g, c, 0));
+    TRY(launch_convert_to_f32(b->ptr, b->dtype, out->b, c, 0));
+    return 0;
+}
+
+static int load_raw(std::map<std::string, RawTensor>& m, const char* key, const void* data, int dtype, int ndim,
+                    const int64_t* shape, int on_device) {
+    SDMI_REQUIRE(key && data && ndim >= 1 && ndim <= 4, "bad tensor arguments");
+    SDMI_REQUIRE(dtype == SDMI_F16 || dtype == SDMI_F32, "dtype must be SDMI_F16 or SDMI_F32");
+    RawTensor t;
+    t.dtype = dtype;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.bytes = n * (dtype == SDMI_F16 ? 2 : 4);
+    SDMI_CHECK_HIP(hipMalloc(&t.ptr, std::max<size_t>(t.bytes, 16)));
+    SDMI_CHECK_HIP(hipMemcpy(t.ptr, data, t.bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    auto it = m.find(key);
+    if (it != m.end()) { (void)hipFree(it->second.ptr); m.erase(it); }
+    m.emplace(key, t);
+    return 0;
+}
+static void free_raw(std::map<std::string, RawTensor>& m) {
+    for (auto& kv : m) (void)hipFree(kv.second.ptr);
+    m.clear();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// UNet construction
+// ------------------------------------------------------------------------------------------------------------
+static int build_res(sdmi_engine* e, const std::string& name, int cin, int cout, bool vae, ResW* r) {
+    auto& m = vae ? e->raw_vae : e->raw_unet;
+    r->cin = cin; r->cout = cout;
+    if (vae) {
+        TRY(pack_norm(e, m, name + ".norm1", &r->n1));
+        TRY(pack_one(e, m, name + ".conv1", true, false, &r->c1));
+        TRY(pack_norm(e, m, name + ".norm2", &r->n2));
+        TRY(pack_one(e, m, name + ".conv2", true, false, &r->c2));
+        r->has_skip = cin != cout;
+        if (r->has_skip) TRY(pack_one(e, m, name + ".nin_shortcut", true, false, &r->skip));
+    } else {
+        TRY(pack_norm(e, m, name + ".in_layers.0", &r->n1));
+        TRY(pack_one(e, m, name + ".in_layers.2", true, false, &r->c1));
+        TRY(pack_norm(e, m, name + ".out_layers.0", &r->n2));
+        TRY(pack_one(e, m, name + ".out_layers.3", true, false, &r->c2));
+        r->has_skip = cin != cout;
+        if (r->has_skip) TRY(pack_one(e, m, name + ".skip_connection", true, false, &r->skip));
+    }
+    return 0;
+}
+
+static int build_st(sdmi_engine* e, const std::string& name, int ch, int heads, int dhead, int depth, STW* st) {
+    auto& m = e->raw_unet;
+    st->ch = ch; st->heads = heads; st->dhead = dhead;
+    SDMI_REQUIRE(heads * dhead == ch, "inner_dim must equal channels");
+    TRY(pack_norm(e, m, name + ".norm", &st->norm));
+    TRY(pack_one(e, m, name + ".proj_in", true, false, &st->proj_in));
+    TRY(pack_one(e, m, name + ".proj_out", true, false, &st->proj_out));
+    for (int d = 0; d < depth; ++d) {
+        const std::string tb = name + ".transformer_blocks." + std::to_string(d);
+        TBlockW b;
+        TRY(pack_norm(e, m, tb + ".norm1", &b.ln1));
+        TRY(pack_norm(e, m, tb + ".norm2", &b.ln2));
+        TRY(pack_norm(e, m, tb + ".norm3", &b.ln3));
+        TRY(pack_stack(e, m, {tb + ".attn1.to_q", tb + ".attn1.to_k"}, true, false, &b.qk1));
+        TRY(pack_one(e, m, tb + ".attn1.to_v", true, false, &b.v1));
+        TRY(pack_one(e, m, tb + ".attn1.to_out.0", true, false, &b.o1));
+        TRY(pack_one(e, m, tb + ".attn2.to_q", true, false, &b.q2));
+        TRY(pack_one(e, m, tb + ".attn2.to_k", true, false, &b.k2));
+        TRY(pack_one(e, m, tb + ".attn2.to_v", true, false, &b.v2));
+        TRY(pack_one(e, m, tb + ".attn2.to_out.0", true, false, &b.o2));
+        TRY(pack_one(e, m, tb + ".ff.net.0.proj", true, true, &b.ff1));
+        TRY(pack_one(e, m, tb + ".ff.net.2", true, false, &b.ff2));
+        b.ctx_slot = e->unet.n_ctx_slots++;
+        st->blocks.push_back(b);
+    }
+    return 0;
+}
+
+static void heads_for(const sdmi_unet_config& c, int ch, int* nh, int* dh) {
+    if (c.num_head_channels == -1) { *nh = c.num_heads; *dh = ch / c.num_heads; }
+    else { *nh = ch / c.num_head_channels; *dh = c.num_head_channels; }
+}
+
+static int unet_build(sdmi_engine* e) {
+    UNetW& u = e->unet;
+    const sdmi_unet_config& c = u.cfg;
+    auto& m = e->raw_unet;
+    const int mc = c.model_channels;
+    u.n_ctx_slots = 0;
+    u.input.clear(); u.output.clear(); u.middle.clear();
+    TRY(pack_one(e, m, "time_embed.0", false, false, &u.te0));
+    TRY(pack_one(e, m, "time_embed.2", false, false, &u.te2));
+    if (c.adm_in_channels > 0) {
+        TRY(pack_one(e, m, "label_emb.0.0", false, false, &u.le0));
+        TRY(pack_one(e, m, "label_emb.0.2", false, false, &u.le2));
+    }
+    std::vector<std::string> emb_names;
+    int emb_cols = 0;
+    auto add_res = [&](const std::string& name, int cin, int cout, int c0, int c1, std::vector<UNetLayer>* dst) -> int {
+        UNetLayer L;
+        L.kind = UNetLayer::RES;
+        L.c0 = c0; L.c1 = c1;
+        TRY(build_res(e, name, cin, cout, false, &L.res));
+        L.res.emb_off = emb_cols;
+        emb_cols += cout;
+        emb_names.push_back(name + ".emb_layers.1");
+        dst->push_back(L);
+        return 0;
+    };
+    auto add_st = [&](const std::string& name, int ch, int level, std::vector<UNetLayer>* dst) -> int {
+        UNetLayer L;
+        L.kind = UNetLayer::ST;
+        int nh, dh;
+        heads_for(c, ch, &nh, &dh);
+        TRY(build_st(e, name, ch, nh, dh, c.transformer_depth[level], &L.st));
+        dst->push_back(L);
+        return 0;
+    };
+    // input blocks
+    {
+        std::vector<UNetLayer> blk;
+        UNetLayer L;
+        L.kind = UNetLayer::CONV_IN;
+        TRY(pack_one(e, m, "input_blocks.0.0", true, false, &L.conv));
+        blk.push_back(L);
+        u.input.push_back(blk);
+    }
+    std::vector<int> chans{mc};
+    int ch = mc, idx = 1;
+    const int nlev = c.num_levels;
+    for (int level = 0; level < nlev; ++level) {
+        for (int i = 0; i < c.num_res_blocks; ++i) {
+            std::vector<UNetLayer> blk;
+            const int cout = c.channel_mult[level] * mc;
+            TRY(add_res("input_blocks." + std::to_string(idx) + ".0", ch, cout, ch, 0, &blk));
+            ch = cout;
+            if (c.attn_level[level]) TRY(add_st("input_blocks." + std::to_string(idx) + ".1", ch, level, &blk));
+            u.input.push_back(blk);
+            chans.push_back(ch);
+            ++idx;
+        }
+        if (level != nlev - 1) {
+            std::vector<UNetLayer> blk;
+            UNetLayer L;
+            L.kind = UNetLayer::DOWN;
+            TRY(pack_one(e, m, "input_blocks." + std::to_string(idx) + ".0.op", true, false, &L.conv));
+            blk.push_back(L);
+            u.input.push_back(blk);
+            chans.push_back(ch);
+            ++idx;
+        }
+    }
+    TRY(add_res("middle_block.0", ch, ch, ch, 0, &u.middle));
+    TRY(add_st("middle_block.1", ch, nlev - 1, &u.middle));
+    TRY(add_res("middle_block.2", ch, ch, ch, 0, &u.middle));
+    idx = 0;
+    for (int level = nlev - 1; level >= 0; --level) {
+        for (int i = 0; i <= c.num_res_blocks; ++i) {
+            std::vector<UNetLayer> blk;
+            const int ich = chans.back();
+            chans.pop_back();
+            const int cout = mc * c.channel_mult[level];
+            const std::string base = "output_blocks." + std::to_string(idx);
+            TRY(add_res(base + ".0", ch + ich, cout, ch, ich, &blk));
+            ch = cout;
+            int li = 1;
+            if (c.attn_level[level]) { TRY(add_st(base + "." + std::to_string(li), ch, level, &blk)); ++li; }
+            if (level && i == c.num_res_blocks) {
+                UNetLayer L;
+                L.kind = UNetLayer::UP;
+                TRY(pack_one(e, m, base + "." + std::to_string(li) + ".conv", true, false, &L.conv));
+                blk.push_back(L);
+            }
+            u.output.push_back(blk);
+            ++idx;
+        }
+    }
+    TRY(pack_norm(e, m, "out.0", &u.out_norm));
+    TRY(pack_one(e, m, "out.2", true, false, &u.out_conv));
+    // fused emb projection: stack emb_layers.1 of every ResBlock -> [sum Cout][ted]
+    TRY(pack_stack(e, m, emb_names, false, false, &u.emb_all));
+    u.emb_cols = emb_cols;
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    u.ready = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const half_t* a0 = nullptr;
+    const half_t* a1 = nullptr;
+    int c0 = 0, c1 = 0;
+    int B = 1, Hi = 1, Wi = 1, Ho = 1, Wo = 1;
+    int stride = 1, pad = 0, up = 0;
+    const float* rowbias = nullptr;
+    int ldrb = 0;
+    const half_t* resid = nullptr;
+    int ldr = 0;
+    void* out = nullptr;
+    int ldo = 0;
+    int flags = 0;
+    int n_real = 0;
+    float alpha = 1.f;
+    int batch = 1;
+    long a_bs = 0, w_bs = 0, o_bs = 0, r_bs = 0;
+};
+
+static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
+    if (r.dry) return 0;
+    GemmP p{};
+    p.a0 = a.a0; p.a1 = a.a1; p.w = W.w; p.bias = W.b; p.rowbias = a.rowbias; p.resid = a.resid; p.out = a.out;
+    p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1; p.lda0 = a.c0; p.lda1 = a.c1;
+    SDMI_REQUIRE(p.cin == W.cin_pad, "conv input channels do not match the packed weight");
+    p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
+    p.taps = W.taps; p.stride = a.stride; p.pad = a.pad; p.up = a.up;
+    p.M = a.B * a.Ho * a.Wo; p.N = W.n_pad; p.K = W.taps * p.cin;
+    p.ldo = a.ldo; p.ldr = a.ldr; p.ldw = p.K; p.ldrb = a.ldrb;
+    p.rows_per_batch = a.Ho * a.Wo;
+    p.n_real = a.n_real ? a.n_real : W.n_pad;
+    p.flags = a.flags | (W.geglu ? EP_GEGLU : 0);
+    p.alpha = a.alpha;
+    p.a_bs = a.a_bs; p.w_bs = a.w_bs; p.o_bs = a.o_bs; p.r_bs = a.r_bs;
+    return launch_gemm(p, a.batch, r.e->force_generic, r.e->use_glds, r.s);
+}
+
+// plain [rows, K] x W^T GEMM on token matrices
+static int run_linear(Run& r, const ConvW& W, const half_t* a, int rows, const half_t* resid, half_t* out, int ldo) {
+    ConvArgs c;
+    c.a0 = a; c.c0 = W.cin_pad;
+    c.B = 1; c.Hi = rows; c.Wi = 1; c.Ho = rows; c.Wo = 1;
+    c.resid = resid; c.ldr = ldo; c.out = out; c.ldo = ldo;
+    return run_conv(r, W, c);
+}
+
+static int run_gn(Run& r, const NormW& n, const half_t* x0, const half_t* x1, int c0, int c1, int B, int HW, float eps,
+                  bool silu, half_t* out) {
+    float* ws = r.F(groupnorm_ws_bytes(B, HW, 32) / sizeof(float));
+    if (r.dry) return 0;
+    SDMI_REQUIRE(n.c == c0 + c1, "GroupNorm channel mismatch");
+    return launch_groupnorm(x0, x1, c0, c1, n.g, n.b, out, B, HW, 32, eps, silu, ws, r.s);
+}
+static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t* out) {
+    if (r.dry) return 0;
+    return launch_layernorm(x, n.g, n.b, out, rows, n.c, 1e-5f, r.s);
+}
+
+// ResBlock (UNet: GroupNorm32 eps 1e-5 + emb add; VAE: eps 1e-6, no emb).  Returns the output buffer.
+static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, int c0, int c1, int B, int H, int Wd,
+                   float eps, const float* embs, int emb_ld, half_t** out) {
+    const int HW = H * Wd;
+    const size_t M = (size_t)B * HW;
+    half_t* t1 = r.H(M * w.cin);
+    TRY(run_gn(r, w.n1, x0, x1, c0, c1, B, HW, eps, true, t1));
+    half_t* h1 = r.H(M * w.cout);
+    {
+        ConvArgs c;
+        c.a0 = t1; c.c0 = w.cin; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
+        if (embs) { c.rowbias = embs + w.emb_off; c.ldrb = emb_ld; }
+        c.out = h1; c.ldo = w.cout;
+        TRY(run_conv(r, w.c1, c));
+    }
+    half_t* t2 = r.H(M * w.cout);
+    TRY(run_gn(r, w.n2, h1, nullptr, w.cout, 0, B, HW, eps, true, t2));
+    const half_t* resid = x0;
+    if (w.has_skip) {
+        half_t* sk = r.H(M * w.cout);
+        ConvArgs c;
+        c.a0 = x0; c.a1 = x1; c.c0 = c0; c.c1 = c1; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd;
+        c.out = sk; c.ldo = w.cout;
+        TRY(run_conv(r, w.skip, c));
+        resid = sk;
+    } else {
+        SDMI_REQUIRE(x1 == nullptr, "identity skip with a concatenated input");
+    }
+    half_t* o = r.H(M * w.cout);
+    {
+        ConvArgs c;
+        c.a0 = t2; c.c0 = w.cout; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
+        c.resid = resid; c.ldr = w.cout; c.out = o; c.ldo = w.cout;
+        TRY(run_conv(r, w.c2, c));
+    }
+    *out = o;
+    return 0;
+}
+
+static int run_attn(Run& r, const half_t* q, const half_t* k, const half_t* vt, half_t* out, int B, int H, int N, int M,
+                    int D, int ldq, int ldk, int vt_ld, int ldo) {
+    if (r.dry) return 0;
+    AttnP p{};
+    p.q = q; p.k = k; p.vt = vt; p.out = out;
+    p.B = B; p.H = H; p.N = N; p.M = M; p.D = D;
+    p.ldq = ldq; p.ldk = ldk; p.vt_ld = vt_ld; p.ldo = ldo;
+    p.scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+    return launch_attention(p, r.e->force_generic, r.s);
+}
+
+// V^T[b] = Wv x X[b]^T :  the weight matrix plays the "activation" role, the tokens of image b the "weight" role.
+static int run_vt(Run& r, const ConvW& Wv, const half_t* x, int ldx, int B, int tokens, int tokens_pad, half_t* vt,
+                  bool bias_row) {
+    if (r.dry) return 0;
+    GemmP p{};
+    const int C = Wv.n_pad, K = Wv.cin_pad;
+    p.a0 = Wv.w; p.c0 = K; p.cin = K; p.lda0 = K;
+    p.w = x; p.ldw = ldx;
+    p.bias = bias_row ? Wv.b : nullptr;
+    p.out = vt;
+    p.Hi = C; p.Wi = 1; p.Ho = C; p.Wo = 1;
+    p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
+    p.M = C; p.N = tokens_pad; p.K = K;
+    p.ldo = tokens_pad; p.rows_per_batch = C; p.n_real = tokens_pad;
+    p.flags = bias_row ? EP_BIAS_ROW : 0;
+    p.alpha = 1.f;
+    SDMI_REQUIRE(tokens_pad == tokens && tokens % 8 == 0, "V^T GEMM needs the token count padded by the caller");
+    p.a_bs = 0; p.w_bs = (long)tokens * ldx;
+    p.o_bs = (long)C * tokens_pad;
+    return launch_gemm(p, B, r.e->force_generic, r.e->use_glds, r.s);
+}
+
+static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, int L, half_t** out) {
+    sdmi_engine* e = r.e;
+    const int C = st.ch, HW = H * Wd;
+    const size_t M = (size_t)B * HW;
+    const int Npad = rup(HW, 64);
+    half_t* n0 = r.H(M * C);
+    TRY(run_gn(r, st.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
+    half_t* cur = r.H(M * C);
+    TRY(run_linear(r, st.proj_in, n0, (int)M, nullptr, cur, C));
+    for (const TBlockW& b : st.blocks) {
+        // --- self attention
+        half_t* n1 = r.H(M * C);
+        TRY(run_ln(r, b.ln1, cur, M, n1));
+        half_t* qk = r.H(M * 2 * C);
+        TRY(run_linear(r, b.qk1, n1, (int)M, nullptr, qk, 2 * C));
+        half_t* vt = r.H((size_t)B * C * Npad);
+        if (Npad != HW) {
+            // token rows beyond HW must exist for the V^T GEMM's "weight" operand; handle odd sizes the simple way
+            SDMI_REQUIRE(false, "latent H*W must be a multiple of 64 for the engine UNet (use the torch UNet for odd sizes)");
+        }
+        TRY(run_vt(r, b.v1, n1, C, B, HW, Npad, vt, false));
+        half_t* a1 = r.H(M * C);
+        TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
+        half_t* x1 = r.H(M * C);
+        TRY(run_linear(r, b.o1, a1, (int)M, cur, x1, C));
+        // --- cross attention (K / V^T of the context are cached per layer by set_context)
+        half_t* n2 = r.H(M * C);
+        TRY(run_ln(r, b.ln2, x1, M, n2));
+        half_t* q2 = r.H(M * C);
+        TRY(run_linear(r, b.q2, n2, (int)M, nullptr, q2, C));
+        half_t* a2 = r.H(M * C);
+        if (!r.dry) {
+            SDMI_REQUIRE(e->ctx_valid && e->ctx_B == B, "context not set for this batch size");
+            // K rows of image b start at b*Lpad: express through ldk and a per-batch offset = Lpad*C
+            AttnP p{};
+            p.q = q2; p.k = e->ctx_k[b.ctx_slot]; p.vt = e->ctx_vt[b.ctx_slot]; p.out = a2;
+            p.B = B; p.H = st.heads; p.N = HW; p.M = e->ctx_L; p.D = st.dhead;
+            p.ldq = C; p.ldk = C; p.vt_ld = e->ctx_Lpad; p.ldo = C;
+            p.scale_log2 = (1.0f / sqrtf((float)st.dhead)) * 1.4426950408889634f;
+            // the attention kernel addresses K as k + b*M*ldk; the cache is laid out with Lpad rows per image, so the
+            // cache stores K compactly with exactly L rows per image (see set_context)
+            TRY(launch_attention(p, e->force_generic, r.s));
+        }
+        half_t* x2 = r.H(M * C);
+        TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C));
+        // --- feed forward (GEGLU fused in the first GEMM's epilogue)
+        half_t* n3 = r.H(M * C);
+        TRY(run_ln(r, b.ln3, x2, M, n3));
+        half_t* g = r.H(M * 4 * C);
+        TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
+        half_t* x3 = r.H(M * C);
+        TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
+        cur = x3;
+    }
+    half_t* o = r.H(M * C);
+    TRY(run_linear(r, st.proj_out, cur, (int)M, x, o, C));
+    *out = o;
+    (void)L;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// context cache
+// ------------------------------------------------------------------------------------------------------------
+static void ctx_free(sdmi_engine* e) {
+    for (void* p : e->ctx_owned) (void)hipFree(p);
+    e->ctx_owned.clear(); e->ctx_k.clear(); e->ctx_vt.clear();
+    e->ctx_f16 = nullptr; e->ctx_valid = false;
+}
+
+static void collect_st(const UNetW& u, std::vector<const STW*>* out) {
+    for (auto& blk : u.input) for (auto& L : blk) if (L.kind == UNetLayer::ST) out->push_back(&L.st);
+    for (auto& L : u.middle) if (L.kind == UNetLayer::ST) out->push_back(&L.st);
+    for (auto& blk : u.output) for (auto& L : blk) if (L.kind == UNetLayer::ST) out->push_back(&L.st);
+}
+
+static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s) {
+    UNetW& u = e->unet;
+    SDMI_REQUIRE(u.ready, "unet not finalized");
+    const int cd = u.cfg.context_dim;
+    const int Lpad = rup(L, 64);
+    if (e->ctx_B != Bn || e->ctx_L != L || e->ctx_k.empty()) {
+        SDMI_CHECK_HIP(hipStreamSynchronize(s));
+        ctx_free(e);
+        void* p = nullptr;
+        SDMI_CHECK_HIP(hipMalloc(&p, (size_t)Bn * Lpad * cd * sizeof(half_t)));
+        e->ctx_owned.push_back(p);
+        e->ctx_f16 = (half_t*)p;
+        SDMI_CHECK_HIP(hipMemsetAsync(p, 0, (size_t)Bn * Lpad * cd * sizeof(half_t), s));
+        std::vector<const STW*> sts;
+        collect_st(u, &sts);
+        e->ctx_k.assign(u.n_ctx_slots, nullptr);
+        e->ctx_vt.assign(u.n_ctx_slots, nullptr);
+        for (const STW* st : sts)
+            for (const TBlockW& b : st->blocks) {
+                SDMI_CHECK_HIP(hipMalloc(&p, (size_t)Bn * L * st->ch * sizeof(half_t)));
+                e->ctx_owned.push_back(p);
+                e->ctx_k[b.ctx_slot] = (half_t*)p;
+                SDMI_CHECK_HIP(hipMalloc(&p, (size_t)Bn * st->ch * Lpad * sizeof(half_t)));
+                e->ctx_owned.push_back(p);
+                e->ctx_vt[b.ctx_slot] = (half_t*)p;
+            }
+        e->ctx_B = Bn; e->ctx_L = L; e->ctx_Lpad = Lpad;
+    }
+    // context -> fp16 rows [Bn][Lpad][cd] (padding rows stay zero)
+    for (int b = 0; b < Bn; ++b) {
+        const char* src = (const char*)ctx + (size_t)b * L * cd * (dtype == SDMI_F16 ? 2 : 4);
+        TRY(launch_convert_to_f16(src, dtype, e->ctx_f16 + (size_t)b * Lpad * cd, (int64_t)L * cd, s));
+    }
+    Run r{e, s, false};
+    std::vector<const STW*> sts;
+    collect_st(u, &sts);
+    for (const STW* st : sts)
+        for (const TBlockW& b : st->blocks) {
+            // K[b] = ctx[b] Wk^T : rows L per image, batched over images (compact [Bn*L][C] output)
+            ConvArgs c;
+            c.a0 = e->ctx_f16; c.c0 = cd; c.B = 1; c.Hi = L; c.Wi = 1; c.Ho = L; c.Wo = 1;
+            c.out = e->ctx_k[b.ctx_slot]; c.ldo = st->ch;
+            c.batch = Bn; c.a_bs = (long)Lpad * cd; c.o_bs = (long)L * st->ch;
+            TRY(run_conv(r, b.k2, c));
+            // V^T[b] = Wv ctx[b]^T : [C][Lpad]
+            TRY(run_vt(r, b.v2, e->ctx_f16, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false));
+        }
+    e->ctx_valid = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// UNet forward
+// ------------------------------------------------------------------------------------------------------------
+struct Act {
+    half_t* p;
+    int C, H, W;
+};
+
+static int unet_run(Run& r, const void* x, const void* t, const void* y, void* out, int io_dtype, int Bn, int h, int w,
+                    int L) {
+    sdmi_engine* e = r.e;
+    UNetW& u = e->unet;
+    const sdmi_unet_config& c = u.cfg;
+    const int mc = c.model_channels, ted = mc * 4;
+    e->arena.reset();
+    // ---- embeddings (fp32 activations, fp16 weights): time_embed(sinusoid(t)) [+ label_emb(y)] --------------
+    float* sinus = r.F((size_t)Bn * mc);
+    float* e1 = r.F((size_t)Bn * ted);
+    float* emb = r.F((size_t)Bn * ted);
+    float* embs = r.F((size_t)Bn * u.emb_cols);
+    float* yf = c.adm_in_channels > 0 ? r.F((size_t)Bn * c.adm_in_channels) : nullptr;
+    float* l1 = c.adm_in_channels > 0 ? r.F((size_t)Bn * ted) : nullptr;
+    if (!r.dry) {
+        TRY(launch_timestep_embedding(t, io_dtype, sinus, Bn, mc, r.s));
+        TRY(launch_small_linear(sinus, u.te0.w, u.te0.b, nullptr, e1, Bn, ted, mc, mc, ted, false, true, r.s));
+        TRY(launch_small_linear(e1, u.te2.w, u.te2.b, nullptr, emb, Bn, ted, ted, ted, ted, false, false, r.s));
+        if (c.adm_in_channels > 0) {
+            SDMI_REQUIRE(y != nullptr, "this UNet needs the vector conditioning y");
+            TRY(launch_convert_to_f32(y, io_dtype, yf, (int64_t)Bn * c.adm_in_channels, r.s));
+            TRY(launch_small_linear(yf, u.le0.w, u.le0.b, nullptr, l1, Bn, ted, c.adm_in_channels, c.adm_in_channels,
+                                    ted, false, true, r.s));
+            TRY(launch_small_linear(l1, u.le2.w, u.le2.b, emb, emb, Bn, ted, ted, ted, ted, false, false, r.s));
+        }
+        // every ResBlock's emb_layers (SiLU -> Linear) in one launch
+        TRY(launch_small_linear(emb, u.emb_all.w, u.emb_all.b, nullptr, embs, Bn, u.emb_cols, ted, ted, u.emb_cols,
+                                true, false, r.s));
+    }
+    // ---- input: NCHW -> NHWC fp16, channels zero-padded to the packed conv_in width ----------------------------
+    const ConvW& cin_w = u.input[0][0].conv;
+    half_t* xin = r.H((size_t)Bn * h * w * cin_w.cin_pad);
+    if (!r.dry) TRY(launch_nchw_to_nhwc(x, io_dtype, xin, Bn, c.in_channels, h * w, cin_w.cin_pad, 1.0f, nullptr, nullptr, r.s));
+
+    std::vector<Act> hs;
+    Act cur{nullptr, 0, h, w};
+    auto run_block = [&](const std::vector<UNetLayer>& blk, const Act* skip) -> int {
+        bool first = true;
+        for (const UNetLayer& Lr : blk) {
+            switch (Lr.kind) {
+                case UNetLayer::CONV_IN: {
+                    half_t* o = r.H((size_t)Bn * cur.H * cur.W * Lr.conv.n_pad);
+                    ConvArgs a;
+                    a.a0 = xin; a.c0 = Lr.conv.cin_pad; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = cur.H; a.Wo = cur.W;
+                    a.pad = 1; a.out = o; a.ldo = Lr.conv.n_pad;
+                    TRY(run_conv(r, Lr.conv, a));
+                    cur = Act{o, Lr.conv.cout, cur.H, cur.W};
+                    break;
+                }
+                case UNetLayer::RES: {
+                    half_t* o = nullptr;
+                    if (skip && first) {
+                        SDMI_REQUIRE(Lr.c0 == cur.C && Lr.c1 == skip->C, "skip concat channel mismatch");
+                        SDMI_REQUIRE(cur.H == skip->H && cur.W == skip->W, "skip connection spatial mismatch");
+                        TRY(run_res(r, Lr.res, cur.p, skip->p, cur.C, skip->C, Bn, cur.H, cur.W, 1e-5f, embs, u.emb_cols, &o));
+                    } else {
+                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bn, cur.H, cur.W, 1e-5f, embs, u.emb_cols, &o));
+                    }
+                    cur = Act{o, Lr.res.cout, cur.H, cur.W};
+                    break;
+                }
+                case UNetLayer::ST: {
+                    half_t* o = nullptr;
+                    TRY(run_st(r, Lr.st, cur.p, Bn, cur.H, cur.W, L, &o));
+                    cur.p = o;
+                    break;
+                }
+                case UNetLayer::DOWN: {
+                    const int Ho = (cur.H + 2 - 3) / 2 + 1, Wo = (cur.W + 2 - 3) / 2 + 1;
+                    half_t* o = r.H((size_t)Bn * Ho * Wo * cur.C);
+                    ConvArgs a;
+                    a.a0 = cur.p; a.c0 = cur.C; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = Ho; a.Wo = Wo;
+                    a.stride = 2; a.pad = 1; a.out = o; a.ldo = cur.C;
+                    TRY(run_conv(r, Lr.conv, a));
+                    cur = Act{o, cur.C, Ho, Wo};
+                    break;
+                }
+                case UNetLayer::UP: {
+                    const int Ho = cur.H * 2, Wo = cur.W * 2;
+                    half_t* o = r.H((size_t)Bn * Ho * Wo * cur.C);
+                    ConvArgs a;
+                    a.a0 = cur.p; a.c0 = cur.C; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = Ho; a.Wo = Wo;
+                    a.up = 1; a.pad = 1; a.out = o; a.ldo = cur.C;
+                    TRY(run_conv(r, Lr.conv, a));
+                    cur = Act{o, cur.C, Ho, Wo};
+                    break;
+                }
+            }
+            first = false;
+        }
+        return 0;
+    };
+    for (auto& blk : u.input) {
+        TRY(run_block(blk, nullptr));
+        hs.push_back(cur);
+    }
+    TRY(run_block(u.middle, nullptr));
+    for (auto& blk : u.output) {
+        Act sk = hs.back();
+        hs.pop_back();
+        TRY(run_block(blk, &sk));
+    }
+    // ---- out: GroupNorm32 + SiLU + conv 3x3 -> fp32 NCHW ---------------------------------------------------
+    const size_t M = (size_t)Bn * cur.H * cur.W;
+    half_t* tn = r.H(M * cur.C);
+    TRY(run_gn(r, u.out_norm, cur.p, nullptr, cur.C, 0, Bn, cur.H * cur.W, 1e-5f, true, tn));
+    float* eps = r.F((size_t)Bn * c.out_channels * cur.H * cur.W);
+    {
+        ConvArgs a;
+        a.a0 = tn; a.c0 = cur.C; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = cur.H; a.Wo = cur.W; a.pad = 1;
+        a.out = eps; a.flags = EP_NCHW; a.n_real = c.out_channels;
+        TRY(run_conv(r, u.out_conv, a));
+    }
+    if (!r.dry) TRY(launch_copy_out(eps, out, io_dtype, (int64_t)Bn * c.out_channels * cur.H * cur.W, r.s));
+    return 0;
+}
+
+static int ensure_arena(sdmi_engine* e, size_t need, hipStream_t s) {
+    if (need <= e->arena.cap) return 0;
+    SDMI_CHECK_HIP(hipStreamSynchronize(s));
+    if (e->arena.base) SDMI_CHECK_HIP(hipFree(e->arena.base));
+    e->arena.base = nullptr; e->arena.cap = 0;
+    const size_t cap = need + (need >> 4) + (1 << 20);
+    SDMI_CHECK_HIP(hipMalloc((void**)&e->arena.base, cap));
+    e->arena.cap = cap;
+    return 0;
+}
+
+int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, const void* y, void* out, int io_dtype,
+                 int Bn, int h, int w, int L, hipStream_t s) {
+    SDMI_REQUIRE(e->unet.ready, "unet not finalized");
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    if (ctx) TRY(unet_set_context(e, ctx, io_dtype, Bn, L, s));
+    // pass 1: dry run to size the arena (pure host arithmetic), pass 2: launch
+    Run dry{e, s, true};
+    e->arena.dry = true; e->arena.high = 0;
+    TRY(unet_run(dry, x, t, y, out, io_dtype, Bn, h, w, L));
+    e->arena.dry = false;
+    TRY(ensure_arena(e, e->arena.high, s));
+    Run run{e, s, false};
+    return unet_run(run, x, t, y, out, io_dtype, Bn, h, w, L);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// VAE
+// ------------------------------------------------------------------------------------------------------------
+static int build_vae_attn(sdmi_engine* e, const std::string& name, int c, VAEAttnW* a) {
+    auto& m = e->raw_vae;
+    a->c = c;
+    TRY(pack_norm(e, m, name + ".norm", &a->norm));
+    TRY(pack_stack(e, m, {name + ".q", name + ".k"}, true, false, &a->qk));
+    TRY(pack_one(e, m, name + ".v", true, false, &a->v));
+    TRY(pack_one(e, m, name + ".proj_out", true, false, &a->proj));
+    return 0;
+}
+
+static int vae_build(sdmi_engine* e) {
+    VAEW& v = e->vae;
+    const sdmi_vae_config& c = v.cfg;
+    auto& m = e->raw_vae;
+    const int nres = c.num_levels, ch = c.ch, z = c.z_channels;
+    // post_quant_conv as fp32 matrices
+    {
+        const RawTensor* w = find_raw(m, "post_quant_conv.weight");
+        const RawTensor* b = find_raw(m, "post_quant_conv.bias");
+        SDMI_REQUIRE(w && b, "missing post_quant_conv");
+        TRY(dev_alloc(e, (void**)&v.pqc_w, (size_t)z * z * sizeof(float)));
+        TRY(dev_alloc(e, (void**)&v.pqc_b, (size_t)z * sizeof(float)));
+        TRY(launch_convert_to_f32(w->ptr, w->dtype, v.pqc_w, (int64_t)z * z, 0));
+        TRY(launch_convert_to_f32(b->ptr, b->dtype, v.pqc_b, z, 0));
+    }
+    int bi = ch * c.ch_mult[nres - 1];
+    TRY(pack_one(e, m, "decoder.conv_in", true, false, &v.d_conv_in));
+    TRY(build_res(e, "decoder.mid.block_1", bi, bi, true, &v.d_mid1));
+    TRY(build_vae_attn(e, "decoder.mid.attn_1", bi, &v.d_attn));
+    TRY(build_res(e, "decoder.mid.block_2", bi, bi, true, &v.d_mid2));
+    v.d_up.assign(nres, VAELevel{});
+    for (int i = nres - 1; i >= 0; --i) {
+        const int bo = ch * c.ch_mult[i];
+        for (int j = 0; j <= c.num_res_blocks; ++j) {
+            ResW r;
+            TRY(build_res(e, "decoder.up." + std::to_string(i) + ".block." + std::to_string(j), bi, bo, true, &r));
+            v.d_up[i].blocks.push_back(r);
+            bi = bo;
+        }
+        if (i != 0) {
+            v.d_up[i].has_resample = true;
+            TRY(pack_one(e, m, "decoder.up." + std::to_string(i) + ".upsample.conv", true, false, &v.d_up[i].resample));
+        }
+    }
+    TRY(pack_norm(e, m, "decoder.norm_out", &v.d_norm_out));
+    TRY(pack_one(e, m, "decoder.conv_out", true, false, &v.d_conv_out));
+
+    v.has_encoder = find_raw(m, "encoder.conv_in.weight") != nullptr && find_raw(m, "quant_conv.weight") != nullptr;
+    if (v.has_encoder) {
+        TRY(pack_one(e, m, "encoder.conv_in", true, false, &v.e_conv_in));
+        v.e_down.assign(nres, VAELevel{});
+        int bin = ch;
+        for (int i = 0; i < nres; ++i) {
+            const int bo = ch * c.ch_mult[i];
+            for (int j = 0; j < c.num_res_blocks; ++j) {
+                ResW r;
+                TRY(build_res(e, "encoder.down." + std::to_string(i) + ".block." + std::to_string(j), bin, bo, true, &r));
+                v.e_down[i].blocks.push_back(r);
+                bin = bo;
+            }
+            if (i != nres - 1) {
+                v.e_down[i].has_resample = true;
+                TRY(pack_one(e, m, "encoder.down." + std::to_string(i) + ".downsample.conv", true, false, &v.e_down[i].resample));
+            }
+        }
+        TRY(build_res(e, "encoder.mid.block_1", bin, bin, true, &v.e_mid1));
+        TRY(build_vae_attn(e, "encoder.mid.attn_1", bin, &v.e_attn));
+        TRY(build_res(e, "encoder.mid.block_2", bin, bin, true, &v.e_mid2));
+        TRY(pack_norm(e, m, "encoder.norm_out", &v.e_norm_out));
+        // fold quant_conv (1x1, 2z -> 2z) into encoder.conv_out on the host:  W' = Wq Wc,  b' = Wq bc + bq
+        const RawTensor* wc = find_raw(m, "encoder.conv_out.weight");
+        const RawTensor* bc = find_raw(m, "encoder.conv_out.bias");
+        const RawTensor* wq = find_raw(m, "quant_conv.weight");
+        const RawTensor* bq = find_raw(m, "quant_conv.bias");
+        SDMI_REQUIRE(wc && bc && wq && bq, "missing encoder.conv_out / quant_conv");
+        const int O = (int)wc->shape[0], I = (int)wc->shape[1];
+        const size_t per = (size_t)I * 9;
+        std::vector<float> hwc((size_t)O * per), hbc(O), hwq((size_t)O * O), hbq(O);
+        float *dwc, *dbc, *dwq, *dbq;
+        SDMI_CHECK_HIP(hipMalloc((void**)&dwc, hwc.size() * 4));
+        SDMI_CHECK_HIP(hipMalloc((void**)&dbc, O * 4));
+        SDMI_CHECK_HIP(hipMalloc((void**)&dwq, hwq.size() * 4));
+        SDMI_CHECK_HIP(hipMalloc((void**)&dbq, O * 4));
+        TRY(launch_convert_to_f32(wc->ptr, wc->dtype, dwc, hwc.size(), 0));
+        TRY(launch_convert_to_f32(bc->ptr, bc->dtype, dbc, O, 0));
+        TRY(launch_convert_to_f32(wq->ptr, wq->dtype, dwq, hwq.size(), 0));
+        TRY(launch_convert_to_f32(bq->ptr, bq->dtype, dbq, O, 0));
+        SDMI_CHECK_HIP(hipMemcpy(hwc.data(), dwc, hwc.size() * 4, hipMemcpyDeviceToHost));
+        SDMI_CHECK_HIP(hipMemcpy(hbc.data(), dbc, O * 4, hipMemcpyDeviceToHost));
+        SDMI_CHECK_HIP(hipMemcpy(hwq.data(), dwq, hwq.size() * 4, hipMemcpyDeviceToHost));
+        SDMI_CHECK_HIP(hipMemcpy(hbq.data(), dbq, O * 4, hipMemcpyDeviceToHost));
+        std::vector<float> fw((size_t)O * per, 0.f), fb(O, 0.f);
+        for (int o = 0; o < O; ++o) {
+            double bacc = hbq[o];
+            for (int k = 0; k < O; ++k) {
+                const float q = hwq[(size_t)o * O + k];
+                bacc += (double)q * hbc[k];
+                for (size_t j = 0; j < per; ++j) fw[(size_t)o * per + j] += q * hwc[(size_t)k * per + j];
+            }
+            fb[o] = (float)bacc;
+        }
+        (void)hipFree(dwc); (void)hipFree(dbc); (void)hipFree(dwq); (void)hipFree(dbq);
+        std::map<std::string, RawTensor> tmp;
+        const int64_t wshape[4] = {O, I, 3, 3}, bshape[1] = {O};
+        TRY(load_raw(tmp, "f.weight", fw.data(), SDMI_F32, 4, wshape, 0));
+        TRY(load_raw(tmp, "f.bias", fb.data(), SDMI_F32, 1, bshape, 0));
+        const int rc = pack_one(e, tmp, "f", true, false, &v.e_conv_out);
+        SDMI_CHECK_HIP(hipDeviceSynchronize());
+        free_raw(tmp);
+        TRY(rc);
+    }
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    v.ready = true;
+    return 0;
+}
+
+// single-head spatial attention of the VAE mid block (N = H*W tokens, d = C = 512): scores materialised through the
+// GEMM kernel (fp32), row softmax, then P V — modules/sd_hijack_optimizations.py:554-610 computes the same product chunked.
+static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H, int Wd, half_t** out) {
+    const int C = a.c, HW = H * Wd, Npad = rup(HW, 64);
+    const size_t M = (size_t)B * HW;
+    SDMI_REQUIRE(Npad == HW, "VAE latent H*W must be a multiple of 64");
+    half_t* n0 = r.H(M * C);
+    TRY(run_gn(r, a.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
+    half_t* qk = r.H(M * 2 * C);
+    TRY(run_linear(r, a.qk, n0, (int)M, nullptr, qk, 2 * C));
+    half_t* vt = r.H((size_t)B * C * Npad);
+    TRY(run_vt(r, a.v, n0, C, B, HW, Npad, vt, true));
+    float* S = r.F((size_t)B * HW * HW);
+    half_t* P = r.H((size_t)B * HW * HW);
+    half_t* o = r.H(M * C);
+    if (!r.dry) {
+        GemmP p{};
+        p.a0 = qk; p.c0 = C; p.cin = C; p.lda0 = 2 * C;
+        p.w = qk + C; p.ldw = 2 * C;
+        p.out = S;
+        p.Hi = HW; p.Wi = 1; p.Ho = HW; p.Wo = 1; p.taps = 1; p.stride = 1;
+        p.M = HW; p.N = HW; p.K = C; p.ldo = HW; p.rows_per_batch = HW; p.n_real = HW;
+        p.flags = EP_OUT_F32;
+        p.alpha = 1.0f / sqrtf((float)C);
+        p.a_bs = (long)HW * 2 * C; p.w_bs = (long)HW * 2 * C; p.o_bs = (long)HW * HW;
+        TRY(launch_gemm(p, B, r.e->force_generic, r.e->use_glds, r.s));
+        TRY(launch_softmax_rows(S, P, (int64_t)B * HW, HW, HW, r.s));
+        GemmP g{};
+        g.a0 = P; g.c0 = HW; g.cin = HW; g.lda0 = HW;
+        g.w = vt; g.ldw = Npad;
+        g.out = o;
+        g.Hi = HW; g.Wi = 1; g.Ho = HW; g.Wo = 1; g.taps = 1; g.stride = 1;
+        g.M = HW; g.N = C; g.K = HW; g.ldo = C; g.rows_per_batch = HW; g.n_real = C;
+        g.alpha = 1.f;
+        g.a_bs = (long)HW * HW; g.w_bs = (long)C * Npad; g.o_bs = (long)HW * C;
+        TRY(launch_gemm(g, B, r.e->force_generic, r.e->use_glds, r.s));
+    }
+    half_t* y = r.H(M * C);
+    TRY(run_linear(r, a.proj, o, (int)M, x, y, C));
+    *out = y;
+    return 0;
+}
+
+static int vae_decode_run(Run& r, const void* z, int io_dtype, float* out, int B, int h, int w) {
+    sdmi_engine* e = r.e;
+    VAEW& v = e->vae;
+    const sdmi_vae_config& c = v.cfg;
+    e->arena.reset();
+    half_t* zin = r.H((size_t)B * h * w * v.d_conv_in.cin_pad);
+    if (!r.dry)
+        TRY(launch_nchw_to_nhwc(z, io_dtype, zin, B, c.z_channels, h * w, v.d_conv_in.cin_pad, 1.0f / c.scale_factor,
+                                v.pqc_w, v.pqc_b, r.s));
+    int H = h, W = w;
+    int C = v.d_conv_in.cout;
+    half_t* cur = r.H((size_t)B * H * W * C);
+    {
+        ConvArgs a;
+        a.a0 = zin; a.c0 = v.d_conv_in.cin_pad; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pad = 1;
+        a.out = cur; a.ldo = C;
+        TRY(run_conv(r, v.d_conv_in, a));
+    }
+    half_t* o = nullptr;
+    TRY(run_res(r, v.d_mid1, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    TRY(run_vae_attn(r, v.d_attn, cur, B, H, W, &o)); cur = o;
+    TRY(run_res(r, v.d_mid2, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    for (int i = c.num_levels - 1; i >= 0; --i) {
+        for (const ResW& rb : v.d_up[i].blocks) {
+            TRY(run_res(r, rb, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o));
+            cur = o; C = rb.cout;
+        }
+        if (v.d_up[i].has_resample) {
+            half_t* u = r.H((size_t)B * (2 * H) * (2 * W) * C);
+            ConvArgs a;
+            a.a0 = cur; a.c0 = C; a.B = B; a.Hi = H; a.Wi = W; a.Ho = 2 * H; a.Wo = 2 * W; a.up = 1; a.pad = 1;
+            a.out = u; a.ldo = C;
+            TRY(run_conv(r, v.d_up[i].resample, a));
+            cur = u; H *= 2; W *= 2;
+        }
+    }
+    half_t* tn = r.H((size_t)B * H * W * C);
+    TRY(run_gn(r, v.d_norm_out, cur, nullptr, C, 0, B, H * W, 1e-6f, true, tn));
+    {
+        ConvArgs a;
+        a.a0 = tn; a.c0 = C; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pad = 1;
+        a.out = out; a.flags = EP_NCHW; a.n_real = c.out_ch;
+        TRY(run_conv(r, v.d_conv_out, a));
+    }
+    return 0;
+}
+
+static int vae_encode_run(Run& r, const void* x, int io_dtype, float* out, int B, int Hin, int Win) {
+    sdmi_engine* e = r.e;
+    VAEW& v = e->vae;
+    const sdmi_vae_config& c = v.cfg;
+    e->arena.reset();
+    int H = Hin, W = Win;
+    half_t* xin = r.H((size_t)B * H * W * v.e_conv_in.cin_pad);
+    if (!r.dry) TRY(launch_nchw_to_nhwc(x, io_dtype, xin, B, c.in_channels, H * W, v.e_conv_in.cin_pad, 1.0f, nullptr, nullptr, r.s));
+    int C = v.e_conv_in.cout;
+    half_t* cur = r.H((size_t)B * H * W * C);
+    {
+        ConvArgs a;
+        a.a0 = xin; a.c0 = v.e_conv_in.cin_pad; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pad = 1;
+        a.out = cur; a.ldo = C;
+        TRY(run_conv(r, v.e_conv_in, a));
+    }
+    half_t* o = nullptr;
+    for (int i = 0; i < c.num_levels; ++i) {
+        for (const ResW& rb : v.e_down[i].blocks) {
+            TRY(run_res(r, rb, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o));
+            cur = o; C = rb.cout;
+        }
+        if (v.e_down[i].has_resample) {
+            // pad (0,1,0,1) then 3x3 stride 2 pad 0  (sd3_impls.py:227-236): out = floor((H + 1 - 3)/2) + 1
+            const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+            half_t* d = r.H((size_t)B * Ho * Wo * C);
+            ConvArgs a;
+            a.a0 = cur; a.c0 = C; a.B = B; a.Hi = H; a.Wi = W; a.Ho = Ho; a.Wo = Wo; a.stride = 2; a.pad = 0;
+            a.out = d; a.ldo = C;
+            TRY(run_conv(r, v.e_down[i].resample, a));
+            cur = d; H = Ho; W = Wo;
+        }
+    }
+    TRY(run_res(r, v.e_mid1, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    TRY(run_vae_attn(r, v.e_attn, cur, B, H, W, &o)); cur = o;
+    TRY(run_res(r, v.e_mid2, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    half_t* tn = r.H((size_t)B * H * W * C);
+    TRY(run_gn(r, v.e_norm_out, cur, nullptr, C, 0, B, H * W, 1e-6f, true, tn));
+    {
+        ConvArgs a;
+        a.a0 = tn; a.c0 = C; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pad = 1;
+        a.out = out; a.flags = EP_NCHW; a.n_real = 2 * c.z_channels;
+        TRY(run_conv(r, v.e_conv_out, a));
+    }
+    return 0;
+}
+
+int vae_decode(sdmi_engine* e, const void* z, int io_dtype, float* out, int B, int h, int w, hipStream_t s) {
+    SDMI_REQUIRE(e->vae.ready, "vae not finalized");
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    Run dry{e, s, true};
+    e->arena.dry = true; e->arena.high = 0;
+    TRY(vae_decode_run(dry, z, io_dtype, out, B, h, w));
+    e->arena.dry = false;
+    TRY(ensure_arena(e, e->arena.high, s));
+    Run run{e, s, false};
+    return vae_decode_run(run, z, io_dtype, out, B, h, w);
+}
+
+int vae_encode(sdmi_engine* e, const void* x, int io_dtype, float* out, int B, int H, int W, hipStream_t s) {
+    SDMI_REQUIRE(e->vae.ready && e->vae.has_encoder, "vae encoder weights not loaded");
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    Run dry{e, s, true};
+    e->arena.dry = true; e->arena.high = 0;
+    TRY(vae_encode_run(dry, x, io_dtype, out, B, H, W));
+    e->arena.dry = false;
+    TRY(ensure_arena(e, e->arena.high, s));
+    Run run{e, s, false};
+    return vae_encode_run(run, x, io_dtype, out, B, H, W);
+}
+
+int engine_load_unet_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                            int on_device) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    return load_raw(e->raw_unet, key, data, dtype, ndim, shape, on_device);
+}
+int engine_load_vae_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                           int on_device) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    return load_raw(e->raw_vae, key, data, dtype, ndim, shape, on_device);
+}
+int engine_unet_finalize(sdmi_engine* e) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    const int rc = unet_build(e);
+    free_raw(e->raw_unet);
+    return rc;
+}
+int engine_vae_finalize(sdmi_engine* e) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    const int rc = vae_build(e);
+    free_raw(e->raw_vae);
+    return rc;
+}
+int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    return unet_set_context(e, ctx, dtype, Bn, L, s);
+}
+
+}  // namespace sdmi
+
+sdmi_engine::~sdmi_engine() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    sdmi::free_raw(raw_unet);
+    sdmi::free_raw(raw_vae);
+    sdmi::ctx_free(this);
+    for (void* p : owned) (void)hipFree(p);
+    if (arena.base) (void)hipFree(arena.base);
+}

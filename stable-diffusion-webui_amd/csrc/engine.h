@@ -1,0 +1,142 @@
+// engine.h — host-side engine of libsdmi: weight registry, packed layouts, activation arena and the UNet / VAE
+// launch graphs.  One engine per GPU, used by one caller at a time (the reference serialises all GPU jobs behind one
+// FIFO lock: /root/reference/modules/call_queue.py:8, modules/fifo_lock.py:6-37).
+#pragma once
+#include "common.h"
+#include "../../include/sdmi.h"
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace sdmi {
+
+struct RawTensor {
+    void* ptr = nullptr;          // device copy (as given dtype)
+    int dtype = 0;
+    std::vector<int64_t> shape;
+    size_t bytes = 0;
+};
+
+// packed conv / linear weights: w [n_pad][taps][cin_pad] fp16, b [n_pad] fp32 (may be null)
+struct ConvW {
+    half_t* w = nullptr;
+    float* b = nullptr;
+    int cin = 0, cin_pad = 0, cout = 0, n_pad = 0, taps = 1;
+    bool geglu = false;
+};
+struct NormW {
+    float* g = nullptr;
+    float* b = nullptr;
+    int c = 0;
+};
+
+struct ResW {
+    NormW n1, n2;
+    ConvW c1, c2, skip;
+    bool has_skip = false;
+    int cin = 0, cout = 0;
+    int emb_off = -1;             // column offset into the fused emb projection output (UNet only)
+};
+struct TBlockW {
+    NormW ln1, ln2, ln3;
+    ConvW qk1;                    // [2C][C]  (to_q ; to_k)
+    ConvW v1;                     // [C][C]   used as the "activation" operand of the V^T GEMM
+    ConvW o1, q2, k2, v2, o2, ff1, ff2;
+    int ctx_slot = -1;            // index into the per-layer context K / V^T cache
+};
+struct STW {
+    NormW norm;
+    ConvW proj_in, proj_out;
+    std::vector<TBlockW> blocks;
+    int ch = 0, heads = 0, dhead = 0;
+};
+struct UNetLayer {
+    enum Kind { CONV_IN, RES, ST, DOWN, UP } kind;
+    ResW res;
+    STW st;
+    ConvW conv;                   // CONV_IN / DOWN / UP
+    int c0 = 0, c1 = 0;           // RES in output blocks: split of the concatenated input (h, skip)
+};
+struct UNetW {
+    sdmi_unet_config cfg{};
+    ConvW te0, te2, le0, le2;     // time_embed / label_emb linears (small-M path: w is plain [N][K] fp16)
+    ConvW emb_all;                // all ResBlock emb_layers.1 stacked: [sum Cout][ted]
+    int emb_cols = 0;
+    std::vector<std::vector<UNetLayer>> input, output;
+    std::vector<UNetLayer> middle;
+    NormW out_norm;
+    ConvW out_conv;
+    int n_ctx_slots = 0;
+    bool ready = false;
+};
+
+struct VAEAttnW {
+    NormW norm;
+    ConvW qk, v, proj;
+    int c = 0;
+};
+struct VAELevel {
+    std::vector<ResW> blocks;
+    ConvW resample;               // upsample.conv (decoder) / downsample.conv (encoder)
+    bool has_resample = false;
+};
+struct VAEW {
+    sdmi_vae_config cfg{};
+    // decoder
+    float* pqc_w = nullptr;       // post_quant_conv as fp32 [z][z]
+    float* pqc_b = nullptr;
+    ConvW d_conv_in, d_conv_out;
+    ResW d_mid1, d_mid2;
+    VAEAttnW d_attn;
+    std::vector<VAELevel> d_up;   // index = level (0 = finest)
+    NormW d_norm_out;
+    // encoder
+    ConvW e_conv_in, e_conv_out;  // e_conv_out has quant_conv folded in
+    ResW e_mid1, e_mid2;
+    VAEAttnW e_attn;
+    std::vector<VAELevel> e_down;
+    NormW e_norm_out;
+    bool has_encoder = false;
+    bool ready = false;
+};
+
+class Arena {
+public:
+    char* base = nullptr;
+    size_t cap = 0, off = 0, high = 0;
+    bool dry = false;
+    void reset() { off = 0; }
+    void* take(size_t bytes) {
+        const size_t a = (off + 255) & ~size_t(255);
+        off = a + bytes;
+        if (off > high) high = off;
+        if (dry) return (void*)(uintptr_t)(0x1000 + a);   // never dereferenced in dry mode
+        return base + a;
+    }
+};
+
+}  // namespace sdmi
+
+struct sdmi_engine {
+    int device = 0;
+    std::map<std::string, sdmi::RawTensor> raw_unet, raw_vae;
+    std::vector<void*> owned;                 // persistent device allocations (weights)
+    sdmi::UNetW unet;
+    sdmi::VAEW vae;
+    sdmi::Arena arena;
+    // options
+    bool force_generic = false;
+    bool use_glds = true;
+    bool use_graph = false;
+    // context cache (persistent between forwards)
+    half_t* ctx_f16 = nullptr;                // [Bn][Lpad][ctx_dim]
+    std::vector<half_t*> ctx_k;               // per slot [Bn*Lpad][C]
+    std::vector<half_t*> ctx_vt;              // per slot [Bn][C][Lpad]
+    std::vector<void*> ctx_owned;
+    int ctx_B = 0, ctx_L = 0, ctx_Lpad = 0;
+    bool ctx_valid = false;
+
+    ~sdmi_engine();
+};

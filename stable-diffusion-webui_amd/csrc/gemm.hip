@@ -1,0 +1,397 @@
+// gemm.hip — implicit-GEMM convolution / linear layer for gfx950 (MI355X), fp16 in, fp32 accumulate on MFMA.
+//
+//   out[m, n] = epilogue( alpha * sum_k A(m, k) * W[n, k] ),   k = tap*Cin + c
+//
+// A(m, k) is gathered on the fly from one or two NHWC fp16 activation tensors (3x3 taps with zero padding,
+// stride 1/2, optional fused nearest-x2 upsample, optional channel concatenation of two sources), so no im2col
+// buffer, no torch.cat and no F.interpolate ever touch HBM.  W is packed [N][K] (K contiguous), which makes both MFMA
+// operands K-contiguous ("B^T" form).
+//
+// Design for CDNA4:
+//   * 256 threads = 4 wave64; block tile BM x BN x 64(K); each wave owns a (BM/WR) x (BN/WC) sub-tile built from
+//     16x16x32 f16 MFMAs (v_mfma_f32_16x16x32_f16), accumulators in registers.
+//   * operands staged global -> LDS with the LDS-direct load (global_load_lds_dwordx4, 16 B/lane, no VGPR round
+//     trip); the LDS image is lane-linear, so the bank-conflict-free XOR swizzle (16-B chunk c of row r lives in slot
+//     c ^ (r & 7)) is applied on the per-lane SOURCE address and undone on the ds_read_b128 side.  Zero padding comes
+//     from pointing padded lanes at a zero page.  (A register-staged variant with the identical LDS image is kept
+//     as template GLDS=false.)
+//   * double-buffered LDS, one barrier per K step; loads of step k+1 are in flight while step k runs on the MFMAs.
+//   * MFMA is issued as D = W_frag x A_frag (i.e. the transposed product) so each lane ends up with 4 CONSECUTIVE
+//     output channels of one pixel: the epilogue does 8-byte packed stores and vector bias / residual loads.
+//   * XCD-aware block remap: consecutive tile ids (which share the gathered A panel) are kept on one XCD's L2.
+//
+// Replaces the torch op sequences enumerated in SURVEY.md 2.3 rows K1, K4, K7, K8 (ldm ResBlock / Downsample /
+// Upsample / SpatialTransformer projections / GEGLU feed-forward; names pinned at
+// /root/reference/extensions-builtin/Lora/networks.py:43-98).
+#include "common.h"
+#include <algorithm>
+
+namespace sdmi {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct RowInfo {
+    int b, yo, xo;
+    bool ok;
+};
+
+// Row bookkeeping of the gather, precomputed once per thread: top-left source coordinate of the 3x3 window (in the
+// x2-upsampled grid when p.up) and the image base pixel.
+struct GRow {
+    int yb, xb;        // yi_raw = yb + dy, xi_raw = xb + dx
+    int pixbase;       // b * Hi * Wi (pixel counts stay far below 2^31)
+    bool ok;
+};
+
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+
+template <int BM, int BN, int WR, int WC, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
+    constexpr int WTM = BM / WR, WTN = BN / WC;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;        // 16-byte chunk loads per thread per stage
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    static_assert(WR * WC == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+
+    // ---- XCD-aware tile id remap (bijective for any grid size) -------------------------------------------
+    const int tiles_n = p.N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, sub = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sub;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const long z = blockIdx.z;
+    const half_t* a0 = p.a0 + z * p.a_bs;
+    const half_t* a1 = p.a1 ? p.a1 + z * p.a_bs : nullptr;
+    const half_t* wbase = p.w + z * p.w_bs;
+
+    // ---- per-thread row bookkeeping for the A gather ---------------------------------------------------------
+    GRow rows[A_IT];
+    const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int idx = it * 256 + tid;
+        const int m = m0 + (idx >> 3);
+        GRow gr;
+        gr.ok = m < p.M;
+        const int mm = gr.ok ? m : 0;
+        const int b = mm / p.rows_per_batch;
+        const int rem = mm - b * p.rows_per_batch;
+        const int yo = rem / p.Wo;
+        const int xo = rem - yo * p.Wo;
+        gr.yb = p.up ? yo - 1 : yo * p.stride - p.pad;
+        gr.xb = p.up ? xo - 1 : xo * p.stride - p.pad;
+        gr.pixbase = b * p.Hi * p.Wi;
+        rows[it] = gr;
+    }
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;
+    uint4 ra[GLDS ? 1 : A_IT], rb[GLDS ? 1 : B_IT];
+
+    // (tap, cbase) of the NEXT stage to issue; advanced incrementally (no integer division in the K loop)
+    int nx_tap = 0, nx_cbase = 0, nx_k0 = 0;
+    auto stage_issue = [&](int sb) {
+        const int tap = nx_tap, cbase = nx_cbase, k0 = nx_k0;
+        nx_k0 += 64;
+        nx_cbase += 64;
+        if (nx_cbase >= p.cin) { nx_cbase = 0; ++nx_tap; }
+        // block-uniform part of the address
+        const bool first = cbase < p.c0;
+        const half_t* src = first ? a0 : a1;
+        const int cch = first ? cbase : cbase - p.c0;
+        const int lda = first ? p.lda0 : p.lda1;
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = (tap * 11) >> 5; dx = tap - dy * 3; }      // tap / 3 for tap in [0, 9)
+        char* abuf = smem + sb * STAGE;
+        char* bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = it * 256 + tid;
+            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
+            const GRow gr = rows[it];
+            const int yr = gr.yb + dy, xr = gr.xb + dx;
+            const bool ok = gr.ok && (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
+            const int pix = gr.pixbase + (yr >> p.up) * p.Wi + (xr >> p.up);
+            const half_t* g = ok ? src + (long)pix * lda + (cch + c * 8) : p.zero;
+            if constexpr (GLDS) {
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            } else {
+                ra[it] = *reinterpret_cast<const uint4*>(g);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int idx = it * 256 + tid;
+            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
+            const half_t* g = wbase + (long)(n0 + r) * p.ldw + k0 + c * 8;
+            if constexpr (GLDS) {
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbuf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            } else {
+                rb[it] = *reinterpret_cast<const uint4*>(g);
+            }
+        }
+    };
+    auto stage_commit = [&](int sb) {
+        if constexpr (!GLDS) {
+            char* abuf = smem + sb * STAGE;
+            char* bbuf = abuf + A_BYTES;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) *reinterpret_cast<uint4*>(abuf + (it * 256 + tid) * 16) = ra[it];
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) *reinterpret_cast<uint4*>(bbuf + (it * 256 + tid) * 16) = rb[it];
+        }
+    };
+    auto compute = [&](int sb) {
+        const char* abuf = smem + sb * STAGE;
+        const char* bbuf = abuf + A_BYTES;
+        const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = ks * 4 + lk;
+            const int sw = (kc ^ (lr & 7)) << 4;          // row & 7 == lane & 7 (tile bases are multiples of 16)
+            h8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const h8*>(abuf + (wr * WTM + i * 16 + lr) * 128 + sw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const h8*>(bbuf + (wc * WTN + j * 16 + lr) * 128 + sw);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: double-buffered, one barrier per K step ------------------------------------------------
+    stage_issue(0);
+    stage_commit(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) stage_issue(cur ^ 1);
+        compute(cur);
+        if (more) stage_commit(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------------
+    // lane holds, for tile (i, j):  m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r
+    const int flags = p.flags;
+    const long ob = z * p.o_bs, rbs = z * p.r_bs;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * WTM + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = m / p.rows_per_batch;
+        if (flags & EP_GEGLU) {
+            // wave tile is 64 wide: column tiles {0,1} hold values, {2,3} the matching gates
+            if constexpr (TN == 4) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nloc = j * 16 + (lane >> 4) * 4;
+                    const int npk = n0 + wc * WTN + nloc;            // packed column of the value
+                    const int nout = (n0 + wc * WTN) / 2 + nloc;     // output column
+                    f4 va = acc[i][j], vg = acc[i][j + 2];
+                    h4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float a = va[r] * p.alpha, g = vg[r] * p.alpha;
+                        if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
+                        o[r] = (half_t)(a * gelu_erf(g));
+                    }
+                    *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+            f4 v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if (p.bias) {
+                if (flags & EP_BIAS_ROW) {
+                    const float bb = p.bias[m];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bb;
+                } else {
+                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
+                    v += bb;
+                }
+            }
+            if (p.rowbias) {
+                const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+                v += bb;
+            }
+            if (p.resid) {
+                const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (flags & EP_NCHW) {
+                const int pix = m - b * p.rows_per_batch;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.n_real)
+                        ((float*)p.out)[ob + ((long)b * p.n_real + n + r) * p.rows_per_batch + pix] = v[r];
+            } else if (flags & EP_OUT_F32) {
+                *reinterpret_cast<f4*>((float*)p.out + ob + (long)m * p.ldo + n) = v;
+            } else {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic kernel: one thread per output element, same addressing rules, no shape restrictions beyond Cin % 8 == 0.
+// Used for shapes the MFMA kernel does not cover and as the independent HIP cross-check in the parity tests.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot_row(const GemmP& p, const half_t* a0, const half_t* a1, const half_t* wrow,
+                                         const RowInfo& ri) {
+    float acc = 0.f;
+    for (int tap = 0; tap < p.taps; ++tap) {
+        for (int cb = 0; cb < p.cin; cb += 8) {
+            // find the source of this 8-channel group
+            const half_t* src;
+            int cch, lda;
+            if (cb < p.c0) { src = a0; cch = cb; lda = p.lda0; } else { src = a1; cch = cb - p.c0; lda = p.lda1; }
+            int dy = 0, dx = 0;
+            if (p.taps == 9) { dy = tap / 3; dx = tap - dy * 3; }
+            int yi, xi;
+            bool ok = true;
+            if (p.up) {
+                int yy = ri.yo + dy - 1, xx = ri.xo + dx - 1;
+                ok = yy >= 0 && xx >= 0 && yy < 2 * p.Hi && xx < 2 * p.Wi;
+                yi = yy >> 1; xi = xx >> 1;
+            } else {
+                yi = ri.yo * p.stride + dy - p.pad;
+                xi = ri.xo * p.stride + dx - p.pad;
+                ok = yi >= 0 && xi >= 0 && yi < p.Hi && xi < p.Wi;
+            }
+            if (!ok) continue;
+            const long pix = ((long)ri.b * p.Hi + yi) * p.Wi + xi;
+            const h8 av = *reinterpret_cast<const h8*>(src + pix * lda + cch);
+            const h8 wv = *reinterpret_cast<const h8*>(wrow + (long)tap * p.cin + cb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)av[e], (float)wv[e], acc);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
+    const long z = blockIdx.z;
+    const half_t* a0 = p.a0 + z * p.a_bs;
+    const half_t* a1 = p.a1 ? p.a1 + z * p.a_bs : nullptr;
+    const half_t* wbase = p.w + z * p.w_bs;
+    const bool geglu = p.flags & EP_GEGLU;
+    const int nout_cols = geglu ? p.N / 2 : ((p.flags & EP_NCHW) ? p.n_real : p.N);
+    const long total = (long)p.M * nout_cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / nout_cols), no = (int)(idx - (long)m * nout_cols);
+        RowInfo ri;
+        ri.ok = true;
+        ri.b = m / p.rows_per_batch;
+        const int rem = m - ri.b * p.rows_per_batch;
+        ri.yo = rem / p.Wo;
+        ri.xo = rem - ri.yo * p.Wo;
+        if (geglu) {
+            const int g = no >> 5, r = no & 31;
+            const int na = g * 64 + r, ng = na + 32;
+            float a = dot_row(p, a0, a1, wbase + (long)na * p.ldw, ri) * p.alpha;
+            float gt = dot_row(p, a0, a1, wbase + (long)ng * p.ldw, ri) * p.alpha;
+            if (p.bias) { a += p.bias[na]; gt += p.bias[ng]; }
+            ((half_t*)p.out)[z * p.o_bs + (long)m * p.ldo + no] = (half_t)(a * gelu_erf(gt));
+            continue;
+        }
+        float v = dot_row(p, a0, a1, wbase + (long)no * p.ldw, ri) * p.alpha;
+        if (p.bias) v += (p.flags & EP_BIAS_ROW) ? p.bias[m] : p.bias[no];
+        if (p.rowbias) v += p.rowbias[(long)ri.b * p.ldrb + no];
+        if (p.resid) v += (float)p.resid[z * p.r_bs + (long)m * p.ldr + no];
+        if (p.flags & EP_NCHW) {
+            ((float*)p.out)[z * p.o_bs + ((long)ri.b * p.n_real + no) * p.rows_per_batch + rem] = v;
+        } else if (p.flags & EP_OUT_F32) {
+            ((float*)p.out)[z * p.o_bs + (long)m * p.ldo + no] = v;
+        } else {
+            ((half_t*)p.out)[z * p.o_bs + (long)m * p.ldo + no] = (half_t)v;
+        }
+    }
+}
+
+template <int BM, int BN, int WR, int WC, bool GLDS>
+static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
+    constexpr int SMEM = 2 * (BM + BN) * 128;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, GLDS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tiles = cdiv(p.M, BM) * (p.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(256), SMEM, s, p);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+bool gemm_mfma_supported(const GemmP& p) {
+    if (p.N % 64 || p.cin % 64 || p.K % 64) return false;
+    if (p.c1 > 0 && (p.c0 % 64)) return false;
+    if ((p.flags & EP_GEGLU) && (p.N % 64)) return false;
+    if (p.c0 % 8 || p.c1 % 8 || p.lda0 % 8 || (p.c1 > 0 && p.lda1 % 8) || p.ldw % 8) return false;
+    return true;
+}
+
+int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s) {
+    GemmP p = p_in;
+    p.zero = zero_page();
+    SDMI_REQUIRE(p.zero != nullptr, "zero page allocation failed");
+    SDMI_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
+    SDMI_REQUIRE(p.cin % 8 == 0, "Cin must be a multiple of 8 (pad channels)");
+    if (force_generic || !gemm_mfma_supported(p)) {
+        const bool geglu = p.flags & EP_GEGLU;
+        const long total = (long)p.M * (geglu ? p.N / 2 : p.N);
+        int blocks = (int)std::min<long>((total + 255) / 256, 65535L * 8);
+        hipLaunchKernelGGL(gemm_generic_kernel, dim3(blocks, 1, batch), dim3(256), 0, s, p);
+        SDMI_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    // tile choice: big 128x128 (or 256x64 when N is not a multiple of 128) while the grid still covers the chip,
+    // otherwise 64x64 tiles so the deep 8x8 / 16x16 levels keep >= 256 workgroups in flight.
+    const bool n128 = (p.N % 128) == 0;
+    const long big_tiles = n128 ? (long)cdiv(p.M, 128) * (p.N / 128) : (long)cdiv(p.M, 256) * (p.N / 64);
+    const bool small = big_tiles * batch < 192;
+#define SDMI_LAUNCH(BM, BN, WR, WC)                                                   \
+    return use_glds ? launch_cfg<BM, BN, WR, WC, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, false>(p, batch, s)
+    if (small) { SDMI_LAUNCH(64, 64, 4, 1); }
+    if (n128) { SDMI_LAUNCH(128, 128, 2, 2); }
+    SDMI_LAUNCH(256, 64, 4, 1);
+#undef SDMI_LAUNCH
+}
+
+}  // namespace sdmi

@@ -1,0 +1,190 @@
+// norm.hip — GroupNorm(+SiLU) and LayerNorm on NHWC fp16 activations for gfx950; statistics in fp32.
+//
+// GroupNorm replaces ldm's GroupNorm32 (fp32 compute, /root/reference/modules/devices.py:284-295) followed by SiLU
+// (/root/reference/modules/sd_hijack.py:69), and — by reading TWO channel-concatenated sources and writing one tensor —
+// the torch.cat of UNet skip connections (/root/reference/modules/sd_hijack_unet.py:10-33).  Both kernels are HBM-bound:
+// every access is a 16-byte (8 x fp16) vector, rows are read fully coalesced, and the statistics pass writes only
+// per-(image, chunk, group) partial sums (no atomics => bit-reproducible).
+//   pass 1  gn_stats : grid (chunks, B); a block owns `rows` pixels x all channels; thread t keeps per-channel
+//                      sum / sum-of-squares of its 8-channel vector in registers, stores them in its own LDS slot
+//                      (one writer per slot), then 1 thread per group reduces its channels in a fixed order
+//                      -> partial[b][chunk][g] = (sum, sumsq)
+//   pass 2  gn_apply : grid (blocks, B); prologue reduces the partials to mean / rstd per group in LDS, then a
+//                      grid-stride elementwise pass y = silu((x - mean) * rstd * gamma + beta).
+// LayerNorm: one wave per token row, row held in registers, two-pass (mean, then centred variance) in fp32.
+#include "common.h"
+#include <algorithm>
+
+namespace sdmi {
+
+static constexpr int GN_MAX_C = 4096;
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const half_t* x1, int c0, int c1, int HW,
+                                                       int groups, int rows_per_chunk, float* partial) {
+    __shared__ float s_sum[GN_MAX_C];
+    __shared__ float s_sq[GN_MAX_C];
+    const int C = c0 + c1, VP = C / 8;
+    const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+    const int tid = threadIdx.x;
+    const int TP = VP < 256 ? VP : 256;          // threads across one pixel row
+    const int R = 256 / TP;                      // pixel rows processed in parallel (R * C <= 2048 when R > 1)
+    for (int c = tid; c < R * C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+    const int p_begin = chunk * rows_per_chunk;
+    const int p_end = min(HW, p_begin + rows_per_chunk);
+    if (tid < TP * R) {
+        const int tr = tid / TP, tc = tid - tr * TP;
+        for (int cv = tc; cv < VP; cv += TP) {
+            const int c = cv * 8;
+            const half_t* src;
+            int cc, ld;
+            if (c < c0) { src = x0; cc = c; ld = c0; } else { src = x1; cc = c - c0; ld = c1; }
+            float a[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; }
+            for (int pix = p_begin + tr; pix < p_end; pix += R) {
+                const h8 v = *reinterpret_cast<const h8*>(src + ((long)b * HW + pix) * ld + cc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; a[e] += f; q[e] = fmaf(f, f, q[e]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s_sum[tr * C + c + e] = a[e]; s_sq[tr * C + c + e] = q[e]; }   // one writer per slot
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const int cpg = C / groups;
+        float a = 0.f, q = 0.f;
+        for (int r = 0; r < R; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += s_sum[r * C + c]; q += s_sq[r * C + c]; }
+        float* dst = partial + (((long)b * nchunk + chunk) * groups + tid) * 2;
+        dst[0] = a; dst[1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const half_t* x1, int c0, int c1, int HW,
+                                                       int groups, int nchunk, const float* partial,
+                                                       const float* gamma, const float* beta, half_t* out, float eps,
+                                                       int silu) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int C = c0 + c1, VP = C / 8, cpg = C / groups;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < groups) {
+        // fixed-order fp32 reduction of the chunk partials (deterministic)
+        float a = 0.f, q = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const float* src = partial + (((long)b * nchunk + ch) * groups + tid) * 2;
+            a += src[0]; q += src[1];
+        }
+        const float n = (float)cpg * (float)HW;
+        const float mean = a / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const long nvec = (long)HW * VP;
+    for (long i = (long)blockIdx.x * 256 + tid; i < nvec; i += (long)gridDim.x * 256) {
+        const int pix = (int)(i / VP), cv = (int)(i - (long)pix * VP);
+        const int c = cv * 8;
+        const half_t* src;
+        int cc, ld;
+        if (c < c0) { src = x0; cc = c; ld = c0; } else { src = x1; cc = c - c0; ld = c1; }
+        const h8 v = *reinterpret_cast<const h8*>(src + ((long)b * HW + pix) * ld + cc);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ce = c + e, g = ce / cpg;
+            float y = ((float)v[e] - s_mean[g]) * s_rstd[g] * gamma[ce] + beta[ce];
+            if (silu) y = y / (1.0f + __expf(-y));
+            o[e] = (half_t)y;
+        }
+        *reinterpret_cast<h8*>(out + ((long)b * HW + pix) * C + c) = o;
+    }
+}
+
+static inline int gn_chunks(int HW) {
+    int n = HW / 128;              // >= 128 pixels per chunk
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+
+int64_t groupnorm_ws_bytes(int B, int HW, int groups) { return (int64_t)B * gn_chunks(HW) * groups * 2 * sizeof(float); }
+
+int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
+                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s) {
+    const int C = c0 + c1;
+    SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
+    SDMI_REQUIRE(C <= GN_MAX_C && groups <= 64 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 64, C % groups == 0");
+    const int nchunk = gn_chunks(HW);
+    const int rows = cdiv(HW, nchunk);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
+    SDMI_CHECK_HIP(hipGetLastError());
+    const long nvec = (long)HW * (C / 8);
+    int blocks = (int)std::min<long>((nvec + 255) / 256, 1024);
+    if ((long)blocks * B > 8192) blocks = std::max(1, 8192 / B);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
+                       beta, out, eps, silu ? 1 : 0);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm: 4 rows per block (one wave each); lane holds up to 4 vectors of 8 channels (C <= 2048).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const float* gamma, const float* beta,
+                                                        half_t* out, long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int VP = C / 8;
+    const half_t* src = x + row * C;
+    h8 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cv = lane + k * 64;
+        if (cv < VP) {
+            v[k] = *reinterpret_cast<const h8*>(src + cv * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[k][e];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cv = lane + k * 64;
+        if (cv < VP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[k][e] - mean; sq = fmaf(d, d, sq); }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cv = lane + k * 64;
+        if (cv < VP) {
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = cv * 8 + e;
+                o[e] = (half_t)(((float)v[k][e] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *reinterpret_cast<h8*>(out + row * C + cv * 8) = o;
+        }
+    }
+}
+
+int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
+                     float eps, hipStream_t s) {
+    SDMI_REQUIRE(C % 8 == 0 && C <= 2048, "LayerNorm: C % 8 == 0 and C <= 2048");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, out, (long)rows, C, eps);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sdmi

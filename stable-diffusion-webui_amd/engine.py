@@ -1,0 +1,154 @@
+"""Python face of the C++ engine (sdmi_engine): weight hand-over from a checkpoint state dict, UNet forward,
+VAE decode / encode.  Torch tensors are used for storage only; every computation is a HIP kernel behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr, dtype_code
+from .schema import UNET_PREFIX, VAE_PREFIX, UNetConfig, VAEConfig, unet_schema, vae_schema
+
+
+def _unet_cfg_c(cfg: UNetConfig) -> _lib.UNetConfigC:
+    c = _lib.UNetConfigC()
+    c.in_channels, c.out_channels, c.model_channels = cfg.in_channels, cfg.out_channels, cfg.model_channels
+    c.num_levels = len(cfg.channel_mult)
+    ds = 1
+    for i, m in enumerate(cfg.channel_mult):
+        c.channel_mult[i] = m
+        c.attn_level[i] = 1 if ds in cfg.attention_resolutions else 0
+        c.transformer_depth[i] = cfg.depth_at(i)
+        ds *= 2
+    c.num_res_blocks = cfg.num_res_blocks
+    c.num_heads = cfg.num_heads
+    c.num_head_channels = cfg.num_head_channels
+    c.context_dim = cfg.context_dim
+    c.adm_in_channels = cfg.adm_in_channels or 0
+    return c
+
+
+def _vae_cfg_c(cfg: VAEConfig) -> _lib.VAEConfigC:
+    c = _lib.VAEConfigC()
+    c.ch, c.num_levels = cfg.ch, len(cfg.ch_mult)
+    for i, m in enumerate(cfg.ch_mult):
+        c.ch_mult[i] = m
+    c.num_res_blocks, c.in_channels, c.out_ch, c.z_channels = cfg.num_res_blocks, cfg.in_channels, cfg.out_ch, cfg.z_channels
+    c.scale_factor = cfg.scale_factor
+    return c
+
+
+class Engine:
+    """One engine per GPU.  Not thread-safe by design: the webui serialises GPU work behind one FIFO lock."""
+
+    def __init__(self, device: int = 0):
+        _lib.require_device()
+        self.device = int(device)
+        self.handle = lib.sdmi_engine_create(self.device)
+        if not self.handle:
+            raise _lib.SdmiError("sdmi_engine_create failed: " + _lib.last_error())
+        self.unet_cfg: Optional[UNetConfig] = None
+        self.vae_cfg: Optional[VAEConfig] = None
+        self._ctx_key = None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.sdmi_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------------
+    def set_option(self, name: str, value: int):
+        check(lib.sdmi_engine_set_option(self.handle, name.encode(), int(value)), "set_option")
+
+    def _load(self, fn, key: str, t: torch.Tensor):
+        if t.dtype not in (torch.float16, torch.float32):
+            t = t.float()
+        t = t.contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        check(fn(self.handle, key.encode(), C.c_void_p(t.data_ptr()), dtype_code(t), t.dim(), shape, 1 if t.is_cuda else 0),
+              f"load_tensor({key})")
+
+    def load_unet(self, cfg: UNetConfig, state_dict: dict, prefix: str = UNET_PREFIX):
+        """Stream ``state_dict[prefix + key]`` for every key of the UNet schema into the engine and pack.
+        ``state_dict`` is what modules/sd_models.py:312-329 read_state_dict returns."""
+        self.unet_cfg = cfg
+        c = _unet_cfg_c(cfg)
+        check(lib.sdmi_unet_configure(self.handle, C.byref(c)), "unet_configure")
+        for key, shape, _ in unet_schema(cfg):
+            t = state_dict[prefix + key]
+            if tuple(t.shape) != tuple(shape):
+                raise _lib.SdmiError(f"checkpoint tensor {prefix + key} has shape {tuple(t.shape)}, expected {shape}")
+            self._load(lib.sdmi_unet_load_tensor, key, t)
+        check(lib.sdmi_unet_finalize(self.handle), "unet_finalize")
+        self._ctx_key = None
+
+    def load_vae(self, cfg: VAEConfig, state_dict: dict, prefix: str = VAE_PREFIX, decoder_only: bool = False):
+        self.vae_cfg = cfg
+        c = _vae_cfg_c(cfg)
+        check(lib.sdmi_vae_configure(self.handle, C.byref(c)), "vae_configure")
+        for key, shape, _ in vae_schema(cfg):
+            if decoder_only and (key.startswith("encoder.") or key.startswith("quant_conv.")):
+                continue
+            self._load(lib.sdmi_vae_load_tensor, key, state_dict[prefix + key])
+        check(lib.sdmi_vae_finalize(self.handle), "vae_finalize")
+
+    # ------------------------------------------------------------------------------------------------------
+    def set_context(self, context: torch.Tensor):
+        """Project the (step-invariant) text conditioning to every cross-attention layer's K / V^T once."""
+        context = context.contiguous()
+        bn, l, _ = context.shape
+        check(lib.sdmi_unet_set_context(self.handle, ptr(context), dtype_code(context), bn, l, stream_ptr()), "set_context")
+        self._ctx_shape = (bn, l)
+
+    def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
+                     y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections."""
+        x = x.contiguous()
+        dt = x.dtype
+        timesteps = timesteps.to(dt).contiguous()
+        bn, _, h, w = x.shape
+        if context is not None:
+            context = context.to(dt).contiguous()
+            l = context.shape[1]
+            self._ctx_shape = (bn, l)
+        else:
+            l = self._ctx_shape[1]
+        if y is not None:
+            y = y.to(dt).contiguous()
+        if out is None:
+            out = torch.empty((bn, self.unet_cfg.out_channels, h, w), dtype=dt, device=x.device)
+        check(lib.sdmi_unet_forward(self.handle, ptr(x), ptr(timesteps), ptr(context), ptr(y), ptr(out), dtype_code(x),
+                                    bn, h, w, l, stream_ptr()), "unet_forward")
+        return out
+
+    def vae_decode(self, z: torch.Tensor) -> torch.Tensor:
+        """decode_first_stage for a whole batch: fp32 NCHW image in [-1, 1]."""
+        z = z.contiguous()
+        b, _, h, w = z.shape
+        nlev = len(self.vae_cfg.ch_mult)
+        f = 2 ** (nlev - 1)
+        out = torch.empty((b, self.vae_cfg.out_ch, h * f, w * f), dtype=torch.float32, device=z.device)
+        check(lib.sdmi_vae_decode(self.handle, ptr(z), dtype_code(z), ptr(out), b, h, w, stream_ptr()), "vae_decode")
+        return out
+
+    def vae_encode_moments(self, x: torch.Tensor) -> torch.Tensor:
+        """quant_conv(encoder(x)): fp32 NCHW [B, 2*z, H/f, W/f] (mean | logvar); x in [-1, 1]."""
+        x = x.contiguous()
+        b, _, hh, ww = x.shape
+        nlev = len(self.vae_cfg.ch_mult)
+        f = 2 ** (nlev - 1)
+        out = torch.empty((b, 2 * self.vae_cfg.z_channels, hh // f, ww // f), dtype=torch.float32, device=x.device)
+        check(lib.sdmi_vae_encode(self.handle, ptr(x), dtype_code(x), ptr(out), b, hh, ww, stream_ptr()), "vae_encode")
+        return out
+
+    def arena_bytes(self) -> int:
+        return int(lib.sdmi_engine_arena_bytes(self.handle))

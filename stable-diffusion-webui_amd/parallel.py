@@ -1,0 +1,127 @@
+"""Multi-GPU data parallelism for the hot path: one process per GPU, images sharded, no per-step communication.
+
+The reference is single-device; images of a batch are independent units — own generator
+(modules/rng.py:108), own cond row, per-image CFG combine (modules/sd_samplers_cfg_denoiser.py:78-80) and decode
+(modules/processing.py:631) — so the job [0, batch_size*n_iter) is split contiguously across ranks and each rank's images
+are bit-identical to the single-GPU result (seeds are ``seed + global_index``).  Collectives (RCCL over xGMI via
+``torch.distributed`` backend "nccl"; "gloo" on CPU for the tests):
+  * once per checkpoint: weights packed into one blob on rank 0 and sent scatter + all-gather, so all 7 xGMI links of every
+    GPU carry 1/W of the blob instead of one link carrying all of it (a ring/chain broadcast is bound by one 153 GB/s link);
+  * once per job: gather of the uint8 images to rank 0.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Join the process group the launcher (torch.distributed.run) described in the environment."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous split of [0, n_items); the first (n_items % world) ranks take one extra item."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def broadcast_blob(blob: torch.Tensor, src: int = 0, algo: str = "scatter_allgather") -> torch.Tensor:
+    """Broadcast a flat uint8 tensor (same length on every rank; contents valid on ``src``)."""
+    world = dist.get_world_size()
+    if world == 1:
+        return blob
+    n = blob.numel()
+    if algo == "broadcast" or n < (1 << 20):
+        dist.broadcast(blob, src=src)
+        return blob
+    assert n % world == 0, "pad the blob to a multiple of the world size"
+    shard = n // world
+    views = list(blob.view(world, shard).unbind(0))
+    mine = torch.empty(shard, dtype=blob.dtype, device=blob.device)
+    dist.scatter(mine, scatter_list=[v.contiguous() for v in views] if dist.get_rank() == src else None, src=src)
+    dist.all_gather(views, mine)          # each rank pulls the other W-1 shards from their owners (all links busy)
+    return blob
+
+
+def broadcast_state_dict(sd: Optional[dict], src: int = 0, device="cpu", algo: str = "scatter_allgather") -> dict:
+    """Rank ``src`` passes the checkpoint dict; every rank returns an identical dict whose tensors are views into one
+    device blob (fp16 tensors stay fp16: ~2.1 GB for SD1.5)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return {k: v.to(device) for k, v in sd.items()}
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        meta[0] = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+    dist.broadcast_object_list(meta, src=src)
+    entries = meta[0]
+    offs, total = [], 0
+    for _, shape, dt in entries:
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=getattr(torch, dt)).element_size()
+        total = _pad_to(total, 256)
+        offs.append((total, nbytes))
+        total += nbytes
+    total = _pad_to(total, 256 * world)
+    blob = torch.empty(total, dtype=torch.uint8, device=device)
+    if rank == src:
+        for (k, shape, dt), (o, nb) in zip(entries, offs):
+            blob[o:o + nb].copy_(sd[k].contiguous().view(-1).view(torch.uint8).to(device))
+    broadcast_blob(blob, src=src, algo=algo)
+    out = {}
+    for (k, shape, dt), (o, nb) in zip(entries, offs):
+        out[k] = blob[o:o + nb].view(getattr(torch, dt)).view(shape)
+    return out
+
+
+def gather_to_rank0(t: torch.Tensor, counts: List[int]) -> Optional[torch.Tensor]:
+    """Concatenate per-rank tensors (rank r contributes counts[r] leading rows) on rank 0."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return t
+    rank = dist.get_rank()
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, gather_list=bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device="cpu") -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

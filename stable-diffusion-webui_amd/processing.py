@@ -1,0 +1,206 @@
+"""Entry point of the path: ``StableDiffusionProcessingTxt2Img`` / ``...Img2Img`` + ``process_images`` with the reference's
+field names and control flow (modules/processing.py:136-227, 819-1150, 1166-1464, 1557-1789), driving the engine.
+
+Inside the webui the reference's own ``modules/processing.py`` stays in charge and reaches the engine through the
+plugin boundaries.  This mirror exists so the same flow runs standalone (bench.py, tests, multi-GPU
+runner) where the webui's Python dependencies are absent: prompts are replaced by ready conditioning tensors
+(``p.c`` / ``p.uc``; the CLIP text encoder is row N2 of SURVEY.md section 8f), images come back as uint8 HWC arrays.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops, sd_samplers, shared
+from .rng import ImageRNG
+
+opt_C = 4
+opt_f = 8
+
+
+@dataclass
+class StableDiffusionProcessing:
+    sd_model: Any = None
+    prompt: Any = ""
+    negative_prompt: Any = ""
+    c: Optional[torch.Tensor] = None                 # conditioning  [N, 77k, ctx]  (N = batch_size * n_iter)
+    uc: Optional[torch.Tensor] = None                # unconditional conditioning
+    y: Optional[torch.Tensor] = None                 # SDXL vector conditioning [N, 2816] (cond) / uy (uncond)
+    uy: Optional[torch.Tensor] = None
+    seed: int = -1
+    subseed: int = -1
+    subseed_strength: float = 0
+    seed_resize_from_h: int = -1
+    seed_resize_from_w: int = -1
+    sampler_name: str = None
+    scheduler: str = None
+    batch_size: int = 1
+    n_iter: int = 1
+    steps: int = 50
+    cfg_scale: float = 7.0
+    width: int = 512
+    height: int = 512
+    denoising_strength: float = None
+    eta: float = None
+    s_min_uncond: float = 0.0
+    s_churn: float = 0.0
+    s_tmax: float = None
+    s_tmin: float = 0.0
+    s_noise: float = None
+    sampler_noise_scheduler_override: Any = None
+    is_hr_pass: bool = False
+    # runtime
+    sampler: Any = None
+    rng: Any = None
+    seeds: List[int] = None
+    all_seeds: List[int] = None
+    iteration: int = 0
+    extra_generation_params: dict = field(default_factory=dict)
+    keep_latents: bool = True
+
+    def init(self, all_prompts, all_seeds, all_subseeds):
+        pass
+
+    def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
+        raise NotImplementedError()
+
+    def close(self):
+        self.sampler = None
+
+
+@dataclass
+class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
+    enable_hr: bool = False
+    denoising_strength: float = 0.75
+    hr_scale: float = 2.0
+    hr_upscaler: str = "Latent"
+    hr_second_pass_steps: int = 0
+    hr_resize_x: int = 0
+    hr_resize_y: int = 0
+    hr_scheduler: str = None
+    hr_sampler_name: str = None
+
+    def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
+        """modules/processing.py:1307-1362"""
+        self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
+        x = self.rng.next()
+        samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning, image_conditioning=None)
+        del x
+        if not self.enable_hr:
+            return samples
+        return self.sample_hr_pass(samples, None, seeds, subseeds, subseed_strength, prompts, conditioning, unconditional_conditioning)
+
+    def sample_hr_pass(self, samples, decoded_samples, seeds, subseeds, subseed_strength, prompts, conditioning, unconditional_conditioning):
+        """modules/processing.py:1364-1464 for latent upscalers (shared.py:54-62: "Latent" = bilinear, no antialias):
+        first-pass latents are not decoded; fresh ImageRNG noise; second pass is sample_img2img at hr size."""
+        if self.hr_upscaler not in ("Latent", "Latent (nearest)", "Latent (bicubic)", "Latent (nearest-exact)"):
+            raise NotImplementedError("only latent hires upscalers are implemented in the engine path")
+        mode = {"Latent": "bilinear", "Latent (nearest)": "nearest", "Latent (bicubic)": "bicubic",
+                "Latent (nearest-exact)": "nearest-exact"}[self.hr_upscaler]
+        self.is_hr_pass = True
+        target_w = self.hr_resize_x or int(self.width * self.hr_scale)
+        target_h = self.hr_resize_y or int(self.height * self.hr_scale)
+        # K16: tiny [B,4,h,w] resample; torch's interpolate on the GPU tensor, as the reference does
+        samples = torch.nn.functional.interpolate(samples, size=(target_h // opt_f, target_w // opt_f), mode=mode,
+                                                  antialias=False)
+        self.rng = ImageRNG(samples.shape[1:], self.seeds, eta_noise_seed_delta=shared.opts.eta_noise_seed_delta,
+                            device=samples.device)
+        noise = self.rng.next()
+        name = self.hr_sampler_name or self.sampler_name
+        self.sampler = sd_samplers.create_sampler(name, self.sd_model)
+        samples = self.sampler.sample_img2img(self, samples.contiguous(), noise, conditioning, unconditional_conditioning,
+                                              steps=self.hr_second_pass_steps or self.steps, image_conditioning=None)
+        self.is_hr_pass = False
+        return samples
+
+
+@dataclass
+class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
+    init_images: Any = None                       # float tensor [N,3,H,W] in [0,1] (the reference builds it at :1700-1728)
+    denoising_strength: float = 0.75
+    latent_mask: Optional[torch.Tensor] = None    # [N,4,h,w] latent-space mask (1 = keep original), optional
+    init_latent: Optional[torch.Tensor] = None
+    mask: Optional[torch.Tensor] = None
+    nmask: Optional[torch.Tensor] = None
+
+    def init(self, all_prompts, all_seeds, all_subseeds):
+        """modules/processing.py:1602-1757 reduced to: image*2-1 -> VAE encode -> latent (posterior mean, deterministic)."""
+        image = self.init_images.to(self.sd_model.device, dtype=torch.float32) * 2.0 - 1.0
+        moments = self.sd_model.encode_first_stage(image.contiguous())
+        self.init_latent_all = self.sd_model.get_first_stage_encoding(moments)
+
+    def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
+        """modules/processing.py:1759-1789"""
+        lo = self.iteration * self.batch_size
+        self.init_latent = self.init_latent_all[lo:lo + self.batch_size].contiguous()
+        if self.latent_mask is not None:
+            self.mask = self.latent_mask[lo:lo + self.batch_size].float().contiguous()
+            self.nmask = (1.0 - self.mask).contiguous()
+        x = self.rng.next()
+        self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
+        samples = self.sampler.sample_img2img(self, self.init_latent, x, conditioning, unconditional_conditioning,
+                                              image_conditioning=None)
+        if self.mask is not None:
+            samples = samples * self.nmask + self.init_latent * self.mask      # :1776-1784 final blend
+        return samples
+
+
+class Processed:
+    """modules/processing.py:516-613 (fields the callers on this path read)."""
+
+    def __init__(self, p, images_list, seed=-1, all_seeds=None, latents=None):
+        self.images = images_list
+        self.seed = seed
+        self.all_seeds = all_seeds or [seed]
+        self.width, self.height = p.width, p.height
+        self.sampler_name, self.cfg_scale, self.steps = p.sampler_name, p.cfg_scale, p.steps
+        self.batch_size = p.batch_size
+        self.latents = latents
+
+
+def decode_latent_batch(model, batch, target_device=None, check_for_nans=False):
+    """modules/processing.py:625-672.  The reference decodes one image at a time; the engine decodes the whole batch in
+    one batched pass (same per-image arithmetic, images are independent)."""
+    if check_for_nans and bool(torch.isnan(batch).all()):
+        raise RuntimeError("A tensor with all NaNs was produced in Unet.")
+    out = model.decode_first_stage(batch)
+    if target_device is not None:
+        out = out.to(target_device)
+    return out
+
+
+def process_images(p: StableDiffusionProcessing) -> Processed:
+    """modules/processing.py:819-1150 (process_images -> process_images_inner) for the engine path."""
+    assert p.c is not None and p.uc is not None, "conditioning tensors p.c / p.uc are required (text encoder is out of scope)"
+    n_total = p.batch_size * p.n_iter
+    seed = int(p.seed) if p.seed is not None and p.seed != -1 else 1000
+    p.all_seeds = [seed + i for i in range(n_total)]                 # :901-909
+    p.init(None, p.all_seeds, None)
+    images, latents = [], []
+    dev = p.sd_model.device
+    for n in range(p.n_iter):
+        p.iteration = n
+        lo, hi = n * p.batch_size, (n + 1) * p.batch_size
+        p.seeds = p.all_seeds[lo:hi]
+        p.rng = ImageRNG((opt_C, p.height // opt_f, p.width // opt_f), p.seeds,
+                         seed_resize_from_h=p.seed_resize_from_h, seed_resize_from_w=p.seed_resize_from_w,
+                         eta_noise_seed_delta=shared.opts.eta_noise_seed_delta, device=dev)      # :949
+        c = p.c[lo:hi].to(dev)
+        uc = p.uc[lo:hi].to(dev)
+        if p.y is not None:
+            p_y_all, p_uy_all = p.y, p.uy
+            p.y, p.uy = p_y_all[lo:hi].to(dev), p_uy_all[lo:hi].to(dev)
+        samples = p.sample(conditioning=c, unconditional_conditioning=uc, seeds=p.seeds, subseeds=None,
+                           subseed_strength=0, prompts=None)                                      # :987-988
+        if p.y is not None:
+            p.y, p.uy = p_y_all, p_uy_all
+        x_samples = decode_latent_batch(p.sd_model, samples, check_for_nans=False)               # :1002
+        u8 = ops.image_to_u8(x_samples)                                                           # :1004-1005, 1034-1035
+        images.extend(list(u8.cpu().numpy()))
+        if p.keep_latents:
+            latents.append(samples)
+    p.close()
+    return Processed(p, images, seed, p.all_seeds, torch.cat(latents) if latents else None)

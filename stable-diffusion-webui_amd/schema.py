@@ -66,6 +66,20 @@ def sdxl_unet() -> UNetConfig:
                       adm_in_channels=2816)
 
 
+def tiny_unet(**kw) -> UNetConfig:
+    """Small SD-shaped UNet for tests / smoke (channels multiples of 64, head size 64 so the MFMA kernels are used)."""
+    base = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(1, 2), num_heads=-1,
+                num_head_channels=64, transformer_depth=1, context_dim=64)
+    base.update(kw)
+    return UNetConfig(**base)
+
+
+def tiny_vae(**kw) -> VAEConfig:
+    base = dict(ch=64, ch_mult=(1, 2), num_res_blocks=1)
+    base.update(kw)
+    return VAEConfig(**base)
+
+
 def sd15_vae() -> VAEConfig:
     return VAEConfig()
 

@@ -1,0 +1,83 @@
+"""Checkpoint -> engine.  Keeps the reference's loader contract: a flat state dict keyed ``model.diffusion_model.*``,
+``first_stage_model.*`` (modules/sd_models.py:312-329 read_state_dict, :262-281 key fix-ups, :392/:452-454 prefixes) is
+the weight source; the engine consumes it tensor by tensor (sdmi_unet_load_tensor / sdmi_vae_load_tensor).
+
+``SdModel`` is the slice of the reference's ``shared.sd_model`` object the hot path touches: ``alphas_cumprod``,
+``parameterization``, ``is_sdxl``, ``decode_first_stage`` / ``encode_first_stage`` / ``get_first_stage_encoding``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+from . import schema
+from .engine import Engine
+
+
+def read_state_dict(checkpoint_file: str, map_location="cpu") -> dict:
+    """modules/sd_models.py:312-329: .safetensors via safetensors, anything else via torch.load (weights_only)."""
+    _, ext = os.path.splitext(checkpoint_file)
+    if ext.lower() == ".safetensors":
+        import safetensors.torch
+        sd = safetensors.torch.load_file(checkpoint_file, device=map_location)
+    else:
+        sd = torch.load(checkpoint_file, map_location=map_location, weights_only=True)
+    sd = sd.pop("state_dict", sd)
+    sd.pop("state_dict", None)
+    return sd
+
+
+def guess_unet_config(sd: dict) -> schema.UNetConfig:
+    """modules/sd_models_config.py:72-115 reduced to the two families on the path: SDXL is recognised by the
+    conditioner / label_emb keys, everything else with a 768-wide attn2.to_k is SD1.x."""
+    if schema.UNET_PREFIX + "label_emb.0.0.weight" in sd:
+        return schema.sdxl_unet()
+    return schema.sd15_unet()
+
+
+class SdModel:
+    def __init__(self, state_dict: dict, unet_cfg: Optional[schema.UNetConfig] = None,
+                 vae_cfg: Optional[schema.VAEConfig] = None, device: int = 0, load_vae: bool = True,
+                 vae_decoder_only: bool = False):
+        self.unet_cfg = unet_cfg or guess_unet_config(state_dict)
+        self.is_sdxl = self.unet_cfg.adm_in_channels is not None
+        self.vae_cfg = vae_cfg or (schema.sdxl_vae() if self.is_sdxl else schema.sd15_vae())
+        self.parameterization = "eps"
+        self.device = torch.device("cuda", device)
+        ac = state_dict.get("alphas_cumprod")
+        self.alphas_cumprod = (ac.float().cpu() if ac is not None else schema.make_alphas_cumprod())
+        self.engine = Engine(device)
+        self.engine.load_unet(self.unet_cfg, state_dict)
+        self.has_vae = False
+        if load_vae and any(k.startswith(schema.VAE_PREFIX) for k in state_dict):
+            self.engine.load_vae(self.vae_cfg, state_dict, decoder_only=vae_decoder_only)
+            self.has_vae = True
+        self.scale_factor = self.vae_cfg.scale_factor
+
+    # --- the methods the reference calls on shared.sd_model around the sampler -----------------------------------
+    def decode_first_stage(self, z: torch.Tensor) -> torch.Tensor:
+        """LatentDiffusion.decode_first_stage: image in [-1, 1], fp32 NCHW (whole batch in one pass)."""
+        return self.engine.vae_decode(z)
+
+    def encode_first_stage(self, x: torch.Tensor) -> torch.Tensor:
+        """Returns the posterior moments (mean | logvar), as AutoencoderKL.encode's DiagonalGaussianDistribution holds."""
+        return self.engine.vae_encode_moments(x)
+
+    def get_first_stage_encoding(self, moments: torch.Tensor, sample: bool = False, generator=None) -> torch.Tensor:
+        """scale_factor * (mean [+ std * eps]); the reference samples (sd3_impls.py:369-374 twin), the measurement plan
+        uses the mean for determinism."""
+        mean, logvar = torch.chunk(moments, 2, dim=1)
+        if not sample:
+            return (mean * self.scale_factor).contiguous()
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        eps = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
+        return ((mean + std * eps) * self.scale_factor).contiguous()
+
+
+def load_model(checkpoint_file: Optional[str] = None, state_dict: Optional[dict] = None, device: int = 0, **kw) -> SdModel:
+    """modules/sd_models.py:786 load_model, reduced to what feeds the engine."""
+    if state_dict is None:
+        state_dict = read_state_dict(checkpoint_file)
+    return SdModel(state_dict, device=device, **kw)

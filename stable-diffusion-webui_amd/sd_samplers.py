@@ -1,0 +1,609 @@
+"""Sampler layer of the engine: mirrors the reference's sampler interface (boundary B3) while running every piece of
+per-step tensor arithmetic in fused HIP kernels.
+
+Reference interface mirrored (same names, argument meaning and error behaviour):
+  modules/sd_samplers_common.py:11-19   SamplerData(name, constructor, aliases, options)
+  modules/sd_samplers_common.py:229-355 Sampler (callback_state, launch_sampling, initialize, sample, sample_img2img)
+  modules/sd_samplers.py:11-44          all_samplers / all_samplers_map / create_sampler
+  modules/sd_samplers_kdiffusion.py:68-236  KDiffusionSampler.get_sigmas / sample / sample_img2img
+  modules/sd_samplers_timesteps.py:75-163   CompVisSampler (DDIM)
+  modules/sd_samplers_cfg_denoiser.py:156-311  CFGDenoiser.forward (fast path: one cond of weight 1 per image,
+        equal cond/uncond token counts, batch_cond_uncond on, no cfg_denoiser callbacks; mask blend supported)
+Sampler math: k-diffusion@ab527a9 sample_euler_ancestral / sample_euler / sample_dpmpp_2m, DiscreteSchedule,
+CompVisDenoiser (third-party, restated from its published algorithm; call sites sd_samplers_kdiffusion.py:11-27,53-64)
+and in-repo DDIM (modules/sd_samplers_timesteps_impl.py:12-40).  Host-side scalars (sigmas, ancestral step sizes,
+DPM++ coefficients, DDIM alpha tables) are computed with the same torch-CPU fp32 / float64 expressions as the
+reference so they round identically; the tensors never leave the GPU.
+"""
+from __future__ import annotations
+
+import inspect
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import _lib, shared
+from ._lib import lib, check, ptr, stream_ptr
+from .schema import make_alphas_cumprod
+
+SamplerDataTuple = namedtuple('SamplerData', ['name', 'constructor', 'aliases', 'options'])
+
+
+class SamplerData(SamplerDataTuple):
+    def total_steps(self, steps):
+        if self.options.get("second_order", False):
+            steps = steps * 2
+        return steps
+
+
+class InterruptedException(BaseException):
+    pass
+
+
+def setup_img2img_steps(p, steps=None):
+    """modules/sd_samplers_common.py:22-31"""
+    if shared.opts.img2img_fix_steps or steps is not None:
+        requested_steps = (steps or p.steps)
+        steps = int(requested_steps / min(p.denoising_strength, 0.999)) if p.denoising_strength > 0 else 0
+        t_enc = requested_steps - 1
+    else:
+        steps = p.steps
+        t_enc = int(min(p.denoising_strength, 0.999) * steps)
+    return steps, t_enc
+
+
+# ------------------------------------------------------------------------------------------------------------
+# schedule (host side, CPU fp32 tensors like the reference keeps them: sd_samplers_kdiffusion.py:132)
+# ------------------------------------------------------------------------------------------------------------
+def append_zero(x):
+    return torch.cat([x, x.new_zeros([1])])
+
+
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7., device='cpu'):
+    ramp = torch.linspace(0, 1, n)
+    min_inv_rho = sigma_min ** (1 / rho)
+    max_inv_rho = sigma_max ** (1 / rho)
+    sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    return append_zero(sigmas).to(device)
+
+
+def get_sigmas_exponential(n, sigma_min, sigma_max, device='cpu'):
+    sigmas = torch.linspace(np.log(sigma_max), np.log(sigma_min), n, device=device).exp()
+    return append_zero(sigmas)
+
+
+class DiscreteSchedule:
+    """k-diffusion external.DiscreteSchedule on CPU tensors."""
+
+    def __init__(self, sigmas, quantize=False):
+        self.sigmas = sigmas
+        self.log_sigmas = sigmas.log()
+        self.quantize = quantize
+
+    @property
+    def sigma_min(self):
+        return self.sigmas[0]
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def get_sigmas(self, n=None):
+        if n is None:
+            return append_zero(self.sigmas.flip(0))
+        t_max = len(self.sigmas) - 1
+        t = torch.linspace(t_max, 0, n)
+        return append_zero(self.t_to_sigma(t))
+
+    def sigma_to_t(self, sigma, quantize=None):
+        quantize = self.quantize if quantize is None else quantize
+        log_sigma = sigma.log()
+        dists = log_sigma - self.log_sigmas[:, None]
+        if quantize:
+            return dists.abs().argmin(dim=0).view(sigma.shape)
+        low_idx = dists.ge(0).cumsum(dim=0).argmax(dim=0).clamp(max=self.log_sigmas.shape[0] - 2)
+        high_idx = low_idx + 1
+        low, high = self.log_sigmas[low_idx], self.log_sigmas[high_idx]
+        w = (low - log_sigma) / (low - high)
+        w = w.clamp(0, 1)
+        t = (1 - w) * low_idx + w * high_idx
+        return t.view(sigma.shape)
+
+    def t_to_sigma(self, t):
+        t = t.float()
+        low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
+        log_sigma = (1 - w) * self.log_sigmas[low_idx] + w * self.log_sigmas[high_idx]
+        return log_sigma.exp()
+
+
+class CompVisDenoiser(DiscreteSchedule):
+    """Schedule + scalings of k-diffusion's CompVisDenoiser; the forward itself is fused in CFGDenoiser below."""
+
+    def __init__(self, sd_model, quantize=False):
+        ac = sd_model.alphas_cumprod.float().cpu()
+        super().__init__(((1 - ac) / ac) ** 0.5, quantize)
+        self.inner_model = sd_model
+        self.sigma_data = 1.
+
+    def get_scalings(self, sigma):
+        c_out = -sigma
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_out, c_in
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CFG denoiser (fused)
+# ------------------------------------------------------------------------------------------------------------
+class CFGDenoiser:
+    """Classifier-free-guidance denoiser with the arithmetic of modules/sd_samplers_cfg_denoiser.py:156-311 fused into
+    three launches per step: build x_in = [x*c_in | x*c_in], whole-UNet forward on 2B images, combine.
+
+    ``mode`` 0: sigma space (k-diffusion samplers; returns denoised), 1: timestep space (DDIM; returns eps).
+    Unsupported reference features raise instead of being silently ignored: AND-composition / per-step prompt
+    schedules, differing cond/uncond lengths, skip-uncond (s_min_uncond, skip_early_cond), edit models.
+    """
+
+    def __init__(self, sampler, mode=0):
+        self.sampler = sampler
+        self.mode = mode
+        self.model_wrap = None
+        self.mask = None
+        self.nmask = None
+        self.init_latent = None
+        self.steps = None
+        self.total_steps = None
+        self.step = 0
+        self.image_cfg_scale = None
+        self.padded_cond_uncond = False
+        self.padded_cond_uncond_v0 = False
+        self.p = None
+        self.cond_scale_miltiplier = 1.0
+        self.mask_before_denoising = mode == 1          # CFGDenoiserTimesteps sets this (sd_samplers_timesteps.py:54)
+        self._ctx_key = None
+        self._x_in = None
+
+    @property
+    def inner_model(self):
+        if self.model_wrap is None:
+            self.model_wrap = CompVisDenoiser(self.sampler.sd_model, quantize=shared.opts.enable_quantization)
+        return self.model_wrap
+
+    def _ensure_context(self, cond, uncond):
+        key = (cond.data_ptr(), uncond.data_ptr(), tuple(cond.shape), tuple(uncond.shape), cond._version, uncond._version)
+        if key != self._ctx_key:
+            if cond.shape[1] != uncond.shape[1]:
+                raise NotImplementedError("cond / uncond token counts differ: use pad_cond_uncond or the torch path")
+            ctx = torch.cat([cond, uncond]).float().contiguous()
+            self.sampler.sd_model.engine.set_context(ctx)
+            self._ctx_key = key
+
+    def forward(self, x, sigma, uncond, cond, cond_scale, s_min_uncond=0.0, image_cond=None, y=None, uy=None):
+        if shared.state.interrupted or shared.state.skipped:
+            raise InterruptedException
+        if s_min_uncond and s_min_uncond > 0:
+            raise NotImplementedError("s_min_uncond (skip-uncond) is not implemented in the fused CFG path")
+        eng = self.sampler.sd_model.engine
+        b, c, h, w = x.shape
+        chw = c * h * w
+        if self.mask_before_denoising and self.mask is not None:
+            raise NotImplementedError("inpainting masks with timestep samplers (DDIM) are not implemented in the engine")
+        self._ensure_context(cond, uncond)
+        if self._x_in is None or self._x_in.shape[0] != 2 * b or self._x_in.shape[2:] != x.shape[2:]:
+            self._x_in = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
+            self._eps = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
+        sig = float(sigma[0])
+        if self.mode == 0:
+            wrap = self.inner_model
+            sig_t = torch.tensor(sig, dtype=torch.float32)
+            c_out, c_in = wrap.get_scalings(sig_t)
+            t = wrap.sigma_to_t(sig_t.reshape(1))[0]
+            c_in_t = torch.full((b,), float(c_in), dtype=torch.float32, device=x.device)
+            c_out_t = torch.full((b,), float(c_out), dtype=torch.float32, device=x.device)
+            check(lib.sdmi_cfg_prepare_input(ptr(x), ptr(c_in_t), ptr(self._x_in), _lib.F32, b, 2, chw, stream_ptr()), "cfg_prepare")
+            ts = torch.full((2 * b,), float(t), dtype=torch.float32, device=x.device)
+        else:
+            c_out_t = None
+            check(lib.sdmi_cfg_prepare_input(ptr(x), None, ptr(self._x_in), _lib.F32, b, 2, chw, stream_ptr()), "cfg_prepare")
+            ts = torch.full((2 * b,), sig, dtype=torch.float32, device=x.device)
+        yy = None
+        if y is not None:
+            yy = torch.cat([y, uy]).float().contiguous()
+        eng.unet_forward(self._x_in, ts, None, yy, out=self._eps)
+        den = torch.empty_like(x)
+        use_mask = (not self.mask_before_denoising) and self.mask is not None
+        check(lib.sdmi_cfg_combine(ptr(x), ptr(self._eps), ptr(c_out_t), float(cond_scale * self.cond_scale_miltiplier), self.mode,
+                                   ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
+                                   ptr(self.init_latent) if use_mask else None, ptr(den), b, chw, stream_ptr()), "cfg_combine")
+        self.sampler.last_latent = den
+        self.step += 1
+        return den
+
+    __call__ = forward
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sampler functions (k-diffusion signatures: func(model, x, sigmas, extra_args, callback, disable, **kw))
+# ------------------------------------------------------------------------------------------------------------
+def get_ancestral_step(sigma_from, sigma_to, eta=1.):
+    if not eta:
+        return sigma_to, 0.
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1.,
+                           noise_sampler=None):
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        noise = noise_sampler(sigmas[i], sigmas[i + 1]) if sigmas[i + 1] > 0 else None
+        check(lib.sdmi_euler_step(ptr(x), ptr(denoised), ptr(noise), float(sigmas[i]), float(sigma_down), float(sigma_up),
+                                  float(s_noise), x.numel(), stream_ptr()), "euler_step")
+    return x
+
+
+def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0.,
+                 s_tmax=float('inf'), s_noise=1.):
+    if s_churn:
+        raise NotImplementedError("s_churn > 0 is not implemented (reference default 0.0)")
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        check(lib.sdmi_euler_step(ptr(x), ptr(denoised), None, float(sigmas[i]), float(sigmas[i + 1]), 0.0, 0.0, x.numel(),
+                                  stream_ptr()), "euler_step")
+    return x
+
+
+def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None, disable=None):
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda sigma: sigma.log().neg()
+    old_denoised = None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        h = t_next - t
+        ratio = sigma_fn(t_next) / sigma_fn(t)
+        em1 = (-h).expm1()
+        if old_denoised is None or sigmas[i + 1] == 0:
+            check(lib.sdmi_dpmpp2m_step(ptr(x), ptr(denoised), None, float(ratio), float(em1), 1.0, 0.0, x.numel(), stream_ptr()),
+                  "dpmpp2m_step")
+        else:
+            h_last = t - t_fn(sigmas[i - 1])
+            r = h_last / h
+            c1, c2 = (1 + 1 / (2 * r)), (1 / (2 * r))
+            check(lib.sdmi_dpmpp2m_step(ptr(x), ptr(denoised), ptr(old_denoised), float(ratio), float(em1), float(c1), float(c2),
+                                        x.numel(), stream_ptr()), "dpmpp2m_step")
+        old_denoised = denoised
+    return x
+
+
+def ddim(model, x, timesteps, extra_args=None, callback=None, disable=None, eta=0.0, noise_sampler=None):
+    """modules/sd_samplers_timesteps_impl.py:12-40 (alphas_prev in float64 at :15, per-step coefficients fp32)."""
+    alphas_cumprod = model.inner_model.inner_model.alphas_cumprod.float().cpu()
+    timesteps = timesteps.cpu()
+    alphas = alphas_cumprod[timesteps]
+    alphas_prev = alphas_cumprod[torch.nn.functional.pad(timesteps[:-1], pad=(1, 0))].to(torch.float64)
+    sqrt_one_minus_alphas = torch.sqrt(1 - alphas)
+    sigmas = eta * np.sqrt((1 - alphas_prev.numpy()) / (1 - alphas) * (1 - alphas / alphas_prev.numpy()))
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones((x.shape[0]))
+    f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))      # python-scalar * fp32 tensor => fp32 (see kernel)
+    for i in range(len(timesteps) - 1):
+        index = len(timesteps) - 1 - i
+        e_t = model(x, timesteps[index].item() * s_in, **extra_args)
+        noise = noise_sampler() if noise_sampler is not None else None
+        pred_x0 = torch.empty_like(x) if callback is not None else None
+        check(lib.sdmi_ddim_step(ptr(x), ptr(e_t), ptr(noise), ptr(pred_x0), f32(alphas[index].item()),
+                                 f32(alphas_prev[index].item()), f32(sigmas[index].item()),
+                                 f32(sqrt_one_minus_alphas[index].item()), x.numel(), stream_ptr()), "ddim_step")
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': 0, 'sigma_hat': 0, 'denoised': pred_x0})
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Sampler classes
+# ------------------------------------------------------------------------------------------------------------
+class Sampler:
+    def __init__(self, funcname, sd_model):
+        self.funcname = funcname
+        self.func = funcname
+        self.sd_model = sd_model
+        self.extra_params = []
+        self.stop_at = None
+        self.eta = None
+        self.config: SamplerData = None
+        self.last_latent = None
+        self.s_min_uncond = None
+        self.s_churn = 0.0
+        self.s_tmin = 0.0
+        self.s_tmax = float('inf')
+        self.s_noise = 1.0
+        self.eta_option_field = 'eta_ancestral'
+        self.eta_default = 1.0
+        self.p = None
+        self.model_wrap_cfg = None
+        self.sampler_extra_args = None
+        self.options = {}
+
+    def callback_state(self, d):
+        step = d['i']
+        if self.stop_at is not None and step > self.stop_at:
+            raise InterruptedException
+        shared.state.sampling_step = step
+
+    def launch_sampling(self, steps, func):
+        self.model_wrap_cfg.steps = steps
+        self.model_wrap_cfg.total_steps = self.config.total_steps(steps) if self.config else steps
+        shared.state.sampling_steps = steps
+        shared.state.sampling_step = 0
+        try:
+            return func()
+        except InterruptedException:
+            return self.last_latent
+
+    def initialize(self, p) -> dict:
+        self.p = p
+        self.model_wrap_cfg.p = p
+        self.model_wrap_cfg.mask = p.mask if hasattr(p, 'mask') else None
+        self.model_wrap_cfg.nmask = p.nmask if hasattr(p, 'nmask') else None
+        self.model_wrap_cfg.step = 0
+        self.model_wrap_cfg.image_cfg_scale = getattr(p, 'image_cfg_scale', None)
+        self.eta = p.eta if p.eta is not None else getattr(shared.opts, self.eta_option_field, 0.0)
+        self.s_min_uncond = getattr(p, 's_min_uncond', 0.0)
+        extra_params_kwargs = {}
+        params = inspect.signature(self.func).parameters
+        for param_name in self.extra_params:
+            if hasattr(p, param_name) and param_name in params:
+                extra_params_kwargs[param_name] = getattr(p, param_name)
+        if 'eta' in params:
+            extra_params_kwargs['eta'] = self.eta
+        if 'noise_sampler' in params:
+            rng = p.rng                                   # TorchHijack.randn_like -> p.rng.next() (common.py:205-226)
+            extra_params_kwargs['noise_sampler'] = (lambda *a: rng.next())
+        return extra_params_kwargs
+
+    def sample(self, p, x, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        raise NotImplementedError()
+
+    def sample_img2img(self, p, x, noise, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        raise NotImplementedError()
+
+
+samplers_k_diffusion = [
+    ('DPM++ 2M', sample_dpmpp_2m, ['k_dpmpp_2m'], {'scheduler': 'karras'}),
+    ('Euler a', sample_euler_ancestral, ['k_euler_a', 'k_euler_ancestral'], {"uses_ensd": True}),
+    ('Euler', sample_euler, ['k_euler'], {}),
+]
+sampler_extra_params = {
+    'sample_euler': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
+}
+schedulers_map = {
+    'automatic': None, 'Automatic': None,
+    'uniform': 'uniform', 'Uniform': 'uniform',
+    'karras': 'karras', 'Karras': 'karras',
+    'exponential': 'exponential', 'Exponential': 'exponential',
+}
+
+
+class KDiffusionSampler(Sampler):
+    def __init__(self, func, sd_model, options=None):
+        super().__init__(func.__name__, sd_model)
+        self.func = func
+        self.extra_params = sampler_extra_params.get(func.__name__, [])
+        self.options = options or {}
+        self.model_wrap_cfg = CFGDenoiser(self, mode=0)
+        self.model_wrap = self.model_wrap_cfg.inner_model
+
+    def get_sigmas(self, p, steps):
+        """modules/sd_samplers_kdiffusion.py:79-132"""
+        opts = shared.opts
+        discard_next_to_last_sigma = self.config is not None and self.config.options.get('discard_next_to_last_sigma', False)
+        if opts.always_discard_next_to_last_sigma and not discard_next_to_last_sigma:
+            discard_next_to_last_sigma = True
+        steps += 1 if discard_next_to_last_sigma else 0
+        scheduler_name = (getattr(p, 'hr_scheduler', None) if getattr(p, 'is_hr_pass', False) else getattr(p, 'scheduler', None)) or 'Automatic'
+        if scheduler_name not in schedulers_map:
+            raise NotImplementedError(f"scheduler {scheduler_name!r} is not implemented in the engine")
+        sched = schedulers_map[scheduler_name]
+        if sched is None:
+            sched = self.config.options.get('scheduler', None) if self.config is not None else None
+        m_sigma_min, m_sigma_max = self.model_wrap.sigmas[0].item(), self.model_wrap.sigmas[-1].item()
+        sigma_min, sigma_max = (0.1, 10) if opts.use_old_karras_scheduler_sigmas else (m_sigma_min, m_sigma_max)
+        if getattr(p, 'sampler_noise_scheduler_override', None):
+            sigmas = p.sampler_noise_scheduler_override(steps)
+        elif sched is None:
+            sigmas = self.model_wrap.get_sigmas(steps)
+        else:
+            kwargs = {'sigma_min': sigma_min, 'sigma_max': sigma_max}
+            if opts.sigma_min != 0 and opts.sigma_min != m_sigma_min:
+                kwargs['sigma_min'] = opts.sigma_min
+            if opts.sigma_max != 0 and opts.sigma_max != m_sigma_max:
+                kwargs['sigma_max'] = opts.sigma_max
+            if sched == 'karras':
+                if opts.rho != 0 and opts.rho != 7.0:
+                    kwargs['rho'] = opts.rho
+                sigmas = get_sigmas_karras(n=steps, **kwargs, device='cpu')
+            elif sched == 'exponential':
+                sigmas = get_sigmas_exponential(n=steps, **kwargs, device='cpu')
+            else:
+                sigmas = self.model_wrap.get_sigmas(steps)
+        if discard_next_to_last_sigma:
+            sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
+        return sigmas.cpu()
+
+    def _extra(self, p, conditioning, unconditional_conditioning, image_conditioning):
+        self.sampler_extra_args = {
+            'cond': conditioning,
+            'image_cond': image_conditioning,
+            'uncond': unconditional_conditioning,
+            'cond_scale': p.cfg_scale,
+            's_min_uncond': self.s_min_uncond,
+        }
+        if getattr(p, 'y', None) is not None:
+            self.sampler_extra_args['y'] = p.y
+            self.sampler_extra_args['uy'] = p.uy
+        return self.sampler_extra_args
+
+    def sample_img2img(self, p, x, noise, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        steps, t_enc = setup_img2img_steps(p, steps)
+        sigmas = self.get_sigmas(p, steps)
+        sigma_sched = sigmas[steps - t_enc - 1:]
+        xi = torch.empty_like(x)
+        check(lib.sdmi_axpby(ptr(xi), ptr(x.contiguous()), 1.0, ptr(noise.contiguous()), float(sigma_sched[0]), x.numel(),
+                             stream_ptr()), "x + noise*sigma")
+        if shared.opts.img2img_extra_noise > 0:
+            raise NotImplementedError("img2img_extra_noise")
+        extra_params_kwargs = self.initialize(p)
+        parameters = inspect.signature(self.func).parameters
+        if 'sigmas' in parameters:
+            extra_params_kwargs['sigmas'] = sigma_sched
+        self.model_wrap_cfg.init_latent = x
+        self.last_latent = x
+        extra = self._extra(p, conditioning, unconditional_conditioning, image_conditioning)
+        return self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=extra, disable=False,
+                                                                  callback=self.callback_state, **extra_params_kwargs))
+
+    def sample(self, p, x, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        steps = steps or p.steps
+        sigmas = self.get_sigmas(p, steps)
+        x0 = torch.empty_like(x)
+        if shared.opts.sgm_noise_multiplier:
+            mult = float(torch.sqrt(1.0 + sigmas[0] ** 2.0))
+        else:
+            mult = float(sigmas[0])
+        check(lib.sdmi_axpby(ptr(x0), ptr(x.contiguous()), mult, None, 0.0, x.numel(), stream_ptr()), "x * sigmas[0]")
+        extra_params_kwargs = self.initialize(p)
+        parameters = inspect.signature(self.func).parameters
+        if 'sigmas' in parameters:
+            extra_params_kwargs['sigmas'] = sigmas
+        self.last_latent = x0
+        extra = self._extra(p, conditioning, unconditional_conditioning, image_conditioning)
+        return self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,
+                                                              callback=self.callback_state, **extra_params_kwargs))
+
+
+class _TimestepsInner:
+    """model.inner_model.inner_model.alphas_cumprod chain the reference's ddim() dereferences (impl.py:13)."""
+    def __init__(self, sd_model):
+        self.inner_model = sd_model
+
+
+class CFGDenoiserTimesteps(CFGDenoiser):
+    def __init__(self, sampler):
+        super().__init__(sampler, mode=1)
+
+    @property
+    def inner_model(self):
+        if self.model_wrap is None:
+            self.model_wrap = _TimestepsInner(self.sampler.sd_model)
+        return self.model_wrap
+
+
+class CompVisSampler(Sampler):
+    """modules/sd_samplers_timesteps.py:75-163 (DDIM only)."""
+
+    def __init__(self, func, sd_model):
+        super().__init__(func.__name__, sd_model)
+        self.func = func
+        self.eta_option_field = 'eta_ddim'
+        self.eta_default = 0.0
+        self.model_wrap_cfg = CFGDenoiserTimesteps(self)
+        self.model_wrap = self.model_wrap_cfg.inner_model
+
+    def get_timesteps(self, p, steps):
+        discard = self.config is not None and self.config.options.get('discard_next_to_last_sigma', False)
+        if shared.opts.always_discard_next_to_last_sigma and not discard:
+            discard = True
+        steps += 1 if discard else 0
+        return torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+
+    def initialize(self, p):
+        kw = super().initialize(p)
+        if 'noise_sampler' in inspect.signature(self.func).parameters:
+            rng = p.rng
+            kw['noise_sampler'] = (lambda *a: rng.next())
+        return kw
+
+    def sample(self, p, x, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        steps = steps or p.steps
+        timesteps = self.get_timesteps(p, steps)
+        extra_params_kwargs = self.initialize(p)
+        extra_params_kwargs['timesteps'] = timesteps
+        self.last_latent = x
+        self.sampler_extra_args = {'cond': conditioning, 'image_cond': image_conditioning,
+                                   'uncond': unconditional_conditioning, 'cond_scale': p.cfg_scale,
+                                   's_min_uncond': self.s_min_uncond}
+        extra = self.sampler_extra_args
+        x0 = x.clone()
+        return self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,
+                                                              callback=self.callback_state, **extra_params_kwargs))
+
+    def sample_img2img(self, p, x, noise, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        steps, t_enc = setup_img2img_steps(p, steps)
+        timesteps = self.get_timesteps(p, steps)
+        timesteps_sched = timesteps[:t_enc]
+        ac = self.sd_model.alphas_cumprod.float().cpu()
+        sqrt_alpha_cumprod = torch.sqrt(ac[timesteps[t_enc]])
+        sqrt_one_minus_alpha_cumprod = torch.sqrt(1 - ac[timesteps[t_enc]])
+        xi = torch.empty_like(x)
+        check(lib.sdmi_axpby(ptr(xi), ptr(x.contiguous()), float(sqrt_alpha_cumprod), ptr(noise.contiguous()),
+                             float(sqrt_one_minus_alpha_cumprod), x.numel(), stream_ptr()), "ddim img2img noise")
+        extra_params_kwargs = self.initialize(p)
+        extra_params_kwargs['timesteps'] = timesteps_sched
+        self.model_wrap_cfg.init_latent = x
+        self.last_latent = x
+        self.sampler_extra_args = {'cond': conditioning, 'image_cond': image_conditioning,
+                                   'uncond': unconditional_conditioning, 'cond_scale': p.cfg_scale,
+                                   's_min_uncond': self.s_min_uncond}
+        extra = self.sampler_extra_args
+        return self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=extra, disable=False,
+                                                                  callback=self.callback_state, **extra_params_kwargs))
+
+
+samplers_data_k_diffusion = [
+    SamplerData(label, lambda model, func=func: KDiffusionSampler(func, model), aliases, options)
+    for label, func, aliases, options in samplers_k_diffusion
+]
+samplers_data_timesteps = [
+    SamplerData('DDIM', lambda model: CompVisSampler(ddim, model), [], {}),
+]
+all_samplers = [*samplers_data_k_diffusion, *samplers_data_timesteps]
+all_samplers_map = {x.name: x for x in all_samplers}
+samplers_map = {}
+for _s in all_samplers:
+    samplers_map[_s.name.lower()] = _s.name
+    for _a in _s.aliases:
+        samplers_map[_a.lower()] = _s.name
+
+
+def find_sampler_config(name):
+    if name is not None:
+        return all_samplers_map.get(name, None) or all_samplers_map.get(samplers_map.get(str(name).lower(), ""), None)
+    return all_samplers[0]
+
+
+def create_sampler(name, model):
+    """modules/sd_samplers.py:33-44"""
+    config = find_sampler_config(name)
+    assert config is not None, f'bad sampler name: {name}'
+    sampler = config.constructor(model)
+    sampler.config = config
+    return sampler

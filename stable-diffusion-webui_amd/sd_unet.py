@@ -1,0 +1,86 @@
+"""Boundary B1: the engine as an ``SdUnet`` (modules/sd_unet.py:63-93).
+
+Inside the webui, ``Mi355xUnetOption`` is appended by an ``on_list_unets`` callback
+(modules/script_callbacks.py:602-606); ``apply_unet`` (modules/sd_unet.py:33-60) then calls ``create_unet()`` /
+``activate()`` and the patched ``UNetModel.forward`` (modules/sd_unet.py:86-93) routes every UNet call to
+``Mi355xUnet.forward(x, timesteps, context, *args, **kwargs)``.  Standalone, the same classes derive from local stand-ins.
+"""
+from __future__ import annotations
+
+import torch
+
+try:                                            # inside the webui: subclass the real plugin base classes
+    from modules import sd_unet as _ref_sd_unet
+    SdUnetOption, SdUnet = _ref_sd_unet.SdUnetOption, _ref_sd_unet.SdUnet
+except Exception:                               # standalone: same interface (modules/sd_unet.py:63-83)
+    class SdUnetOption:
+        model_name = None
+        label = None
+
+        def create_unet(self):
+            raise NotImplementedError()
+
+    class SdUnet(torch.nn.Module):
+        def forward(self, x, timesteps, context, *args, **kwargs):
+            raise NotImplementedError()
+
+        def activate(self):
+            pass
+
+        def deactivate(self):
+            pass
+
+
+class Mi355xUnet(SdUnet):
+    """forward(x, timesteps, context, y=None): x [2B,C,h,w] in dtype_unet already scaled by c_in, timesteps [2B],
+    context [2B,77k,ctx_dim]; returns eps [2B,4,h,w] in x.dtype on x.device (modules/sd_hijack_unet.py:40-54 contract)."""
+
+    def __init__(self, state_dict_provider, unet_cfg=None, device_index: int = 0):
+        super().__init__()
+        self._provider = state_dict_provider
+        self._cfg = unet_cfg
+        self._device_index = device_index
+        self.engine = None
+        self._ctx_key = None
+
+    def activate(self):
+        from . import schema
+        from .engine import Engine
+        sd = self._provider()
+        cfg = self._cfg
+        if cfg is None:
+            from .sd_models import guess_unet_config
+            cfg = guess_unet_config(sd)
+        self.engine = Engine(self._device_index)
+        self.engine.load_unet(cfg, sd, prefix=schema.UNET_PREFIX)
+
+    def deactivate(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+    def forward(self, x, timesteps, context, *args, **kwargs):
+        if kwargs.get("control") is not None or args:
+            raise NotImplementedError("extra UNet inputs (ControlNet residuals etc.) are not supported by the engine UNet")
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        y = kwargs.get("y", None)
+        # context is step-invariant unless prompt editing swaps it: re-project only when the tensor changes
+        key = (context.data_ptr(), tuple(context.shape), context._version, context.dtype)
+        ctx = None
+        if key != self._ctx_key:
+            ctx = context.to(x.dtype)
+            self._ctx_key = key
+        return self.engine.unet_forward(x, timesteps, ctx, y)
+
+
+class Mi355xUnetOption(SdUnetOption):
+    def __init__(self, model_name, state_dict_provider, unet_cfg=None, device_index=0):
+        self.model_name = model_name
+        self.label = f"[MI355X] {model_name}"
+        self._provider = state_dict_provider
+        self._cfg = unet_cfg
+        self._device_index = device_index
+
+    def create_unet(self):
+        return Mi355xUnet(self._provider, self._cfg, self._device_index)

@@ -1,0 +1,49 @@
+"""The handful of reference settings the hot path reads (mirror of the relevant ``shared.opts`` keys).
+
+Inside the webui the real ``modules.shared.opts`` is used instead; standalone (bench, tests) this
+object provides the same names with the reference's defaults (modules/shared_options.py, lines cited per key).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass
+class Options:
+    randn_source: str = "NV"                       # :183  (the engine implements the Philox "NV" source natively)
+    eta_noise_seed_delta: int = 0                  # :399
+    eta_ancestral: float = 1.0                     # :390
+    eta_ddim: float = 0.0                          # :389
+    s_churn: float = 0.0                           # :392
+    s_tmin: float = 0.0                            # :393
+    s_tmax: float = 0.0                            # :394  (0 = inf)
+    s_noise: float = 1.0                           # :395
+    sigma_min: float = 0.0                         # :396  (0 = model default)
+    sigma_max: float = 0.0                         # :397
+    rho: float = 0.0                               # :398
+    always_discard_next_to_last_sigma: bool = False  # :400
+    sgm_noise_multiplier: bool = False             # :401
+    use_old_karras_scheduler_sigmas: bool = False
+    batch_cond_uncond: bool = True                 # :242
+    s_min_uncond: float = 0.0                      # :234
+    skip_early_cond: float = 0.0                   # :407
+    img2img_extra_noise: float = 0.0
+    img2img_fix_steps: bool = False
+    enable_quantization: bool = False              # :176
+    live_previews_enable: bool = False             # :374 (fused path requires previews off)
+
+
+opts = Options()
+
+
+class State:
+    """modules/shared_state.py: only the fields the sampler loop touches."""
+    def __init__(self):
+        self.interrupted = False
+        self.skipped = False
+        self.sampling_step = 0
+        self.sampling_steps = 0
+        self.current_latent = None
+
+
+state = State()
