@@ -221,6 +221,12 @@ int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out_f32, 
 int64_t sdmi_engine_arena_bytes(sdmi_engine* e);
 int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "use_graph", "glds" */
 
+/* Optional per-launch HIP-event profiler: between begin and end every kernel launch of the library is bracketed by events
+ * on its own stream; end() synchronises once and writes {"kernels":[{"name","launches","ms","flops","bytes"},...]} with the
+ * ALGORITHMIC flops / bytes of each launch into json_out. */
+int sdmi_profile_begin(void);
+int sdmi_profile_end(char* json_out, int capacity);
+
 /* Micro-benchmarks used by bench.py's roofline block (HIP-event timed inside the library; returns ms per launch). */
 int sdmi_bench_conv_gemm(const sdmi_conv_desc* d, int iters, float* ms_out, void* stream);
 

@@ -18,6 +18,7 @@
 // Block = 4 waves x 32 queries = 128 queries; KV tile = 64 keys staged through registers into padded LDS rows
 // (row stride = odd number of 16-byte slots => conflict-free ds_read_b128), next tile prefetched during compute.
 #include "common.h"
+#include "prof.h"
 
 namespace sdmi {
 
@@ -276,6 +277,9 @@ static int launch_attn_d(const AttnP& p, hipStream_t s) {
 int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
     SDMI_REQUIRE(p.B > 0 && p.H > 0 && p.N > 0 && p.M > 0 && p.D > 0, "empty attention");
     SDMI_REQUIRE(p.vt_ld >= (p.M + 63) / 64 * 64, "vt_ld must be >= M rounded up to 64");
+    const double pf_flops = 4.0 * p.B * p.H * (double)p.N * p.M * p.D;
+    const double pf_bytes = 2.0 * p.B * p.H * ((double)p.N * p.D * 2 + (double)p.M * p.D * 2);
+    ProfScope ps(force_generic ? "attention_generic" : (p.M > 128 ? "attention_mfma_self" : "attention_mfma_cross"), pf_flops, pf_bytes, s);
     const bool aligned = (p.ldq % 8 == 0) && (p.ldk % 8 == 0) && (p.vt_ld % 8 == 0) && (p.ldo % 4 == 0) && (p.D % 8 == 0);
     if (!force_generic && aligned) {
         switch (p.D) {

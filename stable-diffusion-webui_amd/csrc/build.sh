@@ -11,6 +11,7 @@ for f in gemm.hip attention.hip norm.hip elementwise.hip; do
 done
 hipcc $FLAGS -x hip -c engine.cpp -o build/engine.o & pids+=($!)
 hipcc $FLAGS -x hip -c capi.cpp -o build/capi.o & pids+=($!)
+hipcc $FLAGS -x hip -c prof.cpp -o build/prof.o & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o "$OUT/libsdmi.so"
 echo "built $OUT/libsdmi.so"

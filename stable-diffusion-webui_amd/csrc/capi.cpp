@@ -1,5 +1,7 @@
 // capi.cpp — extern "C" surface of libsdmi.so (declared in include/sdmi.h).
 #include "engine.h"
+#include "prof.h"
+#include <cstring>
 
 namespace sdmi {
 int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, const void* y, void* out, int io_dtype,
@@ -287,6 +289,20 @@ int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out, int 
     API_GUARD_BEGIN
     return vae_encode(e, x, io_dtype, (float*)out, B, H, W, (hipStream_t)stream);
     API_GUARD_END
+}
+
+int sdmi_profile_begin(void) {
+    prof_begin();
+    return 0;
+}
+int sdmi_profile_end(char* json_out, int capacity) {
+    const std::string s = prof_end();
+    if (!json_out || capacity <= (int)s.size()) {
+        set_error("profile buffer too small");
+        return 1;
+    }
+    std::memcpy(json_out, s.c_str(), s.size() + 1);
+    return 0;
 }
 
 int64_t sdmi_engine_arena_bytes(sdmi_engine* e) { return e ? (int64_t)e->arena.cap : 0; }

@@ -58,6 +58,7 @@ struct GemmP {
     int ldrb;             // batch stride of rowbias (elements), normally N
     int rows_per_batch;   // Ho*Wo
     int n_real;
+    int n_valid;          // rows of W that exist (columns >= n_valid read zeros); normally N
     int flags;
     float alpha;
     long a_bs, w_bs, o_bs, r_bs;
@@ -116,7 +117,7 @@ int launch_timestep_embedding(const void* t, int dtype, float* out, int B, int d
 int launch_small_linear(const float* a, const half_t* w, const float* bias, const float* add, float* out, int B,
                         int N, int K, int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s);
 // row softmax: in fp32 [rows, cols] -> out fp16 [rows, ldo] (zero-filled up to ldo)
-int launch_softmax_rows(const float* in, half_t* out, int64_t rows, int cols, int ldo, hipStream_t s);
+int launch_softmax_rows(const float* in, half_t* out, int64_t rows, int cols, int ldi, int ldo, hipStream_t s);
 // weight repack: OIHW (f16|f32) -> [O_pad][kh*kw][I_pad] fp16 (zero padded); geglu: permute output rows
 int launch_pack_conv_weight(const void* w, int dtype, half_t* out, int O, int I, int kh, int kw, int O_pad,
                             int I_pad, int geglu, hipStream_t s);

@@ -328,10 +328,10 @@ int launch_small_linear(const float* a, const half_t* w, const float* bias, cons
 }
 
 // row softmax over fp32 scores -> fp16 probabilities (one block per row, row re-read from L2)
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, half_t* out, int cols, int ldo) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, half_t* out, int cols, int ldi, int ldo) {
     __shared__ float red[8];
     const long row = blockIdx.x;
-    const float* src = in + row * cols;
+    const float* src = in + row * ldi;
     half_t* dst = out + row * ldo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float mx = -INFINITY;
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, half
     const float inv = 1.0f / sum;
     for (int c = tid; c < ldo; c += 256) dst[c] = c < cols ? (half_t)(expf(src[c] - mx) * inv) : (half_t)0.f;
 }
-int launch_softmax_rows(const float* in, half_t* out, int64_t rows, int cols, int ldo, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, cols, ldo);
+int launch_softmax_rows(const float* in, half_t* out, int64_t rows, int cols, int ldi, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, in, out, cols, ldi, ldo);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }

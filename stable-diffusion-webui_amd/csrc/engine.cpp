@@ -425,6 +425,7 @@ static int run_attn(Run& r, const half_t* q, const half_t* k, const half_t* vt, 
 }
 
 // V^T[b] = Wv x X[b]^T :  the weight matrix plays the "activation" role, the tokens of image b the "weight" role.
+// Columns [tokens, tokens_pad) of V^T are written as zeros (n_valid), so the attention kernel's padded keys are finite.
 static int run_vt(Run& r, const ConvW& Wv, const half_t* x, int ldx, int B, int tokens, int tokens_pad, half_t* vt,
                   bool bias_row) {
     if (r.dry) return 0;
@@ -436,11 +437,10 @@ static int run_vt(Run& r, const ConvW& Wv, const half_t* x, int ldx, int B, int 
     p.out = vt;
     p.Hi = C; p.Wi = 1; p.Ho = C; p.Wo = 1;
     p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
-    p.M = C; p.N = tokens_pad; p.K = K;
+    p.M = C; p.N = tokens_pad; p.K = K; p.n_valid = tokens;
     p.ldo = tokens_pad; p.rows_per_batch = C; p.n_real = tokens_pad;
     p.flags = bias_row ? EP_BIAS_ROW : 0;
     p.alpha = 1.f;
-    SDMI_REQUIRE(tokens_pad == tokens && tokens % 8 == 0, "V^T GEMM needs the token count padded by the caller");
     p.a_bs = 0; p.w_bs = (long)tokens * ldx;
     p.o_bs = (long)C * tokens_pad;
     return launch_gemm(p, B, r.e->force_generic, r.e->use_glds, r.s);
@@ -462,10 +462,6 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         half_t* qk = r.H(M * 2 * C);
         TRY(run_linear(r, b.qk1, n1, (int)M, nullptr, qk, 2 * C));
         half_t* vt = r.H((size_t)B * C * Npad);
-        if (Npad != HW) {
-            // token rows beyond HW must exist for the V^T GEMM's "weight" operand; handle odd sizes the simple way
-            SDMI_REQUIRE(false, "latent H*W must be a multiple of 64 for the engine UNet (use the torch UNet for odd sizes)");
-        }
         TRY(run_vt(r, b.v1, n1, C, B, HW, Npad, vt, false));
         half_t* a1 = r.H(M * C);
         TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
@@ -848,15 +844,14 @@ static int vae_build(sdmi_engine* e) {
 static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H, int Wd, half_t** out) {
     const int C = a.c, HW = H * Wd, Npad = rup(HW, 64);
     const size_t M = (size_t)B * HW;
-    SDMI_REQUIRE(Npad == HW, "VAE latent H*W must be a multiple of 64");
     half_t* n0 = r.H(M * C);
     TRY(run_gn(r, a.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
     half_t* qk = r.H(M * 2 * C);
     TRY(run_linear(r, a.qk, n0, (int)M, nullptr, qk, 2 * C));
     half_t* vt = r.H((size_t)B * C * Npad);
     TRY(run_vt(r, a.v, n0, C, B, HW, Npad, vt, true));
-    float* S = r.F((size_t)B * HW * HW);
-    half_t* P = r.H((size_t)B * HW * HW);
+    float* S = r.F((size_t)B * HW * Npad);
+    half_t* P = r.H((size_t)B * HW * Npad);
     half_t* o = r.H(M * C);
     if (!r.dry) {
         GemmP p{};
@@ -864,20 +859,20 @@ static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H
         p.w = qk + C; p.ldw = 2 * C;
         p.out = S;
         p.Hi = HW; p.Wi = 1; p.Ho = HW; p.Wo = 1; p.taps = 1; p.stride = 1;
-        p.M = HW; p.N = HW; p.K = C; p.ldo = HW; p.rows_per_batch = HW; p.n_real = HW;
+        p.M = HW; p.N = Npad; p.n_valid = HW; p.K = C; p.ldo = Npad; p.rows_per_batch = HW; p.n_real = Npad;
         p.flags = EP_OUT_F32;
         p.alpha = 1.0f / sqrtf((float)C);
-        p.a_bs = (long)HW * 2 * C; p.w_bs = (long)HW * 2 * C; p.o_bs = (long)HW * HW;
+        p.a_bs = (long)HW * 2 * C; p.w_bs = (long)HW * 2 * C; p.o_bs = (long)HW * Npad;
         TRY(launch_gemm(p, B, r.e->force_generic, r.e->use_glds, r.s));
-        TRY(launch_softmax_rows(S, P, (int64_t)B * HW, HW, HW, r.s));
+        TRY(launch_softmax_rows(S, P, (int64_t)B * HW, HW, Npad, Npad, r.s));
         GemmP g{};
-        g.a0 = P; g.c0 = HW; g.cin = HW; g.lda0 = HW;
+        g.a0 = P; g.c0 = Npad; g.cin = Npad; g.lda0 = Npad;
         g.w = vt; g.ldw = Npad;
         g.out = o;
         g.Hi = HW; g.Wi = 1; g.Ho = HW; g.Wo = 1; g.taps = 1; g.stride = 1;
-        g.M = HW; g.N = C; g.K = HW; g.ldo = C; g.rows_per_batch = HW; g.n_real = C;
+        g.M = HW; g.N = C; g.K = Npad; g.ldo = C; g.rows_per_batch = HW; g.n_real = C;
         g.alpha = 1.f;
-        g.a_bs = (long)HW * HW; g.w_bs = (long)C * Npad; g.o_bs = (long)HW * C;
+        g.a_bs = (long)HW * Npad; g.w_bs = (long)C * Npad; g.o_bs = (long)HW * C;
         TRY(launch_gemm(g, B, r.e->force_generic, r.e->use_glds, r.s));
     }
     half_t* y = r.H(M * C);

@@ -24,7 +24,9 @@
 // Upsample / SpatialTransformer projections / GEGLU feed-forward; names pinned at
 // /root/reference/extensions-builtin/Lora/networks.py:43-98).
 #include "common.h"
+#include "prof.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace sdmi {
 
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
         for (int it = 0; it < B_IT; ++it) {
             const int idx = it * 256 + tid;
             const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
-            const half_t* g = wbase + (long)(n0 + r) * p.ldw + k0 + c * 8;
+            const half_t* g = (n0 + r < p.n_valid) ? wbase + (long)(n0 + r) * p.ldw + k0 + c * 8 : p.zero;
             if constexpr (GLDS) {
                 __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbuf + (it * 256 + wave * 64) * 16), 16, 0, 0);
             } else {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
             ((half_t*)p.out)[z * p.o_bs + (long)m * p.ldo + no] = (half_t)(a * gelu_erf(gt));
             continue;
         }
-        float v = dot_row(p, a0, a1, wbase + (long)no * p.ldw, ri) * p.alpha;
+        float v = no < p.n_valid ? dot_row(p, a0, a1, wbase + (long)no * p.ldw, ri) * p.alpha : 0.f;
         if (p.bias) v += (p.flags & EP_BIAS_ROW) ? p.bias[m] : p.bias[no];
         if (p.rowbias) v += p.rowbias[(long)ri.b * p.ldrb + no];
         if (p.resid) v += (float)p.resid[z * p.r_bs + (long)m * p.ldr + no];
@@ -369,14 +371,20 @@ bool gemm_mfma_supported(const GemmP& p) {
 
 int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s) {
     GemmP p = p_in;
+    if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     p.zero = zero_page();
     SDMI_REQUIRE(p.zero != nullptr, "zero page allocation failed");
     SDMI_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
     SDMI_REQUIRE(p.cin % 8 == 0, "Cin must be a multiple of 8 (pad channels)");
+    // algorithmic work of this launch: 2*M*N*K flops; bytes = activations read once + weights + output written once
+    const double pf_flops = 2.0 * p.M * (double)p.N * p.K * batch;
+    const double pf_in = (p.taps == 9 ? (double)p.M / (p.stride * p.stride) * (p.up ? 0.25 : 1.0) : (double)p.M) * p.cin * 2.0;
+    const double pf_bytes = (pf_in + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.flags & EP_OUT_F32) ? 4.0 : 2.0)) * batch;
     if (force_generic || !gemm_mfma_supported(p)) {
         const bool geglu = p.flags & EP_GEGLU;
         const long total = (long)p.M * (geglu ? p.N / 2 : p.N);
         int blocks = (int)std::min<long>((total + 255) / 256, 65535L * 8);
+        ProfScope ps("gemm_generic", pf_flops, pf_bytes, s);
         hipLaunchKernelGGL(gemm_generic_kernel, dim3(blocks, 1, batch), dim3(256), 0, s, p);
         SDMI_CHECK_HIP(hipGetLastError());
         return 0;
@@ -386,11 +394,18 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     const bool n128 = (p.N % 128) == 0;
     const long big_tiles = n128 ? (long)cdiv(p.M, 128) * (p.N / 128) : (long)cdiv(p.M, 256) * (p.N / 64);
     const bool small = big_tiles * batch < 192;
-#define SDMI_LAUNCH(BM, BN, WR, WC)                                                   \
-    return use_glds ? launch_cfg<BM, BN, WR, WC, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, false>(p, batch, s)
-    if (small) { SDMI_LAUNCH(64, 64, 4, 1); }
-    if (n128) { SDMI_LAUNCH(128, 128, 2, 2); }
-    SDMI_LAUNCH(256, 64, 4, 1);
+#define SDMI_LAUNCH(BM, BN, WR, WC, NAME)                                                        \
+    {                                                                                            \
+        ProfScope ps(p.taps == 9 ? NAME "_conv3x3" : NAME "_1x1", pf_flops, pf_bytes, s);        \
+        return use_glds ? launch_cfg<BM, BN, WR, WC, true>(p, batch, s)                          \
+                        : launch_cfg<BM, BN, WR, WC, false>(p, batch, s);                        \
+    }
+    if (small) SDMI_LAUNCH(64, 64, 4, 1, "gemm_mfma_64x64")
+    if (n128) SDMI_LAUNCH(128, 128, 2, 2, "gemm_mfma_128x128")
+    // N % 128 != 0 (e.g. 320): 256x64 tiles (80 KB of LDS); SDMI_TILE_N64=128 selects the 48 KB 128x64 variant instead
+    static const bool tile128 = [] { const char* e = getenv("SDMI_TILE_N64"); return e && atoi(e) == 128; }();
+    if (tile128) SDMI_LAUNCH(128, 64, 4, 1, "gemm_mfma_128x64")
+    SDMI_LAUNCH(256, 64, 4, 1, "gemm_mfma_256x64")
 #undef SDMI_LAUNCH
 }
 

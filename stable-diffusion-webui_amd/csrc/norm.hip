@@ -13,6 +13,7 @@
 //                      grid-stride elementwise pass y = silu((x - mean) * rstd * gamma + beta).
 // LayerNorm: one wave per token row, row held in registers, two-pass (mean, then centred variance) in fp32.
 #include "common.h"
+#include "prof.h"
 #include <algorithm>
 
 namespace sdmi {
@@ -119,6 +120,7 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 64 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 64, C % groups == 0");
     const int nchunk = gn_chunks(HW);
     const int rows = cdiv(HW, nchunk);
+    ProfScope ps("groupnorm_silu", 0.0, 3.0 * B * (double)HW * C * 2.0, s);      // read twice + write once
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
     SDMI_CHECK_HIP(hipGetLastError());
     const long nvec = (long)HW * (C / 8);
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const f
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
                      float eps, hipStream_t s) {
     SDMI_REQUIRE(C % 8 == 0 && C <= 2048, "LayerNorm: C % 8 == 0 and C <= 2048");
+    ProfScope ps("layernorm", 0.0, 2.0 * (double)rows * C * 2.0, s);
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, out, (long)rows, C, eps);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;

@@ -1,0 +1,288 @@
+"""GPU parity tests, op level: every HIP kernel behind the C ABI against the fp32 CPU oracle / a plain torch fp32
+reference of the same op, on seeded inputs.  Tolerances are stated per test (fp16 storage, fp32 accumulate)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def sub(name):
+    return importlib.import_module("stable-diffusion-webui_amd." + name)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    lib = sub("_lib")
+    lib.require_device()          # fail loudly: no fallback
+    return torch.device("cuda", 0)
+
+
+def h(t):
+    return t.half().float()       # the fp16-rounded value the kernel sees
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Philox
+# ------------------------------------------------------------------------------------------------------------
+def test_philox_bit_exact_vs_reference_fixture(dev, golden_dir):
+    ops = sub("ops")
+    z = np.load(os.path.join(golden_dir, "philox.npz"))
+    total = mism = 0
+    for key in sorted(k for k in z.files if k.startswith("c")):
+        _, seed, draw = key.split("_")
+        got = ops.philox_randn(z[key].shape, int(seed[4:]), int(draw[4:]), dev).cpu().numpy()
+        total += got.size
+        mism += int((got != z[key]).sum())
+        np.testing.assert_allclose(got, z[key], rtol=0, atol=2.4e-7 * 8)       # never more than a few ulp
+    # device libm double log/sin vs the host's: allow a vanishing fraction of 1-ulp double-rounding differences
+    assert mism <= max(1, total // 20000), f"{mism}/{total} values differ from the reference bit pattern"
+
+
+def test_image_rng_matches_oracle(dev):
+    from oracle import rng as orng
+    r = sub("rng").ImageRNG((4, 8, 8), [1000, 1001, 2 ** 32 + 7], device=dev)
+    o = orng.ImageRNG((4, 8, 8), [1000, 1001, 2 ** 32 + 7])
+    for _ in range(3):
+        np.testing.assert_allclose(r.next().cpu().numpy(), o.next().numpy(), rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# implicit-GEMM conv / linear
+# ------------------------------------------------------------------------------------------------------------
+def _conv_ref(x_nhwc, w, bias, stride=1, pad=1, up=False, asym=False):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if up:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    if asym:
+        x = F.pad(x, (0, 1, 0, 1))
+        y = F.conv2d(x, w, bias, stride=stride, padding=0)
+    else:
+        y = F.conv2d(x, w, bias, stride=stride, padding=pad if w.shape[-1] == 3 else 0)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+IMPLS = ["mfma", "mfma_reg", "generic"]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=12, W=10, cin=64, cout=128, k=3),                       # M = 240: partial 128-row tile
+    dict(B=1, H=16, W=16, cin=128, cout=320, k=3),                      # N = 320 -> 256x64 tiles (5 column tiles)
+    dict(B=2, H=9, W=7, cin=192, cout=64, k=3, stride=2),               # stride 2, odd sizes
+    dict(B=1, H=8, W=8, cin=64, cout=64, k=3, up=True),                 # fused nearest x2 upsample
+    dict(B=1, H=9, W=9, cin=64, cout=64, k=3, stride=2, asym=True),     # VAE-encoder downsample (pad right/bottom)
+    dict(B=3, H=5, W=5, cin=320, cout=640, k=1),                        # 1x1
+    dict(B=1, H=64, W=64, cin=64, cout=128, k=3),                       # M = 4096: full 128x128 tiles, XCD remap
+    dict(B=2, H=32, W=32, cin=128, cout=64, k=3),                       # 256x64 config, many tiles
+])
+def test_conv_gemm_vs_torch(dev, impl, case):
+    ops = sub("ops")
+    B, H, W, cin, cout, k = case["B"], case["H"], case["W"], case["cin"], case["cout"], case["k"]
+    stride, up, asym = case.get("stride", 1), case.get("up", False), case.get("asym", False)
+    x = seeded((B, H, W, cin), 1)
+    w = seeded((cout, cin, k, k), 2, scale=(cin * k * k) ** -0.5)
+    b = seeded((cout,), 3, scale=0.1)
+    ref = _conv_ref(h(x), h(w), b, stride=stride, up=up, asym=asym)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    bp = ops.pack_bias(b.to(dev), wp.shape[0])
+    got = ops.conv_gemm(x.half().to(dev), wp, bias=bp, taps=k * k, stride=stride, pad=0 if asym else 1, up=up, impl=impl)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    # fp32 accumulate, fp16 store: |err| <= 2^-11 |y| + accumulation noise
+    assert rel_l2(got.float().cpu(), ref) < 6e-4, (impl, case)
+    assert float((got.float().cpu() - ref).abs().max()) < 4e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_conv_gemm_epilogues(dev, impl):
+    """bias + per-image rowbias (ResBlock emb add) + residual; fp32 output; NCHW store of a 4-channel conv_out."""
+    ops = sub("ops")
+    B, H, W, cin, cout = 2, 8, 8, 64, 128
+    x, w = seeded((B, H, W, cin), 1), seeded((cout, cin, 3, 3), 2, scale=(cin * 9) ** -0.5)
+    b, rb, res = seeded((cout,), 3, 0.1), seeded((B, cout), 4), seeded((B, H, W, cout), 5)
+    ref = _conv_ref(h(x), h(w), b) + rb[:, None, None, :] + h(res)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    got = ops.conv_gemm(x.half().to(dev), wp, bias=b.to(dev), rowbias=rb.to(dev).contiguous(), resid=res.half().to(dev), impl=impl)
+    assert rel_l2(got.float().cpu(), ref) < 6e-4
+    got32 = ops.conv_gemm(x.half().to(dev), wp, bias=b.to(dev), out_f32=True, impl=impl)
+    assert rel_l2(got32.cpu(), _conv_ref(h(x), h(w), b)) < 2e-5          # fp32 store: only accumulation-order noise
+    # conv_out-like: 4 real output channels, NCHW fp32
+    w4, b4 = seeded((4, cin, 3, 3), 6, scale=(cin * 9) ** -0.5), seeded((4,), 7, 0.1)
+    w4p = ops.pack_conv_weight(w4.half().to(dev))
+    assert w4p.shape[0] == 64
+    got4 = ops.conv_gemm(x.half().to(dev), w4p, bias=ops.pack_bias(b4.to(dev), 64), nchw_real=4, impl=impl)
+    ref4 = _conv_ref(h(x), h(w4), b4).permute(0, 3, 1, 2)
+    assert got4.shape == (B, 4, H, W) and rel_l2(got4.cpu(), ref4) < 2e-5
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_conv_gemm_two_sources_equals_concat(dev, impl):
+    """skip-connection concat elided: reading (h, skip) as two sources == conv over torch.cat([h, skip], C)."""
+    ops = sub("ops")
+    B, H, W, c0, c1, cout = 1, 8, 8, 128, 64, 128
+    x0, x1 = seeded((B, H, W, c0), 1), seeded((B, H, W, c1), 2)
+    w = seeded((cout, c0 + c1, 3, 3), 3, scale=((c0 + c1) * 9) ** -0.5)
+    ref = _conv_ref(h(torch.cat([x0, x1], dim=3)), h(w), None)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    got = ops.conv_gemm(x0.half().to(dev), wp, a1=x1.half().to(dev), impl=impl)
+    assert rel_l2(got.float().cpu(), ref) < 6e-4
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_linear_geglu_epilogue(dev, impl):
+    """FeedForward's GEGLU: out = value * gelu(gate) fused into the first GEMM (ldm GEGLU; erf GELU)."""
+    ops = sub("ops")
+    rows, c = 200, 64
+    x = seeded((1, rows, 1, c), 1)
+    w, b = seeded((8 * c, c), 2, scale=c ** -0.5), seeded((8 * c,), 3, 0.1)
+    y = F.linear(h(x).reshape(rows, c), h(w), b)
+    a, g = y.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    wp = ops.pack_conv_weight(w.half().to(dev), geglu=True)
+    bp = ops.pack_bias(b.to(dev), 8 * c, geglu=True)
+    got = ops.conv_gemm(x.half().to(dev), wp, bias=bp, taps=1, geglu=True, impl=impl)
+    assert got.shape[-1] == 4 * c
+    assert rel_l2(got.float().cpu().reshape(rows, 4 * c), ref) < 8e-4
+
+
+def test_mfma_glds_and_register_staging_agree_bitwise(dev):
+    """Same LDS image, same MFMA order => identical bits; catches any mismatch in the LDS-direct load path."""
+    ops = sub("ops")
+    x, w = seeded((2, 16, 16, 128), 1), seeded((128, 128, 3, 3), 2, scale=(128 * 9) ** -0.5)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    a = ops.conv_gemm(x.half().to(dev), wp, impl="mfma")
+    b = ops.conv_gemm(x.half().to(dev), wp, impl="mfma_reg")
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, heads):
+    b, n, c = q.shape
+    d = c // heads
+    sp = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3)
+    s = torch.einsum('bhid,bhjd->bhij', sp(q), sp(k)) * d ** -0.5
+    o = torch.einsum('bhij,bhjd->bhid', s.softmax(-1), sp(v))
+    return o.permute(0, 2, 1, 3).reshape(b, n, c)
+
+
+@pytest.mark.parametrize("d,heads,n,m", [
+    (40, 8, 256, 256), (40, 2, 200, 77), (64, 2, 128, 128), (64, 1, 70, 333), (80, 8, 256, 256), (80, 2, 64, 77),
+    (128, 1, 130, 64), (160, 8, 64, 64), (160, 2, 256, 77), (160, 1, 300, 300),
+    (32, 2, 50, 60),          # generic kernel (head size without an MFMA instance)
+])
+def test_attention_vs_oracle(dev, d, heads, n, m):
+    ops = sub("ops")
+    b = 2
+    q, k, v = seeded((b, n, heads * d), 1), seeded((b, m, heads * d), 2), seeded((b, m, heads * d), 3)
+    ref = _attn_ref(h(q), h(k), h(v), heads)
+    got = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
+    torch.cuda.synchronize()
+    # fp32 scores/softmax, P rounded to fp16 before PV, fp16 output
+    assert rel_l2(got.float().cpu(), ref) < 1.5e-3, (d, heads, n, m)
+
+
+def test_attention_matches_reference_sub_quadratic_fixture(dev, golden_dir):
+    """Against outputs of the reference's own modules/sub_quadratic_attention.py (tests/golden/make_golden.py)."""
+    ops = sub("ops")
+    z = np.load(os.path.join(golden_dir, "subquad_attention.npz"))
+    for ci in range(3):
+        bh, n, mk, d = [int(v) for v in z[f"c{ci}_shape"]]
+        q, k, v = seeded((bh, n, d), 10 + ci), seeded((bh, mk, d), 20 + ci), seeded((bh, mk, d), 30 + ci)
+        got = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads=1)
+        # inputs are rounded to fp16 for the kernel, the fixture used fp32 inputs: tolerance covers that rounding
+        assert rel_l2(got.float().cpu(), z[f"c{ci}_out"]) < 4e-3
+
+
+def test_attention_softmax_is_shift_invariant_and_handles_spikes(dev):
+    """Online-softmax rescale branch: one key with a huge score late in the sequence (forces a max jump at a later KV
+    tile) and a constant shift of all scores must not change the result beyond rounding."""
+    ops = sub("ops")
+    d, heads, n, m = 64, 1, 64, 256
+    q, k, v = seeded((1, n, d), 1), seeded((1, m, d), 2), seeded((1, m, d), 3)
+    k[0, 200] = q[0, 5] * 6.0                     # spike for query 5 inside the 4th KV tile
+    ref = _attn_ref(h(q), h(k), h(v), heads)
+    got = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
+    assert rel_l2(got.float().cpu(), ref) < 1.5e-3
+    assert float((got[0, 5].float().cpu() - ref[0, 5]).abs().max()) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c0,c1,hw", [(320, 0, (8, 8)), (64, 0, (16, 16)), (1280, 640, (4, 4)), (128, 64, (32, 32)),
+                                      (2560, 0, (8, 8)), (128, 0, (64, 64))])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_silu_vs_torch(dev, c0, c1, hw, silu):
+    ops = sub("ops")
+    B, (H, W) = 2, hw
+    x0 = seeded((B, H, W, c0), 1) * 1.7 + 0.3
+    x1 = seeded((B, H, W, c1), 2) * 0.6 - 0.2 if c1 else None
+    C = c0 + c1
+    g, bt = 1 + 0.1 * seeded((C,), 3), 0.1 * seeded((C,), 4)
+    xx = h(x0) if x1 is None else torch.cat([h(x0), h(x1)], dim=3)
+    ref = F.group_norm(xx.permute(0, 3, 1, 2), 32, g, bt, eps=1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    got = ops.groupnorm(x0.half().to(dev), g.to(dev), bt.to(dev), x1=None if x1 is None else x1.half().to(dev), eps=1e-5, silu=silu)
+    assert rel_l2(got.float().cpu(), ref) < 5e-4
+
+
+@pytest.mark.parametrize("c", [64, 320, 640, 1280])
+def test_layernorm_vs_torch(dev, c):
+    ops = sub("ops")
+    x = seeded((3, 50, c), 1) * 2 + 0.5
+    g, bt = 1 + 0.1 * seeded((c,), 2), 0.1 * seeded((c,), 3)
+    ref = F.layer_norm(h(x), (c,), g, bt, eps=1e-5)
+    got = ops.layernorm(x.half().to(dev), g.to(dev), bt.to(dev))
+    assert rel_l2(got.float().cpu(), ref) < 5e-4
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sampler arithmetic
+# ------------------------------------------------------------------------------------------------------------
+def test_sampler_kernels_match_oracle_formulas(dev):
+    from oracle import kdiffusion as okd
+    lib = sub("_lib")
+    L, check, ptr, sp = lib.lib, lib.check, lib.ptr, lib.stream_ptr
+    B, chw = 3, 4 * 8 * 8
+    x = seeded((B, 4, 8, 8), 1) * 5
+    eps = seeded((2 * B, 4, 8, 8), 2)
+    noise = seeded((B, 4, 8, 8), 3)
+    sigma = torch.tensor(3.3)
+    # CompVisDenoiser + combine_denoised
+    c_out = -sigma
+    x_out = torch.cat([x, x]) + eps * c_out
+    den_ref = okd.CFGDenoiser.combine_denoised(x_out, [[(i, 1.0)] for i in range(B)], B, 7.0)
+    xd, ed = x.to(dev), eps.to(dev)
+    den = torch.empty_like(xd)
+    co = torch.full((B,), float(c_out), device=dev)
+    check(L.sdmi_cfg_combine(ptr(xd), ptr(ed), ptr(co), 7.0, 0, None, None, None, ptr(den), B, chw, sp()))
+    np.testing.assert_allclose(den.cpu().numpy(), den_ref.numpy(), rtol=1e-6, atol=1e-5)
+    # Euler-ancestral update
+    sd_, su = okd.get_ancestral_step(torch.tensor(3.3), torch.tensor(2.1))
+    ref = x + okd.to_d(x, torch.tensor(3.3), den_ref) * (sd_ - 3.3)
+    ref = ref + noise * 1.0 * su
+    xs = xd.clone()
+    check(L.sdmi_euler_step(ptr(xs), ptr(den), ptr(noise.to(dev)), 3.3, float(sd_), float(su), 1.0, xs.numel(), sp()))
+    np.testing.assert_allclose(xs.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-5)
+    # prepare input (fp16 and fp32)
+    ci = torch.full((B,), 0.29, device=dev)
+    xin = torch.empty((2 * B, 4, 8, 8), dtype=torch.float16, device=dev)
+    check(L.sdmi_cfg_prepare_input(ptr(xd), ptr(ci), ptr(xin), 0, B, 2, chw, sp()))
+    want = (torch.cat([x, x]) * torch.tensor(0.29)).half()
+    assert torch.equal(xin.cpu(), want)
+    # uint8 conversion incl. truncation and clamping
+    img = torch.tensor([-1.2, -1.0, 0.0, 0.999, 1.0, 1.7, 0.5019, -0.25]).reshape(1, 1, 2, 4).repeat(1, 3, 1, 1)
+    got = sub("ops").image_to_u8(img.to(dev)).cpu().numpy()
+    from oracle.vae import to_uint8_hwc
+    np.testing.assert_array_equal(got, to_uint8_hwc(img))
