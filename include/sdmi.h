@@ -221,6 +221,10 @@ int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out_f32, 
 int64_t sdmi_engine_arena_bytes(sdmi_engine* e);
 int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "use_graph", "glds" */
 
+/* Tuning knobs for benchmarks: "gemm_cfg" (-1 heuristic, 0..7 force a tile configuration when it fits the shape),
+ * "attn_kvt" (0 heuristic, 64 force 64-key tiles). */
+int sdmi_debug_set(const char* name, int value);
+
 /* Optional per-launch HIP-event profiler: between begin and end every kernel launch of the library is bracketed by events
  * on its own stream; end() synchronises once and writes {"kernels":[{"name","launches","ms","flops","bytes"},...]} with the
  * ALGORITHMIC flops / bytes of each launch into json_out. */

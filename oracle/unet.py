@@ -298,10 +298,10 @@ class UNetModel(nn.Module):
 
 def build_unet(cfg: UNetConfig, state_dict: dict, prefix: str = "model.diffusion_model.") -> UNetModel:
     """Instantiate the oracle UNet and load fp32 copies of ``state_dict[prefix + key]``."""
-    with torch.device("cpu"):
+    with torch.device("meta"):          # skip the (slow) random init; parameters are assigned from the checkpoint
         net = UNetModel(cfg)
     own = {}
     for k in net.state_dict().keys():
         own[k] = state_dict[prefix + k].float()
-    net.load_state_dict(own, strict=True)
+    net.load_state_dict(own, strict=True, assign=True)
     return net.eval().requires_grad_(False)

@@ -202,10 +202,10 @@ class AutoencoderKL(nn.Module):
 
 
 def build_vae(cfg: VAEConfig, state_dict: dict, prefix: str = "first_stage_model.") -> AutoencoderKL:
-    with torch.device("cpu"):
+    with torch.device("meta"):          # skip the (slow) random init; parameters are assigned from the checkpoint
         net = AutoencoderKL(cfg)
     own = {k: state_dict[prefix + k].float() for k in net.state_dict().keys()}
-    net.load_state_dict(own, strict=True)
+    net.load_state_dict(own, strict=True, assign=True)
     return net.eval().requires_grad_(False)
 
 

@@ -99,6 +99,7 @@ _SIGS = {
     "sdmi_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sdmi_vae_decode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sdmi_vae_encode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "sdmi_debug_set": (_i, [C.c_char_p, _i]),
     "sdmi_profile_begin": (_i, []),
     "sdmi_profile_end": (_i, [C.c_char_p, _i]),
     "sdmi_engine_arena_bytes": (_i64, [_vp]),

@@ -19,24 +19,26 @@
 // (row stride = odd number of 16-byte slots => conflict-free ds_read_b128), next tile prefetched during compute.
 #include "common.h"
 #include "prof.h"
+#include <cstdlib>
 
 namespace sdmi {
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
+template <int D, int KVT>
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
     constexpr int DK = (D + 15) / 16 * 16;   // contraction length of S^T, padded to the MFMA K step
     constexpr int NDC = DK / 16;
     constexpr int DV = (D + 31) / 32 * 32;   // rows of O^T, padded to the MFMA M
     constexpr int NDB = DV / 32;
+    constexpr int NKB = KVT / 32;            // 32-key blocks per KV tile
     constexpr int KSTR = DK * 2 + 16;        // bytes; (DK/8 + 1) slots of 16 B -> odd
-    constexpr int VSTR = 64 * 2 + 16;        // 9 slots
-    constexpr int K_BYTES = 64 * KSTR, V_BYTES = DV * VSTR;
+    constexpr int VSTR = KVT * 2 + 16;       // (KVT/8 + 1) slots -> odd
+    constexpr int K_BYTES = KVT * KSTR, V_BYTES = DV * VSTR;
+    constexpr int TILE_BYTES = K_BYTES + V_BYTES;
     constexpr int KCPR = DK / 8;             // 16-byte chunks per K row
-    constexpr int KCH = 64 * KCPR, VCH = DV * 8;
+    constexpr int VCPR = KVT / 8;            // 16-byte chunks per V^T row
+    constexpr int KCH = KVT * KCPR, VCH = DV * VCPR;
     constexpr int K_IT = (KCH + 255) / 256, V_IT = (VCH + 255) / 256;
-    __shared__ __attribute__((aligned(16))) char smem[K_BYTES + V_BYTES];
-    char* Ks = smem;
-    char* Vs = smem + K_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 x (K tile | V^T tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, lq = lane & 31;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
 
     uint4 kr[K_IT], vr[V_IT];
     auto load_tile = [&](int t) {
-        const int key0 = t * 64;
+        const int key0 = t * KVT;
 #pragma unroll
         for (int it = 0; it < K_IT; ++it) {
             const int idx = it * 256 + tid;
@@ -75,13 +77,16 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
 #pragma unroll
         for (int it = 0; it < V_IT; ++it) {
             const int idx = it * 256 + tid;
-            const int row = idx >> 3, c = idx & 7;
+            const int row = idx / VCPR, c = idx - row * VCPR;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < VCH && row < D) v = *reinterpret_cast<const uint4*>(vbase + (long)row * p.vt_ld + key0 + c * 8);
+            if (idx < VCH && row < D && key0 + c * 8 < p.vt_ld)
+                v = *reinterpret_cast<const uint4*>(vbase + (long)row * p.vt_ld + key0 + c * 8);
             vr[it] = v;
         }
     };
-    auto write_tile = [&]() {
+    auto write_tile = [&](int buf) {
+        char* Ks = smem + buf * TILE_BYTES;
+        char* Vs = Ks + K_BYTES;
 #pragma unroll
         for (int it = 0; it < K_IT; ++it) {
             const int idx = it * 256 + tid;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
 #pragma unroll
         for (int it = 0; it < V_IT; ++it) {
             const int idx = it * 256 + tid;
-            const int row = idx >> 3, c = idx & 7;
+            const int row = idx / VCPR, c = idx - row * VCPR;
             if (idx < VCH) *reinterpret_cast<uint4*>(Vs + row * VSTR + c * 16) = vr[it];
         }
     };
@@ -101,65 +106,72 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    // running max is kept in the scaled (log2) domain: t = s * scale_log2
     float m_run = -1e30f, l_run = 0.f;
 
     // K row read by this lane as MFMA row (lane&31): bits 2 and 3 swapped (see header)
     const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
-    const char* ka_ptr = Ks + krow * KSTR + half * 16;
-    const char* va_ptr = Vs + lq * VSTR + half * 16;
+    const int ka_off = krow * KSTR + half * 16;
+    const int va_off = K_BYTES + lq * VSTR + half * 16;
 
-    const int ntiles = (p.M + 63) / 64;
+    const int ntiles = (p.M + KVT - 1) / KVT;
     load_tile(0);
-    write_tile();
+    write_tile(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
         const bool more = t + 1 < ntiles;
         if (more) load_tile(t + 1);
+        const char* tile = smem + cur * TILE_BYTES;
 
-        // ---- S^T for the two 32-key blocks of this tile ------------------------------------------------------
-        f16v s0, s1;
+        // ---- S^T for the NKB 32-key blocks of this tile --------------------------------------------------------
+        f16v sc[NKB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
 #pragma unroll
         for (int dc = 0; dc < NDC; ++dc) {
-            const h8 ka0 = *reinterpret_cast<const h8*>(ka_ptr + dc * 32);
-            const h8 ka1 = *reinterpret_cast<const h8*>(ka_ptr + 32 * KSTR + dc * 32);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka0, qf[dc], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka1, qf[dc], s1, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const h8 ka = *reinterpret_cast<const h8*>(tile + ka_off + kb * 32 * KSTR + dc * 32);
+                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[dc], sc[kb], 0, 0, 0);
+            }
         }
 
-        // ---- online softmax (per lane: one query row, 32 of the tile's 64 keys) -------------------------------
+        // ---- online softmax (per lane: one query row, KVT/2 of the tile's keys) -----------------------------------
         // register r of block kb <-> local key 32*kb + 16*(r>>3) + 8*half + (r&7)
-        const int key0 = t * 64;
-        const bool tail = key0 + 64 > p.M;
+        const int key0 = t * KVT;
+        const bool tail = key0 + KVT > p.M;
         float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a = s0[r] * p.scale_log2, c = s1[r] * p.scale_log2;
-            if (tail) {
-                const int kl = 16 * (r >> 3) + 8 * half + (r & 7);
-                if (key0 + kl >= p.M) a = -INFINITY;
-                if (key0 + 32 + kl >= p.M) c = -INFINITY;
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = sc[kb][r];
+                if (tail) {
+                    const int kl = 32 * kb + 16 * (r >> 3) + 8 * half + (r & 7);
+                    if (key0 + kl >= p.M) a = -INFINITY;
+                    sc[kb][r] = a;
+                }
+                mx = fmaxf(mx, a);
             }
-            s0[r] = a; s1[r] = c;
-            mx = fmaxf(mx, fmaxf(a, c));
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;      // scale > 0: max commutes with the scaling
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float rs = 0.f;
-        h8 pb[2][2];
+        h8 pb[NKB][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e0 = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            const float e1 = __builtin_amdgcn_exp2f(s1[r] - m_new);
-            rs += e0 + e1;
-            pb[0][r >> 3][r & 7] = (half_t)e0;
-            pb[1][r >> 3][r & 7] = (half_t)e1;
-        }
-        l_run = l_run * alpha + rs;
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], p.scale_log2, -m_new));
+                rs += e;
+                pb[kb][r >> 3][r & 7] = (half_t)e;
+            }
+        l_run = fmaf(l_run, alpha, rs);
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -169,16 +181,16 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnP p) {
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
-                    const h8 va = *reinterpret_cast<const h8*>(va_ptr + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
+                    const h8 va = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[kb][sb], o[db], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();                 // every wave is done reading this tile
-        if (more) write_tile();
+        // double-buffered LDS: the other buffer was last read in iteration t-1 (all waves passed its barrier)
+        if (more) write_tile(cur ^ 1);
         __syncthreads();
     }
 
@@ -266,10 +278,20 @@ int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, 
     return 0;
 }
 
-template <int D>
+int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e) : 0; }();
+
+template <int D, int KVT>
 static int launch_attn_d(const AttnP& p, hipStream_t s) {
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
+    constexpr int SMEM = 2 * (KVT * (DK * 2 + 16) + DV * (KVT * 2 + 16));
+    auto kern = attn_mfma_kernel<D, KVT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
     dim3 grid(cdiv(p.N, 128), p.B * p.H);
-    hipLaunchKernelGGL(attn_mfma_kernel<D>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -281,13 +303,16 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
     const double pf_bytes = 2.0 * p.B * p.H * ((double)p.N * p.D * 2 + (double)p.M * p.D * 2);
     ProfScope ps(force_generic ? "attention_generic" : (p.M > 128 ? "attention_mfma_self" : "attention_mfma_cross"), pf_flops, pf_bytes, s);
     const bool aligned = (p.ldq % 8 == 0) && (p.ldk % 8 == 0) && (p.vt_ld % 8 == 0) && (p.ldo % 4 == 0) && (p.D % 8 == 0);
+    const bool kvt128 = g_attn_kvt != 64;
     if (!force_generic && aligned) {
         switch (p.D) {
-            case 40: return launch_attn_d<40>(p, s);
-            case 64: return launch_attn_d<64>(p, s);
-            case 80: return launch_attn_d<80>(p, s);
-            case 128: return launch_attn_d<128>(p, s);
-            case 160: return launch_attn_d<160>(p, s);
+            // KV tile: 128 keys where the register budget allows it (small heads: the per-tile barrier / staging
+            // overhead is amortised over twice the MFMA work), 64 otherwise or when the key sequence is short
+            case 40: return (kvt128 && p.M > 64) ? launch_attn_d<40, 128>(p, s) : launch_attn_d<40, 64>(p, s);
+            case 64: return (kvt128 && p.M > 64) ? launch_attn_d<64, 128>(p, s) : launch_attn_d<64, 64>(p, s);
+            case 80: return launch_attn_d<80, 64>(p, s);
+            case 128: return launch_attn_d<128, 64>(p, s);
+            case 160: return launch_attn_d<160, 64>(p, s);
             default: break;
         }
     }

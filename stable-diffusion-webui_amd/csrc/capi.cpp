@@ -291,6 +291,17 @@ int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out, int 
     API_GUARD_END
 }
 
+int sdmi_debug_set(const char* name, int value) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(name != nullptr, "null name");
+    const std::string n(name);
+    if (n == "gemm_cfg") g_force_gemm_cfg = value;
+    else if (n == "attn_kvt") g_attn_kvt = value;
+    else { set_error("unknown debug knob " + n); return 1; }
+    return 0;
+    API_GUARD_END
+}
+
 int sdmi_profile_begin(void) {
     prof_begin();
     return 0;

@@ -67,6 +67,9 @@ struct GemmP {
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8 };
 
 int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s);
+// debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)
+extern int g_force_gemm_cfg;
+extern int g_attn_kvt;
 
 // ---- attention --------------------------------------------------------------------------------------------
 struct AttnP {

@@ -48,14 +48,27 @@ struct GRow {
 
 __device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
 
-template <int BM, int BN, int WR, int WC, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
+// LDS swizzle: 16-byte chunk c of tile row r is stored in slot c ^ swz(r).  BK=64 (128-byte rows): r & 7.
+// BK=32 (64-byte rows, 4 rows per 256-byte bank row): f((r>>2)&3) with f = {0,2,3,1}, which makes every ds_read_b128
+// lane group {(rows 0-3,c),(rows 12-15,c),(rows 4-11,c^1)} land on 16 distinct 16-byte slots.
+template <int BK>
+__device__ __forceinline__ int swz(int r) {
+    if constexpr (BK == 64) return r & 7;
+    else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
+}
+
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
+__global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
+    constexpr int NT = WR * WC * 64;
     constexpr int WTM = BM / WR, WTN = BN / WC;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;        // 16-byte chunk loads per thread per stage
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int CPR = BK / 8;                          // 16-byte chunks per tile row
+    constexpr int ROWB = BK * 2;                         // bytes per tile row
+    constexpr int A_IT = BM * CPR / NT, B_IT = BN * CPR / NT;   // chunk loads per thread per stage
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    static_assert(WR * WC == 4, "4 waves");
+    static_assert((BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "tile must split evenly over the threads");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the MFMA tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,8 +95,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int idx = it * 256 + tid;
-        const int m = m0 + (idx >> 3);
+        const int idx = it * NT + tid;
+        const int m = m0 + idx / CPR;
         GRow gr;
         gr.ok = m < p.M;
         const int mm = gr.ok ? m : 0;
@@ -103,15 +116,15 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / 64;
+    const int nk = p.K / BK;
     uint4 ra[GLDS ? 1 : A_IT], rb[GLDS ? 1 : B_IT];
 
     // (tap, cbase) of the NEXT stage to issue; advanced incrementally (no integer division in the K loop)
     int nx_tap = 0, nx_cbase = 0, nx_k0 = 0;
     auto stage_issue = [&](int sb) {
         const int tap = nx_tap, cbase = nx_cbase, k0 = nx_k0;
-        nx_k0 += 64;
-        nx_cbase += 64;
+        nx_k0 += BK;
+        nx_cbase += BK;
         if (nx_cbase >= p.cin) { nx_cbase = 0; ++nx_tap; }
         // block-uniform part of the address
         const bool first = cbase < p.c0;
@@ -124,26 +137,26 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
         char* bbuf = abuf + A_BYTES;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int idx = it * 256 + tid;
-            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
             const GRow gr = rows[it];
             const int yr = gr.yb + dy, xr = gr.xb + dx;
             const bool ok = gr.ok && (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
             const int pix = gr.pixbase + (yr >> p.up) * p.Wi + (xr >> p.up);
             const half_t* g = ok ? src + (long)pix * lda + (cch + c * 8) : p.zero;
             if constexpr (GLDS) {
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (it * NT + wave * 64) * 16), 16, 0, 0);
             } else {
                 ra[it] = *reinterpret_cast<const uint4*>(g);
             }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int idx = it * 256 + tid;
-            const int r = idx >> 3, c = (idx & 7) ^ (r & 7);
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
             const half_t* g = (n0 + r < p.n_valid) ? wbase + (long)(n0 + r) * p.ldw + k0 + c * 8 : p.zero;
             if constexpr (GLDS) {
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbuf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbuf + (it * NT + wave * 64) * 16), 16, 0, 0);
             } else {
                 rb[it] = *reinterpret_cast<const uint4*>(g);
             }
@@ -154,9 +167,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
             char* abuf = smem + sb * STAGE;
             char* bbuf = abuf + A_BYTES;
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) *reinterpret_cast<uint4*>(abuf + (it * 256 + tid) * 16) = ra[it];
+            for (int it = 0; it < A_IT; ++it) *reinterpret_cast<uint4*>(abuf + (it * NT + tid) * 16) = ra[it];
 #pragma unroll
-            for (int it = 0; it < B_IT; ++it) *reinterpret_cast<uint4*>(bbuf + (it * 256 + tid) * 16) = rb[it];
+            for (int it = 0; it < B_IT; ++it) *reinterpret_cast<uint4*>(bbuf + (it * NT + tid) * 16) = rb[it];
         }
     };
     auto compute = [&](int sb) {
@@ -164,16 +177,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
         const char* bbuf = abuf + A_BYTES;
         const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 32; ++ks) {
             const int kc = ks * 4 + lk;
-            const int sw = (kc ^ (lr & 7)) << 4;          // row & 7 == lane & 7 (tile bases are multiples of 16)
+            const int sw = (kc ^ swz<BK>(lr)) << 4;       // swz(row) == swz(lane&15): tile bases are multiples of 16
             h8 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const h8*>(abuf + (wr * WTM + i * 16 + lr) * 128 + sw);
+                af[i] = *reinterpret_cast<const h8*>(abuf + (wr * WTM + i * 16 + lr) * ROWB + sw);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const h8*>(bbuf + (wc * WTN + j * 16 + lr) * 128 + sw);
+                bf[j] = *reinterpret_cast<const h8*>(bbuf + (wc * WTN + j * 16 + lr) * ROWB + sw);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -207,22 +220,25 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
         if (m >= p.M) continue;
         const int b = m / p.rows_per_batch;
         if (flags & EP_GEGLU) {
-            // wave tile is 64 wide: column tiles {0,1} hold values, {2,3} the matching gates
-            if constexpr (TN == 4) {
+            // every 64 packed columns = 32 values followed by their 32 gates: column tiles {4g, 4g+1} / {4g+2, 4g+3}
+            if constexpr (WTN % 64 == 0) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int nloc = j * 16 + (lane >> 4) * 4;
-                    const int npk = n0 + wc * WTN + nloc;            // packed column of the value
-                    const int nout = (n0 + wc * WTN) / 2 + nloc;     // output column
-                    f4 va = acc[i][j], vg = acc[i][j + 2];
-                    h4 o;
+                for (int jg = 0; jg < TN / 4; ++jg) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float a = va[r] * p.alpha, g = vg[r] * p.alpha;
-                        if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
-                        o[r] = (half_t)(a * gelu_erf(g));
+                    for (int j = 0; j < 2; ++j) {
+                        const int nloc = j * 16 + (lane >> 4) * 4;
+                        const int npk = n0 + wc * WTN + jg * 64 + nloc;           // packed column of the value
+                        const int nout = (n0 + wc * WTN + jg * 64) / 2 + nloc;    // output column
+                        f4 va = acc[i][jg * 4 + j], vg = acc[i][jg * 4 + j + 2];
+                        h4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float a = va[r] * p.alpha, g = vg[r] * p.alpha;
+                            if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
+                            o[r] = (half_t)(a * gelu_erf(g));
+                        }
+                        *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
                     }
-                    *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
                 }
             }
             continue;
@@ -346,17 +362,18 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
     }
 }
 
-template <int BM, int BN, int WR, int WC, bool GLDS>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
-    constexpr int SMEM = 2 * (BM + BN) * 128;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, GLDS>;
+    constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+    constexpr int NT = WR * WC * 64;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
     const int tiles = cdiv(p.M, BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(256), SMEM, s, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(NT), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -367,6 +384,45 @@ bool gemm_mfma_supported(const GemmP& p) {
     if ((p.flags & EP_GEGLU) && (p.N % 64)) return false;
     if (p.c0 % 8 || p.c1 % 8 || p.lda0 % 8 || (p.c1 > 0 && p.lda1 % 8) || p.ldw % 8) return false;
     return true;
+}
+
+// Tile configurations.  flop per byte staged into LDS = BM*BN/(BM+BN): the big 8-wave tiles exist because the
+// 128x128 tile (64 flop/B) saturates the L2 -> LDS path long before the MFMA pipe.
+enum GemmCfg {
+    CFG_128x128 = 0,      // 4 waves, BK 64, 64 KB LDS  (2 blocks/CU)
+    CFG_256x64 = 1,       // 4 waves, BK 64, 80 KB
+    CFG_64x64 = 2,        // 4 waves, BK 64, 32 KB      (deep, small-M levels)
+    CFG_128x128_K32 = 3,  // 4 waves, BK 32, 32 KB      (3+ blocks/CU)
+    CFG_256x256 = 4,      // 8 waves, BK 64, 128 KB
+    CFG_256x320 = 5,      // 8 waves, BK 64, 144 KB     (N = 320 / 640 / 1280 / 2560)
+    CFG_256x128 = 6,      // 8 waves, BK 64, 96 KB
+    CFG_128x64 = 7,       // 4 waves, BK 64, 48 KB
+    CFG_COUNT = 8
+};
+static const int kCfgBM[CFG_COUNT] = {128, 256, 64, 128, 256, 256, 256, 128};
+static const int kCfgBN[CFG_COUNT] = {128, 64, 64, 128, 256, 320, 128, 64};
+static const char* kCfgName[CFG_COUNT] = {"gemm_mfma_128x128", "gemm_mfma_256x64", "gemm_mfma_64x64", "gemm_mfma_128x128k32",
+                                          "gemm_mfma_256x256", "gemm_mfma_256x320", "gemm_mfma_256x128", "gemm_mfma_128x64"};
+
+int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
+
+static bool cfg_valid(int cfg, const GemmP& p) {
+    if (cfg < 0 || cfg >= CFG_COUNT) return false;
+    if (p.N % kCfgBN[cfg]) return false;
+    if ((p.flags & EP_GEGLU) && cfg == CFG_256x320) return false;      // wave tile 160 wide: not a multiple of 64
+    return true;
+}
+
+static int pick_cfg(const GemmP& p, int batch) {
+    if (g_force_gemm_cfg >= 0 && cfg_valid(g_force_gemm_cfg, p)) return g_force_gemm_cfg;
+    auto tiles = [&](int cfg) { return (long)cdiv(p.M, kCfgBM[cfg]) * (p.N / kCfgBN[cfg]) * batch; };
+    // prefer the largest tile (highest flop/byte into LDS) that still yields >= ~1 wave of workgroups on 256 CUs
+    const int order[] = {CFG_256x320, CFG_256x256, CFG_256x128, CFG_128x128, CFG_256x64, CFG_128x64, CFG_64x64};
+    for (int cfg : order)
+        if (cfg_valid(cfg, p) && tiles(cfg) >= 200) return cfg;
+    for (int cfg : {CFG_64x64, CFG_128x64, CFG_128x128})
+        if (cfg_valid(cfg, p)) return cfg;
+    return CFG_64x64;
 }
 
 int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s) {
@@ -389,24 +445,25 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    // tile choice: big 128x128 (or 256x64 when N is not a multiple of 128) while the grid still covers the chip,
-    // otherwise 64x64 tiles so the deep 8x8 / 16x16 levels keep >= 256 workgroups in flight.
-    const bool n128 = (p.N % 128) == 0;
-    const long big_tiles = n128 ? (long)cdiv(p.M, 128) * (p.N / 128) : (long)cdiv(p.M, 256) * (p.N / 64);
-    const bool small = big_tiles * batch < 192;
-#define SDMI_LAUNCH(BM, BN, WR, WC, NAME)                                                        \
-    {                                                                                            \
-        ProfScope ps(p.taps == 9 ? NAME "_conv3x3" : NAME "_1x1", pf_flops, pf_bytes, s);        \
-        return use_glds ? launch_cfg<BM, BN, WR, WC, true>(p, batch, s)                          \
-                        : launch_cfg<BM, BN, WR, WC, false>(p, batch, s);                        \
+    const int cfg = pick_cfg(p, batch);
+    const std::string pname = std::string(kCfgName[cfg]) + (p.taps == 9 ? "_conv3x3" : "_1x1");
+    ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);
+#define SDMI_CASE(ID, BM, BN, WR, WC, BK)                                                                    \
+    case ID:                                                                                                 \
+        return use_glds ? launch_cfg<BM, BN, WR, WC, BK, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, BK, false>(p, batch, s);
+    switch (cfg) {
+        SDMI_CASE(CFG_128x128, 128, 128, 2, 2, 64)
+        SDMI_CASE(CFG_256x64, 256, 64, 4, 1, 64)
+        SDMI_CASE(CFG_64x64, 64, 64, 4, 1, 64)
+        SDMI_CASE(CFG_128x128_K32, 128, 128, 2, 2, 32)
+        SDMI_CASE(CFG_256x256, 256, 256, 4, 2, 64)
+        SDMI_CASE(CFG_256x320, 256, 320, 4, 2, 64)
+        SDMI_CASE(CFG_256x128, 256, 128, 4, 2, 64)
+        SDMI_CASE(CFG_128x64, 128, 64, 4, 1, 64)
     }
-    if (small) SDMI_LAUNCH(64, 64, 4, 1, "gemm_mfma_64x64")
-    if (n128) SDMI_LAUNCH(128, 128, 2, 2, "gemm_mfma_128x128")
-    // N % 128 != 0 (e.g. 320): 256x64 tiles (80 KB of LDS); SDMI_TILE_N64=128 selects the 48 KB 128x64 variant instead
-    static const bool tile128 = [] { const char* e = getenv("SDMI_TILE_N64"); return e && atoi(e) == 128; }();
-    if (tile128) SDMI_LAUNCH(128, 64, 4, 1, "gemm_mfma_128x64")
-    SDMI_LAUNCH(256, 64, 4, 1, "gemm_mfma_256x64")
-#undef SDMI_LAUNCH
+#undef SDMI_CASE
+    set_error("bad gemm config");
+    return 1;
 }
 
 }  // namespace sdmi

@@ -29,8 +29,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const h
     const int tid = threadIdx.x;
     const int TP = VP < 256 ? VP : 256;          // threads across one pixel row
     const int R = 256 / TP;                      // pixel rows processed in parallel (R * C <= 2048 when R > 1)
-    for (int c = tid; c < R * C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
     const int p_begin = chunk * rows_per_chunk;
     const int p_end = min(HW, p_begin + rows_per_chunk);
     if (tid < TP * R) {
@@ -40,11 +38,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const h
             const half_t* src;
             int cc, ld;
             if (c < c0) { src = x0; cc = c; ld = c0; } else { src = x1; cc = c - c0; ld = c1; }
+            const half_t* base = src + (long)b * HW * ld + cc;
             float a[8], q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; }
-            for (int pix = p_begin + tr; pix < p_end; pix += R) {
-                const h8 v = *reinterpret_cast<const h8*>(src + ((long)b * HW + pix) * ld + cc);
+            int pix = p_begin + tr;
+            // 4 independent 16-byte loads in flight per thread (the pass is pure streaming: latency must be covered by ILP)
+            for (; pix + 3 * R < p_end; pix += 4 * R) {
+                h8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(base + (long)(pix + u * R) * ld);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; a[e] += f; q[e] = fmaf(f, f, q[e]); }
+            }
+            for (; pix < p_end; pix += R) {
+                const h8 v = *reinterpret_cast<const h8*>(base + (long)pix * ld);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; a[e] += f; q[e] = fmaf(f, f, q[e]); }
             }
@@ -67,64 +77,99 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
                                                        int groups, int nchunk, const float* partial,
                                                        const float* gamma, const float* beta, half_t* out, float eps,
                                                        int silu) {
+    __shared__ float s_scale[GN_MAX_C];
+    __shared__ float s_shift[GN_MAX_C];
     __shared__ float s_mean[64], s_rstd[64];
     const int C = c0 + c1, VP = C / 8, cpg = C / groups;
     const int b = blockIdx.y, tid = threadIdx.x;
-    if (tid < groups) {
-        // fixed-order fp32 reduction of the chunk partials (deterministic)
+    {
+        // 8 threads per group reduce the chunk partials in a fixed order (deterministic), then an 8-lane shuffle tree
+        const int g = tid >> 3, l8 = tid & 7;
         float a = 0.f, q = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const float* src = partial + (((long)b * nchunk + ch) * groups + tid) * 2;
-            a += src[0]; q += src[1];
+        if (g < groups)
+            for (int ch = l8; ch < nchunk; ch += 8) {
+                const float* src = partial + (((long)b * nchunk + ch) * groups + g) * 2;
+                a += src[0]; q += src[1];
+            }
+        for (int off = 4; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
+        if (g < groups && l8 == 0) {
+            const float n = (float)cpg * (float)HW;
+            const float mean = a / n;
+            const float var = fmaxf(q / n - mean * mean, 0.f);
+            s_mean[g] = mean;
+            s_rstd[g] = rsqrtf(var + eps);
         }
-        const float n = (float)cpg * (float)HW;
-        const float mean = a / n;
-        const float var = fmaxf(q / n - mean * mean, 0.f);
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * gamma[c];
+        s_scale[c] = sc;
+        s_shift[c] = beta[c] - s_mean[g] * sc;
     }
     __syncthreads();
     const long nvec = (long)HW * VP;
-    for (long i = (long)blockIdx.x * 256 + tid; i < nvec; i += (long)gridDim.x * 256) {
-        const int pix = (int)(i / VP), cv = (int)(i - (long)pix * VP);
-        const int c = cv * 8;
-        const half_t* src;
-        int cc, ld;
-        if (c < c0) { src = x0; cc = c; ld = c0; } else { src = x1; cc = c - c0; ld = c1; }
-        const h8 v = *reinterpret_cast<const h8*>(src + ((long)b * HW + pix) * ld + cc);
-        h8 o;
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + tid; i0 < nvec; i0 += 2 * stride) {
+        h8 v[2];
+        int cs[2];
+        long po[2];
+        bool ok[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ce = c + e, g = ce / cpg;
-            float y = ((float)v[e] - s_mean[g]) * s_rstd[g] * gamma[ce] + beta[ce];
-            if (silu) y = y / (1.0f + __expf(-y));
-            o[e] = (half_t)y;
+        for (int u = 0; u < 2; ++u) {
+            const long i = i0 + u * stride;
+            ok[u] = i < nvec;
+            const long ii = ok[u] ? i : 0;
+            const int pix = (int)(ii / VP), cv = (int)(ii - (long)pix * VP);
+            const int c = cv * 8;
+            cs[u] = c;
+            po[u] = ((long)b * HW + pix) * C + c;
+            const half_t* src;
+            int cc, ld;
+            if (c < c0) { src = x0; cc = c; ld = c0; } else { src = x1; cc = c - c0; ld = c1; }
+            v[u] = *reinterpret_cast<const h8*>(src + ((long)b * HW + pix) * ld + cc);
         }
-        *reinterpret_cast<h8*>(out + ((long)b * HW + pix) * C + c) = o;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const f4 sa = *reinterpret_cast<const f4*>(&s_scale[cs[u]]), sb = *reinterpret_cast<const f4*>(&s_scale[cs[u] + 4]);
+            const f4 ha = *reinterpret_cast<const f4*>(&s_shift[cs[u]]), hb = *reinterpret_cast<const f4*>(&s_shift[cs[u] + 4]);
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sc = e < 4 ? sa[e] : sb[e - 4], sh = e < 4 ? ha[e] : hb[e - 4];
+                float y = fmaf((float)v[u][e], sc, sh);
+                if (silu) y = y / (1.0f + __expf(-y));
+                o[e] = (half_t)y;
+            }
+            *reinterpret_cast<h8*>(out + po[u]) = o;
+        }
     }
 }
 
-static inline int gn_chunks(int HW) {
-    int n = HW / 128;              // >= 128 pixels per chunk
+static inline int gn_chunks(int B, int HW) {
+    // enough workgroups to fill 256 CUs several times over, but >= 32 pixels per chunk and <= 256 chunks
+    int n = (2048 + B - 1) / B;
+    if (n > HW / 32) n = HW / 32;
+    if (n > 256) n = 256;
     if (n < 1) n = 1;
-    if (n > 64) n = 64;
     return n;
 }
 
-int64_t groupnorm_ws_bytes(int B, int HW, int groups) { return (int64_t)B * gn_chunks(HW) * groups * 2 * sizeof(float); }
+int64_t groupnorm_ws_bytes(int B, int HW, int groups) { return (int64_t)B * gn_chunks(B, HW) * groups * 2 * sizeof(float); }
 
 int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
                      half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s) {
     const int C = c0 + c1;
     SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
-    SDMI_REQUIRE(C <= GN_MAX_C && groups <= 64 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 64, C % groups == 0");
-    const int nchunk = gn_chunks(HW);
+    SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
+    const int nchunk = gn_chunks(B, HW);
     const int rows = cdiv(HW, nchunk);
     ProfScope ps("groupnorm_silu", 0.0, 3.0 * B * (double)HW * C * 2.0, s);      // read twice + write once
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
     SDMI_CHECK_HIP(hipGetLastError());
     const long nvec = (long)HW * (C / 8);
-    int blocks = (int)std::min<long>((nvec + 255) / 256, 1024);
+    int blocks = (int)std::min<long>((nvec + 511) / 512, 2048);
     if ((long)blocks * B > 8192) blocks = std::max(1, 8192 / B);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
                        beta, out, eps, silu ? 1 : 0);

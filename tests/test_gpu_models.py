@@ -134,7 +134,8 @@ def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     res = processing.process_images(p)
     lat, img, u8 = opipe.txt2img(tiny["oracle"], cond, uncond, [1000, 1001], steps, sampler, 7.0, (16, 16))
     assert rel_l2(res.latents.cpu(), lat) < 1e-2, sampler
-    assert len(res.images) == 2 and res.images[0].shape == (128, 128, 3) and res.images[0].dtype == np.uint8
+    # the tiny VAE has 2 levels: 16x16 latent -> 32x32 image
+    assert len(res.images) == 2 and res.images[0].shape == (32, 32, 3) and res.images[0].dtype == np.uint8
     diff = np.abs(np.stack(res.images).astype(np.int32) - u8.astype(np.int32))
     assert diff.mean() < 2.0          # uint8 images agree to rounding of a few levels
 
@@ -158,7 +159,7 @@ def test_img2img_and_hires_paths_vs_oracle(dev, tiny):
     processing = sub("processing")
     model, om = tiny["model"], tiny["oracle"]
     cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
-    img = torch.rand((2, 3, 128, 128), generator=torch.Generator().manual_seed(9))
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(9))     # tiny VAE: /2 -> 16x16 latent
     p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=2000, batch_size=2, steps=4, cfg_scale=7.0,
                                                     width=128, height=128, sampler_name="Euler a", init_images=img,
                                                     denoising_strength=0.75)
