@@ -87,6 +87,8 @@ typedef struct sdmi_conv_desc {
     int64_t a_bs, w_bs, o_bs, r_bs;
     int32_t force_generic; /* 1: run the simple non-MFMA HIP kernel (debug / unsupported shapes) */
     int32_t reserved;
+    void* splitk_workspace;          /* optional fp32 scratch enabling deterministic split-K on small-M / large-K shapes */
+    int64_t splitk_workspace_bytes;  /* >= sdmi_conv_splitk_workspace_bytes(M, N, K, batch) or the workspace is ignored */
 } sdmi_conv_desc;
 
 enum {
@@ -96,6 +98,7 @@ enum {
     SDMI_EP_BIAS_ROW = 8    /* bias indexed by output row m instead of column n */
 };
 int sdmi_conv_gemm(const sdmi_conv_desc* d, void* stream);
+int64_t sdmi_conv_splitk_workspace_bytes(int M, int N, int K, int batch);
 
 /* Repack helpers (device side, run once at load): OIHW fp16/fp32 conv weight -> [O][ky*3+kx][I(+pad)] fp16. */
 int sdmi_pack_conv_weight(const void* w_oihw, int dtype, void* out_f16, int O, int I, int kh, int kw,

@@ -239,8 +239,14 @@ def sample_ddim(model, x, timesteps, alphas_cumprod, extra_args, noise_fn, eta=0
     return x
 
 
-def setup_img2img_steps(requested_steps: int, denoising_strength: float):
-    """modules/sd_samplers_common.py:22-31 with ``steps`` given (img2img_fix_steps path)."""
-    steps = int(requested_steps / min(denoising_strength, 0.999)) if denoising_strength > 0 else 0
-    t_enc = requested_steps - 1
+def setup_img2img_steps(requested_steps: int, denoising_strength: float, steps_given: bool = True):
+    """modules/sd_samplers_common.py:22-31.  ``steps_given`` = the caller passed ``steps`` (hires second pass,
+    processing.py:1454) -> first branch; plain img2img (processing.py:1774 passes no steps, img2img_fix_steps off) ->
+    second branch."""
+    if steps_given:
+        steps = int(requested_steps / min(denoising_strength, 0.999)) if denoising_strength > 0 else 0
+        t_enc = requested_steps - 1
+    else:
+        steps = requested_steps
+        t_enc = int(min(denoising_strength, 0.999) * steps)
     return steps, t_enc

@@ -40,7 +40,7 @@ def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, schedul
 @torch.no_grad()
 def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
            latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
-           y=None, uy=None, record=None):
+           y=None, uy=None, record=None, img2img_steps_given=True):
     """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
     (modules/sd_samplers_kdiffusion.py:134-143)."""
     b = len(seeds)
@@ -68,7 +68,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         sigmas = get_sigmas(wrap, sampler, steps)
         x = x * sigmas[0]
     else:
-        total, t_enc = kd.setup_img2img_steps(steps, denoising_strength)
+        total, t_enc = kd.setup_img2img_steps(steps, denoising_strength, img2img_steps_given)
         sigmas = get_sigmas(wrap, sampler, total)[total - t_enc - 1:]
         x = init_latent + x * sigmas[0]
     if sampler == "euler_a":
@@ -93,3 +93,15 @@ def txt2img(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", c
     lat = sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, latent_hw, **kw)
     img = decode(model, lat)
     return lat, img, to_uint8_hwc(img)
+
+
+@torch.no_grad()
+def txt2img_hires(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0, latent_hw=(64, 64),
+                  hr_scale=2.0, denoising_strength=0.75, mode="bilinear"):
+    """txt2img + latent hires fix (modules/processing.py:1349-1464): first pass, F.interpolate of the latent (not decoded),
+    fresh ImageRNG noise with the same seeds (:1429), second pass = sample_img2img with steps given (:1454)."""
+    first = sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, latent_hw)
+    th, tw = int(latent_hw[0] * hr_scale), int(latent_hw[1] * hr_scale)
+    up = torch.nn.functional.interpolate(first, size=(th, tw), mode=mode, antialias=False)
+    return sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, (th, tw), init_latent=up,
+                  denoising_strength=denoising_strength, img2img_steps_given=True)

@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("flags", C.c_int32), ("alpha", C.c_float), ("batch", C.c_int32),
         ("a_bs", C.c_int64), ("w_bs", C.c_int64), ("o_bs", C.c_int64), ("r_bs", C.c_int64),
         ("force_generic", C.c_int32), ("reserved", C.c_int32),
+        ("splitk_workspace", C.c_void_p), ("splitk_workspace_bytes", C.c_int64),
     ]
 
 
@@ -74,6 +75,7 @@ _SIGS = {
     "sdmi_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i64, _vp]),
     "sdmi_attention_vt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sdmi_conv_gemm": (_i, [C.POINTER(ConvDesc), _vp]),
+    "sdmi_conv_splitk_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "sdmi_bench_conv_gemm": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(C.c_float), _vp]),
     "sdmi_pack_conv_weight": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sdmi_groupnorm": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i64, _vp]),

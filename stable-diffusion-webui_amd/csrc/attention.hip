@@ -303,7 +303,7 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
     const double pf_bytes = 2.0 * p.B * p.H * ((double)p.N * p.D * 2 + (double)p.M * p.D * 2);
     ProfScope ps(force_generic ? "attention_generic" : (p.M > 128 ? "attention_mfma_self" : "attention_mfma_cross"), pf_flops, pf_bytes, s);
     const bool aligned = (p.ldq % 8 == 0) && (p.ldk % 8 == 0) && (p.vt_ld % 8 == 0) && (p.ldo % 4 == 0) && (p.D % 8 == 0);
-    const bool kvt128 = g_attn_kvt != 64;
+    const bool kvt128 = g_attn_kvt == 128;       // measured: 64-key tiles win for every head size (profiles/)
     if (!force_generic && aligned) {
         switch (p.D) {
             // KV tile: 128 keys where the register budget allows it (small heads: the per-tile barrier / staging

@@ -86,8 +86,12 @@ static int desc_to_p(const sdmi_conv_desc* d, GemmP* p) {
     p->flags = d->flags;
     p->alpha = d->alpha == 0.f ? 1.f : d->alpha;
     p->a_bs = d->a_bs; p->w_bs = d->w_bs; p->o_bs = d->o_bs; p->r_bs = d->r_bs;
+    const size_t need = gemm_splitk_ws_bytes(p->M, p->N, p->K, d->batch > 0 ? d->batch : 1);
+    if (d->splitk_workspace && need && (size_t)d->splitk_workspace_bytes >= need) p->splitk_ws = (float*)d->splitk_workspace;
     return 0;
 }
+
+int64_t sdmi_conv_splitk_workspace_bytes(int M, int N, int K, int batch) { return (int64_t)gemm_splitk_ws_bytes(M, N, K, batch); }
 
 int sdmi_conv_gemm(const sdmi_conv_desc* d, void* stream) {
     API_GUARD_BEGIN
@@ -297,6 +301,7 @@ int sdmi_debug_set(const char* name, int value) {
     const std::string n(name);
     if (n == "gemm_cfg") g_force_gemm_cfg = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
+    else if (n == "gemm_split") g_force_gemm_split = value;
     else { set_error("unknown debug knob " + n); return 1; }
     return 0;
     API_GUARD_END

@@ -62,13 +62,21 @@ struct GemmP {
     int flags;
     float alpha;
     long a_bs, w_bs, o_bs, r_bs;
+    // split-K (deterministic): grid.y = splitk slices of the K loop, each writing an fp32 partial slab ws[slice][M][N];
+    // splitk_reduce sums the slabs in slice order and applies the epilogue.  splitk <= 1: off.
+    float* splitk_ws;
+    int splitk;
+    int splitk_steps;     // BK-steps per slice
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8 };
 
 int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s);
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)
+// worst-case fp32 workspace a split-K launch of this shape may use (bytes); 0 when split-K would never be chosen
+size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch);
 extern int g_force_gemm_cfg;
+extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = force k slices where allowed
 extern int g_attn_kvt;
 
 // ---- attention --------------------------------------------------------------------------------------------

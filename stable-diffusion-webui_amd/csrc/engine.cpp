@@ -336,8 +336,15 @@ struct ConvArgs {
 };
 
 static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
+    // split-K slabs (only deep / small-M layers qualify); allocated in the dry pass too so the arena layout is identical
+    float* splitk_ws = nullptr;
+    if (!(a.flags & EP_NCHW) && !W.geglu) {
+        const size_t wsb = gemm_splitk_ws_bytes(a.B * a.Ho * a.Wo, W.n_pad, W.taps * (a.c0 + a.c1), a.batch);
+        if (wsb) splitk_ws = r.F(wsb / sizeof(float));
+    }
     if (r.dry) return 0;
     GemmP p{};
+    p.splitk_ws = splitk_ws;
     p.a0 = a.a0; p.a1 = a.a1; p.w = W.w; p.bias = W.b; p.rowbias = a.rowbias; p.resid = a.resid; p.out = a.out;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1; p.lda0 = a.c0; p.lda1 = a.c1;
     SDMI_REQUIRE(p.cin == W.cin_pad, "conv input channels do not match the packed weight");

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "prof.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace sdmi {
@@ -46,7 +47,20 @@ struct GRow {
     bool ok;
 };
 
-__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+// exact (erf) GELU as ldm's GEGLU uses (F.gelu default).  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below
+// the fp16 rounding of the result): the GEGLU epilogue evaluates it 64x per lane per tile, libm erff made it dominate
+// the K = 320 feed-forward GEMMs.
+__device__ __forceinline__ float gelu_erf(float g) {
+    const float x = fabsf(g) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = 1.0f - poly * t * __expf(-x * x);
+    const float erf_v = copysignf(erf_abs, g);
+    return 0.5f * g * (1.0f + erf_v);
+}
 
 // LDS swizzle: 16-byte chunk c of tile row r is stored in slot c ^ swz(r).  BK=64 (128-byte rows): r & 7.
 // BK=32 (64-byte rows, 4 rows per 256-byte bank row): f((r>>2)&3) with f = {0,2,3,1}, which makes every ds_read_b128
@@ -116,11 +130,21 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    int nk = p.K / BK;
+    int k_first = 0;                                     // first BK-step of this block (split-K slice)
+    if (p.splitk > 1) {
+        k_first = blockIdx.y * p.splitk_steps;
+        nk = min(nk - k_first, p.splitk_steps);
+    }
     uint4 ra[GLDS ? 1 : A_IT], rb[GLDS ? 1 : B_IT];
 
     // (tap, cbase) of the NEXT stage to issue; advanced incrementally (no integer division in the K loop)
     int nx_tap = 0, nx_cbase = 0, nx_k0 = 0;
+    if (k_first > 0) {
+        nx_k0 = k_first * BK;
+        nx_tap = nx_k0 / p.cin;
+        nx_cbase = nx_k0 - nx_tap * p.cin;
+    }
     auto stage_issue = [&](int sb) {
         const int tap = nx_tap, cbase = nx_cbase, k0 = nx_k0;
         nx_k0 += BK;
@@ -214,6 +238,20 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     // lane holds, for tile (i, j):  m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r
     const int flags = p.flags;
     const long ob = z * p.o_bs, rbs = z * p.r_bs;
+    if (p.splitk > 1) {
+        float* slab = p.splitk_ws + ((long)blockIdx.y * gridDim.z + z) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wr * WTM + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<f4*>(slab + (long)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wr * WTM + i * 16 + (lane & 15);
@@ -362,6 +400,46 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
     }
 }
 
+// Split-K second pass: out = epilogue(sum over slices, in slice order => bit-reproducible).  One thread per 4 columns.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) {
+    const long quads = (long)p.M * (p.N / 4);
+    const long total = quads * batch;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int z = (int)(idx / quads);
+        const long q = idx - (long)z * quads;
+        const int m = (int)(q / (p.N / 4)), n = (int)(q - (long)m * (p.N / 4)) * 4;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splitk; ++s)
+            v += *reinterpret_cast<const f4*>(p.splitk_ws + ((long)s * batch + z) * (long)p.M * p.N + (long)m * p.N + n);
+        const int b = m / p.rows_per_batch;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+        if (p.bias) {
+            if (p.flags & EP_BIAS_ROW) {
+                const float bb = p.bias[m];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bb;
+            } else {
+                v += *reinterpret_cast<const f4*>(p.bias + n);
+            }
+        }
+        if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+        if (p.resid) {
+            const h4 rr = *reinterpret_cast<const h4*>(p.resid + z * p.r_bs + (long)m * p.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        }
+        if (p.flags & EP_OUT_F32) {
+            *reinterpret_cast<f4*>((float*)p.out + z * p.o_bs + (long)m * p.ldo + n) = v;
+        } else {
+            h4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            *reinterpret_cast<h4*>((half_t*)p.out + z * p.o_bs + (long)m * p.ldo + n) = o;
+        }
+    }
+}
+
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
@@ -373,7 +451,7 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
         attr_set = true;
     }
     const int tiles = cdiv(p.M, BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, batch), dim3(NT), SMEM, s, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(NT), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -397,32 +475,74 @@ enum GemmCfg {
     CFG_256x320 = 5,      // 8 waves, BK 64, 144 KB     (N = 320 / 640 / 1280 / 2560)
     CFG_256x128 = 6,      // 8 waves, BK 64, 96 KB
     CFG_128x64 = 7,       // 4 waves, BK 64, 48 KB
-    CFG_COUNT = 8
+    CFG_128x320 = 8,      // 8 waves, BK 64, 112 KB     (mid levels: twice the tiles of 256x320 at 91 flop/B)
+    CFG_COUNT = 9
 };
-static const int kCfgBM[CFG_COUNT] = {128, 256, 64, 128, 256, 256, 256, 128};
-static const int kCfgBN[CFG_COUNT] = {128, 64, 64, 128, 256, 320, 128, 64};
+static const int kCfgBM[CFG_COUNT] = {128, 256, 64, 128, 256, 256, 256, 128, 128};
+static const int kCfgBN[CFG_COUNT] = {128, 64, 64, 128, 256, 320, 128, 64, 320};
 static const char* kCfgName[CFG_COUNT] = {"gemm_mfma_128x128", "gemm_mfma_256x64", "gemm_mfma_64x64", "gemm_mfma_128x128k32",
-                                          "gemm_mfma_256x256", "gemm_mfma_256x320", "gemm_mfma_256x128", "gemm_mfma_128x64"};
+                                          "gemm_mfma_256x256", "gemm_mfma_256x320", "gemm_mfma_256x128", "gemm_mfma_128x64",
+                                          "gemm_mfma_128x320"};
+// relative MFMA efficiency of each tile once the chip is full (measured, profiles/): used only to rank candidates
+static const float kCfgEff[CFG_COUNT] = {0.65f, 0.55f, 0.30f, 0.70f, 1.0f, 1.0f, 0.60f, 0.68f, 0.85f};
 
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
+
+int g_force_gemm_split = 0;
 
 static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;
     if (p.N % kCfgBN[cfg]) return false;
-    if ((p.flags & EP_GEGLU) && cfg == CFG_256x320) return false;      // wave tile 160 wide: not a multiple of 64
+    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320)) return false;   // wave tile not a multiple of 64
     return true;
 }
 
-static int pick_cfg(const GemmP& p, int batch) {
-    if (g_force_gemm_cfg >= 0 && cfg_valid(g_force_gemm_cfg, p)) return g_force_gemm_cfg;
-    auto tiles = [&](int cfg) { return (long)cdiv(p.M, kCfgBM[cfg]) * (p.N / kCfgBN[cfg]) * batch; };
-    // prefer the largest tile (highest flop/byte into LDS) that still yields >= ~1 wave of workgroups on 256 CUs
-    const int order[] = {CFG_256x320, CFG_256x256, CFG_256x128, CFG_128x128, CFG_256x64, CFG_128x64, CFG_64x64};
-    for (int cfg : order)
-        if (cfg_valid(cfg, p) && tiles(cfg) >= 200) return cfg;
-    for (int cfg : {CFG_64x64, CFG_128x64, CFG_128x128})
-        if (cfg_valid(cfg, p)) return cfg;
-    return CFG_64x64;
+// Expected relative throughput of (cfg, split): tile efficiency x chip fill (waves of 256 CUs, quantised) / split-K overhead.
+static float cfg_score(const GemmP& p, int batch, int cfg, int split) {
+    const long tiles = (long)cdiv(p.M, kCfgBM[cfg]) * (p.N / kCfgBN[cfg]) * batch * split;
+    const int cus = 256;
+    const float waves = (float)tiles / cus;
+    const float fill = waves <= 1.f ? waves : waves / ceilf(waves);          // tail-wave quantisation
+    float score = kCfgEff[cfg] * fill;
+    // short K loops are dominated by prologue / epilogue: favour the higher-occupancy 4-wave tiles there
+    const int ksteps = p.K / 64 / split;
+    if (ksteps < 8 && (cfg == CFG_256x256 || cfg == CFG_256x320 || cfg == CFG_128x320)) score *= 0.9f;
+    if (split > 1) {
+        // extra fp32 slab traffic (write + read) relative to the MFMA time of the launch at ~1 PFLOP/s x score
+        const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
+        const double t_mma = flops / (1.0e15 * (score > 0.05f ? score : 0.05f));
+        const double t_red = (double)split * p.M * p.N * batch * 8.0 / 3.0e12 + 3.0e-6;
+        score = (float)(score * t_mma / (t_mma + t_red));
+    }
+    return score;
+}
+
+static int pick_cfg(const GemmP& p, int batch, int* split_out, bool allow_split) {
+    *split_out = 1;
+    if (g_force_gemm_cfg >= 0 && cfg_valid(g_force_gemm_cfg, p)) {
+        if (allow_split && g_force_gemm_split > 1 && p.K / 64 / g_force_gemm_split >= 4) *split_out = g_force_gemm_split;
+        return g_force_gemm_cfg;
+    }
+    if (g_force_gemm_split == 1) allow_split = false;
+    const int cands[] = {CFG_256x320, CFG_256x256, CFG_128x320, CFG_128x128_K32, CFG_128x128, CFG_128x64, CFG_64x64};
+    int best = -1;
+    float best_score = -1.f;
+    const int nk = p.K / 64;
+    for (int cfg : cands) {
+        if (!cfg_valid(cfg, p)) continue;
+        for (int split : {1, 2, 3, 4, 6, 8}) {
+            if (split > 1 && (!allow_split || nk / split < 12)) break;
+            const float sc = cfg_score(p, batch, cfg, split);
+            if (sc > best_score * 1.03f) { best_score = sc; best = cfg; *split_out = split; }
+        }
+    }
+    return best >= 0 ? best : CFG_64x64;
+}
+
+size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch) {
+    if (K < 64 * 24 || N % 64) return 0;                    // split needs >= 12 BK-steps per slice
+    if ((long)cdiv(M, 128) * cdiv(N, 128) * batch >= 512) return 0;   // chip already full with ordinary tiles
+    return (size_t)8 * M * N * batch * sizeof(float);
 }
 
 int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s) {
@@ -445,12 +565,34 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    const int cfg = pick_cfg(p, batch);
-    const std::string pname = std::string(kCfgName[cfg]) + (p.taps == 9 ? "_conv3x3" : "_1x1");
+    int split = 1;
+    const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW)) && p.N % 4 == 0;
+    const int cfg = pick_cfg(p, batch, &split, can_split);
+    if (split > 1) {
+        const int nk = p.K / (cfg == CFG_128x128_K32 ? 32 : 64);
+        p.splitk_steps = cdiv(nk, split);
+        p.splitk = cdiv(nk, p.splitk_steps);
+        if (p.splitk <= 1) { p.splitk = 0; split = 1; }
+    } else {
+        p.splitk = 0;
+    }
+    const std::string pname = std::string(kCfgName[cfg]) + (split > 1 ? "_splitk" : "") + (p.taps == 9 ? "_conv3x3" : "_1x1");
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);
-#define SDMI_CASE(ID, BM, BN, WR, WC, BK)                                                                    \
-    case ID:                                                                                                 \
-        return use_glds ? launch_cfg<BM, BN, WR, WC, BK, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, BK, false>(p, batch, s);
+    struct Reduce {     // second pass of split-K runs when the main kernel has been enqueued (scope exit of the switch)
+        const GemmP& p; int batch; hipStream_t s; bool on;
+        int run() const {
+            if (!on) return 0;
+            const long total = (long)p.M * (p.N / 4) * batch;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, p, batch);
+            SDMI_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    } reduce{p, batch, s, split > 1};
+#define SDMI_CASE(ID, BM, BN, WR, WC, BK)                                                                       \
+    case ID:                                                                                                    \
+        if (use_glds ? launch_cfg<BM, BN, WR, WC, BK, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, BK, false>(p, batch, s)) \
+            return 1;                                                                                           \
+        return reduce.run();
     switch (cfg) {
         SDMI_CASE(CFG_128x128, 128, 128, 2, 2, 64)
         SDMI_CASE(CFG_256x64, 256, 64, 4, 1, 64)
@@ -460,6 +602,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_CASE(CFG_256x320, 256, 320, 4, 2, 64)
         SDMI_CASE(CFG_256x128, 256, 128, 4, 2, 64)
         SDMI_CASE(CFG_128x64, 128, 64, 4, 1, 64)
+        SDMI_CASE(CFG_128x320, 128, 320, 2, 4, 64)
     }
 #undef SDMI_CASE
     set_error("bad gemm config");

@@ -128,6 +128,10 @@ def conv_gemm(a0: torch.Tensor, w_packed: torch.Tensor, *, a1: Optional[torch.Te
     d.alpha = alpha
     d.batch = 1
     d.force_generic = {"mfma": 0, "generic": 1, "mfma_reg": 2}[impl]
+    wsb = lib.sdmi_conv_splitk_workspace_bytes(b * Ho * Wo, n, taps * (c0 + c1), 1)
+    if wsb and not geglu and not nchw_real:
+        ws = torch.empty(wsb, dtype=torch.uint8, device=a0.device)       # lets small-M / large-K shapes use split-K
+        d.splitk_workspace, d.splitk_workspace_bytes = ws.data_ptr(), wsb
     check(lib.sdmi_conv_gemm(C.byref(d), stream_ptr()), "sdmi_conv_gemm")
     return out
 

@@ -159,13 +159,23 @@ def test_img2img_and_hires_paths_vs_oracle(dev, tiny):
     processing = sub("processing")
     model, om = tiny["model"], tiny["oracle"]
     cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+    # plain img2img: no explicit steps -> t_enc = int(0.75 * steps) (modules/sd_samplers_common.py:28-29)
     img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(9))     # tiny VAE: /2 -> 16x16 latent
     p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=2000, batch_size=2, steps=4, cfg_scale=7.0,
                                                     width=128, height=128, sampler_name="Euler a", init_images=img,
                                                     denoising_strength=0.75)
     res = processing.process_images(p)
     init = om.vae.encode_first_stage_mean(img.half().float() * 2 - 1)
-    lat = opipe.sample(om, cond, uncond, [2000, 2001], 4, "euler_a", 7.0, (16, 16), init_latent=init, denoising_strength=0.75)
+    lat = opipe.sample(om, cond, uncond, [2000, 2001], 4, "euler_a", 7.0, (16, 16), init_latent=init, denoising_strength=0.75,
+                       img2img_steps_given=False)
+    assert rel_l2(res.latents.cpu(), lat) < 1.5e-2
+    # txt2img + latent hires fix x2: second pass is sample_img2img with steps given (26/19-style arithmetic)
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond, uc=uncond, seed=3000, batch_size=2, steps=4, cfg_scale=7.0,
+                                                    width=64, height=64, sampler_name="Euler a", enable_hr=True, hr_scale=2.0,
+                                                    denoising_strength=0.75)
+    res = processing.process_images(p)
+    lat = opipe.txt2img_hires(om, cond, uncond, [3000, 3001], 4, "euler_a", 7.0, (8, 8), hr_scale=2.0, denoising_strength=0.75)
+    assert res.latents.shape == lat.shape == (2, 4, 16, 16)
     assert rel_l2(res.latents.cpu(), lat) < 1.5e-2
 
 

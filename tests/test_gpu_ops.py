@@ -152,6 +152,27 @@ def test_linear_geglu_epilogue(dev, impl):
     assert rel_l2(got.float().cpu().reshape(rows, 4 * c), ref) < 8e-4
 
 
+@pytest.mark.parametrize("cfg,split", [(-1, 0), (0, 3), (5, 4), (8, 2), (3, 6), (4, 2)])
+def test_conv_gemm_split_k_is_exact_and_deterministic(dev, cfg, split):
+    """Deep-level shape (small M, K = 11520): split-K slices summed in slice order by the reduce pass, with the full
+    epilogue (bias + per-image emb add + residual).  Same result as torch, and bit-identical run to run."""
+    ops, lib = sub("ops"), sub("_lib")
+    B, H, W, cin, cout = 2, 8, 8, 1280, 1280
+    x, w = seeded((B, H, W, cin), 1), seeded((cout, cin, 3, 3), 2, scale=(cin * 9) ** -0.5)
+    b, rb, res = seeded((cout,), 3, 0.1), seeded((B, cout), 4), seeded((B, H, W, cout), 5)
+    ref = _conv_ref(h(x), h(w), b) + rb[:, None, None, :] + h(res)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
+    try:
+        args = dict(bias=b.to(dev), rowbias=rb.to(dev).contiguous(), resid=res.half().to(dev))
+        got = ops.conv_gemm(x.half().to(dev), wp, **args)
+        again = ops.conv_gemm(x.half().to(dev), wp, **args)
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
+    assert rel_l2(got.float().cpu(), ref) < 6e-4, (cfg, split)
+    assert torch.equal(got, again)
+
+
 def test_mfma_glds_and_register_staging_agree_bitwise(dev):
     """Same LDS image, same MFMA order => identical bits; catches any mismatch in the LDS-direct load path."""
     ops = sub("ops")

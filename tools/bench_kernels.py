@@ -38,6 +38,10 @@ def bench_conv(B, H, W, cin, cout, taps=9, stride=1, up=False, c1=0, geglu=False
     d.taps, d.stride, d.pad, d.up = taps, stride, 1 if taps == 9 else 0, 1 if up else 0
     d.N, d.ldo, d.flags, d.alpha, d.batch = cout, n_out, (lib.EP_GEGLU if geglu else 0), 1.0, 1
     d.force_generic = {"mfma": 0, "generic": 1, "mfma_reg": 2}[impl]
+    wsb = L.sdmi_conv_splitk_workspace_bytes(B * Ho * Wo, cout, taps * cin, 1)
+    if wsb and not geglu:
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        d.splitk_workspace, d.splitk_workspace_bytes = ws.data_ptr(), wsb
     ms = C.c_float(0)
     lib.check(L.sdmi_bench_conv_gemm(C.byref(d), iters, C.byref(ms), lib.stream_ptr()), "bench_conv")
     flops = 2.0 * B * Ho * Wo * cout * taps * cin
@@ -79,7 +83,7 @@ def bench_gn(B, HW, C, iters=20):
     return ms, 3.0 * x.numel() * 2 / (ms * 1e-3) / 1e12       # TB/s (read, read, write)
 
 
-CFG_NAMES = {-1: "auto", 0: "128x128", 1: "256x64", 2: "64x64", 3: "128x128k32", 4: "256x256", 5: "256x320", 6: "256x128", 7: "128x64"}
+CFG_NAMES = {-1: "auto", 0: "128x128", 1: "256x64", 2: "64x64", 3: "128x128k32", 4: "256x256", 5: "256x320", 6: "256x128", 7: "128x64", 8: "128x320"}
 
 
 def main():
@@ -105,14 +109,14 @@ def main():
             ("vae conv3x3 512->512 @128^2 B2", dict(B=2, H=128, W=128, cin=512, cout=512)),
             ("gemm 8192x8192x8192 (1x1)", dict(B=1, H=8192, W=1, cin=8192, cout=8192, taps=1)),
         ]
-        cfgs = [-1, 0, 3, 4, 5, 6, 1, 7, 2]
+        cfgs = [-1, 0, 3, 4, 5, 8, 7, 2]
         print("== implicit GEMM: TFLOP/s per tile config (glds); '-' = config does not fit the shape ==")
         print(f"{'shape':40s} | " + " | ".join(f"{CFG_NAMES[c]:>10s}" for c in cfgs) + " |   reg(auto)")
-        bn = {0: 128, 1: 64, 2: 64, 3: 128, 4: 256, 5: 320, 6: 128, 7: 64}
+        bn = {0: 128, 1: 64, 2: 64, 3: 128, 4: 256, 5: 320, 6: 128, 7: 64, 8: 320}
         for name, kw in shapes:
             cells = []
             for c in cfgs:
-                if c >= 0 and (kw["cout"] % bn[c] or (c == 5 and kw.get("geglu"))):
+                if c >= 0 and (kw["cout"] % bn[c] or (c in (5, 8) and kw.get("geglu"))):
                     cells.append(f"{'-':>10s}")
                     continue
                 lib.check(L.sdmi_debug_set(b"gemm_cfg", c))
@@ -129,6 +133,28 @@ def main():
             except Exception as e:                          # noqa: BLE001
                 cells.append("ERR")
             print(f"{name:40s} | " + " | ".join(cells), flush=True)
+    if what in ("split", "all"):
+        print("== split-K on the deep levels: TFLOP/s for (cfg, slices); slices=1 is the plain kernel ==")
+        deep = [("conv3x3 1280->1280 @16^2 B16", dict(B=16, H=16, W=16, cin=1280, cout=1280)),
+                ("conv3x3 1280->1280 @8^2 B16", dict(B=16, H=8, W=8, cin=1280, cout=1280)),
+                ("conv3x3 (1280+1280)->1280 @8^2", dict(B=16, H=8, W=8, cin=2560, cout=1280, c1=1280)),
+                ("conv3x3 (1280+640)->1280 @16^2", dict(B=16, H=16, W=16, cin=1920, cout=1280, c1=640))]
+        combos = [(c, sp) for c in (5, 8, 0, 3, 4) for sp in (1, 2, 3, 4, 6, 8)]
+        for name, kw in deep:
+            best = (0, None)
+            line = []
+            for c, sp in combos:
+                lib.check(L.sdmi_debug_set(b"gemm_cfg", c)); lib.check(L.sdmi_debug_set(b"gemm_split", sp))
+                try:
+                    ms, tf = bench_conv(impl="mfma", iters=10, **kw)
+                except Exception as e:                      # noqa: BLE001
+                    tf = 0.0
+                line.append(f"{CFG_NAMES[c]}/s{sp}:{tf:.0f}")
+                if tf > best[0]:
+                    best = (tf, f"{CFG_NAMES[c]}/s{sp}")
+            lib.check(L.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(L.sdmi_debug_set(b"gemm_split", 0))
+            ms, tf = bench_conv(impl="mfma", iters=10, **kw)
+            print(f"{name:36s} auto={tf:.0f}  best={best[1]}:{best[0]:.0f}\n      " + " ".join(line), flush=True)
     if what in ("attn", "all"):
         print("== flash attention (ms | TFLOP/s): KV tile heuristic vs forced 64 ==")
         for name, kw in [("self d40 N4096 B16 H8", dict(B=16, H=8, N=4096, M=4096, D=40)),
