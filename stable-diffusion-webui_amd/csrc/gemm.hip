@@ -71,7 +71,7 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     constexpr int NT = WR * WC * 64;
     constexpr int WTM = BM / WR, WTN = BN / WC;
@@ -252,75 +252,114 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         }
         return;
     }
+    // Two store paths.  fp32 / NCHW outputs (rare, small) are stored straight from the accumulator layout.  fp16
+    // row-major outputs — every activation tensor of the network — are staged through LDS (free after the K loop) so
+    // the global stores are 16 bytes per lane over whole contiguous rows instead of 8-byte pieces on 16 different rows.
+    const bool staged = !(flags & (EP_NCHW | EP_OUT_F32));
+    constexpr bool geglu = GEGLU;                            // compile-time: keeps the erf path out of the plain kernels
+    constexpr int bno = geglu ? BN / 2 : BN;                 // output columns of this tile
+    constexpr int ost = bno + 8;                             // LDS row stride in halves (+16 B: spreads rows over banks)
+    constexpr int SMEM_BYTES = 2 * STAGE;
+    constexpr int PASSES = (BM * (BN + 8) * 2 <= SMEM_BYTES) ? 1 : 2;
+    static_assert(PASSES == 1 || (WR % 2 == 0 && (BM / 2) * (BN + 8) * 2 <= SMEM_BYTES), "epilogue staging does not fit");
+    constexpr int ROWS_PP = BM / PASSES, WR_PP = WR / PASSES;
+    half_t* ot = reinterpret_cast<half_t*>(smem);
+
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wr * WTM + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const int b = m / p.rows_per_batch;
-        if (flags & EP_GEGLU) {
-            // every 64 packed columns = 32 values followed by their 32 gates: column tiles {4g, 4g+1} / {4g+2, 4g+3}
-            if constexpr (WTN % 64 == 0) {
+    for (int ps = 0; ps < PASSES; ++ps) {
+        if (wr / WR_PP == ps) {
+            const int wrl = wr % WR_PP;                      // wave row inside this pass
 #pragma unroll
-                for (int jg = 0; jg < TN / 4; ++jg) {
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wr * WTM + i * 16 + (lane & 15);
+                const bool mok = m < p.M;
+                const int mm = mok ? m : 0;
+                const int b = mm / p.rows_per_batch;
+                half_t* orow = ot + (long)(wrl * WTM + i * 16 + (lane & 15)) * ost;
+                if constexpr (geglu) {
+                    // every 64 packed columns = 32 values followed by their 32 gates: column tiles {4g, 4g+1} / {4g+2, 4g+3}
+                    if constexpr (WTN % 64 == 0) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int nloc = j * 16 + (lane >> 4) * 4;
-                        const int npk = n0 + wc * WTN + jg * 64 + nloc;           // packed column of the value
-                        const int nout = (n0 + wc * WTN + jg * 64) / 2 + nloc;    // output column
-                        f4 va = acc[i][jg * 4 + j], vg = acc[i][jg * 4 + j + 2];
+                        for (int jg = 0; jg < TN / 4; ++jg) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int nloc = j * 16 + (lane >> 4) * 4;
+                                const int npk = n0 + wc * WTN + jg * 64 + nloc;           // packed column of the value
+                                f4 va = acc[i][jg * 4 + j], vg = acc[i][jg * 4 + j + 2];
+                                h4 o;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    float a = va[r] * p.alpha, g = vg[r] * p.alpha;
+                                    if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
+                                    o[r] = (half_t)(a * gelu_erf(g));
+                                }
+                                *reinterpret_cast<h4*>(orow + (wc * WTN + jg * 64) / 2 + nloc) = o;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = wc * WTN + j * 16 + (lane >> 4) * 4;
+                    const int n = n0 + nl;
+                    f4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+                    if (p.bias) {
+                        if (flags & EP_BIAS_ROW) {
+                            const float bb = p.bias[mm];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += bb;
+                        } else {
+                            const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
+                            v += bb;
+                        }
+                    }
+                    if (p.rowbias) {
+                        const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+                        v += bb;
+                    }
+                    if (p.resid && mok) {
+                        const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                    }
+                    if (staged) {
                         h4 o;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float a = va[r] * p.alpha, g = vg[r] * p.alpha;
-                            if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
-                            o[r] = (half_t)(a * gelu_erf(g));
+                        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                        *reinterpret_cast<h4*>(orow + nl) = o;
+                    } else if (mok) {
+                        if (flags & EP_NCHW) {
+                            const int pix = m - b * p.rows_per_batch;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < p.n_real)
+                                    ((float*)p.out)[ob + ((long)b * p.n_real + n + r) * p.rows_per_batch + pix] = v[r];
+                        } else {
+                            *reinterpret_cast<f4*>((float*)p.out + ob + (long)m * p.ldo + n) = v;
                         }
-                        *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
                     }
                 }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
-            f4 v = acc[i][j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-            if (p.bias) {
-                if (flags & EP_BIAS_ROW) {
-                    const float bb = p.bias[m];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bb;
-                } else {
-                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
-                    v += bb;
                 }
             }
-            if (p.rowbias) {
-                const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
-                v += bb;
-            }
-            if (p.resid) {
-                const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
-            if (flags & EP_NCHW) {
-                const int pix = m - b * p.rows_per_batch;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.n_real)
-                        ((float*)p.out)[ob + ((long)b * p.n_real + n + r) * p.rows_per_batch + pix] = v[r];
-            } else if (flags & EP_OUT_F32) {
-                *reinterpret_cast<f4*>((float*)p.out + ob + (long)m * p.ldo + n) = v;
-            } else {
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
+        }
+        if (!staged) continue;
+        __syncthreads();
+        {
+            // coalesced copy-out of rows [ps*ROWS_PP, +ROWS_PP): 16 bytes per lane, consecutive lanes along a row
+            const int cpr = bno / 8;
+            const int n0o = geglu ? n0 / 2 : n0;
+            half_t* obase = (half_t*)p.out + ob;
+            for (int idx = tid; idx < ROWS_PP * cpr; idx += NT) {
+                const int r = idx / cpr, c = idx - r * cpr;
+                const int m = m0 + ps * ROWS_PP + r;
+                if (m < p.M)
+                    *reinterpret_cast<uint4*>(obase + (long)m * p.ldo + n0o + c * 8) =
+                        *reinterpret_cast<const uint4*>(ot + (long)r * ost + c * 8);
             }
         }
+        if (ps + 1 < PASSES) __syncthreads();
     }
 }
 
@@ -440,11 +479,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
-static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU>
+static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -454,6 +493,14 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(NT), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
+static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
+    if constexpr ((BN / WC) % 64 == 0) {
+        if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true>(p, batch, s);
+    }
+    return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false>(p, batch, s);
 }
 
 bool gemm_mfma_supported(const GemmP& p) {
@@ -484,7 +531,7 @@ static const char* kCfgName[CFG_COUNT] = {"gemm_mfma_128x128", "gemm_mfma_256x64
                                           "gemm_mfma_256x256", "gemm_mfma_256x320", "gemm_mfma_256x128", "gemm_mfma_128x64",
                                           "gemm_mfma_128x320"};
 // relative MFMA efficiency of each tile once the chip is full (measured, profiles/): used only to rank candidates
-static const float kCfgEff[CFG_COUNT] = {0.65f, 0.55f, 0.30f, 0.70f, 1.0f, 1.0f, 0.60f, 0.68f, 0.85f};
+static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f, 0.60f, 0.64f, 0.95f};
 
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
@@ -493,25 +540,35 @@ int g_force_gemm_split = 0;
 static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;
     if (p.N % kCfgBN[cfg]) return false;
+    if (cfg == CFG_256x64 || cfg == CFG_256x128) return false;         // measured never best: not instantiated
     if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320)) return false;   // wave tile not a multiple of 64
     return true;
 }
 
-// Expected relative throughput of (cfg, split): tile efficiency x chip fill (waves of 256 CUs, quantised) / split-K overhead.
+// workgroups of each config that fit on one CU (LDS-limited)
+static const int kCfgOcc[CFG_COUNT] = {2, 2, 4, 3, 1, 1, 1, 3, 1};
+
+// Expected relative throughput of (cfg, split): tile efficiency x chip fill / split-K overhead.  Fitted to the sweeps in
+// profiles/ (tools/bench_kernels.py): the first workgroup per CU brings ~80 % of a config's rate, co-resident ones the
+// rest; beyond one full residency the tail wave quantises; split-K slabs that fit the 256 MB Infinity Cache are cheap.
 static float cfg_score(const GemmP& p, int batch, int cfg, int split) {
-    const long tiles = (long)cdiv(p.M, kCfgBM[cfg]) * (p.N / kCfgBN[cfg]) * batch * split;
-    const int cus = 256;
-    const float waves = (float)tiles / cus;
-    const float fill = waves <= 1.f ? waves : waves / ceilf(waves);          // tail-wave quantisation
+    const float tiles = (float)((long)cdiv(p.M, kCfgBM[cfg]) * (p.N / kCfgBN[cfg]) * batch * split);
+    const float cus = 256.f, cap = cus * kCfgOcc[cfg];
+    float fill;
+    if (tiles <= cus) fill = 0.8f * tiles / cus;
+    else if (tiles <= cap) fill = 0.8f + 0.2f * (tiles - cus) / (cap - cus + 1e-3f);
+    else { const float w = tiles / cap; fill = w / ceilf(w); }
+    if (kCfgOcc[cfg] == 1 && tiles <= cus) fill = tiles / cus;
     float score = kCfgEff[cfg] * fill;
     // short K loops are dominated by prologue / epilogue: favour the higher-occupancy 4-wave tiles there
     const int ksteps = p.K / 64 / split;
-    if (ksteps < 8 && (cfg == CFG_256x256 || cfg == CFG_256x320 || cfg == CFG_128x320)) score *= 0.9f;
+    if (ksteps < 8 && kCfgOcc[cfg] == 1) score *= 0.9f;
     if (split > 1) {
-        // extra fp32 slab traffic (write + read) relative to the MFMA time of the launch at ~1 PFLOP/s x score
         const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
         const double t_mma = flops / (1.0e15 * (score > 0.05f ? score : 0.05f));
-        const double t_red = (double)split * p.M * p.N * batch * 8.0 / 3.0e12 + 3.0e-6;
+        const double slab_bytes = (double)split * p.M * p.N * batch * 4.0;
+        const double bw = slab_bytes < 128.0e6 ? 6.0e12 : 3.0e12;
+        const double t_red = 2.0 * slab_bytes / bw + 3.0e-6;
         score = (float)(score * t_mma / (t_mma + t_red));
     }
     return score;
@@ -595,12 +652,10 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         return reduce.run();
     switch (cfg) {
         SDMI_CASE(CFG_128x128, 128, 128, 2, 2, 64)
-        SDMI_CASE(CFG_256x64, 256, 64, 4, 1, 64)
         SDMI_CASE(CFG_64x64, 64, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x128_K32, 128, 128, 2, 2, 32)
         SDMI_CASE(CFG_256x256, 256, 256, 4, 2, 64)
         SDMI_CASE(CFG_256x320, 256, 320, 4, 2, 64)
-        SDMI_CASE(CFG_256x128, 256, 128, 4, 2, 64)
         SDMI_CASE(CFG_128x64, 128, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x320, 128, 320, 2, 4, 64)
     }
