@@ -252,114 +252,78 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         }
         return;
     }
-    // Two store paths.  fp32 / NCHW outputs (rare, small) are stored straight from the accumulator layout.  fp16
-    // row-major outputs — every activation tensor of the network — are staged through LDS (free after the K loop) so
-    // the global stores are 16 bytes per lane over whole contiguous rows instead of 8-byte pieces on 16 different rows.
-    const bool staged = !(flags & (EP_NCHW | EP_OUT_F32));
-    constexpr bool geglu = GEGLU;                            // compile-time: keeps the erf path out of the plain kernels
-    constexpr int bno = geglu ? BN / 2 : BN;                 // output columns of this tile
-    constexpr int ost = bno + 8;                             // LDS row stride in halves (+16 B: spreads rows over banks)
-    constexpr int SMEM_BYTES = 2 * STAGE;
-    constexpr int PASSES = (BM * (BN + 8) * 2 <= SMEM_BYTES) ? 1 : 2;
-    static_assert(PASSES == 1 || (WR % 2 == 0 && (BM / 2) * (BN + 8) * 2 <= SMEM_BYTES), "epilogue staging does not fit");
-    constexpr int ROWS_PP = BM / PASSES, WR_PP = WR / PASSES;
-    half_t* ot = reinterpret_cast<half_t*>(smem);
-
+    // Direct stores from the accumulator layout: each lane owns 4 consecutive output channels of one pixel (8-byte
+    // packed stores).  An LDS-staged, fully row-coalesced variant was measured 5-15 % SLOWER on the memory-bound 1x1
+    // layers (extra barriers + LDS round trip; L2 write-combining already merges the 8-byte pieces) — profiles/.
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-        if (wr / WR_PP == ps) {
-            const int wrl = wr % WR_PP;                      // wave row inside this pass
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * WTM + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = m / p.rows_per_batch;
+        if constexpr (GEGLU) {
+            // every 64 packed columns = 32 values followed by their 32 gates: column tiles {4g, 4g+1} / {4g+2, 4g+3}
+            if constexpr (WTN % 64 == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wr * WTM + i * 16 + (lane & 15);
-                const bool mok = m < p.M;
-                const int mm = mok ? m : 0;
-                const int b = mm / p.rows_per_batch;
-                half_t* orow = ot + (long)(wrl * WTM + i * 16 + (lane & 15)) * ost;
-                if constexpr (geglu) {
-                    // every 64 packed columns = 32 values followed by their 32 gates: column tiles {4g, 4g+1} / {4g+2, 4g+3}
-                    if constexpr (WTN % 64 == 0) {
+                for (int jg = 0; jg < TN / 4; ++jg) {
 #pragma unroll
-                        for (int jg = 0; jg < TN / 4; ++jg) {
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const int nloc = j * 16 + (lane >> 4) * 4;
-                                const int npk = n0 + wc * WTN + jg * 64 + nloc;           // packed column of the value
-                                f4 va = acc[i][jg * 4 + j], vg = acc[i][jg * 4 + j + 2];
-                                h4 o;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    float a = va[r] * p.alpha, g = vg[r] * p.alpha;
-                                    if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
-                                    o[r] = (half_t)(a * gelu_erf(g));
-                                }
-                                *reinterpret_cast<h4*>(orow + (wc * WTN + jg * 64) / 2 + nloc) = o;
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int nl = wc * WTN + j * 16 + (lane >> 4) * 4;
-                    const int n = n0 + nl;
-                    f4 v = acc[i][j];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-                    if (p.bias) {
-                        if (flags & EP_BIAS_ROW) {
-                            const float bb = p.bias[mm];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += bb;
-                        } else {
-                            const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
-                            v += bb;
-                        }
-                    }
-                    if (p.rowbias) {
-                        const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
-                        v += bb;
-                    }
-                    if (p.resid && mok) {
-                        const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                    }
-                    if (staged) {
+                    for (int j = 0; j < 2; ++j) {
+                        const int nloc = j * 16 + (lane >> 4) * 4;
+                        const int npk = n0 + wc * WTN + jg * 64 + nloc;           // packed column of the value
+                        const int nout = (n0 + wc * WTN + jg * 64) / 2 + nloc;    // output column
+                        f4 va = acc[i][jg * 4 + j], vg = acc[i][jg * 4 + j + 2];
                         h4 o;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                        *reinterpret_cast<h4*>(orow + nl) = o;
-                    } else if (mok) {
-                        if (flags & EP_NCHW) {
-                            const int pix = m - b * p.rows_per_batch;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (n + r < p.n_real)
-                                    ((float*)p.out)[ob + ((long)b * p.n_real + n + r) * p.rows_per_batch + pix] = v[r];
-                        } else {
-                            *reinterpret_cast<f4*>((float*)p.out + ob + (long)m * p.ldo + n) = v;
+                        for (int r = 0; r < 4; ++r) {
+                            float a = va[r] * p.alpha, g = vg[r] * p.alpha;
+                            if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
+                            o[r] = (half_t)(a * gelu_erf(g));
                         }
+                        *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
                     }
                 }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+            f4 v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if (p.bias) {
+                if (flags & EP_BIAS_ROW) {
+                    const float bb = p.bias[m];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bb;
+                } else {
+                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
+                    v += bb;
                 }
             }
-        }
-        if (!staged) continue;
-        __syncthreads();
-        {
-            // coalesced copy-out of rows [ps*ROWS_PP, +ROWS_PP): 16 bytes per lane, consecutive lanes along a row
-            const int cpr = bno / 8;
-            const int n0o = geglu ? n0 / 2 : n0;
-            half_t* obase = (half_t*)p.out + ob;
-            for (int idx = tid; idx < ROWS_PP * cpr; idx += NT) {
-                const int r = idx / cpr, c = idx - r * cpr;
-                const int m = m0 + ps * ROWS_PP + r;
-                if (m < p.M)
-                    *reinterpret_cast<uint4*>(obase + (long)m * p.ldo + n0o + c * 8) =
-                        *reinterpret_cast<const uint4*>(ot + (long)r * ost + c * 8);
+            if (p.rowbias) {
+                const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+                v += bb;
+            }
+            if (p.resid) {
+                const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (flags & EP_NCHW) {
+                const int pix = m - b * p.rows_per_batch;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.n_real)
+                        ((float*)p.out)[ob + ((long)b * p.n_real + n + r) * p.rows_per_batch + pix] = v[r];
+            } else if (flags & EP_OUT_F32) {
+                *reinterpret_cast<f4*>((float*)p.out + ob + (long)m * p.ldo + n) = v;
+            } else {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
             }
         }
-        if (ps + 1 < PASSES) __syncthreads();
     }
 }
 

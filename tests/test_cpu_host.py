@@ -156,7 +156,11 @@ WORKER = textwrap.dedent("""
 def test_weight_broadcast_and_gather_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
+    import socket
+    with socket.socket() as sk:                       # a free port: avoids clashes with other jobs on the host
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
