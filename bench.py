@@ -82,7 +82,7 @@ def roofline_block(args, run_once):
     lib.check(lib.lib.sdmi_profile_begin(), "profile_begin")
     run_once()
     torch.cuda.synchronize()
-    buf = ctypes.create_string_buffer(1 << 16)
+    buf = ctypes.create_string_buffer(1 << 20)
     lib.check(lib.lib.sdmi_profile_end(buf, len(buf)), "profile_end")
     kernels = json.loads(buf.value.decode())["kernels"]
     fam = [k for k in kernels if k["name"].startswith("gemm_mfma")]

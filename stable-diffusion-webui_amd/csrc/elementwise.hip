@@ -290,38 +290,56 @@ int launch_timestep_embedding(const void* t, int dtype, float* out, int B, int d
     return 0;
 }
 
-// one wave per output element (b, n); K is split across lanes in 8-wide fp16 vectors of the weight row
+// one wave per output column n, ALL batch rows: the weight row is read once (51 MB for the fused ResBlock emb projection of
+// SD1.5 — the earlier one-wave-per-(b, n) version re-read it B times: 265 MB / launch in the PMC profile).
+template <int BMAX>
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* a, const half_t* w, const float* bias, const float* add,
                                                           float* out, int B, int N, int K, int lda, int ldo, int silu_in,
                                                           int silu_out) {
     const int lane = threadIdx.x & 63;
-    const long widx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (widx >= (long)B * N) return;
-    const int b = (int)(widx / N), n = (int)(widx - (long)b * N);
-    const float* ar = a + (long)b * lda;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
     const half_t* wr = w + (long)n * K;
-    float acc = 0.f;
-    for (int k = lane * 8; k < K; k += 64 * 8) {
-        const h8 wv = *reinterpret_cast<const h8*>(wr + k);
+    for (int b0 = 0; b0 < B; b0 += BMAX) {
+        float acc[BMAX];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float av = ar[k + e];
-            if (silu_in) av = av / (1.0f + expf(-av));
-            acc = fmaf(av, (float)wv[e], acc);
+        for (int i = 0; i < BMAX; ++i) acc[i] = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const h8 wv = *reinterpret_cast<const h8*>(wr + k);
+            float wf[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[e] = (float)wv[e];
+#pragma unroll
+            for (int i = 0; i < BMAX; ++i) {
+                if (b0 + i < B) {
+                    const float* ar = a + (long)(b0 + i) * lda + k;
+                    const f4 a0 = *reinterpret_cast<const f4*>(ar), a1 = *reinterpret_cast<const f4*>(ar + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float av = e < 4 ? a0[e] : a1[e - 4];
+                        if (silu_in) av = av / (1.0f + expf(-av));
+                        acc[i] = fmaf(av, wf[e], acc[i]);
+                    }
+                }
+            }
         }
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) {
-        float v = acc + (bias ? bias[n] : 0.f);
-        if (silu_out) v = v / (1.0f + expf(-v));
-        if (add) v += add[(long)b * ldo + n];
-        out[(long)b * ldo + n] = v;
+#pragma unroll
+        for (int i = 0; i < BMAX; ++i) {
+            float v = acc[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && b0 + i < B) {
+                v += bias ? bias[n] : 0.f;
+                if (silu_out) v = v / (1.0f + expf(-v));
+                if (add) v += add[(long)(b0 + i) * ldo + n];
+                out[(long)(b0 + i) * ldo + n] = v;
+            }
+        }
     }
 }
 int launch_small_linear(const float* a, const half_t* w, const float* bias, const float* add, float* out, int B, int N, int K,
                         int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s) {
-    SDMI_REQUIRE(K % 8 == 0, "small_linear: K % 8 == 0");
-    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv((int64_t)B * N, 4)), dim3(256), 0, s, a, w, bias, add, out, B, N, K, lda, ldo,
+    SDMI_REQUIRE(K % 8 == 0 && lda % 4 == 0, "small_linear: K % 8 == 0, lda % 4 == 0");
+    hipLaunchKernelGGL(small_linear_kernel<16>, dim3(cdiv(N, 4)), dim3(256), 0, s, a, w, bias, add, out, B, N, K, lda, ldo,
                        silu_in ? 1 : 0, silu_out ? 1 : 0);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;

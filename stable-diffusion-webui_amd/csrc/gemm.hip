@@ -597,7 +597,12 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     } else {
         p.splitk = 0;
     }
-    const std::string pname = std::string(kCfgName[cfg]) + (split > 1 ? "_splitk" : "") + (p.taps == 9 ? "_conv3x3" : "_1x1");
+    std::string pname;
+    if (prof_enabled()) {
+        pname = std::string(kCfgName[cfg]) + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
+                ((p.flags & EP_GEGLU) ? "_geglu" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
+                (batch > 1 ? " x" + std::to_string(batch) : "");
+    }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);
     struct Reduce {     // second pass of split-K runs when the main kernel has been enqueued (scope exit of the switch)
         const GemmP& p; int batch; hipStream_t s; bool on;

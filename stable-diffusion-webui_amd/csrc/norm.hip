@@ -169,8 +169,9 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
     SDMI_CHECK_HIP(hipGetLastError());
     const long nvec = (long)HW * (C / 8);
-    int blocks = (int)std::min<long>((nvec + 511) / 512, 2048);
-    if ((long)blocks * B > 8192) blocks = std::max(1, 8192 / B);
+    // >= 16 vectors per thread so the per-workgroup prologue (partials -> mean/rstd -> per-channel scale/shift in LDS) is
+    // amortised, while keeping ~4 workgroups per CU in flight
+    int blocks = (int)std::max<long>(1, std::min<long>(nvec / (256 * 16), std::max(1, 1024 / B)));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
                        beta, out, eps, silu ? 1 : 0);
     SDMI_CHECK_HIP(hipGetLastError());

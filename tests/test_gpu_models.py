@@ -202,3 +202,49 @@ def test_sd15_full_size_unet_single_forward_vs_oracle(dev):
     torch.cuda.synchronize()
     assert rel_l2(got.cpu(), ref) < 5e-3
     eng.close()
+
+
+def test_sdxl_shaped_unet_vs_oracle(dev):
+    """SDXL-style UNet features (configs/sd_xl_inpaint.yaml:19-37; modules/sd_models_xl.py:12-43): vector conditioning y ->
+    label_emb, Linear proj_in/proj_out, per-level transformer depth > 1, head size 64, no attention at level 0."""
+    schema = sub("schema")
+    from oracle import unet as ou
+    kw = dict(model_channels=64, channel_mult=(1, 2, 4), num_res_blocks=2, attention_resolutions=(2, 4), num_heads=-1,
+              num_head_channels=64, transformer_depth=(1, 2, 3), context_dim=128, use_linear_in_transformer=True,
+              adm_in_channels=192)
+    cfg = schema.UNetConfig(**kw)
+    sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
+    net = ou.build_unet(ou.UNetConfig(**kw), sd)
+    eng = sub("engine").Engine(0)
+    eng.load_unet(cfg, sd)
+    x, t = seeded((2, 4, 32, 32), 1), torch.tensor([911.0, 45.5])
+    ctx, y = seeded((2, 77, 128), 2), seeded((2, 192), 3)
+    with torch.no_grad():
+        ref = net(x, t, ctx.half().float(), y)
+    got = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev), y.to(dev))
+    torch.cuda.synchronize()
+    assert rel_l2(got.cpu(), ref) < 5e-3
+    eng.close()
+
+
+def test_c0_shape_sd15_256px_b1_euler_a_5_steps(dev):
+    """BASELINE.json configs[0]: SD1.5 txt2img 256x256, 5-step Euler-a, batch 1 — full architecture, final latent vs oracle."""
+    schema, processing = sub("schema"), sub("processing")
+    from oracle import pipeline as opipe, unet as ou
+    cfg = schema.sd15_unet()
+    sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
+    model = sub("sd_models").SdModel(sd, cfg, None, device=0, load_vae=False)
+    om = opipe.OracleModel(sd, ou.sd15_config(), None)
+    g = torch.Generator().manual_seed(21)
+    cond, uncond = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    sampler = sub("sd_samplers").create_sampler("Euler a", model)
+
+    class P:
+        steps, cfg_scale, eta, scheduler, is_hr_pass = 5, 7.0, None, None, False
+        sampler_noise_scheduler_override = None
+        rng = sub("rng").ImageRNG((4, 32, 32), [1000], device=dev)
+    p = P()
+    got = sampler.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev))
+    ref = opipe.sample(om, cond, uncond, [1000], 5, "euler_a", 7.0, (32, 32))
+    assert rel_l2(got.cpu(), ref) < 1e-2
+    model.engine.close()
