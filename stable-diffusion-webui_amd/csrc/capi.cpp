@@ -302,6 +302,7 @@ int sdmi_debug_set(const char* name, int value) {
     if (n == "gemm_cfg") g_force_gemm_cfg = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "gemm_split") g_force_gemm_split = value;
+    else if (n == "gemm_pipe") g_gemm_pipe = value;
     else { set_error("unknown debug knob " + n); return 1; }
     return 0;
     API_GUARD_END

@@ -62,6 +62,107 @@ __device__ __forceinline__ float gelu_erf(float g) {
     return 0.5f * g * (1.0f + erf_v);
 }
 
+// Epilogue shared by the GEMM kernels.  Lane holds, for accumulator tile (i, j):
+//   m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive channels)
+template <int TM, int TN, int WTM, int WTN, bool GEGLU>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z) {
+    // ---- epilogue ----------------------------------------------------------------------------------------
+    // lane holds, for tile (i, j):  m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r
+    const int flags = p.flags;
+    const long ob = z * p.o_bs, rbs = z * p.r_bs;
+    if (p.splitk > 1) {
+        float* slab = p.splitk_ws + ((long)blockIdx.y * gridDim.z + z) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wr * WTM + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<f4*>(slab + (long)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    // Direct stores from the accumulator layout: each lane owns 4 consecutive output channels of one pixel (8-byte
+    // packed stores).  An LDS-staged, fully row-coalesced variant was measured 5-15 % SLOWER on the memory-bound 1x1
+    // layers (extra barriers + LDS round trip; L2 write-combining already merges the 8-byte pieces) — profiles/.
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * WTM + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = m / p.rows_per_batch;
+        if constexpr (GEGLU) {
+            // every 64 packed columns = 32 values followed by their 32 gates: column tiles {4g, 4g+1} / {4g+2, 4g+3}
+            if constexpr (WTN % 64 == 0) {
+#pragma unroll
+                for (int jg = 0; jg < TN / 4; ++jg) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int nloc = j * 16 + (lane >> 4) * 4;
+                        const int npk = n0 + wc * WTN + jg * 64 + nloc;           // packed column of the value
+                        const int nout = (n0 + wc * WTN + jg * 64) / 2 + nloc;    // output column
+                        f4 va = acc[i][jg * 4 + j], vg = acc[i][jg * 4 + j + 2];
+                        f4 ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias) {
+                            ba = *reinterpret_cast<const f4*>(p.bias + npk);
+                            bg = *reinterpret_cast<const f4*>(p.bias + npk + 32);
+                        }
+                        h4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = fmaf(va[r], p.alpha, ba[r]), g = fmaf(vg[r], p.alpha, bg[r]);
+                            o[r] = (half_t)(a * gelu_erf(g));
+                        }
+                        *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+            f4 v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if (p.bias) {
+                if (flags & EP_BIAS_ROW) {
+                    const float bb = p.bias[m];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += bb;
+                } else {
+                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
+                    v += bb;
+                }
+            }
+            if (p.rowbias) {
+                const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+                v += bb;
+            }
+            if (p.resid) {
+                const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (flags & EP_NCHW) {
+                const int pix = m - b * p.rows_per_batch;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.n_real)
+                        ((float*)p.out)[ob + ((long)b * p.n_real + n + r) * p.rows_per_batch + pix] = v[r];
+            } else if (flags & EP_OUT_F32) {
+                *reinterpret_cast<f4*>((float*)p.out + ob + (long)m * p.ldo + n) = v;
+            } else {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
 // LDS swizzle: 16-byte chunk c of tile row r is stored in slot c ^ swz(r).  BK=64 (128-byte rows): r & 7.
 // BK=32 (64-byte rows, 4 rows per 256-byte bank row): f((r>>2)&3) with f = {0,2,3,1}, which makes every ds_read_b128
 // lane group {(rows 0-3,c),(rows 12-15,c),(rows 4-11,c^1)} land on 16 distinct 16-byte slots.
@@ -234,97 +335,180 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         __syncthreads();
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------------------
-    // lane holds, for tile (i, j):  m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r
-    const int flags = p.flags;
-    const long ob = z * p.o_bs, rbs = z * p.r_bs;
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wr, wc, lane, z);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Deep-pipelined variant (the default for the large tiles).  The two-stage kernel above drains every load
+// (s_waitcnt vmcnt(0)) once per K step, so each step pays a full L2/HBM round trip that one workgroup per CU cannot
+// hide (measured 2.9 us per 64-deep step of a 256x320 tile = 37 % of the MFMA rate).  Here K advances in BK = 32
+// stages through an NS-deep LDS ring with NS-1 stages of LDS-direct loads in flight at all times:
+//   iteration kt:  s_waitcnt vmcnt((NS-2) * loads_per_stage)   -- only stage kt has to have landed (COUNTED, never 0
+//                                                                  in steady state)
+//                  s_barrier                                    -- every wave's share of stage kt is visible; every wave
+//                                                                  has finished reading stage kt-1's buffer
+//                  issue stage kt+NS-1 into the buffer stage kt-1 just vacated
+//                  MFMAs of stage kt
+// One raw s_barrier per stage, no __syncthreads() (which would drain the DMA queue).  RAW: a stage is read only after
+// the issuing waves' counted vmcnt + a barrier; WAR: a buffer is refilled only after the barrier that follows its
+// last read.  The ISA of the loop is checked for the absence of vmcnt(0) in tests/ (CPU side, llvm-objdump).
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WR, int WC, int NS, bool GEGLU>
+__global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_pipe_kernel(GemmP p) {
+    constexpr int BK = 32, NT = WR * WC * 64;
+    constexpr int WTM = BM / WR, WTN = BN / WC;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int CPR = 4, ROWB = 64;
+    constexpr int A_CH = BM * CPR, B_CH = BN * CPR;
+    constexpr int A_IT = (A_CH + NT - 1) / NT, B_IT = (B_CH + NT - 1) / NT;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr bool A_EVEN = A_CH % NT == 0, B_EVEN = B_CH % NT == 0;
+    static_assert(A_EVEN || B_EVEN, "at most one operand may have a partial last load iteration");
+    static_assert((A_CH % 64 == 0) && (B_CH % 64 == 0), "whole waves only");
+    constexpr int LPT_FULL = A_IT + B_IT;                 // loads per thread per stage (waves in the partial tail: one less)
+    static_assert((NS - 2) * LPT_FULL < 64, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar branches, SGPR LDS bases
+    const int wr = wave / WC, wc = wave % WC;
+
+    const int tiles_n = p.N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, sub = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sub;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const long z = blockIdx.z;
+    const half_t* a0 = p.a0 + z * p.a_bs;
+    const half_t* a1 = p.a1 ? p.a1 + z * p.a_bs : nullptr;
+    const half_t* wbase = p.w + z * p.w_bs;
+
+    // wave-uniform: does this wave take part in the (possibly partial) last load iteration of A / B ?
+    const bool a_last = A_EVEN || ((A_IT - 1) * NT + wave * 64 < A_CH);
+    const bool b_last = B_EVEN || ((B_IT - 1) * NT + wave * 64 < B_CH);
+    const bool full_wave = a_last && b_last;
+
+    GRow rows[A_IT];
+    const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int idx = it * NT + tid;
+        const int m = m0 + idx / CPR;
+        GRow gr;
+        gr.ok = m < p.M && idx < A_CH;
+        const int mm = gr.ok ? m : 0;
+        const int b = mm / p.rows_per_batch;
+        const int rem = mm - b * p.rows_per_batch;
+        const int yo = rem / p.Wo;
+        const int xo = rem - yo * p.Wo;
+        gr.yb = p.up ? yo - 1 : yo * p.stride - p.pad;
+        gr.xb = p.up ? xo - 1 : xo * p.stride - p.pad;
+        gr.pixbase = b * p.Hi * p.Wi;
+        rows[it] = gr;
+    }
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    int nk = p.K / BK;
+    int k_first = 0;
     if (p.splitk > 1) {
-        float* slab = p.splitk_ws + ((long)blockIdx.y * gridDim.z + z) * (long)p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wr * WTM + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
-                *reinterpret_cast<f4*>(slab + (long)m * p.N + n) = acc[i][j];
-            }
-        }
-        return;
+        k_first = blockIdx.y * p.splitk_steps;
+        nk = min(nk - k_first, p.splitk_steps);
     }
-    // Direct stores from the accumulator layout: each lane owns 4 consecutive output channels of one pixel (8-byte
-    // packed stores).  An LDS-staged, fully row-coalesced variant was measured 5-15 % SLOWER on the memory-bound 1x1
-    // layers (extra barriers + LDS round trip; L2 write-combining already merges the 8-byte pieces) — profiles/.
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wr * WTM + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const int b = m / p.rows_per_batch;
-        if constexpr (GEGLU) {
-            // every 64 packed columns = 32 values followed by their 32 gates: column tiles {4g, 4g+1} / {4g+2, 4g+3}
-            if constexpr (WTN % 64 == 0) {
-#pragma unroll
-                for (int jg = 0; jg < TN / 4; ++jg) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int nloc = j * 16 + (lane >> 4) * 4;
-                        const int npk = n0 + wc * WTN + jg * 64 + nloc;           // packed column of the value
-                        const int nout = (n0 + wc * WTN + jg * 64) / 2 + nloc;    // output column
-                        f4 va = acc[i][jg * 4 + j], vg = acc[i][jg * 4 + j + 2];
-                        h4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float a = va[r] * p.alpha, g = vg[r] * p.alpha;
-                            if (p.bias) { a += p.bias[npk + r]; g += p.bias[npk + 32 + r]; }
-                            o[r] = (half_t)(a * gelu_erf(g));
-                        }
-                        *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
-                    }
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
-            f4 v = acc[i][j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-            if (p.bias) {
-                if (flags & EP_BIAS_ROW) {
-                    const float bb = p.bias[m];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bb;
-                } else {
-                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
-                    v += bb;
-                }
-            }
-            if (p.rowbias) {
-                const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
-                v += bb;
-            }
-            if (p.resid) {
-                const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
-            if (flags & EP_NCHW) {
-                const int pix = m - b * p.rows_per_batch;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.n_real)
-                        ((float*)p.out)[ob + ((long)b * p.n_real + n + r) * p.rows_per_batch + pix] = v[r];
-            } else if (flags & EP_OUT_F32) {
-                *reinterpret_cast<f4*>((float*)p.out + ob + (long)m * p.ldo + n) = v;
-            } else {
-                h4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
-            }
-        }
+    int nx_tap = 0, nx_cbase = 0, nx_k0 = 0;
+    if (k_first > 0) {
+        nx_k0 = k_first * BK;
+        nx_tap = nx_k0 / p.cin;
+        nx_cbase = nx_k0 - nx_tap * p.cin;
     }
+
+    auto stage_issue = [&](int sb) {
+        const int tap = nx_tap, cbase = nx_cbase, k0 = nx_k0;
+        nx_k0 += BK;
+        nx_cbase += BK;
+        if (nx_cbase >= p.cin) { nx_cbase = 0; ++nx_tap; }
+        const bool first = cbase < p.c0;
+        const half_t* src = first ? a0 : a1;
+        const int cch = first ? cbase : cbase - p.c0;
+        const int lda = first ? p.lda0 : p.lda1;
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = (tap * 11) >> 5; dx = tap - dy * 3; }
+        char* abuf = smem + sb * STAGE;
+        char* bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            if (it == A_IT - 1 && !a_last) break;                     // wave-uniform
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
+            const GRow gr = rows[it];
+            const int yr = gr.yb + dy, xr = gr.xb + dx;
+            const bool ok = gr.ok && (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
+            const int pix = gr.pixbase + (yr >> p.up) * p.Wi + (xr >> p.up);
+            const half_t* g = ok ? src + (long)pix * lda + (cch + c * 8) : p.zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (it * NT + wave * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            if (it == B_IT - 1 && !b_last) break;                     // wave-uniform
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
+            const half_t* g = (n0 + r < p.n_valid) ? wbase + (long)(n0 + r) * p.ldw + k0 + c * 8 : p.zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbuf + (it * NT + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    auto compute = [&](int sb) {
+        const char* abuf = smem + sb * STAGE;
+        const char* bbuf = abuf + A_BYTES;
+        const int lr = lane & 15, lk = lane >> 4;
+        const int sw = (lk ^ swz<BK>(lr)) << 4;
+        h8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(abuf + (wr * WTM + i * 16 + lr) * ROWB + sw);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(bbuf + (wc * WTN + j * 16 + lr) * ROWB + sw);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: NS-1 stages in flight ---------------------------------------------------------------------
+    const int pre = nk < NS - 1 ? nk : NS - 1;
+    for (int st = 0; st < pre; ++st) stage_issue(st);
+    // ---- main loop ---------------------------------------------------------------------------------------------
+    int buf = 0;                                          // ring slot of stage kt
+    int nxt = pre % NS;                                   // ring slot the next issued stage goes to
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + NS - 2 <= nk - 1) {                      // steady state: NS-2 younger stages may stay in flight
+            if (full_wave) wait_vmcnt<(NS - 2) * LPT_FULL>();
+            else wait_vmcnt<(NS - 2) * (LPT_FULL - 1)>();
+        } else {
+            wait_vmcnt<0>();                              // tail: fewer stages were issued behind this one
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NS - 1 < nk) {
+            stage_issue(nxt);
+            nxt = nxt + 1 == NS ? 0 : nxt + 1;
+        }
+        compute(buf);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wr, wc, lane, z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -459,6 +643,29 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     return 0;
 }
 
+template <int BM, int BN, int WR, int WC, int NS, bool GEGLU>
+static int launch_pipe2(const GemmP& p, int batch, hipStream_t s) {
+    constexpr int SMEM = NS * (BM + BN) * 64;
+    constexpr int NT = WR * WC * 64;
+    auto kern = gemm_mfma_pipe_kernel<BM, BN, WR, WC, NS, GEGLU>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tiles = cdiv(p.M, BM) * (p.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(NT), SMEM, s, p);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+template <int BM, int BN, int WR, int WC, int NS>
+static int launch_pipe(const GemmP& p, int batch, hipStream_t s) {
+    if constexpr ((BN / WC) % 64 == 0) {
+        if (p.flags & EP_GEGLU) return launch_pipe2<BM, BN, WR, WC, NS, true>(p, batch, s);
+    }
+    return launch_pipe2<BM, BN, WR, WC, NS, false>(p, batch, s);
+}
+
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
     if constexpr ((BN / WC) % 64 == 0) {
@@ -500,6 +707,7 @@ static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f,
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
 int g_force_gemm_split = 0;
+int g_gemm_pipe = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 1; }();   // 1: deep-pipelined kernels for the big tiles
 
 static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;
@@ -589,8 +797,10 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     int split = 1;
     const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW)) && p.N % 4 == 0;
     const int cfg = pick_cfg(p, batch, &split, can_split);
+    const bool pipe = use_glds && g_gemm_pipe != 0 && (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_128x320 ||
+                                                       (g_gemm_pipe > 1 && cfg == CFG_128x128));
     if (split > 1) {
-        const int nk = p.K / (cfg == CFG_128x128_K32 ? 32 : 64);
+        const int nk = p.K / ((cfg == CFG_128x128_K32 || pipe) ? 32 : 64);
         p.splitk_steps = cdiv(nk, split);
         p.splitk = cdiv(nk, p.splitk_steps);
         if (p.splitk <= 1) { p.splitk = 0; split = 1; }
@@ -599,7 +809,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     }
     std::string pname;
     if (prof_enabled()) {
-        pname = std::string(kCfgName[cfg]) + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
+        pname = std::string(kCfgName[cfg]) + (pipe ? "p" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
                 ((p.flags & EP_GEGLU) ? "_geglu" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 (batch > 1 ? " x" + std::to_string(batch) : "");
     }
@@ -619,6 +829,18 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         if (use_glds ? launch_cfg<BM, BN, WR, WC, BK, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, BK, false>(p, batch, s)) \
             return 1;                                                                                           \
         return reduce.run();
+    if (pipe) {
+        int rc = 1;
+        switch (cfg) {
+            case CFG_256x320: rc = launch_pipe<256, 320, 4, 2, 4>(p, batch, s); break;
+            case CFG_256x256: rc = launch_pipe<256, 256, 4, 2, 4>(p, batch, s); break;
+            case CFG_128x320: rc = launch_pipe<128, 320, 2, 4, 4>(p, batch, s); break;
+            case CFG_128x128: rc = launch_pipe<128, 128, 2, 2, 4>(p, batch, s); break;
+            default: break;
+        }
+        if (rc) return 1;
+        return reduce.run();
+    }
     switch (cfg) {
         SDMI_CASE(CFG_128x128, 128, 128, 2, 2, 64)
         SDMI_CASE(CFG_64x64, 64, 64, 4, 1, 64)

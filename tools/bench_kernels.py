@@ -133,6 +133,39 @@ def main():
             except Exception as e:                          # noqa: BLE001
                 cells.append("ERR")
             print(f"{name:40s} | " + " | ".join(cells), flush=True)
+    if what in ("pipe", "all"):
+        print("== two-stage (pipe=0) vs deep-pipelined (pipe=1; 2 = also 128x128) kernels, auto tile choice: TFLOP/s ==")
+        shapes_p = [
+            ("conv3x3 320->320 @64^2 B16", dict(B=16, H=64, W=64, cin=320, cout=320)),
+            ("conv3x3 640->640 @32^2 B16", dict(B=16, H=32, W=32, cin=640, cout=640)),
+            ("conv3x3 1280->1280 @16^2 B16", dict(B=16, H=16, W=16, cin=1280, cout=1280)),
+            ("conv3x3 1280->1280 @8^2 B16", dict(B=16, H=8, W=8, cin=1280, cout=1280)),
+            ("conv3x3 (640+320)->320 @64^2", dict(B=16, H=64, W=64, cin=960, cout=320, c1=320)),
+            ("linear 320->320 tok65536", dict(B=16, H=64, W=64, cin=320, cout=320, taps=1)),
+            ("linear qk 320->640 tok65536", dict(B=16, H=64, W=64, cin=320, cout=640, taps=1)),
+            ("linear 640->640 tok16384", dict(B=16, H=32, W=32, cin=640, cout=640, taps=1)),
+            ("linear 1280->1280 tok4096", dict(B=16, H=16, W=16, cin=1280, cout=1280, taps=1)),
+            ("linear ff1 geglu 320->2560", dict(B=16, H=64, W=64, cin=320, cout=2560, taps=1, geglu=True)),
+            ("linear ff1 geglu 640->5120 @32^2", dict(B=16, H=32, W=32, cin=640, cout=5120, taps=1, geglu=True)),
+            ("linear ff1 geglu 1280->10240 @16^2", dict(B=16, H=16, W=16, cin=1280, cout=10240, taps=1, geglu=True)),
+            ("linear ff2 1280->320", dict(B=16, H=64, W=64, cin=1280, cout=320, taps=1)),
+            ("vae conv3x3 128->128 @512^2 B2", dict(B=2, H=512, W=512, cin=128, cout=128)),
+            ("vae conv3x3 256->256 @256^2 B2", dict(B=2, H=256, W=256, cin=256, cout=256)),
+            ("vae conv3x3 512->512 @128^2 B2", dict(B=2, H=128, W=128, cin=512, cout=512)),
+            ("gemm 8192x8192x8192 (1x1)", dict(B=1, H=8192, W=1, cin=8192, cout=8192, taps=1)),
+        ]
+        for name, kw in shapes_p:
+            cells = []
+            for pv in (0, 1, 2):
+                lib.check(L.sdmi_debug_set(b"gemm_pipe", pv))
+                try:
+                    ms, tf = bench_conv(impl="mfma", iters=10, **kw)
+                    cells.append(f"{tf:8.1f}")
+                except Exception as e:                      # noqa: BLE001
+                    cells.append("ERR")
+                    print("   error:", e)
+            lib.check(L.sdmi_debug_set(b"gemm_pipe", 1))
+            print(f"{name:40s} | " + " | ".join(cells), flush=True)
     if what in ("split", "all"):
         print("== split-K on the deep levels: TFLOP/s for (cfg, slices); slices=1 is the plain kernel ==")
         deep = [("conv3x3 1280->1280 @16^2 B16", dict(B=16, H=16, W=16, cin=1280, cout=1280)),
