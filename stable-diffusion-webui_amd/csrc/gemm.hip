@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Deep-pipelined variant (the default for the large tiles).  The two-stage kernel above drains every load
+// Deep-pipelined variant (selectable with sdmi_debug_set("gemm_pipe", 1); NOT the default, see g_gemm_pipe).  The two-stage kernel above drains every load
 // (s_waitcnt vmcnt(0)) once per K step, so each step pays a full L2/HBM round trip that one workgroup per CU cannot
 // hide (measured 2.9 us per 64-deep step of a 256x320 tile = 37 % of the MFMA rate).  Here K advances in BK = 32
 // stages through an NS-deep LDS ring with NS-1 stages of LDS-direct loads in flight at all times:
@@ -707,7 +707,10 @@ static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f,
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
 int g_force_gemm_split = 0;
-int g_gemm_pipe = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 1; }();   // 1: deep-pipelined kernels for the big tiles
+// 0 (default): two-stage kernels.  1: deep-pipelined kernels for the big tiles, 2: also 128x128 — kept selectable; measured
+// 7-25 % SLOWER than the two-stage BK=64 kernels on every shape of the workload (profiles/r01_microbench_pipe.txt): one
+// barrier per 40 MFMAs costs more than the vmcnt(0) drain it removes.
+int g_gemm_pipe = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 0; }();
 
 static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;

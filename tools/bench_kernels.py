@@ -164,7 +164,7 @@ def main():
                 except Exception as e:                      # noqa: BLE001
                     cells.append("ERR")
                     print("   error:", e)
-            lib.check(L.sdmi_debug_set(b"gemm_pipe", 1))
+            lib.check(L.sdmi_debug_set(b"gemm_pipe", 0))
             print(f"{name:40s} | " + " | ".join(cells), flush=True)
     if what in ("split", "all"):
         print("== split-K on the deep levels: TFLOP/s for (cfg, slices); slices=1 is the plain kernel ==")
