@@ -23,6 +23,9 @@
 
 namespace sdmi {
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
 template <int D, int KVT>
 __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
     constexpr int DK = (D + 15) / 16 * 16;   // contraction length of S^T, padded to the MFMA K step
@@ -38,6 +41,11 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
     constexpr int VCPR = KVT / 8;            // 16-byte chunks per V^T row
     constexpr int KCH = KVT * KCPR, VCH = DV * VCPR;
     constexpr int K_IT = (KCH + 255) / 256, V_IT = (VCH + 255) / 256;
+    // When the head size leaves a spare (padding) row in O^T, V^T row D is held at 1.0 in LDS: the PV MFMA then accumulates
+    // sum_k P[q][k] in O^T row D — the softmax denominator, rescaled together with O — and the VALU row sum disappears.
+    constexpr bool SUMROW = DV > D;
+    constexpr int L_RR = D - (D / 32) * 32, L_DB = D / 32;       // where that row lives in the 32x32 accumulator
+    constexpr int L_HALF = (L_RR >> 2) & 1, L_R = (L_RR & 3) + 4 * (L_RR >> 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 x (K tile | V^T tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,26 +85,32 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
     const half_t* kbase = p.k + (long)b * p.M * p.ldk + h * D;
     const half_t* vbase = p.vt + ((long)b * p.H + h) * D * (long)p.vt_ld;
 
-    uint4 kr[K_IT], vr[V_IT];
+    // Staging is branch-free in the steady state: addresses are clamped instead of predicating the loads with a zero fill
+    // (the select / phi copies of the predicated form cost more VALU issue slots than the softmax itself).
+    //   K rows >= M  : re-read row M-1; their scores are masked in the (peeled) tail tile.
+    //   K cols >= D  : re-read chunk 0; Q is zero there, so any finite value contributes 0.
+    //   V^T rows >= D: loaded from a clamped row and not written to LDS; they only feed O^T rows that are not stored
+    //                  (row D is the ones row, see SUMROW).
+    //   V^T cols     : key0 + 8c < vt_ld holds for 64-key tiles (vt_ld >= M rounded up to 64); clamped for wider tiles.
+    u4v kr[K_IT], vr[V_IT];
     auto load_tile = [&](int t) {
         const int key0 = t * KVT;
 #pragma unroll
         for (int it = 0; it < K_IT; ++it) {
             const int idx = it * 256 + tid;
             const int row = idx / KCPR, c = idx - row * KCPR;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < KCH && key0 + row < p.M && c * 8 < D)
-                v = *reinterpret_cast<const uint4*>(kbase + (long)(key0 + row) * p.ldk + c * 8);
-            kr[it] = v;
+            // threads past the end of the tile (idx >= KCH) load a clamped row too; only their LDS write is skipped
+            const int rr = min(key0 + row, p.M - 1);
+            const int cc = (DK == D || c * 8 < D) ? c : 0;
+            kr[it] = *reinterpret_cast<const u4v*>(kbase + (long)rr * p.ldk + cc * 8);
         }
 #pragma unroll
         for (int it = 0; it < V_IT; ++it) {
             const int idx = it * 256 + tid;
             const int row = idx / VCPR, c = idx - row * VCPR;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < VCH && row < D && key0 + c * 8 < p.vt_ld)
-                v = *reinterpret_cast<const uint4*>(vbase + (long)row * p.vt_ld + key0 + c * 8);
-            vr[it] = v;
+            int col = key0 + c * 8;
+            if (KVT > 64) col = min(col, p.vt_ld - 8);
+            vr[it] = *reinterpret_cast<const u4v*>(vbase + (long)min(row, D - 1) * p.vt_ld + col);
         }
     };
     auto write_tile = [&](int buf) {
@@ -106,13 +120,13 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
         for (int it = 0; it < K_IT; ++it) {
             const int idx = it * 256 + tid;
             const int row = idx / KCPR, c = idx - row * KCPR;
-            if (idx < KCH) *reinterpret_cast<uint4*>(Ks + row * KSTR + c * 16) = kr[it];
+            if (KCH % 256 == 0 || it + 1 < K_IT || idx < KCH) *reinterpret_cast<u4v*>(Ks + row * KSTR + c * 16) = kr[it];
         }
 #pragma unroll
         for (int it = 0; it < V_IT; ++it) {
             const int idx = it * 256 + tid;
             const int row = idx / VCPR, c = idx - row * VCPR;
-            if (idx < VCH) *reinterpret_cast<uint4*>(Vs + row * VSTR + c * 16) = vr[it];
+            if (row < D) *reinterpret_cast<u4v*>(Vs + row * VSTR + c * 16) = vr[it];
         }
     };
 
@@ -122,7 +136,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     // running max is kept in the scaled (log2) domain: t = s * scale_log2
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = -1e30f;
+    f2v l_run = {0.f, 0.f};
 
     // K row read by this lane as MFMA row (lane&31): bits 2 and 3 swapped (see header)
     const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
@@ -130,10 +145,22 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
     const int va_off = K_BYTES + lq * VSTR + half * 16;
 
     const int ntiles = (p.M + KVT - 1) / KVT;
+    const int nfull = p.M / KVT;
     load_tile(0);
     write_tile(0);
+    if (SUMROW) {
+        // V^T rows D..DV-1 of both buffers: row D = 1.0 (fp16 0x3C00), the rest 0 — written once, never overwritten
+        constexpr int PADCH = (DV - D) * VCPR;
+        for (int i = tid; i < 2 * PADCH; i += 256) {
+            const int buf = i / PADCH, j = i - buf * PADCH;
+            const int row = D + j / VCPR, c = j % VCPR;
+            const unsigned w = row == D ? 0x3C003C00u : 0u;
+            *reinterpret_cast<uint4*>(smem + buf * TILE_BYTES + K_BYTES + row * VSTR + c * 16) = make_uint4(w, w, w, w);
+        }
+    }
     __syncthreads();
 
+    const f2v sl2 = {p.scale_log2, p.scale_log2};
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
         const bool more = t + 1 < ntiles;
@@ -157,36 +184,41 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
 
         // ---- online softmax (per lane: one query row, KVT/2 of the tile's keys) -----------------------------------
         // register r of block kb <-> local key 32*kb + 16*(r>>3) + 8*half + (r&7)
-        const int key0 = t * KVT;
-        const bool tail = key0 + KVT > p.M;
+        if (t >= nfull) {
+            // ragged last tile only (cross-attention, M = 77).  The empty volatile asm keeps this a real (wave-uniform)
+            // branch: if-converted, the 32 compare+select pairs would run on every tile of every self-attention call.
+            asm volatile("");
+            const int lim = p.M - t * KVT - 8 * half;          // local keys >= lim are past the end
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * kb + 16 * (r >> 3) + (r & 7) >= lim) sc[kb][r] = -INFINITY;
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float a = sc[kb][r];
-                if (tail) {
-                    const int kl = 32 * kb + 16 * (r >> 3) + 8 * half + (r & 7);
-                    if (key0 + kl >= p.M) a = -INFINITY;
-                    sc[kb][r] = a;
-                }
-                mx = fmaxf(mx, a);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;      // scale > 0: max commutes with the scaling
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        float rs = 0.f;
+        const f2v mneg = {-m_new, -m_new};
+        f2v rs = {0.f, 0.f};
         h8 pb[NKB][2];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], p.scale_log2, -m_new));
-                rs += e;
-                pb[kb][r >> 3][r & 7] = (half_t)e;
+            for (int r = 0; r < 16; r += 2) {
+                const f2v s2 = {sc[kb][r], sc[kb][r + 1]};
+                const f2v y = __builtin_elementwise_fma(s2, sl2, mneg);          // v_pk_fma_f32
+                const f2v e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+                if (!SUMROW) rs += e;                                            // v_pk_add_f32
+                pb[kb][r >> 3][r & 7] = (half_t)e.x;
+                pb[kb][r >> 3][(r & 7) + 1] = (half_t)e.y;
             }
-        l_run = fmaf(l_run, alpha, rs);
+        if (!SUMROW) l_run = l_run * alpha + rs;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -210,7 +242,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
     }
 
     // ---- normalise and store: o[db][r] is O[q][db*32 + (r&3) + 8*(r>>2) + 4*half] ----------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if (SUMROW) l_tot = __shfl(o[L_DB][L_R], lq + 32 * L_HALF);
+    else l_tot = (l_run.x + l_run.y) + __shfl_xor(l_run.x + l_run.y, 32);
     const float inv = 1.0f / l_tot;
     if (qok) {
         half_t* optr = p.out + ((long)b * p.N + q) * p.ldo + h * D;
