@@ -15,6 +15,7 @@
 #include "common.h"
 #include "prof.h"
 #include <algorithm>
+#include <cstdio>
 
 namespace sdmi {
 
@@ -63,13 +64,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const h
         }
     }
     __syncthreads();
-    if (tid < groups) {
-        const int cpg = C / groups;
+    {
+        // 8 lanes per group walk the group's R x cpg LDS slots in a fixed order, then an 8-lane shuffle tree (deterministic)
+        const int g = tid >> 3, l8 = tid & 7;
+        const int cpg = C / groups, n = R * cpg;
         float a = 0.f, q = 0.f;
-        for (int r = 0; r < R; ++r)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += s_sum[r * C + c]; q += s_sq[r * C + c]; }
-        float* dst = partial + (((long)b * nchunk + chunk) * groups + tid) * 2;
-        dst[0] = a; dst[1] = q;
+        if (g < groups)
+            for (int i = l8; i < n; i += 8) {
+                const int r = i / cpg, c = g * cpg + (i - r * cpg);
+                a += s_sum[r * C + c]; q += s_sq[r * C + c];
+            }
+        for (int off = 4; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
+        if (g < groups && l8 == 0) {
+            float* dst = partial + (((long)b * nchunk + chunk) * groups + g) * 2;
+            dst[0] = a; dst[1] = q;
+        }
     }
 }
 
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
             for (int e = 0; e < 8; ++e) {
                 const float sc = e < 4 ? sa[e] : sb[e - 4], sh = e < 4 ? ha[e] : hb[e - 4];
                 float y = fmaf((float)v[u][e], sc, sh);
-                if (silu) y = y / (1.0f + __expf(-y));
+                if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
                 o[e] = (half_t)y;
             }
             *reinterpret_cast<h8*>(out + po[u]) = o;
@@ -148,10 +157,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
 }
 
 static inline int gn_chunks(int B, int HW) {
-    // enough workgroups to fill 256 CUs several times over, but >= 32 pixels per chunk and <= 256 chunks
-    int n = (2048 + B - 1) / B;
+    // ~1024 workgroups over the batch (4 per CU), >= 32 pixels per chunk, <= 64 chunks: few enough partials that the
+    // apply kernel's prologue (a dependent chain of global loads per workgroup) stays short
+    int n = (1024 + B - 1) / B;
     if (n > HW / 32) n = HW / 32;
-    if (n > 256) n = 256;
+    if (n > 64) n = 64;
     if (n < 1) n = 1;
     return n;
 }
@@ -165,7 +175,9 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
     const int nchunk = gn_chunks(B, HW);
     const int rows = cdiv(HW, nchunk);
-    ProfScope ps("groupnorm_silu", 0.0, 3.0 * B * (double)HW * C * 2.0, s);      // read twice + write once
+    char pname[64];
+    snprintf(pname, sizeof pname, "groupnorm_silu B%d HW%d C%d", B, HW, C);
+    ProfScope ps(pname, 0.0, 3.0 * B * (double)HW * C * 2.0, s);      // read twice + write once
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
     SDMI_CHECK_HIP(hipGetLastError());
     const long nvec = (long)HW * (C / 8);
@@ -179,50 +191,79 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LayerNorm: 4 rows per block (one wave each); lane holds up to 4 vectors of 8 channels (C <= 2048).
+// LayerNorm: one wave per token row; lane holds K = ceil(C/512) <= 4 vectors of 8 channels.  A wave
+// works on RPW rows at once (all of their loads issued before the first reduction) so that a CU keeps enough bytes in
+// flight to cover HBM latency: with one 640-byte row per wave the kernel was latency-, not bandwidth-bound.
 // ---------------------------------------------------------------------------------------------------------------
+template <int K, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const float* gamma, const float* beta,
                                                         half_t* out, long rows, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * RPW;
+    if (row0 >= rows) return;
     const int VP = C / 8;
-    const half_t* src = x + row * C;
-    h8 v[4];
-    float sum = 0.f;
+    const float inv_c = 1.0f / (float)C;
+    h8 v[RPW][K];
+    float sum[RPW];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int cv = lane + k * 64;
-        if (cv < VP) {
-            v[k] = *reinterpret_cast<const h8*>(src + cv * 8);
+    for (int r = 0; r < RPW; ++r) {
+        const long row = min(row0 + r, rows - 1);           // clamped duplicate rows are computed but not stored
+        const half_t* src = x + row * C;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (float)v[k][e];
+        for (int k = 0; k < K; ++k) {
+            const int cv = lane + k * 64;
+            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            v[r][k] = cv < VP ? *reinterpret_cast<const h8*>(src + cv * 8) : z;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    const float mean = sum / (float)C;
-    float sq = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int cv = lane + k * 64;
-        if (cv < VP) {
+    for (int r = 0; r < RPW; ++r) {
+        float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = (float)v[k][e] - mean; sq = fmaf(d, d, sq); }
-        }
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += (float)v[r][k][e];      // padding lanes hold zeros
+        sum[r] = a;
     }
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
-    const float rstd = rsqrtf(sq / (float)C + eps);
+    for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int cv = lane + k * 64;
-        if (cv < VP) {
-            h8 o;
+        for (int r = 0; r < RPW; ++r) sum[r] += __shfl_xor(sum[r], off);
+    float mean[RPW], sq[RPW];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = cv * 8 + e;
-                o[e] = (half_t)(((float)v[k][e] - mean) * rstd * gamma[c] + beta[c]);
+    for (int r = 0; r < RPW; ++r) {
+        mean[r] = sum[r] * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < VP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[r][k][e] - mean[r]; q = fmaf(d, d, q); }
             }
-            *reinterpret_cast<h8*>(out + row * C + cv * 8) = o;
+        }
+        sq[r] = q;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) sq[r] += __shfl_xor(sq[r], off);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int cv = lane + k * 64;
+        if (cv < VP) {
+            const f4 g0 = *reinterpret_cast<const f4*>(gamma + cv * 8), g1 = *reinterpret_cast<const f4*>(gamma + cv * 8 + 4);
+            const f4 b0 = *reinterpret_cast<const f4*>(beta + cv * 8), b1 = *reinterpret_cast<const f4*>(beta + cv * 8 + 4);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                if (row0 + r >= rows) continue;
+                const float rstd = rsqrtf(fmaf(sq[r], inv_c, eps));
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float g = e < 4 ? g0[e] : g1[e - 4], bb = e < 4 ? b0[e] : b1[e - 4];
+                    o[e] = (half_t)(((float)v[r][k][e] - mean[r]) * rstd * g + bb);
+                }
+                *reinterpret_cast<h8*>(out + (row0 + r) * C + cv * 8) = o;
+            }
         }
     }
 }
@@ -230,8 +271,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const f
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
                      float eps, hipStream_t s) {
     SDMI_REQUIRE(C % 8 == 0 && C <= 2048, "LayerNorm: C % 8 == 0 and C <= 2048");
-    ProfScope ps("layernorm", 0.0, 2.0 * (double)rows * C * 2.0, s);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, out, (long)rows, C, eps);
+    char pname[48];
+    snprintf(pname, sizeof pname, "layernorm rows%ld C%d", (long)rows, C);
+    ProfScope ps(pname, 0.0, 2.0 * (double)rows * C * 2.0, s);
+    const int K = cdiv(C / 8, 64);
+#define SDMI_LN(KK, RR)                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<KK, RR>), dim3(cdiv(rows, 4 * RR)), dim3(256), 0, s, x, gamma, beta, out,     \
+                       (long)rows, C, eps)
+    if (K == 1) SDMI_LN(1, 4);
+    else if (K == 2) SDMI_LN(2, 2);
+    else if (K == 3) SDMI_LN(3, 1);
+    else SDMI_LN(4, 1);
+#undef SDMI_LN
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }

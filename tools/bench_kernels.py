@@ -83,6 +83,22 @@ def bench_gn(B, HW, C, iters=20):
     return ms, 3.0 * x.numel() * 2 / (ms * 1e-3) / 1e12       # TB/s (read, read, write)
 
 
+def bench_ln(rows, C, iters=20):
+    dev = torch.device("cuda")
+    x = torch.randn(rows, C, device=dev).half()
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    for _ in range(2):
+        ops.layernorm(x, g, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.layernorm(x, g, b)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * x.numel() * 2 / (ms * 1e-3) / 1e12       # TB/s (read, write)
+
+
 CFG_NAMES = {-1: "auto", 0: "128x128", 1: "256x64", 2: "64x64", 3: "128x128k32", 4: "256x256", 5: "256x320", 6: "256x128", 7: "128x64", 8: "128x320"}
 
 
@@ -211,13 +227,19 @@ def main():
     if what in ("norm", "all"):
         print("== GroupNorm+SiLU (ms | TB/s algorithmic: 3 x tensor bytes) ==")
         for name, kw in [("B16 64^2 C320", dict(B=16, HW=4096, C=320)), ("B16 32^2 C640", dict(B=16, HW=1024, C=640)),
-                         ("B16 16^2 C1280", dict(B=16, HW=256, C=1280)), ("B8 512^2 C128 (vae)", dict(B=8, HW=262144, C=128)),
+                         ("B16 16^2 C1280", dict(B=16, HW=256, C=1280)), ("B16 8^2 C1280", dict(B=16, HW=64, C=1280)),
+                         ("B16 64^2 C960", dict(B=16, HW=4096, C=960)), ("B16 32^2 C1920", dict(B=16, HW=1024, C=1920)),
+                         ("B8 512^2 C128 (vae)", dict(B=8, HW=262144, C=128)),
                          ("B8 256^2 C256 (vae)", dict(B=8, HW=65536, C=256))]:
             try:
                 ms, tb = bench_gn(**kw)
                 print(f"{name:40s} | {ms:8.3f} ms {tb:7.3f} TB/s", flush=True)
             except Exception as e:                          # noqa: BLE001
                 print(f"{name:40s} | ERR {e}")
+        print("== LayerNorm (ms | TB/s algorithmic: 2 x tensor bytes) ==")
+        for rows, C in [(65536, 320), (16384, 640), (4096, 1280), (1024, 1280), (8192, 2048)]:
+            ms, tb = bench_ln(rows, C)
+            print(f"rows {rows:6d} C {C:5d}                       | {ms:8.3f} ms {tb:7.3f} TB/s", flush=True)
 
 
 if __name__ == "__main__":
