@@ -36,6 +36,9 @@ const char* get_error();
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // A 256-byte zeroed device buffer per device used as the source of padding lanes in LDS-direct loads.
+// Device page of zeros that padded / out-of-image operand lanes are pointed at.  32 KB: the ping-pong GEMM adds a channel
+// offset of up to Cin halfs to it instead of re-selecting the pointer per load.
+constexpr int kZeroPageHalfs = 16384;
 const half_t* zero_page();
 
 // ---- GEMM / implicit conv parameters (kernel argument, POD) -----------------------------------------------
@@ -67,18 +70,24 @@ struct GemmP {
     float* splitk_ws;
     int splitk;
     int splitk_steps;     // BK-steps per slice
+    long long* dbg;       // tuning only: per-wave section timers of the ping-pong kernel (sdmi_debug_set gemm_dbg_lo/hi)
 };
 
-enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8 };
+enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
+       EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
+       EP_DBG_NO_DSREAD = 0x1000 };    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
 
 int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s);
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)
 // worst-case fp32 workspace a split-K launch of this shape may use (bytes); 0 when split-K would never be chosen
 size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch);
 extern int g_force_gemm_cfg;
-extern int g_gemm_pipe;             // 0 = two-stage kernels only, 1 = pipelined big tiles (default), 2 = also 128x128
+extern int g_gemm_pipe;             // 0 = two-stage kernels, 1 = BK32 ring for the big tiles, 2 = also 128x128, 3 = phase-split big tiles
+extern int g_gemm_pipe_default;     // value restored by sdmi_debug_set("gemm_pipe", -1)
 extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = force k slices where allowed
 extern int g_attn_kvt;
+extern int g_gemm_dbgflags;
+extern unsigned long long g_gemm_dbg;   // device pointer (0 = off): 5 x int64 per wave of section cycle sums
 
 // ---- attention --------------------------------------------------------------------------------------------
 struct AttnP {

@@ -31,8 +31,8 @@ const half_t* zero_page() {
     auto it = pages.find(dev);
     if (it == pages.end()) {
         void* p = nullptr;
-        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        if (hipMalloc(&p, kZeroPageHalfs * sizeof(half_t)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, kZeroPageHalfs * sizeof(half_t)) != hipSuccess) return nullptr;
         it = pages.emplace(dev, (half_t*)p).first;
     }
     cached_dev = dev;

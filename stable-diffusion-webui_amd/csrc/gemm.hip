@@ -512,6 +512,288 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_pipe_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Ping-pong kernel for the 256-row tiles: BK = 64, 8 waves as 2 (M) x 4 (N).  Every SIMD holds one wave of each
+// wave-row group; the two groups run the same program ONE BARRIER APART, so that while one group is in its MFMA section
+// the other one is in its load section (LDS -> register fragment reads, LDS-direct global loads, address arithmetic,
+// waits).  With all waves in lockstep (the two-stage kernel above) the MFMA pipe idles through every load section.
+//
+// A K tile is computed in 4 phases; phase q multiplies rows [32q, 32q+32) of the wave's 128-row sub-tile with all of the
+// wave's B fragments (read once per K tile, in phase 0, and kept in registers).  Each phase is
+//     L: ds_reads of this phase's fragments | issue one group of LDS-direct loads | counted vmcnt wait | lgkmcnt(0) | s_barrier
+//     M: s_setprio 1 | 2 x 2 x TN MFMAs | s_setprio 0 | s_barrier
+// (measured, tools/micro/pingpong_steps.hip: bare ping-pong MFMA sections run at 98 % of the MFMA rate; LDS reads and
+// LDS-direct loads issued from the L section cost ~7 % together, the same reads issued from the M section ~15 % alone).
+// LDS is double-buffered per K tile but refilled PIECEWISE as soon as a piece has been read for the last time, which puts
+// loads 5-7 phases (~1.5 K tiles) ahead of their use instead of less than one K tile:
+//     piece        last read     refilled for tile T+2 in          needed in
+//     B half 0/1   L(0) of T     L(1) / L(2) of T                  L(0) of T+2
+//     A rows 0-63  L(0), L(1)    L(3) of T                         L(0), L(1) of T+2
+//     A rows 64-   L(2), L(3)    L(0) of T+1                       L(2), L(3) of T+2
+// ("A rows" of both wave-row halves; the half-h rows are staged by the waves of group h and read only by group h.)
+// vmcnt retires in issue order and every thread issues the same number of loads per group, so two counted waits per tile
+// order everything (no vmcnt(0) in the steady state):
+//     W1 in L(3) of T : B + A rows 0-63 of tile T+1 landed  <=> at most N1 = 4 + BU younger loads outstanding
+//     W2 in L(1) of T : A rows 64-127 of tile T landed      <=> at most N2 = 4 + BU + BU/2 younger loads outstanding
+// RAW: a piece is read only after the issuing waves' counted wait AND a barrier (group 1 waits one slot after group 0;
+// the shared B pieces are first read by group 0 two slots after its own W1, one slot after group 1's).  WAR: lgkmcnt(0)
+// precedes the barrier that closes every L section, so a piece is refilled only after both groups' reads have returned.
+// Accumulation order over k equals the two-stage kernel's: results are bit-identical to it (tests/test_gpu_ops.py).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long stamp() {           // s_memtime; callers sit at points where lgkmcnt is already 0
+    const long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+}
+
+template <int BN, bool GEGLU, bool TIMING = false>
+__global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
+    constexpr int BM = 256, BK = 64, WC = 4, ROWB = 128;
+    constexpr int WTM = 128, WTN = BN / WC, TM = WTM / 16, TN = WTN / 16;
+    constexpr int RP = 32, TMP = 2;                          // rows / MFMA row-tiles of the wave tile per phase
+    constexpr int BU = BN / 64;                              // 64-row pieces of the weight tile (one chunk per thread each)
+    constexpr int NB0 = BU / 2, NB1 = BU - NB0;              // pieces in B half 0 / 1
+    constexpr int N1 = 4 + BU, N2 = 4 + BU + NB0;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    static_assert(BN % 64 == 0 && WTN % 16 == 0 && N2 < 64, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+
+    const int tiles_n = p.N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, sub = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sub;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const long z = blockIdx.z;
+    const half_t* a0 = p.a0 + z * p.a_bs;
+    const half_t* a1 = p.a1 ? p.a1 + z * p.a_bs : nullptr;
+    const half_t* wbase = p.w + z * p.w_bs;
+
+    // ---- staging roles of this thread -----------------------------------------------------------------------------
+    // A unit q (rows [32q, 32q+32) of both halves): group-h waves stage the half-h rows; thread -> row 8*(wave&3) + lane/8
+    // of the unit's 32 rows, chunk lane & 7.  B piece i (64 rows): thread -> row tid / 8, chunk tid & 7.
+    const int ch = tid & 7;
+    const int a_rin = (wave & 3) * 8 + (lane >> 3);
+    const int b_row = tid >> 3;
+    // all rows a thread stages are congruent to lane/8 mod 8, so one source-side swizzle serves every piece
+    const int src_chunk = (ch ^ (lane >> 3)) * 8;            // logical chunk (in halfs) whose data lands in slot `ch`
+    // Gather bookkeeping per staged row, ONE register: image index << 24 | (yb & 0xfff) << 12 | (xb & 0xfff) with (yb, xb)
+    // the window origin (a row past M gets yb = -2048, which fails every bounds test) — the launcher guarantees
+    // B < 128 and window coordinates within +-2047 — plus the row's source pointer for the CURRENT (tap, source) segment
+    // of K, rebuilt only when a K tile starts a new segment, so a steady-state load costs one 64-bit add.
+    // Out-of-image taps point at the zero page (32 KB of zeros: any channel offset of the segment stays inside it).
+    // (the packed words live in LDS behind the tile buffers: they are needed once per segment, and VGPRs are the scarce
+    // resource of the 256x320 instantiation — a compiler spill would put scratch loads, i.e. vmcnt traffic, in the loop)
+    int* rinfo = reinterpret_cast<int*>(smem + 2 * STAGE) + tid;        // [q * 512]
+    const half_t* rptr[4];
+    const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wr * WTM + q * RP + a_rin;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / p.rows_per_batch;
+        const int rem = mm - b * p.rows_per_batch;
+        const int yo = rem / p.Wo;
+        const int xo = rem - yo * p.Wo;
+        const int yb = ok ? (p.up ? yo - 1 : yo * p.stride - p.pad) : -2048;
+        const int xb = p.up ? xo - 1 : xo * p.stride - p.pad;
+        rinfo[q * 512] = (b << 24) | ((yb & 0xfff) << 12) | (xb & 0xfff);
+        rptr[q] = p.zero;
+    }
+    const int img_pix = p.Hi * p.Wi;
+    const bool plain = p.taps == 1 && p.stride == 1 && !p.up && p.Ho == p.Hi && p.Wo == p.Wi;
+    const int a_lds = (wr * WTM + (wave & 3) * 8) * ROWB;    // wave-uniform: the wave's 8 rows inside unit 0
+    const int b_lds = A_BYTES + wave * 8 * ROWB;             // the wave's 8 rows inside piece 0
+    const half_t* b_src = wbase + (long)(n0 + b_row) * p.ldw + src_chunk;
+    const long b_piece = 64L * p.ldw;                        // elements between consecutive 64-row pieces
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    int nk = p.K / BK;
+    int k_first = 0;
+    if (p.splitk > 1) {
+        k_first = blockIdx.y * p.splitk_steps;
+        nk = min(nk - k_first, p.splitk_steps);
+    }
+    // (tap, cbase) of K tiles T+1 and T+2; advanced once per tile, no division in the loop
+    int tap1, cb1, tap2, cb2;
+    auto advance = [&](int& tap, int& cb) {
+        cb += BK;
+        if (cb >= p.cin) { cb = 0; ++tap; }
+    };
+    {
+        const int k0 = k_first * BK;
+        tap1 = k0 / p.cin;
+        cb1 = k0 - tap1 * p.cin;
+    }
+
+    // A units [q0, q0+2) of the K tile at (tap, cbase) into LDS buffer sb
+    auto issue_a = [&](int q0, int tap, int cbase, int sb, bool force) {
+        char* base = smem + sb * STAGE + a_lds;
+        const bool first = cbase < p.c0;
+        const int seg0 = first ? 0 : p.c0;
+        if (force || cbase == seg0) {                    // block-uniform: the tile opens a new (tap, source) segment
+            const half_t* src = first ? a0 : a1;
+            const int lda = first ? p.lda0 : p.lda1;
+            int dy = 0, dx = 0;
+            if (p.taps == 9) { dy = (tap * 11) >> 5; dx = tap - dy * 3; }
+#pragma unroll
+            for (int q = q0; q < q0 + 2; ++q) {
+                bool ok;
+                int pix;
+                if (plain) {                              // 1x1, stride 1: the GEMM row IS the pixel index
+                    pix = m0 + wr * WTM + q * RP + a_rin;
+                    ok = pix < p.M;
+                } else {
+                    const int ri = rinfo[q * 512];
+                    const int yr = ((ri << 8) >> 20) + dy, xr = ((ri << 20) >> 20) + dx;     // sign-extended 12-bit fields
+                    ok = (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
+                    pix = (ri >> 24) * img_pix + (yr >> p.up) * p.Wi + (xr >> p.up);
+                }
+                rptr[q] = (ok ? src + (long)pix * lda : p.zero) + ((tid & 7) ^ (lane >> 3)) * 8;
+            }
+        }
+        const int coff = cbase - seg0;                   // uniform channel offset inside the segment
+#pragma unroll
+        for (int q = q0; q < q0 + 2; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(rptr[q] + coff), (lptr_t)(base + q * RP * ROWB), 16, 0, 0);
+    };
+    // B pieces [i0, i0+n) of K tile kt (relative to k_first) into LDS buffer sb
+    auto issue_b = [&](int i0, int n, int kt, int sb) {
+        char* base = smem + sb * STAGE + b_lds;
+        const half_t* bt = b_src + (long)(k_first + kt) * BK;
+#pragma unroll
+        for (int i = i0; i < i0 + n; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(bt + i * b_piece), (lptr_t)(base + i * 64 * ROWB), 16, 0, 0);
+    };
+
+    const int lr = lane & 15, lk = lane >> 4;
+    const int sw0 = (lk ^ (lr & 7)) << 4, sw1 = ((4 + lk) ^ (lr & 7)) << 4;
+    const int a_rd = (wr * WTM + lr) * ROWB, b_rd = A_BYTES + (wc * WTN + lr) * ROWB;
+    h8 bf[2][TN], af[2][TMP];
+    auto read_b = [&](const char* sbuf) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf[0][j] = *reinterpret_cast<const h8*>(sbuf + b_rd + j * 16 * ROWB + sw0);
+            bf[1][j] = *reinterpret_cast<const h8*>(sbuf + b_rd + j * 16 * ROWB + sw1);
+        }
+    };
+    auto read_a = [&](const char* sbuf, int ph) {
+#pragma unroll
+        for (int i = 0; i < TMP; ++i) {
+            af[0][i] = *reinterpret_cast<const h8*>(sbuf + a_rd + (ph * RP + i * 16) * ROWB + sw0);
+            af[1][i] = *reinterpret_cast<const h8*>(sbuf + a_rd + (ph * RP + i * 16) * ROWB + sw1);
+        }
+    };
+
+    // ---- prologue: all of tile 0; B and A rows 0-63 of tile 1 ------------------------------------------------------
+    issue_b(0, NB0, 0, 0);
+    issue_b(NB0, NB1, 0, 0);
+    issue_a(0, tap1, cb1, 0, true);
+    issue_a(2, tap1, cb1, 0, true);
+    advance(tap1, cb1);                                  // (tap1, cb1) = tile 1
+    tap2 = tap1; cb2 = cb1;
+    if (nk > 1) {
+        issue_b(0, NB0, 1, 1);
+        issue_b(NB0, NB1, 1, 1);
+        issue_a(0, tap1, cb1, 1, true);
+        wait_vmcnt<N1>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    advance(tap2, cb2);                                  // (tap2, cb2) = tile 2
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) {                                       // group 1 runs one barrier behind group 0 from here on
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    long long tm[5] = {0, 0, 0, 0, 0};                   // TIMING: cycles in L work, barrier a, M issue, barrier b; phases
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const char* sbuf = smem + cur * STAGE;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (TIMING) t0 = stamp();
+            // ================= L section: fragment reads of this phase, refill one group, counted waits =================
+            // (LDS reads cost nothing here, beside the other group's MFMAs; issued from the M section — before or after
+            // the MFMAs — the same reads add ~80 cycles per phase: tools/micro/pingpong_steps.hip)
+            if (!(TIMING && (p.flags & EP_DBG_NO_DSREAD)) || t == 0) {
+                if (ph == 0) read_b(sbuf);
+                read_a(sbuf, ph);
+            }
+            if (!(TIMING && (p.flags & EP_DBG_NO_GLDS))) {
+            if (ph == 0) {
+                if (t + 1 < nk) issue_a(2, tap1, cb1, cur ^ 1, false);
+            } else if (ph == 1) {
+                if (t + 2 < nk) issue_b(0, NB0, t + 2, cur);
+            } else if (ph == 2) {
+                if (t + 2 < nk) issue_b(NB0, NB1, t + 2, cur);
+            } else {
+                if (t + 2 < nk) issue_a(0, tap2, cb2, cur, false);
+            }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (TIMING && (p.flags & EP_DBG_NO_VMWAIT)) {
+            } else if (ph == 1) {
+                if (t + 2 < nk) wait_vmcnt<N2>(); else wait_vmcnt<0>();          // W2: A rows 64-127 of tile t
+            } else if (ph == 3) {
+                if (t + 2 < nk) wait_vmcnt<N1>(); else wait_vmcnt<0>();          // W1: B and A rows 0-63 of tile t+1
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this phase's fragments are in registers
+            if (TIMING) t1 = stamp();
+            if (!(TIMING && (p.flags & EP_DBG_NO_BAR_A))) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (TIMING) t2 = stamp();
+            // ================= M section: MFMAs only =================
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TMP; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[ph * TMP + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j], af[ks][i], acc[ph * TMP + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (TIMING) t3 = stamp();
+            if (!(ph == 3 && wr == 1 && t + 1 == nk) && !(TIMING && (p.flags & EP_DBG_NO_BAR_B))) {   // group 1's very last barrier would have no partner
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (TIMING) {
+                const long long t4 = stamp();
+                tm[0] += t1 - t0; tm[1] += t2 - t1; tm[2] += t3 - t2; tm[3] += t4 - t3; tm[4] += 1;
+            }
+        }
+        tap1 = tap2; cb1 = cb2;
+        advance(tap2, cb2);
+    }
+    if (TIMING) {
+        if (lane == 0 && p.dbg) {
+            long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 5;
+            for (int i = 0; i < 5; ++i) d[i] = tm[i];
+        }
+    }
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wr, wc, lane, z);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Generic kernel: one thread per output element, same addressing rules, no shape restrictions beyond Cin % 8 == 0.
 // Used for shapes the MFMA kernel does not cover and as the independent HIP cross-check in the parity tests.
 // ---------------------------------------------------------------------------------------------------------------
@@ -666,6 +948,41 @@ static int launch_pipe(const GemmP& p, int batch, hipStream_t s) {
     return launch_pipe2<BM, BN, WR, WC, NS, false>(p, batch, s);
 }
 
+template <int BN, bool GEGLU>
+static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
+    constexpr int SMEM = 2 * (256 + BN) * 128 + 8192;     // tile buffers + packed gather words
+    auto kern = gemm_mfma_pingpong_kernel<BN, GEGLU>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tiles = cdiv(p.M, 256) * (p.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(512), SMEM, s, p);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+unsigned long long g_gemm_dbg = 0;
+int g_gemm_dbgflags = 0;
+
+template <int BN>
+static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
+    if (g_gemm_dbg && !(p.flags & EP_GEGLU)) {            // tuning: instrumented instantiation
+        GemmP q = p;
+        q.dbg = (long long*)g_gemm_dbg;
+        constexpr int SMEM = 2 * (256 + BN) * 128 + 8192;
+        auto kern = gemm_mfma_pingpong_kernel<BN, false, true>;
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        hipLaunchKernelGGL(kern, dim3(cdiv(q.M, 256) * (q.N / BN), q.splitk > 1 ? q.splitk : 1, batch), dim3(512), SMEM, s, q);
+        SDMI_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if constexpr ((BN / 4) % 64 == 0) {
+        if (p.flags & EP_GEGLU) return launch_pingpong2<BN, true>(p, batch, s);
+    }
+    return launch_pingpong2<BN, false>(p, batch, s);
+}
+
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
     if constexpr ((BN / WC) % 64 == 0) {
@@ -707,10 +1024,11 @@ static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f,
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
 int g_force_gemm_split = 0;
-// 0 (default): two-stage kernels.  1: deep-pipelined kernels for the big tiles, 2: also 128x128 — kept selectable; measured
-// 7-25 % SLOWER than the two-stage BK=64 kernels on every shape of the workload (profiles/r01_microbench_pipe.txt): one
-// barrier per 40 MFMAs costs more than the vmcnt(0) drain it removes.
-int g_gemm_pipe = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 0; }();
+// 3 (default): ping-pong kernel for the 256-row tiles (+5..13 % over the two-stage kernel on the big shapes, bit-identical
+// results), two-stage kernels elsewhere.  0: two-stage kernels only.  1: BK=32 ring kernels for the big tiles, 2: also
+// 128x128 — kept selectable; measured 7-25 % SLOWER than the two-stage kernels (profiles/r01_microbench_pipe.txt).
+int g_gemm_pipe_default = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 3; }();
+int g_gemm_pipe = g_gemm_pipe_default;
 
 static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;
@@ -779,6 +1097,7 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch) {
 
 int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s) {
     GemmP p = p_in;
+    p.flags |= g_gemm_dbgflags;
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     p.zero = zero_page();
     SDMI_REQUIRE(p.zero != nullptr, "zero page allocation failed");
@@ -800,8 +1119,14 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     int split = 1;
     const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW)) && p.N % 4 == 0;
     const int cfg = pick_cfg(p, batch, &split, can_split);
-    const bool pipe = use_glds && g_gemm_pipe != 0 && (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_128x320 ||
-                                                       (g_gemm_pipe > 1 && cfg == CFG_128x128));
+    // ping-pong kernel: every weight row must exist (no n_valid masking) and a (tap, source) segment must fit the zero page
+    const bool phase = use_glds && g_gemm_pipe == 3 && (cfg == CFG_256x320 || cfg == CFG_256x256) && p.n_valid == p.N &&
+                       p.cin + 64 <= kZeroPageHalfs &&
+                       ((p.taps == 1 && p.stride == 1 && !p.up && p.Ho == p.Hi && p.Wo == p.Wi) ||
+                        (p.M / p.rows_per_batch < 128 && (p.up ? 2 : 1) * p.Hi < 2040 && (p.up ? 2 : 1) * p.Wi < 2040 &&
+                         p.stride * p.Ho < 2040 && p.stride * p.Wo < 2040));
+    const bool pipe = !phase && use_glds && g_gemm_pipe != 0 && g_gemm_pipe != 3 && (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_128x320 ||
+                                                                 (g_gemm_pipe > 1 && cfg == CFG_128x128));
     if (split > 1) {
         const int nk = p.K / ((cfg == CFG_128x128_K32 || pipe) ? 32 : 64);
         p.splitk_steps = cdiv(nk, split);
@@ -812,7 +1137,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     }
     std::string pname;
     if (prof_enabled()) {
-        pname = std::string(kCfgName[cfg]) + (pipe ? "p" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
+        pname = std::string(kCfgName[cfg]) + (pipe ? "p" : "") + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
                 ((p.flags & EP_GEGLU) ? "_geglu" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 (batch > 1 ? " x" + std::to_string(batch) : "");
     }
@@ -832,6 +1157,16 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         if (use_glds ? launch_cfg<BM, BN, WR, WC, BK, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, BK, false>(p, batch, s)) \
             return 1;                                                                                           \
         return reduce.run();
+    if (phase) {
+        int rc = 1;
+        switch (cfg) {
+            case CFG_256x320: rc = launch_pingpong<320>(p, batch, s); break;
+            case CFG_256x256: rc = launch_pingpong<256>(p, batch, s); break;
+            default: break;
+        }
+        if (rc) return 1;
+        return reduce.run();
+    }
     if (pipe) {
         int rc = 1;
         switch (cfg) {

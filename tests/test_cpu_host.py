@@ -177,6 +177,32 @@ def test_weight_broadcast_and_gather_world_size_2_gloo(tmp_path):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
 
 
+def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):
+    """The ping-pong GEMM's pipelining rests on COUNTED `s_waitcnt vmcnt(N)` (N1 = 4 + BN/64, N2 = N1 + BN/128) and raw
+    s_barrier / s_setprio in its K loop; a compiler that folded them into vmcnt(0) would silently serialise the loads.
+    Cross-compile the kernel to gfx950 assembly and check the loop body."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "stable-diffusion-webui_amd", "csrc", "gemm.hip")
+    out = tmp_path / "gemm.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    text = out.read_text()
+    for bn, n1, n2 in ((256, 8, 10), (320, 9, 11)):
+        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELb0ELb0EEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % bn, text, re.S | re.M)
+        assert m, f"ping-pong kernel <{bn}> not found in the assembly"
+        body = m.group(1)
+        first, last = body.index("s_setprio 1"), body.rindex("s_setprio 0")
+        loop = body[first:last]
+        assert loop.count("s_setprio 1") == 4 and loop.count("v_mfma_f32_16x16x32_f16") == 4 * 4 * (bn // 64)
+        assert f"s_waitcnt vmcnt({n1})" in loop and f"s_waitcnt vmcnt({n2})" in loop
+        assert loop.count("s_barrier") == 6          # 3 x (barrier b, barrier a) between the first and last MFMA sections
+        assert "scratch_" not in loop, "register spill inside the K loop (scratch traffic would disturb the vmcnt accounting)"
+
+
 def test_oracle_pipeline_batch_invariance():
     """Image i of a batch equals that image generated alone (per-image generators, modules/rng.py:108)."""
     schema = sub("schema")

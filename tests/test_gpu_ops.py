@@ -173,6 +173,77 @@ def test_conv_gemm_split_k_is_exact_and_deterministic(dev, cfg, split):
     assert torch.equal(got, again)
 
 
+PHASE_CASES = [
+    # (cfg, B, H, W, c0, c1, cout, taps, stride, up, split)   cfg 5 = 256x320, 4 = 256x256, 8 = 128x320
+    (5, 2, 16, 16, 64, 0, 320, 1, 1, False, 0),        # K = 64: a single K tile (prologue only)
+    (5, 2, 16, 16, 128, 0, 320, 1, 1, False, 0),       # K = 128: two K tiles (no steady state)
+    (5, 1, 24, 20, 192, 0, 640, 1, 1, False, 0),       # K = 192, M = 480: ragged last row tile, two column tiles
+    (5, 2, 16, 16, 320, 0, 320, 9, 1, False, 0),       # 3x3 with zero padding, 45 K tiles
+    (5, 2, 17, 15, 128, 0, 320, 9, 2, False, 0),       # stride 2, odd sizes
+    (5, 1, 12, 12, 128, 0, 320, 9, 1, True, 0),        # fused nearest x2 upsample
+    (5, 1, 16, 16, 128, 64, 320, 9, 1, False, 0),      # two sources (skip concat), source switch inside the K loop
+    (4, 2, 16, 16, 128, 0, 256, 9, 1, False, 0),       # 256x256 tile
+    (4, 1, 20, 20, 64, 0, 512, 1, 1, False, 0),        # 256x256, K = 64
+    (8, 2, 16, 16, 192, 0, 320, 9, 1, False, 0),       # 128x320 tile, two phases
+    (8, 1, 10, 10, 64, 0, 640, 1, 1, False, 0),        # 128x320, single K tile, ragged M
+    (5, 2, 8, 8, 1280, 0, 1280, 9, 1, False, 4),       # split-K slices (each slice runs its own prologue / tail)
+    (8, 2, 8, 8, 1280, 0, 1280, 9, 1, False, 3),
+]
+
+
+@pytest.mark.parametrize("case", PHASE_CASES)
+def test_pingpong_gemm_is_bit_identical_to_two_stage_kernel(dev, case):
+    """The ping-pong kernel (default for the 256-row tiles) refills LDS piecewise ~1.5 K tiles ahead with counted vmcnt
+    waits and runs its two wave groups one barrier apart; a staging race would show up as wrong tiles.  Same MFMA order as the two-stage kernel => the outputs must be identical bit for bit (and equal to torch
+    within the usual tolerance), on every path of the gather (padding, stride, upsample, concat) and for K loops too short
+    to reach the steady state."""
+    ops, lib = sub("ops"), sub("_lib")
+    cfg, B, H, W, c0, c1, cout, taps, stride, up, split = case
+    k = 3 if taps == 9 else 1
+    x0 = seeded((B, H, W, c0), 1)
+    x1 = seeded((B, H, W, c1), 2) if c1 else None
+    w = seeded((cout, c0 + c1, k, k), 3, scale=((c0 + c1) * k * k) ** -0.5)
+    b, res_seed = seeded((cout,), 4, 0.1), 5
+    xin = torch.cat([x0, x1], dim=3) if c1 else x0
+    ref = _conv_ref(h(xin), h(w), b, stride=stride, up=up)
+    res = seeded(tuple(ref.shape), res_seed)
+    ref = ref + h(res)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    args = dict(a1=None if x1 is None else x1.half().to(dev), bias=ops.pack_bias(b.to(dev), wp.shape[0]),
+                resid=res.half().to(dev), taps=taps, stride=stride, up=up)
+    outs = {}
+    try:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
+        for pipe in (0, 3, 3, 3):
+            lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", pipe))
+            outs.setdefault(pipe, []).append(ops.conv_gemm(x0.half().to(dev), wp, **args))
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1))
+    torch.cuda.synchronize()
+    assert rel_l2(outs[0][0].float().cpu(), ref) < 6e-4, case
+    for o in outs[3]:
+        assert torch.equal(o, outs[0][0]), case
+
+
+def test_pingpong_geglu_bit_identical(dev):
+    ops, lib = sub("ops"), sub("_lib")
+    rows, c = 700, 320
+    x = seeded((1, rows, 1, c), 1)
+    w, b = seeded((8 * c, c), 2, scale=c ** -0.5), seeded((8 * c,), 3, 0.1)
+    wp = ops.pack_conv_weight(w.half().to(dev), geglu=True)
+    bp = ops.pack_bias(b.to(dev), 8 * c, geglu=True)
+    outs = []
+    try:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", 4))
+        for pipe in (0, 3):
+            lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", pipe))
+            outs.append(ops.conv_gemm(x.half().to(dev), wp, bias=bp, taps=1, geglu=True))
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1))
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_mfma_glds_and_register_staging_agree_bitwise(dev):
     """Same LDS image, same MFMA order => identical bits; catches any mismatch in the LDS-direct load path."""
     ops = sub("ops")

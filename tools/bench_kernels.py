@@ -149,8 +149,7 @@ def main():
             except Exception as e:                          # noqa: BLE001
                 cells.append("ERR")
             print(f"{name:40s} | " + " | ".join(cells), flush=True)
-    if what in ("pipe", "all"):
-        print("== two-stage (pipe=0) vs deep-pipelined (pipe=1; 2 = also 128x128) kernels, auto tile choice: TFLOP/s ==")
+    if what in ("pipe", "phase", "all"):
         shapes_p = [
             ("conv3x3 320->320 @64^2 B16", dict(B=16, H=64, W=64, cin=320, cout=320)),
             ("conv3x3 640->640 @32^2 B16", dict(B=16, H=32, W=32, cin=640, cout=640)),
@@ -170,6 +169,8 @@ def main():
             ("vae conv3x3 512->512 @128^2 B2", dict(B=2, H=128, W=128, cin=512, cout=512)),
             ("gemm 8192x8192x8192 (1x1)", dict(B=1, H=8192, W=1, cin=8192, cout=8192, taps=1)),
         ]
+    if what in ("pipe", "all"):
+        print("== two-stage (pipe=0) vs deep-pipelined (pipe=1; 2 = also 128x128) kernels, auto tile choice: TFLOP/s ==")
         for name, kw in shapes_p:
             cells = []
             for pv in (0, 1, 2):
@@ -181,6 +182,28 @@ def main():
                     cells.append("ERR")
                     print("   error:", e)
             lib.check(L.sdmi_debug_set(b"gemm_pipe", 0))
+            print(f"{name:40s} | " + " | ".join(cells), flush=True)
+    if what in ("phase",):
+        print("== two-stage (a) vs phase-split (b) kernels, TFLOP/s; auto tile choice, then forced 256x320 / 256x256 / 128x320 ==")
+        bn = {5: 320, 4: 256, 8: 320}
+        for name, kw in shapes_p:
+            cells = []
+            for cfg in (-1, 5, 4, 8):
+                if cfg >= 0 and (kw["cout"] % bn[cfg] or (kw.get("geglu") and cfg != 4)):
+                    cells.append("       -        ")
+                    continue
+                lib.check(L.sdmi_debug_set(b"gemm_cfg", cfg))
+                pair = []
+                for pv in (0, 3):
+                    lib.check(L.sdmi_debug_set(b"gemm_pipe", pv))
+                    try:
+                        ms, tf = bench_conv(impl="mfma", iters=10, **kw)
+                        pair.append(f"{tf:7.1f}")
+                    except Exception as e:                  # noqa: BLE001
+                        pair.append("ERR")
+                        print("   error:", e)
+                cells.append("/".join(pair))
+            lib.check(L.sdmi_debug_set(b"gemm_pipe", -1)); lib.check(L.sdmi_debug_set(b"gemm_cfg", -1))
             print(f"{name:40s} | " + " | ".join(cells), flush=True)
     if what in ("split", "all"):
         print("== split-K on the deep levels: TFLOP/s for (cfg, slices); slices=1 is the plain kernel ==")
