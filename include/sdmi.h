@@ -157,6 +157,16 @@ int sdmi_ddim_step(void* x_f32, const void* e_t_f32, const void* noise_f32_or_nu
 /* y = a*x + b*z elementwise fp32 (x*sigmas[0]; init_latent + noise*sigma: modules/sd_samplers_kdiffusion.py:143,199). */
 int sdmi_axpby(void* y_f32, const void* x_f32, float a, const void* z_f32_or_null, float b, int64_t n, void* stream);
 
+/* out = sum_k coefs[k] * terms[k] (1..6 fp32 tensors of n elements, accumulated left to right; out may alias a term).
+ * The update rules of the k-diffusion samplers that have no dedicated kernel (Heun, DPM2, DPM2 a, LMS, DPM++ 2S a:
+ * names at modules/sd_samplers_kdiffusion.py:11-27) and of PLMS (modules/sd_samplers_timesteps_impl.py:85-137) are
+ * linear combinations of x, denoiser outputs and noise; `terms` / `coefs` are HOST arrays. */
+int sdmi_lincomb(void* out_f32, const void* const* terms_f32, const float* coefs, int n_terms, int64_t n, void* stream);
+
+/* x = init*mask + nmask*x, all fp32 tensors of n elements: the inpainting blend CFGDenoiser applies before / after
+ * denoising (modules/sd_samplers_cfg_denoiser.py:206-209, 279-280). */
+int sdmi_mask_blend(void* x_f32, const void* init_f32, const void* mask_f32, const void* nmask_f32, int64_t n, void* stream);
+
 /* clamp((x+1)/2,0,1)*255 truncated to uint8, NCHW fp32 -> NHWC uint8 (modules/processing.py:1004-1005,1034-1035). */
 int sdmi_image_to_u8(const void* img_f32_nchw, void* out_u8_nhwc, int B, int C, int H, int W, void* stream);
 

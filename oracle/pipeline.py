@@ -28,57 +28,92 @@ class OracleModel:
         return self.unet(x, t, cond, y)
 
 
+# sampler -> (default scheduler, discard_next_to_last_sigma): the options column of modules/sd_samplers_kdiffusion.py:11-27
+SAMPLER_OPTIONS = {
+    "euler_a": (None, False), "euler": (None, False), "lms": (None, False), "heun": (None, False),
+    "dpmpp_2m": ("karras", False), "dpmpp_2s_a": ("karras", False), "dpm_2": ("karras", True), "dpm_2_a": ("karras", True),
+}
+
+
 def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, scheduler: str = "automatic"):
-    """modules/sd_samplers_kdiffusion.py:79-132 for the two schedules the configs use."""
+    """modules/sd_samplers_kdiffusion.py:79-132 with default options (sigma_min/max/rho overrides off)."""
+    from . import schedulers as osch
+    default, discard = SAMPLER_OPTIONS[sampler]
+    steps += 1 if discard else 0
     if scheduler == "automatic":
-        scheduler = "karras" if sampler == "dpmpp_2m" else "uniform"
-    if scheduler == "karras":
-        return kd.get_sigmas_karras(steps, model_wrap.sigmas[0].item(), model_wrap.sigmas[-1].item())
-    return model_wrap.get_sigmas(steps)
+        scheduler = default
+    if scheduler is None:
+        sigmas = model_wrap.get_sigmas(steps)
+    else:
+        fn, need_inner = osch.SCHEDULERS[scheduler]
+        smin, smax = model_wrap.sigmas[0].item(), model_wrap.sigmas[-1].item()
+        sigmas = fn(steps, smin, smax, model_wrap) if need_inner else fn(steps, smin, smax)
+    if discard:
+        sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
+    return sigmas
 
 
 @torch.no_grad()
 def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
            latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
-           y=None, uy=None, record=None, img2img_steps_given=True):
+           y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None):
     """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
-    (modules/sd_samplers_kdiffusion.py:134-143)."""
+    (modules/sd_samplers_kdiffusion.py:134-143); ``mask`` (1 = keep the original latent) adds the inpainting blends of
+    modules/sd_samplers_cfg_denoiser.py:186-187 / 292-293 and the final blend of modules/processing.py:1776-1784."""
     b = len(seeds)
     rng = ImageRNG((4, latent_hw[0], latent_hw[1]), seeds)
     x = rng.next()
+    nmask = None if mask is None else 1.0 - mask
 
     def apply_model(xi, t, c):
         if y is not None:
             return model.apply_model(xi, t, c, torch.cat([y, uy]))
         return model.apply_model(xi, t, c)
 
-    if sampler == "ddim":
+    def finish(samples):
+        if mask is not None:
+            samples = samples * nmask + init_latent * mask
+        return samples
+
+    if sampler in ("ddim", "plms"):
         # CFGDenoiserTimesteps: inner model is apply_model on integer timesteps, CFG combines eps.
-        cfg = kd.CFGDenoiser(lambda xi, ti, ci: apply_model(xi, ti, ci))
+        cfg = kd.CFGDenoiser(lambda xi, ti, ci: apply_model(xi, ti, ci), mask, nmask, init_latent)
         cfg.mask_before_denoising = True
         ts = kd.ddim_timesteps(steps)
         extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
-        return kd.sample_ddim(cfg, x, ts, model.alphas_cumprod, extra, rng.next,
-                              eta=0.0 if eta is None else eta, callback=record)
+        if init_latent is not None:
+            total, t_enc = kd.setup_img2img_steps(steps, denoising_strength, img2img_steps_given)
+            ts = kd.ddim_timesteps(total)
+            ac = model.alphas_cumprod
+            x = init_latent * torch.sqrt(ac[ts[t_enc]]) + x * torch.sqrt(1 - ac[ts[t_enc]])       # sd_samplers_timesteps.py:103-107
+            ts = ts[:t_enc]
+        if sampler == "plms":
+            return finish(kd.sample_plms(cfg, x, ts, model.alphas_cumprod, extra, callback=record))
+        return finish(kd.sample_ddim(cfg, x, ts, model.alphas_cumprod, extra, rng.next,
+                                     eta=0.0 if eta is None else eta, callback=record))
 
     wrap = kd.CompVisDenoiser(apply_model, model.alphas_cumprod)
-    cfg = kd.CFGDenoiser(wrap)
+    cfg = kd.CFGDenoiser(wrap, mask, nmask, init_latent)
     extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
     if init_latent is None:
-        sigmas = get_sigmas(wrap, sampler, steps)
+        sigmas = get_sigmas(wrap, sampler, steps, scheduler)
         x = x * sigmas[0]
     else:
         total, t_enc = kd.setup_img2img_steps(steps, denoising_strength, img2img_steps_given)
-        sigmas = get_sigmas(wrap, sampler, total)[total - t_enc - 1:]
+        sigmas = get_sigmas(wrap, sampler, total, scheduler)[total - t_enc - 1:]
         x = init_latent + x * sigmas[0]
+    anc = dict(eta=1.0 if eta is None else eta, s_noise=s_noise, callback=record)
     if sampler == "euler_a":
-        return kd.sample_euler_ancestral(cfg, x, sigmas, extra, rng.next, eta=1.0 if eta is None else eta,
-                                         s_noise=s_noise, callback=record)
-    if sampler == "euler":
-        return kd.sample_euler(cfg, x, sigmas, extra, callback=record)
-    if sampler == "dpmpp_2m":
-        return kd.sample_dpmpp_2m(cfg, x, sigmas, extra, callback=record)
-    raise ValueError(sampler)
+        return finish(kd.sample_euler_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
+    if sampler == "dpm_2_a":
+        return finish(kd.sample_dpm_2_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
+    if sampler == "dpmpp_2s_a":
+        return finish(kd.sample_dpmpp_2s_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
+    fn = {"euler": kd.sample_euler, "dpmpp_2m": kd.sample_dpmpp_2m, "heun": kd.sample_heun, "dpm_2": kd.sample_dpm_2,
+          "lms": kd.sample_lms}.get(sampler)
+    if fn is None:
+        raise ValueError(sampler)
+    return finish(fn(cfg, x, sigmas, extra, callback=record))
 
 
 @torch.no_grad()

@@ -196,6 +196,20 @@ int sdmi_ddim_step(void* x, const void* e_t, const void* noise, void* pred_x0, f
     API_GUARD_END
 }
 
+int sdmi_lincomb(void* out, const void* const* terms, const float* coefs, int n_terms, int64_t n, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(out && terms && coefs, "null argument");
+    return launch_lincomb((float*)out, (const float* const*)terms, coefs, n_terms, n, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_mask_blend(void* x, const void* init, const void* mask, const void* nmask, int64_t n, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(x && init && mask && nmask, "null argument");
+    return launch_mask_blend((float*)x, (const float*)init, (const float*)mask, (const float*)nmask, n, (hipStream_t)stream);
+    API_GUARD_END
+}
+
 int sdmi_axpby(void* y, const void* x, float a, const void* z, float b, int64_t n, void* stream) {
     API_GUARD_BEGIN
     return launch_axpby((float*)y, (const float*)x, a, (const float*)z, b, n, (hipStream_t)stream);

@@ -123,6 +123,8 @@ int launch_dpmpp2m_step(float* x, const float* den, const float* old, float rati
 int launch_ddim_step(float* x, const float* e, const float* noise, float* pred_x0, float a_t, float a_prev,
                      float sigma_t, float somat, int64_t n, hipStream_t s);
 int launch_axpby(float* y, const float* x, float a, const float* z, float b, int64_t n, hipStream_t s);
+int launch_lincomb(float* out, const float* const* terms, const float* coefs, int n_terms, int64_t n, hipStream_t s);
+int launch_mask_blend(float* x, const float* init, const float* mask, const float* nmask, int64_t n, hipStream_t s);
 int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
 
 // NCHW (f16|f32) * scale -> NHWC fp16 with channels zero-padded to cpad; optional 1x1 channel mix (pqc) first.

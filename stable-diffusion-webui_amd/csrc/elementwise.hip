@@ -181,6 +181,42 @@ int launch_axpby(float* y, const float* x, float a, const float* z, float b, int
     return 0;
 }
 
+struct LinTerms {
+    const float* t[6];
+    float c[6];
+    int n;
+};
+// out = sum_k c[k] * t[k], accumulated left to right in fp32 (out may alias any term: each element is read before written)
+__global__ __launch_bounds__(256) void lincomb_kernel(float* out, LinTerms lt, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = lt.t[0][i] * lt.c[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k)
+            if (k < lt.n) v = v + lt.t[k][i] * lt.c[k];
+        out[i] = v;
+    }
+}
+int launch_lincomb(float* out, const float* const* terms, const float* coefs, int n_terms, int64_t n, hipStream_t s) {
+    SDMI_REQUIRE(n_terms >= 1 && n_terms <= 6, "lincomb takes 1..6 terms");
+    LinTerms lt{};
+    lt.n = n_terms;
+    for (int k = 0; k < n_terms; ++k) { lt.t[k] = terms[k]; lt.c[k] = coefs[k]; }
+    hipLaunchKernelGGL(lincomb_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, out, lt, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// x = init * mask + nmask * x   (inpainting blend, modules/sd_samplers_cfg_denoiser.py:206-209 / :279-280)
+__global__ __launch_bounds__(256) void mask_blend_kernel(float* x, const float* init, const float* mask, const float* nmask, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        x[i] = init[i] * mask[i] + nmask[i] * x[i];
+}
+int launch_mask_blend(float* x, const float* init, const float* mask, const float* nmask, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(mask_blend_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, init, mask, nmask, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void image_to_u8_kernel(const float* img, uint8_t* out, int C, long HW, long n) {
     // n = B*HW*C output elements, NHWC
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {

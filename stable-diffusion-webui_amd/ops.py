@@ -169,6 +169,30 @@ def philox_randn(shape, seed: int, offset: int, device) -> torch.Tensor:
     return out
 
 
+def lincomb(out: torch.Tensor, terms, coefs) -> torch.Tensor:
+    """out = sum_k coefs[k] * terms[k] on fp32 tensors of one shape (out may be one of the terms)."""
+    _lib.require_device()
+    n = len(terms)
+    assert 1 <= n <= 6 and len(coefs) == n
+    for t in terms:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == out.numel()
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    tarr = (C.c_void_p * n)(*[t.data_ptr() for t in terms])
+    carr = (C.c_float * n)(*[float(c) for c in coefs])
+    check(lib.sdmi_lincomb(ptr(out), tarr, carr, n, out.numel(), stream_ptr()), "sdmi_lincomb")
+    return out
+
+
+def mask_blend(x: torch.Tensor, init: torch.Tensor, mask: torch.Tensor, nmask: torch.Tensor) -> torch.Tensor:
+    """x = init*mask + nmask*x in place (modules/sd_samplers_cfg_denoiser.py:206-209); mask/nmask are broadcast to x's shape."""
+    _lib.require_device()
+    m = mask.to(x.device, torch.float32).expand_as(x).contiguous()
+    nm = nmask.to(x.device, torch.float32).expand_as(x).contiguous()
+    init = init.to(x.device, torch.float32).expand_as(x).contiguous()
+    check(lib.sdmi_mask_blend(ptr(x), ptr(init), ptr(m), ptr(nm), x.numel(), stream_ptr()), "sdmi_mask_blend")
+    return x
+
+
 def image_to_u8(img: torch.Tensor) -> torch.Tensor:
     """fp32 NCHW in [-1,1] -> uint8 NHWC (modules/processing.py:1004-1005, 1034-1035)."""
     _lib.require_device()

@@ -45,10 +45,10 @@ class StableDiffusionProcessing:
     height: int = 512
     denoising_strength: float = None
     eta: float = None
-    s_min_uncond: float = 0.0
-    s_churn: float = 0.0
+    s_min_uncond: float = None
+    s_churn: float = None
     s_tmax: float = None
-    s_tmin: float = 0.0
+    s_tmin: float = None
     s_noise: float = None
     sampler_noise_scheduler_override: Any = None
     is_hr_pass: bool = False
@@ -60,6 +60,15 @@ class StableDiffusionProcessing:
     iteration: int = 0
     extra_generation_params: dict = field(default_factory=dict)
     keep_latents: bool = True
+
+    def __post_init__(self):
+        """modules/processing.py:246-251: unset sampler parameters fall back to the options; s_tmax 0 means infinity."""
+        opts = shared.opts
+        self.s_min_uncond = self.s_min_uncond if self.s_min_uncond is not None else opts.s_min_uncond
+        self.s_churn = self.s_churn if self.s_churn is not None else opts.s_churn
+        self.s_tmin = self.s_tmin if self.s_tmin is not None else opts.s_tmin
+        self.s_tmax = (self.s_tmax if self.s_tmax is not None else opts.s_tmax) or float('inf')
+        self.s_noise = self.s_noise if self.s_noise is not None else opts.s_noise
 
     def init(self, all_prompts, all_seeds, all_subseeds):
         pass
@@ -137,7 +146,8 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
         lo = self.iteration * self.batch_size
         self.init_latent = self.init_latent_all[lo:lo + self.batch_size].contiguous()
         if self.latent_mask is not None:
-            self.mask = self.latent_mask[lo:lo + self.batch_size].float().contiguous()
+            dev = self.init_latent.device
+            self.mask = self.latent_mask[lo:lo + self.batch_size].to(dev, torch.float32).expand_as(self.init_latent).contiguous()
             self.nmask = (1.0 - self.mask).contiguous()
         x = self.rng.next()
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)

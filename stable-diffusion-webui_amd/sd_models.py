@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from . import schema
+from . import schema, shared
 from .engine import Engine
 
 
@@ -43,6 +43,7 @@ class SdModel:
                  vae_decoder_only: bool = False):
         self.unet_cfg = unet_cfg or guess_unet_config(state_dict)
         self.is_sdxl = self.unet_cfg.adm_in_channels is not None
+        shared.sd_model = self                            # the reference's global (modules/shared.py); schedulers read is_sdxl
         self.vae_cfg = vae_cfg or (schema.sdxl_vae() if self.is_sdxl else schema.sd15_vae())
         self.parameterization = "eps"
         self.device = torch.device("cuda", device)

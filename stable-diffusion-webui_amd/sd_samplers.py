@@ -23,7 +23,7 @@ from collections import namedtuple
 import numpy as np
 import torch
 
-from . import _lib, shared
+from . import _lib, ops, shared
 from ._lib import lib, check, ptr, stream_ptr
 from .schema import make_alphas_cumprod
 
@@ -56,21 +56,7 @@ def setup_img2img_steps(p, steps=None):
 # ------------------------------------------------------------------------------------------------------------
 # schedule (host side, CPU fp32 tensors like the reference keeps them: sd_samplers_kdiffusion.py:132)
 # ------------------------------------------------------------------------------------------------------------
-def append_zero(x):
-    return torch.cat([x, x.new_zeros([1])])
-
-
-def get_sigmas_karras(n, sigma_min, sigma_max, rho=7., device='cpu'):
-    ramp = torch.linspace(0, 1, n)
-    min_inv_rho = sigma_min ** (1 / rho)
-    max_inv_rho = sigma_max ** (1 / rho)
-    sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
-    return append_zero(sigmas).to(device)
-
-
-def get_sigmas_exponential(n, sigma_min, sigma_max, device='cpu'):
-    sigmas = torch.linspace(np.log(sigma_max), np.log(sigma_min), n, device=device).exp()
-    return append_zero(sigmas)
+from .sd_schedulers import append_zero, get_sigmas_karras, get_sigmas_exponential, schedulers_map  # noqa: E402,F401
 
 
 class DiscreteSchedule:
@@ -187,7 +173,9 @@ class CFGDenoiser:
         b, c, h, w = x.shape
         chw = c * h * w
         if self.mask_before_denoising and self.mask is not None:
-            raise NotImplementedError("inpainting masks with timestep samplers (DDIM) are not implemented in the engine")
+            # blend in the original latents BEFORE denoising (timestep samplers, cfg_denoiser.py:186-187); the sampler keeps
+            # its own, unblended x for the update, so work on a copy
+            x = ops.mask_blend(x.clone(), self.init_latent, self.mask, self.nmask)
         self._ensure_context(cond, uncond)
         if self._x_in is None or self._x_in.shape[0] != 2 * b or self._x_in.shape[2:] != x.shape[2:]:
             self._x_in = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
@@ -293,6 +281,202 @@ def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None, disable=No
     return x
 
 
+# ---- samplers without a dedicated fused kernel: every update is a linear combination of (x, denoiser outputs, noise),
+# evaluated on the device by sdmi_lincomb.  Formulas: k-diffusion sampling.py (third-party, names at
+# modules/sd_samplers_kdiffusion.py:11-27); the oracle restates them op by op (oracle/kdiffusion.py).
+def _lc(out, terms, coefs):
+    return ops.lincomb(out, [t.contiguous() for t in terms], [float(c) for c in coefs])
+
+
+def _to_d(x, sigma, denoised):
+    return _lc(torch.empty_like(x), [x, denoised], [1.0 / float(sigma), -1.0 / float(sigma)])
+
+
+def _churn(sigmas, i, s_churn, s_tmin, s_tmax):
+    gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.
+    return sigmas[i] * (gamma + 1), gamma
+
+
+def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'),
+                s_noise=1., noise_sampler=None):
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        sigma_hat, gamma = _churn(sigmas, i, s_churn, s_tmin, s_tmax)
+        if gamma > 0:
+            x = _lc(torch.empty_like(x), [x, noise_sampler(sigmas[i], sigmas[i + 1])], [1.0, s_noise * float((sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5)])
+        denoised = model(x, sigma_hat * s_in, **extra_args)
+        d = _to_d(x, sigma_hat, denoised)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        dt = float(sigmas[i + 1] - sigma_hat)
+        if sigmas[i + 1] == 0:
+            x = _lc(torch.empty_like(x), [x, d], [1.0, dt])
+        else:
+            x_2 = _lc(torch.empty_like(x), [x, d], [1.0, dt])
+            denoised_2 = model(x_2, sigmas[i + 1] * s_in, **extra_args)
+            d_2 = _to_d(x_2, sigmas[i + 1], denoised_2)
+            x = _lc(torch.empty_like(x), [x, d, d_2], [1.0, 0.5 * dt, 0.5 * dt])
+    return x
+
+
+def sample_dpm_2(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'),
+                 s_noise=1., noise_sampler=None):
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        sigma_hat, gamma = _churn(sigmas, i, s_churn, s_tmin, s_tmax)
+        if gamma > 0:
+            x = _lc(torch.empty_like(x), [x, noise_sampler(sigmas[i], sigmas[i + 1])], [1.0, s_noise * float((sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5)])
+        denoised = model(x, sigma_hat * s_in, **extra_args)
+        d = _to_d(x, sigma_hat, denoised)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        if sigmas[i + 1] == 0:
+            x = _lc(torch.empty_like(x), [x, d], [1.0, float(sigmas[i + 1] - sigma_hat)])
+        else:
+            sigma_mid = sigma_hat.log().lerp(sigmas[i + 1].log(), 0.5).exp()
+            dt_1 = float(sigma_mid - sigma_hat)
+            dt_2 = float(sigmas[i + 1] - sigma_hat)
+            x_2 = _lc(torch.empty_like(x), [x, d], [1.0, dt_1])
+            denoised_2 = model(x_2, sigma_mid * s_in, **extra_args)
+            d_2 = _to_d(x_2, sigma_mid, denoised_2)
+            x = _lc(torch.empty_like(x), [x, d_2], [1.0, dt_2])
+    return x
+
+
+def sample_dpm_2_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        d = _to_d(x, sigmas[i], denoised)
+        if sigma_down == 0:
+            x = _lc(torch.empty_like(x), [x, d], [1.0, float(sigma_down - sigmas[i])])
+        else:
+            sigma_mid = sigmas[i].log().lerp(sigma_down.log(), 0.5).exp()
+            dt_1 = float(sigma_mid - sigmas[i])
+            dt_2 = float(sigma_down - sigmas[i])
+            x_2 = _lc(torch.empty_like(x), [x, d], [1.0, dt_1])
+            denoised_2 = model(x_2, sigma_mid * s_in, **extra_args)
+            d_2 = _to_d(x_2, sigma_mid, denoised_2)
+            x = _lc(torch.empty_like(x), [x, d_2, noise_sampler(sigmas[i], sigmas[i + 1])], [1.0, dt_2, s_noise * float(sigma_up)])
+    return x
+
+
+def linear_multistep_coeff(order, t, i, j):
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f'Order {order} too high for step {i}')
+
+    def fn(tau):
+        prod = 1.
+        for k in range(order):
+            if j == k:
+                continue
+            prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(fn, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+def sample_lms(model, x, sigmas, extra_args=None, callback=None, disable=None, order=4):
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    sigmas_cpu = sigmas.detach().cpu().numpy()
+    ds = []
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        d = _to_d(x, sigmas[i], denoised)
+        ds.append(d)
+        if len(ds) > order:
+            ds.pop(0)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        cur_order = min(i + 1, order)
+        coeffs = [linear_multistep_coeff(cur_order, sigmas_cpu, i, j) for j in range(cur_order)]
+        x = _lc(torch.empty_like(x), [x] + list(reversed(ds))[:cur_order], [1.0] + coeffs)
+    return x
+
+
+def sample_dpmpp_2s_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda sigma: sigma.log().neg()
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        if sigma_down == 0:
+            x = _lc(torch.empty_like(x), [x, _to_d(x, sigmas[i], denoised)], [1.0, float(sigma_down - sigmas[i])])
+        else:
+            t, t_next = t_fn(sigmas[i]), t_fn(sigma_down)
+            r = 1 / 2
+            h = t_next - t
+            s_ = t + r * h
+            x_2 = _lc(torch.empty_like(x), [x, denoised], [float(sigma_fn(s_) / sigma_fn(t)), -float((-h * r).expm1())])
+            denoised_2 = model(x_2, sigma_fn(s_) * s_in, **extra_args)
+            x = _lc(torch.empty_like(x), [x, denoised_2], [float(sigma_fn(t_next) / sigma_fn(t)), -float((-h).expm1())])
+        if sigmas[i + 1] > 0:
+            x = _lc(torch.empty_like(x), [x, noise_sampler(sigmas[i], sigmas[i + 1])], [1.0, s_noise * float(sigma_up)])
+    return x
+
+
+def plms(model, x, timesteps, extra_args=None, callback=None, disable=None):
+    """modules/sd_samplers_timesteps_impl.py:85-137: pseudo linear multistep on eps; coefficients in fp32 as there."""
+    alphas_cumprod = model.inner_model.inner_model.alphas_cumprod.float().cpu()
+    timesteps = timesteps.cpu()
+    alphas = alphas_cumprod[timesteps]
+    alphas_prev = alphas_cumprod[torch.nn.functional.pad(timesteps[:-1], pad=(1, 0))].to(torch.float64)
+    sqrt_one_minus_alphas = torch.sqrt(1 - alphas)
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+    old_eps = []
+
+    def get_x_prev_and_pred_x0(e_t, index):
+        a_t, a_prev = f32(alphas[index].item()), f32(alphas_prev[index].item())
+        somat = f32(sqrt_one_minus_alphas[index].item())
+        # pred_x0 = (x - somat*e)/sqrt(a_t);  x_prev = sqrt(a_prev)*pred_x0 + sqrt(1-a_prev)*e
+        pred_x0 = _lc(torch.empty_like(x), [x, e_t], [1.0 / float(a_t.sqrt()), -float(somat) / float(a_t.sqrt())])
+        x_prev = _lc(torch.empty_like(x), [pred_x0, e_t], [float(a_prev.sqrt()), float((1. - a_prev).sqrt())])
+        return x_prev, pred_x0
+
+    for i in range(len(timesteps) - 1):
+        index = len(timesteps) - 1 - i
+        ts = timesteps[index].item() * s_in
+        t_next = timesteps[max(index - 1, 0)].item() * s_in
+        e_t = model(x, ts, **extra_args)
+        if len(old_eps) == 0:
+            x_prev, pred_x0 = get_x_prev_and_pred_x0(e_t, index)
+            e_t_next = model(x_prev, t_next, **extra_args)
+            e_t_prime = _lc(torch.empty_like(x), [e_t, e_t_next], [0.5, 0.5])
+        elif len(old_eps) == 1:
+            e_t_prime = _lc(torch.empty_like(x), [e_t, old_eps[-1]], [3 / 2, -1 / 2])
+        elif len(old_eps) == 2:
+            e_t_prime = _lc(torch.empty_like(x), [e_t, old_eps[-1], old_eps[-2]], [23 / 12, -16 / 12, 5 / 12])
+        else:
+            e_t_prime = _lc(torch.empty_like(x), [e_t, old_eps[-1], old_eps[-2], old_eps[-3]], [55 / 24, -59 / 24, 37 / 24, -9 / 24])
+        x_prev, pred_x0 = get_x_prev_and_pred_x0(e_t_prime, index)
+        old_eps.append(e_t)
+        if len(old_eps) >= 4:
+            old_eps.pop(0)
+        x = x_prev
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': 0, 'sigma_hat': 0, 'denoised': pred_x0})
+    return x
+
+
 def ddim(model, x, timesteps, extra_args=None, callback=None, disable=None, eta=0.0, noise_sampler=None):
     """modules/sd_samplers_timesteps_impl.py:12-40 (alphas_prev in float64 at :15, per-step coefficients fp32)."""
     alphas_cumprod = model.inner_model.inner_model.alphas_cumprod.float().cpu()
@@ -375,6 +559,27 @@ class Sampler:
                 extra_params_kwargs[param_name] = getattr(p, param_name)
         if 'eta' in params:
             extra_params_kwargs['eta'] = self.eta
+        if len(self.extra_params) > 0:                    # modules/sd_samplers_common.py:309-331 (options override p)
+            opts = shared.opts
+            s_churn = getattr(opts, 's_churn', getattr(p, 's_churn', 0.0))
+            s_tmin = getattr(opts, 's_tmin', getattr(p, 's_tmin', 0.0))
+            s_tmax = getattr(opts, 's_tmax', getattr(p, 's_tmax', 0.0)) or self.s_tmax      # 0 = inf
+            s_noise = getattr(opts, 's_noise', getattr(p, 's_noise', 1.0))
+            if 's_churn' in extra_params_kwargs and s_churn != self.s_churn:
+                extra_params_kwargs['s_churn'] = s_churn
+                p.s_churn = s_churn
+            if 's_tmin' in extra_params_kwargs and s_tmin != self.s_tmin:
+                extra_params_kwargs['s_tmin'] = s_tmin
+                p.s_tmin = s_tmin
+            if 's_tmax' in extra_params_kwargs and s_tmax != self.s_tmax:
+                extra_params_kwargs['s_tmax'] = s_tmax
+                p.s_tmax = s_tmax
+            if 's_noise' in extra_params_kwargs and s_noise != self.s_noise:
+                extra_params_kwargs['s_noise'] = s_noise
+                p.s_noise = s_noise
+            for k in ('s_churn', 's_tmin', 's_tmax', 's_noise'):     # a caller that left the field unset gets the sampler default
+                if k in extra_params_kwargs and extra_params_kwargs[k] is None:
+                    extra_params_kwargs[k] = getattr(self, k)
         if 'noise_sampler' in params:
             rng = p.rng                                   # TorchHijack.randn_like -> p.rng.next() (common.py:205-226)
             extra_params_kwargs['noise_sampler'] = (lambda *a: rng.next())
@@ -387,21 +592,25 @@ class Sampler:
         raise NotImplementedError()
 
 
+# the rows of modules/sd_samplers_kdiffusion.py:11-27 the engine implements (same labels, aliases and options); the SDE /
+# DPM fast / adaptive / Restart rows need BrownianTree noise or adaptive step control and are not implemented yet
 samplers_k_diffusion = [
     ('DPM++ 2M', sample_dpmpp_2m, ['k_dpmpp_2m'], {'scheduler': 'karras'}),
+    ('DPM++ 2S a', sample_dpmpp_2s_ancestral, ['k_dpmpp_2s_a'], {'scheduler': 'karras', "uses_ensd": True, "second_order": True}),
     ('Euler a', sample_euler_ancestral, ['k_euler_a', 'k_euler_ancestral'], {"uses_ensd": True}),
     ('Euler', sample_euler, ['k_euler'], {}),
+    ('LMS', sample_lms, ['k_lms'], {}),
+    ('Heun', sample_heun, ['k_heun'], {"second_order": True}),
+    ('DPM2', sample_dpm_2, ['k_dpm_2'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "second_order": True}),
+    ('DPM2 a', sample_dpm_2_ancestral, ['k_dpm_2_a'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "uses_ensd": True, "second_order": True}),
 ]
-sampler_extra_params = {
+sampler_extra_params = {                                 # modules/sd_samplers_kdiffusion.py:36-46
     'sample_euler': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
+    'sample_heun': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
+    'sample_dpm_2': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
+    'sample_dpm_2_ancestral': ['s_noise'],
+    'sample_dpmpp_2s_ancestral': ['s_noise'],
 }
-schedulers_map = {
-    'automatic': None, 'Automatic': None,
-    'uniform': 'uniform', 'Uniform': 'uniform',
-    'karras': 'karras', 'Karras': 'karras',
-    'exponential': 'exponential', 'Exponential': 'exponential',
-}
-
 
 class KDiffusionSampler(Sampler):
     def __init__(self, func, sd_model, options=None):
@@ -420,31 +629,28 @@ class KDiffusionSampler(Sampler):
             discard_next_to_last_sigma = True
         steps += 1 if discard_next_to_last_sigma else 0
         scheduler_name = (getattr(p, 'hr_scheduler', None) if getattr(p, 'is_hr_pass', False) else getattr(p, 'scheduler', None)) or 'Automatic'
-        if scheduler_name not in schedulers_map:
-            raise NotImplementedError(f"scheduler {scheduler_name!r} is not implemented in the engine")
-        sched = schedulers_map[scheduler_name]
-        if sched is None:
-            sched = self.config.options.get('scheduler', None) if self.config is not None else None
+        if scheduler_name == 'Automatic':
+            scheduler_name = self.config.options.get('scheduler', None) if self.config is not None else None
+        scheduler = schedulers_map.get(scheduler_name)
+        if scheduler_name is not None and scheduler is None:
+            raise NotImplementedError(f"unknown scheduler {scheduler_name!r}")
         m_sigma_min, m_sigma_max = self.model_wrap.sigmas[0].item(), self.model_wrap.sigmas[-1].item()
         sigma_min, sigma_max = (0.1, 10) if opts.use_old_karras_scheduler_sigmas else (m_sigma_min, m_sigma_max)
         if getattr(p, 'sampler_noise_scheduler_override', None):
             sigmas = p.sampler_noise_scheduler_override(steps)
-        elif sched is None:
+        elif scheduler is None or scheduler.function is None:
             sigmas = self.model_wrap.get_sigmas(steps)
         else:
-            kwargs = {'sigma_min': sigma_min, 'sigma_max': sigma_max}
+            sigmas_kwargs = {'sigma_min': sigma_min, 'sigma_max': sigma_max}
             if opts.sigma_min != 0 and opts.sigma_min != m_sigma_min:
-                kwargs['sigma_min'] = opts.sigma_min
+                sigmas_kwargs['sigma_min'] = opts.sigma_min
             if opts.sigma_max != 0 and opts.sigma_max != m_sigma_max:
-                kwargs['sigma_max'] = opts.sigma_max
-            if sched == 'karras':
-                if opts.rho != 0 and opts.rho != 7.0:
-                    kwargs['rho'] = opts.rho
-                sigmas = get_sigmas_karras(n=steps, **kwargs, device='cpu')
-            elif sched == 'exponential':
-                sigmas = get_sigmas_exponential(n=steps, **kwargs, device='cpu')
-            else:
-                sigmas = self.model_wrap.get_sigmas(steps)
+                sigmas_kwargs['sigma_max'] = opts.sigma_max
+            if scheduler.default_rho != -1 and opts.rho != 0 and opts.rho != scheduler.default_rho:
+                sigmas_kwargs['rho'] = opts.rho
+            if scheduler.need_inner_model:
+                sigmas_kwargs['inner_model'] = self.model_wrap
+            sigmas = scheduler.function(n=steps, **sigmas_kwargs, device='cpu')
         if discard_next_to_last_sigma:
             sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
         return sigmas.cpu()
@@ -582,8 +788,9 @@ samplers_data_k_diffusion = [
     SamplerData(label, lambda model, func=func: KDiffusionSampler(func, model), aliases, options)
     for label, func, aliases, options in samplers_k_diffusion
 ]
-samplers_data_timesteps = [
+samplers_data_timesteps = [                               # modules/sd_samplers_timesteps.py:12-17 (UniPC, DDIM CFG++: not yet)
     SamplerData('DDIM', lambda model: CompVisSampler(ddim, model), [], {}),
+    SamplerData('PLMS', lambda model: CompVisSampler(plms, model), [], {}),
 ]
 all_samplers = [*samplers_data_k_diffusion, *samplers_data_timesteps]
 all_samplers_map = {x.name: x for x in all_samplers}

@@ -31,6 +31,8 @@ class Options:
     img2img_fix_steps: bool = False
     enable_quantization: bool = False              # :176
     live_previews_enable: bool = False             # :374 (fused path requires previews off)
+    beta_dist_alpha: float = 0.6                   # :408
+    beta_dist_beta: float = 0.6                    # :409
 
 
 opts = Options()
@@ -47,3 +49,4 @@ class State:
 
 
 state = State()
+sd_model = None                                    # set by sd_models.SdModel (schedulers read is_sdxl, sd_schedulers.py:57)

@@ -166,6 +166,63 @@ def gen_ddim():
         out[f"c{ci}_out"] = res.numpy()
     np.savez_compressed(os.path.join(OUT, "ddim.npz"), **out)
     print("ddim.npz")
+    # PLMS (same file, :85-137): deterministic, no noise
+    out = {}
+    for ci, steps in enumerate([20, 6]):
+        timesteps = torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+        x0 = seeded((2, 4, 8, 8), 870 + ci)
+        res = impl.plms(Model(), x0.clone(), timesteps, extra_args={}, disable=True)
+        out[f"c{ci}_steps"] = np.array([steps])
+        out[f"c{ci}_out"] = res.numpy()
+    np.savez_compressed(os.path.join(OUT, "plms.npz"), **out)
+    print("plms.npz")
+
+
+def gen_schedulers():
+    """Execute modules/sd_schedulers.py.  Its only third-party dependency is the k-diffusion denoiser object passed in as
+    ``inner_model`` (sigmas / sigma_to_t / t_to_sigma / get_sigmas) and k_diffusion.sampling's three get_sigmas_* functions
+    referenced by the table; the oracle's restatements stand in for both (they are what the fixture is NOT pinning)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import kdiffusion as okd, schedulers as osch
+    kd = types.ModuleType("k_diffusion")
+    kds = types.ModuleType("k_diffusion.sampling")
+    kds.get_sigmas_karras = lambda n, sigma_min, sigma_max, rho=7.0, device="cpu": okd.get_sigmas_karras(n, sigma_min, sigma_max, rho)
+    kds.get_sigmas_exponential = lambda n, sigma_min, sigma_max, device="cpu": osch.get_sigmas_exponential(n, sigma_min, sigma_max)
+    kds.get_sigmas_polyexponential = lambda n, sigma_min, sigma_max, rho=1.0, device="cpu": osch.get_sigmas_polyexponential(n, sigma_min, sigma_max, rho)
+    kd.sampling = kds
+    sys.modules["k_diffusion"] = kd
+    sys.modules["k_diffusion.sampling"] = kds
+    sys.modules.setdefault("modules", types.ModuleType("modules"))
+    shared = types.ModuleType("modules.shared")
+
+    class Opts:
+        beta_dist_alpha = 0.6
+        beta_dist_beta = 0.6
+
+    class SdModel:
+        is_sdxl = False
+    shared.opts, shared.sd_model = Opts(), SdModel()
+    sys.modules["modules.shared"] = shared
+    sys.modules["modules"].shared = shared
+    ref = load_by_path("ref_sd_schedulers", "modules/sd_schedulers.py")
+    inner = okd.CompVisDenoiser(None, okd.make_alphas_cumprod())
+    smin, smax = inner.sigmas[0].item(), inner.sigmas[-1].item()
+    out = {"names": np.array([s.name for s in ref.schedulers]), "labels": np.array([s.label for s in ref.schedulers]),
+           "default_rho": np.array([s.default_rho for s in ref.schedulers]),
+           "need_inner_model": np.array([s.need_inner_model for s in ref.schedulers])}
+    for n in (5, 11, 20, 50):
+        for sch in ref.schedulers:
+            if sch.function is None or sch.name in ("karras", "exponential", "polyexponential"):
+                continue
+            if sch.need_inner_model:
+                sig = sch.function(n, smin, smax, inner, "cpu")
+            else:
+                sig = sch.function(n, smin, smax, "cpu")
+            out[f"{sch.name}_{n}"] = torch.as_tensor(sig).float().numpy()
+    SdModel.is_sdxl = True
+    out["align_your_steps_sdxl_20"] = ref.get_align_your_steps_sigmas(20, smin, smax, "cpu").numpy()
+    np.savez_compressed(os.path.join(OUT, "schedulers.npz"), **out)
+    print("schedulers.npz")
 
 
 if __name__ == "__main__":
@@ -174,3 +231,4 @@ if __name__ == "__main__":
     gen_subquad()
     gen_vae()
     gen_ddim()
+    gen_schedulers()

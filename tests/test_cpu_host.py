@@ -101,6 +101,66 @@ def test_sampler_registry_and_sigma_selection():
     assert ss.setup_img2img_steps(P2(), 20) == (26, 19)
 
 
+def test_host_schedulers_match_reference_functions(golden_dir):
+    """The product's sd_schedulers module (host side, like the reference's) against the same reference-generated fixture the
+    oracle is pinned with, plus the table itself (names, labels, default_rho, need_inner_model, aliases)."""
+    hs, ss = sub("sd_schedulers"), sub("sd_samplers")
+    z = np.load(os.path.join(golden_dir, "schedulers.npz"))
+    assert [x.name for x in hs.schedulers] == list(z["names"]) and [x.label for x in hs.schedulers] == list(z["labels"])
+    assert [x.default_rho for x in hs.schedulers] == list(z["default_rho"])
+    assert [x.need_inner_model for x in hs.schedulers] == list(z["need_inner_model"])
+    assert hs.schedulers_map["SGM Uniform"] is hs.schedulers_map["sgm_uniform"]
+
+    class M:
+        alphas_cumprod = sub("schema").make_alphas_cumprod()
+    inner = ss.CompVisDenoiser(M())
+    smin, smax = inner.sigmas[0].item(), inner.sigmas[-1].item()
+    for n in (5, 11, 20, 50):
+        for sch in hs.schedulers:
+            key = f"{sch.name}_{n}"
+            if key not in z.files:
+                continue
+            got = sch.function(n, smin, smax, inner, "cpu") if sch.need_inner_model else sch.function(n, smin, smax, "cpu")
+            np.testing.assert_allclose(got.float().numpy(), z[key], rtol=1e-6, atol=1e-7, err_msg=key)
+    from oracle import schedulers as osch
+    for n in (7, 30):
+        assert torch.equal(hs.get_sigmas_exponential(n, smin, smax), osch.get_sigmas_exponential(n, smin, smax))
+        assert torch.equal(hs.get_sigmas_polyexponential(n, smin, smax, 1.0), osch.get_sigmas_polyexponential(n, smin, smax, 1.0))
+
+
+def test_sampler_table_matches_reference_rows():
+    """Labels, aliases and options of the implemented rows of modules/sd_samplers_kdiffusion.py:11-27 and
+    modules/sd_samplers_timesteps.py:12-17; scheduler selection and the discarded penultimate sigma follow :79-132."""
+    ss = sub("sd_samplers")
+    rows = {x.name: x for x in ss.all_samplers}
+    assert rows["DPM2"].options == {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "second_order": True}
+    assert rows["DPM2 a"].aliases == ['k_dpm_2_a'] and rows["DPM++ 2S a"].options["uses_ensd"] is True
+    assert rows["Heun"].options == {"second_order": True} and rows["LMS"].aliases == ['k_lms']
+    assert {"PLMS", "DDIM"} <= set(rows)
+    assert ss.sampler_extra_params['sample_heun'] == ['s_churn', 's_tmin', 's_tmax', 's_noise']
+
+    class M:
+        alphas_cumprod = sub("schema").make_alphas_cumprod()
+        engine = None
+
+    class P:
+        scheduler = None
+        is_hr_pass = False
+        sampler_noise_scheduler_override = None
+    from oracle import pipeline as opipe
+    ora = okd.CompVisDenoiser(None, okd.make_alphas_cumprod())
+    for name, key in (("DPM2", "dpm_2"), ("DPM2 a", "dpm_2_a"), ("Heun", "heun"), ("LMS", "lms"), ("DPM++ 2S a", "dpmpp_2s_a")):
+        got = ss.create_sampler(name, M()).get_sigmas(P(), 12)
+        want = opipe.get_sigmas(ora, key, 12)
+        assert torch.equal(got, want), name
+    assert ss.create_sampler("DPM2", M()).get_sigmas(P(), 12).shape == (13,)       # 13 + 1 sigmas, penultimate dropped
+    P.scheduler = "Align Your Steps"
+    assert abs(float(ss.create_sampler("Euler", M()).get_sigmas(P(), 11)[1]) - 6.475) < 1e-5
+    P.scheduler = "no such scheduler"
+    with pytest.raises(NotImplementedError):
+        ss.create_sampler("Euler", M()).get_sigmas(P(), 10)
+
+
 def test_shard_range_partitions_exactly():
     par = sub("parallel")
     for n in (1, 7, 8, 64, 65):

@@ -126,7 +126,9 @@ def test_vae_decoder_against_reference_class_fixture(dev, golden_dir):
 
 
 @pytest.mark.parametrize("sampler,name,steps", [("euler_a", "Euler a", 5), ("dpmpp_2m", "DPM++ 2M", 6), ("ddim", "DDIM", 5),
-                                                ("euler", "Euler", 4)])
+                                                ("euler", "Euler", 4), ("heun", "Heun", 4), ("dpm_2", "DPM2", 4),
+                                                ("dpm_2_a", "DPM2 a", 4), ("lms", "LMS", 6), ("dpmpp_2s_a", "DPM++ 2S a", 4),
+                                                ("plms", "PLMS", 5)])
 def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     from oracle import pipeline as opipe
     processing = sub("processing")
@@ -140,6 +142,44 @@ def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     assert len(res.images) == 2 and res.images[0].shape == (32, 32, 3) and res.images[0].dtype == np.uint8
     diff = np.abs(np.stack(res.images).astype(np.int32) - u8.astype(np.int32))
     assert diff.mean() < 2.0          # uint8 images agree to rounding of a few levels
+
+
+@pytest.mark.parametrize("sched,key", [("SGM Uniform", "sgm_uniform"), ("KL Optimal", "kl_optimal"), ("Exponential", "exponential"),
+                                       ("Beta", "beta")])
+def test_txt2img_scheduler_choice_vs_oracle(dev, tiny, sched, key):
+    """p.scheduler routes through the scheduler table (modules/sd_samplers_kdiffusion.py:87-126) to the same sigmas as the oracle."""
+    from oracle import pipeline as opipe
+    processing = sub("processing")
+    cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=77, batch_size=2, steps=5,
+                                                    cfg_scale=6.0, width=128, height=128, sampler_name="Euler", scheduler=sched)
+    res = processing.process_images(p)
+    lat = opipe.sample(tiny["oracle"], cond, uncond, [77, 78], 5, "euler", 6.0, (16, 16), scheduler=key)
+    assert rel_l2(res.latents.cpu(), lat) < 1e-2, sched
+
+
+@pytest.mark.parametrize("sampler,name", [("euler_a", "Euler a"), ("ddim", "DDIM"), ("plms", "PLMS")])
+def test_inpainting_mask_paths_vs_oracle(dev, tiny, sampler, name):
+    """img2img with a latent mask: k-diffusion samplers blend AFTER denoising (cfg_denoiser.py:292-293, fused into the CFG
+    combine kernel), timestep samplers BEFORE (:186-187, sdmi_mask_blend on a copy); both end with processing.py:1776-1784."""
+    from oracle import pipeline as opipe
+    processing = sub("processing")
+    model, om = tiny["model"], tiny["oracle"]
+    cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(11))
+    mask = torch.zeros(2, 4, 16, 16)
+    mask[:, :, 4:12, 2:9] = 1.0                          # 1 = keep the original latent there
+    mask[1, :, 0:3, :] = 0.5                             # soft mask values blend
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=3000, batch_size=2, steps=5, cfg_scale=7.0,
+                                                    width=128, height=128, sampler_name=name, init_images=img,
+                                                    denoising_strength=0.6, latent_mask=mask)
+    res = processing.process_images(p)
+    init = om.vae.encode_first_stage_mean(img.half().float() * 2 - 1)
+    lat = opipe.sample(om, cond, uncond, [3000, 3001], 5, sampler, 7.0, (16, 16), init_latent=init, denoising_strength=0.6,
+                       img2img_steps_given=False, mask=mask)
+    assert rel_l2(res.latents.cpu(), lat) < 1.5e-2, sampler
+    keep = mask == 1.0
+    assert rel_l2(res.latents.cpu()[keep], init[keep]) < 5e-3            # masked region = the encoded original
 
 
 def test_txt2img_batch_split_matches(dev, tiny):

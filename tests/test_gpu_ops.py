@@ -342,6 +342,24 @@ def test_layernorm_vs_torch(dev, c):
 # ------------------------------------------------------------------------------------------------------------
 # sampler arithmetic
 # ------------------------------------------------------------------------------------------------------------
+def test_lincomb_and_mask_blend(dev):
+    ops = sub("ops")
+    ts = [seeded((2, 4, 8, 8), 40 + i) for i in range(6)]
+    cs = [0.5, -1.25, 3.0, 0.125, -0.75, 2.0]
+    for n in (1, 2, 3, 6):
+        want = ts[0] * cs[0]
+        for k in range(1, n):
+            want = want + ts[k] * cs[k]
+        got = ops.lincomb(torch.empty(2, 4, 8, 8, device=dev), [t.to(dev) for t in ts[:n]], cs[:n])
+        assert torch.equal(got.cpu(), want), n                       # same left-to-right fp32 mul/add sequence
+    x = ts[0].to(dev).clone()
+    ops.lincomb(x, [x, ts[1].to(dev)], [1.0, 0.5])                   # in place on a term
+    assert torch.equal(x.cpu(), ts[0] * 1.0 + ts[1] * 0.5)
+    mask = (seeded((2, 1, 8, 8), 50) > 0).float()
+    xb = ops.mask_blend(ts[2].to(dev).clone(), ts[3].to(dev), mask.to(dev), (1 - mask).to(dev))
+    assert torch.equal(xb.cpu(), ts[2] * (1 - mask) + ts[3] * mask)
+
+
 def test_sampler_kernels_match_oracle_formulas(dev):
     from oracle import kdiffusion as okd
     lib = sub("_lib")

@@ -111,6 +111,50 @@ def test_ddim_matches_reference(golden_dir):
         np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
 
 
+def test_plms_matches_reference(golden_dir):
+    """oracle sample_plms == modules/sd_samplers_timesteps_impl.py:85-137 on an analytic eps model."""
+    z = np.load(os.path.join(golden_dir, "plms.npz"))
+    ac = kd.make_alphas_cumprod()
+
+    def model(x, t, **kw):
+        return torch.tanh(0.7 * x + (t / 1000.0)[:, None, None, None]) * 0.9 + 0.05 * x
+
+    for ci in range(2):
+        steps = int(z[f"c{ci}_steps"][0])
+        out = kd.sample_plms(model, seeded((2, 4, 8, 8), 870 + ci), kd.ddim_timesteps(steps), ac, {})
+        np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
+
+
+def test_schedulers_match_reference_functions(golden_dir):
+    """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
+    kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
+    default_rho / need_inner_model as :130-143."""
+    from oracle import schedulers as osch
+    z = np.load(os.path.join(golden_dir, "schedulers.npz"))
+    inner = kd.CompVisDenoiser(None, kd.make_alphas_cumprod())
+    smin, smax = inner.sigmas[0].item(), inner.sigmas[-1].item()
+    assert list(z["names"])[1:] == list(osch.SCHEDULERS) and z["names"][0] == "automatic"
+    for i, name in enumerate(z["names"]):
+        if name != "automatic":
+            assert bool(z["need_inner_model"][i]) == osch.SCHEDULERS[name][1], name
+    checked = 0
+    for n in (5, 11, 20, 50):
+        for name, (fn, need_inner) in osch.SCHEDULERS.items():
+            key = f"{name}_{n}"
+            if key not in z.files:
+                continue
+            got = fn(n, smin, smax, inner) if need_inner else fn(n, smin, smax)
+            np.testing.assert_allclose(torch.as_tensor(got).float().numpy(), z[key], rtol=1e-6, atol=1e-7, err_msg=key)
+            checked += 1
+    assert checked == 4 * 8
+    np.testing.assert_allclose(osch.align_your_steps(20, smin, smax, is_sdxl=True).numpy(), z["align_your_steps_sdxl_20"], rtol=1e-6)
+    # third-party get_sigmas_* (restated): end points and monotonicity
+    for fn in (osch.get_sigmas_exponential, osch.get_sigmas_polyexponential, kd.get_sigmas_karras):
+        s = fn(20, smin, smax)
+        assert s.shape == (21,) and abs(s[0].item() - smax) < 1e-3 and abs(s[-2].item() - smin) < 1e-5 and s[-1] == 0
+        assert bool((s[:-1] > s[1:]).all())
+
+
 def test_schedule_known_answers():
     """SURVEY.md appendix A.3 (in-tree hints modules/shared_options.py:396-397, sd_schedulers.py:60-63)."""
     ac = kd.make_alphas_cumprod()
