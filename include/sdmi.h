@@ -207,6 +207,19 @@ int sdmi_unet_load_tensor(sdmi_engine* e, const char* key, const void* data, int
                           const int64_t* shape, int on_device);
 int sdmi_unet_finalize(sdmi_engine* e);            /* packs layouts; errors if a required key is missing */
 
+/* Replace ONE conv / linear weight ("<layer>.weight", same shape as loaded) of the finalized UNet: re-packed in place.
+ * This is where the weight rewrite of extensions-builtin/Lora/networks.py:411-480 (network_apply_weights: restore the
+ * backup, add every loaded network's delta, copy into the layer) lands for a UNet that no longer owns torch modules.
+ * Call sdmi_unet_set_context again afterwards (cached cross-attention projections depend on attn2.to_k / to_v). */
+int sdmi_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim,
+                            const int64_t* shape, int on_device);
+
+/* out[rows*cols] fp32 = W + scale * (up[rows][rank] @ down[rank][cols]); W / up / down fp16 or fp32 device tensors.
+ * The LoRA delta of extensions-builtin/Lora/network_lora.py:65-80 with lyco_helpers.rebuild_conventional (:9-15) and
+ * network.py:196-216 finalize_updown (scale = alpha / rank * multiplier) folded into the weight in one pass. */
+int sdmi_lora_merge(void* out_f32, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype,
+                    int rows, int cols, int rank, float scale, void* stream);
+
 int sdmi_vae_configure(sdmi_engine* e, const sdmi_vae_config* cfg);
 int sdmi_vae_load_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim,
                          const int64_t* shape, int on_device);

@@ -11,6 +11,7 @@ int vae_encode(sdmi_engine* e, const void* x, int io_dtype, float* out, int B, i
 int engine_load_unet_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_load_vae_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_unet_finalize(sdmi_engine* e);
+int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_vae_finalize(sdmi_engine* e);
 int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s);
 }  // namespace sdmi
@@ -263,6 +264,20 @@ int sdmi_unet_load_tensor(sdmi_engine* e, const char* key, const void* data, int
 int sdmi_unet_finalize(sdmi_engine* e) {
     API_GUARD_BEGIN
     return engine_unet_finalize(e);
+    API_GUARD_END
+}
+int sdmi_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                            int on_device) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_unet_update_weight(e, key, data, dtype, ndim, shape, on_device);
+    API_GUARD_END
+}
+int sdmi_lora_merge(void* out, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype,
+                    int rows, int cols, int rank, float scale, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(out && w && up && down && rows > 0 && cols > 0 && rank > 0, "bad lora_merge arguments");
+    return launch_lora_merge((float*)out, w, w_dtype, up, up_dtype, down, down_dtype, rows, cols, rank, scale, (hipStream_t)stream);
     API_GUARD_END
 }
 int sdmi_vae_configure(sdmi_engine* e, const sdmi_vae_config* cfg) {

@@ -124,6 +124,8 @@ int launch_ddim_step(float* x, const float* e, const float* noise, float* pred_x
                      float sigma_t, float somat, int64_t n, hipStream_t s);
 int launch_axpby(float* y, const float* x, float a, const float* z, float b, int64_t n, hipStream_t s);
 int launch_lincomb(float* out, const float* const* terms, const float* coefs, int n_terms, int64_t n, hipStream_t s);
+int launch_lora_merge(float* out, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype,
+                      int rows, int cols, int rank, float scale, hipStream_t s);
 int launch_mask_blend(float* x, const float* init, const float* mask, const float* nmask, int64_t n, hipStream_t s);
 int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
 

@@ -217,6 +217,42 @@ int launch_mask_blend(float* x, const float* init, const float* mask, const floa
     return 0;
 }
 
+// W' = W + scale * (up @ down): the LoRA weight delta of extensions-builtin/Lora/network_lora.py:65-80 (rebuild_conventional,
+// lyco_helpers.py:9-15) folded into the weight, fp32 accumulate in k order.  up [rows][rank], down [rank][cols] (cols = Cin*kh*kw
+// for conv weights), W any of fp16 / fp32; one thread per output element (a few MFLOP per layer, done once per LoRA change).
+template <typename TW, typename TU, typename TD>
+__global__ __launch_bounds__(256) void lora_merge_kernel(float* out, const TW* w, const TU* up, const TD* down, int rows,
+                                                         int cols, int rank, float scale) {
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+        float acc = 0.f;
+        for (int k = 0; k < rank; ++k) acc += (float)up[(long)r * rank + k] * (float)down[(long)k * cols + c];
+        out[i] = (float)w[i] + acc * scale;
+    }
+}
+int launch_lora_merge(float* out, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype,
+                      int rows, int cols, int rank, float scale, hipStream_t s) {
+    const long n = (long)rows * cols;
+#define SDMI_LM(TW, TU, TD)                                                                                              \
+    hipLaunchKernelGGL((lora_merge_kernel<TW, TU, TD>), dim3(ew_blocks(n)), dim3(256), 0, s, out, (const TW*)w,           \
+                       (const TU*)up, (const TD*)down, rows, cols, rank, scale)
+    const int sel = (w_dtype == 0 ? 0 : 4) | (up_dtype == 0 ? 0 : 2) | (down_dtype == 0 ? 0 : 1);
+    switch (sel) {
+        case 0: SDMI_LM(half_t, half_t, half_t); break;
+        case 1: SDMI_LM(half_t, half_t, float); break;
+        case 2: SDMI_LM(half_t, float, half_t); break;
+        case 3: SDMI_LM(half_t, float, float); break;
+        case 4: SDMI_LM(float, half_t, half_t); break;
+        case 5: SDMI_LM(float, half_t, float); break;
+        case 6: SDMI_LM(float, float, half_t); break;
+        default: SDMI_LM(float, float, float); break;
+    }
+#undef SDMI_LM
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void image_to_u8_kernel(const float* img, uint8_t* out, int C, long HW, long n) {
     // n = B*HW*C output elements, NHWC
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {

@@ -108,6 +108,9 @@ static int pack_stack(sdmi_engine* e, const std::map<std::string, RawTensor>& m,
         const int kh = taps == 9 ? 3 : 1;
         TRY(launch_pack_conv_weight(w->ptr, w->dtype, out->w + (size_t)row * taps * out->cin_pad, O, cin, kh, kh, Opad,
                                     out->cin_pad, geglu ? 1 : 0, 0));
+        if (e->recording_unet_sites)
+            e->unet_sites[names[i] + ".weight"].push_back({out->w + (size_t)row * taps * out->cin_pad, O, cin, kh, Opad,
+                                                           out->cin_pad, geglu ? 1 : 0});
         const RawTensor* b = find_raw(m, names[i] + ".bias");
         if (b) TRY(launch_pack_bias(b->ptr, b->dtype, out->b + row, O, Opad, geglu ? 1 : 0, 0));
         row += Opad;
@@ -1018,8 +1021,46 @@ int engine_load_vae_tensor(sdmi_engine* e, const char* key, const void* data, in
 }
 int engine_unet_finalize(sdmi_engine* e) {
     SDMI_CHECK_HIP(hipSetDevice(e->device));
+    e->unet_sites.clear();
+    e->recording_unet_sites = true;
     const int rc = unet_build(e);
+    e->recording_unet_sites = false;
     free_raw(e->raw_unet);
+    return rc;
+}
+// Re-pack one conv / linear weight of the finalized UNet in place (same shape as at load time).  The caller re-runs
+// sdmi_unet_set_context afterwards: cached cross-attention K / V^T depend on attn2.to_k / to_v.
+int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                              int on_device) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    SDMI_REQUIRE(e->unet.ready, "unet not finalized");
+    SDMI_REQUIRE(key && data && (ndim == 2 || ndim == 4), "bad tensor arguments");
+    SDMI_REQUIRE(dtype == SDMI_F16 || dtype == SDMI_F32, "dtype must be SDMI_F16 or SDMI_F32");
+    auto it = e->unet_sites.find(key);
+    SDMI_REQUIRE(it != e->unet_sites.end(), std::string("no packed conv / linear weight named ") + key);
+    const int O = (int)shape[0], I = (int)shape[1], kh = ndim == 4 ? (int)shape[2] : 1;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    const void* src = data;
+    void* tmp = nullptr;
+    if (!on_device) {
+        const size_t bytes = n * (dtype == SDMI_F16 ? 2 : 4);
+        SDMI_CHECK_HIP(hipMalloc(&tmp, bytes));
+        SDMI_CHECK_HIP(hipMemcpy(tmp, data, bytes, hipMemcpyHostToDevice));
+        src = tmp;
+    }
+    int rc = 0;
+    for (const auto& st : it->second) {
+        if (st.O != O || st.cin != I || st.kh != kh || (ndim == 4 && shape[3] != kh)) {
+            set_error(std::string("shape of ") + key + " differs from the loaded weight");
+            rc = 1;
+            break;
+        }
+        rc = launch_pack_conv_weight(src, dtype, st.dst, O, I, kh, kh, st.Opad, st.cin_pad, st.geglu, 0);
+        if (rc) break;
+    }
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    if (tmp) (void)hipFree(tmp);
     return rc;
 }
 int engine_vae_finalize(sdmi_engine* e) {

@@ -122,6 +122,11 @@ public:
 struct sdmi_engine {
     int device = 0;
     std::map<std::string, sdmi::RawTensor> raw_unet, raw_vae;
+    // where each "<layer>.weight" of the UNet checkpoint landed in the packed weights (filled by the build), so that a single
+    // layer can be re-packed in place when a LoRA changes it (sdmi_unet_update_weight)
+    struct PackSite { half_t* dst; int O, cin, kh, Opad, cin_pad, geglu; };
+    std::map<std::string, std::vector<PackSite>> unet_sites;
+    bool recording_unet_sites = false;
     std::vector<void*> owned;                 // persistent device allocations (weights)
     sdmi::UNetW unet;
     sdmi::VAEW vae;

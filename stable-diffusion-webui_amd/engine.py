@@ -91,6 +91,13 @@ class Engine:
         check(lib.sdmi_unet_finalize(self.handle), "unet_finalize")
         self._ctx_key = None
 
+    def update_unet_weight(self, key: str, t: torch.Tensor):
+        """Replace one conv / linear weight of the loaded UNet (LoRA rewrite, networks.network_apply_weights) and drop the
+        cached cross-attention projections."""
+        self._load(lib.sdmi_unet_update_weight, key, t)
+        self._ctx_key = None
+        self.weights_version = getattr(self, "weights_version", 0) + 1
+
     def load_vae(self, cfg: VAEConfig, state_dict: dict, prefix: str = VAE_PREFIX, decoder_only: bool = False):
         self.vae_cfg = cfg
         c = _vae_cfg_c(cfg)

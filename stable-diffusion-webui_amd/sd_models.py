@@ -51,11 +51,17 @@ class SdModel:
         self.alphas_cumprod = (ac.float().cpu() if ac is not None else schema.make_alphas_cumprod())
         self.engine = Engine(device)
         self.engine.load_unet(self.unet_cfg, state_dict)
+        self._checkpoint = state_dict                     # kept by reference: the "weights backup" LoRA rewrites start from
         self.has_vae = False
         if load_vae and any(k.startswith(schema.VAE_PREFIX) for k in state_dict):
             self.engine.load_vae(self.vae_cfg, state_dict, decoder_only=vae_decoder_only)
             self.has_vae = True
         self.scale_factor = self.vae_cfg.scale_factor
+
+    def unet_checkpoint_tensor(self, engine_key: str) -> torch.Tensor:
+        """The unmodified checkpoint weight of a UNet layer (extensions-builtin/Lora/networks.py:423-432 keeps the same thing
+        as ``network_weights_backup``)."""
+        return self._checkpoint[schema.UNET_PREFIX + engine_key]
 
     # --- the methods the reference calls on shared.sd_model around the sampler -----------------------------------
     def decode_first_stage(self, z: torch.Tensor) -> torch.Tensor:

@@ -156,7 +156,8 @@ class CFGDenoiser:
         return self.model_wrap
 
     def _ensure_context(self, cond, uncond):
-        key = (cond.data_ptr(), uncond.data_ptr(), tuple(cond.shape), tuple(uncond.shape), cond._version, uncond._version)
+        key = (cond.data_ptr(), uncond.data_ptr(), tuple(cond.shape), tuple(uncond.shape), cond._version, uncond._version,
+               getattr(self.sampler.sd_model.engine, "weights_version", 0))      # a LoRA rewrite invalidates the cached K / V
         if key != self._ctx_key:
             if cond.shape[1] != uncond.shape[1]:
                 raise NotImplementedError("cond / uncond token counts differ: use pad_cond_uncond or the torch path")

@@ -66,7 +66,8 @@ class Mi355xUnet(SdUnet):
             x = x.float()
         y = kwargs.get("y", None)
         # context is step-invariant unless prompt editing swaps it: re-project only when the tensor changes
-        key = (context.data_ptr(), tuple(context.shape), context._version, context.dtype)
+        key = (context.data_ptr(), tuple(context.shape), context._version, context.dtype,
+               getattr(self.engine, "weights_version", 0))
         ctx = None
         if key != self._ctx_key:
             ctx = context.to(x.dtype)

@@ -225,6 +225,41 @@ def gen_schedulers():
     print("schedulers.npz")
 
 
+def gen_lora_names():
+    """Execute convert_diffusers_name_to_compvis (extensions-builtin/Lora/networks.py:40-120) on kohya-style LoRA keys of
+    every UNet layer family.  The module imports the whole webui, so only the function and the three module-level objects it
+    uses are exec'd from the file's own text (nothing is copied into this repository)."""
+    import json
+    import re
+    src = open(os.path.join(REF, "extensions-builtin/Lora/networks.py")).read()
+    a = src.index("re_digits = re.compile")
+    b = src.index("def assign_network_names_to_compvis_modules")
+    ns = {"re": re}
+    exec(src[a:b], ns)
+    conv = ns["convert_diffusers_name_to_compvis"]
+    keys = ["lora_unet_conv_in", "lora_unet_conv_out", "lora_unet_time_embedding_linear_1", "lora_unet_time_embedding_linear_2"]
+    for blk in range(4):
+        for j in range(2):
+            for sfx in ("conv1", "conv2", "time_emb_proj", "conv_shortcut", "norm1"):
+                keys.append(f"lora_unet_down_blocks_{blk}_resnets_{j}_{sfx}")
+            for sfx in ("proj_in", "proj_out", "transformer_blocks_0_attn1_to_q", "transformer_blocks_0_attn2_to_k",
+                        "transformer_blocks_0_attn1_to_out_0", "transformer_blocks_0_ff_net_0_proj", "transformer_blocks_0_ff_net_2"):
+                keys.append(f"lora_unet_down_blocks_{blk}_attentions_{j}_{sfx}")
+        keys.append(f"lora_unet_down_blocks_{blk}_downsamplers_0_conv")
+        for j in range(3):
+            keys.append(f"lora_unet_up_blocks_{blk}_resnets_{j}_conv1")
+            keys.append(f"lora_unet_up_blocks_{blk}_attentions_{j}_transformer_blocks_0_attn2_to_v")
+        keys.append(f"lora_unet_up_blocks_{blk}_upsamplers_0_conv")
+    keys += ["lora_unet_mid_block_resnets_0_conv1", "lora_unet_mid_block_resnets_1_conv2", "lora_unet_mid_block_attentions_0_proj_in",
+             "lora_unet_mid_block_attentions_0_transformer_blocks_0_attn1_to_k",
+             "lora_te_text_model_encoder_layers_3_self_attn_q_proj", "lora_te_text_model_encoder_layers_11_mlp_fc1",
+             "lora_te2_text_model_encoder_layers_5_mlp_fc2", "lora_unet_input_blocks_4_1_transformer_blocks_1_attn1_to_q",
+             "something_else_entirely"]
+    out = {"sd1": {k: conv(k, False) for k in keys}, "sd2": {k: conv(k, True) for k in keys if "lora_te_" in k}}
+    json.dump(out, open(os.path.join(OUT, "lora_names.json"), "w"), indent=0, sort_keys=True)
+    print("lora_names.json", len(keys))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -232,3 +267,4 @@ if __name__ == "__main__":
     gen_vae()
     gen_ddim()
     gen_schedulers()
+    gen_lora_names()

@@ -161,6 +161,43 @@ def test_sampler_table_matches_reference_rows():
         ss.create_sampler("Euler", M()).get_sigmas(P(), 10)
 
 
+def test_host_lora_names_and_grouping_match_reference(golden_dir):
+    """networks.convert_diffusers_name_to_compvis against the reference-generated fixture, and load_network's grouping /
+    layer lookup (extensions-builtin/Lora/networks.py:183-240) on the tiny UNet's layer map."""
+    import json
+    nets, schema = sub("networks"), sub("schema")
+    z = json.load(open(os.path.join(golden_dir, "lora_names.json")))
+    for k, want in z["sd1"].items():
+        assert nets.convert_diffusers_name_to_compvis(k, False) == want, k
+    for k, want in z["sd2"].items():
+        assert nets.convert_diffusers_name_to_compvis(k, True) == want, k
+
+    class M:
+        unet_cfg = schema.tiny_unet()
+    m = M()
+    mapping = nets.assign_network_names_to_compvis_modules(m)
+    assert mapping["diffusion_model_input_blocks_1_1_transformer_blocks_0_attn1_to_q"][0] == "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"
+    assert "diffusion_model_input_blocks_1_0_in_layers_0" not in mapping            # norms are not conv / linear sites
+    g = torch.Generator().manual_seed(0)
+    c = mapping["diffusion_model_input_blocks_1_1_proj_in"][1][0]
+    sd = {"lora_unet_down_blocks_0_attentions_0_proj_in.lora_up.weight": torch.randn(c, 4, 1, 1, generator=g),
+          "lora_unet_down_blocks_0_attentions_0_proj_in.lora_down.weight": torch.randn(4, c, 1, 1, generator=g),
+          "lora_unet_down_blocks_0_attentions_0_proj_in.alpha": torch.tensor(2.0),
+          "lora_unet_input_blocks_1_1_proj_out.lora_B.weight": torch.randn(c, 4, generator=g),        # compvis-named + A/B naming
+          "lora_unet_input_blocks_1_1_proj_out.lora_A.weight": torch.randn(4, c, generator=g),
+          "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight": torch.randn(8, 2, generator=g)}
+    net = nets.load_network("t", sd, m)
+    assert set(net.modules) == {"diffusion_model_input_blocks_1_1_proj_in", "diffusion_model_input_blocks_1_1_proj_out"}
+    mod = net.modules["diffusion_model_input_blocks_1_1_proj_in"]
+    assert mod.dim == 4 and mod.calc_scale() == 0.5 and mod.engine_key == "input_blocks.1.1.proj_in.weight"
+    assert net.modules["diffusion_model_input_blocks_1_1_proj_out"].calc_scale() == 1.0
+    assert list(net.keys_failed_to_match) == ["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight"]
+    bad = dict(sd)
+    bad["lora_unet_down_blocks_0_attentions_0_proj_in.lora_up.weight"] = torch.randn(c + 8, 4, 1, 1, generator=g)
+    with pytest.raises(AssertionError):
+        nets.load_network("bad", bad, m)
+
+
 def test_shard_range_partitions_exactly():
     par = sub("parallel")
     for n in (1, 7, 8, 64, 65):

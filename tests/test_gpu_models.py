@@ -182,6 +182,73 @@ def test_inpainting_mask_paths_vs_oracle(dev, tiny, sampler, name):
     assert rel_l2(res.latents.cpu()[keep], init[keep]) < 5e-3            # masked region = the encoded original
 
 
+def _tiny_lora(cfg_schema, seed, rank=4):
+    """A kohya-style LoRA for the tiny UNet: self-attention q / k (stacked inside the engine), cross-attention k / v (cached
+    projections), GEGLU feed-forward, 1x1 proj_in, the time-embedding projection of a ResBlock and a 3x3 LoCon conv."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = {k: s for k, s, _ in cfg_schema}
+    targets = {
+        "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q": "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight",
+        "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_k": "input_blocks.1.1.transformer_blocks.0.attn1.to_k.weight",
+        "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn2_to_k": "input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight",
+        "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn2_to_v": "input_blocks.1.1.transformer_blocks.0.attn2.to_v.weight",
+        "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_ff_net_0_proj": "input_blocks.1.1.transformer_blocks.0.ff.net.0.proj.weight",
+        "lora_unet_down_blocks_0_attentions_0_proj_in": "input_blocks.1.1.proj_in.weight",
+        "lora_unet_down_blocks_0_resnets_0_time_emb_proj": "input_blocks.1.0.emb_layers.1.weight",
+        "lora_unet_mid_block_resnets_0_conv1": "middle_block.0.in_layers.2.weight",
+    }
+    sd = {}
+    for lk, ck in targets.items():
+        shp = shapes[ck]
+        out_c, in_c = shp[0], shp[1]
+        if len(shp) == 4 and shp[2] == 3:
+            up, down = torch.randn(out_c, rank, 1, 1, generator=g), torch.randn(rank, in_c, 3, 3, generator=g) * (in_c * 9) ** -0.5
+        elif len(shp) == 4:
+            up, down = torch.randn(out_c, rank, 1, 1, generator=g), torch.randn(rank, in_c, 1, 1, generator=g) * in_c ** -0.5
+        else:
+            up, down = torch.randn(out_c, rank, generator=g), torch.randn(rank, in_c, generator=g) * in_c ** -0.5
+        sd[lk + ".lora_up.weight"] = (up * 0.3).half()
+        sd[lk + ".lora_down.weight"] = down.half()
+        sd[lk + ".alpha"] = torch.tensor(float(rank) / 2)
+    sd["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight"] = torch.randn(8, rank, generator=g).half()
+    return sd
+
+
+def test_lora_merge_into_engine_vs_oracle_and_restore(dev, tiny):
+    """networks.load_networks rewrites the packed engine weights (incl. the stacked q|k, the cached cross-attention K / V and
+    the interleaved GEGLU rows); the UNet then matches the oracle built from oracle.lora.merge'd weights, two networks
+    accumulate, and unloading restores the original output bit for bit."""
+    schema, nets = sub("schema"), sub("networks")
+    from oracle import lora as olora, unet as ou
+    model, sd = tiny["model"], tiny["sd"]
+    eng = model.engine
+    x = seeded((4, 4, 16, 16), 21).to(dev)
+    t = torch.tensor([900.0, 900.0, 120.0, 120.0], device=dev)
+    ctx = seeded((4, 77, 64), 22).to(dev)
+
+    def fwd():
+        eng.set_context(ctx)
+        return eng.unet_forward(x, t, None, None).float().cpu()
+    base = fwd()
+    la, lb = _tiny_lora(schema.unet_schema(schema.tiny_unet()), 5), _tiny_lora(schema.unet_schema(schema.tiny_unet()), 6, rank=8)
+    try:
+        loaded = nets.load_networks(model, ["a"], [la], unet_multipliers=[0.9])
+        assert len(loaded[0].modules) == 8 and len(loaded[0].keys_failed_to_match) == 1
+        got = fwd()
+        ref_sd = olora.merge({k: v.float() for k, v in sd.items()}, [(la, 0.9)])
+        ref = ou.build_unet(ou.tiny_config(), ref_sd)(x.cpu(), t.cpu(), ctx.cpu())
+        assert rel_l2(got, ref) < 8e-3
+        assert rel_l2(got, base) > 5e-2                                   # the LoRA really changed the output
+        nets.load_networks(model, ["a", "b"], [la, lb], unet_multipliers=[0.9, -0.4])
+        got2 = fwd()
+        ref_sd2 = olora.merge({k: v.float() for k, v in sd.items()}, [(la, 0.9), (lb, -0.4)])
+        ref2 = ou.build_unet(ou.tiny_config(), ref_sd2)(x.cpu(), t.cpu(), ctx.cpu())
+        assert rel_l2(got2, ref2) < 8e-3
+    finally:
+        nets.load_networks(model, [], [])
+    assert torch.equal(fwd(), base)
+
+
 def test_txt2img_batch_split_matches(dev, tiny):
     """Sharding contract of the multi-GPU runner: images [0,4) generated as 4, as 2+2 (n_iter) or as the tail pair are the
     same images — per-image Philox streams (modules/rng.py:108) + per-image arithmetic everywhere.  Bitwise when the per-call

@@ -155,6 +155,52 @@ def test_schedulers_match_reference_functions(golden_dir):
         assert bool((s[:-1] > s[1:]).all())
 
 
+def test_lora_layer_names_match_reference_function(golden_dir):
+    """oracle.lora.convert_diffusers_name_to_compvis == extensions-builtin/Lora/networks.py:56-120 on 141 kohya-style keys."""
+    import json
+    from oracle import lora as olora
+    z = json.load(open(os.path.join(golden_dir, "lora_names.json")))
+    for k, want in z["sd1"].items():
+        assert olora.convert_diffusers_name_to_compvis(k, False) == want, k
+    for k, want in z["sd2"].items():
+        assert olora.convert_diffusers_name_to_compvis(k, True) == want, k
+
+
+def test_lora_merge_arithmetic():
+    """W' = W + (up @ down).reshape(W.shape) * alpha/dim * multiplier (network_lora.py:65-80, network.py:167-216), for a linear,
+    a 1x1 conv given as 2-D factors and a 3x3 LoCon layer; two networks add up in list order."""
+    from oracle import lora as olora
+    g = torch.Generator().manual_seed(0)
+    sd = {"model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight": torch.randn(64, 64, generator=g),
+          "model.diffusion_model.input_blocks.1.1.proj_in.weight": torch.randn(64, 64, 1, 1, generator=g),
+          "model.diffusion_model.input_blocks.1.0.in_layers.2.weight": torch.randn(64, 64, 3, 3, generator=g),
+          "model.diffusion_model.input_blocks.1.0.in_layers.2.bias": torch.randn(64, generator=g)}
+    lora = {"lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.lora_up.weight": torch.randn(64, 4, generator=g),
+            "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.lora_down.weight": torch.randn(4, 64, generator=g),
+            "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.alpha": torch.tensor(2.0),
+            "lora_unet_down_blocks_0_attentions_0_proj_in.lora_up.weight": torch.randn(64, 8, 1, 1, generator=g),
+            "lora_unet_down_blocks_0_attentions_0_proj_in.lora_down.weight": torch.randn(8, 64, 1, 1, generator=g),
+            "lora_unet_down_blocks_0_resnets_0_conv1.lora_up.weight": torch.randn(64, 4, 1, 1, generator=g),
+            "lora_unet_down_blocks_0_resnets_0_conv1.lora_down.weight": torch.randn(4, 64, 3, 3, generator=g),
+            "lora_unet_down_blocks_0_resnets_0_conv1.alpha": torch.tensor(4.0),
+            "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight": torch.randn(8, 2, generator=g)}
+    out = olora.merge(sd, [(lora, 0.8)])
+    k = "model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"
+    up, down = lora["lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.lora_up.weight"], \
+        lora["lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.lora_down.weight"]
+    np.testing.assert_allclose(out[k].numpy(), (sd[k] + up @ down * (2.0 / 4) * 0.8).numpy(), rtol=1e-6, atol=1e-6)
+    k = "model.diffusion_model.input_blocks.1.0.in_layers.2.weight"
+    up, down = lora["lora_unet_down_blocks_0_resnets_0_conv1.lora_up.weight"], lora["lora_unet_down_blocks_0_resnets_0_conv1.lora_down.weight"]
+    want = sd[k] + (up.reshape(64, 4) @ down.reshape(4, -1)).reshape(64, 64, 3, 3) * (4.0 / 4) * 0.8
+    np.testing.assert_allclose(out[k].numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+    assert torch.equal(out["model.diffusion_model.input_blocks.1.0.in_layers.2.bias"], sd["model.diffusion_model.input_blocks.1.0.in_layers.2.bias"])
+    twice = olora.merge(sd, [(lora, 0.8), (lora, -0.8)])
+    for kk in sd:
+        np.testing.assert_allclose(twice[kk].numpy(), sd[kk].numpy(), atol=2e-5)
+    _, failed = olora.group_network(lora, olora.layer_mapping(sd))
+    assert list(failed) == ["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight"]
+
+
 def test_schedule_known_answers():
     """SURVEY.md appendix A.3 (in-tree hints modules/shared_options.py:396-397, sd_schedulers.py:60-63)."""
     ac = kd.make_alphas_cumprod()
