@@ -260,6 +260,41 @@ int sdmi_profile_end(char* json_out, int capacity);
 /* Micro-benchmarks used by bench.py's roofline block (HIP-event timed inside the library; returns ms per launch). */
 int sdmi_bench_conv_gemm(const sdmi_conv_desc* d, int iters, float* ms_out, void* stream);
 
+/* ---- CLIP text encoder ---------------------------------------------------------------------------
+ * The transformer behind FrozenCLIPEmbedderWithCustomWords.encode_with_transformers (modules/sd_hijack_clip.py:351-360:
+ * `self.wrapped.transformer(input_ids=tokens, output_hidden_states=-opts.CLIP_stop_at_last_layers)`, i.e. transformers'
+ * CLIPTextModel; in-repo plain-torch twin modules/models/sd3/other_impls.py:61-150): token + position embeddings,
+ * `layers` pre-LN blocks (causal self-attention, MLP with quick_gelu or gelu), final LayerNorm.  Prompt parsing, chunking,
+ * emphasis and textual-inversion vector injection stay on the host (they feed `inputs_embeds`).  Two slots: SDXL carries
+ * two text encoders. */
+typedef struct sdmi_clip_config {
+    int vocab_size;        /* 49408 */
+    int max_positions;     /* 77 */
+    int hidden;            /* 768 (CLIP-L), 1280 (OpenCLIP bigG) */
+    int layers;            /* 12 / 32 */
+    int heads;             /* hidden / 64 */
+    int intermediate;      /* 4 * hidden */
+    int act;               /* 0 = quick_gelu, 1 = gelu (erf) */
+    float eps;             /* LayerNorm eps, 1e-5 */
+} sdmi_clip_config;
+
+int sdmi_clip_configure(sdmi_engine* e, int slot, const sdmi_clip_config* cfg);
+/* keys as in transformers' CLIPTextModel state dict below "text_model.": "embeddings.token_embedding.weight",
+ * "embeddings.position_embedding.weight", "encoder.layers.<i>.{layer_norm1,layer_norm2}.{weight,bias}",
+ * "encoder.layers.<i>.self_attn.{q_proj,k_proj,v_proj,out_proj}.{weight,bias}", "encoder.layers.<i>.mlp.{fc1,fc2}.{weight,bias}",
+ * "final_layer_norm.{weight,bias}". */
+int sdmi_clip_load_tensor(sdmi_engine* e, int slot, const char* key, const void* data, int dtype, int ndim,
+                          const int64_t* shape, int on_device);
+int sdmi_clip_finalize(sdmi_engine* e, int slot);
+/* tokens int32 [B, L] (device); inputs_embeds fp32 [B, L, hidden] or NULL (token embeddings already looked up / patched by
+ * the caller: textual inversion, modules/sd_hijack.py EmbeddingsWithFixes).  Runs the first `layers - skip + 1` blocks
+ * (skip = opts.CLIP_stop_at_last_layers >= 1: hidden_states[-skip]) and, if apply_final_ln, final_layer_norm — which is
+ * last_hidden_state for skip = 1 and the clip-skip branch of sd_hijack_clip.py:354-356 otherwise; SDXL's CLIP-L takes
+ * hidden_states[-2] without the norm (sd_hijack_clip.py:369-377).  out fp32 [B, L, hidden]; pooled fp32 [B, hidden] or NULL
+ * = the output row at the EOS (largest id) position. */
+int sdmi_clip_forward(sdmi_engine* e, int slot, const void* tokens_i32, const void* inputs_embeds_f32_or_null, int B, int L,
+                      int skip, int apply_final_ln, void* out_f32, void* pooled_f32_or_null, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,11 @@ class VAEConfigC(C.Structure):
     ]
 
 
+class ClipConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("max_positions", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32),
+                ("heads", C.c_int32), ("intermediate", C.c_int32), ("act", C.c_int32), ("eps", C.c_float)]
+
+
 def declared_symbols() -> list:
     """Every function name declared in include/sdmi.h (used by the CPU-side export test)."""
     src = open(HEADER_PATH).read()
@@ -96,6 +101,10 @@ _SIGS = {
     "sdmi_unet_configure": (_i, [_vp, C.POINTER(UNetConfigC)]),
     "sdmi_unet_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
     "sdmi_unet_finalize": (_i, [_vp]),
+    "sdmi_clip_configure": (_i, [_vp, _i, C.POINTER(ClipConfigC)]),
+    "sdmi_clip_load_tensor": (_i, [_vp, _i, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
+    "sdmi_clip_finalize": (_i, [_vp, _i]),
+    "sdmi_clip_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sdmi_unet_update_weight": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
     "sdmi_lora_merge": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sdmi_vae_configure": (_i, [_vp, C.POINTER(VAEConfigC)]),

@@ -184,11 +184,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP
 
         // ---- online softmax (per lane: one query row, KVT/2 of the tile's keys) -----------------------------------
         // register r of block kb <-> local key 32*kb + 16*(r>>3) + 8*half + (r&7)
-        if (t >= nfull) {
-            // ragged last tile only (cross-attention, M = 77).  The empty volatile asm keeps this a real (wave-uniform)
-            // branch: if-converted, the 32 compare+select pairs would run on every tile of every self-attention call.
+        if (t >= nfull || p.causal) {
+            // ragged last tile (cross-attention, M = 77) or causal mask (CLIP).  The empty volatile asm keeps this a real
+            // (wave-uniform) branch: if-converted, the 32 compare+select pairs would run on every tile of every call.
             asm volatile("");
-            const int lim = p.M - t * KVT - 8 * half;          // local keys >= lim are past the end
+            int lim = p.M - t * KVT - 8 * half;                // local keys >= lim are past the end
+            if (p.causal) lim = min(lim, q + 1 - t * KVT - 8 * half);      // ... or in this query's future
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -276,7 +277,9 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(AttnP p) {
     const half_t* kbase = p.k + (long)b * p.M * p.ldk + h * p.D;
     const half_t* vbase = p.vt + ((long)b * p.H + h) * p.D * (long)p.vt_ld;
     float mx = -INFINITY;
+    const int m_vis = p.causal ? min(p.M, q + 1) : p.M;       // keys visible to this query
     for (int key = lane; key < p.M; key += 64) {
+        if (key >= m_vis) { sc[key] = -INFINITY; continue; }
         const half_t* kp = kbase + (long)key * p.ldk;
         float acc = 0.f;
         for (int d = 0; d < p.D; ++d) acc = fmaf((float)qptr[d], (float)kp[d], acc);

@@ -11,6 +11,11 @@ int vae_encode(sdmi_engine* e, const void* x, int io_dtype, float* out, int B, i
 int engine_load_unet_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_load_vae_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_unet_finalize(sdmi_engine* e);
+int engine_clip_configure(sdmi_engine* e, int slot, const sdmi_clip_config* cfg);
+int engine_clip_load_tensor(sdmi_engine* e, int slot, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
+int engine_clip_finalize(sdmi_engine* e, int slot);
+int engine_clip_forward(sdmi_engine* e, int slot, const int* tokens, const float* inputs_embeds, int B, int L, int skip,
+                        int apply_final_ln, float* out, float* pooled, hipStream_t s);
 int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_vae_finalize(sdmi_engine* e);
 int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s);
@@ -278,6 +283,33 @@ int sdmi_lora_merge(void* out, const void* w, int w_dtype, const void* up, int u
     API_GUARD_BEGIN
     SDMI_REQUIRE(out && w && up && down && rows > 0 && cols > 0 && rank > 0, "bad lora_merge arguments");
     return launch_lora_merge((float*)out, w, w_dtype, up, up_dtype, down, down_dtype, rows, cols, rank, scale, (hipStream_t)stream);
+    API_GUARD_END
+}
+int sdmi_clip_configure(sdmi_engine* e, int slot, const sdmi_clip_config* cfg) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e && cfg, "null argument");
+    return engine_clip_configure(e, slot, cfg);
+    API_GUARD_END
+}
+int sdmi_clip_load_tensor(sdmi_engine* e, int slot, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
+                          int on_device) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_clip_load_tensor(e, slot, key, data, dtype, ndim, shape, on_device);
+    API_GUARD_END
+}
+int sdmi_clip_finalize(sdmi_engine* e, int slot) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_clip_finalize(e, slot);
+    API_GUARD_END
+}
+int sdmi_clip_forward(sdmi_engine* e, int slot, const void* tokens, const void* inputs_embeds, int B, int L, int skip,
+                      int apply_final_ln, void* out, void* pooled, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_clip_forward(e, slot, (const int*)tokens, (const float*)inputs_embeds, B, L, skip, apply_final_ln, (float*)out,
+                               (float*)pooled, (hipStream_t)stream);
     API_GUARD_END
 }
 int sdmi_vae_configure(sdmi_engine* e, const sdmi_vae_config* cfg) {

@@ -74,6 +74,7 @@ struct GemmP {
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
+       EP_QUICK_GELU = 16, EP_GELU = 32,               // activation on the biased result (CLIP MLP: x*sigmoid(1.702x) / erf GELU)
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000 };    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
 
@@ -98,6 +99,7 @@ struct AttnP {
     int B, H, N, M, D;
     int ldq, ldk, vt_ld, ldo;
     float scale_log2;      // softmax scale * log2(e)
+    int causal;            // 1: key j is visible to query i only if j <= i (CLIP text encoder; requires N == M)
 };
 int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 // v [B, M, ldv] (head h at h*D) -> vt [B, H*D, Mpad] (zero padded)
@@ -126,6 +128,9 @@ int launch_axpby(float* y, const float* x, float a, const float* z, float b, int
 int launch_lincomb(float* out, const float* const* terms, const float* coefs, int n_terms, int64_t n, hipStream_t s);
 int launch_lora_merge(float* out, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype,
                       int rows, int cols, int rank, float scale, hipStream_t s);
+int launch_clip_embed(const int* tokens, const void* tok_emb, int tok_dtype, const float* pos_emb, const float* inputs_embeds,
+                      half_t* out, int B, int L, int C, int vocab, hipStream_t s);
+int launch_clip_pool(const int* tokens, const half_t* hidden, float* pooled, int B, int L, int C, hipStream_t s);
 int launch_mask_blend(float* x, const float* init, const float* mask, const float* nmask, int64_t n, hipStream_t s);
 int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
 

@@ -217,6 +217,54 @@ int launch_mask_blend(float* x, const float* init, const float* mask, const floa
     return 0;
 }
 
+// CLIP text embeddings: out[b,l,:] = (inputs_embeds[b,l,:] if given else tok_emb[token[b,l],:]) + pos_emb[l,:]  -> fp16 rows
+// (transformers CLIPTextEmbeddings; in-repo twin modules/models/sd3/other_impls.py:117-125)
+template <typename TT>
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int* tokens, const TT* tok_emb, const float* pos_emb,
+                                                         const float* inputs_embeds, half_t* out, int L, int C, int vocab, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / C;
+        const int c = (int)(i - row * C), l = (int)(row % L);
+        float v;
+        if (inputs_embeds) {
+            v = inputs_embeds[i];
+        } else {
+            int t = tokens[row];
+            t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+            v = (float)tok_emb[(long)t * C + c];
+        }
+        out[i] = (half_t)(v + pos_emb[(long)l * C + c]);
+    }
+}
+int launch_clip_embed(const int* tokens, const void* tok_emb, int tok_dtype, const float* pos_emb, const float* inputs_embeds,
+                      half_t* out, int B, int L, int C, int vocab, hipStream_t s) {
+    const long n = (long)B * L * C;
+    if (tok_dtype == 0)
+        hipLaunchKernelGGL((clip_embed_kernel<half_t>), dim3(ew_blocks(n)), dim3(256), 0, s, tokens, (const half_t*)tok_emb, pos_emb,
+                           inputs_embeds, out, L, C, vocab, n);
+    else
+        hipLaunchKernelGGL((clip_embed_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, s, tokens, (const float*)tok_emb, pos_emb,
+                           inputs_embeds, out, L, C, vocab, n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// pooled[b,:] = hidden[b, argmax_l tokens[b,l], :]   (the EOS position: CLIP's EOS id is the largest id; other_impls.py:146)
+__global__ __launch_bounds__(256) void clip_pool_kernel(const int* tokens, const half_t* hidden, float* pooled, int L, int C) {
+    const int b = blockIdx.x;
+    int best = 0, bv = tokens[(long)b * L];
+    for (int l = 1; l < L; ++l) {
+        const int t = tokens[(long)b * L + l];
+        if (t > bv) { bv = t; best = l; }                // first maximum, like torch.argmax
+    }
+    for (int c = threadIdx.x; c < C; c += 256) pooled[(long)b * C + c] = (float)hidden[((long)b * L + best) * C + c];
+}
+int launch_clip_pool(const int* tokens, const half_t* hidden, float* pooled, int B, int L, int C, hipStream_t s) {
+    hipLaunchKernelGGL(clip_pool_kernel, dim3(B), dim3(256), 0, s, tokens, hidden, pooled, L, C);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // W' = W + scale * (up @ down): the LoRA weight delta of extensions-builtin/Lora/network_lora.py:65-80 (rebuild_conventional,
 // lyco_helpers.py:9-15) folded into the weight, fp32 accumulate in k order.  up [rows][rank], down [rank][cols] (cols = Cin*kh*kw
 // for conv weights), W any of fp16 / fp32; one thread per output element (a few MFLOP per layer, done once per LoRA change).

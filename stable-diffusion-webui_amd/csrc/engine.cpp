@@ -1009,6 +1009,138 @@ int vae_encode(sdmi_engine* e, const void* x, int io_dtype, float* out, int B, i
     return vae_encode_run(run, x, io_dtype, out, B, H, W);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// CLIP text encoder
+// ------------------------------------------------------------------------------------------------------------
+static int clip_build(sdmi_engine* e, int slot) {
+    ClipW& c = e->clip[slot];
+    auto& m = e->raw_clip[slot];
+    const sdmi_clip_config& cfg = c.cfg;
+    const RawTensor* te = find_raw(m, "embeddings.token_embedding.weight");
+    const RawTensor* pe = find_raw(m, "embeddings.position_embedding.weight");
+    SDMI_REQUIRE(te && pe, "missing CLIP embeddings");
+    SDMI_REQUIRE(te->shape.size() == 2 && te->shape[0] == cfg.vocab_size && te->shape[1] == cfg.hidden, "token_embedding shape");
+    SDMI_REQUIRE(pe->shape.size() == 2 && pe->shape[0] == cfg.max_positions && pe->shape[1] == cfg.hidden, "position_embedding shape");
+    TRY(dev_alloc(e, &c.tok_emb, te->bytes));
+    SDMI_CHECK_HIP(hipMemcpy(c.tok_emb, te->ptr, te->bytes, hipMemcpyDeviceToDevice));
+    c.tok_dtype = te->dtype;
+    TRY(dev_alloc(e, (void**)&c.pos_emb, (size_t)cfg.max_positions * cfg.hidden * sizeof(float)));
+    TRY(launch_convert_to_f32(pe->ptr, pe->dtype, c.pos_emb, (int64_t)cfg.max_positions * cfg.hidden, 0));
+    c.layers.clear();
+    for (int i = 0; i < cfg.layers; ++i) {
+        const std::string b = "encoder.layers." + std::to_string(i);
+        ClipLayerW L;
+        TRY(pack_norm(e, m, b + ".layer_norm1", &L.ln1));
+        TRY(pack_norm(e, m, b + ".layer_norm2", &L.ln2));
+        TRY(pack_stack(e, m, {b + ".self_attn.q_proj", b + ".self_attn.k_proj"}, true, false, &L.qk));
+        TRY(pack_one(e, m, b + ".self_attn.v_proj", true, false, &L.v));
+        TRY(pack_one(e, m, b + ".self_attn.out_proj", true, false, &L.o));
+        TRY(pack_one(e, m, b + ".mlp.fc1", true, false, &L.fc1));
+        TRY(pack_one(e, m, b + ".mlp.fc2", true, false, &L.fc2));
+        c.layers.push_back(L);
+    }
+    TRY(pack_norm(e, m, "final_layer_norm", &c.final_ln));
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    c.ready = true;
+    return 0;
+}
+
+static int clip_run(Run& r, const ClipW& c, const int* tokens, const float* inputs_embeds, int B, int L, int skip,
+                    int apply_final_ln, float* out, float* pooled) {
+    const sdmi_clip_config& cfg = c.cfg;
+    const int C = cfg.hidden, H = cfg.heads, D = C / H;
+    const size_t M = (size_t)B * L;
+    const int Lpad = rup(L, 64);
+    r.e->arena.reset();
+    half_t* cur = r.H(M * C);
+    if (!r.dry) TRY(launch_clip_embed(tokens, c.tok_emb, c.tok_dtype, c.pos_emb, inputs_embeds, cur, B, L, C, cfg.vocab_size, r.s));
+    const int nrun = cfg.layers - skip + 1;
+    for (int i = 0; i < nrun; ++i) {
+        const ClipLayerW& w = c.layers[i];
+        half_t* n1 = r.H(M * C);
+        if (!r.dry) TRY(launch_layernorm(cur, w.ln1.g, w.ln1.b, n1, (int64_t)M, C, cfg.eps, r.s));
+        half_t* qk = r.H(M * 2 * C);
+        TRY(run_linear(r, w.qk, n1, (int)M, nullptr, qk, 2 * C));
+        half_t* vt = r.H((size_t)B * C * Lpad);
+        TRY(run_vt(r, w.v, n1, C, B, L, Lpad, vt, true));
+        half_t* a = r.H(M * C);
+        if (!r.dry) {
+            AttnP p{};
+            p.q = qk; p.k = qk + C; p.vt = vt; p.out = a;
+            p.B = B; p.H = H; p.N = L; p.M = L; p.D = D;
+            p.ldq = 2 * C; p.ldk = 2 * C; p.vt_ld = Lpad; p.ldo = C;
+            p.scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+            p.causal = 1;
+            TRY(launch_attention(p, r.e->force_generic, r.s));
+        }
+        half_t* x1 = r.H(M * C);
+        TRY(run_linear(r, w.o, a, (int)M, cur, x1, C));
+        half_t* n2 = r.H(M * C);
+        if (!r.dry) TRY(launch_layernorm(x1, w.ln2.g, w.ln2.b, n2, (int64_t)M, C, cfg.eps, r.s));
+        half_t* hmid = r.H(M * cfg.intermediate);
+        {
+            ConvArgs ca;
+            ca.a0 = n2; ca.c0 = w.fc1.cin_pad;
+            ca.B = 1; ca.Hi = (int)M; ca.Wi = 1; ca.Ho = (int)M; ca.Wo = 1;
+            ca.out = hmid; ca.ldo = cfg.intermediate;
+            ca.flags = cfg.act == 0 ? EP_QUICK_GELU : EP_GELU;
+            TRY(run_conv(r, w.fc1, ca));
+        }
+        half_t* x2 = r.H(M * C);
+        TRY(run_linear(r, w.fc2, hmid, (int)M, x1, x2, C));
+        cur = x2;
+    }
+    half_t* fin = cur;
+    if (apply_final_ln) {
+        fin = r.H(M * C);
+        if (!r.dry) TRY(launch_layernorm(cur, c.final_ln.g, c.final_ln.b, fin, (int64_t)M, C, cfg.eps, r.s));
+    }
+    if (r.dry) return 0;
+    TRY(launch_convert_to_f32(fin, SDMI_F16, out, (int64_t)M * C, r.s));
+    if (pooled) TRY(launch_clip_pool(tokens, fin, pooled, B, L, C, r.s));
+    return 0;
+}
+
+int engine_clip_configure(sdmi_engine* e, int slot, const sdmi_clip_config* cfg) {
+    SDMI_REQUIRE(slot == 0 || slot == 1, "clip slot must be 0 or 1");
+    SDMI_REQUIRE(cfg->hidden % 64 == 0 && cfg->intermediate % 64 == 0 && cfg->heads > 0 && cfg->hidden % cfg->heads == 0,
+                 "clip: hidden and intermediate must be multiples of 64");
+    SDMI_REQUIRE(cfg->layers >= 1 && cfg->max_positions >= 1 && cfg->vocab_size >= 1, "clip: bad config");
+    e->clip[slot].cfg = *cfg;
+    e->clip[slot].configured = true;
+    e->clip[slot].ready = false;
+    return 0;
+}
+int engine_clip_load_tensor(sdmi_engine* e, int slot, const char* key, const void* data, int dtype, int ndim,
+                            const int64_t* shape, int on_device) {
+    SDMI_REQUIRE(slot == 0 || slot == 1, "clip slot must be 0 or 1");
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    return load_raw(e->raw_clip[slot], key, data, dtype, ndim, shape, on_device);
+}
+int engine_clip_finalize(sdmi_engine* e, int slot) {
+    SDMI_REQUIRE((slot == 0 || slot == 1) && e->clip[slot].configured, "clip slot not configured");
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    const int rc = clip_build(e, slot);
+    free_raw(e->raw_clip[slot]);
+    return rc;
+}
+int engine_clip_forward(sdmi_engine* e, int slot, const int* tokens, const float* inputs_embeds, int B, int L, int skip,
+                        int apply_final_ln, float* out, float* pooled, hipStream_t s) {
+    SDMI_REQUIRE((slot == 0 || slot == 1) && e->clip[slot].ready, "clip not finalized");
+    const ClipW& c = e->clip[slot];
+    SDMI_REQUIRE(B >= 1 && L >= 1 && L <= c.cfg.max_positions, "clip: 1 <= L <= max_positions");
+    SDMI_REQUIRE(skip >= 1 && skip <= c.cfg.layers, "clip: 1 <= skip <= layers");
+    SDMI_REQUIRE(tokens != nullptr && out != nullptr, "null argument");
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    Run dry{e, s, true};
+    e->arena.dry = true; e->arena.high = 0;
+    TRY(clip_run(dry, c, tokens, inputs_embeds, B, L, skip, apply_final_ln, out, pooled));
+    e->arena.dry = false;
+    TRY(ensure_arena(e, e->arena.high, s));
+    Run run{e, s, false};
+    return clip_run(run, c, tokens, inputs_embeds, B, L, skip, apply_final_ln, out, pooled);
+}
+
 int engine_load_unet_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape,
                             int on_device) {
     SDMI_CHECK_HIP(hipSetDevice(e->device));
@@ -1081,6 +1213,8 @@ sdmi_engine::~sdmi_engine() {
     (void)hipDeviceSynchronize();
     sdmi::free_raw(raw_unet);
     sdmi::free_raw(raw_vae);
+    sdmi::free_raw(raw_clip[0]);
+    sdmi::free_raw(raw_clip[1]);
     sdmi::ctx_free(this);
     for (void* p : owned) (void)hipFree(p);
     if (arena.base) (void)hipFree(arena.base);

@@ -82,6 +82,20 @@ struct VAELevel {
     ConvW resample;               // upsample.conv (decoder) / downsample.conv (encoder)
     bool has_resample = false;
 };
+struct ClipLayerW {
+    NormW ln1, ln2;
+    ConvW qk, v, o, fc1, fc2;     // q;k stacked, V separate (produced transposed), out_proj, MLP
+};
+struct ClipW {
+    sdmi_clip_config cfg{};
+    void* tok_emb = nullptr;      // [vocab][hidden] in the checkpoint dtype
+    int tok_dtype = 0;
+    float* pos_emb = nullptr;     // [max_positions][hidden] fp32
+    std::vector<ClipLayerW> layers;
+    NormW final_ln;
+    bool configured = false, ready = false;
+};
+
 struct VAEW {
     sdmi_vae_config cfg{};
     // decoder
@@ -130,6 +144,8 @@ struct sdmi_engine {
     std::vector<void*> owned;                 // persistent device allocations (weights)
     sdmi::UNetW unet;
     sdmi::VAEW vae;
+    sdmi::ClipW clip[2];
+    std::map<std::string, sdmi::RawTensor> raw_clip[2];
     sdmi::Arena arena;
     // options
     bool force_generic = false;

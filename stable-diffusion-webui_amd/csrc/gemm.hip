@@ -140,6 +140,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
                 v += bb;
             }
+            if (flags & (EP_QUICK_GELU | EP_GELU)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
+            }
             if (p.resid) {
                 const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
 #pragma unroll
@@ -858,6 +863,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
         float v = no < p.n_valid ? dot_row(p, a0, a1, wbase + (long)no * p.ldw, ri) * p.alpha : 0.f;
         if (p.bias) v += (p.flags & EP_BIAS_ROW) ? p.bias[m] : p.bias[no];
         if (p.rowbias) v += p.rowbias[(long)ri.b * p.ldrb + no];
+        if (p.flags & EP_QUICK_GELU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+        if (p.flags & EP_GELU) v = gelu_erf(v);
         if (p.resid) v += (float)p.resid[z * p.r_bs + (long)m * p.ldr + no];
         if (p.flags & EP_NCHW) {
             ((float*)p.out)[z * p.o_bs + ((long)ri.b * p.n_real + no) * p.rows_per_batch + rem] = v;
@@ -893,6 +900,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
             }
         }
         if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+        if (p.flags & (EP_QUICK_GELU | EP_GELU)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[r] = (p.flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
+        }
         if (p.resid) {
             const h4 rr = *reinterpret_cast<const h4*>(p.resid + z * p.r_bs + (long)m * p.ldr + n);
 #pragma unroll

@@ -108,6 +108,44 @@ class Engine:
             self._load(lib.sdmi_vae_load_tensor, key, state_dict[prefix + key])
         check(lib.sdmi_vae_finalize(self.handle), "vae_finalize")
 
+    def load_clip(self, cfg, state_dict: dict, prefix: str = None, slot: int = 0):
+        """Stream a transformers-layout CLIP text model (keys below ``prefix`` = ".text_model.") into the engine."""
+        from .schema import CLIP_PREFIX, clip_schema
+        prefix = CLIP_PREFIX if prefix is None else prefix
+        c = _lib.ClipConfigC(cfg.vocab_size, cfg.max_positions, cfg.hidden, cfg.layers, cfg.heads, cfg.intermediate,
+                             {"quick_gelu": 0, "gelu": 1}[cfg.act], cfg.eps)
+        check(lib.sdmi_clip_configure(self.handle, slot, C.byref(c)), "clip_configure")
+        for key, shape, _ in clip_schema(cfg):
+            t = state_dict[prefix + key]
+            if tuple(t.shape) != tuple(shape):
+                raise _lib.SdmiError(f"checkpoint tensor {prefix + key} has shape {tuple(t.shape)}, expected {shape}")
+            if t.dtype not in (torch.float16, torch.float32):
+                t = t.float()
+            t = t.contiguous()
+            shp = (C.c_int64 * t.dim())(*t.shape)
+            check(lib.sdmi_clip_load_tensor(self.handle, slot, key.encode(), C.c_void_p(t.data_ptr()), dtype_code(t), t.dim(), shp,
+                                            1 if t.is_cuda else 0), f"clip_load_tensor({key})")
+        check(lib.sdmi_clip_finalize(self.handle, slot), "clip_finalize")
+        self.clip_cfg = getattr(self, "clip_cfg", {})
+        self.clip_cfg[slot] = cfg
+
+    def clip_forward(self, tokens: torch.Tensor, skip: int = 1, apply_final_ln: bool = True, inputs_embeds: torch.Tensor = None,
+                     slot: int = 0, return_pooled: bool = False):
+        """tokens [B, L] integer tensor on the engine's device -> hidden states [B, L, hidden] fp32 (see sdmi_clip_forward)."""
+        dev = torch.device("cuda", self.device)
+        tok = tokens.to(dev, torch.int32).contiguous()
+        b, l = tok.shape
+        hidden = self.clip_cfg[slot].hidden
+        emb = None
+        if inputs_embeds is not None:
+            emb = inputs_embeds.to(dev, torch.float32).contiguous()
+            assert emb.shape == (b, l, hidden)
+        out = torch.empty((b, l, hidden), dtype=torch.float32, device=dev)
+        pooled = torch.empty((b, hidden), dtype=torch.float32, device=dev) if return_pooled else None
+        check(lib.sdmi_clip_forward(self.handle, slot, ptr(tok), ptr(emb), b, l, int(skip), 1 if apply_final_ln else 0, ptr(out),
+                                    ptr(pooled), stream_ptr()), "clip_forward")
+        return (out, pooled) if return_pooled else out
+
     # ------------------------------------------------------------------------------------------------------
     def set_context(self, context: torch.Tensor):
         """Project the (step-invariant) text conditioning to every cross-attention layer's K / V^T once."""

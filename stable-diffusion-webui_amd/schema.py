@@ -56,6 +56,49 @@ class VAEConfig:
     scale_factor: float = 0.18215
 
 
+@dataclass
+class ClipConfig:
+    """transformers CLIPTextConfig fields the text transformer uses (SD1.x CLIP-L: configs of openai/clip-vit-large-patch14)."""
+    vocab_size: int = 49408
+    max_positions: int = 77
+    hidden: int = 768
+    layers: int = 12
+    heads: int = 12
+    intermediate: int = 3072
+    act: str = "quick_gelu"          # "quick_gelu" (OpenAI CLIP) | "gelu" (OpenCLIP bigG)
+    eps: float = 1e-5
+
+
+CLIP_PREFIX = "cond_stage_model.transformer.text_model."     # where an SD1.x checkpoint keeps the text encoder
+
+
+def sd15_clip() -> ClipConfig:
+    return ClipConfig()
+
+
+def tiny_clip(**kw) -> ClipConfig:
+    base = dict(vocab_size=1000, max_positions=77, hidden=128, layers=3, heads=2, intermediate=256, act="quick_gelu")
+    base.update(kw)
+    return ClipConfig(**base)
+
+
+def clip_schema(cfg: ClipConfig):
+    """[(key below "text_model.", shape, kind)] of transformers' CLIPTextModel state dict (position_ids buffer excluded)."""
+    C, I = cfg.hidden, cfg.intermediate
+    out = [("embeddings.token_embedding.weight", (cfg.vocab_size, C), "e"),
+           ("embeddings.position_embedding.weight", (cfg.max_positions, C), "e")]
+    for i in range(cfg.layers):
+        b = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            out += [(b + f"self_attn.{n}.weight", (C, C), "w"), (b + f"self_attn.{n}.bias", (C,), "b")]
+        out += [(b + "layer_norm1.weight", (C,), "g"), (b + "layer_norm1.bias", (C,), "b"),
+                (b + "mlp.fc1.weight", (I, C), "w"), (b + "mlp.fc1.bias", (I,), "b"),
+                (b + "mlp.fc2.weight", (C, I), "w"), (b + "mlp.fc2.bias", (C,), "b"),
+                (b + "layer_norm2.weight", (C,), "g"), (b + "layer_norm2.bias", (C,), "b")]
+    out += [("final_layer_norm.weight", (C,), "g"), ("final_layer_norm.bias", (C,), "b")]
+    return out
+
+
 def sd15_unet() -> UNetConfig:
     return UNetConfig()
 
@@ -279,7 +322,7 @@ def make_alphas_cumprod(linear_start=0.00085, linear_end=0.0120, n=1000) -> torc
 
 
 def synthetic_state_dict(unet_cfg: Optional[UNetConfig] = None, vae_cfg: Optional[VAEConfig] = None,
-                         seed: int = 0x5D15, dtype=torch.float16, device="cpu") -> dict:
+                         seed: int = 0x5D15, dtype=torch.float16, device="cpu", clip_cfg: Optional["ClipConfig"] = None) -> dict:
     """Seeded synthetic checkpoint in the reference's state-dict schema (no checkpoint exists offline).
 
     Values are generated in fp32 on ``device`` then cast to ``dtype`` (fp16 = what ``model.half()`` leaves in a
@@ -293,6 +336,8 @@ def synthetic_state_dict(unet_cfg: Optional[UNetConfig] = None, vae_cfg: Optiona
             if kind == "w":
                 fan_in = int(np.prod(shape[1:]))
                 t = torch.randn(shape, generator=g, dtype=torch.float32) * (fan_in ** -0.5)
+            elif kind == "e":
+                t = 0.5 * torch.randn(shape, generator=g, dtype=torch.float32)
             elif kind == "g":
                 t = 1.0 + 0.02 * torch.randn(shape, generator=g, dtype=torch.float32)
             else:
@@ -303,5 +348,7 @@ def synthetic_state_dict(unet_cfg: Optional[UNetConfig] = None, vae_cfg: Optiona
         fill(UNET_PREFIX, unet_schema(unet_cfg))
     if vae_cfg is not None:
         fill(VAE_PREFIX, vae_schema(vae_cfg))
+    if clip_cfg is not None:
+        fill(CLIP_PREFIX, clip_schema(clip_cfg))
     sd["alphas_cumprod"] = make_alphas_cumprod().to(device)
     return sd

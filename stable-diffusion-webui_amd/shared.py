@@ -31,6 +31,8 @@ class Options:
     img2img_fix_steps: bool = False
     enable_quantization: bool = False              # :176
     live_previews_enable: bool = False             # :374 (fused path requires previews off)
+    CLIP_stop_at_last_layers: int = 1              # :170 ("Clip skip")
+    sdxl_clip_l_skip: bool = False                 # :222
     beta_dist_alpha: float = 0.6                   # :408
     beta_dist_beta: float = 0.6                    # :409
 

@@ -225,6 +225,54 @@ def gen_schedulers():
     print("schedulers.npz")
 
 
+def gen_clip():
+    """Execute the reference's plain-torch CLIP text model (modules/models/sd3/other_impls.py:61-150) on a small configuration
+    with seeded weights: last_hidden_state, the penultimate hidden state with the final norm (clip skip 2), pooled output; both
+    activations.  Its two imports from outside torch are stubbed: transformers' tokenizers (unused) and
+    sd_hijack.TextualInversionEmbeddings (a plain nn.Embedding when no embedding is registered)."""
+    tr = types.ModuleType("transformers")
+    tr.CLIPTokenizer = object
+    tr.T5TokenizerFast = object
+    sys.modules["transformers"] = tr
+    sys.modules.setdefault("modules", types.ModuleType("modules"))
+    hij = types.ModuleType("modules.sd_hijack")
+
+    class TextualInversionEmbeddings(torch.nn.Embedding):
+        def __init__(self, num_embeddings, embedding_dim, textual_inversion_key='clip_l', **kwargs):
+            super().__init__(num_embeddings, embedding_dim, **kwargs)
+    hij.TextualInversionEmbeddings = TextualInversionEmbeddings
+    sys.modules["modules.sd_hijack"] = hij
+    sys.modules["modules"].sd_hijack = hij
+    oi = load_by_path("ref_other_impls", "modules/models/sd3/other_impls.py")
+    out = {}
+    with torch.no_grad():
+        for ci, act in enumerate(("quick_gelu", "gelu")):
+            cfgd = {"num_hidden_layers": 3, "hidden_size": 128, "num_attention_heads": 2, "intermediate_size": 256, "hidden_act": act}
+            m = oi.CLIPTextModel_(cfgd, torch.float32, "cpu")
+            # vocab is fixed at 49408 in the reference class; seed every parameter in state-dict order
+            g = torch.Generator().manual_seed(4000 + ci)
+            for name, prm in m.state_dict().items():
+                if name.endswith("embedding.weight"):
+                    prm.copy_(torch.randn(prm.shape, generator=g) * 0.5)
+                elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("layer_norm.weight"):
+                    prm.copy_(1.0 + 0.02 * torch.randn(prm.shape, generator=g))
+                elif name.endswith(".bias"):
+                    prm.copy_(0.02 * torch.randn(prm.shape, generator=g))
+                else:
+                    prm.copy_(torch.randn(prm.shape, generator=g) * prm.shape[-1] ** -0.5)
+            tok = torch.randint(0, 49407, (2, 77), generator=torch.Generator().manual_seed(4100 + ci))
+            tok[:, 0] = 49406
+            tok[0, 20:] = 49407
+            tok[1, 50:] = 49407
+            x, inter, pooled = m(tok.clone(), intermediate_output=-2)
+            out[f"c{ci}_tokens"] = tok.numpy()
+            out[f"c{ci}_last"] = x.numpy()
+            out[f"c{ci}_skip2"] = inter.numpy()
+            out[f"c{ci}_pooled"] = pooled.numpy()
+    np.savez_compressed(os.path.join(OUT, "clip_text.npz"), **out)
+    print("clip_text.npz")
+
+
 def gen_lora_names():
     """Execute convert_diffusers_name_to_compvis (extensions-builtin/Lora/networks.py:40-120) on kohya-style LoRA keys of
     every UNet layer family.  The module imports the whole webui, so only the function and the three module-level objects it
@@ -268,3 +316,4 @@ if __name__ == "__main__":
     gen_ddim()
     gen_schedulers()
     gen_lora_names()
+    gen_clip()

@@ -249,6 +249,74 @@ def test_lora_merge_into_engine_vs_oracle_and_restore(dev, tiny):
     assert torch.equal(fwd(), base)
 
 
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_clip_text_encoder_tiny_vs_oracle(dev, act):
+    """sdmi_clip_forward behind encode_with_transformers: last hidden state, clip skip 2 (+ final norm), SDXL-style
+    hidden_states[-2] without the norm, pooled row, textual-inversion style inputs_embeds; MFMA and generic kernels agree."""
+    schema, hc, eng_mod = sub("schema"), sub("sd_hijack_clip"), sub("engine")
+    from oracle import clip as oclip
+    cfg = schema.tiny_clip(act=act)
+    sd = schema.synthetic_state_dict(clip_cfg=cfg, dtype=torch.float16)
+    om = oclip.build_clip(oclip.ClipConfig(vocab_size=cfg.vocab_size, hidden=cfg.hidden, layers=cfg.layers, heads=cfg.heads,
+                                           intermediate=cfg.intermediate, act=act), sd)
+    eng = eng_mod.Engine(0)
+    enc = hc.Mi355xClipTextEncoder(eng, cfg, sd)
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randint(0, 998, (3, 77), generator=g)
+    tok[:, 0] = 998
+    tok[0, 12:] = 999
+    tok[1, 60:] = 999
+    tok[2, 76] = 999
+    shared = sub("shared")
+    got = enc.encode_with_transformers(tok.to(dev))
+    assert got.shape == (3, 77, cfg.hidden) and got.dtype == torch.float32
+    assert rel_l2(got.cpu(), om(tok)) < 4e-3
+    try:
+        shared.opts.CLIP_stop_at_last_layers = 2
+        assert rel_l2(enc.encode_with_transformers(tok.to(dev)).cpu(), om(tok, skip=2)) < 4e-3
+    finally:
+        shared.opts.CLIP_stop_at_last_layers = 1
+    enc.layer, enc.layer_idx = "hidden", 2                       # SDXL CLIP-L style: hidden_states[layer_idx], no final norm
+    want = om.hidden_states(tok)[2]
+    assert rel_l2(enc.encode_with_transformers_sdxl(tok.to(dev)).cpu(), want) < 4e-3
+    out, pooled = eng.clip_forward(tok.to(dev), return_pooled=True)
+    _, opooled = om(tok, return_pooled=True)
+    assert rel_l2(pooled.cpu(), opooled) < 4e-3
+    emb = om.embeddings.token_embedding(tok).detach().clone()
+    emb[1, 5:9] = torch.randn(4, cfg.hidden, generator=g) * 0.5   # a 4-vector textual-inversion embedding spliced in
+    got_e = eng.clip_forward(tok.to(dev), inputs_embeds=emb.to(dev))
+    assert rel_l2(got_e.cpu(), om(tok, inputs_embeds=emb)) < 4e-3
+    assert rel_l2(got_e.cpu()[0], got.cpu()[0]) < 1e-6            # image 0 untouched by the splice in image 1
+    eng.set_option("force_generic", 1)
+    try:
+        gen = eng.clip_forward(tok.to(dev))
+    finally:
+        eng.set_option("force_generic", 0)
+    assert rel_l2(gen.cpu(), got.cpu()) < 2e-3
+    # causality: changing tokens after position 30 must not change positions <= 30
+    tok2 = tok.clone()
+    tok2[:, 31:] = torch.randint(0, 998, (3, 46), generator=g)
+    got2 = eng.clip_forward(tok2.to(dev))
+    assert torch.equal(got2[:, :31], got[:, :31])
+
+
+def test_clip_l_full_size_vs_oracle(dev):
+    """CLIP-L geometry (12 layers x 768, 12 heads of 64, 3072 MLP, vocab 49408) with seeded synthetic weights, B = 2."""
+    schema, eng_mod = sub("schema"), sub("engine")
+    from oracle import clip as oclip
+    cfg = schema.sd15_clip()
+    sd = schema.synthetic_state_dict(clip_cfg=cfg, dtype=torch.float16)
+    eng = eng_mod.Engine(0)
+    eng.load_clip(cfg, sd)
+    tok = torch.randint(0, 49405, (2, 77), generator=torch.Generator().manual_seed(5))
+    tok[:, 0] = 49406
+    tok[0, 9:] = 49407
+    tok[1, 70:] = 49407
+    got = eng.clip_forward(tok.to(dev))
+    ref = oclip.build_clip(oclip.ClipConfig(), sd)(tok)
+    assert rel_l2(got.cpu(), ref) < 5e-3
+
+
 def test_txt2img_batch_split_matches(dev, tiny):
     """Sharding contract of the multi-GPU runner: images [0,4) generated as 4, as 2+2 (n_iter) or as the tail pair are the
     same images — per-image Philox streams (modules/rng.py:108) + per-image arithmetic everywhere.  Bitwise when the per-call

@@ -201,6 +201,66 @@ def test_lora_merge_arithmetic():
     assert list(failed) == ["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight"]
 
 
+def _seed_clip_like_fixture(model, ci):
+    """Same seeding as tests/golden/make_golden.py::gen_clip (parameters visited in state-dict order)."""
+    g = torch.Generator().manual_seed(4000 + ci)
+    with torch.no_grad():
+        for name, prm in model.state_dict().items():
+            if name.endswith("embedding.weight"):
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.5)
+            elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("layer_norm.weight"):
+                prm.copy_(1.0 + 0.02 * torch.randn(prm.shape, generator=g))
+            elif name.endswith(".bias"):
+                prm.copy_(0.02 * torch.randn(prm.shape, generator=g))
+            else:
+                prm.copy_(torch.randn(prm.shape, generator=g) * prm.shape[-1] ** -0.5)
+
+
+def test_clip_text_model_matches_reference_twin(golden_dir):
+    """oracle.clip.ClipTextModel == modules/models/sd3/other_impls.py CLIPTextModel_ (last hidden state, clip-skip-2 + final
+    norm, pooled), quick_gelu and gelu."""
+    from oracle import clip as oclip
+    z = np.load(os.path.join(golden_dir, "clip_text.npz"))
+    for ci, act in enumerate(("quick_gelu", "gelu")):
+        cfg = oclip.ClipConfig(vocab_size=49408, hidden=128, layers=3, heads=2, intermediate=256, act=act)
+        m = oclip.ClipTextModel(cfg).eval()
+        _seed_clip_like_fixture(m, ci)
+        tok = torch.from_numpy(z[f"c{ci}_tokens"])
+        last, pooled = m(tok, skip=1, return_pooled=True)
+        np.testing.assert_allclose(last.numpy(), z[f"c{ci}_last"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(pooled.numpy(), z[f"c{ci}_pooled"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(m(tok, skip=2).numpy(), z[f"c{ci}_skip2"], rtol=0, atol=2e-5)
+
+
+def test_clip_text_model_matches_installed_transformers():
+    """The third-party network itself, when importable here: transformers' CLIPTextModel on a small random configuration —
+    last_hidden_state, hidden_states[-2] + final_layer_norm (the clip-skip branch of sd_hijack_clip.py:354-356), pooler_output."""
+    transformers = pytest.importorskip("transformers")
+    from oracle import clip as oclip
+    hf_cfg = transformers.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                                         num_attention_heads=2, max_position_embeddings=77, hidden_act="quick_gelu",
+                                         eos_token_id=999, bos_token_id=998, pad_token_id=999)
+    torch.manual_seed(0)
+    hf = transformers.CLIPTextModel(hf_cfg).eval()
+    cfg = oclip.ClipConfig(vocab_size=1000, hidden=128, layers=3, heads=2, intermediate=256)
+    # transformers 4.x keeps the network under ".text_model.", 5.x flattened it: normalise to the 4.x (checkpoint) layout
+    sd = {"cond_stage_model.transformer." + (k if k.startswith("text_model.") else "text_model." + k): v
+          for k, v in hf.state_dict().items()}
+    m = oclip.build_clip(cfg, sd)
+    tok = torch.randint(0, 998, (2, 77), generator=torch.Generator().manual_seed(1))
+    tok[:, 0] = 998
+    tok[0, 30:] = 999
+    tok[1, 76] = 999
+    with torch.no_grad():
+        out = hf(input_ids=tok, output_hidden_states=True)
+        np.testing.assert_allclose(m(tok).numpy(), out.last_hidden_state.numpy(), rtol=0, atol=2e-5)
+        want2 = getattr(hf, "text_model", hf).final_layer_norm(out.hidden_states[-2])
+        np.testing.assert_allclose(m(tok, skip=2).numpy(), want2.numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(m(tok, skip=2, apply_final_ln=False).numpy(), out.hidden_states[-2].numpy(), rtol=0, atol=2e-5)
+        _, pooled = m(tok, return_pooled=True)
+        np.testing.assert_allclose(pooled.numpy(), out.pooler_output.numpy(), rtol=0, atol=2e-5)
+
+
 def test_schedule_known_answers():
     """SURVEY.md appendix A.3 (in-tree hints modules/shared_options.py:396-397, sd_schedulers.py:60-63)."""
     ac = kd.make_alphas_cumprod()
