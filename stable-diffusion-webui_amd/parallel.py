@@ -63,8 +63,13 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0, algo: str = "scatter_allgat
     shard = n // world
     views = list(blob.view(world, shard).unbind(0))
     mine = torch.empty(shard, dtype=blob.dtype, device=blob.device)
-    dist.scatter(mine, scatter_list=[v.contiguous() for v in views] if dist.get_rank() == src else None, src=src)
-    dist.all_gather(views, mine)          # each rank pulls the other W-1 shards from their owners (all links busy)
+    try:
+        dist.scatter(mine, scatter_list=[v.contiguous() for v in views] if dist.get_rank() == src else None, src=src)
+        dist.all_gather(views, mine)      # each rank pulls the other W-1 shards from their owners (all links busy)
+    except (RuntimeError, NotImplementedError, ValueError) as e:      # a backend without scatter: correctness first
+        if dist.get_rank() == src:
+            print(f"[parallel] scatter + all-gather unavailable ({type(e).__name__}: {e}); falling back to broadcast", flush=True)
+        dist.broadcast(blob, src=src)
     return blob
 
 
@@ -107,8 +112,12 @@ def gather_to_rank0(t: torch.Tensor, counts: List[int]) -> Optional[torch.Tensor
     mx = max(counts)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-    dist.gather(pad, gather_list=bufs, dst=0)
+    try:
+        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, gather_list=bufs, dst=0)
+    except (RuntimeError, NotImplementedError, ValueError):           # a backend without gather: all-gather and drop
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
     if rank != 0:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)])

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 REPO=$(pwd)
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -q -n 1 --max-worker-restart 60 -p no:cacheprovider --tb=short > gpurun_out/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q -n 1 --max-worker-restart 4 -p no:cacheprovider --tb=short > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -2 gpurun_out/pytest_gpu.log
 timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1
 echo "bench rc=$?" >> gpurun_out/bench.log; tail -2 gpurun_out/bench.log | cut -c1-1500
@@ -16,6 +16,8 @@ timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $REPO/gpurun_out/prof_p
 echo "pmc fetch rc=$?" >> $REPO/gpurun_out/prof_pmc_fetch.log
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $REPO/gpurun_out/prof_pmc_write -o pmc -- python $REPO/bench.py --steps 1 --warmup 0 --sampler-steps 2 --no-cpu-baseline --no-roofline > $REPO/gpurun_out/prof_pmc_write.log 2>&1
 echo "pmc write rc=$?" >> $REPO/gpurun_out/prof_pmc_write.log
+timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $REPO/gpurun_out/prof_pmc_mfma -o pmc -- python $REPO/bench.py --steps 1 --warmup 0 --sampler-steps 2 --no-cpu-baseline --no-roofline > $REPO/gpurun_out/prof_pmc_mfma.log 2>&1
+echo "pmc mfma rc=$?" >> $REPO/gpurun_out/prof_pmc_mfma.log
 cd $REPO
 find gpurun_out -name "*.csv" | head -30
 du -sh gpurun_out

@@ -71,12 +71,37 @@ def main():
             c, fv, fd = fe[n]
             wv = wr.get(n, [1, 0.0, 0.0])
             f.write(f"| `{short(n)}` | {c} | {2 * fv / c / 1024:.1f} | {wv[1] / max(wv[0], 1) / 1024:.1f} | {fd / c / 1e3:.1f} |\n")
-            if "gemm_mfma_kernel" in n:
+            if "gemm_mfma" in n:
                 fam["calls"] += c; fam["fetch_kb"] += 2 * fv; fam["write_kb"] += wv[1] * c / max(wv[0], 1)
     per_launch = (fam["fetch_kb"] + fam["write_kb"]) * 1024 / max(fam["calls"], 1)
     json.dump({"round": rnd, "gemm_mfma_bytes_per_launch": round(per_launch), "gemm_mfma_launches": fam["calls"],
-               "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over every gemm_mfma_kernel launch of the PMC pass"},
+               "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over every gemm_mfma_* (two-stage + ping-pong) launch of the PMC pass"},
               open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    # MFMA utilisation / effective clock per kernel (third PMC pass, optional)
+    mdir = os.path.join(G, "prof_pmc_mfma")
+    if os.path.isdir(mdir):
+        c = sqlite3.connect(first_db(mdir))
+        d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))
+        for name, cn, val, dur in c.execute("select kernel_name, counter_name, value, duration from counters_collection"):
+            a = d[name][cn]
+            a[0] += 1; a[1] += val; a[2] += dur
+        rows = []
+        for name, cs in d.items():
+            if "GRBM_GUI_ACTIVE" not in cs or "SQ_VALU_MFMA_BUSY_CYCLES" not in cs:
+                continue
+            n, gui, dur = cs["GRBM_GUI_ACTIVE"]
+            mf = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1]
+            cyc = gui / 8.0                                 # counter is summed over the 8 XCDs
+            rows.append((dur, name, n, dur / n / 1e3, cyc / max(dur, 1) * 1e0, mf / max(cyc * 1024, 1)))
+        rows.sort(reverse=True)
+        with open(os.path.join(P, f"{rnd}_pmc_mfma.md"), "w") as f:
+            f.write(f"# MFMA utilisation and effective clock per kernel ({rnd})\n\n`rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE "
+                    "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES` over `python bench.py --steps 1 --warmup 0 --sampler-steps 2 "
+                    "--no-cpu-baseline --no-roofline`.  clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA util = "
+                    "SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs) (the counter adds 16 cycles per 16x16x32 MFMA, 32 per 32x32x16).\n\n"
+                    "| kernel | launches | avg us | clock GHz | MFMA util |\n|---|---:|---:|---:|---:|\n")
+            for dur, name, n, avg, ghz, util in rows[:16]:
+                f.write(f"| `{short(name)}` | {n} | {avg:.1f} | {ghz:.2f} | {util:.3f} |\n")
     print("wrote", os.listdir(P))
 
 
