@@ -163,6 +163,11 @@ int sdmi_axpby(void* y_f32, const void* x_f32, float a, const void* z_f32_or_nul
  * linear combinations of x, denoiser outputs and noise; `terms` / `coefs` are HOST arrays. */
 int sdmi_lincomb(void* out_f32, const void* const* terms_f32, const float* coefs, int n_terms, int64_t n, void* stream);
 
+/* Latent upscale of the hires-fix pass: torch.nn.functional.interpolate(samples, size=(ho, wo), mode, antialias=False) on
+ * `planes` = B*C fp32 planes of hi x wi (modules/processing.py:1392 with the "Latent*" upscalers of modules/shared.py:54-62).
+ * mode: 0 "nearest", 1 "nearest-exact", 2 "bilinear", 3 "bicubic" (align_corners = False, ATen index arithmetic). */
+int sdmi_latent_resize(const void* in_f32, void* out_f32, int planes, int hi, int wi, int ho, int wo, int mode, void* stream);
+
 /* x = init*mask + nmask*x, all fp32 tensors of n elements: the inpainting blend CFGDenoiser applies before / after
  * denoising (modules/sd_samplers_cfg_denoiser.py:206-209, 279-280). */
 int sdmi_mask_blend(void* x_f32, const void* init_f32, const void* mask_f32, const void* nmask_f32, int64_t n, void* stream);

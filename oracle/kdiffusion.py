@@ -117,6 +117,9 @@ class CFGDenoiser:
         self.step = 0
         self.mask, self.nmask, self.init_latent = mask, nmask, init_latent
         self.mask_before_denoising = False
+        self.cond_scale_miltiplier = 1.0                     # modules/sd_samplers_cfg_denoiser.py:61-64
+        self.need_last_noise_uncond = False
+        self.last_noise_uncond = None
 
     @staticmethod
     def combine_denoised(x_out, conds_list, uncond_n, cond_scale):
@@ -136,7 +139,9 @@ class CFGDenoiser:
         sigma_in = torch.cat([sigma, sigma])
         cond_in = torch.cat([cond, uncond])
         x_out = self.inner_model(x_in, sigma_in, cond_in)
-        denoised = self.combine_denoised(x_out, conds_list, b, cond_scale)
+        if self.need_last_noise_uncond:
+            self.last_noise_uncond = torch.clone(x_out[-b:])                     # :281-282
+        denoised = self.combine_denoised(x_out, conds_list, b, cond_scale * self.cond_scale_miltiplier)
         if not self.mask_before_denoising and self.mask is not None:
             denoised = denoised * self.nmask + self.init_latent * self.mask
         self.step += 1
@@ -411,6 +416,34 @@ def sample_ddim(model, x, timesteps, alphas_cumprod, extra_args, noise_fn, eta=0
         sqrt_one_minus_at = sqrt_one_minus_alphas[index].item() * s_x
         pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
         dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
+        noise = sigma_t * noise_fn()
+        x = a_prev.sqrt() * pred_x0 + dir_xt + noise
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': 0, 'sigma_hat': 0, 'denoised': pred_x0})
+    return x
+
+
+def sample_ddim_cfgpp(model, x, timesteps, alphas_cumprod, extra_args, noise_fn, eta=0.0, callback=None):
+    """modules/sd_samplers_timesteps_impl.py:43-82 (pinned by tests/golden/ddim.npz, keys cfgpp_*).  ``model`` is the CFG
+    denoiser: the function sets cond_scale_miltiplier = 1/12.5 and reads model.last_noise_uncond after every call."""
+    alphas = alphas_cumprod[timesteps]
+    alphas_prev = alphas_cumprod[torch.nn.functional.pad(timesteps[:-1], pad=(1, 0))].to(torch.float64)
+    sqrt_one_minus_alphas = torch.sqrt(1 - alphas)
+    sigmas = eta * np.sqrt((1 - alphas_prev.cpu().numpy()) / (1 - alphas.cpu()) * (1 - alphas.cpu() / alphas_prev.cpu().numpy()))
+    model.cond_scale_miltiplier = 1 / 12.5
+    model.need_last_noise_uncond = True
+    s_in = x.new_ones((x.shape[0]))
+    s_x = x.new_ones((x.shape[0], 1, 1, 1))
+    for i in range(len(timesteps) - 1):
+        index = len(timesteps) - 1 - i
+        e_t = model(x, timesteps[index].item() * s_in, **extra_args)
+        last_noise_uncond = model.last_noise_uncond
+        a_t = alphas[index].item() * s_x
+        a_prev = alphas_prev[index].item() * s_x
+        sigma_t = sigmas[index].item() * s_x
+        sqrt_one_minus_at = sqrt_one_minus_alphas[index].item() * s_x
+        pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+        dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * last_noise_uncond
         noise = sigma_t * noise_fn()
         x = a_prev.sqrt() * pred_x0 + dir_xt + noise
         if callback is not None:

@@ -75,7 +75,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
             samples = samples * nmask + init_latent * mask
         return samples
 
-    if sampler in ("ddim", "plms"):
+    if sampler in ("ddim", "plms", "ddim_cfgpp"):
         # CFGDenoiserTimesteps: inner model is apply_model on integer timesteps, CFG combines eps.
         cfg = kd.CFGDenoiser(lambda xi, ti, ci: apply_model(xi, ti, ci), mask, nmask, init_latent)
         cfg.mask_before_denoising = True
@@ -89,6 +89,9 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
             ts = ts[:t_enc]
         if sampler == "plms":
             return finish(kd.sample_plms(cfg, x, ts, model.alphas_cumprod, extra, callback=record))
+        if sampler == "ddim_cfgpp":
+            return finish(kd.sample_ddim_cfgpp(cfg, x, ts, model.alphas_cumprod, extra, rng.next,
+                                               eta=0.0 if eta is None else eta, callback=record))
         return finish(kd.sample_ddim(cfg, x, ts, model.alphas_cumprod, extra, rng.next,
                                      eta=0.0 if eta is None else eta, callback=record))
 

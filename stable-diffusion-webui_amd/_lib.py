@@ -95,6 +95,7 @@ _SIGS = {
     "sdmi_axpby": (_i, [_vp, _vp, _f, _vp, _f, _i64, _vp]),
     "sdmi_lincomb": (_i, [_vp, C.POINTER(_vp), C.POINTER(_f), _i, _i64, _vp]),
     "sdmi_mask_blend": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "sdmi_latent_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sdmi_image_to_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sdmi_engine_create": (_vp, [_i]),
     "sdmi_engine_destroy": (None, [_vp]),

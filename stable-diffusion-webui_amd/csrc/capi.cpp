@@ -209,6 +209,13 @@ int sdmi_lincomb(void* out, const void* const* terms, const float* coefs, int n_
     API_GUARD_END
 }
 
+int sdmi_latent_resize(const void* in, void* out, int planes, int hi, int wi, int ho, int wo, int mode, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(in && out, "null argument");
+    return launch_latent_resize((const float*)in, (float*)out, planes, hi, wi, ho, wo, mode, (hipStream_t)stream);
+    API_GUARD_END
+}
+
 int sdmi_mask_blend(void* x, const void* init, const void* mask, const void* nmask, int64_t n, void* stream) {
     API_GUARD_BEGIN
     SDMI_REQUIRE(x && init && mask && nmask, "null argument");

@@ -217,6 +217,65 @@ int launch_mask_blend(float* x, const float* init, const float* mask, const floa
     return 0;
 }
 
+// Latent resample of the hires-fix pass: torch.nn.functional.interpolate(samples, size, mode, antialias=False) on [B,4,h,w]
+// fp32 (modules/processing.py:1392; upscaler table modules/shared.py:54-62).  Index arithmetic follows ATen's upsample
+// kernels (align_corners = False): scale = in / out; nearest: floor(dst * scale); nearest-exact: floor((dst + 0.5) * scale);
+// bilinear: src = max(scale * (dst + 0.5) - 0.5, 0); bicubic: same src unclamped, cubic convolution with A = -0.75 and
+// border-clamped taps.  mode: 0 nearest, 1 nearest-exact, 2 bilinear, 3 bicubic.
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__global__ __launch_bounds__(256) void latent_resize_kernel(const float* in, float* out, int planes, int hi, int wi, int ho,
+                                                            int wo, int mode) {
+    const long n = (long)planes * ho * wo;
+    const float sh = (float)hi / (float)ho, sw = (float)wi / (float)wo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % wo), y = (int)((i / wo) % ho);
+        const long pl = i / ((long)wo * ho);
+        const float* src = in + pl * (long)hi * wi;
+        float v;
+        if (mode <= 1) {
+            const float off = mode == 1 ? 0.5f : 0.f;
+            const int ys = min((int)floorf(((float)y + off) * sh), hi - 1), xs = min((int)floorf(((float)x + off) * sw), wi - 1);
+            v = src[(long)ys * wi + xs];
+        } else if (mode == 2) {
+            const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            v = hy * (hx * src[(long)y0 * wi + x0] + lx * src[(long)y0 * wi + x1]) +
+                ly * (hx * src[(long)y1 * wi + x0] + lx * src[(long)y1 * wi + x1]);
+        } else {
+            const float A = -0.75f;
+            const float fy = sh * ((float)y + 0.5f) - 0.5f, fx = sw * ((float)x + 0.5f) - 0.5f;
+            const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+            const float ty = fy - (float)iy, tx = fx - (float)ix;
+            const float cy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+            const float cx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+            v = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int yy = min(max(iy - 1 + a, 0), hi - 1);
+                float row = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int xx = min(max(ix - 1 + b, 0), wi - 1);
+                    row = row + cx[b] * src[(long)yy * wi + xx];
+                }
+                v = v + cy[a] * row;
+            }
+        }
+        out[i] = v;
+    }
+}
+int launch_latent_resize(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, int mode, hipStream_t s) {
+    SDMI_REQUIRE(mode >= 0 && mode <= 3 && planes > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, "latent_resize: bad arguments");
+    const long n = (long)planes * ho * wo;
+    hipLaunchKernelGGL(latent_resize_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, in, out, planes, hi, wi, ho, wo, mode);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // CLIP text embeddings: out[b,l,:] = (inputs_embeds[b,l,:] if given else tok_emb[token[b,l],:]) + pos_emb[l,:]  -> fp16 rows
 // (transformers CLIPTextEmbeddings; in-repo twin modules/models/sd3/other_impls.py:117-125)
 template <typename TT>

@@ -193,6 +193,18 @@ def mask_blend(x: torch.Tensor, init: torch.Tensor, mask: torch.Tensor, nmask: t
     return x
 
 
+def latent_resize(x: torch.Tensor, size, mode: str = "bilinear") -> torch.Tensor:
+    """F.interpolate(x, size=size, mode=mode, antialias=False) for fp32 NCHW latents (modules/processing.py:1392)."""
+    _lib.require_device()
+    x = x.float().contiguous()
+    b, c, hi, wi = x.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=x.device)
+    code = {"nearest": 0, "nearest-exact": 1, "bilinear": 2, "bicubic": 3}[mode]
+    check(lib.sdmi_latent_resize(ptr(x), ptr(out), b * c, hi, wi, ho, wo, code, stream_ptr()), "sdmi_latent_resize")
+    return out
+
+
 def image_to_u8(img: torch.Tensor) -> torch.Tensor:
     """fp32 NCHW in [-1,1] -> uint8 NHWC (modules/processing.py:1004-1005, 1034-1035)."""
     _lib.require_device()

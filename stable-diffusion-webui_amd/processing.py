@@ -112,9 +112,8 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         self.is_hr_pass = True
         target_w = self.hr_resize_x or int(self.width * self.hr_scale)
         target_h = self.hr_resize_y or int(self.height * self.hr_scale)
-        # K16: tiny [B,4,h,w] resample; torch's interpolate on the GPU tensor, as the reference does
-        samples = torch.nn.functional.interpolate(samples, size=(target_h // opt_f, target_w // opt_f), mode=mode,
-                                                  antialias=False)
+        # K16: [B,4,h,w] resample = F.interpolate(..., mode, antialias=False) (modules/processing.py:1392)
+        samples = ops.latent_resize(samples, (target_h // opt_f, target_w // opt_f), mode)
         self.rng = ImageRNG(samples.shape[1:], self.seeds, eta_noise_seed_delta=shared.opts.eta_noise_seed_delta,
                             device=samples.device)
         noise = self.rng.next()

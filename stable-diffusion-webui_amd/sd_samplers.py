@@ -145,6 +145,8 @@ class CFGDenoiser:
         self.padded_cond_uncond_v0 = False
         self.p = None
         self.cond_scale_miltiplier = 1.0
+        self.need_last_noise_uncond = False                 # DDIM CFG++ (cfg_denoiser.py:63-64, 281-282)
+        self.last_noise_uncond = None
         self.mask_before_denoising = mode == 1          # CFGDenoiserTimesteps sets this (sd_samplers_timesteps.py:54)
         self._ctx_key = None
         self._x_in = None
@@ -199,6 +201,8 @@ class CFGDenoiser:
         if y is not None:
             yy = torch.cat([y, uy]).float().contiguous()
         eng.unet_forward(self._x_in, ts, None, yy, out=self._eps)
+        if self.need_last_noise_uncond:
+            self.last_noise_uncond = self._eps[b:].clone()
         den = torch.empty_like(x)
         use_mask = (not self.mask_before_denoising) and self.mask is not None
         check(lib.sdmi_cfg_combine(ptr(x), ptr(self._eps), ptr(c_out_t), float(cond_scale * self.cond_scale_miltiplier), self.mode,
@@ -429,6 +433,36 @@ def sample_dpmpp_2s_ancestral(model, x, sigmas, extra_args=None, callback=None, 
             x = _lc(torch.empty_like(x), [x, denoised_2], [float(sigma_fn(t_next) / sigma_fn(t)), -float((-h).expm1())])
         if sigmas[i + 1] > 0:
             x = _lc(torch.empty_like(x), [x, noise_sampler(sigmas[i], sigmas[i + 1])], [1.0, s_noise * float(sigma_up)])
+    return x
+
+
+def ddim_cfgpp(model, x, timesteps, extra_args=None, callback=None, disable=None, eta=0.0, noise_sampler=None):
+    """modules/sd_samplers_timesteps_impl.py:43-82 — CFG++: the direction term uses the UNCONDITIONAL eps and the CFG scale is
+    mapped from [0, 12.5] to [0, 1]."""
+    alphas_cumprod = model.inner_model.inner_model.alphas_cumprod.float().cpu()
+    timesteps = timesteps.cpu()
+    alphas = alphas_cumprod[timesteps]
+    alphas_prev = alphas_cumprod[torch.nn.functional.pad(timesteps[:-1], pad=(1, 0))].to(torch.float64)
+    sqrt_one_minus_alphas = torch.sqrt(1 - alphas)
+    sigmas = eta * np.sqrt((1 - alphas_prev.numpy()) / (1 - alphas) * (1 - alphas / alphas_prev.numpy()))
+    model.cond_scale_miltiplier = 1 / 12.5
+    model.need_last_noise_uncond = True
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones((x.shape[0]))
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+    for i in range(len(timesteps) - 1):
+        index = len(timesteps) - 1 - i
+        e_t = model(x, timesteps[index].item() * s_in, **extra_args)
+        last_noise_uncond = model.last_noise_uncond
+        a_t, a_prev = f32(alphas[index].item()), f32(alphas_prev[index].item())
+        sigma_t, somat = f32(sigmas[index].item()), f32(sqrt_one_minus_alphas[index].item())
+        pred_x0 = _lc(torch.empty_like(x), [x, e_t], [1.0 / float(a_t.sqrt()), -float(somat) / float(a_t.sqrt())])
+        noise = noise_sampler() if noise_sampler is not None else torch.zeros_like(x)
+        x = _lc(torch.empty_like(x), [pred_x0, last_noise_uncond, noise],
+                [float(a_prev.sqrt()), float((1. - a_prev - sigma_t ** 2).sqrt()), float(sigma_t)])
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': 0, 'sigma_hat': 0, 'denoised': pred_x0})
     return x
 
 
@@ -789,9 +823,10 @@ samplers_data_k_diffusion = [
     SamplerData(label, lambda model, func=func: KDiffusionSampler(func, model), aliases, options)
     for label, func, aliases, options in samplers_k_diffusion
 ]
-samplers_data_timesteps = [                               # modules/sd_samplers_timesteps.py:12-17 (UniPC, DDIM CFG++: not yet)
-    SamplerData('DDIM', lambda model: CompVisSampler(ddim, model), [], {}),
-    SamplerData('PLMS', lambda model: CompVisSampler(plms, model), [], {}),
+samplers_data_timesteps = [                               # modules/sd_samplers_timesteps.py:10-15 (UniPC: not yet)
+    SamplerData('DDIM', lambda model: CompVisSampler(ddim, model), ['ddim'], {}),
+    SamplerData('DDIM CFG++', lambda model: CompVisSampler(ddim_cfgpp, model), ['ddim_cfgpp'], {}),
+    SamplerData('PLMS', lambda model: CompVisSampler(plms, model), ['plms'], {}),
 ]
 all_samplers = [*samplers_data_k_diffusion, *samplers_data_timesteps]
 all_samplers_map = {x.name: x for x in all_samplers}

@@ -164,6 +164,26 @@ def gen_ddim():
         res = impl.ddim(Model(), x0.clone(), timesteps, extra_args={}, disable=True, eta=eta)
         out[f"c{ci}_steps_eta"] = np.array([steps, eta])
         out[f"c{ci}_out"] = res.numpy()
+    # DDIM CFG++ (same file, :43-82): the model object also exposes last_noise_uncond
+    class ModelPP(Model):
+        def __call__(self, x, t, **kw):
+            self.last_noise_uncond = torch.sin(0.3 * x) * 0.8 - 0.1 * (t / 1000.0)[:, None, None, None]
+            return super().__call__(x, t, **kw)
+    for ci, (steps, eta) in enumerate([(12, 0.0), (9, 0.7)]):
+        noise_draws = [seeded((2, 4, 8, 8), 950 + i) for i in range(steps + 2)]
+        it = iter(noise_draws)
+
+        class TH2:
+            @staticmethod
+            def randn_like(x):
+                return next(it)
+        kds.torch = TH2
+        timesteps = torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+        mpp = ModelPP()
+        res = impl.ddim_cfgpp(mpp, seeded((2, 4, 8, 8), 940 + ci), timesteps, extra_args={}, disable=True, eta=eta)
+        assert mpp.cond_scale_miltiplier == 1 / 12.5 and mpp.need_last_noise_uncond is True
+        out[f"cfgpp{ci}_steps_eta"] = np.array([steps, eta])
+        out[f"cfgpp{ci}_out"] = res.numpy()
     np.savez_compressed(os.path.join(OUT, "ddim.npz"), **out)
     print("ddim.npz")
     # PLMS (same file, :85-137): deterministic, no noise

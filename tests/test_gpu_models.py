@@ -128,7 +128,7 @@ def test_vae_decoder_against_reference_class_fixture(dev, golden_dir):
 @pytest.mark.parametrize("sampler,name,steps", [("euler_a", "Euler a", 5), ("dpmpp_2m", "DPM++ 2M", 6), ("ddim", "DDIM", 5),
                                                 ("euler", "Euler", 4), ("heun", "Heun", 4), ("dpm_2", "DPM2", 4),
                                                 ("dpm_2_a", "DPM2 a", 4), ("lms", "LMS", 6), ("dpmpp_2s_a", "DPM++ 2S a", 4),
-                                                ("plms", "PLMS", 5)])
+                                                ("plms", "PLMS", 5), ("ddim_cfgpp", "DDIM CFG++", 5)])
 def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     from oracle import pipeline as opipe
     processing = sub("processing")

@@ -342,6 +342,22 @@ def test_layernorm_vs_torch(dev, c):
 # ------------------------------------------------------------------------------------------------------------
 # sampler arithmetic
 # ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["nearest", "nearest-exact", "bilinear", "bicubic"])
+@pytest.mark.parametrize("src,dst", [((64, 64), (128, 128)), ((16, 24), (25, 31)), ((40, 30), (24, 21))])
+def test_latent_resize_matches_torch_interpolate(dev, mode, src, dst):
+    """The hires-fix latent upscale (modules/processing.py:1392) against torch's own CPU interpolate, incl. non-integer and
+    downscaling factors."""
+    ops = sub("ops")
+    x = seeded((2, 4) + src, 60)
+    want = F.interpolate(x, size=dst, mode=mode, antialias=False) if mode in ("bilinear", "bicubic") else F.interpolate(x, size=dst, mode=mode)
+    got = ops.latent_resize(x.to(dev), dst, mode)
+    assert got.shape == want.shape
+    if mode.startswith("nearest"):
+        assert torch.equal(got.cpu(), want)
+    else:
+        assert float((got.cpu() - want).abs().max()) < 2e-5
+
+
 def test_lincomb_and_mask_blend(dev):
     ops = sub("ops")
     ts = [seeded((2, 4, 8, 8), 40 + i) for i in range(6)]

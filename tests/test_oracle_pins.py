@@ -111,6 +111,26 @@ def test_ddim_matches_reference(golden_dir):
         np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
 
 
+def test_ddim_cfgpp_matches_reference(golden_dir):
+    """oracle sample_ddim_cfgpp == modules/sd_samplers_timesteps_impl.py:43-82 (uncond-eps direction term, multiplier 1/12.5)."""
+    z = np.load(os.path.join(golden_dir, "ddim.npz"))
+    ac = kd.make_alphas_cumprod()
+
+    class Model:
+        def __call__(self, x, t, **kw):
+            self.last_noise_uncond = torch.sin(0.3 * x) * 0.8 - 0.1 * (t / 1000.0)[:, None, None, None]
+            return torch.tanh(0.7 * x + (t / 1000.0)[:, None, None, None]) * 0.9 + 0.05 * x
+
+    for ci in range(2):
+        steps, eta = z[f"cfgpp{ci}_steps_eta"]
+        steps = int(steps)
+        draws = iter([seeded((2, 4, 8, 8), 950 + i) for i in range(steps + 2)])
+        m = Model()
+        out = kd.sample_ddim_cfgpp(m, seeded((2, 4, 8, 8), 940 + ci), kd.ddim_timesteps(steps), ac, {}, lambda: next(draws), eta=float(eta))
+        assert m.cond_scale_miltiplier == 1 / 12.5
+        np.testing.assert_allclose(out.numpy(), z[f"cfgpp{ci}_out"], rtol=0, atol=1e-6)
+
+
 def test_plms_matches_reference(golden_dir):
     """oracle sample_plms == modules/sd_samplers_timesteps_impl.py:85-137 on an analytic eps model."""
     z = np.load(os.path.join(golden_dir, "plms.npz"))
