@@ -140,6 +140,15 @@ int sdmi_cfg_combine(const void* x_f32, const void* eps_f32, const void* c_out_f
                      const void* mask_f32, const void* nmask_f32, const void* init_latent_f32,
                      void* denoised_f32, int B, int64_t chw, void* stream);
 
+/* CFG combine for v-prediction checkpoints (SD 2.x 768-v; `parameterization == "v"`, modules/sd_models_config.py:86-94):
+ * each half of the UNet output goes through d = out * c_out[b] + x * c_skip[b] first — k-diffusion's CompVisVDenoiser in
+ * sigma space (denoised; c_skip = 1/(s^2+1), c_out = -s/sqrt(s^2+1), selected at modules/sd_samplers_kdiffusion.py:60-62)
+ * or CompVisTimestepsVDenoiser.predict_eps_from_z_and_v in timestep space (eps; c_out = sqrt(a_t), c_skip = sqrt(1 - a_t),
+ * modules/sd_samplers_timesteps.py:33-45) — then u + (c - u) * cond_scale and the optional mask blend as above. */
+int sdmi_cfg_combine_affine(const void* x_f32, const void* out_f32, const void* c_out_f32, const void* c_skip_f32,
+                            float cond_scale, const void* mask_f32, const void* nmask_f32, const void* init_latent_f32,
+                            void* denoised_f32, int B, int64_t chw, void* stream);
+
 /* k-diffusion sample_euler_ancestral / sample_euler update (pinned k-diffusion@ab527a9; to_d per
  * modules/sd_schedulers.py:10-15):  d=(x-den)/sigma; x+=d*(sigma_down-sigma); x+=noise*s_noise*sigma_up (if noise). */
 int sdmi_euler_step(void* x_f32, const void* denoised_f32, const void* noise_f32_or_null,

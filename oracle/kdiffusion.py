@@ -107,6 +107,27 @@ class CompVisDenoiser(DiscreteSchedule):
         return input + eps * c_out
 
 
+class CompVisVDenoiser(CompVisDenoiser):
+    """v-prediction wrapper (k-diffusion external.DiscreteVDDPMDenoiser / CompVisVDenoiser, [3P]; constructed at
+    modules/sd_samplers_kdiffusion.py:60-62 for parameterization == "v"): denoised = v(x*c_in, t) * c_out + x * c_skip."""
+
+    def get_scalings(self, sigma):
+        c_skip = self.sigma_data ** 2 / (sigma ** 2 + self.sigma_data ** 2)
+        c_out = -sigma * self.sigma_data / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_skip, c_out, c_in
+
+    def __call__(self, input, sigma, cond):
+        c_skip, c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
+        return self.apply_model(input * c_in, self.sigma_to_t(sigma), cond) * c_out + input * c_skip
+
+
+def timesteps_v_to_eps(alphas_cumprod, x_t, t, v):
+    """CompVisTimestepsVDenoiser.predict_eps_from_z_and_v (modules/sd_samplers_timesteps.py:38-39)."""
+    return torch.sqrt(alphas_cumprod)[t.to(torch.int), None, None, None] * v + \
+        torch.sqrt(1 - alphas_cumprod)[t.to(torch.int), None, None, None] * x_t
+
+
 # ---------------------------------------------------------------------------------------------
 # CFG  (modules/sd_samplers_cfg_denoiser.py:74-82, 156-311 for the plain txt2img case:
 #       one cond per image with weight 1.0, equal token counts, batch_cond_uncond on, no mask)

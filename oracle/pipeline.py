@@ -56,7 +56,7 @@ def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, schedul
 @torch.no_grad()
 def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
            latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
-           y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None):
+           y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None, parameterization="eps"):
     """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
     (modules/sd_samplers_kdiffusion.py:134-143); ``mask`` (1 = keep the original latent) adds the inpainting blends of
     modules/sd_samplers_cfg_denoiser.py:186-187 / 292-293 and the final blend of modules/processing.py:1776-1784."""
@@ -77,7 +77,11 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
 
     if sampler in ("ddim", "plms", "ddim_cfgpp"):
         # CFGDenoiserTimesteps: inner model is apply_model on integer timesteps, CFG combines eps.
-        cfg = kd.CFGDenoiser(lambda xi, ti, ci: apply_model(xi, ti, ci), mask, nmask, init_latent)
+        if parameterization == "v":
+            inner = lambda xi, ti, ci: kd.timesteps_v_to_eps(model.alphas_cumprod, xi, ti, apply_model(xi, ti, ci))
+        else:
+            inner = lambda xi, ti, ci: apply_model(xi, ti, ci)
+        cfg = kd.CFGDenoiser(inner, mask, nmask, init_latent)
         cfg.mask_before_denoising = True
         ts = kd.ddim_timesteps(steps)
         extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
@@ -95,7 +99,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         return finish(kd.sample_ddim(cfg, x, ts, model.alphas_cumprod, extra, rng.next,
                                      eta=0.0 if eta is None else eta, callback=record))
 
-    wrap = kd.CompVisDenoiser(apply_model, model.alphas_cumprod)
+    wrap = (kd.CompVisVDenoiser if parameterization == "v" else kd.CompVisDenoiser)(apply_model, model.alphas_cumprod)
     cfg = kd.CFGDenoiser(wrap, mask, nmask, init_latent)
     extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
     if init_latent is None:

@@ -89,6 +89,7 @@ _SIGS = {
     "sdmi_philox_randn": (_i, [_vp, _i64, C.c_uint64, C.c_uint32, _vp]),
     "sdmi_cfg_prepare_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "sdmi_cfg_combine": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "sdmi_cfg_combine_affine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "sdmi_euler_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     "sdmi_dpmpp2m_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     "sdmi_ddim_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),

@@ -216,6 +216,16 @@ int sdmi_latent_resize(const void* in, void* out, int planes, int hi, int wi, in
     API_GUARD_END
 }
 
+int sdmi_cfg_combine_affine(const void* x, const void* out, const void* c_out, const void* c_skip, float cond_scale,
+                            const void* mask, const void* nmask, const void* init_latent, void* den, int B, int64_t chw, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(x && out && c_out && c_skip && den, "null argument");
+    return launch_cfg_combine_affine((const float*)x, (const float*)out, (const float*)c_out, (const float*)c_skip, cond_scale,
+                                     (const float*)mask, (const float*)nmask, (const float*)init_latent, (float*)den, B, chw,
+                                     (hipStream_t)stream);
+    API_GUARD_END
+}
+
 int sdmi_mask_blend(void* x, const void* init, const void* mask, const void* nmask, int64_t n, void* stream) {
     API_GUARD_BEGIN
     SDMI_REQUIRE(x && init && mask && nmask, "null argument");

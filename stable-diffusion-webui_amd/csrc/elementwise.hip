@@ -108,6 +108,33 @@ int launch_cfg_combine(const float* x, const float* eps, const float* c_out, flo
     return 0;
 }
 
+// v-prediction models: each half is first mapped through an affine wrapper  d_h = out_h * c_out[b] + x * c_skip[b]
+//   sigma space   : k-diffusion CompVisVDenoiser  (c_skip = 1/(s^2+1), c_out = -s/sqrt(s^2+1)) -> denoised
+//   timestep space: CompVisTimestepsVDenoiser.predict_eps_from_z_and_v (modules/sd_samplers_timesteps.py:38-39:
+//                   c_out = sqrt(alpha_t), c_skip = sqrt(1 - alpha_t)) -> eps
+// then combined like cfg_combine_kernel.
+__global__ __launch_bounds__(256) void cfg_combine_affine_kernel(const float* x, const float* out, const float* c_out,
+                                                                const float* c_skip, float cond_scale, const float* mask,
+                                                                const float* nmask, const float* init, float* den, int B, long chw) {
+    const long n = (long)B * chw;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / chw);
+        const float xv = x[i], co = c_out[b], cs = c_skip[b];
+        const float dc = out[i] * co + xv * cs, du = out[n + i] * co + xv * cs;
+        float d = du + (dc - du) * cond_scale;
+        if (mask) d = d * nmask[i] + init[i] * mask[i];
+        den[i] = d;
+    }
+}
+int launch_cfg_combine_affine(const float* x, const float* out, const float* c_out, const float* c_skip, float cond_scale,
+                              const float* mask, const float* nmask, const float* init_latent, float* den, int B, int64_t chw,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(cfg_combine_affine_kernel, dim3(ew_blocks((int64_t)B * chw)), dim3(256), 0, s, x, out, c_out, c_skip,
+                       cond_scale, mask, nmask, init_latent, den, B, (long)chw);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void euler_step_kernel(float* x, const float* den, const float* noise, float sigma,
                                                         float sigma_down, float sigma_up, float s_noise, long n) {
     const float dt = sigma_down - sigma;

@@ -109,6 +109,12 @@ def sdxl_unet() -> UNetConfig:
                       adm_in_channels=2816)
 
 
+def sd21_unet() -> UNetConfig:
+    """SD 2.x (configs/v2-inference(-v).yaml of Stability-AI/stablediffusion, selected at modules/sd_models_config.py:86-94):
+    OpenCLIP-H context (1024), 64-channel heads, linear proj_in / proj_out."""
+    return UNetConfig(num_heads=-1, num_head_channels=64, context_dim=1024, use_linear_in_transformer=True)
+
+
 def tiny_unet(**kw) -> UNetConfig:
     """Small SD-shaped UNet for tests / smoke (channels multiples of 64, head size 64 so the MFMA kernels are used)."""
     base = dict(model_channels=64, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(1, 2), num_heads=-1,

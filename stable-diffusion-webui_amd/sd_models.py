@@ -40,12 +40,13 @@ def guess_unet_config(sd: dict) -> schema.UNetConfig:
 class SdModel:
     def __init__(self, state_dict: dict, unet_cfg: Optional[schema.UNetConfig] = None,
                  vae_cfg: Optional[schema.VAEConfig] = None, device: int = 0, load_vae: bool = True,
-                 vae_decoder_only: bool = False):
+                 vae_decoder_only: bool = False, parameterization: str = "eps"):
         self.unet_cfg = unet_cfg or guess_unet_config(state_dict)
         self.is_sdxl = self.unet_cfg.adm_in_channels is not None
         shared.sd_model = self                            # the reference's global (modules/shared.py); schedulers read is_sdxl
         self.vae_cfg = vae_cfg or (schema.sdxl_vae() if self.is_sdxl else schema.sd15_vae())
-        self.parameterization = "eps"
+        assert parameterization in ("eps", "v")
+        self.parameterization = parameterization          # "v": SD 2.x 768-v (modules/sd_models_config.py:86-94)
         self.device = torch.device("cuda", device)
         ac = state_dict.get("alphas_cumprod")
         self.alphas_cumprod = (ac.float().cpu() if ac is not None else schema.make_alphas_cumprod())

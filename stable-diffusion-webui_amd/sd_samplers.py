@@ -118,6 +118,17 @@ class CompVisDenoiser(DiscreteSchedule):
         return c_out, c_in
 
 
+class CompVisVDenoiser(CompVisDenoiser):
+    """k-diffusion's CompVisVDenoiser for v-prediction checkpoints (chosen at modules/sd_samplers_kdiffusion.py:60-62 when
+    sd_model.parameterization == "v"): denoised = v(x * c_in, t) * c_out + x * c_skip."""
+
+    def get_scalings(self, sigma):
+        c_skip = self.sigma_data ** 2 / (sigma ** 2 + self.sigma_data ** 2)
+        c_out = -sigma * self.sigma_data / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_skip, c_out, c_in
+
+
 # ------------------------------------------------------------------------------------------------------------
 # CFG denoiser (fused)
 # ------------------------------------------------------------------------------------------------------------
@@ -154,7 +165,8 @@ class CFGDenoiser:
     @property
     def inner_model(self):
         if self.model_wrap is None:
-            self.model_wrap = CompVisDenoiser(self.sampler.sd_model, quantize=shared.opts.enable_quantization)
+            denoiser = CompVisVDenoiser if getattr(self.sampler.sd_model, "parameterization", "eps") == "v" else CompVisDenoiser
+            self.model_wrap = denoiser(self.sampler.sd_model, quantize=shared.opts.enable_quantization)
         return self.model_wrap
 
     def _ensure_context(self, cond, uncond):
@@ -184,10 +196,16 @@ class CFGDenoiser:
             self._x_in = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
             self._eps = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
         sig = float(sigma[0])
+        vpred = getattr(self.sampler.sd_model, "parameterization", "eps") == "v"
+        c_skip_t = None
         if self.mode == 0:
             wrap = self.inner_model
             sig_t = torch.tensor(sig, dtype=torch.float32)
-            c_out, c_in = wrap.get_scalings(sig_t)
+            if vpred:
+                c_skip, c_out, c_in = wrap.get_scalings(sig_t)
+                c_skip_t = torch.full((b,), float(c_skip), dtype=torch.float32, device=x.device)
+            else:
+                c_out, c_in = wrap.get_scalings(sig_t)
             t = wrap.sigma_to_t(sig_t.reshape(1))[0]
             c_in_t = torch.full((b,), float(c_in), dtype=torch.float32, device=x.device)
             c_out_t = torch.full((b,), float(c_out), dtype=torch.float32, device=x.device)
@@ -195,6 +213,13 @@ class CFGDenoiser:
             ts = torch.full((2 * b,), float(t), dtype=torch.float32, device=x.device)
         else:
             c_out_t = None
+            if vpred:                                     # eps = sqrt(a_t) * v + sqrt(1 - a_t) * x_t  (sd_samplers_timesteps.py:38-39)
+                if self.need_last_noise_uncond:
+                    raise NotImplementedError("DDIM CFG++ with a v-prediction model is not implemented")
+                ac = self.sampler.sd_model.alphas_cumprod.float().cpu()
+                a_t = ac[int(sig)]
+                c_out_t = torch.full((b,), float(torch.sqrt(a_t)), dtype=torch.float32, device=x.device)
+                c_skip_t = torch.full((b,), float(torch.sqrt(1 - a_t)), dtype=torch.float32, device=x.device)
             check(lib.sdmi_cfg_prepare_input(ptr(x), None, ptr(self._x_in), _lib.F32, b, 2, chw, stream_ptr()), "cfg_prepare")
             ts = torch.full((2 * b,), sig, dtype=torch.float32, device=x.device)
         yy = None
@@ -205,9 +230,16 @@ class CFGDenoiser:
             self.last_noise_uncond = self._eps[b:].clone()
         den = torch.empty_like(x)
         use_mask = (not self.mask_before_denoising) and self.mask is not None
-        check(lib.sdmi_cfg_combine(ptr(x), ptr(self._eps), ptr(c_out_t), float(cond_scale * self.cond_scale_miltiplier), self.mode,
-                                   ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
-                                   ptr(self.init_latent) if use_mask else None, ptr(den), b, chw, stream_ptr()), "cfg_combine")
+        if vpred:
+            check(lib.sdmi_cfg_combine_affine(ptr(x), ptr(self._eps), ptr(c_out_t), ptr(c_skip_t),
+                                              float(cond_scale * self.cond_scale_miltiplier),
+                                              ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
+                                              ptr(self.init_latent) if use_mask else None, ptr(den), b, chw, stream_ptr()),
+                  "cfg_combine_affine")
+        else:
+            check(lib.sdmi_cfg_combine(ptr(x), ptr(self._eps), ptr(c_out_t), float(cond_scale * self.cond_scale_miltiplier), self.mode,
+                                       ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
+                                       ptr(self.init_latent) if use_mask else None, ptr(den), b, chw, stream_ptr()), "cfg_combine")
         self.sampler.last_latent = den
         self.step += 1
         return den

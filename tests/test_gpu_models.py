@@ -317,6 +317,31 @@ def test_clip_l_full_size_vs_oracle(dev):
     assert rel_l2(got.cpu(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("sampler,name,steps", [("euler_a", "Euler a", 4), ("dpmpp_2m", "DPM++ 2M", 5), ("ddim", "DDIM", 5)])
+def test_v_prediction_model_vs_oracle(dev, sampler, name, steps):
+    """parameterization == "v" (SD 2.x 768-v): CompVisVDenoiser scalings in sigma space, v -> eps conversion in timestep
+    space (modules/sd_samplers_timesteps.py:33-45), fused into sdmi_cfg_combine_affine; SD2-style UNet (linear proj_in/out)."""
+    from oracle import pipeline as opipe, unet as ou
+    schema, processing = sub("schema"), sub("processing")
+    ucfg = schema.tiny_unet(use_linear_in_transformer=True)
+    sd = schema.synthetic_state_dict(ucfg, None, dtype=torch.float16)
+    model = sub("sd_models").SdModel(sd, ucfg, None, device=0, load_vae=False, parameterization="v")
+    om = opipe.OracleModel(sd, ou.tiny_config(use_linear_in_transformer=True), None)
+    g = torch.Generator().manual_seed(12)
+    cond, uncond = torch.randn(2, 77, 64, generator=g), torch.randn(2, 77, 64, generator=g)
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond, uc=uncond, seed=500, batch_size=2, steps=steps,
+                                                    cfg_scale=5.0, width=128, height=128, sampler_name=name)
+    p.decode = False
+    sampler_obj = sub("sd_samplers").create_sampler(name, model)
+    p.rng = sub("rng").ImageRNG((4, 16, 16), [500, 501], device=dev)
+    p.seeds = [500, 501]
+    got = sampler_obj.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev))
+    lat = opipe.sample(om, cond, uncond, [500, 501], steps, sampler, 5.0, (16, 16), parameterization="v")
+    assert rel_l2(got.cpu(), lat) < 1e-2, sampler
+    eps_lat = opipe.sample(om, cond, uncond, [500, 501], steps, sampler, 5.0, (16, 16))
+    assert rel_l2(got.cpu(), eps_lat) > 5e-2                 # and it is not the eps-parameterised answer
+
+
 def test_txt2img_batch_split_matches(dev, tiny):
     """Sharding contract of the multi-GPU runner: images [0,4) generated as 4, as 2+2 (n_iter) or as the tail pair are the
     same images — per-image Philox streams (modules/rng.py:108) + per-image arithmetic everywhere.  Bitwise when the per-call
