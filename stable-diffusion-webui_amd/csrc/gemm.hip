@@ -550,14 +550,21 @@ __device__ __forceinline__ long long stamp() {           // s_memtime; callers s
     return t;
 }
 
-template <int BN, bool GEGLU, bool TIMING = false>
+template <int BM, int BN, bool GEGLU, bool TIMING = false>
 __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
-    constexpr int BM = 256, BK = 64, WC = 4, ROWB = 128;
-    constexpr int WTM = 128, WTN = BN / WC, TM = WTM / 16, TN = WTN / 16;
+    constexpr int BK = 64, WC = 4, ROWB = 128;
+    constexpr int WTM = BM / 2, WTN = BN / WC, TM = WTM / 16, TN = WTN / 16;
     constexpr int RP = 32, TMP = 2;                          // rows / MFMA row-tiles of the wave tile per phase
+    constexpr int PH = WTM / RP;                             // phases per K tile: 4 (BM = 256) or 2 (BM = 128, see below)
+    static_assert(PH == 4 || PH == 2, "BM must be 256 or 128");
     constexpr int BU = BN / 64;                              // 64-row pieces of the weight tile (one chunk per thread each)
     constexpr int NB0 = BU / 2, NB1 = BU - NB0;              // pieces in B half 0 / 1
-    constexpr int N1 = 4 + BU, N2 = 4 + BU + NB0;
+    constexpr int N1 = 4 + BU, N2 = 4 + BU + NB0;            // PH = 4 wait thresholds
+    // PH = 2 (128-row tiles): phase 0 reads B + A rows 0-31, phase 1 reads A rows 32-63.  Only two refill slots per tile:
+    //   L(1) of T : all of B and A rows 0-31 of tile T+2 (their slots were last read in L(0) of T)
+    //   L(0) of T+1: A rows 32-63 of tile T+2
+    // and one counted wait in each: at most N3 = BU + 2 younger loads outstanding (2 phases of flight time).
+    constexpr int N3 = BU + 2;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     static_assert(BN % 64 == 0 && WTN % 16 == 0 && N2 < 64, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -597,10 +604,10 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     // (the packed words live in LDS behind the tile buffers: they are needed once per segment, and VGPRs are the scarce
     // resource of the 256x320 instantiation — a compiler spill would put scratch loads, i.e. vmcnt traffic, in the loop)
     int* rinfo = reinterpret_cast<int*>(smem + 2 * STAGE) + tid;        // [q * 512]
-    const half_t* rptr[4];
+    const half_t* rptr[PH];
     const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < PH; ++q) {
         const int m = m0 + wr * WTM + q * RP + a_rin;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
@@ -644,8 +651,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         cb1 = k0 - tap1 * p.cin;
     }
 
-    // A units [q0, q0+2) of the K tile at (tap, cbase) into LDS buffer sb
-    auto issue_a = [&](int q0, int tap, int cbase, int sb, bool force) {
+    // A units [q0, q0+nq) of the K tile at (tap, cbase) into LDS buffer sb
+    auto issue_a = [&](int q0, int nq, int tap, int cbase, int sb, bool force) {
         char* base = smem + sb * STAGE + a_lds;
         const bool first = cbase < p.c0;
         const int seg0 = first ? 0 : p.c0;
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             int dy = 0, dx = 0;
             if (p.taps == 9) { dy = (tap * 11) >> 5; dx = tap - dy * 3; }
 #pragma unroll
-            for (int q = q0; q < q0 + 2; ++q) {
+            for (int q = q0; q < q0 + nq; ++q) {
                 bool ok;
                 int pix;
                 if (plain) {                              // 1x1, stride 1: the GEMM row IS the pixel index
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         }
         const int coff = cbase - seg0;                   // uniform channel offset inside the segment
 #pragma unroll
-        for (int q = q0; q < q0 + 2; ++q)
+        for (int q = q0; q < q0 + nq; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(rptr[q] + coff), (lptr_t)(base + q * RP * ROWB), 16, 0, 0);
     };
     // B pieces [i0, i0+n) of K tile kt (relative to k_first) into LDS buffer sb
@@ -703,18 +710,18 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         }
     };
 
-    // ---- prologue: all of tile 0; B and A rows 0-63 of tile 1 ------------------------------------------------------
+    // ---- prologue: all of tile 0; of tile 1 everything except the group the first L(0) issues -------------------------
     issue_b(0, NB0, 0, 0);
     issue_b(NB0, NB1, 0, 0);
-    issue_a(0, tap1, cb1, 0, true);
-    issue_a(2, tap1, cb1, 0, true);
+    issue_a(0, PH / 2, tap1, cb1, 0, true);
+    issue_a(PH / 2, PH / 2, tap1, cb1, 0, true);
     advance(tap1, cb1);                                  // (tap1, cb1) = tile 1
     tap2 = tap1; cb2 = cb1;
     if (nk > 1) {
         issue_b(0, NB0, 1, 1);
         issue_b(NB0, NB1, 1, 1);
-        issue_a(0, tap1, cb1, 1, true);
-        wait_vmcnt<N1>();
+        issue_a(0, PH / 2, tap1, cb1, 1, true);
+        wait_vmcnt<(PH == 4 ? N1 : N3)>();
     } else {
         wait_vmcnt<0>();
     }
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         const int cur = t & 1;
         const char* sbuf = smem + cur * STAGE;
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
+        for (int ph = 0; ph < PH; ++ph) {
             long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
             if (TIMING) t0 = stamp();
             // ================= L section: fragment reads of this phase, refill one group, counted waits =================
@@ -741,22 +748,39 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                 read_a(sbuf, ph);
             }
             if (!(TIMING && (p.flags & EP_DBG_NO_GLDS))) {
-            if (ph == 0) {
-                if (t + 1 < nk) issue_a(2, tap1, cb1, cur ^ 1, false);
-            } else if (ph == 1) {
-                if (t + 2 < nk) issue_b(0, NB0, t + 2, cur);
-            } else if (ph == 2) {
-                if (t + 2 < nk) issue_b(NB0, NB1, t + 2, cur);
-            } else {
-                if (t + 2 < nk) issue_a(0, tap2, cb2, cur, false);
-            }
+                if (PH == 4) {
+                    if (ph == 0) {
+                        if (t + 1 < nk) issue_a(2, 2, tap1, cb1, cur ^ 1, false);
+                    } else if (ph == 1) {
+                        if (t + 2 < nk) issue_b(0, NB0, t + 2, cur);
+                    } else if (ph == 2) {
+                        if (t + 2 < nk) issue_b(NB0, NB1, t + 2, cur);
+                    } else {
+                        if (t + 2 < nk) issue_a(0, 2, tap2, cb2, cur, false);
+                    }
+                } else {
+                    if (ph == 0) {
+                        if (t + 1 < nk) issue_a(1, 1, tap1, cb1, cur ^ 1, false);
+                    } else if (t + 2 < nk) {
+                        issue_b(0, BU, t + 2, cur);
+                        issue_a(0, 1, tap2, cb2, cur, false);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (TIMING && (p.flags & EP_DBG_NO_VMWAIT)) {
-            } else if (ph == 1) {
-                if (t + 2 < nk) wait_vmcnt<N2>(); else wait_vmcnt<0>();          // W2: A rows 64-127 of tile t
-            } else if (ph == 3) {
-                if (t + 2 < nk) wait_vmcnt<N1>(); else wait_vmcnt<0>();          // W1: B and A rows 0-63 of tile t+1
+            } else if (PH == 4) {
+                if (ph == 1) {
+                    if (t + 2 < nk) wait_vmcnt<N2>(); else wait_vmcnt<0>();      // W2: A rows 64-127 of tile t
+                } else if (ph == 3) {
+                    if (t + 2 < nk) wait_vmcnt<N1>(); else wait_vmcnt<0>();      // W1: B and A rows 0-63 of tile t+1
+                }
+            } else {
+                if (ph == 0) {
+                    if (t + 1 < nk) wait_vmcnt<N3>(); else wait_vmcnt<0>();      // A rows 32-63 of tile t
+                } else {
+                    if (t + 2 < nk) wait_vmcnt<N3>(); else wait_vmcnt<0>();      // B and A rows 0-31 of tile t+1
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this phase's fragments are in registers
             if (TIMING) t1 = stamp();
@@ -776,7 +800,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (TIMING) t3 = stamp();
-            if (!(ph == 3 && wr == 1 && t + 1 == nk) && !(TIMING && (p.flags & EP_DBG_NO_BAR_B))) {   // group 1's very last barrier would have no partner
+            if (!(ph == PH - 1 && wr == 1 && t + 1 == nk) && !(TIMING && (p.flags & EP_DBG_NO_BAR_B))) {   // group 1's very last barrier would have no partner
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
@@ -960,16 +984,16 @@ static int launch_pipe(const GemmP& p, int batch, hipStream_t s) {
     return launch_pipe2<BM, BN, WR, WC, NS, false>(p, batch, s);
 }
 
-template <int BN, bool GEGLU>
+template <int BM, int BN, bool GEGLU>
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
-    constexpr int SMEM = 2 * (256 + BN) * 128 + 8192;     // tile buffers + packed gather words
-    auto kern = gemm_mfma_pingpong_kernel<BN, GEGLU>;
+    constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
+    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    const int tiles = cdiv(p.M, 256) * (p.N / BN);
+    const int tiles = cdiv(p.M, BM) * (p.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(512), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
@@ -977,22 +1001,22 @@ static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
 unsigned long long g_gemm_dbg = 0;
 int g_gemm_dbgflags = 0;
 
-template <int BN>
+template <int BM, int BN>
 static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
     if (g_gemm_dbg && !(p.flags & EP_GEGLU)) {            // tuning: instrumented instantiation
         GemmP q = p;
         q.dbg = (long long*)g_gemm_dbg;
-        constexpr int SMEM = 2 * (256 + BN) * 128 + 8192;
-        auto kern = gemm_mfma_pingpong_kernel<BN, false, true>;
+        constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;
+        auto kern = gemm_mfma_pingpong_kernel<BM, BN, false, true>;
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        hipLaunchKernelGGL(kern, dim3(cdiv(q.M, 256) * (q.N / BN), q.splitk > 1 ? q.splitk : 1, batch), dim3(512), SMEM, s, q);
+        hipLaunchKernelGGL(kern, dim3(cdiv(q.M, BM) * (q.N / BN), q.splitk > 1 ? q.splitk : 1, batch), dim3(512), SMEM, s, q);
         SDMI_CHECK_HIP(hipGetLastError());
         return 0;
     }
     if constexpr ((BN / 4) % 64 == 0) {
-        if (p.flags & EP_GEGLU) return launch_pingpong2<BN, true>(p, batch, s);
+        if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true>(p, batch, s);
     }
-    return launch_pingpong2<BN, false>(p, batch, s);
+    return launch_pingpong2<BM, BN, false>(p, batch, s);
 }
 
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
@@ -1036,10 +1060,10 @@ static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f,
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
 int g_force_gemm_split = 0;
-// 3 (default): ping-pong kernel for the 256-row tiles (+5..13 % over the two-stage kernel on the big shapes, bit-identical
-// results), two-stage kernels elsewhere.  0: two-stage kernels only.  1: BK=32 ring kernels for the big tiles, 2: also
+// 4 (default): ping-pong kernel for the 256-row tiles and the 128x320 tile (+5..22 % over the two-stage kernel per shape,
+// bit-identical results), two-stage kernels elsewhere.  3: ping-pong for the 256-row tiles only.  0: two-stage kernels only.  1: BK=32 ring kernels for the big tiles, 2: also
 // 128x128 — kept selectable; measured 7-25 % SLOWER than the two-stage kernels (profiles/r01_microbench_pipe.txt).
-int g_gemm_pipe_default = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 3; }();
+int g_gemm_pipe_default = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 4; }();
 int g_gemm_pipe = g_gemm_pipe_default;
 
 static bool cfg_valid(int cfg, const GemmP& p) {
@@ -1068,6 +1092,9 @@ static float cfg_score(const GemmP& p, int batch, int cfg, int split) {
     // short K loops are dominated by prologue / epilogue: favour the higher-occupancy 4-wave tiles there
     const int ksteps = p.K / 64 / split;
     if (ksteps < 8 && kCfgOcc[cfg] == 1) score *= 0.9f;
+    // K = 320 / 384 projections over many tokens: two half-height tiles per CU overlap one tile's store tail with the next
+    // tile's loads (tools/geglu_sweep.py: 128x320 381 / 419 TFLOP/s vs 256x320 362 / 383 on the 320->320 / 320->640 layers)
+    if (ksteps <= 6 && cfg == CFG_256x320) score *= 0.93f;
     if (split > 1) {
         const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
         const double t_mma = flops / (1.0e15 * (score > 0.05f ? score : 0.05f));
@@ -1132,12 +1159,13 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW)) && p.N % 4 == 0;
     const int cfg = pick_cfg(p, batch, &split, can_split);
     // ping-pong kernel: every weight row must exist (no n_valid masking) and a (tap, source) segment must fit the zero page
-    const bool phase = use_glds && g_gemm_pipe == 3 && (cfg == CFG_256x320 || cfg == CFG_256x256) && p.n_valid == p.N &&
+    const bool phase = use_glds && (g_gemm_pipe == 3 || g_gemm_pipe == 4) &&
+                       (cfg == CFG_256x320 || cfg == CFG_256x256 || (cfg == CFG_128x320 && g_gemm_pipe == 4)) && p.n_valid == p.N &&
                        p.cin + 64 <= kZeroPageHalfs &&
                        ((p.taps == 1 && p.stride == 1 && !p.up && p.Ho == p.Hi && p.Wo == p.Wi) ||
                         (p.M / p.rows_per_batch < 128 && (p.up ? 2 : 1) * p.Hi < 2040 && (p.up ? 2 : 1) * p.Wi < 2040 &&
                          p.stride * p.Ho < 2040 && p.stride * p.Wo < 2040));
-    const bool pipe = !phase && use_glds && g_gemm_pipe != 0 && g_gemm_pipe != 3 && (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_128x320 ||
+    const bool pipe = !phase && use_glds && g_gemm_pipe != 0 && g_gemm_pipe < 3 && (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_128x320 ||
                                                                  (g_gemm_pipe > 1 && cfg == CFG_128x128));
     if (split > 1) {
         const int nk = p.K / ((cfg == CFG_128x128_K32 || pipe) ? 32 : 64);
@@ -1172,8 +1200,9 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     if (phase) {
         int rc = 1;
         switch (cfg) {
-            case CFG_256x320: rc = launch_pingpong<320>(p, batch, s); break;
-            case CFG_256x256: rc = launch_pingpong<256>(p, batch, s); break;
+            case CFG_256x320: rc = launch_pingpong<256, 320>(p, batch, s); break;
+            case CFG_256x256: rc = launch_pingpong<256, 256>(p, batch, s); break;
+            case CFG_128x320: rc = launch_pingpong<128, 320>(p, batch, s); break;
             default: break;
         }
         if (rc) return 1;

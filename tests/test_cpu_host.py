@@ -275,7 +275,8 @@ def test_weight_broadcast_and_gather_world_size_2_gloo(tmp_path):
 
 
 def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):
-    """The ping-pong GEMM's pipelining rests on COUNTED `s_waitcnt vmcnt(N)` (N1 = 4 + BN/64, N2 = N1 + BN/128) and raw
+    """The ping-pong GEMM's pipelining rests on COUNTED `s_waitcnt vmcnt(N)` (256-row tiles: N1 = 4 + BN/64, N2 = N1 + BN/128;
+    128-row tile: N3 = BN/64 + 2) and raw
     s_barrier / s_setprio in its K loop; a compiler that folded them into vmcnt(0) would silently serialise the loads.
     Cross-compile the kernel to gfx950 assembly and check the loop body."""
     import re
@@ -288,15 +289,16 @@ def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     text = out.read_text()
-    for bn, n1, n2 in ((256, 8, 10), (320, 9, 11)):
-        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELb0ELb0EEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % bn, text, re.S | re.M)
-        assert m, f"ping-pong kernel <{bn}> not found in the assembly"
+    for bm, bn, waits, phases in ((256, 256, (8, 10), 4), (256, 320, (9, 11), 4), (128, 320, (7,), 2)):
+        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELi%dELb0ELb0EEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn), text, re.S | re.M)
+        assert m, f"ping-pong kernel <{bm},{bn}> not found in the assembly"
         body = m.group(1)
         first, last = body.index("s_setprio 1"), body.rindex("s_setprio 0")
         loop = body[first:last]
-        assert loop.count("s_setprio 1") == 4 and loop.count("v_mfma_f32_16x16x32_f16") == 4 * 4 * (bn // 64)
-        assert f"s_waitcnt vmcnt({n1})" in loop and f"s_waitcnt vmcnt({n2})" in loop
-        assert loop.count("s_barrier") == 6          # 3 x (barrier b, barrier a) between the first and last MFMA sections
+        assert loop.count("s_setprio 1") == phases and loop.count("v_mfma_f32_16x16x32_f16") == phases * 4 * (bn // 64)
+        for n in waits:
+            assert f"s_waitcnt vmcnt({n})" in loop, (bm, bn, n)
+        assert loop.count("s_barrier") == 2 * (phases - 1)   # (barrier b, barrier a) pairs between the first and last MFMA sections
         assert "scratch_" not in loop, "register spill inside the K loop (scratch traffic would disturb the vmcnt accounting)"
 
 

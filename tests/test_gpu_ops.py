@@ -188,6 +188,10 @@ PHASE_CASES = [
     (8, 1, 10, 10, 64, 0, 640, 1, 1, False, 0),        # 128x320, single K tile, ragged M
     (5, 2, 8, 8, 1280, 0, 1280, 9, 1, False, 4),       # split-K slices (each slice runs its own prologue / tail)
     (8, 2, 8, 8, 1280, 0, 1280, 9, 1, False, 3),
+    (8, 2, 16, 16, 128, 0, 320, 1, 1, False, 0),       # 128x320: K = 128 (two K tiles)
+    (8, 1, 12, 12, 128, 64, 640, 9, 1, False, 0),      # 128x320: two sources
+    (8, 2, 17, 15, 128, 0, 320, 9, 2, False, 0),       # 128x320: stride 2
+    (8, 1, 12, 12, 128, 0, 320, 9, 1, True, 0),        # 128x320: upsample
 ]
 
 
@@ -214,9 +218,10 @@ def test_pingpong_gemm_is_bit_identical_to_two_stage_kernel(dev, case):
     outs = {}
     try:
         lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
-        for pipe in (0, 3, 3, 3):
+        pp = 4 if cfg == 8 else 3                          # 4 also routes the 128x320 tile to the ping-pong kernel
+        for pipe in (0, pp, pp, pp):
             lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", pipe))
-            outs.setdefault(pipe, []).append(ops.conv_gemm(x0.half().to(dev), wp, **args))
+            outs.setdefault(3 if pipe else 0, []).append(ops.conv_gemm(x0.half().to(dev), wp, **args))
     finally:
         lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
         lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1))

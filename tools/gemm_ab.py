@@ -24,6 +24,10 @@ SHAPES = [
     ("linear ff2 1280->320 tok65536", dict(B=16, H=64, W=64, cin=1280, cout=320, taps=1), 5),
     ("linear 320->320 tok65536", dict(B=16, H=64, W=64, cin=320, cout=320, taps=1), 5),
     ("gemm 8192^3", dict(B=1, H=8192, W=1, cin=8192, cout=8192, taps=1), 4),
+    ("conv3x3 640->640 @32^2 B16", dict(B=16, H=32, W=32, cin=640, cout=640, taps=9), 8),
+    ("conv3x3 1280->1280 @16^2 B16", dict(B=16, H=16, W=16, cin=1280, cout=1280, taps=9), 8),
+    ("linear 640->640 tok16384", dict(B=16, H=32, W=32, cin=640, cout=640, taps=1), 8),
+    ("linear ff2 2560->640 tok16384", dict(B=16, H=32, W=32, cin=2560, cout=640, taps=1), 8),
 ]
 
 
@@ -43,7 +47,8 @@ def main():
         wp = ops.pack_conv_weight(w)
         flops = 2.0 * kw["B"] * kw["H"] * kw["W"] * kw["cout"] * kw["cin"] * k * k
         lib.check(L.sdmi_debug_set(b"gemm_cfg", cfg))
-        arms = [(0, 0), (3, 0)] + [(3, int(f, 16)) for f in os.environ.get("AB_FLAGS", "").split(",") if f]
+        pp = 4 if cfg == 8 else 3
+        arms = [(0, 0), (pp, 0)] + [(pp, int(f, 16)) for f in os.environ.get("AB_FLAGS", "").split(",") if f]
         res = {a: [] for a in arms}
         for rnd in range(3):
             for arm in arms:
@@ -61,7 +66,7 @@ def main():
         lib.check(L.sdmi_debug_set(b"gemm_pipe", -1)); lib.check(L.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(L.sdmi_debug_set(b"gemm_dbgflags", 0))
         fmt = lambda v: "/".join(f"{t:5.0f}" for t in v)
         extra = "".join(f" | pp flags {a[1]:#x} {fmt(res[a])}" for a in arms[2:])
-        print(f"{name:34s} cfg{cfg} | two-stage {fmt(res[(0, 0)])} | ping-pong {fmt(res[(3, 0)])}{extra} TF", flush=True)
+        print(f"{name:34s} cfg{cfg} | two-stage {fmt(res[(0, 0)])} | ping-pong {fmt(res[(pp, 0)])}{extra} TF", flush=True)
 
 
 if __name__ == "__main__":
