@@ -1092,9 +1092,8 @@ static float cfg_score(const GemmP& p, int batch, int cfg, int split) {
     // short K loops are dominated by prologue / epilogue: favour the higher-occupancy 4-wave tiles there
     const int ksteps = p.K / 64 / split;
     if (ksteps < 8 && kCfgOcc[cfg] == 1) score *= 0.9f;
-    // K = 320 / 384 projections over many tokens: two half-height tiles per CU overlap one tile's store tail with the next
-    // tile's loads (tools/geglu_sweep.py: 128x320 381 / 419 TFLOP/s vs 256x320 362 / 383 on the 320->320 / 320->640 layers)
-    if (ksteps <= 6 && cfg == CFG_256x320) score *= 0.93f;
+    // (Tried: preferring 128x320 over 256x320 for the K <= 384 projections — +13 % in the isolated sweep of
+    // tools/geglu_sweep.py, but -1.5 % on the whole job in a same-box A/B: in the engine the inputs are cache-resident.)
     if (split > 1) {
         const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
         const double t_mma = flops / (1.0e15 * (score > 0.05f ? score : 0.05f));
