@@ -135,6 +135,7 @@ int launch_latent_resize(const float* in, float* out, int planes, int hi, int wi
 int launch_cfg_combine_affine(const float* x, const float* out, const float* c_out, const float* c_skip, float cond_scale,
                               const float* mask, const float* nmask, const float* init_latent, float* den, int B, int64_t chw,
                               hipStream_t s);
+int launch_silu_f32(const float* x, float* y, int64_t n, hipStream_t s);
 int launch_mask_blend(float* x, const float* init, const float* mask, const float* nmask, int64_t n, hipStream_t s);
 int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
 

@@ -542,6 +542,19 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* a, const
         }
     }
 }
+// y = silu(x) elementwise fp32 (same expression as small_linear's silu_in, so hoisting it out changes no bits)
+__global__ __launch_bounds__(256) void silu_f32_kernel(const float* x, float* y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float av = x[i];
+        y[i] = av / (1.0f + expf(-av));
+    }
+}
+int launch_silu_f32(const float* x, float* y, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_small_linear(const float* a, const half_t* w, const float* bias, const float* add, float* out, int B, int N, int K,
                         int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s) {
     SDMI_REQUIRE(K % 8 == 0 && lda % 4 == 0, "small_linear: K % 8 == 0, lda % 4 == 0");

@@ -599,6 +599,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     float* e1 = r.F((size_t)Bn * ted);
     float* emb = r.F((size_t)Bn * ted);
     float* embs = r.F((size_t)Bn * u.emb_cols);
+    float* emb_act = r.F((size_t)Bn * ted);              // silu(emb), computed once instead of once per output column
     float* yf = c.adm_in_channels > 0 ? r.F((size_t)Bn * c.adm_in_channels) : nullptr;
     float* l1 = c.adm_in_channels > 0 ? r.F((size_t)Bn * ted) : nullptr;
     if (!r.dry) {
@@ -613,8 +614,9 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
             TRY(launch_small_linear(l1, u.le2.w, u.le2.b, emb, emb, Bn, ted, ted, ted, ted, false, false, r.s));
         }
         // every ResBlock's emb_layers (SiLU -> Linear) in one launch
-        TRY(launch_small_linear(emb, u.emb_all.w, u.emb_all.b, nullptr, embs, Bn, u.emb_cols, ted, ted, u.emb_cols,
-                                true, false, r.s));
+        TRY(launch_silu_f32(emb, emb_act, (int64_t)Bn * ted, r.s));
+        TRY(launch_small_linear(emb_act, u.emb_all.w, u.emb_all.b, nullptr, embs, Bn, u.emb_cols, ted, ted, u.emb_cols,
+                                false, false, r.s));
     }
     // ---- input: NCHW -> NHWC fp16, channels zero-padded to the packed conv_in width ----------------------------
     const ConvW& cin_w = u.input[0][0].conv;
