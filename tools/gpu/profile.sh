@@ -5,6 +5,7 @@ REPO=$(pwd)
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q -n 1 --max-worker-restart 4 -p no:cacheprovider --tb=short > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; tail -2 gpurun_out/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1
 echo "bench rc=$?" >> gpurun_out/bench.log; tail -2 gpurun_out/bench.log | cut -c1-1500
 cd /tmp
