@@ -296,7 +296,7 @@ int sdmi_clip_configure(sdmi_engine* e, int slot, const sdmi_clip_config* cfg);
 /* keys as in transformers' CLIPTextModel state dict below "text_model.": "embeddings.token_embedding.weight",
  * "embeddings.position_embedding.weight", "encoder.layers.<i>.{layer_norm1,layer_norm2}.{weight,bias}",
  * "encoder.layers.<i>.self_attn.{q_proj,k_proj,v_proj,out_proj}.{weight,bias}", "encoder.layers.<i>.mlp.{fc1,fc2}.{weight,bias}",
- * "final_layer_norm.{weight,bias}". */
+ * "final_layer_norm.{weight,bias}", and optionally "text_projection.weight" [proj_dim, hidden] (nn.Linear layout). */
 int sdmi_clip_load_tensor(sdmi_engine* e, int slot, const char* key, const void* data, int dtype, int ndim,
                           const int64_t* shape, int on_device);
 int sdmi_clip_finalize(sdmi_engine* e, int slot);
@@ -304,8 +304,10 @@ int sdmi_clip_finalize(sdmi_engine* e, int slot);
  * the caller: textual inversion, modules/sd_hijack.py EmbeddingsWithFixes).  Runs the first `layers - skip + 1` blocks
  * (skip = opts.CLIP_stop_at_last_layers >= 1: hidden_states[-skip]) and, if apply_final_ln, final_layer_norm — which is
  * last_hidden_state for skip = 1 and the clip-skip branch of sd_hijack_clip.py:354-356 otherwise; SDXL's CLIP-L takes
- * hidden_states[-2] without the norm (sd_hijack_clip.py:369-377).  out fp32 [B, L, hidden]; pooled fp32 [B, hidden] or NULL
- * = the output row at the EOS (largest id) position. */
+ * hidden_states[-2] without the norm (sd_hijack_clip.py:369-377).  out fp32 [B, L, hidden]; pooled fp32 [B, proj_dim or
+ * hidden] or NULL = final_layer_norm(last block)'s row at the EOS (largest id) position, times text_projection when loaded
+ * (transformers pooler_output / text_embeds; open_clip `pool(ln_final(x)) @ text_projection`, the SDXL "pooled" vector read
+ * at modules/sd_hijack_open_clip.py:60-66) — always taken after the LAST block, whatever `skip` is. */
 int sdmi_clip_forward(sdmi_engine* e, int slot, const void* tokens_i32, const void* inputs_embeds_f32_or_null, int B, int L,
                       int skip, int apply_final_ln, void* out_f32, void* pooled_f32_or_null, void* stream);
 

@@ -26,6 +26,7 @@ class ClipConfig:
     intermediate: int = 3072
     act: str = "quick_gelu"
     eps: float = 1e-5
+    proj_dim: int = None
 
 
 def quick_gelu(x):
@@ -102,6 +103,7 @@ class ClipTextModel(nn.Module):
         self.embeddings = ClipEmbeddings(cfg)
         self.encoder = ClipEncoder(cfg)
         self.final_layer_norm = nn.LayerNorm(cfg.hidden, eps=cfg.eps)
+        self.text_projection = nn.Linear(cfg.hidden, cfg.proj_dim, bias=False) if cfg.proj_dim else None
 
     def hidden_states(self, tokens, inputs_embeds=None):
         x = self.embeddings(tokens, inputs_embeds)
@@ -117,11 +119,17 @@ class ClipTextModel(nn.Module):
     def forward(self, tokens, skip: int = 1, apply_final_ln: bool = True, inputs_embeds=None, return_pooled: bool = False):
         """= encode_with_transformers with opts.CLIP_stop_at_last_layers = skip (sd_hijack_clip.py:351-360); pooled = the row
         at the EOS (argmax id) position, as transformers' pooler_output / other_impls.py:146."""
-        z = self.hidden_states(tokens, inputs_embeds)[-skip]
+        hs = self.hidden_states(tokens, inputs_embeds)
+        z = hs[-skip]
         if apply_final_ln:
             z = self.final_layer_norm(z)
         if return_pooled:
-            return z, z[torch.arange(z.shape[0]), tokens.to(torch.int).argmax(dim=-1)]
+            # always from the LAST block + final norm (transformers pooler_output; open_clip pool(ln_final(x)) @ text_projection)
+            last = self.final_layer_norm(hs[-1])
+            pooled = last[torch.arange(last.shape[0]), tokens.to(torch.int).argmax(dim=-1)]
+            if self.text_projection is not None:
+                pooled = self.text_projection(pooled)
+            return z, pooled
         return z
 
 

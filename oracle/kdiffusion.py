@@ -414,6 +414,72 @@ def sample_plms(model, x, timesteps, alphas_cumprod, extra_args, callback=None):
     return x
 
 
+def restart_sampler(model, x, sigmas, extra_args, noise_fn, callback=None, s_noise=1.0, restart_list=None):
+    """modules/sd_samplers_extra.py:6-74 (in-repo; pinned by tests/golden/restart.npz): Heun steps over a Karras schedule with
+    "restart" segments that re-noise from sigma ~0.1 back up to sigma ~2."""
+    s_in = x.new_ones([x.shape[0]])
+    step_id = 0
+
+    def heun_step(x, old_sigma, new_sigma, second_order=True):
+        nonlocal step_id
+        denoised = model(x, old_sigma * s_in, **extra_args)
+        d = to_d(x, old_sigma, denoised)
+        if callback is not None:
+            callback({'x': x, 'i': step_id, 'sigma': new_sigma, 'sigma_hat': old_sigma, 'denoised': denoised})
+        dt = new_sigma - old_sigma
+        if new_sigma == 0 or not second_order:
+            x = x + d * dt
+        else:
+            x_2 = x + d * dt
+            denoised_2 = model(x_2, new_sigma * s_in, **extra_args)
+            d_2 = to_d(x_2, new_sigma, denoised_2)
+            d_prime = (d + d_2) / 2
+            x = x + d_prime * dt
+        step_id += 1
+        return x
+
+    step_list = restart_step_list(sigmas, restart_list)
+    last_sigma = None
+    for old_sigma, new_sigma in step_list:
+        if last_sigma is None:
+            last_sigma = old_sigma
+        elif last_sigma < old_sigma:
+            x = x + noise_fn() * s_noise * (old_sigma ** 2 - last_sigma ** 2) ** 0.5
+        x = heun_step(x, old_sigma, new_sigma)
+        last_sigma = new_sigma
+    return x
+
+
+def restart_step_list(sigmas, restart_list=None):
+    """The (old_sigma, new_sigma) sequence of modules/sd_samplers_extra.py:38-62."""
+    steps = sigmas.shape[0] - 1
+    if restart_list is None:
+        if steps >= 20:
+            restart_steps = 9
+            restart_times = 1
+            if steps >= 36:
+                restart_steps = steps // 4
+                restart_times = 2
+            sigmas = get_sigmas_karras(steps - restart_steps * restart_times, sigmas[-2].item(), sigmas[0].item())
+            restart_list = {0.1: [restart_steps + 1, restart_times, 2]}
+        else:
+            restart_list = {}
+    restart_list = {int(torch.argmin(abs(sigmas - key), dim=0)): value for key, value in restart_list.items()}
+    step_list = []
+    for i in range(len(sigmas) - 1):
+        step_list.append((sigmas[i], sigmas[i + 1]))
+        if i + 1 in restart_list:
+            restart_steps, restart_times, restart_max = restart_list[i + 1]
+            min_idx = i + 1
+            max_idx = int(torch.argmin(abs(sigmas - restart_max), dim=0))
+            if max_idx < min_idx:
+                sigma_restart = get_sigmas_karras(restart_steps, sigmas[min_idx].item(), sigmas[max_idx].item())[:-1]
+                while restart_times > 0:
+                    restart_times -= 1
+                    step_list.extend(zip(sigma_restart[:-1], sigma_restart[1:]))
+    return step_list
+
+
 def ddim_timesteps(steps: int) -> torch.Tensor:
     """modules/sd_samplers_timesteps.py:94"""
     return torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)

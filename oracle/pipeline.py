@@ -32,6 +32,7 @@ class OracleModel:
 SAMPLER_OPTIONS = {
     "euler_a": (None, False), "euler": (None, False), "lms": (None, False), "heun": (None, False),
     "dpmpp_2m": ("karras", False), "dpmpp_2s_a": ("karras", False), "dpm_2": ("karras", True), "dpm_2_a": ("karras", True),
+    "restart": ("karras", False),
 }
 
 
@@ -116,6 +117,8 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         return finish(kd.sample_dpm_2_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
     if sampler == "dpmpp_2s_a":
         return finish(kd.sample_dpmpp_2s_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
+    if sampler == "restart":
+        return finish(kd.restart_sampler(cfg, x, sigmas, extra, rng.next, callback=record, s_noise=s_noise))
     fn = {"euler": kd.sample_euler, "dpmpp_2m": kd.sample_dpmpp_2m, "heun": kd.sample_heun, "dpm_2": kd.sample_dpm_2,
           "lms": kd.sample_lms}.get(sampler)
     if fn is None:

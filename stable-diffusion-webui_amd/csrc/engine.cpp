@@ -1042,6 +1042,15 @@ static int clip_build(sdmi_engine* e, int slot) {
         c.layers.push_back(L);
     }
     TRY(pack_norm(e, m, "final_layer_norm", &c.final_ln));
+    // optional pooled-output projection, given in nn.Linear layout [proj_dim][hidden] (transformers' text_projection.weight;
+    // open_clip stores the transpose, the host converts): kept as plain fp16 rows for the small-M linear kernel
+    c.text_proj = nullptr; c.proj_dim = 0;
+    if (const RawTensor* tp = find_raw(m, "text_projection.weight")) {
+        SDMI_REQUIRE(tp->shape.size() == 2 && tp->shape[1] == cfg.hidden && tp->shape[1] % 8 == 0, "text_projection must be [proj][hidden]");
+        ConvW tmp;
+        TRY(pack_one(e, m, "text_projection", false, false, &tmp));
+        c.text_proj = tmp.w; c.proj_dim = (int)tp->shape[0];
+    }
     SDMI_CHECK_HIP(hipDeviceSynchronize());
     c.ready = true;
     return 0;
@@ -1056,8 +1065,13 @@ static int clip_run(Run& r, const ClipW& c, const int* tokens, const float* inpu
     r.e->arena.reset();
     half_t* cur = r.H(M * C);
     if (!r.dry) TRY(launch_clip_embed(tokens, c.tok_emb, c.tok_dtype, c.pos_emb, inputs_embeds, cur, B, L, C, cfg.vocab_size, r.s));
-    const int nrun = cfg.layers - skip + 1;
+    // `out` taps the residual stream after block layers-skip+1; the pooled row always comes from the LAST block + final norm
+    // (transformers' pooler_output; open_clip's pool(ln_final(x)) @ text_projection), so run on when it is requested
+    const int ntap = cfg.layers - skip + 1;
+    const int nrun = pooled ? cfg.layers : ntap;
+    half_t* tap = nullptr;
     for (int i = 0; i < nrun; ++i) {
+        if (i == ntap) tap = cur;
         const ClipLayerW& w = c.layers[i];
         half_t* n1 = r.H(M * C);
         if (!r.dry) TRY(launch_layernorm(cur, w.ln1.g, w.ln1.b, n1, (int64_t)M, C, cfg.eps, r.s));
@@ -1092,14 +1106,29 @@ static int clip_run(Run& r, const ClipW& c, const int* tokens, const float* inpu
         TRY(run_linear(r, w.fc2, hmid, (int)M, x1, x2, C));
         cur = x2;
     }
-    half_t* fin = cur;
+    if (tap == nullptr) tap = cur;                           // ntap == nrun
+    half_t* fin = tap;
     if (apply_final_ln) {
         fin = r.H(M * C);
-        if (!r.dry) TRY(launch_layernorm(cur, c.final_ln.g, c.final_ln.b, fin, (int64_t)M, C, cfg.eps, r.s));
+        if (!r.dry) TRY(launch_layernorm(tap, c.final_ln.g, c.final_ln.b, fin, (int64_t)M, C, cfg.eps, r.s));
+    }
+    half_t* last_ln = nullptr;
+    float* pool_raw = nullptr;
+    if (pooled) {
+        last_ln = (apply_final_ln && tap == cur) ? fin : r.H(M * C);
+        if (c.text_proj) pool_raw = r.F((size_t)B * C);
     }
     if (r.dry) return 0;
     TRY(launch_convert_to_f32(fin, SDMI_F16, out, (int64_t)M * C, r.s));
-    if (pooled) TRY(launch_clip_pool(tokens, fin, pooled, B, L, C, r.s));
+    if (pooled) {
+        if (last_ln != fin) TRY(launch_layernorm(cur, c.final_ln.g, c.final_ln.b, last_ln, (int64_t)M, C, cfg.eps, r.s));
+        if (c.text_proj) {
+            TRY(launch_clip_pool(tokens, last_ln, pool_raw, B, L, C, r.s));
+            TRY(launch_small_linear(pool_raw, c.text_proj, nullptr, nullptr, pooled, B, c.proj_dim, C, C, c.proj_dim, false, false, r.s));
+        } else {
+            TRY(launch_clip_pool(tokens, last_ln, pooled, B, L, C, r.s));
+        }
+    }
     return 0;
 }
 

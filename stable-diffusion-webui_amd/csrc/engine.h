@@ -93,6 +93,8 @@ struct ClipW {
     float* pos_emb = nullptr;     // [max_positions][hidden] fp32
     std::vector<ClipLayerW> layers;
     NormW final_ln;
+    half_t* text_proj = nullptr;  // optional [proj_dim][hidden] fp16 (rows = output features): pooled @ text_projection
+    int proj_dim = 0;
     bool configured = false, ready = false;
 };
 

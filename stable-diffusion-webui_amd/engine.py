@@ -141,7 +141,8 @@ class Engine:
             emb = inputs_embeds.to(dev, torch.float32).contiguous()
             assert emb.shape == (b, l, hidden)
         out = torch.empty((b, l, hidden), dtype=torch.float32, device=dev)
-        pooled = torch.empty((b, hidden), dtype=torch.float32, device=dev) if return_pooled else None
+        pdim = self.clip_cfg[slot].proj_dim or hidden
+        pooled = torch.empty((b, pdim), dtype=torch.float32, device=dev) if return_pooled else None
         check(lib.sdmi_clip_forward(self.handle, slot, ptr(tok), ptr(emb), b, l, int(skip), 1 if apply_final_ln else 0, ptr(out),
                                     ptr(pooled), stream_ptr()), "clip_forward")
         return (out, pooled) if return_pooled else out

@@ -65,8 +65,9 @@ class ClipConfig:
     layers: int = 12
     heads: int = 12
     intermediate: int = 3072
-    act: str = "quick_gelu"          # "quick_gelu" (OpenAI CLIP) | "gelu" (OpenCLIP bigG)
+    act: str = "quick_gelu"          # "quick_gelu" (OpenAI CLIP) | "gelu" (OpenCLIP)
     eps: float = 1e-5
+    proj_dim: Optional[int] = None   # text_projection output width (pooled vector), None = no projection
 
 
 CLIP_PREFIX = "cond_stage_model.transformer.text_model."     # where an SD1.x checkpoint keeps the text encoder
@@ -74,6 +75,45 @@ CLIP_PREFIX = "cond_stage_model.transformer.text_model."     # where an SD1.x ch
 
 def sd15_clip() -> ClipConfig:
     return ClipConfig()
+
+
+def openclip_h() -> ClipConfig:
+    """OpenCLIP ViT-H/14 text tower (SD 2.x cond_stage_model, configs/v2-inference*.yaml: FrozenOpenCLIPEmbedder, penultimate)."""
+    return ClipConfig(hidden=1024, layers=24, heads=16, intermediate=4096, act="gelu")
+
+
+def openclip_bigg() -> ClipConfig:
+    """OpenCLIP ViT-bigG/14 text tower (SDXL conditioner.embedders.1, FrozenOpenCLIPEmbedder2: penultimate + pooled)."""
+    return ClipConfig(hidden=1280, layers=32, heads=20, intermediate=5120, act="gelu", proj_dim=1280)
+
+
+def openclip_to_transformers_keys(sd: dict, prefix: str, out_prefix: str = CLIP_PREFIX) -> dict:
+    """open_clip text-tower state dict (keys below ``prefix``, e.g. "cond_stage_model.model." for SD 2.x or
+    "conditioner.embedders.1.model." for SDXL) -> the transformers CLIPTextModel layout the engine loads:
+    nn.MultiheadAttention's packed in_proj_{weight,bias} [3C, ...] split into q / k / v, ln_1 / ln_2 / c_fc / c_proj renamed,
+    positional_embedding -> position_embedding.weight, text_projection [C, P] (used as x @ W) -> nn.Linear weight [P, C]."""
+    out = {}
+    g = lambda k: sd[prefix + k]
+    out[out_prefix + "embeddings.token_embedding.weight"] = g("token_embedding.weight")
+    out[out_prefix + "embeddings.position_embedding.weight"] = g("positional_embedding")
+    i = 0
+    while prefix + f"transformer.resblocks.{i}.ln_1.weight" in sd:
+        src, dst = f"transformer.resblocks.{i}.", out_prefix + f"encoder.layers.{i}."
+        w, b = g(src + "attn.in_proj_weight"), g(src + "attn.in_proj_bias")
+        c = w.shape[1]
+        for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            out[dst + f"self_attn.{n}.weight"] = w[j * c:(j + 1) * c].contiguous()
+            out[dst + f"self_attn.{n}.bias"] = b[j * c:(j + 1) * c].contiguous()
+        for a, bname in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                         ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            out[dst + bname + ".weight"] = g(src + a + ".weight")
+            out[dst + bname + ".bias"] = g(src + a + ".bias")
+        i += 1
+    out[out_prefix + "final_layer_norm.weight"] = g("ln_final.weight")
+    out[out_prefix + "final_layer_norm.bias"] = g("ln_final.bias")
+    if prefix + "text_projection" in sd:
+        out[out_prefix + "text_projection.weight"] = g("text_projection").t().contiguous()
+    return out
 
 
 def tiny_clip(**kw) -> ClipConfig:
@@ -96,6 +136,8 @@ def clip_schema(cfg: ClipConfig):
                 (b + "mlp.fc2.weight", (C, I), "w"), (b + "mlp.fc2.bias", (C,), "b"),
                 (b + "layer_norm2.weight", (C,), "g"), (b + "layer_norm2.bias", (C,), "b")]
     out += [("final_layer_norm.weight", (C,), "g"), ("final_layer_norm.bias", (C,), "b")]
+    if cfg.proj_dim:
+        out += [("text_projection.weight", (cfg.proj_dim, C), "w")]
     return out
 
 

@@ -41,3 +41,16 @@ class Mi355xClipTextEncoder:
         # hidden_states[layer_idx]: index 0 = embeddings ... layers = after the last block; -k = after block layers-k+1
         idx = self.layer_idx if self.layer_idx < 0 else self.layer_idx - (self.cfg.layers + 1)
         return self.engine.clip_forward(tokens, skip=-idx, apply_final_ln=False, inputs_embeds=inputs_embeds, slot=self.slot)
+
+    def encode_with_transformer_openclip(self, tokens: torch.Tensor, inputs_embeds: Optional[torch.Tensor] = None):
+        """SD 2.x: ldm FrozenOpenCLIPEmbedder.encode_with_transformer with layer="penultimate" (called from
+        modules/sd_hijack_open_clip.py:26-30): the last block is skipped, ln_final applied."""
+        return self.engine.clip_forward(tokens, skip=2, apply_final_ln=True, inputs_embeds=inputs_embeds, slot=self.slot)
+
+    def encode_with_transformer_openclip2(self, tokens: torch.Tensor, inputs_embeds: Optional[torch.Tensor] = None):
+        """SDXL: sgm FrozenOpenCLIPEmbedder2 (legacy=False) as consumed at modules/sd_hijack_open_clip.py:57-66: z = the
+        penultimate hidden state WITHOUT ln_final, z.pooled = ln_final(last)[EOS] @ text_projection."""
+        z, pooled = self.engine.clip_forward(tokens, skip=2, apply_final_ln=False, inputs_embeds=inputs_embeds, slot=self.slot,
+                                             return_pooled=True)
+        z.pooled = pooled
+        return z

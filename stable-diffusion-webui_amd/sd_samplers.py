@@ -468,6 +468,67 @@ def sample_dpmpp_2s_ancestral(model, x, sigmas, extra_args=None, callback=None, 
     return x
 
 
+def restart_sampler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_noise=1., restart_list=None, noise_sampler=None):
+    """modules/sd_samplers_extra.py:6-74: Heun steps over a Karras schedule with restart segments (re-noise from sigma ~0.1 up
+    to sigma ~2); schedule construction verbatim on the host, tensor updates on the device."""
+    extra_args = {} if extra_args is None else extra_args
+    x = x.contiguous()
+    s_in = x.new_ones([x.shape[0]])
+    step_id = 0
+
+    def heun_step(x, old_sigma, new_sigma, second_order=True):
+        nonlocal step_id
+        denoised = model(x, old_sigma * s_in, **extra_args)
+        d = _to_d(x, old_sigma, denoised)
+        if callback is not None:
+            callback({'x': x, 'i': step_id, 'sigma': new_sigma, 'sigma_hat': old_sigma, 'denoised': denoised})
+        dt = float(new_sigma - old_sigma)
+        if new_sigma == 0 or not second_order:
+            x = _lc(torch.empty_like(x), [x, d], [1.0, dt])
+        else:
+            x_2 = _lc(torch.empty_like(x), [x, d], [1.0, dt])
+            denoised_2 = model(x_2, new_sigma * s_in, **extra_args)
+            d_2 = _to_d(x_2, new_sigma, denoised_2)
+            x = _lc(torch.empty_like(x), [x, d, d_2], [1.0, 0.5 * dt, 0.5 * dt])
+        step_id += 1
+        return x
+
+    steps = sigmas.shape[0] - 1
+    if restart_list is None:
+        if steps >= 20:
+            restart_steps = 9
+            restart_times = 1
+            if steps >= 36:
+                restart_steps = steps // 4
+                restart_times = 2
+            sigmas = get_sigmas_karras(steps - restart_steps * restart_times, sigmas[-2].item(), sigmas[0].item(), device=sigmas.device)
+            restart_list = {0.1: [restart_steps + 1, restart_times, 2]}
+        else:
+            restart_list = {}
+    restart_list = {int(torch.argmin(abs(sigmas - key), dim=0)): value for key, value in restart_list.items()}
+    step_list = []
+    for i in range(len(sigmas) - 1):
+        step_list.append((sigmas[i], sigmas[i + 1]))
+        if i + 1 in restart_list:
+            restart_steps, restart_times, restart_max = restart_list[i + 1]
+            min_idx = i + 1
+            max_idx = int(torch.argmin(abs(sigmas - restart_max), dim=0))
+            if max_idx < min_idx:
+                sigma_restart = get_sigmas_karras(restart_steps, sigmas[min_idx].item(), sigmas[max_idx].item(), device=sigmas.device)[:-1]
+                while restart_times > 0:
+                    restart_times -= 1
+                    step_list.extend(zip(sigma_restart[:-1], sigma_restart[1:]))
+    last_sigma = None
+    for old_sigma, new_sigma in step_list:
+        if last_sigma is None:
+            last_sigma = old_sigma
+        elif last_sigma < old_sigma:
+            x = _lc(torch.empty_like(x), [x, noise_sampler(old_sigma, new_sigma)], [1.0, s_noise * float((old_sigma ** 2 - last_sigma ** 2) ** 0.5)])
+        x = heun_step(x, old_sigma, new_sigma)
+        last_sigma = new_sigma
+    return x
+
+
 def ddim_cfgpp(model, x, timesteps, extra_args=None, callback=None, disable=None, eta=0.0, noise_sampler=None):
     """modules/sd_samplers_timesteps_impl.py:43-82 — CFG++: the direction term uses the UNCONDITIONAL eps and the CFG scale is
     mapped from [0, 12.5] to [0, 1]."""
@@ -660,7 +721,7 @@ class Sampler:
 
 
 # the rows of modules/sd_samplers_kdiffusion.py:11-27 the engine implements (same labels, aliases and options); the SDE /
-# DPM fast / adaptive / Restart rows need BrownianTree noise or adaptive step control and are not implemented yet
+# DPM fast / adaptive rows need BrownianTree noise or adaptive step control and are not implemented yet
 samplers_k_diffusion = [
     ('DPM++ 2M', sample_dpmpp_2m, ['k_dpmpp_2m'], {'scheduler': 'karras'}),
     ('DPM++ 2S a', sample_dpmpp_2s_ancestral, ['k_dpmpp_2s_a'], {'scheduler': 'karras', "uses_ensd": True, "second_order": True}),
@@ -670,6 +731,7 @@ samplers_k_diffusion = [
     ('Heun', sample_heun, ['k_heun'], {"second_order": True}),
     ('DPM2', sample_dpm_2, ['k_dpm_2'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "second_order": True}),
     ('DPM2 a', sample_dpm_2_ancestral, ['k_dpm_2_a'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "uses_ensd": True, "second_order": True}),
+    ('Restart', restart_sampler, ['restart'], {'scheduler': 'karras', "second_order": True}),
 ]
 sampler_extra_params = {                                 # modules/sd_samplers_kdiffusion.py:36-46
     'sample_euler': ['s_churn', 's_tmin', 's_tmax', 's_noise'],

@@ -293,6 +293,50 @@ def gen_clip():
     print("clip_text.npz")
 
 
+def gen_restart():
+    """Execute modules/sd_samplers_extra.py restart_sampler on the analytic denoiser; k_diffusion.sampling is stubbed with the
+    oracle's to_d / get_sigmas_karras (third-party functions the fixture does not pin) and a scripted randn_like."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import kdiffusion as okd
+    kd = types.ModuleType("k_diffusion")
+    kds = types.ModuleType("k_diffusion.sampling")
+    kds.to_d = okd.to_d
+    kds.get_sigmas_karras = lambda n, sigma_min, sigma_max, rho=7.0, device="cpu": okd.get_sigmas_karras(n, sigma_min, sigma_max, rho)
+    kd.sampling = kds
+    sys.modules["k_diffusion"] = kd
+    sys.modules["k_diffusion.sampling"] = kds
+    try:
+        import tqdm  # noqa: F401
+    except ImportError:
+        t = types.ModuleType("tqdm")
+        t.tqdm = lambda it, disable=None: it
+        sys.modules["tqdm"] = t
+    ref = load_by_path("ref_samplers_extra", "modules/sd_samplers_extra.py")
+    den = okd.CompVisDenoiser(None, okd.make_alphas_cumprod())
+    smin, smax = den.sigmas[0].item(), den.sigmas[-1].item()
+
+    def model(x, sigma, **kw):                              # a smooth "denoiser": pulls x toward tanh(x) more as sigma shrinks
+        s = sigma[:, None, None, None]
+        return x / (1 + s * s) + torch.tanh(0.5 * x) * (s * s / (1 + s * s)) * 0.3
+
+    out = {}
+    for ci, steps in enumerate([8, 22, 40]):
+        draws = iter([seeded((2, 4, 8, 8), 3000 + 10 * ci + i) for i in range(8)])
+
+        class TH:
+            @staticmethod
+            def randn_like(x):
+                return next(draws)
+        kds.torch = TH
+        sigmas = okd.get_sigmas_karras(steps, smin, smax)
+        x0 = seeded((2, 4, 8, 8), 2990 + ci) * sigmas[0]
+        res = ref.restart_sampler(model, x0.clone(), sigmas, extra_args={}, disable=True)
+        out[f"c{ci}_steps"] = np.array([steps])
+        out[f"c{ci}_out"] = res.numpy()
+    np.savez_compressed(os.path.join(OUT, "restart.npz"), **out)
+    print("restart.npz")
+
+
 def gen_lora_names():
     """Execute convert_diffusers_name_to_compvis (extensions-builtin/Lora/networks.py:40-120) on kohya-style LoRA keys of
     every UNet layer family.  The module imports the whole webui, so only the function and the three module-level objects it
@@ -337,3 +381,4 @@ if __name__ == "__main__":
     gen_schedulers()
     gen_lora_names()
     gen_clip()
+    gen_restart()

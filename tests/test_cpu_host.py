@@ -254,24 +254,30 @@ def test_weight_broadcast_and_gather_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     import socket
-    with socket.socket() as sk:                       # a free port: avoids clashes with other jobs on the host
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
-    procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=180)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            out, _ = p.communicate()
-        outs.append(out.decode())
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+    last = ""
+    for attempt in range(3):                                  # a rendezvous port can be taken between probing and use: retry
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+        procs = []
+        for r in range(2):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = []
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=180)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                out, _ = p.communicate()
+            outs.append(out.decode())
+        if all(p.returncode == 0 and f"RANK_OK {r}" in o for r, (p, o) in enumerate(zip(procs, outs))):
+            return
+        last = "\n".join(outs)
+        if "AssertionError" in last:                          # a real mismatch, not a rendezvous problem
+            break
+    raise AssertionError(last)
 
 
 def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):

@@ -128,7 +128,7 @@ def test_vae_decoder_against_reference_class_fixture(dev, golden_dir):
 @pytest.mark.parametrize("sampler,name,steps", [("euler_a", "Euler a", 5), ("dpmpp_2m", "DPM++ 2M", 6), ("ddim", "DDIM", 5),
                                                 ("euler", "Euler", 4), ("heun", "Heun", 4), ("dpm_2", "DPM2", 4),
                                                 ("dpm_2_a", "DPM2 a", 4), ("lms", "LMS", 6), ("dpmpp_2s_a", "DPM++ 2S a", 4),
-                                                ("plms", "PLMS", 5), ("ddim_cfgpp", "DDIM CFG++", 5)])
+                                                ("plms", "PLMS", 5), ("ddim_cfgpp", "DDIM CFG++", 5), ("restart", "Restart", 22)])
 def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     from oracle import pipeline as opipe
     processing = sub("processing")
@@ -298,6 +298,43 @@ def test_clip_text_encoder_tiny_vs_oracle(dev, act):
     tok2[:, 31:] = torch.randint(0, 998, (3, 46), generator=g)
     got2 = eng.clip_forward(tok2.to(dev))
     assert torch.equal(got2[:, :31], got[:, :31])
+
+
+def test_openclip_layout_penultimate_and_pooled_projection_vs_oracle(dev):
+    """An open_clip-layout text tower (packed in_proj, ln_1/ln_2, c_fc/c_proj, positional_embedding, text_projection [C, P]) is
+    translated to the engine's layout; SD 2.x semantics (penultimate + ln_final) and SDXL bigG semantics (penultimate without
+    ln_final, pooled = ln_final(last)[EOS] @ text_projection) match the oracle."""
+    schema, hc, eng_mod = sub("schema"), sub("sd_hijack_clip"), sub("engine")
+    from oracle import clip as oclip
+    C, P, layers = 128, 192, 3
+    g = torch.Generator().manual_seed(17)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    pre = "conditioner.embedders.1.model."
+    oc = {pre + "token_embedding.weight": rn(1000, C, sc=0.5), pre + "positional_embedding": rn(77, C, sc=0.5),
+          pre + "ln_final.weight": 1 + rn(C, sc=0.02), pre + "ln_final.bias": rn(C, sc=0.02), pre + "text_projection": rn(C, P, sc=C ** -0.5)}
+    for i in range(layers):
+        b = pre + f"transformer.resblocks.{i}."
+        oc.update({b + "ln_1.weight": 1 + rn(C, sc=0.02), b + "ln_1.bias": rn(C, sc=0.02), b + "ln_2.weight": 1 + rn(C, sc=0.02),
+                   b + "ln_2.bias": rn(C, sc=0.02), b + "attn.in_proj_weight": rn(3 * C, C, sc=C ** -0.5),
+                   b + "attn.in_proj_bias": rn(3 * C, sc=0.02), b + "attn.out_proj.weight": rn(C, C, sc=C ** -0.5),
+                   b + "attn.out_proj.bias": rn(C, sc=0.02), b + "mlp.c_fc.weight": rn(2 * C, C, sc=C ** -0.5),
+                   b + "mlp.c_fc.bias": rn(2 * C, sc=0.02), b + "mlp.c_proj.weight": rn(C, 2 * C, sc=(2 * C) ** -0.5),
+                   b + "mlp.c_proj.bias": rn(C, sc=0.02)})
+    oc = {k: v.half() for k, v in oc.items()}
+    sd = schema.openclip_to_transformers_keys(oc, pre)
+    cfg = schema.ClipConfig(vocab_size=1000, hidden=C, layers=layers, heads=2, intermediate=2 * C, act="gelu", proj_dim=P)
+    om = oclip.build_clip(oclip.ClipConfig(vocab_size=1000, hidden=C, layers=layers, heads=2, intermediate=2 * C, act="gelu", proj_dim=P), sd)
+    enc = hc.Mi355xClipTextEncoder(eng_mod.Engine(0), cfg, sd)
+    tok = torch.randint(1, 990, (2, 77), generator=g)
+    tok[:, 0] = 998
+    tok[0, 15] = 999; tok[0, 16:] = 0                       # open_clip pads with 0 after <end_of_text>
+    tok[1, 40] = 999; tok[1, 41:] = 0
+    z2 = enc.encode_with_transformer_openclip(tok.to(dev))
+    assert rel_l2(z2.cpu(), om(tok, skip=2, apply_final_ln=True)) < 4e-3
+    z = enc.encode_with_transformer_openclip2(tok.to(dev))
+    want, wpool = om(tok, skip=2, apply_final_ln=False, return_pooled=True)
+    assert z.shape == (2, 77, C) and z.pooled.shape == (2, P)
+    assert rel_l2(z.cpu(), want) < 4e-3 and rel_l2(z.pooled.cpu(), wpool) < 5e-3
 
 
 def test_clip_l_full_size_vs_oracle(dev):

@@ -131,6 +131,26 @@ def test_ddim_cfgpp_matches_reference(golden_dir):
         np.testing.assert_allclose(out.numpy(), z[f"cfgpp{ci}_out"], rtol=0, atol=1e-6)
 
 
+def test_restart_sampler_matches_reference(golden_dir):
+    """oracle restart_sampler == modules/sd_samplers_extra.py:6-74 for 8 steps (no restart), 22 (one restart of 9 steps) and
+    40 (two restarts of 10)."""
+    z = np.load(os.path.join(golden_dir, "restart.npz"))
+    den = kd.CompVisDenoiser(None, kd.make_alphas_cumprod())
+    smin, smax = den.sigmas[0].item(), den.sigmas[-1].item()
+
+    def model(x, sigma, **kw):
+        s = sigma[:, None, None, None]
+        return x / (1 + s * s) + torch.tanh(0.5 * x) * (s * s / (1 + s * s)) * 0.3
+
+    for ci in range(3):
+        steps = int(z[f"c{ci}_steps"][0])
+        draws = iter([seeded((2, 4, 8, 8), 3000 + 10 * ci + i) for i in range(8)])
+        sigmas = kd.get_sigmas_karras(steps, smin, smax)
+        out = kd.restart_sampler(model, seeded((2, 4, 8, 8), 2990 + ci) * sigmas[0], sigmas, {}, lambda: next(draws))
+        np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=2e-6)
+    assert len(kd.restart_step_list(kd.get_sigmas_karras(22, smin, smax))) == 13 + 9
+
+
 def test_plms_matches_reference(golden_dir):
     """oracle sample_plms == modules/sd_samplers_timesteps_impl.py:85-137 on an analytic eps model."""
     z = np.load(os.path.join(golden_dir, "plms.npz"))
