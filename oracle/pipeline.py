@@ -76,7 +76,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
             samples = samples * nmask + init_latent * mask
         return samples
 
-    if sampler in ("ddim", "plms", "ddim_cfgpp"):
+    if sampler in ("ddim", "plms", "ddim_cfgpp", "unipc"):
         # CFGDenoiserTimesteps: inner model is apply_model on integer timesteps, CFG combines eps.
         if parameterization == "v":
             inner = lambda xi, ti, ci: kd.timesteps_v_to_eps(model.alphas_cumprod, xi, ti, apply_model(xi, ti, ci))
@@ -92,6 +92,9 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
             ac = model.alphas_cumprod
             x = init_latent * torch.sqrt(ac[ts[t_enc]]) + x * torch.sqrt(1 - ac[ts[t_enc]])       # sd_samplers_timesteps.py:103-107
             ts = ts[:t_enc]
+        if sampler == "unipc":                   # default opts.uni_pc_* (modules/shared_options.py:402-405)
+            from . import unipc
+            return finish(unipc.sample_unipc(cfg, x, ts, model.alphas_cumprod, extra, callback=record, is_img2img=init_latent is not None))
         if sampler == "plms":
             return finish(kd.sample_plms(cfg, x, ts, model.alphas_cumprod, extra, callback=record))
         if sampler == "ddim_cfgpp":

@@ -630,6 +630,147 @@ def ddim(model, x, timesteps, extra_args=None, callback=None, disable=None, eta=
     return x
 
 
+# ---- UniPC (modules/models/diffusion/uni_pc/uni_pc.py, driven by unipc() at modules/sd_samplers_timesteps_impl.py:170-179) ----
+class _DiscreteVP:
+    """NoiseScheduleVP('discrete') of uni_pc.py:96-175, on host fp32 scalars (the reference evaluates the same handful of
+    scalars per step on the device).  log(alpha) is piecewise linear over t_k = k/N; beyond either end the outermost segment
+    is extended (interpolate_fn, uni_pc.py:811-850)."""
+
+    def __init__(self, alphas_cumprod):
+        self.log_alpha = 0.5 * torch.log(alphas_cumprod.float().cpu())
+        self.total_N = int(self.log_alpha.shape[0])
+        self.T = 1.0
+        self.t_grid = torch.linspace(0., 1., self.total_N + 1)[1:]
+
+    @staticmethod
+    def _pwl(x, xp, yp):
+        x = x.reshape(-1)
+        k = xp.shape[0]
+        j = torch.clamp(torch.searchsorted(xp, x.contiguous()) - 1, 0, k - 2)
+        return yp[j] + (x - xp[j]) * (yp[j + 1] - yp[j]) / (xp[j + 1] - xp[j])
+
+    def log_mean_coeff(self, t):
+        return self._pwl(t, self.t_grid, self.log_alpha)
+
+    def alpha_sigma(self, t):
+        lmc = self.log_mean_coeff(t)
+        return torch.exp(lmc), torch.sqrt(1. - torch.exp(2. * lmc))
+
+    def lam(self, t):
+        lmc = self.log_mean_coeff(t)
+        return lmc - 0.5 * torch.log(1. - torch.exp(2. * lmc))
+
+    def inverse_lam(self, lamb):
+        la = -0.5 * torch.logaddexp(torch.zeros((1,)), -2. * lamb)
+        return self._pwl(la, torch.flip(self.log_alpha, [0]), torch.flip(self.t_grid, [0]))
+
+    def time_steps(self, skip_type, t_T, t_0, n):                         # uni_pc.py:459-474
+        if skip_type == 'logSNR':
+            return self.inverse_lam(torch.linspace(self.lam(torch.tensor(t_T)).item(), self.lam(torch.tensor(t_0)).item(), n + 1))
+        if skip_type == 'time_uniform':
+            return torch.linspace(t_T, t_0, n + 1)
+        if skip_type == 'time_quadratic':
+            return torch.linspace(t_T ** 0.5, t_0 ** 0.5, n + 1).pow(2)
+        raise ValueError(f"Unsupported skip_type {skip_type}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'")
+
+
+def _lc_long(terms, coefs):
+    """sum_k coefs[k] * terms[k] for any number of terms (sdmi_lincomb takes six per launch)."""
+    out = torch.empty_like(terms[0])
+    _lc(out, terms[:6], coefs[:6])
+    for k in range(6, len(terms), 5):
+        _lc(out, [out, *terms[k:k + 5]], [1.0, *coefs[k:k + 5]])
+    return out
+
+
+def _unipc_bh_coefs(ns, t_hist, t, order, variant, use_corrector):
+    """Scalar part of multistep_uni_pc_bh_update (uni_pc.py:625-700), predict_x0 form.  With m_0 the newest data prediction,
+    m_k the k-th older one and D_k = (m_k - m_0) / r_k:
+        x_base = (sigma_t / sigma_0) x - alpha_t (e^{-h} - 1) m_0
+        x_pred = x_base - alpha_t B(h) sum_k rho^p_k D_k
+        x_corr = x_base - alpha_t B(h) (sum_k rho^c_k D_k + rho^c_last (m_t - m_0))
+    Both are linear in (x, m_0, m_1.., m_t); returns the folded coefficient lists ([x, m_0, m_1..], and the same + m_t)."""
+    lam0, lam_t = ns.lam(t_hist[-1]), ns.lam(t)
+    (_, sig0), (alpha_t, sig_t) = ns.alpha_sigma(t_hist[-1]), ns.alpha_sigma(t)
+    h = lam_t - lam0
+    rks = [((ns.lam(t_hist[-(i + 1)]) - lam0) / h)[0] for i in range(1, order)]
+    rks_t = torch.tensor([*rks, 1.])
+    hh = -h[0]
+    h_phi_1 = torch.expm1(hh)
+    if variant == 'bh1':
+        b_h = hh
+    elif variant == 'bh2':
+        b_h = torch.expm1(hh)
+    else:
+        raise NotImplementedError(f"UniPC variant {variant!r} (only bh1 / bh2)")
+    h_phi_k = h_phi_1 / hh - 1
+    fact = 1
+    rows, b = [], []
+    for i in range(1, order + 1):
+        rows.append(torch.pow(rks_t, i - 1))
+        b.append(h_phi_k * fact / b_h)
+        fact *= (i + 1)
+        h_phi_k = h_phi_k / hh - 1 / fact
+    r_mat, b = torch.stack(rows), torch.tensor(b)
+    rhos_p = []
+    if order > 1:
+        rhos_p = [0.5] if order == 2 else torch.linalg.solve(r_mat[:-1, :-1], b[:-1]).tolist()
+    c_x, c_m0, ab = float(sig_t / sig0), -float(alpha_t * h_phi_1), float(alpha_t * b_h)
+    rk = [float(r) for r in rks]
+    pred = [c_x, c_m0 + ab * sum(p / r for p, r in zip(rhos_p, rk)), *[-ab * p / r for p, r in zip(rhos_p, rk)]]
+    corr = None
+    if use_corrector:
+        rhos_c = [0.5] if order == 1 else torch.linalg.solve(r_mat, b).tolist()
+        corr = [c_x, c_m0 + ab * (sum(c / r for c, r in zip(rhos_c[:-1], rk)) + rhos_c[-1]),
+                *[-ab * c / r for c, r in zip(rhos_c[:-1], rk)], -ab * rhos_c[-1]]
+    return pred, corr
+
+
+def unipc(model, x, timesteps, extra_args=None, callback=None, disable=None, is_img2img=False):
+    """modules/sd_samplers_timesteps_impl.py:170-179: UniPC multistep (uni_pc.py:746-805), data prediction, B(h) variants;
+    variant / skip type / order / lower_order_final from shared.opts.uni_pc_*.  Every tensor update is one sdmi_lincomb."""
+    ns = _DiscreteVP(model.inner_model.inner_model.alphas_cumprod)
+    variant, skip_type = shared.opts.uni_pc_variant, shared.opts.uni_pc_skip_type
+    order, lower_order_final = int(shared.opts.uni_pc_order), bool(shared.opts.uni_pc_lower_order_final)
+    extra_args = {} if extra_args is None else extra_args
+    steps = len(timesteps)
+    t_T = float(timesteps[-1].cpu() / 1000 + 1 / 1000) if is_img2img else ns.T
+    assert steps >= order, "UniPC order must be < sampling steps"
+    ts = ns.time_steps(skip_type, t_T, 1. / ns.total_N, steps)
+    x = x.contiguous()
+    s_in = x.new_ones((x.shape[0]))
+    index = [0]
+
+    def model_fn(xx, t):                                                 # uni_pc.py:435-448 over UniPCCFG.model (impl.py:160-167)
+        eps = model(xx, float((t - 1. / ns.total_N) * 1000.) * s_in, **extra_args)
+        alpha_t, sigma_t = ns.alpha_sigma(t)
+        return _lc(torch.empty_like(xx), [xx, eps], [1.0 / float(alpha_t), -float(sigma_t) / float(alpha_t)])
+
+    def update(xx, m_hist, t_hist, t, step_order, use_corrector):
+        pred, corr = _unipc_bh_coefs(ns, t_hist, t, step_order, variant, use_corrector)
+        hist = [m_hist[-(i + 1)] for i in range(step_order)]              # m_0 (newest), m_1, ...
+        x_t = _lc_long([xx, *hist], pred)
+        model_t = None
+        if use_corrector:
+            model_t = model_fn(x_t, t)
+            x_t = _lc_long([xx, *hist, model_t], corr)
+        if callback is not None:                                          # UniPCCFG.after_update, impl.py:149-151
+            callback({'x': x_t, 'i': index[0], 'sigma': 0, 'sigma_hat': 0, 'denoised': model_t})
+        index[0] += 1
+        return x_t, model_t
+
+    m_hist, t_hist = [model_fn(x, ts[0])], [ts[0]]
+    for init_order in range(1, order):                                   # warm-up: orders 1 .. order-1
+        x, model_x = update(x, m_hist, t_hist, ts[init_order], init_order, True)
+        m_hist.append(model_x)
+        t_hist.append(ts[init_order])
+    for step in range(order, steps + 1):
+        step_order = min(order, steps + 1 - step) if lower_order_final else order
+        x, model_x = update(x, m_hist, t_hist, ts[step], step_order, step != steps)   # no corrector on the final step
+        m_hist, t_hist = [*m_hist[1:], model_x], [*t_hist[1:], ts[step]]
+    return x
+
+
 # ------------------------------------------------------------------------------------------------------------
 # Sampler classes
 # ------------------------------------------------------------------------------------------------------------
@@ -853,7 +994,7 @@ class CFGDenoiserTimesteps(CFGDenoiser):
 
 
 class CompVisSampler(Sampler):
-    """modules/sd_samplers_timesteps.py:75-163 (DDIM only)."""
+    """modules/sd_samplers_timesteps.py:75-163."""
 
     def __init__(self, func, sd_model):
         super().__init__(func.__name__, sd_model)
@@ -903,6 +1044,8 @@ class CompVisSampler(Sampler):
                              float(sqrt_one_minus_alpha_cumprod), x.numel(), stream_ptr()), "ddim img2img noise")
         extra_params_kwargs = self.initialize(p)
         extra_params_kwargs['timesteps'] = timesteps_sched
+        if 'is_img2img' in inspect.signature(self.func).parameters:       # sd_samplers_timesteps.py:122-123 (UniPC start time)
+            extra_params_kwargs['is_img2img'] = True
         self.model_wrap_cfg.init_latent = x
         self.last_latent = x
         self.sampler_extra_args = {'cond': conditioning, 'image_cond': image_conditioning,
@@ -917,10 +1060,11 @@ samplers_data_k_diffusion = [
     SamplerData(label, lambda model, func=func: KDiffusionSampler(func, model), aliases, options)
     for label, func, aliases, options in samplers_k_diffusion
 ]
-samplers_data_timesteps = [                               # modules/sd_samplers_timesteps.py:10-15 (UniPC: not yet)
+samplers_data_timesteps = [                               # modules/sd_samplers_timesteps.py:10-15
     SamplerData('DDIM', lambda model: CompVisSampler(ddim, model), ['ddim'], {}),
     SamplerData('DDIM CFG++', lambda model: CompVisSampler(ddim_cfgpp, model), ['ddim_cfgpp'], {}),
     SamplerData('PLMS', lambda model: CompVisSampler(plms, model), ['plms'], {}),
+    SamplerData('UniPC', lambda model: CompVisSampler(unipc, model), ['unipc'], {}),
 ]
 all_samplers = [*samplers_data_k_diffusion, *samplers_data_timesteps]
 all_samplers_map = {x.name: x for x in all_samplers}

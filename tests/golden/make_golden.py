@@ -372,6 +372,73 @@ def gen_lora_names():
     print("lora_names.json", len(keys))
 
 
+def gen_unipc():
+    """modules/sd_samplers_timesteps_impl.py:144-190 (UniPCCFG + unipc()) over the real modules/models/diffusion/uni_pc/uni_pc.py,
+    with a fixed analytic eps model; covers the three skip types, both B(h) variants, orders 1-4, lower_order_final off and the
+    img2img start."""
+    kd = types.ModuleType("k_diffusion")
+    kds = types.ModuleType("k_diffusion.sampling")
+    kd.sampling = kds
+    sys.modules["k_diffusion"] = kd
+    sys.modules["k_diffusion.sampling"] = kds
+    for name in ("modules", "modules.models", "modules.models.diffusion"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    shared = types.ModuleType("modules.shared")
+    shared.opts = types.SimpleNamespace()
+    sys.modules["modules.shared"] = shared
+    sys.modules["modules"].shared = shared
+    real = load_by_path("modules.models.diffusion.uni_pc.uni_pc", "modules/models/diffusion/uni_pc/uni_pc.py")
+    unipc_pkg = types.ModuleType("modules.models.diffusion.uni_pc")
+    unipc_pkg.uni_pc = real
+    sys.modules["modules.models.diffusion.uni_pc"] = unipc_pkg
+    tu = load_by_path("modules.torch_utils", "modules/torch_utils.py")
+    sys.modules["modules"].torch_utils = tu
+    impl = load_by_path("ref_timesteps_impl_unipc", "modules/sd_samplers_timesteps_impl.py")
+
+    betas = torch.linspace(0.00085 ** 0.5, 0.0120 ** 0.5, 1000, dtype=torch.float64) ** 2
+    alphas_cumprod = torch.tensor(np.cumprod(1.0 - betas.numpy(), axis=0), dtype=torch.float32)
+
+    class Model:
+        def __init__(self):
+            self.inner_model = types.SimpleNamespace(inner_model=types.SimpleNamespace(alphas_cumprod=alphas_cumprod))
+            self.ts = []
+
+        def __call__(self, x, t, **kw):
+            self.ts.append(float(t[0]))
+            return torch.tanh(0.7 * x + (t / 1000.0)[:, None, None, None]) * 0.9 + 0.05 * x
+
+    cases = [  # steps, variant, skip_type, order, lower_order_final, is_img2img(t_enc)
+        (20, "bh1", "time_uniform", 3, True, 0),
+        (8, "bh2", "time_uniform", 3, True, 0),
+        (10, "bh1", "time_quadratic", 2, True, 0),
+        (9, "bh2", "logSNR", 3, False, 0),
+        (6, "bh1", "time_uniform", 1, True, 0),
+        (12, "bh1", "time_uniform", 4, True, 0),
+        (20, "bh1", "time_uniform", 3, True, 11),
+    ]
+    out = {}
+    for ci, (steps, variant, skip, order, lof, t_enc) in enumerate(cases):
+        shared.opts.uni_pc_variant, shared.opts.uni_pc_skip_type = variant, skip
+        shared.opts.uni_pc_order, shared.opts.uni_pc_lower_order_final = order, lof
+        timesteps = torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+        if t_enc:
+            timesteps = timesteps[:t_enc]
+        m = Model()
+        dens = []
+        res = impl.unipc(m, seeded((2, 4, 8, 8), 990 + ci), timesteps, extra_args={}, disable=True,
+                         callback=lambda d: dens.append(None if d['denoised'] is None else d['denoised'].clone()),
+                         is_img2img=bool(t_enc))
+        out[f"c{ci}_cfg"] = np.array([steps, order, int(lof), t_enc])
+        out[f"c{ci}_variant_skip"] = np.array([variant, skip])
+        out[f"c{ci}_out"] = res.numpy()
+        out[f"c{ci}_model_t"] = np.array(m.ts, dtype=np.float64)
+        assert dens[-1] is None          # the final update runs without corrector: callback gets denoised=None (uni_pc.py:775-789)
+        out[f"c{ci}_last_denoised"] = dens[-2].numpy()
+        out[f"c{ci}_n_callbacks"] = np.array([len(dens)])
+    np.savez_compressed(os.path.join(OUT, "unipc.npz"), **out)
+    print("unipc.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -382,3 +449,4 @@ if __name__ == "__main__":
     gen_lora_names()
     gen_clip()
     gen_restart()
+    gen_unipc()

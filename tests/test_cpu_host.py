@@ -161,6 +161,38 @@ def test_sampler_table_matches_reference_rows():
         ss.create_sampler("Euler", M()).get_sigmas(P(), 10)
 
 
+def test_host_unipc_coefficients_match_reference(golden_dir, monkeypatch):
+    """The host UniPC (sd_samplers.unipc) folds each predictor / corrector update into ONE linear combination evaluated by
+    sdmi_lincomb.  Here the device launch is replaced by the same sum in torch (this test only — the product has no such
+    path) so that the host schedule / coefficient logic is checked against the reference-generated fixture on the CPU."""
+    ss = sub("sd_samplers")
+    z = np.load(os.path.join(golden_dir, "unipc.npz"))
+    monkeypatch.setattr(ss, "_lc", lambda out, terms, coefs: out.copy_(sum(float(c) * t for c, t in zip(coefs, terms))))
+    ac = sub("schema").make_alphas_cumprod()
+
+    class Model:
+        inner_model = type("I", (), {"inner_model": type("M", (), {"alphas_cumprod": ac})})
+
+        def __call__(self, x, t, **_):
+            return torch.tanh(0.7 * x + (t / 1000.0)[:, None, None, None]) * 0.9 + 0.05 * x
+
+    from tests.test_oracle_pins import _unipc_cases, seeded
+    opts = ss.shared.opts
+    keep = (opts.uni_pc_variant, opts.uni_pc_skip_type, opts.uni_pc_order, opts.uni_pc_lower_order_final)
+    try:
+        for ci, ts, kw in _unipc_cases(z):
+            opts.uni_pc_variant, opts.uni_pc_skip_type = kw["variant"], kw["skip_type"]
+            opts.uni_pc_order, opts.uni_pc_lower_order_final = kw["order"], kw["lower_order_final"]
+            dens = []
+            out = ss.unipc(Model(), seeded((2, 4, 8, 8), 990 + ci), ts, extra_args={}, callback=lambda d: dens.append(d['denoised']),
+                           is_img2img=kw["is_img2img"])
+            np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=2e-4)
+            assert len(dens) == int(z[f"c{ci}_n_callbacks"][0]) and dens[-1] is None
+    finally:
+        opts.uni_pc_variant, opts.uni_pc_skip_type, opts.uni_pc_order, opts.uni_pc_lower_order_final = keep
+    assert ss.find_sampler_config("unipc").name == "UniPC"
+
+
 def test_host_lora_names_and_grouping_match_reference(golden_dir):
     """networks.convert_diffusers_name_to_compvis against the reference-generated fixture, and load_network's grouping /
     layer lookup (extensions-builtin/Lora/networks.py:183-240) on the tiny UNet's layer map."""

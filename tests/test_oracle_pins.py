@@ -165,6 +165,36 @@ def test_plms_matches_reference(golden_dir):
         np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
 
 
+def _unipc_cases(z):
+    for ci in range(7):
+        steps, order, lof, t_enc = (int(v) for v in z[f"c{ci}_cfg"])
+        variant, skip = (str(v) for v in z[f"c{ci}_variant_skip"])
+        ts = kd.ddim_timesteps(steps)
+        yield ci, (ts[:t_enc] if t_enc else ts), dict(is_img2img=bool(t_enc), variant=variant, skip_type=skip, order=order,
+                                                       lower_order_final=bool(lof))
+
+
+def test_unipc_matches_reference(golden_dir):
+    """oracle/unipc.py == unipc() (modules/sd_samplers_timesteps_impl.py:144-179) over the real uni_pc.py: final latents, the
+    model times of every evaluation, the callback count and the last data prediction, for the three skip types, bh1 / bh2,
+    orders 1-4, lower_order_final off and an img2img start."""
+    from oracle import unipc
+    z = np.load(os.path.join(golden_dir, "unipc.npz"))
+    ac = kd.make_alphas_cumprod()
+    for ci, ts, kw in _unipc_cases(z):
+        times, dens = [], []
+
+        def model(x, t, **_):
+            times.append(float(t[0]))
+            return torch.tanh(0.7 * x + (t / 1000.0)[:, None, None, None]) * 0.9 + 0.05 * x
+
+        out = unipc.sample_unipc(model, seeded((2, 4, 8, 8), 990 + ci), ts, ac, {}, callback=lambda d: dens.append(d['denoised']), **kw)
+        np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(np.array(times), z[f"c{ci}_model_t"], rtol=0, atol=1e-4)
+        assert len(dens) == int(z[f"c{ci}_n_callbacks"][0]) and dens[-1] is None
+        np.testing.assert_allclose(dens[-2].numpy(), z[f"c{ci}_last_denoised"], rtol=0, atol=1e-6)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
