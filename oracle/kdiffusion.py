@@ -122,6 +122,45 @@ class CompVisVDenoiser(CompVisDenoiser):
         return self.apply_model(input * c_in, self.sigma_to_t(sigma), cond) * c_out + input * c_skip
 
 
+class LCMCompVisDenoiser(CompVisDenoiser):
+    """modules/sd_samplers_lcm.py:10-63 (pinned by tests/golden/lcm.npz): the eps wrapper over the 50 "original" LCM timesteps
+    (every 20th alpha, counted back from t = 999) and the consistency-model boundary scaling of its output."""
+
+    def __init__(self, apply_model, alphas_cumprod):
+        timesteps, original = 1000, 50
+        self.skip_steps = timesteps // original
+        valid = torch.zeros((original,), dtype=torch.float32)
+        for k in range(original):
+            valid[original - 1 - k] = alphas_cumprod[timesteps - 1 - k * self.skip_steps]
+        super().__init__(apply_model, valid, quantize=None)
+
+    def get_sigmas(self, n=None):
+        if n is None:
+            return append_zero(self.sigmas.flip(0))
+        start, end = self.sigma_to_t(self.sigma_max), self.sigma_to_t(self.sigma_min)
+        return append_zero(self.t_to_sigma(torch.linspace(start, end, n)))
+
+    def sigma_to_t(self, sigma, quantize=None):
+        dists = sigma.log() - self.log_sigmas[:, None]
+        return dists.abs().argmin(dim=0).view(sigma.shape) * self.skip_steps + (self.skip_steps - 1)
+
+    def t_to_sigma(self, timestep):
+        t = torch.clamp(((timestep - (self.skip_steps - 1)) / self.skip_steps).float(), min=0, max=(len(self.sigmas) - 1))
+        return super().t_to_sigma(t)
+
+    def get_scaled_out(self, sigma, output, input):
+        sigma_data = 0.5
+        scaled_timestep = append_dims(self.sigma_to_t(sigma), output.ndim) * 10.0
+        c_skip = sigma_data ** 2 / (scaled_timestep ** 2 + sigma_data ** 2)
+        c_out = scaled_timestep / (scaled_timestep ** 2 + sigma_data ** 2) ** 0.5
+        return c_out * output + c_skip * input
+
+    def __call__(self, input, sigma, cond):
+        c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
+        eps = self.apply_model(input * c_in, self.sigma_to_t(sigma), cond)
+        return self.get_scaled_out(sigma, input + eps * c_out, input)
+
+
 def timesteps_v_to_eps(alphas_cumprod, x_t, t, v):
     """CompVisTimestepsVDenoiser.predict_eps_from_z_and_v (modules/sd_samplers_timesteps.py:38-39)."""
     return torch.sqrt(alphas_cumprod)[t.to(torch.int), None, None, None] * v + \
@@ -197,6 +236,19 @@ def sample_euler_ancestral(model, x, sigmas, extra_args, noise_fn, eta=1.0, s_no
         x = x + d * dt
         if sigmas[i + 1] > 0:
             x = x + noise_fn() * s_noise * sigma_up
+    return x
+
+
+def sample_lcm(model, x, sigmas, extra_args, noise_fn, callback=None):
+    """modules/sd_samplers_lcm.py:66-80: x <- denoised (+ sigma_next * noise while sigma_next > 0)."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        x = denoised
+        if sigmas[i + 1] > 0:
+            x = x + sigmas[i + 1] * noise_fn()
     return x
 
 

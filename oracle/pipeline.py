@@ -32,7 +32,7 @@ class OracleModel:
 SAMPLER_OPTIONS = {
     "euler_a": (None, False), "euler": (None, False), "lms": (None, False), "heun": (None, False),
     "dpmpp_2m": ("karras", False), "dpmpp_2s_a": ("karras", False), "dpm_2": ("karras", True), "dpm_2_a": ("karras", True),
-    "restart": ("karras", False),
+    "restart": ("karras", False), "lcm": (None, False),
 }
 
 
@@ -103,7 +103,10 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         return finish(kd.sample_ddim(cfg, x, ts, model.alphas_cumprod, extra, rng.next,
                                      eta=0.0 if eta is None else eta, callback=record))
 
-    wrap = (kd.CompVisVDenoiser if parameterization == "v" else kd.CompVisDenoiser)(apply_model, model.alphas_cumprod)
+    if sampler == "lcm":                         # CFGDenoiserLCM: always the LCM eps wrapper (modules/sd_samplers_lcm.py:83-90)
+        wrap = kd.LCMCompVisDenoiser(apply_model, model.alphas_cumprod)
+    else:
+        wrap = (kd.CompVisVDenoiser if parameterization == "v" else kd.CompVisDenoiser)(apply_model, model.alphas_cumprod)
     cfg = kd.CFGDenoiser(wrap, mask, nmask, init_latent)
     extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
     if init_latent is None:
@@ -120,6 +123,8 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         return finish(kd.sample_dpm_2_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
     if sampler == "dpmpp_2s_a":
         return finish(kd.sample_dpmpp_2s_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
+    if sampler == "lcm":
+        return finish(kd.sample_lcm(cfg, x, sigmas, extra, rng.next, callback=record))
     if sampler == "restart":
         return finish(kd.restart_sampler(cfg, x, sigmas, extra, rng.next, callback=record, s_noise=s_noise))
     fn = {"euler": kd.sample_euler, "dpmpp_2m": kd.sample_dpmpp_2m, "heun": kd.sample_heun, "dpm_2": kd.sample_dpm_2,

@@ -129,6 +129,44 @@ class CompVisVDenoiser(CompVisDenoiser):
         return c_skip, c_out, c_in
 
 
+class LCMCompVisDenoiser(CompVisDenoiser):
+    """modules/sd_samplers_lcm.py:10-63: eps wrapper over the 50 original LCM timesteps plus the consistency boundary scaling
+        denoised = c_out' * (x + eps * c_out) + c_skip' * x          (get_scaled_out, :48-57)
+    which is affine in (eps, x); get_scalings returns it folded as (c_skip, c_out, c_in) for sdmi_cfg_combine_affine."""
+
+    def __init__(self, sd_model):
+        timesteps, original = 1000, 50
+        self.skip_steps = timesteps // original
+        ac = sd_model.alphas_cumprod.float().cpu()
+        valid = torch.zeros((original,), dtype=torch.float32)
+        for k in range(original):
+            valid[original - 1 - k] = ac[timesteps - 1 - k * self.skip_steps]
+        DiscreteSchedule.__init__(self, ((1 - valid) / valid) ** 0.5, None)
+        self.inner_model = sd_model
+        self.sigma_data = 1.
+
+    def get_sigmas(self, n=None):
+        if n is None:
+            return append_zero(self.sigmas.flip(0))
+        start, end = self.sigma_to_t(self.sigma_max), self.sigma_to_t(self.sigma_min)
+        return append_zero(self.t_to_sigma(torch.linspace(start, end, n)))
+
+    def sigma_to_t(self, sigma, quantize=None):
+        dists = sigma.log() - self.log_sigmas[:, None]
+        return dists.abs().argmin(dim=0).view(sigma.shape) * self.skip_steps + (self.skip_steps - 1)
+
+    def t_to_sigma(self, timestep):
+        t = torch.clamp(((timestep - (self.skip_steps - 1)) / self.skip_steps).float(), min=0, max=(len(self.sigmas) - 1))
+        return super().t_to_sigma(t)
+
+    def get_scalings(self, sigma):
+        c_out, c_in = super().get_scalings(sigma)
+        st = self.sigma_to_t(sigma.reshape(1))[0] * 10.0
+        k_skip = 0.5 ** 2 / (st ** 2 + 0.5 ** 2)
+        k_out = st / (st ** 2 + 0.5 ** 2) ** 0.5
+        return k_out + k_skip, k_out * c_out, c_in
+
+
 # ------------------------------------------------------------------------------------------------------------
 # CFG denoiser (fused)
 # ------------------------------------------------------------------------------------------------------------
@@ -201,11 +239,12 @@ class CFGDenoiser:
         if self.mode == 0:
             wrap = self.inner_model
             sig_t = torch.tensor(sig, dtype=torch.float32)
-            if vpred:
-                c_skip, c_out, c_in = wrap.get_scalings(sig_t)
+            scalings = wrap.get_scalings(sig_t)
+            if len(scalings) == 3:                      # v-prediction / LCM wrappers: denoised = out * c_out + x * c_skip
+                c_skip, c_out, c_in = scalings
                 c_skip_t = torch.full((b,), float(c_skip), dtype=torch.float32, device=x.device)
             else:
-                c_out, c_in = wrap.get_scalings(sig_t)
+                c_out, c_in = scalings
             t = wrap.sigma_to_t(sig_t.reshape(1))[0]
             c_in_t = torch.full((b,), float(c_in), dtype=torch.float32, device=x.device)
             c_out_t = torch.full((b,), float(c_out), dtype=torch.float32, device=x.device)
@@ -230,7 +269,7 @@ class CFGDenoiser:
             self.last_noise_uncond = self._eps[b:].clone()
         den = torch.empty_like(x)
         use_mask = (not self.mask_before_denoising) and self.mask is not None
-        if vpred:
+        if c_skip_t is not None:
             check(lib.sdmi_cfg_combine_affine(ptr(x), ptr(self._eps), ptr(c_out_t), ptr(c_skip_t),
                                               float(cond_scale * self.cond_scale_miltiplier),
                                               ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
@@ -315,6 +354,20 @@ def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None, disable=No
             check(lib.sdmi_dpmpp2m_step(ptr(x), ptr(denoised), ptr(old_denoised), float(ratio), float(em1), float(c1), float(c2),
                                         x.numel(), stream_ptr()), "dpmpp2m_step")
         old_denoised = denoised
+    return x
+
+
+def sample_lcm(model, x, sigmas, extra_args=None, callback=None, disable=None, noise_sampler=None):
+    """modules/sd_samplers_lcm.py:66-80: x <- denoised, plus sigma_next * noise while sigma_next > 0."""
+    extra_args = {} if extra_args is None else extra_args
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        x = denoised
+        if sigmas[i + 1] > 0:
+            x = _lc(torch.empty_like(x), [x, noise_sampler(sigmas[i], sigmas[i + 1])], [1.0, float(sigmas[i + 1])])
     return x
 
 
@@ -976,6 +1029,25 @@ class KDiffusionSampler(Sampler):
                                                               callback=self.callback_state, **extra_params_kwargs))
 
 
+class CFGDenoiserLCM(CFGDenoiser):
+    """modules/sd_samplers_lcm.py:83-90: same CFG arithmetic over the LCM denoiser wrapper (always the eps form)."""
+
+    @property
+    def inner_model(self):
+        if self.model_wrap is None:
+            self.model_wrap = LCMCompVisDenoiser(self.sampler.sd_model)
+        return self.model_wrap
+
+
+class LCMSampler(KDiffusionSampler):
+    """modules/sd_samplers_lcm.py:93-97"""
+
+    def __init__(self, func, sd_model, options=None):
+        super().__init__(func, sd_model, options)
+        self.model_wrap_cfg = CFGDenoiserLCM(self, mode=0)
+        self.model_wrap = self.model_wrap_cfg.inner_model
+
+
 class _TimestepsInner:
     """model.inner_model.inner_model.alphas_cumprod chain the reference's ddim() dereferences (impl.py:13)."""
     def __init__(self, sd_model):
@@ -1066,7 +1138,8 @@ samplers_data_timesteps = [                               # modules/sd_samplers_
     SamplerData('PLMS', lambda model: CompVisSampler(plms, model), ['plms'], {}),
     SamplerData('UniPC', lambda model: CompVisSampler(unipc, model), ['unipc'], {}),
 ]
-all_samplers = [*samplers_data_k_diffusion, *samplers_data_timesteps]
+samplers_data_lcm = [SamplerData('LCM', lambda model: LCMSampler(sample_lcm, model), ['k_lcm'], {})]   # sd_samplers_lcm.py:100-104
+all_samplers = [*samplers_data_k_diffusion, *samplers_data_timesteps, *samplers_data_lcm]              # modules/sd_samplers.py:11-15
 all_samplers_map = {x.name: x for x in all_samplers}
 samplers_map = {}
 for _s in all_samplers:

@@ -439,6 +439,83 @@ def gen_unipc():
     print("unipc.npz")
 
 
+def gen_lcm():
+    """Execute modules/sd_samplers_lcm.py (LCMCompVisDenoiser :10-63, sample_lcm :66-80).  k_diffusion is third-party and absent:
+    its DiscreteEpsDDPMDenoiser base / append_dims / append_zero are supplied from the oracle's restatement of k-diffusion
+    (not pinned by this fixture); everything the reference file itself adds — the 50-entry sigma table, its get_sigmas /
+    sigma_to_t / t_to_sigma, the consistency-model output scaling and the sampling loop — is."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import kdiffusion as okd
+    import collections
+
+    class DiscreteEpsDDPMDenoiser(okd.DiscreteSchedule):
+        def __init__(self, model, alphas_cumprod, quantize):
+            super().__init__(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5, quantize)
+            self.inner_model = model
+            self.sigma_data = 1.
+
+        def get_scalings(self, sigma):
+            return -sigma, 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+
+        def __call__(self, *a, **kw):
+            return self.forward(*a, **kw)
+
+    kd = types.ModuleType("k_diffusion")
+    kds = types.ModuleType("k_diffusion.sampling")
+    kdu = types.ModuleType("k_diffusion.utils")
+    kde = types.ModuleType("k_diffusion.external")
+    kdu.append_dims = okd.append_dims
+    kds.append_zero = okd.append_zero
+    kds.trange = lambda n, disable=None: range(n)
+    kds.default_noise_sampler = lambda x: None
+    kde.DiscreteEpsDDPMDenoiser = DiscreteEpsDDPMDenoiser
+    kd.sampling, kd.utils, kd.external = kds, kdu, kde
+    for n, m in (("k_diffusion", kd), ("k_diffusion.sampling", kds), ("k_diffusion.utils", kdu), ("k_diffusion.external", kde)):
+        sys.modules[n] = m
+    mods = sys.modules.setdefault("modules", types.ModuleType("modules"))
+    ac = okd.make_alphas_cumprod()
+
+    class SdModel:
+        device = "cpu"
+        alphas_cumprod = ac
+
+        @staticmethod
+        def apply_model(x, t, **kw):
+            return torch.tanh(0.6 * x + (t.float() / 1000.0)[:, None, None, None]) * 0.8 + 0.1 * x
+
+    shared = types.ModuleType("modules.shared")
+    shared.sd_model = SdModel()
+    cfgd = types.ModuleType("modules.sd_samplers_cfg_denoiser")
+    cfgd.CFGDenoiser = type("CFGDenoiser", (), {})
+    kdiff = types.ModuleType("modules.sd_samplers_kdiffusion")
+    kdiff.KDiffusionSampler = type("KDiffusionSampler", (), {})
+    common = types.ModuleType("modules.sd_samplers_common")
+    common.SamplerData = collections.namedtuple('SamplerData', ['name', 'constructor', 'aliases', 'options'])
+    for n, m in (("shared", shared), ("sd_samplers_cfg_denoiser", cfgd), ("sd_samplers_kdiffusion", kdiff), ("sd_samplers_common", common)):
+        sys.modules["modules." + n] = m
+        setattr(mods, n, m)
+    ref = load_by_path("ref_samplers_lcm", "modules/sd_samplers_lcm.py")
+    den = ref.LCMCompVisDenoiser(shared.sd_model)
+    out = {"sigmas": den.sigmas.numpy(), "get_sigmas_all": den.get_sigmas().numpy()}
+    probe = torch.tensor([0.03, 0.5, 1.7, 3.3, 14.6, 20.0])
+    out["probe_sigma"] = probe.numpy()
+    out["probe_t"] = den.sigma_to_t(probe).numpy()
+    out["probe_t_to_sigma"] = den.t_to_sigma(torch.tensor([0., 19., 59., 333., 500.5, 999., 1200.])).numpy()
+    x = seeded((2, 4, 8, 8), 4100)
+    for k, sg in enumerate([14.6, 2.2, 0.4]):
+        out[f"forward{k}"] = den(x * sg, torch.full((2,), sg)).numpy()
+    for ci, steps in enumerate([4, 8]):
+        sigmas = den.get_sigmas(steps)
+        out[f"c{ci}_sigmas"] = sigmas.numpy()
+        draws = iter([seeded((2, 4, 8, 8), 4200 + 10 * ci + i) for i in range(steps)])
+        res = ref.sample_lcm(den, seeded((2, 4, 8, 8), 4190 + ci) * sigmas[0], sigmas, extra_args={}, disable=True,
+                             noise_sampler=lambda a, b: next(draws))
+        out[f"c{ci}_out"] = res.numpy()
+    assert [x.name for x in ref.samplers_data_lcm] == ["LCM"] and ref.samplers_lcm[0][2] == ['k_lcm'] and ref.samplers_lcm[0][3] == {}
+    np.savez_compressed(os.path.join(OUT, "lcm.npz"), **out)
+    print("lcm.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -450,3 +527,4 @@ if __name__ == "__main__":
     gen_clip()
     gen_restart()
     gen_unipc()
+    gen_lcm()

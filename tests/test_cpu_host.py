@@ -193,6 +193,30 @@ def test_host_unipc_coefficients_match_reference(golden_dir, monkeypatch):
     assert ss.find_sampler_config("unipc").name == "UniPC"
 
 
+def test_host_lcm_schedule_and_folded_scalings_match_reference(golden_dir):
+    """Host LCMCompVisDenoiser: sigma table / get_sigmas / sigma_to_t equal the reference-generated fixture, and the folded
+    affine scalings reproduce its forward: denoised = eps * c_out + x * c_skip with eps evaluated at x * c_in."""
+    ss = sub("sd_samplers")
+    z = np.load(os.path.join(golden_dir, "lcm.npz"))
+    M = type("M", (), {"alphas_cumprod": sub("schema").make_alphas_cumprod(), "engine": None})
+    s = ss.create_sampler("k_lcm", M())
+    assert s.config.name == "LCM" and isinstance(s.model_wrap, ss.LCMCompVisDenoiser) and s.model_wrap_cfg.inner_model is s.model_wrap
+    den = s.model_wrap
+    assert np.array_equal(den.sigmas.numpy(), z["sigmas"])
+    assert np.array_equal(den.sigma_to_t(torch.tensor(z["probe_sigma"])).numpy(), z["probe_t"])
+    P = type("P", (), {"scheduler": None, "is_hr_pass": False, "sampler_noise_scheduler_override": None})
+    for ci, steps in enumerate([4, 8]):
+        np.testing.assert_allclose(s.get_sigmas(P(), steps).numpy(), z[f"c{ci}_sigmas"], rtol=1e-6)
+    from tests.test_oracle_pins import seeded
+    x = seeded((2, 4, 8, 8), 4100)
+    for k, sg in enumerate([14.6, 2.2, 0.4]):
+        c_skip, c_out, c_in = den.get_scalings(torch.tensor(sg))
+        t = den.sigma_to_t(torch.full((2,), sg))
+        xin = x * sg
+        eps = torch.tanh(0.6 * (xin * c_in) + (t.float() / 1000.0)[:, None, None, None]) * 0.8 + 0.1 * (xin * c_in)
+        np.testing.assert_allclose((eps * c_out + xin * c_skip).numpy(), z[f"forward{k}"], rtol=0, atol=2e-5)
+
+
 def test_host_lora_names_and_grouping_match_reference(golden_dir):
     """networks.convert_diffusers_name_to_compvis against the reference-generated fixture, and load_network's grouping /
     layer lookup (extensions-builtin/Lora/networks.py:183-240) on the tiny UNet's layer map."""

@@ -129,7 +129,7 @@ def test_vae_decoder_against_reference_class_fixture(dev, golden_dir):
                                                 ("euler", "Euler", 4), ("heun", "Heun", 4), ("dpm_2", "DPM2", 4),
                                                 ("dpm_2_a", "DPM2 a", 4), ("lms", "LMS", 6), ("dpmpp_2s_a", "DPM++ 2S a", 4),
                                                 ("plms", "PLMS", 5), ("ddim_cfgpp", "DDIM CFG++", 5), ("restart", "Restart", 22),
-                                                ("unipc", "UniPC", 6)])
+                                                ("unipc", "UniPC", 6), ("lcm", "LCM", 4)])
 def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     from oracle import pipeline as opipe
     processing = sub("processing")
@@ -159,7 +159,7 @@ def test_txt2img_scheduler_choice_vs_oracle(dev, tiny, sched, key):
     assert rel_l2(res.latents.cpu(), lat) < 1e-2, sched
 
 
-@pytest.mark.parametrize("sampler,name", [("euler_a", "Euler a"), ("ddim", "DDIM"), ("plms", "PLMS"), ("unipc", "UniPC")])
+@pytest.mark.parametrize("sampler,name", [("euler_a", "Euler a"), ("ddim", "DDIM"), ("plms", "PLMS"), ("unipc", "UniPC"), ("lcm", "LCM")])
 def test_inpainting_mask_paths_vs_oracle(dev, tiny, sampler, name):
     """img2img with a latent mask: k-diffusion samplers blend AFTER denoising (cfg_denoiser.py:292-293, fused into the CFG
     combine kernel), timestep samplers BEFORE (:186-187, sdmi_mask_blend on a copy); both end with processing.py:1776-1784."""

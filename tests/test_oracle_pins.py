@@ -195,6 +195,26 @@ def test_unipc_matches_reference(golden_dir):
         np.testing.assert_allclose(dens[-2].numpy(), z[f"c{ci}_last_denoised"], rtol=0, atol=1e-6)
 
 
+def test_lcm_matches_reference(golden_dir):
+    """oracle LCMCompVisDenoiser / sample_lcm == modules/sd_samplers_lcm.py executed over the oracle's k-diffusion base classes:
+    the 50-entry sigma table, get_sigmas (all / n steps), sigma_to_t, t_to_sigma, the scaled forward and 4- and 8-step runs."""
+    z = np.load(os.path.join(golden_dir, "lcm.npz"))
+    am = lambda x, t, c=None: torch.tanh(0.6 * x + (t.float() / 1000.0)[:, None, None, None]) * 0.8 + 0.1 * x
+    den = kd.LCMCompVisDenoiser(am, kd.make_alphas_cumprod())
+    assert np.array_equal(den.sigmas.numpy(), z["sigmas"]) and np.array_equal(den.get_sigmas().numpy(), z["get_sigmas_all"])
+    assert np.array_equal(den.sigma_to_t(torch.tensor(z["probe_sigma"])).numpy(), z["probe_t"])
+    np.testing.assert_allclose(den.t_to_sigma(torch.tensor([0., 19., 59., 333., 500.5, 999., 1200.])).numpy(), z["probe_t_to_sigma"], rtol=1e-6)
+    x = seeded((2, 4, 8, 8), 4100)
+    for k, sg in enumerate([14.6, 2.2, 0.4]):
+        np.testing.assert_allclose(den(x * sg, torch.full((2,), sg), None).numpy(), z[f"forward{k}"], rtol=0, atol=1e-6)
+    for ci, steps in enumerate([4, 8]):
+        sig = den.get_sigmas(steps)
+        np.testing.assert_allclose(sig.numpy(), z[f"c{ci}_sigmas"], rtol=1e-6)
+        draws = iter([seeded((2, 4, 8, 8), 4200 + 10 * ci + i) for i in range(steps)])
+        out = kd.sample_lcm(lambda xx, s, **kw: den(xx, s, None), seeded((2, 4, 8, 8), 4190 + ci) * sig[0], sig, {}, lambda: next(draws))
+        np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
