@@ -172,17 +172,33 @@ def timesteps_v_to_eps(alphas_cumprod, x_t, t, v):
 #       one cond per image with weight 1.0, equal token counts, batch_cond_uncond on, no mask)
 # ---------------------------------------------------------------------------------------------
 class CFGDenoiser:
+    """modules/sd_samplers_cfg_denoiser.py:35-311, pinned by tests/golden/cfg_denoiser.npz (the reference class executed over
+    twenty scenarios).  ``cond`` is a tensor (one prompt of weight 1 per image) or the (conds_list, tensor) pair that
+    prompt_parser.reconstruct_multicond_batch returns (AND composition, :169); ``inner_model(x_in, sigma_in, cond_in)`` — with a
+    fourth argument, the per-row image conditioning, when ``image_cond`` is given.  The reference's options are attributes.
+    Not restated: script callbacks, refiner switch, live previews, opts.batch_cond_uncond = False (same rows, smaller calls)."""
+
     def __init__(self, inner_model, mask=None, nmask=None, init_latent=None):
         self.inner_model = inner_model
         self.step = 0
+        self.total_steps = None
         self.mask, self.nmask, self.init_latent = mask, nmask, init_latent
         self.mask_before_denoising = False
-        self.cond_scale_miltiplier = 1.0                     # modules/sd_samplers_cfg_denoiser.py:61-64
+        self.cond_scale_miltiplier = 1.0                     # :61-64
         self.need_last_noise_uncond = False
         self.last_noise_uncond = None
+        self.image_cfg_scale = None                          # with is_edit_model: InstructPix2Pix (:166)
+        self.is_edit_cond_stage = False                      # shared.sd_model.cond_stage_key == "edit"
+        self.skip_early_cond = 0.0                           # opts.skip_early_cond
+        self.s_min_uncond_all = False                        # opts.s_min_uncond_all
+        self.pad_cond_uncond = False                         # opts.pad_cond_uncond (needs empty_prompt)
+        self.pad_cond_uncond_v0 = False                      # opts.pad_cond_uncond_v0
+        self.empty_prompt = None                             # shared.sd_model.cond_stage_model_empty_prompt
+        self.padded_cond_uncond = self.padded_cond_uncond_v0 = False
+        self.skipped_uncond = False
 
     @staticmethod
-    def combine_denoised(x_out, conds_list, uncond_n, cond_scale):
+    def combine_denoised(x_out, conds_list, uncond_n, cond_scale):                       # :73-82
         denoised_uncond = x_out[-uncond_n:]
         denoised = torch.clone(denoised_uncond)
         for i, conds in enumerate(conds_list):
@@ -190,20 +206,81 @@ class CFGDenoiser:
                 denoised[i] += (x_out[cond_index] - denoised_uncond[i]) * (weight * cond_scale)
         return denoised
 
-    def __call__(self, x, sigma, uncond, cond, cond_scale):
+    def combine_denoised_for_edit_model(self, x_out, cond_scale):                         # :84-88
+        out_cond, out_img_cond, out_uncond = x_out.chunk(3)
+        return out_uncond + cond_scale * (out_cond - out_img_cond) + self.image_cfg_scale * (out_img_cond - out_uncond)
+
+    def _pad(self, tensor, uncond):                                                       # :100-155
+        if self.pad_cond_uncond_v0:
+            if uncond.shape[1] < tensor.shape[1]:
+                uncond = torch.hstack([uncond, uncond[:, -1:].repeat([1, tensor.shape[1] - uncond.shape[1], 1])])
+            else:
+                uncond = uncond[:, :tensor.shape[1]]
+            self.padded_cond_uncond_v0 = True
+        elif self.pad_cond_uncond:
+            empty = self.empty_prompt
+            n = (tensor.shape[1] - uncond.shape[1]) // empty.shape[1]
+            if n < 0:
+                tensor = torch.cat([tensor, empty.repeat((tensor.shape[0], -n, 1))], axis=1)
+            elif n > 0:
+                uncond = torch.cat([uncond, empty.repeat((uncond.shape[0], n, 1))], axis=1)
+            self.padded_cond_uncond = n != 0
+        return tensor, uncond
+
+    def __call__(self, x, sigma, uncond, cond, cond_scale, s_min_uncond=0.0, image_cond=None):
         b = x.shape[0]
-        conds_list = [[(i, 1.0)] for i in range(b)]
-        if self.mask_before_denoising and self.mask is not None:
+        conds_list, tensor = cond if isinstance(cond, tuple) else ([[(i, 1.0)] for i in range(b)], cond)
+        is_edit = self.is_edit_cond_stage and self.image_cfg_scale is not None and self.image_cfg_scale != 1.0
+        assert not is_edit or all(len(c) == 1 for c in conds_list)
+        if self.mask_before_denoising and self.mask is not None:                          # :186-187
             x = x * self.nmask + self.init_latent * self.mask
-        x_in = torch.cat([x, x])
-        sigma_in = torch.cat([sigma, sigma])
-        cond_in = torch.cat([cond, uncond])
-        x_out = self.inner_model(x_in, sigma_in, cond_in)
+        repeats = [len(c) for c in conds_list]
+        rep = lambda t: torch.cat([torch.stack([t[i] for _ in range(n)]) for i, n in enumerate(repeats)])
+        tail = [x, x] if is_edit else [x]
+        x_in = torch.cat([rep(x)] + tail)                                                 # :203-209
+        sigma_in = torch.cat([rep(sigma)] + [sigma] * len(tail))
+        image_cond_in = None
+        if image_cond is not None:
+            image_cond_in = torch.cat([rep(image_cond), image_cond] + ([torch.zeros_like(self.init_latent)] if is_edit else []))
+        skip_uncond = False                                                               # :218-230
+        if self.skip_early_cond != 0. and self.step / self.total_steps <= self.skip_early_cond:
+            skip_uncond = True
+        elif (self.step % 2 or self.s_min_uncond_all) and s_min_uncond > 0 and sigma[0] < s_min_uncond and not is_edit:
+            skip_uncond = True
+        self.skipped_uncond = skip_uncond
+        if skip_uncond:
+            x_in, sigma_in = x_in[:-b], sigma_in[:-b]
+        self.padded_cond_uncond = self.padded_cond_uncond_v0 = False
+        if tensor.shape[1] != uncond.shape[1] and (self.pad_cond_uncond_v0 or self.pad_cond_uncond):
+            tensor, uncond = self._pad(tensor, uncond)
+
+        def run(a, e, c):
+            if image_cond_in is None:
+                return self.inner_model(x_in[a:e], sigma_in[a:e], c)
+            return self.inner_model(x_in[a:e], sigma_in[a:e], c, image_cond_in[a:e])
+
+        if tensor.shape[1] == uncond.shape[1] or skip_uncond:                              # :240-246
+            cond_in = torch.cat([tensor, uncond, uncond]) if is_edit else tensor if skip_uncond else torch.cat([tensor, uncond])
+            x_out = run(0, x_in.shape[0], cond_in)
+        else:                                                                             # :253-268: token counts differ
+            x_out = torch.zeros_like(x_in)
+            n = tensor.shape[0]
+            x_out[:n] = run(0, n, tensor)
+            x_out[-b:] = run(x_in.shape[0] - b, x_in.shape[0], uncond)
+        image_index = [c[0][0] for c in conds_list]
+        if skip_uncond:                                                                   # :270-273
+            x_out = torch.cat([x_out, torch.cat([x_out[i:i + 1] for i in image_index])])
         if self.need_last_noise_uncond:
-            self.last_noise_uncond = torch.clone(x_out[-b:])                     # :281-282
-        denoised = self.combine_denoised(x_out, conds_list, b, cond_scale * self.cond_scale_miltiplier)
-        if not self.mask_before_denoising and self.mask is not None:
+            self.last_noise_uncond = torch.clone(x_out[-b:])                              # :281-282
+        if is_edit:
+            denoised = self.combine_denoised_for_edit_model(x_out, cond_scale * self.cond_scale_miltiplier)
+        elif skip_uncond:
+            denoised = self.combine_denoised(x_out, conds_list, b, 1.0)
+        else:
+            denoised = self.combine_denoised(x_out, conds_list, b, cond_scale * self.cond_scale_miltiplier)
+        if not self.mask_before_denoising and self.mask is not None:                      # :292-293
             denoised = denoised * self.nmask + self.init_latent * self.mask
+        self.last_latent = torch.cat([x_out[i:i + 1] for i in image_index])               # base get_pred_x0 = x_out (:90-91)
         self.step += 1
         return denoised
 

@@ -57,7 +57,8 @@ def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, schedul
 @torch.no_grad()
 def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
            latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
-           y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None, parameterization="eps"):
+           y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None, parameterization="eps",
+           s_min_uncond=0.0):
     """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
     (modules/sd_samplers_kdiffusion.py:134-143); ``mask`` (1 = keep the original latent) adds the inpainting blends of
     modules/sd_samplers_cfg_denoiser.py:186-187 / 292-293 and the final blend of modules/processing.py:1776-1784."""
@@ -68,7 +69,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
 
     def apply_model(xi, t, c):
         if y is not None:
-            return model.apply_model(xi, t, c, torch.cat([y, uy]))
+            return model.apply_model(xi, t, c, y if xi.shape[0] == y.shape[0] else torch.cat([y, uy]))   # cond rows only: uncond skipped
         return model.apply_model(xi, t, c)
 
     def finish(samples):
@@ -85,7 +86,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         cfg = kd.CFGDenoiser(inner, mask, nmask, init_latent)
         cfg.mask_before_denoising = True
         ts = kd.ddim_timesteps(steps)
-        extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
+        extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond)
         if init_latent is not None:
             total, t_enc = kd.setup_img2img_steps(steps, denoising_strength, img2img_steps_given)
             ts = kd.ddim_timesteps(total)
@@ -108,7 +109,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
     else:
         wrap = (kd.CompVisVDenoiser if parameterization == "v" else kd.CompVisDenoiser)(apply_model, model.alphas_cumprod)
     cfg = kd.CFGDenoiser(wrap, mask, nmask, init_latent)
-    extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale)
+    extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond)
     if init_latent is None:
         sigmas = get_sigmas(wrap, sampler, steps, scheduler)
         x = x * sigmas[0]

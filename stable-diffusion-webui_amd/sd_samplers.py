@@ -175,8 +175,9 @@ class CFGDenoiser:
     three launches per step: build x_in = [x*c_in | x*c_in], whole-UNet forward on 2B images, combine.
 
     ``mode`` 0: sigma space (k-diffusion samplers; returns denoised), 1: timestep space (DDIM; returns eps).
-    Unsupported reference features raise instead of being silently ignored: AND-composition / per-step prompt
-    schedules, differing cond/uncond lengths, skip-uncond (s_min_uncond, skip_early_cond), edit models.
+    Also covered (see ``forward``): AND composition, skip-uncond (NGMS / skip_early_cond), cond / uncond of different token
+    counts and the two padding options.  Per-step prompt schedules are the caller's job (pass the step's tensors);
+    InstructPix2Pix three-way CFG, script callbacks and the refiner switch raise / are not called.
     """
 
     def __init__(self, sampler, mode=0):
@@ -199,6 +200,7 @@ class CFGDenoiser:
         self.mask_before_denoising = mode == 1          # CFGDenoiserTimesteps sets this (sd_samplers_timesteps.py:54)
         self._ctx_key = None
         self._x_in = None
+        self._comb = None
 
     @property
     def inner_model(self):
@@ -207,35 +209,87 @@ class CFGDenoiser:
             self.model_wrap = denoiser(self.sampler.sd_model, quantize=shared.opts.enable_quantization)
         return self.model_wrap
 
-    def _ensure_context(self, cond, uncond):
-        key = (cond.data_ptr(), uncond.data_ptr(), tuple(cond.shape), tuple(uncond.shape), cond._version, uncond._version,
+    def _ensure_context(self, ctx_parts):
+        """Cache the cross-attention K / V projections of the UNet batch's context rows (cat of ``ctx_parts``)."""
+        key = (tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ctx_parts),
                getattr(self.sampler.sd_model.engine, "weights_version", 0))      # a LoRA rewrite invalidates the cached K / V
         if key != self._ctx_key:
-            if cond.shape[1] != uncond.shape[1]:
-                raise NotImplementedError("cond / uncond token counts differ: use pad_cond_uncond or the torch path")
-            ctx = torch.cat([cond, uncond]).float().contiguous()
+            ctx = torch.cat([t.float() for t in ctx_parts]).contiguous()
             self.sampler.sd_model.engine.set_context(ctx)
             self._ctx_key = key
 
+    def pad_cond_uncond(self, cond, uncond):
+        """modules/sd_samplers_cfg_denoiser.py:100-111: pad the shorter side with repeats of the empty-prompt embedding."""
+        empty = getattr(self.sampler.sd_model, "cond_stage_model_empty_prompt", None)
+        if empty is None:
+            raise NotImplementedError("pad_cond_uncond needs sd_model.cond_stage_model_empty_prompt (the encoded empty prompt)")
+        empty = empty.to(cond.device, cond.dtype)
+        num_repeats = (cond.shape[1] - uncond.shape[1]) // empty.shape[1]
+        if num_repeats < 0:
+            cond = torch.cat([cond, empty.repeat((cond.shape[0], -num_repeats, 1))], axis=1)
+            self.padded_cond_uncond = True
+        elif num_repeats > 0:
+            uncond = torch.cat([uncond, empty.repeat((uncond.shape[0], num_repeats, 1))], axis=1)
+            self.padded_cond_uncond = True
+        return cond, uncond
+
+    def pad_cond_uncond_v0(self, cond, uncond):
+        """modules/sd_samplers_cfg_denoiser.py:113-154: repeat uncond's last token / truncate it to cond's length."""
+        if uncond.shape[1] < cond.shape[1]:
+            uncond = torch.hstack([uncond, uncond[:, -1:].repeat([1, cond.shape[1] - uncond.shape[1], 1])])
+            self.padded_cond_uncond_v0 = True
+        elif uncond.shape[1] > cond.shape[1]:
+            uncond = uncond[:, :cond.shape[1]]
+            self.padded_cond_uncond_v0 = True
+        return cond, uncond
+
     def forward(self, x, sigma, uncond, cond, cond_scale, s_min_uncond=0.0, image_cond=None, y=None, uy=None):
+        """modules/sd_samplers_cfg_denoiser.py:156-311.  ``cond`` is a tensor [B, T, C] (one prompt of weight 1 per image) or
+        the (conds_list, tensor) pair of prompt_parser.reconstruct_multicond_batch (AND composition: several weighted prompts
+        per image).  Skip-uncond (NGMS ``s_min_uncond`` / ``opts.skip_early_cond``), cond / uncond of different token counts
+        (two UNet calls, or opts.pad_cond_uncond / pad_cond_uncond_v0) and the inpainting blends follow the reference."""
         if shared.state.interrupted or shared.state.skipped:
             raise InterruptedException
-        if s_min_uncond and s_min_uncond > 0:
-            raise NotImplementedError("s_min_uncond (skip-uncond) is not implemented in the fused CFG path")
-        eng = self.sampler.sd_model.engine
+        opts = shared.opts
+        sd_model = self.sampler.sd_model
+        eng = sd_model.engine
+        if getattr(sd_model, "cond_stage_key", "txt") == "edit" and self.image_cfg_scale is not None and self.image_cfg_scale != 1.0:
+            raise NotImplementedError("InstructPix2Pix three-way CFG is not implemented")
         b, c, h, w = x.shape
         chw = c * h * w
+        conds_list, tensor = cond if isinstance(cond, tuple) else (None, cond)
+        if conds_list is not None and all(len(cl) == 1 and cl[0] == (i, 1.0) for i, cl in enumerate(conds_list)):
+            conds_list = None                                 # plain CFG written the long way
         if self.mask_before_denoising and self.mask is not None:
             # blend in the original latents BEFORE denoising (timestep samplers, cfg_denoiser.py:186-187); the sampler keeps
             # its own, unblended x for the update, so work on a copy
             x = ops.mask_blend(x.clone(), self.init_latent, self.mask, self.nmask)
-        self._ensure_context(cond, uncond)
-        if self._x_in is None or self._x_in.shape[0] != 2 * b or self._x_in.shape[2:] != x.shape[2:]:
-            self._x_in = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
-            self._eps = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
+        n_cond = b if conds_list is None else sum(len(cl) for cl in conds_list)
+        if tensor.shape[0] != n_cond:
+            raise ValueError(f"cond has {tensor.shape[0]} rows, conds_list names {n_cond}")
+
+        skip_uncond = False                                   # :218-230
+        if opts.skip_early_cond != 0. and self.step / self.total_steps <= opts.skip_early_cond:
+            skip_uncond = True
+        elif (self.step % 2 or opts.s_min_uncond_all) and s_min_uncond > 0 and float(sigma[0]) < s_min_uncond:
+            skip_uncond = True
+        self.padded_cond_uncond = False
+        self.padded_cond_uncond_v0 = False
+        if opts.pad_cond_uncond_v0 and tensor.shape[1] != uncond.shape[1]:
+            tensor, uncond = self.pad_cond_uncond_v0(tensor, uncond)
+        elif opts.pad_cond_uncond and tensor.shape[1] != uncond.shape[1]:
+            tensor, uncond = self.pad_cond_uncond(tensor, uncond)
+        split_calls = tensor.shape[1] != uncond.shape[1] and not skip_uncond      # :253-268: one UNet call per context length
+
+        rows = n_cond + (0 if skip_uncond else b)
+        if self._x_in is None or self._x_in.shape[0] < max(rows, 2 * b) or self._x_in.shape[2:] != x.shape[2:]:
+            self._x_in = torch.empty((max(rows, 2 * b), c, h, w), dtype=torch.float32, device=x.device)
+            self._eps = torch.empty((max(rows, 2 * b), c, h, w), dtype=torch.float32, device=x.device)
+            self._comb = None
         sig = float(sigma[0])
-        vpred = getattr(self.sampler.sd_model, "parameterization", "eps") == "v"
+        vpred = getattr(sd_model, "parameterization", "eps") == "v"
         c_skip_t = None
+        c_in_t = None
         if self.mode == 0:
             wrap = self.inner_model
             sig_t = torch.tensor(sig, dtype=torch.float32)
@@ -245,38 +299,82 @@ class CFGDenoiser:
                 c_skip_t = torch.full((b,), float(c_skip), dtype=torch.float32, device=x.device)
             else:
                 c_out, c_in = scalings
-            t = wrap.sigma_to_t(sig_t.reshape(1))[0]
+            t_model = float(wrap.sigma_to_t(sig_t.reshape(1))[0])
             c_in_t = torch.full((b,), float(c_in), dtype=torch.float32, device=x.device)
             c_out_t = torch.full((b,), float(c_out), dtype=torch.float32, device=x.device)
-            check(lib.sdmi_cfg_prepare_input(ptr(x), ptr(c_in_t), ptr(self._x_in), _lib.F32, b, 2, chw, stream_ptr()), "cfg_prepare")
-            ts = torch.full((2 * b,), float(t), dtype=torch.float32, device=x.device)
         else:
             c_out_t = None
+            t_model = sig
             if vpred:                                     # eps = sqrt(a_t) * v + sqrt(1 - a_t) * x_t  (sd_samplers_timesteps.py:38-39)
                 if self.need_last_noise_uncond:
                     raise NotImplementedError("DDIM CFG++ with a v-prediction model is not implemented")
-                ac = self.sampler.sd_model.alphas_cumprod.float().cpu()
+                ac = sd_model.alphas_cumprod.float().cpu()
                 a_t = ac[int(sig)]
                 c_out_t = torch.full((b,), float(torch.sqrt(a_t)), dtype=torch.float32, device=x.device)
                 c_skip_t = torch.full((b,), float(torch.sqrt(1 - a_t)), dtype=torch.float32, device=x.device)
-            check(lib.sdmi_cfg_prepare_input(ptr(x), None, ptr(self._x_in), _lib.F32, b, 2, chw, stream_ptr()), "cfg_prepare")
-            ts = torch.full((2 * b,), sig, dtype=torch.float32, device=x.device)
+        # x_in rows: every image once per prompt, then (unless skipped) every image once more for uncond (:203-205)
+        x_in, eps = self._x_in[:rows], self._eps[:rows]
+        if conds_list is None:
+            check(lib.sdmi_cfg_prepare_input(ptr(x), ptr(c_in_t), ptr(x_in), _lib.F32, b, 1 if skip_uncond else 2, chw, stream_ptr()),
+                  "cfg_prepare")
+        else:
+            row = 0
+            for i, cl in enumerate(conds_list):
+                check(lib.sdmi_cfg_prepare_input(ptr(x[i]), None if c_in_t is None else ptr(c_in_t[i:]), ptr(x_in[row:]), _lib.F32, 1,
+                                                 len(cl), chw, stream_ptr()), "cfg_prepare")
+                row += len(cl)
+            if not skip_uncond:
+                check(lib.sdmi_cfg_prepare_input(ptr(x), ptr(c_in_t), ptr(x_in[n_cond:]), _lib.F32, b, 1, chw, stream_ptr()), "cfg_prepare")
+        ts = torch.full((rows,), t_model, dtype=torch.float32, device=x.device)
         yy = None
         if y is not None:
-            yy = torch.cat([y, uy]).float().contiguous()
-        eng.unet_forward(self._x_in, ts, None, yy, out=self._eps)
-        if self.need_last_noise_uncond:
-            self.last_noise_uncond = self._eps[b:].clone()
+            if conds_list is not None:
+                raise NotImplementedError("AND composition with vector conditioning (SDXL)")
+            yy = (y if skip_uncond else torch.cat([y, uy])).float().contiguous()
+        if split_calls:
+            eng.unet_forward(x_in[:n_cond], ts[:n_cond], tensor.float().contiguous(), None if yy is None else yy[:n_cond], out=eps[:n_cond])
+            eng.unet_forward(x_in[n_cond:], ts[n_cond:], uncond.float().contiguous(), None if yy is None else yy[n_cond:], out=eps[n_cond:])
+            self._ctx_key = None
+        else:
+            self._ensure_context([tensor] if skip_uncond else [tensor, uncond])
+            eng.unet_forward(x_in, ts, None, yy, out=eps)
+
+        # ---- combine (:73-82, :270-290).  The fused kernel takes eps = [cond(B) | uncond(B)]; the general cases are reduced to it
+        # by first forming, per image, E = (1 - s*sum(w)) * eps_u + sum_j s*w_j * eps_cj (the same affine map commutes with the
+        # wrapper's out * c_out + x * c_skip because the coefficients sum to 1) and handing it over as both halves with scale 1.
+        scale = float(cond_scale * self.cond_scale_miltiplier)
+        if conds_list is None and not skip_uncond:
+            pair = eps
+        else:
+            if self._comb is None:
+                self._comb = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
+            pair = self._comb
+            first = [i for i in range(b)] if conds_list is None else [cl[0][0] for cl in conds_list]
+            cl_all = conds_list if conds_list is not None else [[(i, 1.0)] for i in range(b)]
+            s_eff = 1.0 if skip_uncond else scale
+            for i, cl in enumerate(cl_all):
+                unc = eps[first[i]] if skip_uncond else eps[n_cond + i]          # skipped: the first prompt's output stands in (:272)
+                pair[b + i].copy_(unc)
+                terms, coefs = [unc], [1.0 - s_eff * sum(float(wt) for _, wt in cl)]
+                for ci, wt in cl:
+                    terms.append(eps[ci])
+                    coefs.append(s_eff * float(wt))
+                _lc_long(terms, coefs, out=pair[i])
+            pair[b:].copy_(pair[:b])
+            scale = 1.0
+            if self.need_last_noise_uncond:
+                self.last_noise_uncond = torch.stack([(eps[first[i]] if skip_uncond else eps[n_cond + i]) for i in range(b)])
+        if self.need_last_noise_uncond and pair is eps:
+            self.last_noise_uncond = eps[b:2 * b].clone()
         den = torch.empty_like(x)
         use_mask = (not self.mask_before_denoising) and self.mask is not None
         if c_skip_t is not None:
-            check(lib.sdmi_cfg_combine_affine(ptr(x), ptr(self._eps), ptr(c_out_t), ptr(c_skip_t),
-                                              float(cond_scale * self.cond_scale_miltiplier),
+            check(lib.sdmi_cfg_combine_affine(ptr(x), ptr(pair), ptr(c_out_t), ptr(c_skip_t), scale,
                                               ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
                                               ptr(self.init_latent) if use_mask else None, ptr(den), b, chw, stream_ptr()),
                   "cfg_combine_affine")
         else:
-            check(lib.sdmi_cfg_combine(ptr(x), ptr(self._eps), ptr(c_out_t), float(cond_scale * self.cond_scale_miltiplier), self.mode,
+            check(lib.sdmi_cfg_combine(ptr(x), ptr(pair), ptr(c_out_t), scale, self.mode,
                                        ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
                                        ptr(self.init_latent) if use_mask else None, ptr(den), b, chw, stream_ptr()), "cfg_combine")
         self.sampler.last_latent = den
@@ -727,9 +825,9 @@ class _DiscreteVP:
         raise ValueError(f"Unsupported skip_type {skip_type}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'")
 
 
-def _lc_long(terms, coefs):
+def _lc_long(terms, coefs, out=None):
     """sum_k coefs[k] * terms[k] for any number of terms (sdmi_lincomb takes six per launch)."""
-    out = torch.empty_like(terms[0])
+    out = torch.empty_like(terms[0]) if out is None else out
     _lc(out, terms[:6], coefs[:6])
     for k in range(6, len(terms), 5):
         _lc(out, [out, *terms[k:k + 5]], [1.0, *coefs[k:k + 5]])

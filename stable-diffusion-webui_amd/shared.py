@@ -29,7 +29,10 @@ class Options:
     sgm_noise_multiplier: bool = False             # :401
     use_old_karras_scheduler_sigmas: bool = False
     batch_cond_uncond: bool = True                 # :242
-    s_min_uncond: float = 0.0                      # :234
+    s_min_uncond: float = 0.0                      # :234  (NGMS: skip the negative prompt on alternate steps below this sigma)
+    s_min_uncond_all: bool = False                 # :235
+    pad_cond_uncond: bool = False                  # :239
+    pad_cond_uncond_v0: bool = False               # :240
     skip_early_cond: float = 0.0                   # :407
     img2img_extra_noise: float = 0.0
     img2img_fix_steps: bool = False

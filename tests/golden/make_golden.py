@@ -516,6 +516,120 @@ def gen_lcm():
     print("lcm.npz")
 
 
+CFG_SCENARIOS = [
+    # name, dict(b, conds_list | None, t_cond, t_uncond, cond_scale, s_min_uncond, sigma, step, total_steps, opts overrides, flags)
+    ("plain", dict()),
+    ("and", dict(conds_list=[[(0, 1.0), (1, 0.6)], [(2, 0.8)]])),
+    ("ngms_odd", dict(s_min_uncond=5.0, sigma=2.0, step=1)),
+    ("ngms_even", dict(s_min_uncond=5.0, sigma=2.0, step=2)),
+    ("ngms_all", dict(s_min_uncond=5.0, sigma=2.0, step=2, opts=dict(s_min_uncond_all=True))),
+    ("ngms_high_sigma", dict(s_min_uncond=1.0, sigma=2.0, step=1)),
+    ("skip_early", dict(step=1, total_steps=10, opts=dict(skip_early_cond=0.3))),
+    ("skip_early_and", dict(step=0, total_steps=10, opts=dict(skip_early_cond=0.3), conds_list=[[(0, 1.0), (1, 0.6)], [(2, 0.8)]])),
+    ("mask_after", dict(mask=True)),
+    ("mask_before", dict(mask=True, mask_before=True)),
+    ("long_cond", dict(t_cond=16, t_uncond=8)),
+    ("long_uncond", dict(t_cond=8, t_uncond=24)),
+    ("long_cond_pad", dict(t_cond=16, t_uncond=8, opts=dict(pad_cond_uncond=True))),
+    ("long_uncond_pad", dict(t_cond=8, t_uncond=24, opts=dict(pad_cond_uncond=True))),
+    ("long_cond_pad_v0", dict(t_cond=16, t_uncond=8, opts=dict(pad_cond_uncond_v0=True))),
+    ("long_uncond_pad_v0", dict(t_cond=8, t_uncond=24, opts=dict(pad_cond_uncond_v0=True))),
+    ("cfgpp", dict(need_last_noise_uncond=True, cond_scale_miltiplier=1 / 12.5)),
+    ("no_batch", dict(opts=dict(batch_cond_uncond=False))),
+    ("edit", dict(edit=True, image_cfg_scale=1.5)),
+    ("edit_scale_1", dict(edit=True, image_cfg_scale=1.0, conds_list=[[(0, 1.0), (1, 0.6)], [(2, 0.8)]])),
+]
+
+
+def cfg_scenario_inputs(k, sc):
+    """Seeded inputs of CFG scenario k (shared by the generator and the tests)."""
+    b, c, hw, dim = 2, 4, 8, 6
+    conds_list = sc.get("conds_list") or [[(i, 1.0)] for i in range(b)]
+    n_cond = sum(len(x) for x in conds_list)
+    return dict(
+        x=seeded((b, c, hw, hw), 5000 + 10 * k), conds_list=conds_list,
+        cond=seeded((n_cond, sc.get("t_cond", 8), dim), 5001 + 10 * k, 0.5),
+        uncond=seeded((b, sc.get("t_uncond", 8), dim), 5002 + 10 * k, 0.5),
+        image_cond=seeded((b, 4 if sc.get("edit") else 5, hw, hw), 5003 + 10 * k), init_latent=seeded((b, c, hw, hw), 5004 + 10 * k),
+        mask=(seeded((b, 1, hw, hw), 5005 + 10 * k) > 0).float(), empty=seeded((1, 8, dim), 4999, 0.5),
+        sigma=torch.full((b,), float(sc.get("sigma", 3.0))))
+
+
+def cfg_inner_model(x_in, sigma_in, c_crossattn, c_concat):
+    """Analytic stand-in for the wrapped UNet: depends on every input, and on the token COUNT of the context."""
+    ctx = c_crossattn.sum(dim=(1, 2))[:, None, None, None]
+    # (the reference leaves c_concat at full length when it drops the uncond rows, :212-214 — only the matching rows are read)
+    return torch.tanh(0.5 * x_in + 0.2 * ctx + 0.1 * sigma_in[:, None, None, None]) + 0.05 * c_concat[:x_in.shape[0], :4] * x_in
+
+
+def gen_cfg_denoiser():
+    """Execute CFGDenoiser.forward (modules/sd_samplers_cfg_denoiser.py:156-311) with the webui modules it imports stubbed
+    (prompt_parser hands back the (conds_list, tensor) pair it is given; script callbacks are no-ops) over CFG_SCENARIOS:
+    plain CFG, AND composition, skip-uncond (NGMS / skip-early), inpainting mask before / after, cond / uncond of different
+    token counts with and without the two padding options, CFG++ bookkeeping, unbatched cond / uncond, InstructPix2Pix."""
+    mods = sys.modules.setdefault("modules", types.ModuleType("modules"))
+    pp = types.ModuleType("modules.prompt_parser")
+    pp.reconstruct_multicond_batch = lambda c, step: c
+    pp.reconstruct_cond_batch = lambda c, step: c
+    common = types.ModuleType("modules.sd_samplers_common")
+    common.InterruptedException = type("InterruptedException", (BaseException,), {})
+    common.apply_refiner = lambda cfg, sigma=None: False
+    common.store_latent = lambda x: None
+    shared = types.ModuleType("modules.shared")
+    shared.state = types.SimpleNamespace(interrupted=False, skipped=False, sampling_step=0, sampling_steps=20)
+    cb = types.ModuleType("modules.script_callbacks")
+
+    class _Params:
+        def __init__(self, *a, **kw):
+            names = {8: ["x", "image_cond", "sigma", "sampling_step", "total_sampling_steps", "text_cond", "text_uncond", "denoiser"],
+                     4: ["x", "sampling_step", "total_sampling_steps", "inner_model"], 3: ["x", "sampling_step", "total_sampling_steps"]}[len(a)]
+            for n, v in zip(names, a):
+                setattr(self, n, v)
+    cb.CFGDenoiserParams = cb.CFGDenoisedParams = cb.AfterCFGCallbackParams = _Params
+    cb.cfg_denoiser_callback = cb.cfg_denoised_callback = cb.cfg_after_cfg_callback = lambda params: None
+    for n, m in (("prompt_parser", pp), ("sd_samplers_common", common), ("shared", shared), ("script_callbacks", cb)):
+        sys.modules["modules." + n] = m
+        setattr(mods, n, m)
+    out = {}
+    for k, (name, sc) in enumerate(CFG_SCENARIOS):
+        base = dict(skip_early_cond=0.0, s_min_uncond_all=False, pad_cond_uncond=False, pad_cond_uncond_v0=False,
+                    batch_cond_uncond=True, live_preview_content="Prompt")
+        base.update(sc.get("opts", {}))
+        shared.opts = types.SimpleNamespace(**base)
+        inp = cfg_scenario_inputs(k, sc)
+        shared.sd_model = types.SimpleNamespace(cond_stage_key="edit" if sc.get("edit") else "txt",
+                                                model=types.SimpleNamespace(conditioning_key="hybrid"),
+                                                cond_stage_model_empty_prompt=inp["empty"])
+        ref = load_by_path("ref_cfg_denoiser", "modules/sd_samplers_cfg_denoiser.py")       # re-imported: binds this opts object
+
+        class D(ref.CFGDenoiser):
+            @property
+            def inner_model(self):
+                return lambda x_in, sigma_in, cond: cfg_inner_model(x_in, sigma_in, cond["c_crossattn"][0], cond["c_concat"][0])
+
+        d = D(types.SimpleNamespace(last_latent=None, sampler_extra_args={}))
+        d.p = types.SimpleNamespace(extra_generation_params={}, scripts=None)
+        d.step, d.total_steps = sc.get("step", 0), sc.get("total_steps", 20)
+        d.image_cfg_scale = sc.get("image_cfg_scale")
+        d.cond_scale_miltiplier = sc.get("cond_scale_miltiplier", 1.0)
+        d.need_last_noise_uncond = sc.get("need_last_noise_uncond", False)
+        d.mask_before_denoising = sc.get("mask_before", False)
+        if sc.get("mask") or sc.get("edit"):
+            d.init_latent = inp["init_latent"]
+        if sc.get("mask"):
+            d.mask, d.nmask = inp["mask"], 1.0 - inp["mask"]
+        res = d.forward(inp["x"].clone(), inp["sigma"], inp["uncond"].clone(), (inp["conds_list"], inp["cond"].clone()), 7.0,
+                        sc.get("s_min_uncond", 0.0), inp["image_cond"])
+        out[f"{name}_denoised"] = res.numpy()
+        out[f"{name}_last_latent"] = d.sampler.last_latent.numpy()
+        out[f"{name}_flags"] = np.array([d.padded_cond_uncond, d.padded_cond_uncond_v0, d.step,
+                                         "NGMS" in d.p.extra_generation_params, "Skip Early CFG" in d.p.extra_generation_params], dtype=np.int64)
+        if d.need_last_noise_uncond:
+            out[f"{name}_last_noise_uncond"] = d.last_noise_uncond.numpy()
+    np.savez_compressed(os.path.join(OUT, "cfg_denoiser.npz"), **out)
+    print("cfg_denoiser.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -528,3 +642,4 @@ if __name__ == "__main__":
     gen_restart()
     gen_unipc()
     gen_lcm()
+    gen_cfg_denoiser()

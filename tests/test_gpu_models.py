@@ -380,6 +380,86 @@ def test_v_prediction_model_vs_oracle(dev, sampler, name, steps):
     assert rel_l2(got.cpu(), eps_lat) > 5e-2                 # and it is not the eps-parameterised answer
 
 
+CFG_VARIANTS = {
+    # name: (conds_list, T_cond, T_uncond, s_min_uncond, step, opts)
+    "and": ([[(0, 1.0), (1, 0.6)], [(2, 0.8)]], 77, 77, 0.0, 0, {}),
+    "weight": ([[(0, 1.3)], [(1, 0.7)]], 77, 77, 0.0, 0, {}),
+    "ngms_odd": (None, 77, 77, 5.0, 1, {}),
+    "ngms_even": (None, 77, 77, 5.0, 2, {}),
+    "ngms_all": (None, 77, 77, 5.0, 2, {"s_min_uncond_all": True}),
+    "skip_early_and": ([[(0, 1.0), (1, 0.6)], [(2, 0.8)]], 77, 77, 0.0, 1, {"skip_early_cond": 0.3}),
+    "long_cond": (None, 154, 77, 0.0, 0, {}),
+    "long_uncond": (None, 77, 231, 0.0, 0, {}),
+    "long_cond_pad": (None, 154, 77, 0.0, 0, {"pad_cond_uncond": True}),
+    "long_uncond_pad_v0": (None, 77, 231, 0.0, 0, {"pad_cond_uncond_v0": True}),
+    "long_cond_skip": (None, 154, 77, 5.0, 1, {}),
+}
+
+
+@pytest.mark.parametrize("mode", ["sigma", "timestep"])
+@pytest.mark.parametrize("variant", sorted(CFG_VARIANTS))
+def test_cfg_denoiser_variants_vs_oracle(dev, tiny, variant, mode):
+    """One CFGDenoiser.forward per scenario of modules/sd_samplers_cfg_denoiser.py:156-311 beyond plain CFG — AND composition,
+    prompt weights, skip-uncond (NGMS odd / even / all steps, skip-early), cond / uncond of different token counts (two UNet
+    calls; the two padding options) — in sigma space (k-diffusion samplers) and timestep space (DDIM family), against the
+    oracle's CFGDenoiser (itself pinned to the reference class by tests/golden/cfg_denoiser.npz)."""
+    from oracle import kdiffusion as okd
+    ss, shared = sub("sd_samplers"), sub("shared")
+    conds_list, t_c, t_u, s_min, step, o = CFG_VARIANTS[variant]
+    model, om = tiny["model"], tiny["oracle"]
+    b = 2
+    g = torch.Generator().manual_seed(321)
+    n_cond = b if conds_list is None else sum(len(c) for c in conds_list)
+    cond, uncond = torch.randn(n_cond, t_c, 64, generator=g), torch.randn(b, t_u, 64, generator=g)
+    empty = torch.randn(1, 77, 64, generator=g)
+    x = seeded((b, 4, 16, 16), 77) * 2.0
+    sig = 2.0 if mode == "sigma" else 401.0
+    if mode == "timestep" and s_min > 0:
+        s_min = 500.0                                         # there "sigma" is the timestep the threshold is compared with
+    sigma = torch.full((b,), sig)
+    keep = {k: getattr(shared.opts, k) for k in o}
+    model.cond_stage_model_empty_prompt = empty.to(dev)
+    try:
+        for k, v in o.items():
+            setattr(shared.opts, k, v)
+        sampler = ss.create_sampler("Euler a" if mode == "sigma" else "DDIM", model)
+        cfg = sampler.model_wrap_cfg
+        cfg.step, cfg.total_steps = step, 10
+        c_arg = cond.to(dev) if conds_list is None else (conds_list, cond.to(dev))
+        got = cfg(x.to(dev), sigma.to(dev), uncond.to(dev), c_arg, 7.0, s_min_uncond=s_min)
+        torch.cuda.synchronize()
+    finally:
+        for k, v in keep.items():
+            setattr(shared.opts, k, v)
+    if mode == "sigma":
+        inner = okd.CompVisDenoiser(lambda xi, t, c: om.apply_model(xi, t, c), om.alphas_cumprod)
+    else:
+        inner = lambda xi, t, c: om.apply_model(xi, t, c)
+    oc = okd.CFGDenoiser(inner)
+    oc.step, oc.total_steps, oc.empty_prompt = step, 10, empty
+    for k, v in o.items():
+        setattr(oc, k, v)
+    c_arg = cond if conds_list is None else (conds_list, cond)
+    want = oc(x, sigma, uncond, c_arg, 7.0, s_min_uncond=s_min)
+    assert oc.skipped_uncond == (variant in ("ngms_odd", "ngms_all", "skip_early_and", "long_cond_skip"))
+    assert rel_l2(got.cpu(), want) < 1e-2, (variant, mode)
+    assert cfg.step == step + 1 and cfg.padded_cond_uncond == oc.padded_cond_uncond and cfg.padded_cond_uncond_v0 == oc.padded_cond_uncond_v0
+
+
+def test_txt2img_ngms_end_to_end_vs_oracle(dev, tiny):
+    """p.s_min_uncond reaches the denoiser through sampler_extra_args (modules/sd_samplers_kdiffusion.py:197-203): alternate
+    low-sigma steps run the UNet on the cond rows only."""
+    from oracle import pipeline as opipe
+    processing = sub("processing")
+    cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=1000, batch_size=2, steps=6,
+                                                    cfg_scale=7.0, width=128, height=128, sampler_name="Euler a", s_min_uncond=20.0)
+    res = processing.process_images(p)
+    lat = opipe.sample(tiny["oracle"], cond, uncond, [1000, 1001], 6, "euler_a", 7.0, (16, 16), s_min_uncond=20.0)
+    plain = opipe.sample(tiny["oracle"], cond, uncond, [1000, 1001], 6, "euler_a", 7.0, (16, 16))
+    assert rel_l2(res.latents.cpu(), lat) < 1e-2 and rel_l2(plain, lat) > 5e-2
+
+
 def test_txt2img_batch_split_matches(dev, tiny):
     """Sharding contract of the multi-GPU runner: images [0,4) generated as 4, as 2+2 (n_iter) or as the tail pair are the
     same images — per-image Philox streams (modules/rng.py:108) + per-image arithmetic everywhere.  Bitwise when the per-call

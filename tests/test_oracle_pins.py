@@ -215,6 +215,48 @@ def test_lcm_matches_reference(golden_dir):
         np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
 
 
+def _golden_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_cfg_denoiser_matches_reference(golden_dir):
+    """oracle CFGDenoiser == the reference class (modules/sd_samplers_cfg_denoiser.py:35-311) executed by make_golden over twenty
+    scenarios: plain CFG, AND composition, NGMS / skip-early skip-uncond (odd, even, all steps, sigma above the threshold, with
+    AND), mask before / after, cond and uncond of different token counts (two calls, pad_cond_uncond, pad_cond_uncond_v0, both
+    directions), CFG++ bookkeeping, unbatched cond / uncond, InstructPix2Pix three-way CFG and its scale-1 fallback."""
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "cfg_denoiser.npz"))
+    assert len(mg.CFG_SCENARIOS) == 20
+    for k, (name, sc) in enumerate(mg.CFG_SCENARIOS):
+        inp = mg.cfg_scenario_inputs(k, sc)
+        d = kd.CFGDenoiser(lambda xi, si, c, ic: mg.cfg_inner_model(xi, si, c, ic))
+        for key, val in sc.get("opts", {}).items():
+            if key != "batch_cond_uncond":
+                setattr(d, key, val)
+        d.empty_prompt, d.step, d.total_steps = inp["empty"], sc.get("step", 0), sc.get("total_steps", 20)
+        d.image_cfg_scale, d.is_edit_cond_stage = sc.get("image_cfg_scale"), bool(sc.get("edit"))
+        d.cond_scale_miltiplier = sc.get("cond_scale_miltiplier", 1.0)
+        d.need_last_noise_uncond = sc.get("need_last_noise_uncond", False)
+        d.mask_before_denoising = sc.get("mask_before", False)
+        if sc.get("mask") or sc.get("edit"):
+            d.init_latent = inp["init_latent"]
+        if sc.get("mask"):
+            d.mask, d.nmask = inp["mask"], 1 - inp["mask"]
+        out = d(inp["x"].clone(), inp["sigma"], inp["uncond"], (inp["conds_list"], inp["cond"]), 7.0, sc.get("s_min_uncond", 0.0),
+                inp["image_cond"])
+        fl = z[name + "_flags"]
+        np.testing.assert_allclose(out.numpy(), z[name + "_denoised"], rtol=0, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(d.last_latent.numpy(), z[name + "_last_latent"], rtol=0, atol=1e-6, err_msg=name)
+        assert (int(d.padded_cond_uncond), int(d.padded_cond_uncond_v0), d.step) == tuple(fl[:3]), name
+        assert d.skipped_uncond == bool(fl[3] or fl[4]), name
+        if d.need_last_noise_uncond:
+            np.testing.assert_allclose(d.last_noise_uncond.numpy(), z[name + "_last_noise_uncond"], rtol=0, atol=1e-6)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
