@@ -131,6 +131,14 @@ int sdmi_philox_randn(void* out_f32, int64_t n, uint64_t seed, uint32_t offset, 
 int sdmi_cfg_prepare_input(const void* x_f32, const void* c_in_f32, void* x_in, int out_dtype,
                            int B, int reps, int64_t chw, void* stream);
 
+/* The same for checkpoints whose UNet input is cat([x, c_concat], dim=1) — inpainting (9 channels: x | mask | masked-image
+ * latent) and InstructPix2Pix (8: x | image latent); ldm's DiffusionWrapper does the cat for conditioning_key "hybrid" /
+ * "concat", fed by make_condition_dict at modules/sd_samplers_cfg_denoiser.py:193-209:
+ *   x_in[r*B + b, 0:C] = x[b] * c_in[b],   x_in[r*B + b, C:C+Cc] = c_concat[b]   (zeros when bit r of zero_reps is set:
+ *   the third, image-unconditional group of the edit model, :209).  x [B,C,h,w], c_concat [B,Cc,h,w] fp32, hw = h*w. */
+int sdmi_cfg_prepare_concat(const void* x_f32, const void* c_in_f32, const void* c_concat_f32, void* x_in, int out_dtype,
+                            int B, int reps, int C, int Cc, int64_t hw, uint32_t zero_reps, void* stream);
+
 /* denoised[b] = u + (c - u) * cond_scale  with  c = x + eps_c * c_out[b], u = x + eps_u * c_out[b]
  * (eps = [cond(B) | uncond(B)], fp32 NCHW).  Replaces CompVisDenoiser's `input + eps * c_out` and
  * CFGDenoiser.combine_denoised (modules/sd_samplers_cfg_denoiser.py:74-82) for one cond of weight 1 per image.

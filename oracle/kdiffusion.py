@@ -101,9 +101,16 @@ class CompVisDenoiser(DiscreteSchedule):
         c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
         return c_out, c_in
 
-    def __call__(self, input, sigma, cond):
+    def _eps(self, x_scaled, t, cond, image_cond):
+        """apply_model; ``image_cond`` is the c_concat the model concatenates to its (already scaled) input along the
+        channels (ldm DiffusionWrapper, conditioning_key "hybrid" / "concat"; fed from sd_samplers_cfg_denoiser.py:193-209)."""
+        if image_cond is None:
+            return self.apply_model(x_scaled, t, cond)
+        return self.apply_model(x_scaled, t, cond, image_cond)
+
+    def __call__(self, input, sigma, cond, image_cond=None):
         c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
-        eps = self.apply_model(input * c_in, self.sigma_to_t(sigma), cond)
+        eps = self._eps(input * c_in, self.sigma_to_t(sigma), cond, image_cond)
         return input + eps * c_out
 
 
@@ -117,9 +124,9 @@ class CompVisVDenoiser(CompVisDenoiser):
         c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
         return c_skip, c_out, c_in
 
-    def __call__(self, input, sigma, cond):
+    def __call__(self, input, sigma, cond, image_cond=None):
         c_skip, c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
-        return self.apply_model(input * c_in, self.sigma_to_t(sigma), cond) * c_out + input * c_skip
+        return self._eps(input * c_in, self.sigma_to_t(sigma), cond, image_cond) * c_out + input * c_skip
 
 
 class LCMCompVisDenoiser(CompVisDenoiser):
@@ -155,9 +162,9 @@ class LCMCompVisDenoiser(CompVisDenoiser):
         c_out = scaled_timestep / (scaled_timestep ** 2 + sigma_data ** 2) ** 0.5
         return c_out * output + c_skip * input
 
-    def __call__(self, input, sigma, cond):
+    def __call__(self, input, sigma, cond, image_cond=None):
         c_out, c_in = [append_dims(x, input.ndim) for x in self.get_scalings(sigma)]
-        eps = self.apply_model(input * c_in, self.sigma_to_t(sigma), cond)
+        eps = self._eps(input * c_in, self.sigma_to_t(sigma), cond, image_cond)
         return self.get_scaled_out(sigma, input + eps * c_out, input)
 
 

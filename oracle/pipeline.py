@@ -58,19 +58,28 @@ def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, schedul
 def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
            latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
            y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None, parameterization="eps",
-           s_min_uncond=0.0):
+           s_min_uncond=0.0, image_cond=None, image_cfg_scale=None, noise_multiplier=1.0):
     """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
     (modules/sd_samplers_kdiffusion.py:134-143); ``mask`` (1 = keep the original latent) adds the inpainting blends of
     modules/sd_samplers_cfg_denoiser.py:186-187 / 292-293 and the final blend of modules/processing.py:1776-1784."""
     b = len(seeds)
     rng = ImageRNG((4, latent_hw[0], latent_hw[1]), seeds)
     x = rng.next()
+    if init_latent is not None and noise_multiplier != 1.0:      # modules/processing.py:1762-1764 (img2img only)
+        x = x * noise_multiplier
     nmask = None if mask is None else 1.0 - mask
 
-    def apply_model(xi, t, c):
+    def apply_model(xi, t, c, ic=None):
+        if ic is not None:                       # inpainting / edit checkpoints: the UNet input is cat([x, c_concat], dim=1)
+            xi = torch.cat([xi, ic], dim=1)
         if y is not None:
             return model.apply_model(xi, t, c, y if xi.shape[0] == y.shape[0] else torch.cat([y, uy]))   # cond rows only: uncond skipped
         return model.apply_model(xi, t, c)
+
+    def _edit(cfg):                              # InstructPix2Pix: cond_stage_key "edit" + p.image_cfg_scale (cfg_denoiser.py:166)
+        if image_cfg_scale is not None:
+            cfg.is_edit_cond_stage, cfg.image_cfg_scale = True, image_cfg_scale
+            cfg.init_latent = init_latent if init_latent is not None else torch.zeros_like(x)
 
     def finish(samples):
         if mask is not None:
@@ -80,13 +89,14 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
     if sampler in ("ddim", "plms", "ddim_cfgpp", "unipc"):
         # CFGDenoiserTimesteps: inner model is apply_model on integer timesteps, CFG combines eps.
         if parameterization == "v":
-            inner = lambda xi, ti, ci: kd.timesteps_v_to_eps(model.alphas_cumprod, xi, ti, apply_model(xi, ti, ci))
+            inner = lambda xi, ti, ci, ic=None: kd.timesteps_v_to_eps(model.alphas_cumprod, xi, ti, apply_model(xi, ti, ci, ic))
         else:
-            inner = lambda xi, ti, ci: apply_model(xi, ti, ci)
+            inner = lambda xi, ti, ci, ic=None: apply_model(xi, ti, ci, ic)
         cfg = kd.CFGDenoiser(inner, mask, nmask, init_latent)
         cfg.mask_before_denoising = True
+        _edit(cfg)
         ts = kd.ddim_timesteps(steps)
-        extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond)
+        extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond, image_cond=image_cond)
         if init_latent is not None:
             total, t_enc = kd.setup_img2img_steps(steps, denoising_strength, img2img_steps_given)
             ts = kd.ddim_timesteps(total)
@@ -109,7 +119,8 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
     else:
         wrap = (kd.CompVisVDenoiser if parameterization == "v" else kd.CompVisDenoiser)(apply_model, model.alphas_cumprod)
     cfg = kd.CFGDenoiser(wrap, mask, nmask, init_latent)
-    extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond)
+    _edit(cfg)
+    extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond, image_cond=image_cond)
     if init_latent is None:
         sigmas = get_sigmas(wrap, sampler, steps, scheduler)
         x = x * sigmas[0]
@@ -159,3 +170,35 @@ def txt2img_hires(model: OracleModel, cond, uncond, seeds, steps, sampler="euler
     up = torch.nn.functional.interpolate(first, size=(th, tw), mode=mode, antialias=False)
     return sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, (th, tw), init_latent=up,
                   denoising_strength=denoising_strength, img2img_steps_given=True)
+
+
+# ---- image conditioning of inpainting / edit checkpoints (c_concat) -------------------------------------------------------
+@torch.no_grad()
+def txt2img_image_conditioning(model: OracleModel, batch, height, width):
+    """modules/processing.py:100-111 for conditioning_key hybrid / concat: the "masked image" is all 0.5 (everything masked),
+    encoded (images_tensor_to_samples, modules/sd_samplers_common.py:96-113: image * 2 - 1 -> first stage; posterior mean
+    here), with a mask channel of ones in front."""
+    image = torch.ones(batch, 3, height, width) * 0.5
+    latent = model.vae.encode_first_stage_mean(image * 2 - 1)
+    return torch.nn.functional.pad(latent, (0, 0, 0, 0, 1, 0), value=1.0)
+
+
+@torch.no_grad()
+def inpainting_image_conditioning(model: OracleModel, source_image, latent_hw, image_mask=None, mask_weight=1.0, round_image_mask=True):
+    """modules/processing.py:332-374.  ``source_image`` [B,3,H,W] in [-1,1]; ``image_mask`` [1,1,H,W] in [0,1] (1 = repaint)."""
+    if image_mask is not None:
+        conditioning_mask = torch.round(image_mask) if round_image_mask else image_mask
+    else:
+        conditioning_mask = source_image.new_ones(1, 1, *source_image.shape[-2:])
+    conditioning_image = torch.lerp(source_image, source_image * (1.0 - conditioning_mask), mask_weight)
+    conditioning_image = model.vae.encode_first_stage_mean(conditioning_image)
+    conditioning_mask = torch.nn.functional.interpolate(conditioning_mask, size=latent_hw)
+    conditioning_mask = conditioning_mask.expand(conditioning_image.shape[0], -1, -1, -1)
+    return torch.cat([conditioning_mask, conditioning_image], dim=1)
+
+
+@torch.no_grad()
+def edit_image_conditioning(model: OracleModel, source_image):
+    """modules/processing.py:321-324: the UNSCALED posterior mode of the source image."""
+    mean, _ = torch.chunk(model.vae.encode_moments(source_image), 2, dim=1)
+    return mean

@@ -71,7 +71,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 _SIGS = {
     "sdmi_version": (C.c_int, []),
     "sdmi_last_error": (C.c_char_p, []),
@@ -88,6 +88,7 @@ _SIGS = {
     "sdmi_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "sdmi_philox_randn": (_i, [_vp, _i64, C.c_uint64, C.c_uint32, _vp]),
     "sdmi_cfg_prepare_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
+    "sdmi_cfg_prepare_concat": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _u32, _vp]),
     "sdmi_cfg_combine": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "sdmi_cfg_combine_affine": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "sdmi_euler_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),

@@ -170,6 +170,16 @@ int sdmi_cfg_prepare_input(const void* x, const void* c_in, void* x_in, int out_
     API_GUARD_END
 }
 
+int sdmi_cfg_prepare_concat(const void* x, const void* c_in, const void* c_concat, void* x_in, int out_dtype, int B, int reps,
+                            int C, int Cc, int64_t hw, uint32_t zero_reps, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(x && c_concat && x_in, "null pointer");
+    SDMI_REQUIRE(B > 0 && reps > 0 && reps <= 32 && C > 0 && Cc > 0 && hw > 0, "bad sizes");
+    return launch_cfg_prepare_concat((const float*)x, (const float*)c_in, (const float*)c_concat, x_in, out_dtype, B, reps, C, Cc, hw,
+                                     zero_reps, (hipStream_t)stream);
+    API_GUARD_END
+}
+
 int sdmi_cfg_combine(const void* x, const void* eps, const void* c_out, float cond_scale, int mode, const void* mask,
                      const void* nmask, const void* init_latent, void* den, int B, int64_t chw, void* stream) {
     API_GUARD_BEGIN

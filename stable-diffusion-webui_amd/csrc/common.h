@@ -115,6 +115,8 @@ int launch_layernorm(const half_t* x, const float* gamma, const float* beta, hal
 // ---- elementwise / misc -----------------------------------------------------------------------------------
 int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t offset, hipStream_t s);
 int launch_cfg_prepare(const float* x, const float* c_in, void* xin, int out_dtype, int B, int reps, int64_t chw, hipStream_t s);
+int launch_cfg_prepare_concat(const float* x, const float* c_in, const float* cond, void* xin, int out_dtype, int B, int reps,
+                              int C, int Cc, int64_t hw, unsigned zero_reps, hipStream_t s);
 int launch_cfg_combine(const float* x, const float* eps, const float* c_out, float cond_scale, int mode,
                        const float* mask, const float* nmask, const float* init_latent, float* den, int B,
                        int64_t chw, hipStream_t s);

@@ -79,6 +79,35 @@ int launch_cfg_prepare(const float* x, const float* c_in, void* xin, int out_dty
     return 0;
 }
 
+// x_in rows of a UNet whose input is cat([x, c_concat], dim=1) (inpainting / InstructPix2Pix checkpoints): row r*B+b holds
+// x[b]*c_in[b] in channels [0,C) and cond[b] in channels [C,C+Cc) — zeros there for the repetitions named in zero_reps.
+template <typename TO>
+__global__ __launch_bounds__(256) void cfg_prepare_concat_kernel(const float* x, const float* c_in, const float* cond, TO* xin,
+                                                                int B, int reps, int C, int Cc, long hw, unsigned zero_reps) {
+    const long per = (long)(C + Cc) * hw, n = (long)B * per;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / per);
+        const long rem = i - (long)b * per;
+        const int ch = (int)(rem / hw);
+        const long px = rem - (long)ch * hw;
+        const bool is_x = ch < C;
+        const float v = is_x ? x[((long)b * C + ch) * hw + px] * (c_in ? c_in[b] : 1.0f) : cond[((long)b * Cc + (ch - C)) * hw + px];
+        for (int r = 0; r < reps; ++r) xin[(long)r * n + i] = (TO)((!is_x && ((zero_reps >> r) & 1u)) ? 0.0f : v);
+    }
+}
+int launch_cfg_prepare_concat(const float* x, const float* c_in, const float* cond, void* xin, int out_dtype, int B, int reps,
+                              int C, int Cc, int64_t hw, unsigned zero_reps, hipStream_t s) {
+    const int64_t n = (int64_t)B * (C + Cc) * hw;
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(cfg_prepare_concat_kernel<half_t>, dim3(ew_blocks(n)), dim3(256), 0, s, x, c_in, cond, (half_t*)xin, B, reps, C, Cc,
+                           (long)hw, zero_reps);
+    else
+        hipLaunchKernelGGL(cfg_prepare_concat_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, s, x, c_in, cond, (float*)xin, B, reps, C, Cc,
+                           (long)hw, zero_reps);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void cfg_combine_kernel(const float* x, const float* eps, const float* c_out, float cond_scale,
                                                          int mode, const float* mask, const float* nmask, const float* init,
                                                          float* den, int B, long chw) {

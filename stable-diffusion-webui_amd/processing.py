@@ -52,6 +52,8 @@ class StableDiffusionProcessing:
     s_noise: float = None
     sampler_noise_scheduler_override: Any = None
     is_hr_pass: bool = False
+    inpainting_mask_weight: float = None              # opts.inpainting_mask_weight ("Conditional mask weight")
+    is_using_inpainting_conditioning: bool = False
     # runtime
     sampler: Any = None
     rng: Any = None
@@ -72,6 +74,59 @@ class StableDiffusionProcessing:
 
     def init(self, all_prompts, all_seeds, all_subseeds):
         pass
+
+    # ---- image conditioning (c_concat) of inpainting / edit checkpoints: modules/processing.py:100-133, 298-393 -------------
+    def _conditioning_key(self):
+        return getattr(getattr(self.sd_model, "model", None), "conditioning_key", "crossattn")
+
+    def txt2img_image_conditioning(self, x, width=None, height=None):
+        """:100-133, 298-301.  Inpainting checkpoints: everything is masked, so the "masked image" is flat 0.5, encoded, behind a
+        mask channel of ones; ordinary checkpoints get the reference's dummy [B,5,1,1] zeros (never read)."""
+        b = x.shape[0]
+        if self._conditioning_key() in {'hybrid', 'concat'} or getattr(self.sd_model, "is_sdxl_inpaint", False):
+            self.is_using_inpainting_conditioning = self._conditioning_key() in {'hybrid', 'concat'}
+            # image size = latent size x the first stage's downscale (= width / height for the real 8x VAE; test VAEs are shallower)
+            f = 2 ** (len(self.sd_model.vae_cfg.ch_mult) - 1)
+            image = torch.zeros((b, 3, x.shape[2] * f, x.shape[3] * f), dtype=torch.float32, device=x.device)   # 0.5 * 2 - 1
+            latent = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(image))
+            ones = torch.ones((b, 1, *latent.shape[2:]), dtype=torch.float32, device=x.device)
+            return torch.cat([ones, latent], dim=1).contiguous()
+        return x.new_zeros(b, 5, 1, 1)
+
+    def inpainting_image_conditioning(self, source_image, latent_image, image_mask=None, round_image_mask=True):
+        """:332-374.  ``source_image`` [B,3,H,W] in [-1,1] on the device; ``image_mask`` a float tensor [1,1,H,W] in [0,1]
+        (1 = repaint).  c_concat = cat([mask at latent size (nearest), encode(lerp(image, image * (1 - mask), weight))])."""
+        self.is_using_inpainting_conditioning = True
+        dev = source_image.device
+        if image_mask is not None:
+            conditioning_mask = image_mask.to(dev, torch.float32).reshape(-1, 1, *image_mask.shape[-2:])
+            if round_image_mask:
+                conditioning_mask = torch.round(conditioning_mask)
+        else:
+            conditioning_mask = source_image.new_ones(1, 1, *source_image.shape[-2:])
+        weight = self.inpainting_mask_weight if self.inpainting_mask_weight is not None else shared.opts.inpainting_mask_weight
+        # lerp(s, s * (1 - m), w) = s * (1 - w * m): one blend launch with keep = 1 - w * m
+        keep = ops.lincomb(torch.empty_like(conditioning_mask), [torch.ones_like(conditioning_mask), conditioning_mask.contiguous()],
+                           [1.0, -float(weight)])
+        zeros = torch.zeros_like(source_image)
+        conditioning_image = ops.mask_blend(source_image.clone().contiguous(), zeros, zeros, keep.expand_as(source_image))
+        conditioning_image = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(conditioning_image))
+        conditioning_mask = ops.latent_resize(conditioning_mask.contiguous(), tuple(latent_image.shape[-2:]), "nearest")
+        conditioning_mask = conditioning_mask.expand(conditioning_image.shape[0], -1, -1, -1)
+        return torch.cat([conditioning_mask, conditioning_image], dim=1).contiguous()
+
+    def edit_image_conditioning(self, source_image):
+        """:321-324: InstructPix2Pix conditions on the UNSCALED posterior mode of the source image."""
+        mean, _ = torch.chunk(self.sd_model.encode_first_stage(source_image), 2, dim=1)
+        return mean.contiguous()
+
+    def img2img_image_conditioning(self, source_image, latent_image, image_mask=None, round_image_mask=True):
+        """:376-393 (depth2img and unCLIP checkpoints are not on the path)."""
+        if getattr(self.sd_model, "cond_stage_key", "txt") == "edit":
+            return self.edit_image_conditioning(source_image)
+        if self._conditioning_key() in {'hybrid', 'concat'} or getattr(self.sd_model, "is_sdxl_inpaint", False):
+            return self.inpainting_image_conditioning(source_image, latent_image, image_mask=image_mask, round_image_mask=round_image_mask)
+        return latent_image.new_zeros(latent_image.shape[0], 5, 1, 1)
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
         raise NotImplementedError()
@@ -96,7 +151,8 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         """modules/processing.py:1307-1362"""
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
         x = self.rng.next()
-        samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning, image_conditioning=None)
+        samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning,
+                                      image_conditioning=self.txt2img_image_conditioning(x))
         del x
         if not self.enable_hr:
             return samples
@@ -114,13 +170,19 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         target_h = self.hr_resize_y or int(self.height * self.hr_scale)
         # K16: [B,4,h,w] resample = F.interpolate(..., mode, antialias=False) (modules/processing.py:1392)
         samples = ops.latent_resize(samples, (target_h // opt_f, target_w // opt_f), mode)
+        # :1395-1399 (at the default mask weight 1.0 the hires pass of an inpainting checkpoint is conditioned like txt2img)
+        weight = self.inpainting_mask_weight if self.inpainting_mask_weight is not None else shared.opts.inpainting_mask_weight
+        if weight < 1.0 and self._conditioning_key() in {'hybrid', 'concat'}:
+            image_conditioning = self.img2img_image_conditioning(self.sd_model.decode_first_stage(samples), samples)
+        else:
+            image_conditioning = self.txt2img_image_conditioning(samples, target_w, target_h)
         self.rng = ImageRNG(samples.shape[1:], self.seeds, eta_noise_seed_delta=shared.opts.eta_noise_seed_delta,
                             device=samples.device)
         noise = self.rng.next()
         name = self.hr_sampler_name or self.sampler_name
         self.sampler = sd_samplers.create_sampler(name, self.sd_model)
         samples = self.sampler.sample_img2img(self, samples.contiguous(), noise, conditioning, unconditional_conditioning,
-                                              steps=self.hr_second_pass_steps or self.steps, image_conditioning=None)
+                                              steps=self.hr_second_pass_steps or self.steps, image_conditioning=image_conditioning)
         self.is_hr_pass = False
         return samples
 
@@ -130,15 +192,38 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
     init_images: Any = None                       # float tensor [N,3,H,W] in [0,1] (the reference builds it at :1700-1728)
     denoising_strength: float = 0.75
     latent_mask: Optional[torch.Tensor] = None    # [N,4,h,w] latent-space mask (1 = keep original), optional
+    image_mask: Optional[torch.Tensor] = None     # [1,1,H,W] image-space mask in [0,1] (1 = repaint): conditions inpainting checkpoints
+    mask_round: bool = True
+    inpainting_fill: int = 1                      # 1 original, 2 latent noise, 3 latent nothing (0 "fill" is image-space: not here)
+    initial_noise_multiplier: float = None        # opts.initial_noise_multiplier
+    image_cfg_scale: float = None                 # InstructPix2Pix
     init_latent: Optional[torch.Tensor] = None
     mask: Optional[torch.Tensor] = None
     nmask: Optional[torch.Tensor] = None
+    image_conditioning_all: Optional[torch.Tensor] = None
 
     def init(self, all_prompts, all_seeds, all_subseeds):
-        """modules/processing.py:1602-1757 reduced to: image*2-1 -> VAE encode -> latent (posterior mean, deterministic)."""
-        image = self.init_images.to(self.sd_model.device, dtype=torch.float32) * 2.0 - 1.0
-        moments = self.sd_model.encode_first_stage(image.contiguous())
+        """modules/processing.py:1602-1757 from the point where the image tensor exists: image*2-1 -> VAE encode -> latent
+        (posterior mean, deterministic), the "masked content" fills 2 / 3 over the latent mask (:1747-1753) and the image
+        conditioning of inpainting / edit checkpoints (:1755)."""
+        if getattr(self.sd_model, "cond_stage_key", "txt") != "edit":
+            self.image_cfg_scale = None                                                    # :1605
+        if self.initial_noise_multiplier is None:
+            self.initial_noise_multiplier = shared.opts.initial_noise_multiplier
+        image = (self.init_images.to(self.sd_model.device, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+        moments = self.sd_model.encode_first_stage(image)
         self.init_latent_all = self.sd_model.get_first_stage_encoding(moments)
+        if self.latent_mask is not None and self.inpainting_fill in (2, 3):
+            dev = self.init_latent_all.device
+            keep = self.latent_mask.to(dev, torch.float32).expand_as(self.init_latent_all).contiguous()
+            if self.inpainting_fill == 2:         # init * mask + create_random_tensors(shape, all_seeds[:N]) * nmask
+                fill = ImageRNG(tuple(self.init_latent_all.shape[1:]), all_seeds[0:self.init_latent_all.shape[0]], device=dev).next()
+            else:                                 # init * mask
+                fill = torch.zeros_like(self.init_latent_all)
+            self.init_latent_all = ops.mask_blend(fill.contiguous(), self.init_latent_all, keep, (1.0 - keep).contiguous())
+        elif self.inpainting_fill not in (1, 2, 3):
+            raise NotImplementedError("inpainting_fill 0 ('fill') works on the image before encoding and is not implemented")
+        self.image_conditioning_all = self.img2img_image_conditioning(image, self.init_latent_all, self.image_mask, self.mask_round)
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
         """modules/processing.py:1759-1789"""
@@ -149,11 +234,13 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             self.mask = self.latent_mask[lo:lo + self.batch_size].to(dev, torch.float32).expand_as(self.init_latent).contiguous()
             self.nmask = (1.0 - self.mask).contiguous()
         x = self.rng.next()
+        if self.initial_noise_multiplier != 1.0:                                # :1762-1764
+            x = ops.lincomb(x, [x], [float(self.initial_noise_multiplier)])
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
         samples = self.sampler.sample_img2img(self, self.init_latent, x, conditioning, unconditional_conditioning,
-                                              image_conditioning=None)
+                                              image_conditioning=self.image_conditioning_all[lo:lo + self.batch_size].contiguous())
         if self.mask is not None:
-            samples = samples * self.nmask + self.init_latent * self.mask      # :1776-1784 final blend
+            samples = ops.mask_blend(samples.contiguous(), self.init_latent, self.mask, self.nmask)      # :1776-1784 final blend
         return samples
 
 

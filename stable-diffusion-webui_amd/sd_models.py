@@ -7,7 +7,9 @@ the weight source; the engine consumes it tensor by tensor (sdmi_unet_load_tenso
 """
 from __future__ import annotations
 
+import dataclasses
 import os
+import types
 from typing import Optional
 
 import torch
@@ -32,17 +34,25 @@ def read_state_dict(checkpoint_file: str, map_location="cpu") -> dict:
 def guess_unet_config(sd: dict) -> schema.UNetConfig:
     """modules/sd_models_config.py:72-115 reduced to the two families on the path: SDXL is recognised by the
     conditioner / label_emb keys, everything else with a 768-wide attn2.to_k is SD1.x."""
-    if schema.UNET_PREFIX + "label_emb.0.0.weight" in sd:
-        return schema.sdxl_unet()
-    return schema.sd15_unet()
+    cfg = schema.sdxl_unet() if schema.UNET_PREFIX + "label_emb.0.0.weight" in sd else schema.sd15_unet()
+    conv_in = sd.get(schema.UNET_PREFIX + "input_blocks.0.0.weight")
+    if conv_in is not None and conv_in.shape[1] != cfg.in_channels:      # 9: inpainting, 8: InstructPix2Pix (sd_models_config.py:100-107)
+        cfg = dataclasses.replace(cfg, in_channels=int(conv_in.shape[1]))
+    return cfg
 
 
 class SdModel:
     def __init__(self, state_dict: dict, unet_cfg: Optional[schema.UNetConfig] = None,
                  vae_cfg: Optional[schema.VAEConfig] = None, device: int = 0, load_vae: bool = True,
-                 vae_decoder_only: bool = False, parameterization: str = "eps"):
+                 vae_decoder_only: bool = False, parameterization: str = "eps", cond_stage_key: Optional[str] = None):
         self.unet_cfg = unet_cfg or guess_unet_config(state_dict)
         self.is_sdxl = self.unet_cfg.adm_in_channels is not None
+        # what the reference reads from the checkpoint's yaml (modules/sd_models_config.py:72-115): 9 input channels = inpainting
+        # ("hybrid": c_concat = mask + masked-image latent), 8 = InstructPix2Pix (also "hybrid", cond_stage_key "edit")
+        cin = self.unet_cfg.in_channels
+        self.cond_stage_key = cond_stage_key or ("edit" if cin == 8 else "txt")
+        self.is_sdxl_inpaint = self.is_sdxl and cin == 9
+        self.model = types.SimpleNamespace(conditioning_key="hybrid" if cin in (8, 9) and not self.is_sdxl else "crossattn")
         shared.sd_model = self                            # the reference's global (modules/shared.py); schedulers read is_sdxl
         self.vae_cfg = vae_cfg or (schema.sdxl_vae() if self.is_sdxl else schema.sd15_vae())
         assert parameterization in ("eps", "v")

@@ -176,8 +176,9 @@ class CFGDenoiser:
 
     ``mode`` 0: sigma space (k-diffusion samplers; returns denoised), 1: timestep space (DDIM; returns eps).
     Also covered (see ``forward``): AND composition, skip-uncond (NGMS / skip_early_cond), cond / uncond of different token
-    counts and the two padding options.  Per-step prompt schedules are the caller's job (pass the step's tensors);
-    InstructPix2Pix three-way CFG, script callbacks and the refiner switch raise / are not called.
+    counts and the two padding options, inpainting checkpoints (UNet input cat([x, c_concat])) and InstructPix2Pix
+    three-way CFG.  Per-step prompt schedules are the caller's job (pass the step's tensors); script callbacks and the
+    refiner switch are not called.
     """
 
     def __init__(self, sampler, mode=0):
@@ -253,10 +254,18 @@ class CFGDenoiser:
         opts = shared.opts
         sd_model = self.sampler.sd_model
         eng = sd_model.engine
-        if getattr(sd_model, "cond_stage_key", "txt") == "edit" and self.image_cfg_scale is not None and self.image_cfg_scale != 1.0:
-            raise NotImplementedError("InstructPix2Pix three-way CFG is not implemented")
+        # at image_cfg_scale == 1.0 the edit model's result equals normal sampling, which also allows AND (:164-166)
+        is_edit_model = (getattr(sd_model, "cond_stage_key", "txt") == "edit" and self.image_cfg_scale is not None
+                         and self.image_cfg_scale != 1.0)
         b, c, h, w = x.shape
         chw = c * h * w
+        cin = eng.unet_cfg.in_channels
+        if cin > c:                                           # conditioning_key hybrid / concat: UNet input = cat([x, c_concat], 1)
+            if image_cond is None or tuple(image_cond.shape) != (b, cin - c, h, w):
+                raise ValueError(f"this checkpoint needs image_cond of shape {(b, cin - c, h, w)} (inpainting / edit conditioning)")
+            image_cond = image_cond.to(x.device, torch.float32).contiguous()
+        else:
+            image_cond = None                                 # the dummy [B,5,1,1] of ordinary checkpoints is never read
         conds_list, tensor = cond if isinstance(cond, tuple) else (None, cond)
         if conds_list is not None and all(len(cl) == 1 and cl[0] == (i, 1.0) for i, cl in enumerate(conds_list)):
             conds_list = None                                 # plain CFG written the long way
@@ -279,11 +288,18 @@ class CFGDenoiser:
             tensor, uncond = self.pad_cond_uncond_v0(tensor, uncond)
         elif opts.pad_cond_uncond and tensor.shape[1] != uncond.shape[1]:
             tensor, uncond = self.pad_cond_uncond(tensor, uncond)
+        if is_edit_model:
+            if conds_list is not None:
+                raise AssertionError("AND is not supported for InstructPix2Pix checkpoint (unless using Image CFG scale = 1.0)")
+            skip_uncond = skip_uncond and opts.skip_early_cond != 0.         # NGMS is off for edit models (:224)
         split_calls = tensor.shape[1] != uncond.shape[1] and not skip_uncond      # :253-268: one UNet call per context length
+        if is_edit_model and (split_calls or skip_uncond):
+            raise NotImplementedError("InstructPix2Pix with skip-uncond or cond / uncond of different token counts")
 
-        rows = n_cond + (0 if skip_uncond else b)
-        if self._x_in is None or self._x_in.shape[0] < max(rows, 2 * b) or self._x_in.shape[2:] != x.shape[2:]:
-            self._x_in = torch.empty((max(rows, 2 * b), c, h, w), dtype=torch.float32, device=x.device)
+        rows = n_cond + (0 if skip_uncond else b) + (b if is_edit_model else 0)
+        if (self._x_in is None or self._x_in.shape[0] < max(rows, 2 * b) or self._x_in.shape[1] != cin
+                or self._x_in.shape[2:] != x.shape[2:]):
+            self._x_in = torch.empty((max(rows, 2 * b), cin, h, w), dtype=torch.float32, device=x.device)
             self._eps = torch.empty((max(rows, 2 * b), c, h, w), dtype=torch.float32, device=x.device)
             self._comb = None
         sig = float(sigma[0])
@@ -314,36 +330,53 @@ class CFGDenoiser:
                 c_skip_t = torch.full((b,), float(torch.sqrt(1 - a_t)), dtype=torch.float32, device=x.device)
         # x_in rows: every image once per prompt, then (unless skipped) every image once more for uncond (:203-205)
         x_in, eps = self._x_in[:rows], self._eps[:rows]
-        if conds_list is None:
-            check(lib.sdmi_cfg_prepare_input(ptr(x), ptr(c_in_t), ptr(x_in), _lib.F32, b, 1 if skip_uncond else 2, chw, stream_ptr()),
-                  "cfg_prepare")
+
+        def prepare(xs, c_in_s, ic_s, dst, nb, reps, zero_reps=0):
+            if image_cond is None:
+                check(lib.sdmi_cfg_prepare_input(ptr(xs), None if c_in_s is None else ptr(c_in_s), ptr(dst), _lib.F32, nb, reps, chw,
+                                                 stream_ptr()), "cfg_prepare")
+            else:
+                check(lib.sdmi_cfg_prepare_concat(ptr(xs), None if c_in_s is None else ptr(c_in_s), ptr(ic_s), ptr(dst), _lib.F32, nb, reps,
+                                                  c, cin - c, h * w, zero_reps, stream_ptr()), "cfg_prepare_concat")
+
+        if conds_list is None:      # [cond | uncond] (+ a third group without the image for the edit model, :207-209)
+            prepare(x, c_in_t, image_cond, x_in, b, rows // b, 0b100 if is_edit_model else 0)
         else:
             row = 0
             for i, cl in enumerate(conds_list):
-                check(lib.sdmi_cfg_prepare_input(ptr(x[i]), None if c_in_t is None else ptr(c_in_t[i:]), ptr(x_in[row:]), _lib.F32, 1,
-                                                 len(cl), chw, stream_ptr()), "cfg_prepare")
+                prepare(x[i], None if c_in_t is None else c_in_t[i:], None if image_cond is None else image_cond[i], x_in[row:], 1, len(cl))
                 row += len(cl)
             if not skip_uncond:
-                check(lib.sdmi_cfg_prepare_input(ptr(x), ptr(c_in_t), ptr(x_in[n_cond:]), _lib.F32, b, 1, chw, stream_ptr()), "cfg_prepare")
+                prepare(x, c_in_t, image_cond, x_in[n_cond:], b, 1)
         ts = torch.full((rows,), t_model, dtype=torch.float32, device=x.device)
         yy = None
         if y is not None:
             if conds_list is not None:
                 raise NotImplementedError("AND composition with vector conditioning (SDXL)")
-            yy = (y if skip_uncond else torch.cat([y, uy])).float().contiguous()
+            yy = (y if skip_uncond else torch.cat([y, uy, uy] if is_edit_model else [y, uy])).float().contiguous()
         if split_calls:
             eng.unet_forward(x_in[:n_cond], ts[:n_cond], tensor.float().contiguous(), None if yy is None else yy[:n_cond], out=eps[:n_cond])
             eng.unet_forward(x_in[n_cond:], ts[n_cond:], uncond.float().contiguous(), None if yy is None else yy[n_cond:], out=eps[n_cond:])
             self._ctx_key = None
         else:
-            self._ensure_context([tensor] if skip_uncond else [tensor, uncond])
+            self._ensure_context([tensor] if skip_uncond else [tensor, uncond, uncond] if is_edit_model else [tensor, uncond])
             eng.unet_forward(x_in, ts, None, yy, out=eps)
 
         # ---- combine (:73-82, :270-290).  The fused kernel takes eps = [cond(B) | uncond(B)]; the general cases are reduced to it
         # by first forming, per image, E = (1 - s*sum(w)) * eps_u + sum_j s*w_j * eps_cj (the same affine map commutes with the
         # wrapper's out * c_out + x * c_skip because the coefficients sum to 1) and handing it over as both halves with scale 1.
         scale = float(cond_scale * self.cond_scale_miltiplier)
-        if conds_list is None and not skip_uncond:
+        if is_edit_model:           # :84-88  u + s (c - i) + s_img (i - u)  =  s c + (s_img - s) i + (1 - s_img) u
+            if self._comb is None:
+                self._comb = torch.empty((2 * b, c, h, w), dtype=torch.float32, device=x.device)
+            pair = self._comb
+            s_img = float(self.image_cfg_scale)
+            _lc(pair[:b], [eps[:b], eps[b:2 * b], eps[2 * b:]], [scale, s_img - scale, 1.0 - s_img])
+            pair[b:].copy_(pair[:b])
+            scale = 1.0
+            if self.need_last_noise_uncond:
+                self.last_noise_uncond = eps[2 * b:].clone()
+        elif conds_list is None and not skip_uncond:
             pair = eps
         else:
             if self._comb is None:

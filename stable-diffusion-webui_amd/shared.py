@@ -35,6 +35,8 @@ class Options:
     pad_cond_uncond_v0: bool = False               # :240
     skip_early_cond: float = 0.0                   # :407
     img2img_extra_noise: float = 0.0
+    inpainting_mask_weight: float = 1.0            # :216
+    initial_noise_multiplier: float = 1.0          # :217
     img2img_fix_steps: bool = False
     enable_quantization: bool = False              # :176
     live_previews_enable: bool = False             # :374 (fused path requires previews off)

@@ -630,6 +630,75 @@ def gen_cfg_denoiser():
     print("cfg_denoiser.npz")
 
 
+class FakeFirstStage:
+    """Deterministic stand-in for the VAE encoder in the image-conditioning fixture: a fixed strided conv to 8 "moment"
+    channels.  Exposes both the reference's sd_model methods and the oracle's model.vae methods."""
+    scale_factor = 0.5
+
+    def __init__(self):
+        self.w = seeded((8, 3, 2, 2), 6100, 0.4)
+        self.vae = self
+        self.model = types.SimpleNamespace(conditioning_key="hybrid")
+        self.first_stage_model = types.SimpleNamespace(to=lambda *a, **k: None)
+        self.is_sdxl_inpaint = False
+        self.dtype = torch.float32
+
+    def encode_moments(self, x):
+        return torch.nn.functional.conv2d(x, self.w, stride=2)
+
+    def encode_first_stage(self, x):                      # the reference gets a distribution object; .mode() = the mean
+        m = self.encode_moments(x)
+        return types.SimpleNamespace(moments=m, mode=lambda: torch.chunk(m, 2, dim=1)[0])
+
+    def get_first_stage_encoding(self, enc):
+        return torch.chunk(enc.moments, 2, dim=1)[0] * self.scale_factor
+
+    def encode_first_stage_mean(self, x):
+        return torch.chunk(self.encode_moments(x), 2, dim=1)[0] * self.scale_factor
+
+
+def gen_image_conditioning():
+    """Exec, from modules/processing.py's own text, txt2img_image_conditioning (:100-133) and the methods
+    inpainting_image_conditioning (:332-374) / edit_image_conditioning (:321-324), plus images_tensor_to_samples from
+    modules/sd_samplers_common.py (:83-113), over FakeFirstStage; nothing is copied into this repository."""
+    import re
+    import textwrap
+    fs = FakeFirstStage()
+    shared = types.SimpleNamespace(sd_model=fs, device="cpu", opts=types.SimpleNamespace(inpainting_mask_weight=1.0, sd_vae_encode_method="Full"))
+    devices = types.SimpleNamespace(device="cpu", dtype=torch.float32, dtype_vae=torch.float32)
+    ns = {"torch": torch, "np": np, "shared": shared, "opts": shared.opts, "devices": devices, "approximation_indexes": {"Full": 0}}
+    src = open(os.path.join(REF, "modules/sd_samplers_common.py")).read()
+    a = src.index("def images_tensor_to_samples")
+    exec(src[a:src.index("def store_latent")], ns)
+    src = open(os.path.join(REF, "modules/processing.py")).read()
+    a = src.index("def txt2img_image_conditioning(sd_model")
+    exec(src[a:src.index("@dataclass(repr=False)")], ns)
+    a = src.index("    def edit_image_conditioning(self")
+    b = src.index("    def unclip_image_conditioning(self")
+    exec(textwrap.dedent(src[a:b]), ns)
+    a = src.index("    def inpainting_image_conditioning(self")
+    b = src.index("    def img2img_image_conditioning(self")
+    exec(textwrap.dedent(src[a:b]), ns)
+    self_ = types.SimpleNamespace(sd_model=fs)
+    out = {}
+    x = torch.zeros(3, 4, 6, 8)
+    out["txt2img"] = ns["txt2img_image_conditioning"](fs, x, 16, 12).numpy()
+    img = seeded((2, 3, 12, 16), 6101).clamp(-1, 1)
+    from PIL import Image
+    mask_u8 = ((seeded((12, 16), 6102) * 0.5 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).numpy()
+    mask = Image.fromarray(mask_u8, mode="L")            # the webui hands a PIL mask over; tensors skip the rounding (:336-347)
+    out["mask_u8"] = mask_u8
+    lat = torch.zeros(2, 4, 6, 8)
+    out["inpaint_round"] = ns["inpainting_image_conditioning"](self_, img, lat, image_mask=mask, round_image_mask=True).numpy()
+    out["inpaint_soft"] = ns["inpainting_image_conditioning"](self_, img, lat, image_mask=mask, round_image_mask=False).numpy()
+    out["inpaint_nomask"] = ns["inpainting_image_conditioning"](self_, img, lat).numpy()
+    self_.inpainting_mask_weight = 0.35
+    out["inpaint_weight"] = ns["inpainting_image_conditioning"](self_, img, lat, image_mask=mask, round_image_mask=True).numpy()
+    out["edit"] = ns["edit_image_conditioning"](self_, img).numpy()
+    np.savez_compressed(os.path.join(OUT, "image_conditioning.npz"), **out)
+    print("image_conditioning.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -643,3 +712,4 @@ if __name__ == "__main__":
     gen_unipc()
     gen_lcm()
     gen_cfg_denoiser()
+    gen_image_conditioning()

@@ -460,6 +460,111 @@ def test_txt2img_ngms_end_to_end_vs_oracle(dev, tiny):
     assert rel_l2(res.latents.cpu(), lat) < 1e-2 and rel_l2(plain, lat) > 5e-2
 
 
+def _concat_model(in_channels, **kw):
+    from oracle import pipeline as opipe, unet as ou, vae as ov
+    schema = sub("schema")
+    ucfg, vcfg = schema.tiny_unet(in_channels=in_channels), schema.tiny_vae()
+    sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16, seed=0x1A9 + in_channels)
+    assert sub("sd_models").guess_unet_config({schema.UNET_PREFIX + "input_blocks.0.0.weight": sd[schema.UNET_PREFIX + "input_blocks.0.0.weight"]}).in_channels == in_channels
+    model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0, **kw)
+    om = opipe.OracleModel(sd, ou.tiny_config(in_channels=in_channels), ov.tiny_vae_config())
+    g = torch.Generator().manual_seed(13)
+    return model, om, torch.randn(2, 77, 64, generator=g), torch.randn(2, 77, 64, generator=g)
+
+
+@pytest.mark.parametrize("sampler,name", [("euler_a", "Euler a"), ("ddim", "DDIM")])
+def test_inpainting_checkpoint_vs_oracle(dev, sampler, name):
+    """9-channel inpainting checkpoints (conditioning_key "hybrid"): c_concat = [mask | masked-image latent] is concatenated to
+    every UNet input row (sdmi_cfg_prepare_concat).  txt2img conditions on an all-masked flat image (processing.py:100-111);
+    img2img on lerp(image, image * (1 - mask), weight) encoded + the mask at latent size (processing.py:332-374), together with
+    the latent-mask blends."""
+    from oracle import pipeline as opipe
+    processing = sub("processing")
+    model, om, cond, uncond = _concat_model(9)
+    assert model.model.conditioning_key == "hybrid" and model.cond_stage_key == "txt"
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond, uc=uncond, seed=900, batch_size=2, steps=4, cfg_scale=6.0,
+                                                    width=128, height=128, sampler_name=name)
+    res = processing.process_images(p)
+    ic = opipe.txt2img_image_conditioning(om, 2, 32, 32)      # the tiny VAE has f = 2: a 16x16 latent is a 32x32 image
+    assert ic.shape == (2, 5, 16, 16)
+    lat = opipe.sample(om, cond, uncond, [900, 901], 4, sampler, 6.0, (16, 16), image_cond=ic)
+    assert rel_l2(res.latents.cpu(), lat) < 1e-2
+    other = opipe.sample(om, cond, uncond, [900, 901], 4, sampler, 6.0, (16, 16), image_cond=torch.zeros_like(ic))
+    assert rel_l2(other, lat) > 3e-2                          # the conditioning channels matter
+
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(21)).half().float()
+    image_mask = torch.zeros(1, 1, 32, 32)
+    image_mask[:, :, 8:24, 4:20] = 1.0
+    image_mask[:, :, 0:4, :] = 0.6                            # rounds to 1
+    image_mask[:, :, 28:, :] = 0.4                            # rounds to 0
+    latent_mask = 1.0 - torch.nn.functional.interpolate(torch.round(image_mask), size=(16, 16)).expand(2, 4, 16, 16)
+    for weight in (1.0, 0.7):
+        p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=910, batch_size=2, steps=5, cfg_scale=6.0,
+                                                        width=128, height=128, sampler_name=name, init_images=img,
+                                                        denoising_strength=0.7, latent_mask=latent_mask, image_mask=image_mask,
+                                                        inpainting_mask_weight=weight)
+        res = processing.process_images(p)
+        init = om.vae.encode_first_stage_mean(img * 2 - 1)
+        ic = opipe.inpainting_image_conditioning(om, img * 2 - 1, (16, 16), image_mask, mask_weight=weight)
+        lat = opipe.sample(om, cond, uncond, [910, 911], 5, sampler, 6.0, (16, 16), init_latent=init, denoising_strength=0.7,
+                           img2img_steps_given=False, mask=latent_mask, image_cond=ic)
+        assert rel_l2(res.latents.cpu(), lat) < 1.5e-2, weight
+
+
+def test_instruct_pix2pix_checkpoint_vs_oracle(dev):
+    """8-channel InstructPix2Pix checkpoints (cond_stage_key "edit"): three UNet rows per image — [cond, image], [uncond, image],
+    [uncond, no image] — and u + s (c - i) + s_img (i - u) (sd_samplers_cfg_denoiser.py:84-88, 207-209); the image conditioning
+    is the unscaled posterior mode (processing.py:321-324).  At image_cfg_scale 1.0 it is ordinary two-way CFG."""
+    from oracle import pipeline as opipe
+    processing = sub("processing")
+    model, om, cond, uncond = _concat_model(8)
+    assert model.cond_stage_key == "edit" and model.model.conditioning_key == "hybrid"
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(22)).half().float()
+    init = om.vae.encode_first_stage_mean(img * 2 - 1)
+    ic = opipe.edit_image_conditioning(om, img * 2 - 1)
+    outs = {}
+    for s_img in (1.5, 1.0):
+        p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=920, batch_size=2, steps=5, cfg_scale=6.0,
+                                                        width=128, height=128, sampler_name="Euler a", init_images=img,
+                                                        denoising_strength=0.8, image_cfg_scale=s_img)
+        res = processing.process_images(p)
+        lat = opipe.sample(om, cond, uncond, [920, 921], 5, "euler_a", 6.0, (16, 16), init_latent=init, denoising_strength=0.8,
+                           img2img_steps_given=False, image_cond=ic, image_cfg_scale=s_img)
+        assert rel_l2(res.latents.cpu(), lat) < 1.5e-2, s_img
+        outs[s_img] = lat
+    assert rel_l2(outs[1.5], outs[1.0]) > 3e-2
+
+
+def test_img2img_masked_content_fills_and_noise_multiplier(dev, tiny):
+    """inpainting_fill 2 / 3 ("latent noise" / "latent nothing", processing.py:1747-1753) rewrite the masked part of the init
+    latent before sampling; initial_noise_multiplier scales the img2img noise (:1762-1764)."""
+    from oracle import pipeline as opipe
+    from oracle.rng import ImageRNG as ORNG
+    processing = sub("processing")
+    model, om = tiny["model"], tiny["oracle"]
+    cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(23)).half().float()
+    mask = torch.zeros(2, 4, 16, 16)
+    mask[:, :, 3:11, 5:14] = 1.0
+    init = om.vae.encode_first_stage_mean(img * 2 - 1)
+    for fill in (2, 3):
+        p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=3100, batch_size=2, steps=5, cfg_scale=7.0,
+                                                        width=128, height=128, sampler_name="Euler a", init_images=img,
+                                                        denoising_strength=0.6, latent_mask=mask, inpainting_fill=fill)
+        res = processing.process_images(p)
+        filled = init * mask + (ORNG((4, 16, 16), [3100, 3101]).next() * (1 - mask) if fill == 2 else 0.0)
+        lat = opipe.sample(om, cond, uncond, [3100, 3101], 5, "euler_a", 7.0, (16, 16), init_latent=filled, denoising_strength=0.6,
+                           img2img_steps_given=False, mask=mask)
+        assert rel_l2(res.latents.cpu(), lat) < 1.5e-2, fill
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=3100, batch_size=2, steps=5, cfg_scale=7.0,
+                                                    width=128, height=128, sampler_name="Euler a", init_images=img,
+                                                    denoising_strength=0.6, initial_noise_multiplier=1.1)
+    res = processing.process_images(p)
+    lat = opipe.sample(om, cond, uncond, [3100, 3101], 5, "euler_a", 7.0, (16, 16), init_latent=init, denoising_strength=0.6,
+                       img2img_steps_given=False, noise_multiplier=1.1)
+    assert rel_l2(res.latents.cpu(), lat) < 1.5e-2
+
+
 def test_txt2img_batch_split_matches(dev, tiny):
     """Sharding contract of the multi-GPU runner: images [0,4) generated as 4, as 2+2 (n_iter) or as the tail pair are the
     same images — per-image Philox streams (modules/rng.py:108) + per-image arithmetic everywhere.  Bitwise when the per-call

@@ -257,6 +257,26 @@ def test_cfg_denoiser_matches_reference(golden_dir):
             np.testing.assert_allclose(d.last_noise_uncond.numpy(), z[name + "_last_noise_uncond"], rtol=0, atol=1e-6)
 
 
+def test_image_conditioning_builders_match_reference(golden_dir):
+    """oracle/pipeline.py txt2img_image_conditioning / inpainting_image_conditioning / edit_image_conditioning == the reference
+    functions (modules/processing.py:100-133, 321-324, 332-374) exec'd over a stand-in first stage: rounded / soft / absent mask
+    and a mask weight below 1."""
+    from oracle import pipeline as opipe
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "image_conditioning.npz"))
+    fs = mg.FakeFirstStage()
+    np.testing.assert_allclose(opipe.txt2img_image_conditioning(fs, 3, 12, 16).numpy(), z["txt2img"], rtol=0, atol=1e-6)
+    img = seeded((2, 3, 12, 16), 6101).clamp(-1, 1)
+    mask = torch.from_numpy(z["mask_u8"].astype(np.float32) / 255.0)[None, None]
+    f = lambda **kw: opipe.inpainting_image_conditioning(fs, img, (6, 8), **kw).numpy()
+    np.testing.assert_allclose(f(image_mask=mask), z["inpaint_round"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(f(image_mask=mask, round_image_mask=False), z["inpaint_soft"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(f(), z["inpaint_nomask"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(f(image_mask=mask, mask_weight=0.35), z["inpaint_weight"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(opipe.edit_image_conditioning(fs, img).numpy(), z["edit"], rtol=0, atol=1e-6)
+    assert np.abs(z["inpaint_round"] - z["inpaint_soft"]).max() > 0.1
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
