@@ -202,3 +202,65 @@ def edit_image_conditioning(model: OracleModel, source_image):
     """modules/processing.py:321-324: the UNSCALED posterior mode of the source image."""
     mean, _ = torch.chunk(model.vae.encode_moments(source_image), 2, dim=1)
     return mean
+
+
+# ---- hires fix through an image-space upscaler ----------------------------------------------------------------------------
+def hires_target_resolution(width, height, hr_scale=2.0, hr_resize_x=0, hr_resize_y=0, opt_f=8):
+    """modules/processing.py:1221-1250 -> (upscale_to_x, upscale_to_y, truncate_x, truncate_y)."""
+    tx = ty = 0
+    if hr_resize_x == 0 and hr_resize_y == 0:
+        ux, uy = int(width * hr_scale), int(height * hr_scale)
+    elif hr_resize_y == 0:
+        ux, uy = hr_resize_x, hr_resize_x * height // width
+    elif hr_resize_x == 0:
+        ux, uy = hr_resize_y * width // height, hr_resize_y
+    else:
+        if width / height < hr_resize_x / hr_resize_y:
+            ux, uy = hr_resize_x, hr_resize_x * height // width
+        else:
+            ux, uy = hr_resize_y * width // height, hr_resize_y
+        tx, ty = (ux - hr_resize_x) // opt_f, (uy - hr_resize_y) // opt_f
+    return ux, uy, tx, ty
+
+
+def resize_image_mode0(im, width, height, upscaler_name=None):
+    """images.resize_image(0, ...) (modules/images.py:252-291) over the built-in PIL scalers (modules/upscaler.py:54-76, 107-154);
+    pinned by tests/golden/resize_image.npz."""
+    from PIL import Image
+    lanczos, nearest = Image.Resampling.LANCZOS, Image.Resampling.NEAREST
+    if upscaler_name is None or upscaler_name == "None" or im.mode == 'L':
+        return im.resize((width, height), resample=lanczos)
+    scale = max(width / im.width, height / im.height)
+    if scale > 1.0:
+        kind = {"Lanczos": lanczos, "Nearest": nearest}[upscaler_name]
+        dest_w, dest_h = int((im.width * scale) // 8 * 8), int((im.height * scale) // 8 * 8)
+        for i in range(3):
+            if im.width >= dest_w and im.height >= dest_h and (i > 0 or scale != 1):
+                break
+            shape = (im.width, im.height)
+            im = im.resize((int(im.width * scale), int(im.height * scale)), resample=kind)
+            if shape == (im.width, im.height):
+                break
+        if im.width != dest_w or im.height != dest_h:
+            im = im.resize((dest_w, dest_h), resample=lanczos)
+    if im.width != width or im.height != height:
+        im = im.resize((width, height), resample=lanczos)
+    return im
+
+
+@torch.no_grad()
+def txt2img_hires_image(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0, width=64, height=64,
+                        hr_scale=2.0, hr_resize_x=0, hr_resize_y=0, denoising_strength=0.75, upscaler="Lanczos", opt_f=8):
+    """txt2img + hires fix with an image-space upscaler (modules/processing.py:1353-1354, 1400-1427): the first pass is decoded,
+    converted to uint8 PIL images, resized, re-encoded (posterior mean) and truncated to the requested size."""
+    import numpy as np
+    from PIL import Image
+    first = sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, (height // opt_f, width // opt_f))
+    ux, uy, tx, ty = hires_target_resolution(width, height, hr_scale, hr_resize_x, hr_resize_y, opt_f)
+    u8 = to_uint8_hwc(decode(model, first))
+    batch = [np.moveaxis(np.array(resize_image_mode0(Image.fromarray(im), ux, uy, upscaler)).astype(np.float32) / 255.0, 2, 0) for im in u8]
+    decoded = torch.from_numpy(np.array(batch))
+    up = model.vae.encode_first_stage_mean(decoded * 2 - 1)
+    up = up[:, :, ty // 2:up.shape[2] - (ty + 1) // 2, tx // 2:up.shape[3] - (tx + 1) // 2]
+    return sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, tuple(up.shape[-2:]), init_latent=up,
+                  denoising_strength=denoising_strength, img2img_steps_given=True)

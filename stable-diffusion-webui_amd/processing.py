@@ -146,6 +146,48 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
     hr_resize_y: int = 0
     hr_scheduler: str = None
     hr_sampler_name: str = None
+    hr_c: Optional[torch.Tensor] = None              # hires prompt conditioning (calculate_hr_conds, :1468-1490); default: p.c / p.uc
+    hr_uc: Optional[torch.Tensor] = None
+    hr_sd_model: Any = None                          # hires checkpoint (:1253-1259, 1360-1361): another resident SdModel
+    hr_upscale_to_x: int = 0
+    hr_upscale_to_y: int = 0
+    truncate_x: int = 0
+    truncate_y: int = 0
+
+    def calculate_target_resolution(self):
+        """modules/processing.py:1213-1250 (without the pre-1.0 compatibility option)."""
+        if self.hr_resize_x == 0 and self.hr_resize_y == 0:
+            self.hr_upscale_to_x = int(self.width * self.hr_scale)
+            self.hr_upscale_to_y = int(self.height * self.hr_scale)
+        elif self.hr_resize_y == 0:
+            self.hr_upscale_to_x = self.hr_resize_x
+            self.hr_upscale_to_y = self.hr_resize_x * self.height // self.width
+        elif self.hr_resize_x == 0:
+            self.hr_upscale_to_x = self.hr_resize_y * self.width // self.height
+            self.hr_upscale_to_y = self.hr_resize_y
+        else:
+            target_w, target_h = self.hr_resize_x, self.hr_resize_y
+            if self.width / self.height < self.hr_resize_x / self.hr_resize_y:
+                self.hr_upscale_to_x = self.hr_resize_x
+                self.hr_upscale_to_y = self.hr_resize_x * self.height // self.width
+            else:
+                self.hr_upscale_to_x = self.hr_resize_y * self.width // self.height
+                self.hr_upscale_to_y = self.hr_resize_y
+            self.truncate_x = (self.hr_upscale_to_x - target_w) // opt_f
+            self.truncate_y = (self.hr_upscale_to_y - target_h) // opt_f
+
+    def init(self, all_prompts, all_seeds, all_subseeds):
+        """:1252-1305: target size, latent vs image-space upscaler."""
+        if self.enable_hr:
+            self.latent_scale_mode = {"Latent": "bilinear", "Latent (nearest)": "nearest", "Latent (bicubic)": "bicubic",
+                                      "Latent (nearest-exact)": "nearest-exact"}.get(self.hr_upscaler)       # shared.py:54-62
+            if self.latent_scale_mode is None:
+                from . import upscaler
+                if not shared.sd_upscalers:
+                    shared.sd_upscalers = upscaler.builtin_upscalers()
+                if not any(x.name == self.hr_upscaler for x in shared.sd_upscalers):
+                    raise Exception(f"could not find upscaler named {self.hr_upscaler}")                    # :1285-1286
+            self.calculate_target_resolution()
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
         """modules/processing.py:1307-1362"""
@@ -156,32 +198,60 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         del x
         if not self.enable_hr:
             return samples
-        return self.sample_hr_pass(samples, None, seeds, subseeds, subseed_strength, prompts, conditioning, unconditional_conditioning)
+        decoded_samples = None
+        if self.latent_scale_mode is None:                   # image-space upscaler: the first pass is decoded (:1353-1354)
+            decoded_samples = decode_latent_batch(self.sd_model, samples)
+        first_model = self.sd_model
+        if self.hr_sd_model is not None:                     # :1360-1361 reload_model_weights(hr_checkpoint_info): both stay resident
+            self.sd_model = self.hr_sd_model
+        try:
+            return self.sample_hr_pass(samples, decoded_samples, seeds, subseeds, subseed_strength, prompts, conditioning,
+                                       unconditional_conditioning)
+        finally:
+            self.sd_model = first_model
 
     def sample_hr_pass(self, samples, decoded_samples, seeds, subseeds, subseed_strength, prompts, conditioning, unconditional_conditioning):
-        """modules/processing.py:1364-1464 for latent upscalers (shared.py:54-62: "Latent" = bilinear, no antialias):
-        first-pass latents are not decoded; fresh ImageRNG noise; second pass is sample_img2img at hr size."""
-        if self.hr_upscaler not in ("Latent", "Latent (nearest)", "Latent (bicubic)", "Latent (nearest-exact)"):
-            raise NotImplementedError("only latent hires upscalers are implemented in the engine path")
-        mode = {"Latent": "bilinear", "Latent (nearest)": "nearest", "Latent (bicubic)": "bicubic",
-                "Latent (nearest-exact)": "nearest-exact"}[self.hr_upscaler]
+        """modules/processing.py:1364-1464.  Latent upscalers (shared.py:54-62) resample the undecoded first-pass latents on the
+        device; image-space upscalers get the decoded uint8 images (PIL, exactly as the reference hands them to
+        images.resize_image) and the result is re-encoded.  Fresh ImageRNG noise; second pass = sample_img2img at hr size."""
         self.is_hr_pass = True
-        target_w = self.hr_resize_x or int(self.width * self.hr_scale)
-        target_h = self.hr_resize_y or int(self.height * self.hr_scale)
-        # K16 (SURVEY.md 2.3): [B,4,h,w] resample = F.interpolate(..., mode, antialias=False) (modules/processing.py:1392)
-        samples = ops.latent_resize(samples, (target_h // opt_f, target_w // opt_f), mode)
-        # :1395-1399 (at the default mask weight 1.0 the hires pass of an inpainting checkpoint is conditioned like txt2img)
-        weight = self.inpainting_mask_weight if self.inpainting_mask_weight is not None else shared.opts.inpainting_mask_weight
-        if weight < 1.0 and self._conditioning_key() in {'hybrid', 'concat'}:
-            image_conditioning = self.img2img_image_conditioning(self.sd_model.decode_first_stage(samples), samples)
+        target_w, target_h = self.hr_upscale_to_x, self.hr_upscale_to_y
+        name = self.hr_sampler_name or self.sampler_name
+        self.sampler = sd_samplers.create_sampler(name, self.sd_model)
+        if self.latent_scale_mode is not None:
+            # K16 (SURVEY.md 2.3): [B,4,h,w] resample = F.interpolate(..., mode, antialias=False) (modules/processing.py:1392)
+            samples = ops.latent_resize(samples, (target_h // opt_f, target_w // opt_f), self.latent_scale_mode)
+            # :1395-1399 (at the default mask weight 1.0 the hires pass of an inpainting checkpoint is conditioned like txt2img)
+            weight = self.inpainting_mask_weight if self.inpainting_mask_weight is not None else shared.opts.inpainting_mask_weight
+            if weight < 1.0 and self._conditioning_key() in {'hybrid', 'concat'}:
+                image_conditioning = self.img2img_image_conditioning(self.sd_model.decode_first_stage(samples), samples)
+            else:
+                image_conditioning = self.txt2img_image_conditioning(samples, target_w, target_h)
         else:
-            image_conditioning = self.txt2img_image_conditioning(samples, target_w, target_h)
+            from PIL import Image
+            from . import upscaler
+            u8 = ops.image_to_u8(decoded_samples).cpu().numpy()          # clamp((x + 1) / 2) * 255 -> uint8 HWC (:1401-1406)
+            batch_images = []
+            for x_sample in u8:
+                image = upscaler.resize_image(0, Image.fromarray(x_sample), target_w, target_h, upscaler_name=self.hr_upscaler)
+                batch_images.append(np.moveaxis(np.array(image).astype(np.float32) / 255.0, 2, 0))
+            decoded = torch.from_numpy(np.array(batch_images)).to(samples.device, dtype=torch.float32)
+            image = ops.lincomb(torch.empty_like(decoded), [decoded, torch.ones_like(decoded)], [2.0, -1.0])   # image * 2 - 1
+            samples = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(image))          # :1421
+            image_conditioning = self.img2img_image_conditioning(decoded, samples)       # (sic) the [0,1] image, as :1423 passes it
+        # :1427
+        samples = samples[:, :, self.truncate_y // 2:samples.shape[2] - (self.truncate_y + 1) // 2,
+                          self.truncate_x // 2:samples.shape[3] - (self.truncate_x + 1) // 2].contiguous()
+        if image_conditioning.shape[-2:] != (1, 1) and image_conditioning.shape[-2:] != samples.shape[-2:]:
+            image_conditioning = image_conditioning[:, :, self.truncate_y // 2:image_conditioning.shape[2] - (self.truncate_y + 1) // 2,
+                                                    self.truncate_x // 2:image_conditioning.shape[3] - (self.truncate_x + 1) // 2].contiguous()
         self.rng = ImageRNG(samples.shape[1:], self.seeds, eta_noise_seed_delta=shared.opts.eta_noise_seed_delta,
                             device=samples.device)
         noise = self.rng.next()
-        name = self.hr_sampler_name or self.sampler_name
-        self.sampler = sd_samplers.create_sampler(name, self.sd_model)
-        samples = self.sampler.sample_img2img(self, samples.contiguous(), noise, conditioning, unconditional_conditioning,
+        lo = self.iteration * self.batch_size
+        hr_c = conditioning if self.hr_c is None else self.hr_c[lo:lo + self.batch_size].to(samples.device)
+        hr_uc = unconditional_conditioning if self.hr_uc is None else self.hr_uc[lo:lo + self.batch_size].to(samples.device)
+        samples = self.sampler.sample_img2img(self, samples, noise, hr_c, hr_uc,
                                               steps=self.hr_second_pass_steps or self.steps, image_conditioning=image_conditioning)
         self.is_hr_pass = False
         return samples
@@ -293,7 +363,8 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
                            subseed_strength=0, prompts=None)                                      # :987-988
         if p.y is not None:
             p.y, p.uy = p_y_all, p_uy_all
-        x_samples = decode_latent_batch(p.sd_model, samples, check_for_nans=False)               # :1002
+        decode_model = getattr(p, "hr_sd_model", None) if getattr(p, "enable_hr", False) and getattr(p, "hr_sd_model", None) is not None else p.sd_model
+        x_samples = decode_latent_batch(decode_model, samples, check_for_nans=False)             # :1002 (hires: decoded inside sample_hr_pass, :1459)
         u8 = ops.image_to_u8(x_samples)                                                           # :1004-1005, 1034-1035
         images.extend(list(u8.cpu().numpy()))
         if p.keep_latents:

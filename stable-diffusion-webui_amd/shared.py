@@ -36,6 +36,7 @@ class Options:
     skip_early_cond: float = 0.0                   # :407
     img2img_extra_noise: float = 0.0
     inpainting_mask_weight: float = 1.0            # :216
+    upscaler_for_img2img: str = None               # :106
     initial_noise_multiplier: float = 1.0          # :217
     img2img_fix_steps: bool = False
     enable_quantization: bool = False              # :176
@@ -60,4 +61,5 @@ class State:
 
 
 state = State()
+sd_upscalers = []                                  # UpscalerData entries (upscaler.py; modules/shared.py:64)
 sd_model = None                                    # set by sd_models.SdModel (schedulers read is_sdxl, sd_schedulers.py:57)

@@ -699,6 +699,39 @@ def gen_image_conditioning():
     print("image_conditioning.npz")
 
 
+RESIZE_CASES = [(48, 32, "Lanczos"), (56, 40, "Lanczos"), (48, 32, "Nearest"), (50, 36, "Nearest"), (48, 32, "None"), (48, 32, None),
+                (20, 12, "Lanczos"), (96, 64, "Nearest"), (24, 16, "Lanczos")]
+
+
+def gen_resize_image():
+    """Exec, from their own text, images.resize_image (modules/images.py:252-291) and the Upscaler driver loop + the None /
+    Lanczos / Nearest scalers (modules/upscaler.py:10-154) and run RESIZE_CASES on a seeded 24x16 RGB image (mode 0 = what the
+    non-latent hires fix calls, modules/processing.py:1411)."""
+    from PIL import Image
+    import abc
+    shared = types.SimpleNamespace(opts=types.SimpleNamespace(ESRGAN_tile=192, ESRGAN_tile_overlap=8, upscaler_for_img2img=None),
+                                   device="cpu", cmd_opts=types.SimpleNamespace(no_half=True), models_path="/nonexistent",
+                                   state=types.SimpleNamespace(interrupted=False), sd_upscalers=[])
+    modules_ns = types.SimpleNamespace(shared=shared)
+    ns = {"Image": Image, "PIL": __import__("PIL"), "os": os, "abstractmethod": abc.abstractmethod, "modules": modules_ns, "shared": shared,
+          "modelloader": None}
+    src = open(os.path.join(REF, "modules/upscaler.py")).read()
+    exec(src[src.index("LANCZOS = "):], ns)
+    shared.sd_upscalers = [*ns["UpscalerNone"]().scalers, *ns["UpscalerLanczos"]().scalers, *ns["UpscalerNearest"]().scalers]
+    src = open(os.path.join(REF, "modules/images.py")).read()
+    a = src.index("def resize_image(")
+    ns["opts"] = shared.opts
+    exec(src[a:src.index("\nif not shared.cmd_opts.unix_filenames_sanitization", a)], ns)
+    g = np.random.RandomState(77)
+    base = g.randint(0, 256, size=(16, 24, 3)).astype(np.uint8)
+    out = {"base": base}
+    for k, (w, h, name) in enumerate(RESIZE_CASES):
+        out[f"r{k}"] = np.array(ns["resize_image"](0, Image.fromarray(base), w, h, upscaler_name=name))
+        assert out[f"r{k}"].shape == (h, w, 3)
+    np.savez_compressed(os.path.join(OUT, "resize_image.npz"), **out)
+    print("resize_image.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -713,3 +746,4 @@ if __name__ == "__main__":
     gen_lcm()
     gen_cfg_denoiser()
     gen_image_conditioning()
+    gen_resize_image()

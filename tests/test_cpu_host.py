@@ -217,6 +217,31 @@ def test_host_lcm_schedule_and_folded_scalings_match_reference(golden_dir):
         np.testing.assert_allclose((eps * c_out + xin * c_skip).numpy(), z[f"forward{k}"], rtol=0, atol=2e-5)
 
 
+def test_host_upscaler_handoff_matches_reference(golden_dir):
+    """upscaler.resize_image / Upscaler.upscale / built-in scalers reproduce the reference-generated uint8 images, and
+    StableDiffusionProcessingTxt2Img.calculate_target_resolution the reference's size / truncation arithmetic."""
+    from PIL import Image
+    from tests.test_oracle_pins import _golden_module
+    from oracle import pipeline as opipe
+    up, shared, processing = sub("upscaler"), sub("shared"), sub("processing")
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "resize_image.npz"))
+    shared.sd_upscalers = up.builtin_upscalers()
+    assert [x.name for x in shared.sd_upscalers] == ["None", "Lanczos", "Nearest"]
+    for k, (w, h, name) in enumerate(mg.RESIZE_CASES):
+        assert np.array_equal(np.array(up.resize_image(0, Image.fromarray(z["base"]), w, h, upscaler_name=name)), z[f"r{k}"]), (w, h, name)
+    for kw in (dict(), dict(hr_resize_x=1000), dict(hr_resize_y=900), dict(hr_resize_x=1024, hr_resize_y=1024),
+               dict(hr_resize_x=1024, hr_resize_y=640), dict(hr_scale=1.5)):
+        for wh in ((512, 768), (768, 512), (512, 512)):
+            p = processing.StableDiffusionProcessingTxt2Img(width=wh[0], height=wh[1], enable_hr=True, **kw)
+            p.calculate_target_resolution()
+            want = opipe.hires_target_resolution(wh[0], wh[1], kw.get("hr_scale", 2.0), kw.get("hr_resize_x", 0), kw.get("hr_resize_y", 0))
+            assert (p.hr_upscale_to_x, p.hr_upscale_to_y, p.truncate_x, p.truncate_y) == want
+    p = processing.StableDiffusionProcessingTxt2Img(enable_hr=True, hr_upscaler="ESRGAN_4x")
+    with pytest.raises(Exception, match="could not find upscaler"):
+        p.init(None, None, None)
+
+
 def test_host_lora_names_and_grouping_match_reference(golden_dir):
     """networks.convert_diffusers_name_to_compvis against the reference-generated fixture, and load_network's grouping /
     layer lookup (extensions-builtin/Lora/networks.py:183-240) on the tiny UNet's layer map."""

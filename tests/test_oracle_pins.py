@@ -277,6 +277,22 @@ def test_image_conditioning_builders_match_reference(golden_dir):
     assert np.abs(z["inpaint_round"] - z["inpaint_soft"]).max() > 0.1
 
 
+def test_resize_image_matches_reference(golden_dir):
+    """oracle resize_image_mode0 == images.resize_image(0, ...) + the Upscaler loop + Lanczos / Nearest / None scalers
+    (modules/images.py:252-291, modules/upscaler.py:54-154) exec'd by make_golden: bit-identical uint8 images."""
+    from PIL import Image
+    from oracle import pipeline as opipe
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "resize_image.npz"))
+    for k, (w, h, name) in enumerate(mg.RESIZE_CASES):
+        assert np.array_equal(np.array(opipe.resize_image_mode0(Image.fromarray(z["base"]), w, h, name)), z[f"r{k}"]), (w, h, name)
+    assert opipe.hires_target_resolution(512, 768, 2.0) == (1024, 1536, 0, 0)
+    assert opipe.hires_target_resolution(512, 768, hr_resize_x=1000) == (1000, 1500, 0, 0)
+    assert opipe.hires_target_resolution(512, 768, hr_resize_y=900) == (600, 900, 0, 0)
+    assert opipe.hires_target_resolution(512, 768, hr_resize_x=1024, hr_resize_y=1024) == (1024, 1536, 0, 64)
+    assert opipe.hires_target_resolution(768, 512, hr_resize_x=1024, hr_resize_y=1024) == (1536, 1024, 64, 0)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
