@@ -178,6 +178,32 @@ def timesteps_v_to_eps(alphas_cumprod, x_t, t, v):
 # CFG  (modules/sd_samplers_cfg_denoiser.py:74-82, 156-311 for the plain txt2img case:
 #       one cond per image with weight 1.0, equal token counts, batch_cond_uncond on, no mask)
 # ---------------------------------------------------------------------------------------------
+def refiner_due(step, total_steps, sigma, sigmas_table, switch_at, has_refiner, on_refiner, by_sample_steps=False, enable_hr=False,
+                is_hr_pass=False, hires_fix_refiner_pass="second pass"):
+    """The decision part of apply_refiner (modules/sd_samplers_common.py:158-190; pinned by tests/golden/refiner.npz): progress
+    is measured in model timesteps — the table entry nearest to the current sigma, or the timestep itself for the DDIM family
+    (``sigmas_table`` None) — unless opts.refiner_switch_by_sample_steps; then the switch point, the checkpoint identity and the
+    hires-pass option are checked."""
+    if by_sample_steps or sigma is None:
+        completed_ratio = step / total_steps
+    else:
+        if sigmas_table is not None:
+            timestep = torch.argmin(torch.abs(sigmas_table - torch.max(sigma)))
+        else:
+            timestep = torch.max(sigma).to(dtype=int)
+        completed_ratio = (999 - timestep) / 1000
+    if switch_at is not None and completed_ratio < switch_at:
+        return False
+    if not has_refiner or on_refiner:
+        return False
+    if enable_hr:
+        if hires_fix_refiner_pass == "first pass" and is_hr_pass:
+            return False
+        if hires_fix_refiner_pass == "second pass" and not is_hr_pass:
+            return False
+    return True
+
+
 class CFGDenoiser:
     """modules/sd_samplers_cfg_denoiser.py:35-311, pinned by tests/golden/cfg_denoiser.npz (the reference class executed over
     twenty scenarios).  ``cond`` is a tensor (one prompt of weight 1 per image) or the (conds_list, tensor) pair that
@@ -203,6 +229,22 @@ class CFGDenoiser:
         self.empty_prompt = None                             # shared.sd_model.cond_stage_model_empty_prompt
         self.padded_cond_uncond = self.padded_cond_uncond_v0 = False
         self.skipped_uncond = False
+        self.refiner = None                                  # dict(inner_model=, cond=, uncond=, switch_at=[, extra=the sampler's dict])
+        self.on_refiner = False
+
+    def apply_refiner(self, sigma):
+        """modules/sd_samplers_common.py:158-202 + CFGDenoiser.update_inner_model (cfg_denoiser.py:93-98): from the switch point on
+        the refiner checkpoint's wrapped model and its own conds replace the base model's; the sampler loop's extra_args dict is
+        updated in place, so later steps pass the new conds by themselves."""
+        r = self.refiner
+        table = getattr(self.inner_model, "sigmas", None)
+        if r is None or not refiner_due(self.step, self.total_steps, sigma, table, r.get("switch_at"), True, self.on_refiner,
+                                        r.get("by_sample_steps", False)):
+            return False
+        self.inner_model, self.on_refiner = r["inner_model"], True
+        if r.get("extra") is not None:
+            r["extra"]["cond"], r["extra"]["uncond"] = r["cond"], r["uncond"]
+        return True
 
     @staticmethod
     def combine_denoised(x_out, conds_list, uncond_n, cond_scale):                       # :73-82
@@ -236,6 +278,8 @@ class CFGDenoiser:
 
     def __call__(self, x, sigma, uncond, cond, cond_scale, s_min_uncond=0.0, image_cond=None):
         b = x.shape[0]
+        if self.apply_refiner(sigma):                                                     # :160-162
+            cond, uncond = self.refiner["cond"], self.refiner["uncond"]
         conds_list, tensor = cond if isinstance(cond, tuple) else ([[(i, 1.0)] for i in range(b)], cond)
         is_edit = self.is_edit_cond_stage and self.image_cfg_scale is not None and self.image_cfg_scale != 1.0
         assert not is_edit or all(len(c) == 1 for c in conds_list)

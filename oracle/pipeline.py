@@ -58,7 +58,7 @@ def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, schedul
 def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
            latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
            y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None, parameterization="eps",
-           s_min_uncond=0.0, image_cond=None, image_cfg_scale=None, noise_multiplier=1.0):
+           s_min_uncond=0.0, image_cond=None, image_cfg_scale=None, noise_multiplier=1.0, refiner=None):
     """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
     (modules/sd_samplers_kdiffusion.py:134-143); ``mask`` (1 = keep the original latent) adds the inpainting blends of
     modules/sd_samplers_cfg_denoiser.py:186-187 / 292-293 and the final blend of modules/processing.py:1776-1784."""
@@ -75,6 +75,18 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         if y is not None:
             return model.apply_model(xi, t, c, y if xi.shape[0] == y.shape[0] else torch.cat([y, uy]))   # cond rows only: uncond skipped
         return model.apply_model(xi, t, c)
+
+    def _refiner(cfg, extra, wrap_cls=None):
+        """p.refiner_checkpoint / p.refiner_switch_at (modules/processing.py:177-178, 882-885): the refiner's UNet behind the same
+        kind of wrapper, with the conds computed for it (p.setup_conds after the reload, sd_samplers_common.py:198)."""
+        if refiner is None:
+            return
+        rm = refiner["model"]
+        am = lambda xi, t, c, ic=None: rm.apply_model(xi if ic is None else torch.cat([xi, ic], dim=1), t, c)
+        inner = wrap_cls(am, rm.alphas_cumprod) if wrap_cls is not None else am
+        cfg.refiner = dict(inner_model=inner, cond=refiner["cond"], uncond=refiner["uncond"], switch_at=refiner.get("switch_at"),
+                           by_sample_steps=refiner.get("by_sample_steps", False), extra=extra)
+        cfg.total_steps = refiner.get("total_steps", steps)
 
     def _edit(cfg):                              # InstructPix2Pix: cond_stage_key "edit" + p.image_cfg_scale (cfg_denoiser.py:166)
         if image_cfg_scale is not None:
@@ -97,6 +109,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         _edit(cfg)
         ts = kd.ddim_timesteps(steps)
         extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond, image_cond=image_cond)
+        _refiner(cfg, extra)
         if init_latent is not None:
             total, t_enc = kd.setup_img2img_steps(steps, denoising_strength, img2img_steps_given)
             ts = kd.ddim_timesteps(total)
@@ -121,6 +134,7 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
     cfg = kd.CFGDenoiser(wrap, mask, nmask, init_latent)
     _edit(cfg)
     extra = dict(uncond=uncond, cond=cond, cond_scale=cfg_scale, s_min_uncond=s_min_uncond, image_cond=image_cond)
+    _refiner(cfg, extra, type(wrap))
     if init_latent is None:
         sigmas = get_sigmas(wrap, sampler, steps, scheduler)
         x = x * sigmas[0]

@@ -53,6 +53,12 @@ class StableDiffusionProcessing:
     sampler_noise_scheduler_override: Any = None
     is_hr_pass: bool = False
     inpainting_mask_weight: float = None              # opts.inpainting_mask_weight ("Conditional mask weight")
+    refiner_sd_model: Any = None                      # p.refiner_checkpoint (:177, 882-885) as a second, resident SdModel
+    refiner_switch_at: float = None                   # :178
+    refiner_c: Optional[torch.Tensor] = None          # conds encoded by the refiner's own text encoder (p.setup_conds after the switch)
+    refiner_uc: Optional[torch.Tensor] = None
+    refiner_y: Optional[torch.Tensor] = None
+    refiner_uy: Optional[torch.Tensor] = None
     is_using_inpainting_conditioning: bool = False
     # runtime
     sampler: Any = None
@@ -363,11 +369,13 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
                            subseed_strength=0, prompts=None)                                      # :987-988
         if p.y is not None:
             p.y, p.uy = p_y_all, p_uy_all
-        decode_model = getattr(p, "hr_sd_model", None) if getattr(p, "enable_hr", False) and getattr(p, "hr_sd_model", None) is not None else p.sd_model
+        # the model that finished the sampling decodes (a hires checkpoint or the refiner is still "loaded" at :1002 / :1459)
+        decode_model = p.sampler.sd_model if getattr(p, "sampler", None) is not None else p.sd_model
         x_samples = decode_latent_batch(decode_model, samples, check_for_nans=False)             # :1002 (hires: decoded inside sample_hr_pass, :1459)
         u8 = ops.image_to_u8(x_samples)                                                           # :1004-1005, 1034-1035
         images.extend(list(u8.cpu().numpy()))
         if p.keep_latents:
             latents.append(samples)
     p.close()
+    shared.sd_model = p.sd_model                                     # :941 reload_model_weights(): back from a refiner
     return Processed(p, images, seed, p.all_seeds, torch.cat(latents) if latents else None)

@@ -167,6 +167,42 @@ class LCMCompVisDenoiser(CompVisDenoiser):
         return k_out + k_skip, k_out * c_out, c_in
 
 
+def apply_refiner(cfg_denoiser, sigma=None):
+    """modules/sd_samplers_common.py:158-202.  The reference reloads the refiner checkpoint over the base model
+    (sd_models.reload_model_weights) and recomputes the conds with it; with 288 GB of HBM both engines stay resident:
+    ``p.refiner_sd_model`` is a second SdModel, ``p.refiner_c / refiner_uc`` (and ``refiner_y / refiner_uy`` for SDXL) are the
+    conds encoded by ITS text encoder, and the switch is a pointer swap on the sampler."""
+    opts = shared.opts
+    p = cfg_denoiser.p
+    if opts.refiner_switch_by_sample_steps or sigma is None:
+        completed_ratio = cfg_denoiser.step / cfg_denoiser.total_steps
+    else:
+        try:       # torch.max(sigma) only to handle rare case where we might have different sigmas in the same batch
+            timestep = torch.argmin(torch.abs(cfg_denoiser.inner_model.sigmas - torch.max(sigma).cpu()))
+        except AttributeError:  # for samplers that don't use sigmas (DDIM) sigma is actually the timestep
+            timestep = torch.max(sigma).to(dtype=int)
+        completed_ratio = (999 - int(timestep)) / 1000
+    refiner_switch_at = getattr(p, "refiner_switch_at", None)
+    refiner = getattr(p, "refiner_sd_model", None)
+    if refiner_switch_at is not None and completed_ratio < refiner_switch_at:
+        return False
+    if refiner is None or cfg_denoiser.sampler.sd_model is refiner:
+        return False
+    if getattr(p, "enable_hr", False):
+        is_second_pass = p.is_hr_pass
+        if opts.hires_fix_refiner_pass == "first pass" and is_second_pass:
+            return False
+        if opts.hires_fix_refiner_pass == "second pass" and not is_second_pass:
+            return False
+        if opts.hires_fix_refiner_pass != "second pass":
+            p.extra_generation_params['Hires refiner'] = opts.hires_fix_refiner_pass
+    p.extra_generation_params['Refiner switch at'] = refiner_switch_at
+    cfg_denoiser.sampler.sd_model = refiner                  # = reload_model_weights(info=refiner_checkpoint_info)
+    shared.sd_model = refiner
+    cfg_denoiser.update_inner_model()                         # p.setup_conds() + new wrapped model
+    return True
+
+
 # ------------------------------------------------------------------------------------------------------------
 # CFG denoiser (fused)
 # ------------------------------------------------------------------------------------------------------------
@@ -210,6 +246,24 @@ class CFGDenoiser:
             self.model_wrap = denoiser(self.sampler.sd_model, quantize=shared.opts.enable_quantization)
         return self.model_wrap
 
+    def update_inner_model(self):
+        """modules/sd_samplers_cfg_denoiser.py:93-98 after a refiner switch: drop the wrapped model (rebuilt over the new
+        checkpoint's alphas) and put the refiner's conds into the sampler loop's extra_args."""
+        self.model_wrap = None
+        self._ctx_key = None
+        p, lo = self.p, self.p.iteration * self.p.batch_size
+        if getattr(p, "refiner_c", None) is None or getattr(p, "refiner_uc", None) is None:
+            raise ValueError("p.refiner_c / p.refiner_uc (conds encoded for the refiner checkpoint) are required")
+        dev = self.sampler.sd_model.device
+        args = self.sampler.sampler_extra_args
+        args['cond'] = p.refiner_c[lo:lo + p.batch_size].to(dev)
+        args['uncond'] = p.refiner_uc[lo:lo + p.batch_size].to(dev)
+        if getattr(p, "refiner_y", None) is not None:
+            args['y'], args['uy'] = p.refiner_y[lo:lo + p.batch_size].to(dev), p.refiner_uy[lo:lo + p.batch_size].to(dev)
+        else:
+            args.pop('y', None)
+            args.pop('uy', None)
+
     def _ensure_context(self, ctx_parts):
         """Cache the cross-attention K / V projections of the UNet batch's context rows (cat of ``ctx_parts``)."""
         key = (tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ctx_parts),
@@ -251,6 +305,9 @@ class CFGDenoiser:
         (two UNet calls, or opts.pad_cond_uncond / pad_cond_uncond_v0) and the inpainting blends follow the reference."""
         if shared.state.interrupted or shared.state.skipped:
             raise InterruptedException
+        if apply_refiner(self, sigma):                        # :160-162
+            args = self.sampler.sampler_extra_args
+            cond, uncond, y, uy = args['cond'], args['uncond'], args.get('y'), args.get('uy')
         opts = shared.opts
         sd_model = self.sampler.sd_model
         eng = sd_model.engine

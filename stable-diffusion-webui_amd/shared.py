@@ -37,6 +37,8 @@ class Options:
     img2img_extra_noise: float = 0.0
     inpainting_mask_weight: float = 1.0            # :216
     upscaler_for_img2img: str = None               # :106
+    hires_fix_refiner_pass: str = "second pass"    # :185
+    refiner_switch_by_sample_steps: bool = False   # :256
     initial_noise_multiplier: float = 1.0          # :217
     img2img_fix_steps: bool = False
     enable_quantization: bool = False              # :176

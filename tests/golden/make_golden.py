@@ -732,6 +732,53 @@ def gen_resize_image():
     print("resize_image.npz")
 
 
+def refiner_cases():
+    """(step, total_steps, sigma or None, sigma-space?, switch_at, by_steps, has_refiner, already_refiner, enable_hr, is_hr_pass, hires_pass_opt)"""
+    cases = []
+    for step, sigma in ((0, 14.6), (3, 6.1), (7, 1.9), (12, 0.71), (17, 0.2), (19, 0.03)):
+        for switch_at in (0.5, 0.8, None):
+            cases.append((step, 20, sigma, True, switch_at, False, True, False, False, False, "second pass"))
+            cases.append((step, 20, sigma, True, switch_at, True, True, False, False, False, "second pass"))
+    for t in (981.0, 601.0, 421.0, 201.0, 1.0):
+        cases.append((5, 20, t, False, 0.6, False, True, False, False, False, "second pass"))
+    cases.append((15, 20, 0.4, True, 0.5, False, False, False, False, False, "second pass"))     # no refiner given
+    cases.append((15, 20, 0.4, True, 0.5, False, True, True, False, False, "second pass"))       # already on the refiner
+    for opt in ("first pass", "second pass", "both passes"):
+        for is_hr in (False, True):
+            cases.append((15, 20, 0.4, True, 0.5, False, True, False, True, is_hr, opt))
+    cases.append((15, 20, None, True, 0.5, False, True, False, False, False, "second pass"))     # sigma None -> by steps
+    return cases
+
+
+def gen_refiner():
+    """Exec apply_refiner from modules/sd_samplers_common.py (:158-202) and record its decision for refiner_cases()."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import kdiffusion as okd
+    src = open(os.path.join(REF, "modules/sd_samplers_common.py")).read()
+    a = src.index("def apply_refiner(")
+    ns = {"torch": torch}
+    opts = types.SimpleNamespace()
+    base_info, ref_info = types.SimpleNamespace(short_title="base"), types.SimpleNamespace(short_title="refiner")
+    shared = types.SimpleNamespace(sd_model=types.SimpleNamespace(sd_checkpoint_info=base_info))
+    calls = []
+    ns.update(opts=opts, shared=shared, devices=types.SimpleNamespace(torch_gc=lambda: None),
+              sd_models=types.SimpleNamespace(SkipWritingToConfig=lambda: __import__("contextlib").nullcontext(),
+                                              reload_model_weights=lambda info=None: calls.append(info)))
+    exec(src[a:src.index("class TorchHijack")], ns)
+    sigmas = okd.CompVisDenoiser(None, okd.make_alphas_cumprod()).sigmas
+    out = []
+    for (step, total, sigma, sigma_space, switch_at, by_steps, has_ref, already, enable_hr, is_hr, hopt) in refiner_cases():
+        opts.refiner_switch_by_sample_steps, opts.hires_fix_refiner_pass = by_steps, hopt
+        shared.sd_model.sd_checkpoint_info = ref_info if already else base_info
+        p = types.SimpleNamespace(extra_generation_params={}, refiner_switch_at=switch_at, refiner_checkpoint_info=ref_info if has_ref else None,
+                                  enable_hr=enable_hr, is_hr_pass=is_hr, setup_conds=lambda: None)
+        inner = types.SimpleNamespace(sigmas=sigmas) if sigma_space else types.SimpleNamespace()
+        d = types.SimpleNamespace(step=step, total_steps=total, p=p, inner_model=inner, update_inner_model=lambda: None)
+        out.append(bool(ns["apply_refiner"](d, None if sigma is None else torch.full((2,), float(sigma)))))
+    np.savez_compressed(os.path.join(OUT, "refiner.npz"), decisions=np.array(out))
+    print("refiner.npz", sum(out), "of", len(out))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -747,3 +794,4 @@ if __name__ == "__main__":
     gen_cfg_denoiser()
     gen_image_conditioning()
     gen_resize_image()
+    gen_refiner()

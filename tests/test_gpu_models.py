@@ -630,6 +630,37 @@ def test_hires_fix_image_space_upscaler_vs_oracle(dev, upscaler, kw):
     assert res.images[0].shape == ((128, 160, 3) if kw else (128, 128, 3))
 
 
+@pytest.mark.parametrize("sampler,name,by_steps", [("euler_a", "Euler a", False), ("ddim", "DDIM", False), ("dpmpp_2m", "DPM++ 2M", True)])
+def test_refiner_switch_vs_oracle(dev, tiny, sampler, name, by_steps):
+    """p.refiner_checkpoint / refiner_switch_at (modules/sd_samplers_common.py:158-202): from the switch point on the second,
+    resident checkpoint and ITS conds drive the same sampler loop; the final decode uses the refiner's first stage."""
+    from oracle import pipeline as opipe, unet as ou, vae as ov
+    schema, processing, shared = sub("schema"), sub("processing"), sub("shared")
+    ucfg, vcfg = schema.tiny_unet(), schema.tiny_vae()
+    sd2 = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16, seed=0xBEEF)
+    refiner = sub("sd_models").SdModel(sd2, ucfg, vcfg, device=0)
+    om2 = opipe.OracleModel(sd2, ou.tiny_config(), ov.tiny_vae_config())
+    cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+    g = torch.Generator().manual_seed(99)
+    rc, ruc = torch.randn(2, 77, 64, generator=g), torch.randn(2, 77, 64, generator=g)
+    keep = shared.opts.refiner_switch_by_sample_steps
+    shared.opts.refiner_switch_by_sample_steps = by_steps
+    try:
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=4000, batch_size=2, steps=8,
+                                                        cfg_scale=6.0, width=128, height=128, sampler_name=name,
+                                                        refiner_sd_model=refiner, refiner_switch_at=0.5, refiner_c=rc, refiner_uc=ruc)
+        res = processing.process_images(p)
+    finally:
+        shared.opts.refiner_switch_by_sample_steps = keep
+    assert shared.sd_model is tiny["model"]
+    ref = dict(model=om2, cond=rc, uncond=ruc, switch_at=0.5, by_sample_steps=by_steps)
+    lat = opipe.sample(tiny["oracle"], cond, uncond, [4000, 4001], 8, sampler, 6.0, (16, 16), refiner=ref)
+    base_only = opipe.sample(tiny["oracle"], cond, uncond, [4000, 4001], 8, sampler, 6.0, (16, 16))
+    assert rel_l2(res.latents.cpu(), lat) < 1.5e-2 and rel_l2(base_only, lat) > 5e-2
+    u8 = opipe.to_uint8_hwc(opipe.decode(om2, lat))
+    assert np.abs(np.stack(res.images).astype(np.int32) - u8.astype(np.int32)).mean() < 2.5
+
+
 def test_sd15_full_size_unet_single_forward_vs_oracle(dev):
     """The real SD1.5 architecture (859,520,964 parameters), 32x32 latent, batch 2: one forward vs the fp32 oracle."""
     schema = sub("schema")

@@ -293,6 +293,20 @@ def test_resize_image_matches_reference(golden_dir):
     assert opipe.hires_target_resolution(768, 512, hr_resize_x=1024, hr_resize_y=1024) == (1536, 1024, 64, 0)
 
 
+def test_refiner_switch_decision_matches_reference(golden_dir):
+    """oracle refiner_due == apply_refiner (modules/sd_samplers_common.py:158-190) exec'd by make_golden over 50 cases: sigma- and
+    timestep-space progress, switch by sampling steps, missing / already active refiner, the three hires-pass options."""
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "refiner.npz"))["decisions"]
+    table = kd.CompVisDenoiser(None, kd.make_alphas_cumprod()).sigmas
+    cases = mg.refiner_cases()
+    assert len(cases) == len(z) == 50 and 10 < z.sum() < 40
+    for want, (step, total, sigma, sigma_space, switch_at, by_steps, has_ref, already, enable_hr, is_hr, hopt) in zip(z, cases):
+        got = kd.refiner_due(step, total, None if sigma is None else torch.full((2,), float(sigma)), table if sigma_space else None,
+                             switch_at, has_ref, already, by_steps, enable_hr, is_hr, hopt)
+        assert bool(got) == bool(want), (step, sigma, switch_at, by_steps, enable_hr, is_hr, hopt)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
