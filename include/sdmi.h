@@ -242,6 +242,21 @@ int sdmi_unet_update_weight(sdmi_engine* e, const char* key, const void* data, i
 int sdmi_lora_merge(void* out_f32, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype,
                     int rows, int cols, int rank, float scale, void* stream);
 
+/* The other LyCORIS module types of extensions-builtin/Lora (dispatch order networks.py:26-36), all on fp32 device buffers with the
+ * layer's current weight W viewed [rows][cols], cols = Cin*kh*kw; the small factor products they start from are plain
+ * sdmi_lora_merge calls over a zero W.
+ *   hadamard  LoHa, network_hada.py:28-55:   out = W + scale * a * b                      (a, b = the two rebuilt products)
+ *   kron      LoKr, network_lokr.py:19-23:   out = W + scale * kron(w1[r1][c1], w2[r2][c2][k])   (k = kh*kw taps of w2)
+ *   ia3       IA3,  network_ia3.py:18-30:    out = W + scale * W * v[col if on_input else row]
+ *   dora      DoRA, network.py:175-194:      out = W + mult * ((W + delta) * dora_scale[j] / ||(W + delta)[:, j]|| - W), the
+ *             norm per input channel j over (out, kh, kw); delta = the module's updown * calc_scale (fp32 [rows][cin][k]). */
+int sdmi_weight_hadamard(void* out_f32, const void* w_f32, const void* a_f32, const void* b_f32, float scale, int64_t n, void* stream);
+int sdmi_weight_kron(void* out_f32, const void* w_f32, const void* w1_f32, const void* w2_f32, int r1, int c1, int r2, int c2, int k,
+                     float scale, void* stream);
+int sdmi_weight_ia3(void* out_f32, const void* w_f32, const void* v_f32, int rows, int cols, int on_input, float scale, void* stream);
+int sdmi_weight_dora(void* out_f32, const void* w_f32, const void* delta_f32, const void* dora_scale_f32, int rows, int cin, int k,
+                     float mult, void* stream);
+
 int sdmi_vae_configure(sdmi_engine* e, const sdmi_vae_config* cfg);
 int sdmi_vae_load_tensor(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim,
                          const int64_t* shape, int on_device);

@@ -4,7 +4,9 @@ Follows /root/reference/extensions-builtin/Lora: key grouping and lookup network
 names networks.py:56-120 (pinned by tests/golden/lora_names.json, produced by executing that function), module creation
 network_lora.py:9-35, delta network_lora.py:65-80 + lyco_helpers.py:9-15, scaling network.py:161-173 / 196-216, weight
 rewrite networks.py:455-472 (W + updown per loaded network, in list order).  UNet layers only (the text encoder is not
-on the engine's path); cp-decomposition (lora_mid), DoRA, bias and the other LyCORIS module types are not restated."""
+on the engine's path).  All LyCORIS module types of the reference except OFT / BOFT are restated (LoRA / LoCon incl.
+cp-decomposition and DoRA, LoHa, LoKr, GLoRA, IA3, full, norm) and pinned by tests/golden/lyco.npz, which make_golden produces by
+loading the reference's network_*.py files."""
 from __future__ import annotations
 
 import re
@@ -96,21 +98,145 @@ def group_network(lora_sd: dict, mapping: dict, is_sd2: bool = False):
     return matched, failed
 
 
-def calc_updown(w: dict, orig_shape, multiplier: float) -> torch.Tensor:
-    if "lora_A.weight" in w:
-        w = dict(w, **{"lora_up.weight": w["lora_B.weight"], "lora_down.weight": w["lora_A.weight"]})
-    up, down = w["lora_up.weight"].float(), w["lora_down.weight"].float()
-    if "lora_mid.weight" in w:
-        raise NotImplementedError("cp-decomposition")
-    dim = down.shape[0]
-    updown = (up.reshape(up.size(0), -1) @ down.reshape(down.size(0), -1)).reshape(orig_shape)
+def _cp(t, wa, wb):
+    """lyco_helpers.make_weight_cp (:4-6): contract the Tucker core t[i,j,k,l] with wa[i,r] and wb[j,r']."""
+    temp = torch.einsum('i j k l, j r -> i r k l', t, wb)
+    return torch.einsum('i j k l, i r -> r j k l', temp, wa)
+
+
+def _conventional(up, down, shape, dyn_dim=None):
+    """lyco_helpers.rebuild_conventional (:9-15)"""
+    up, down = up.reshape(up.size(0), -1), down.reshape(down.size(0), -1)
+    if dyn_dim is not None:
+        up, down = up[:, :dyn_dim], down[:dyn_dim, :]
+    return (up @ down).reshape(shape)
+
+
+def module_kind(w: dict) -> str:
+    """Dispatch of networks.py:26-36 (module_types order: lora, hada, ia3, lokr, full, norm, glora, oft)."""
+    if all(x in w for x in ("lora_up.weight", "lora_down.weight")) or all(x in w for x in ("lora_A.weight", "lora_B.weight")):
+        return "lora"
+    if all(x in w for x in ("hada_w1_a", "hada_w1_b", "hada_w2_a", "hada_w2_b")):
+        return "hada"
+    if "weight" in w:
+        return "ia3"
+    if ("lokr_w1" in w or ("lokr_w1_a" in w and "lokr_w1_b" in w)) and ("lokr_w2" in w or ("lokr_w2_a" in w and "lokr_w2_b" in w)):
+        return "lokr"
+    if "diff" in w:
+        return "full"
+    if all(x in w for x in ("w_norm", "b_norm")):
+        return "norm"
+    if all(x in w for x in ("a1.weight", "a2.weight", "alpha", "b1.weight", "b2.weight")):
+        return "glora"
+    if "oft_blocks" in w or "oft_diag" in w:
+        return "oft"
+    raise AssertionError(f"Could not find a module type that would accept those keys: {', '.join(w)}")
+
+
+def calc_updown(w: dict, orig_weight, multiplier: float, dyn_dim=None, with_bias: bool = False):
+    """NetworkModule*.calc_updown + finalize_updown for every module type except OFT (network_lora.py:65-80, network_hada.py:28-55,
+    network_lokr.py:37-64, network_glora.py:21-33, network_ia3.py:18-30, network_full.py:17-27, network_norm.py:17-28,
+    network.py:175-216), pinned by tests/golden/lyco.npz.  ``orig_weight`` is the layer's current weight (a shape is accepted
+    where the type does not read it).  Returns updown, or (updown, ex_bias) with ``with_bias``."""
+    if not torch.is_tensor(orig_weight):
+        orig_weight = torch.zeros(tuple(orig_weight))
+    orig = orig_weight.float()
+    w = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in w.items()}
+    kind = module_kind(w)
+    dim, ex_bias = None, None
+    if kind == "lora":
+        if "lora_A.weight" in w:
+            w = dict(w, **{"lora_up.weight": w["lora_B.weight"], "lora_down.weight": w["lora_A.weight"]})
+        up, down = w["lora_up.weight"], w["lora_down.weight"]
+        dim = down.shape[0]
+        if orig.dim() == 4 and down.dim() == 2:                         # conv layers keep their factors as 1x1 convs (:36-52)
+            down = down.reshape(down.shape[0], -1, 1, 1)
+        if orig.dim() == 4:
+            up = up.reshape(up.shape[0], -1, 1, 1)
+        output_shape = [up.size(0), down.size(1)]
+        if "lora_mid.weight" in w:                                       # cp-decomposition (lyco_helpers.py:18-21)
+            mid = w["lora_mid.weight"]
+            updown = torch.einsum('n m k l, i n, m j -> i j k l', mid, up.reshape(up.size(0), -1), down.reshape(down.size(0), -1))
+            output_shape += mid.shape[2:]
+        else:
+            if down.dim() == 4:
+                output_shape += down.shape[2:]
+            updown = _conventional(up, down, output_shape, dyn_dim)
+    elif kind == "hada":
+        w1a, w1b, w2a, w2b = w["hada_w1_a"], w["hada_w1_b"], w["hada_w2_a"], w["hada_w2_b"]
+        dim = w1b.shape[0]
+        output_shape = [w1a.size(0), w1b.size(1)]
+        if w.get("hada_t1") is not None:
+            output_shape = [w1a.size(1), w1b.size(1)]
+            updown1 = _cp(w["hada_t1"], w1a, w1b)
+            output_shape += w["hada_t1"].shape[2:]
+        else:
+            if w1b.dim() == 4:
+                output_shape += w1b.shape[2:]
+            updown1 = _conventional(w1a, w1b, output_shape)
+        updown2 = _cp(w["hada_t2"], w2a, w2b) if w.get("hada_t2") is not None else _conventional(w2a, w2b, output_shape)
+        updown = updown1 * updown2
+    elif kind == "lokr":
+        if w.get("lokr_w1_b") is not None:
+            dim = w["lokr_w1_b"].shape[0]
+        if w.get("lokr_w2_b") is not None:
+            dim = w["lokr_w2_b"].shape[0]
+        w1 = w["lokr_w1"] if w.get("lokr_w1") is not None else w["lokr_w1_a"] @ w["lokr_w1_b"]
+        if w.get("lokr_w2") is not None:
+            w2 = w["lokr_w2"]
+        elif w.get("lokr_t2") is None:
+            w2 = w["lokr_w2_a"] @ w["lokr_w2_b"]
+        else:
+            w2 = _cp(w["lokr_t2"], w["lokr_w2_a"], w["lokr_w2_b"])
+        output_shape = [w1.size(0) * w2.size(0), w1.size(1) * w2.size(1)]
+        if orig.dim() == 4:
+            output_shape = orig.shape
+        if w2.dim() == 4:
+            w1 = w1.unsqueeze(2).unsqueeze(2)
+        updown = torch.kron(w1, w2.contiguous()).reshape(tuple(output_shape))
+    elif kind == "glora":
+        w1a, w1b, w2a, w2b = w["a1.weight"], w["b1.weight"], w["a2.weight"], w["b2.weight"]
+        output_shape = [w1a.size(0), w1b.size(1)]
+        updown = (w2b @ w1b) + ((orig @ w2a) @ w1a)
+    elif kind == "ia3":
+        ww = w["weight"]
+        output_shape = [ww.size(0), orig.size(1)]
+        if w["on_input"].item():
+            output_shape.reverse()
+        else:
+            ww = ww.reshape(-1, 1)
+        updown = orig * ww
+    elif kind == "full":
+        updown, output_shape, ex_bias = w["diff"], w["diff"].shape, w.get("diff_b")
+    elif kind == "norm":
+        updown, output_shape, ex_bias = w["w_norm"], w["w_norm"].shape, w.get("b_norm")
+    else:
+        raise NotImplementedError(kind)
+
+    # finalize_updown (network.py:196-216)
+    if w.get("bias") is not None:
+        updown = updown.reshape(w["bias"].shape) + w["bias"]
+        updown = updown.reshape(tuple(output_shape))
+    if len(output_shape) == 4:
+        updown = updown.reshape(tuple(output_shape))
+    if orig.numel() == updown.numel():
+        updown = updown.reshape(orig.shape)
+    if ex_bias is not None:
+        ex_bias = ex_bias * multiplier
     if "scale" in w:
         scale = w["scale"].item()
-    elif "alpha" in w:
+    elif dim is not None and "alpha" in w:
         scale = w["alpha"].item() / dim
     else:
         scale = 1.0
-    return updown * scale * multiplier
+    updown = updown * scale
+    if w.get("dora_scale") is not None:                                  # apply_weight_decompose (network.py:175-194)
+        merged = updown + orig
+        norm = (merged.transpose(0, 1).reshape(merged.shape[1], -1).norm(dim=1, keepdim=True)
+                .reshape(merged.shape[1], *[1] * (orig.dim() - 1)).transpose(0, 1))
+        updown = merged * (w["dora_scale"] / norm) - orig
+    updown = updown * multiplier
+    return (updown, ex_bias) if with_bias else updown
 
 
 def merge(state_dict: dict, networks, prefix: str = "model.diffusion_model.") -> dict:
@@ -123,5 +249,5 @@ def merge(state_dict: dict, networks, prefix: str = "model.diffusion_model.") ->
         for key, w in matched.items():
             ck = mapping[key]
             base = out[ck].float()
-            out[ck] = base + calc_updown(w, base.shape, mult)
+            out[ck] = base + calc_updown(w, base, mult)
     return out

@@ -110,6 +110,10 @@ _SIGS = {
     "sdmi_clip_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sdmi_unet_update_weight": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
     "sdmi_lora_merge": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sdmi_weight_hadamard": (_i, [_vp, _vp, _vp, _vp, _f, _i64, _vp]),
+    "sdmi_weight_kron": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "sdmi_weight_ia3": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "sdmi_weight_dora": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "sdmi_vae_configure": (_i, [_vp, C.POINTER(VAEConfigC)]),
     "sdmi_vae_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
     "sdmi_vae_finalize": (_i, [_vp]),

@@ -312,6 +312,37 @@ int sdmi_lora_merge(void* out, const void* w, int w_dtype, const void* up, int u
     return launch_lora_merge((float*)out, w, w_dtype, up, up_dtype, down, down_dtype, rows, cols, rank, scale, (hipStream_t)stream);
     API_GUARD_END
 }
+
+int sdmi_weight_hadamard(void* out, const void* w, const void* a, const void* b, float scale, int64_t n, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(out && w && a && b && n > 0, "bad arguments");
+    return launch_weight_hadamard((float*)out, (const float*)w, (const float*)a, (const float*)b, scale, n, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_weight_kron(void* out, const void* w, const void* w1, const void* w2, int r1, int c1, int r2, int c2, int k, float scale,
+                     void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(out && w && w1 && w2 && r1 > 0 && c1 > 0 && r2 > 0 && c2 > 0 && k > 0, "bad arguments");
+    return launch_weight_kron((float*)out, (const float*)w, (const float*)w1, (const float*)w2, r1, c1, r2, c2, k, scale, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_weight_ia3(void* out, const void* w, const void* v, int rows, int cols, int on_input, float scale, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(out && w && v && rows > 0 && cols > 0, "bad arguments");
+    return launch_weight_ia3((float*)out, (const float*)w, (const float*)v, rows, cols, on_input, scale, (hipStream_t)stream);
+    API_GUARD_END
+}
+
+int sdmi_weight_dora(void* out, const void* w, const void* delta, const void* dora_scale, int rows, int cin, int k, float mult,
+                     void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(out && w && delta && dora_scale && rows > 0 && cin > 0 && k > 0, "bad arguments");
+    return launch_weight_dora((float*)out, (const float*)w, (const float*)delta, (const float*)dora_scale, rows, cin, k, mult,
+                              (hipStream_t)stream);
+    API_GUARD_END
+}
 int sdmi_clip_configure(sdmi_engine* e, int slot, const sdmi_clip_config* cfg) {
     API_GUARD_BEGIN
     SDMI_REQUIRE(e && cfg, "null argument");

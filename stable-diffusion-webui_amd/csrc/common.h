@@ -115,6 +115,12 @@ int launch_layernorm(const half_t* x, const float* gamma, const float* beta, hal
 // ---- elementwise / misc -----------------------------------------------------------------------------------
 int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t offset, hipStream_t s);
 int launch_cfg_prepare(const float* x, const float* c_in, void* xin, int out_dtype, int B, int reps, int64_t chw, hipStream_t s);
+int launch_weight_hadamard(float* out, const float* w, const float* a, const float* b, float scale, int64_t n, hipStream_t s);
+int launch_weight_kron(float* out, const float* w, const float* w1, const float* w2, int r1, int c1, int r2, int c2, int k, float scale,
+                       hipStream_t s);
+int launch_weight_ia3(float* out, const float* w, const float* v, int rows, int cols, int on_input, float scale, hipStream_t s);
+int launch_weight_dora(float* out, const float* w, const float* delta, const float* dora_scale, int rows, int cin, int k, float mult,
+                       hipStream_t s);
 int launch_cfg_prepare_concat(const float* x, const float* c_in, const float* cond, void* xin, int out_dtype, int B, int reps,
                               int C, int Cc, int64_t hw, unsigned zero_reps, hipStream_t s);
 int launch_cfg_combine(const float* x, const float* eps, const float* c_out, float cond_scale, int mode,

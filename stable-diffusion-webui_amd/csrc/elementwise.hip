@@ -416,6 +416,84 @@ int launch_lora_merge(float* out, const void* w, int w_dtype, const void* up, in
     return 0;
 }
 
+// ---- LyCORIS weight deltas other than plain LoRA (extensions-builtin/Lora/network_{hada,lokr,ia3}.py, network.py:175-194).
+// All fp32, W = the layer's current weight viewed [rows][cols] (cols = Cin*kh*kw), done once per network change.
+
+// LoHa (network_hada.py:52): out = W + scale * a * b, a and b the two rebuilt low-rank products.
+__global__ __launch_bounds__(256) void weight_hadamard_kernel(float* out, const float* w, const float* a, const float* b, float scale, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = w[i] + scale * (a[i] * b[i]);
+}
+// LoKr (network_lokr.py:19-23 make_kron): out[(i1*r2+i2)][(j1*c2+j2)][k] = W + scale * w1[i1][j1] * w2[i2][j2][k], k = kh*kw taps.
+__global__ __launch_bounds__(256) void weight_kron_kernel(float* out, const float* w, const float* w1, const float* w2, int r1, int c1,
+                                                          int r2, int c2, int k, float scale) {
+    const long n = (long)r1 * r2 * c1 * c2 * k;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int kk = (int)(i % k);
+        const long rc = i / k;
+        const int col = (int)(rc % ((long)c1 * c2)), row = (int)(rc / ((long)c1 * c2));
+        const int i1 = row / r2, i2 = row - i1 * r2, j1 = col / c2, j2 = col - j1 * c2;
+        out[i] = w[i] + scale * (w1[(long)i1 * c1 + j1] * w2[((long)i2 * c2 + j2) * k + kk]);
+    }
+}
+// IA3 (network_ia3.py:18-30): out = W + scale * W * v, v indexed by the input column (on_input) or the output row.
+__global__ __launch_bounds__(256) void weight_ia3_kernel(float* out, const float* w, const float* v, int rows, int cols, int on_input,
+                                                         float scale) {
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+        out[i] = w[i] + scale * (w[i] * v[on_input ? c : r]);
+    }
+}
+// DoRA (network.py:175-194 apply_weight_decompose): merged = W + delta; per INPUT channel j the L2 norm over (out, kh, kw);
+// out = W + mult * (merged * dora_scale[j] / norm[j] - W).  One workgroup per input channel: reduce, then rescale.
+__global__ __launch_bounds__(256) void weight_dora_kernel(float* out, const float* w, const float* delta, const float* dora_scale, int rows,
+                                                          int cin, int k, float mult) {
+    __shared__ float red[256];
+    const int j = blockIdx.x;
+    const long per_row = (long)cin * k;
+    const int cnt = rows * k;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const long idx = (long)(e / k) * per_row + (long)j * k + (e % k);
+        const float m = w[idx] + delta[idx];
+        acc += m * m;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float f = dora_scale[j] / sqrtf(red[0]);
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const long idx = (long)(e / k) * per_row + (long)j * k + (e % k);
+        const float m = w[idx] + delta[idx];
+        out[idx] = w[idx] + mult * (m * f - w[idx]);
+    }
+}
+int launch_weight_hadamard(float* out, const float* w, const float* a, const float* b, float scale, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(weight_hadamard_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, out, w, a, b, scale, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_weight_kron(float* out, const float* w, const float* w1, const float* w2, int r1, int c1, int r2, int c2, int k, float scale,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(weight_kron_kernel, dim3(ew_blocks((int64_t)r1 * r2 * c1 * c2 * k)), dim3(256), 0, s, out, w, w1, w2, r1, c1, r2, c2, k, scale);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_weight_ia3(float* out, const float* w, const float* v, int rows, int cols, int on_input, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(weight_ia3_kernel, dim3(ew_blocks((int64_t)rows * cols)), dim3(256), 0, s, out, w, v, rows, cols, on_input, scale);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_weight_dora(float* out, const float* w, const float* delta, const float* dora_scale, int rows, int cin, int k, float mult,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(weight_dora_kernel, dim3(cin), dim3(256), 0, s, out, w, delta, dora_scale, rows, cin, k, mult);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void image_to_u8_kernel(const float* img, uint8_t* out, int C, long HW, long n) {
     // n = B*HW*C output elements, NHWC
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {

@@ -6,8 +6,10 @@ lora_patches.py:7-18) — hooks a fused UNet never runs.  Here ``load_networks``
 rewrite eagerly: for every UNet layer a loaded network touches, start from the checkpoint weight (the "backup",
 networks.py:423-432), add each network's delta ``up @ down * alpha/dim * multiplier`` on the GPU (sdmi_lora_merge) and
 re-pack that one layer inside the engine (sdmi_unet_update_weight).  Layers no network touches any more are restored.
-Text-encoder keys are reported in ``keys_failed_to_match`` (the text encoder is outside the engine); LyCORIS module types
-other than plain LoRA, cp-decomposition (lora_mid), DoRA and bias deltas raise NotImplementedError."""
+Text-encoder keys are reported in ``keys_failed_to_match`` (the text encoder is outside the engine).  Module types, in the
+reference's dispatch order (networks.py:26-36): LoRA / LoCon (incl. cp-decomposition, dyn_dim, the inpainting conv_in padding),
+LoHa, IA3, LoKr, full diff, GLoRA, each optionally weight-decomposed (DoRA); norm, OFT / BOFT and bias deltas raise
+NotImplementedError.  Every full-size operation is a HIP kernel (sdmi_lora_merge / sdmi_weight_*); torch only moves data."""
 from __future__ import annotations
 
 import ctypes as C
@@ -97,29 +99,23 @@ class NetworkWeights:                                     # network.py:96-101 (s
     engine_key: str
 
 
-class NetworkModuleLora:                                  # network_lora.py:25-80 + network.py:111-216
+class NetworkModule:                                      # network.py:111-216 (the parts a weight rewrite needs)
+    kind = None
+
     def __init__(self, net: "Network", weights: NetworkWeights, shape):
         self.network = net
         self.network_key = weights.network_key
         self.sd_key = weights.sd_key
         self.engine_key = weights.engine_key
         self.shape = tuple(shape)
+        self.w = weights.w
         w = weights.w
-        if "lora_mid.weight" in w:
-            raise NotImplementedError(f"{self.network_key}: cp-decomposition (lora_mid) is not implemented")
-        if "dora_scale" in w or "bias" in w:
-            raise NotImplementedError(f"{self.network_key}: DoRA / bias deltas are not implemented")
-        self.up = w["lora_up.weight"]
-        self.down = w["lora_down.weight"]
-        self.dim = self.down.shape[0]
+        self.dim = None
         self.alpha = w["alpha"].item() if "alpha" in w else None
         self.scale = w["scale"].item() if "scale" in w else None
-        rows, cols = self.shape[0], 1
-        for d in self.shape[1:]:
-            cols *= d
-        if self.up.reshape(self.up.shape[0], -1).shape != (rows, self.dim) or self.down.reshape(self.dim, -1).shape[1] != cols:
-            raise AssertionError(f"Lora layer {self.network_key}: up {tuple(self.up.shape)} @ down {tuple(self.down.shape)} "
-                                 f"does not rebuild a weight of shape {self.shape}")
+        self.dora_scale = w.get("dora_scale", None)
+        if w.get("bias") is not None:
+            raise NotImplementedError(f"{self.network_key}: 'bias' deltas are not implemented")
 
     def multiplier(self):                                 # network.py:161-165
         if 'transformer' in self.sd_key[:20]:
@@ -132,6 +128,177 @@ class NetworkModuleLora:                                  # network_lora.py:25-8
         if self.dim is not None and self.alpha is not None:
             return self.alpha / self.dim
         return 1.0
+
+    def add_delta(self, base, scale, device):
+        """base + scale * updown as a fresh fp32 tensor of the layer's shape (``base``: fp32, contiguous, on the device)."""
+        raise NotImplementedError()
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _mm(a, b, base=None, scale=1.0):
+    """base + scale * (a @ b) for fp32 device matrices through sdmi_lora_merge (zero base when omitted)."""
+    rows, rank = a.shape
+    cols = b.shape[1]
+    assert b.shape[0] == rank, (tuple(a.shape), tuple(b.shape))
+    out = torch.empty((rows, cols), dtype=torch.float32, device=a.device)
+    base = torch.zeros_like(out) if base is None else base
+    check(lib.sdmi_lora_merge(ptr(out), ptr(base), _lib.F32, ptr(a.contiguous()), _lib.F32, ptr(b.contiguous()), _lib.F32,
+                              rows, cols, rank, float(scale), stream_ptr()), "sdmi_lora_merge")
+    return out
+
+
+def _cp(t, wa, wb):
+    """lyco_helpers.make_weight_cp (:4-6) as two matrix products: out[r, r', k, l] = sum_ij t[i,j,k,l] wa[i,r] wb[j,r']."""
+    i, j, k, l = t.shape
+    rp = wb.shape[1]
+    temp = _mm(t.permute(0, 2, 3, 1).reshape(i * k * l, j).contiguous(), wb)                    # [(i,k,l), r']
+    temp = temp.reshape(i, k, l, rp).permute(0, 3, 1, 2).reshape(i, rp * k * l).contiguous()   # [i, (r',k,l)]
+    return _mm(wa.t().contiguous(), temp).reshape(wa.shape[1], rp, k, l)
+
+
+class NetworkModuleLora(NetworkModule):                   # network_lora.py:25-80
+    kind = "lora"
+
+    def __init__(self, net, weights, shape):
+        super().__init__(net, weights, shape)
+        w = weights.w
+        self.up = w["lora_up.weight"]
+        self.down = w["lora_down.weight"]
+        self.mid = w.get("lora_mid.weight")
+        self.dim = self.down.shape[0]
+        rows, cols = self.shape[0], 1
+        for d in self.shape[1:]:
+            cols *= d
+        self.pad_inpaint = False
+        if self.mid is None:
+            got_cols = self.down.reshape(self.dim, -1).shape[1]
+            if len(self.shape) == 4 and self.shape[1] == 9 and got_cols * 9 == cols * 4:
+                self.pad_inpaint = True                   # inpainting conv_in: the 4-channel delta is zero-padded to 9 (networks.py:468-470)
+            elif self.up.reshape(self.up.shape[0], -1).shape != (rows, self.dim) or got_cols != cols:
+                raise AssertionError(f"Lora layer {self.network_key}: up {tuple(self.up.shape)} @ down {tuple(self.down.shape)} "
+                                     f"does not rebuild a weight of shape {self.shape}")
+
+    def add_delta(self, base, scale, device):
+        rows = self.shape[0]
+        up = _f32(self.up, device).reshape(rows, -1)
+        down = _f32(self.down, device)
+        down = down.reshape(down.shape[0], -1)
+        if self.mid is not None:                          # cp-decomposition (lyco_helpers.py:18-21)
+            mid = _f32(self.mid, device)
+            n, m, k, l = mid.shape
+            t = _mm(mid.permute(0, 2, 3, 1).reshape(n * k * l, m).contiguous(), down)            # [(n,k,l), j]
+            j = down.shape[1]
+            t = t.reshape(n, k, l, j).permute(0, 3, 1, 2).reshape(n, j * k * l).contiguous()
+            return _mm(up, t, base.reshape(rows, -1), scale).reshape(self.shape)
+        if self.network.dyn_dim is not None:              # lyco_helpers.py:12-14
+            d = self.network.dyn_dim
+            up, down = up[:, :d].contiguous(), down[:d, :].contiguous()
+        if self.pad_inpaint:
+            kk = self.shape[2] * self.shape[3]
+            delta = _mm(up, down, None, scale).reshape(rows, 4, self.shape[2], self.shape[3])
+            delta = torch.nn.functional.pad(delta, (0, 0, 0, 0, 0, 5)).contiguous()
+            from . import ops
+            return ops.lincomb(torch.empty_like(base), [base, delta], [1.0, 1.0])
+        return _mm(up, down, base.reshape(rows, -1), scale).reshape(self.shape)
+
+
+class NetworkModuleHada(NetworkModule):                   # network_hada.py:14-55 (LoHa)
+    kind = "hada"
+
+    def __init__(self, net, weights, shape):
+        super().__init__(net, weights, shape)
+        self.dim = weights.w["hada_w1_b"].shape[0]
+
+    def add_delta(self, base, scale, device):
+        w = self.w
+        w1a, w1b, w2a, w2b = (_f32(w[k], device) for k in ("hada_w1_a", "hada_w1_b", "hada_w2_a", "hada_w2_b"))
+        t1, t2 = w.get("hada_t1"), w.get("hada_t2")
+        rebuild = lambda a, b: _mm(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1))
+        u1 = _cp(_f32(t1, device), w1a, w1b) if t1 is not None else rebuild(w1a, w1b)
+        u2 = _cp(_f32(t2, device), w2a, w2b) if t2 is not None else rebuild(w2a, w2b)
+        if u1.numel() != base.numel() or u2.numel() != base.numel():
+            raise AssertionError(f"LoHa layer {self.network_key} does not rebuild a weight of shape {self.shape}")
+        out = torch.empty_like(base)
+        check(lib.sdmi_weight_hadamard(ptr(out), ptr(base), ptr(u1.contiguous()), ptr(u2.contiguous()), float(scale), base.numel(),
+                                       stream_ptr()), "sdmi_weight_hadamard")
+        return out
+
+
+class NetworkModuleLokr(NetworkModule):                   # network_lokr.py:26-64
+    kind = "lokr"
+
+    def __init__(self, net, weights, shape):
+        super().__init__(net, weights, shape)
+        w = weights.w
+        if w.get("lokr_w1_b") is not None:
+            self.dim = w["lokr_w1_b"].shape[0]
+        if w.get("lokr_w2_b") is not None:
+            self.dim = w["lokr_w2_b"].shape[0]
+
+    def add_delta(self, base, scale, device):
+        w = self.w
+        w1 = _f32(w["lokr_w1"], device) if w.get("lokr_w1") is not None else _mm(_f32(w["lokr_w1_a"], device), _f32(w["lokr_w1_b"], device))
+        if w.get("lokr_w2") is not None:
+            w2 = _f32(w["lokr_w2"], device)
+        elif w.get("lokr_t2") is None:
+            w2 = _mm(_f32(w["lokr_w2_a"], device), _f32(w["lokr_w2_b"], device))
+        else:
+            w2 = _cp(_f32(w["lokr_t2"], device), _f32(w["lokr_w2_a"], device), _f32(w["lokr_w2_b"], device))
+        r1, c1 = w1.shape
+        r2, c2 = w2.shape[0], w2.shape[1]
+        k = w2.numel() // (r2 * c2)
+        if r1 * r2 * c1 * c2 * k != base.numel() or r1 * r2 != self.shape[0]:
+            raise AssertionError(f"LoKr layer {self.network_key}: kron({tuple(w1.shape)}, {tuple(w2.shape)}) is not a weight of shape {self.shape}")
+        out = torch.empty_like(base)
+        check(lib.sdmi_weight_kron(ptr(out), ptr(base), ptr(w1.contiguous()), ptr(w2.contiguous()), r1, c1, r2, c2, k, float(scale),
+                                   stream_ptr()), "sdmi_weight_kron")
+        return out
+
+
+class NetworkModuleGLora(NetworkModule):                  # network_glora.py:12-33
+    kind = "glora"
+
+    def add_delta(self, base, scale, device):
+        if len(self.shape) != 2:
+            raise NotImplementedError(f"GLoRA layer {self.network_key}: only linear layers")
+        w1a, w1b, w2a, w2b = (_f32(self.w[k], device) for k in ("a1.weight", "b1.weight", "a2.weight", "b2.weight"))
+        out = _mm(_mm(base, w2a), w1a, base, scale)       # (W @ a2) @ a1 reads the CURRENT weight, like the reference's orig_weight
+        return _mm(w2b, w1b, out, scale)
+
+
+class NetworkModuleIa3(NetworkModule):                    # network_ia3.py:13-30
+    kind = "ia3"
+
+    def add_delta(self, base, scale, device):
+        if len(self.shape) != 2:
+            raise NotImplementedError(f"IA3 layer {self.network_key}: only linear layers")
+        v = _f32(self.w["weight"], device).reshape(-1)
+        on_input = bool(self.w["on_input"].item())
+        rows, cols = self.shape
+        if v.numel() != (cols if on_input else rows):
+            raise AssertionError(f"IA3 layer {self.network_key}: {v.numel()} scales for a weight of shape {self.shape}")
+        out = torch.empty_like(base)
+        check(lib.sdmi_weight_ia3(ptr(out), ptr(base), ptr(v), rows, cols, int(on_input), float(scale), stream_ptr()), "sdmi_weight_ia3")
+        return out
+
+
+class NetworkModuleFull(NetworkModule):                   # network_full.py:12-27
+    kind = "full"
+
+    def __init__(self, net, weights, shape):
+        super().__init__(net, weights, shape)
+        if weights.w.get("diff_b") is not None:
+            raise NotImplementedError(f"{self.network_key}: bias differences (diff_b) are not implemented")
+
+    def add_delta(self, base, scale, device):
+        diff = _f32(self.w["diff"], device)
+        if diff.numel() != base.numel():
+            raise AssertionError(f"full-diff layer {self.network_key}: diff {tuple(diff.shape)} for a weight of shape {self.shape}")
+        from . import ops
+        return ops.lincomb(torch.empty_like(base), [base, diff.reshape(base.shape).contiguous()], [1.0, float(scale)])
 
 
 class ModuleTypeLora:                                     # network_lora.py:9-22
@@ -146,7 +313,32 @@ class ModuleTypeLora:                                     # network_lora.py:9-22
         return None
 
 
-module_types = [ModuleTypeLora()]
+class _ModuleTypeByKeys:
+    def __init__(self, cls, accepts):
+        self.cls, self.accepts = cls, accepts
+
+    def create_module(self, net, weights: NetworkWeights, shape):
+        return self.cls(net, weights, shape) if self.accepts(weights.w) else None
+
+
+def _unsupported(name):
+    def make(net, weights, shape):
+        raise NotImplementedError(f"{weights.network_key}: LyCORIS module type {name} is not implemented")
+    return make
+
+
+module_types = [                                          # the order of networks.py:26-36
+    ModuleTypeLora(),
+    _ModuleTypeByKeys(NetworkModuleHada, lambda w: all(x in w for x in ["hada_w1_a", "hada_w1_b", "hada_w2_a", "hada_w2_b"])),
+    _ModuleTypeByKeys(NetworkModuleIa3, lambda w: "weight" in w),
+    _ModuleTypeByKeys(NetworkModuleLokr, lambda w: ("lokr_w1" in w or ("lokr_w1_a" in w and "lokr_w1_b" in w))
+                      and ("lokr_w2" in w or ("lokr_w2_a" in w and "lokr_w2_b" in w))),
+    _ModuleTypeByKeys(NetworkModuleFull, lambda w: "diff" in w),
+    _ModuleTypeByKeys(_unsupported("norm (w_norm / b_norm: normalisation layers are fused into the engine's kernels)"),
+                      lambda w: all(x in w for x in ["w_norm", "b_norm"])),
+    _ModuleTypeByKeys(NetworkModuleGLora, lambda w: all(x in w for x in ["a1.weight", "a2.weight", "alpha", "b1.weight", "b2.weight"])),
+    _ModuleTypeByKeys(_unsupported("OFT / BOFT"), lambda w: "oft_blocks" in w or "oft_diag" in w),
+]
 
 
 @dataclass
@@ -155,7 +347,7 @@ class Network:                                            # network.py:104-118
     te_multiplier: float = 1.0
     unet_multiplier: float = 1.0
     dyn_dim: Optional[int] = None
-    modules: Dict[str, NetworkModuleLora] = field(default_factory=dict)
+    modules: Dict[str, NetworkModule] = field(default_factory=dict)
     keys_failed_to_match: Dict[str, str] = field(default_factory=dict)
 
 
@@ -203,24 +395,23 @@ def load_network(name, sd: dict, sd_model) -> Network:    # networks.py:150-262
     return net
 
 
-def _merge_on_device(base: torch.Tensor, module: NetworkModuleLora, device) -> torch.Tensor:
-    rows = base.shape[0]
-    cols = base.numel() // rows
-    up = module.up.to(device).contiguous()
-    down = module.down.to(device).contiguous()
-    if up.dtype not in (torch.float16, torch.float32):
-        up = up.float()
-    if down.dtype not in (torch.float16, torch.float32):
-        down = down.float()
-    if module.network.dyn_dim is not None:                # lyco_helpers.py:12-14
-        d = module.network.dyn_dim
-        up = up.reshape(rows, -1)[:, :d].contiguous()
-        down = down.reshape(down.shape[0], -1)[:d, :].contiguous()
-    rank = down.shape[0]
-    out = torch.empty(base.shape, dtype=torch.float32, device=device)
-    scale = float(module.calc_scale()) * float(module.multiplier())
-    check(lib.sdmi_lora_merge(ptr(out), ptr(base), dtype_code(base), ptr(up), dtype_code(up), ptr(down), dtype_code(down),
-                              rows, cols, rank, scale, stream_ptr()), "sdmi_lora_merge")
+def _merge_on_device(base: torch.Tensor, module: NetworkModule, device) -> torch.Tensor:
+    """One network module's contribution to one layer, network.py:196-216 finalize_updown folded in:
+    W + updown * calc_scale * multiplier, or with a ``dora_scale`` the weight-decomposed form of network.py:175-194."""
+    base = _f32(base, device)
+    scale, mult = float(module.calc_scale()), float(module.multiplier())
+    if module.dora_scale is None:
+        return module.add_delta(base, scale * mult, device)
+    if module.kind in ("ia3", "glora"):
+        raise NotImplementedError(f"{module.network_key}: DoRA on {module.kind} modules is not implemented")
+    delta = module.add_delta(torch.zeros_like(base), scale, device)
+    rows, cin = base.shape[0], base.shape[1]
+    k = base.numel() // (rows * cin)
+    dora_scale = _f32(module.dora_scale, device).reshape(-1)
+    if dora_scale.numel() != cin:
+        raise AssertionError(f"{module.network_key}: dora_scale has {dora_scale.numel()} entries for {cin} input channels")
+    out = torch.empty_like(base)
+    check(lib.sdmi_weight_dora(ptr(out), ptr(base), ptr(delta.contiguous()), ptr(dora_scale), rows, cin, k, mult, stream_ptr()), "sdmi_weight_dora")
     return out
 
 

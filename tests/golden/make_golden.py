@@ -779,6 +779,116 @@ def gen_refiner():
     print("refiner.npz", sum(out), "of", len(out))
 
 
+def lyco_cases():
+    """name -> (module kind, sd_module spec, weight-dict builder).  Shapes are small; seeds derive from the case index."""
+    lin, conv3, conv1 = ("linear", 24, 16), ("conv", 24, 16, 3), ("conv", 24, 16, 1)       # (out=24, in=16)
+
+    def t(shape, seed, scale=0.3):
+        return seeded(shape, seed, scale)
+
+    cases = {
+        "lora_linear": ("lora", lin, lambda k: {"lora_up.weight": t((24, 4), k), "lora_down.weight": t((4, 16), k + 1), "alpha": torch.tensor(2.0)}),
+        "lora_linear_scale": ("lora", lin, lambda k: {"lora_up.weight": t((24, 4), k), "lora_down.weight": t((4, 16), k + 1), "scale": torch.tensor(0.7)}),
+        "lora_conv3": ("lora", conv3, lambda k: {"lora_up.weight": t((24, 4, 1, 1), k), "lora_down.weight": t((4, 16, 3, 3), k + 1), "alpha": torch.tensor(4.0)}),
+        "lora_conv_cp": ("lora", conv3, lambda k: {"lora_up.weight": t((24, 5, 1, 1), k), "lora_down.weight": t((4, 16, 1, 1), k + 1),
+                                                   "lora_mid.weight": t((5, 4, 3, 3), k + 2), "alpha": torch.tensor(2.0)}),
+        "lora_dora": ("lora", lin, lambda k: {"lora_up.weight": t((24, 4), k), "lora_down.weight": t((4, 16), k + 1), "alpha": torch.tensor(2.0),
+                                              "dora_scale": t((1, 16), k + 2, 0.2).abs() + 1.0}),
+        "lora_conv_dora": ("lora", conv3, lambda k: {"lora_up.weight": t((24, 4, 1, 1), k), "lora_down.weight": t((4, 16, 3, 3), k + 1),
+                                                     "alpha": torch.tensor(4.0), "dora_scale": t((1, 16, 1, 1), k + 2, 0.2).abs() + 1.0}),
+        "lora_dyn": ("lora", lin, lambda k: {"lora_up.weight": t((24, 8), k), "lora_down.weight": t((8, 16), k + 1), "alpha": torch.tensor(8.0)}),
+        "hada_linear": ("hada", lin, lambda k: {"hada_w1_a": t((24, 4), k), "hada_w1_b": t((4, 16), k + 1), "hada_w2_a": t((24, 4), k + 2),
+                                                "hada_w2_b": t((4, 16), k + 3), "alpha": torch.tensor(2.0)}),
+        "hada_conv_t": ("hada", conv3, lambda k: {"hada_w1_a": t((4, 24), k), "hada_w1_b": t((4, 16), k + 1), "hada_t1": t((4, 4, 3, 3), k + 2),
+                                                  "hada_w2_a": t((4, 24), k + 3), "hada_w2_b": t((4, 16), k + 4), "hada_t2": t((4, 4, 3, 3), k + 5),
+                                                  "alpha": torch.tensor(4.0)}),
+        "lokr_full": ("lokr", lin, lambda k: {"lokr_w1": t((4, 2), k), "lokr_w2": t((6, 8), k + 1), "alpha": torch.tensor(3.0)}),
+        "lokr_lowrank": ("lokr", lin, lambda k: {"lokr_w1_a": t((4, 2), k), "lokr_w1_b": t((2, 2), k + 1), "lokr_w2_a": t((6, 3), k + 2),
+                                                 "lokr_w2_b": t((3, 8), k + 3), "alpha": torch.tensor(1.5)}),
+        "lokr_conv": ("lokr", conv3, lambda k: {"lokr_w1": t((4, 2), k), "lokr_w2": t((6, 8, 3, 3), k + 1), "alpha": torch.tensor(3.0)}),
+        "lokr_conv_t2": ("lokr", conv3, lambda k: {"lokr_w1": t((4, 2), k), "lokr_w2_a": t((3, 6), k + 1), "lokr_w2_b": t((3, 8), k + 2),
+                                                   "lokr_t2": t((3, 3, 3, 3), k + 3), "alpha": torch.tensor(3.0)}),
+        "glora": ("glora", lin, lambda k: {"a1.weight": t((4, 16), k), "a2.weight": t((16, 4), k + 1), "b1.weight": t((4, 16), k + 2),
+                                           "b2.weight": t((24, 4), k + 3), "alpha": torch.tensor(2.0)}),
+        "ia3_out": ("ia3", lin, lambda k: {"weight": t((24,), k), "on_input": torch.tensor(False)}),
+        "ia3_in": ("ia3", lin, lambda k: {"weight": t((16,), k), "on_input": torch.tensor(True)}),
+        "full": ("full", conv1, lambda k: {"diff": t((24, 16, 1, 1), k)}),
+        "full_bias": ("full", lin, lambda k: {"diff": t((24, 16), k), "diff_b": t((24,), k + 1)}),
+        "norm": ("norm", ("groupnorm", 24), lambda k: {"w_norm": t((24,), k), "b_norm": t((24,), k + 1)}),
+    }
+    return cases
+
+
+def lyco_orig_weight(spec, k):
+    if spec[0] == "linear":
+        return seeded((spec[1], spec[2]), 8000 + k, 0.2)
+    if spec[0] == "conv":
+        return seeded((spec[1], spec[2], spec[3], spec[3]), 8000 + k, 0.2)
+    return seeded((spec[1],), 8000 + k, 0.2) + 1.0
+
+
+def gen_lyco():
+    """Load extensions-builtin/Lora/{network,lyco_helpers,network_lora,network_hada,network_lokr,network_glora,network_ia3,
+    network_full,network_norm}.py by path (webui modules stubbed) and record calc_updown(orig_weight) for lyco_cases() with
+    unet_multiplier 0.8 (dyn_dim 3 for the lora_dyn case)."""
+    mods = sys.modules.setdefault("modules", types.ModuleType("modules"))
+    for n in ("sd_models", "cache", "errors", "hashes", "devices"):
+        m = types.ModuleType("modules." + n)
+        sys.modules["modules." + n] = m
+        setattr(mods, n, m)
+    sys.modules["modules.devices"].cpu = torch.device("cpu")
+    sys.modules["modules.devices"].dtype = torch.float32
+    sys.modules["modules.devices"].device = torch.device("cpu")
+    shared = types.ModuleType("modules.shared")
+    shared.opts = types.SimpleNamespace()
+    sys.modules["modules.shared"] = shared
+    mods.shared = shared
+    for n in ("modules.models", "modules.models.sd3"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    mmdit = types.ModuleType("modules.models.sd3.mmdit")
+    mmdit.QkvLinear = type("QkvLinear", (torch.nn.Linear,), {})
+    sys.modules["modules.models.sd3.mmdit"] = mmdit
+    sys.modules["modules.models"].sd3 = sys.modules["modules.models.sd3"]
+    sys.modules["modules.models.sd3"].mmdit = mmdit
+    mods.models = sys.modules["modules.models"]
+    lora_dir = "extensions-builtin/Lora/"
+    for name in ("lyco_helpers", "network"):
+        sys.modules[name] = load_by_path(name, lora_dir + name + ".py")
+    kinds = {}
+    for name, cls in (("lora", "ModuleTypeLora"), ("hada", "ModuleTypeHada"), ("lokr", "ModuleTypeLokr"), ("glora", "ModuleTypeGLora"),
+                      ("ia3", "ModuleTypeIa3"), ("full", "ModuleTypeFull"), ("norm", "ModuleTypeNorm")):
+        kinds[name] = getattr(load_by_path("network_" + name, lora_dir + "network_" + name + ".py"), cls)()
+    network = sys.modules["network"]
+    out = {}
+    for k, (name, (kind, spec, build)) in enumerate(lyco_cases().items()):
+        if spec[0] == "linear":
+            sd_module = torch.nn.Linear(spec[2], spec[1])
+        elif spec[0] == "conv":
+            sd_module = torch.nn.Conv2d(spec[2], spec[1], spec[3], padding=spec[3] // 2)
+        else:
+            sd_module = torch.nn.GroupNorm(4, spec[1])
+        orig = lyco_orig_weight(spec, k)
+        with torch.no_grad():
+            sd_module.weight.copy_(orig)
+        net = network.Network("n", None)
+        net.unet_multiplier, net.te_multiplier = 0.8, 0.3
+        net.dyn_dim = 3 if name == "lora_dyn" else None
+        w = build(9000 + 10 * k)
+        weights = network.NetworkWeights(network_key="lora_unet_x", sd_key="diffusion_model_x", w=dict(w), sd_module=sd_module)
+        module = kinds[kind].create_module(net, weights)
+        assert module is not None, name
+        for other, mt in kinds.items():          # the type dispatch order of networks.py:26-36 never mis-assigns these cases
+            if other != kind and other in ("hada", "lokr", "glora", "ia3", "full", "norm"):
+                assert mt.create_module(net, network.NetworkWeights("a", "b", dict(w), sd_module)) is None or kind == "lora", (name, other)
+        with torch.no_grad():
+            updown, ex_bias = module.calc_updown(sd_module.weight)
+        out[name + "_updown"] = updown.numpy()
+        if ex_bias is not None:
+            out[name + "_ex_bias"] = ex_bias.numpy()
+    np.savez_compressed(os.path.join(OUT, "lyco.npz"), **out)
+    print("lyco.npz", len(out))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -795,3 +905,4 @@ if __name__ == "__main__":
     gen_image_conditioning()
     gen_resize_image()
     gen_refiner()
+    gen_lyco()

@@ -8,6 +8,8 @@ Stated tolerances (fp16 weights/activations, fp32 accumulation, fp32 sampler sta
 """
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -245,6 +247,87 @@ def test_lora_merge_into_engine_vs_oracle_and_restore(dev, tiny):
         ref_sd2 = olora.merge({k: v.float() for k, v in sd.items()}, [(la, 0.9), (lb, -0.4)])
         ref2 = ou.build_unet(ou.tiny_config(), ref_sd2)(x.cpu(), t.cpu(), ctx.cpu())
         assert rel_l2(got2, ref2) < 8e-3
+    finally:
+        nets.load_networks(model, [], [])
+    assert torch.equal(fwd(), base)
+
+
+def test_lycoris_module_types_vs_reference_fixture(dev, golden_dir):
+    """Every module type of networks.module_types on the reference-generated cases of tests/golden/lyco.npz (LoRA / LoCon with
+    cp-decomposition, DoRA and dyn_dim, LoHa with and without Tucker cores, LoKr in its four forms, GLoRA, IA3, full diff):
+    W + updown computed by the HIP kernels equals W + the reference's calc_updown."""
+    from tests.test_oracle_pins import _golden_module
+    nets = sub("networks")
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "lyco.npz"))
+    seen = set()
+    for k, (name, (kind, spec, build)) in enumerate(mg.lyco_cases().items()):
+        orig, w = mg.lyco_orig_weight(spec, k), build(9000 + 10 * k)
+        net = nets.Network("n", unet_multiplier=0.8, te_multiplier=0.3, dyn_dim=3 if name == "lora_dyn" else None)
+        weights = nets.NetworkWeights(network_key="lora_unet_x", sd_key="diffusion_model_x", w=dict(w), engine_key="x.weight")
+        if kind == "norm" or "diff_b" in w:
+            with pytest.raises(NotImplementedError):
+                for mt in nets.module_types:
+                    if mt.create_module(net, weights, tuple(orig.shape)) is not None:
+                        break
+            continue
+        module = None
+        for mt in nets.module_types:
+            module = mt.create_module(net, weights, tuple(orig.shape))
+            if module is not None:
+                break
+        assert module is not None and module.kind == kind, name
+        got = nets._merge_on_device(orig.to(dev), module, dev)
+        torch.cuda.synchronize()
+        want = orig + torch.from_numpy(z[name + "_updown"])
+        assert got.shape == want.shape and float((got.cpu() - want).abs().max()) < 2e-6, name
+        seen.add(kind)
+    assert seen == {"lora", "hada", "lokr", "glora", "ia3", "full"}
+
+
+def test_lycoris_networks_into_engine_vs_oracle(dev, tiny):
+    """A LoHa + LoKr + IA3 + DoRA network and a plain LoRA loaded together: the rewritten engine matches the oracle UNet built from
+    oracle.lora.merge'd weights, and unloading restores the original bits."""
+    schema, nets = sub("schema"), sub("networks")
+    from oracle import lora as olora, unet as ou
+    model, sd = tiny["model"], tiny["sd"]
+    eng = model.engine
+    x = seeded((2, 4, 16, 16), 31).to(dev)
+    t = torch.tensor([700.0, 80.0], device=dev)
+    ctx = seeded((2, 77, 64), 32).to(dev)
+
+    def fwd():
+        eng.set_context(ctx)
+        return eng.unet_forward(x, t, None, None).float().cpu()
+    base = fwd()
+    g = torch.Generator().manual_seed(77)
+    r = lambda *shape: torch.randn(*shape, generator=g) * 0.25
+    blk = "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_"
+    lyco = {
+        # LoHa on the self-attention v projection (64 -> 64)
+        blk + "attn1_to_v.hada_w1_a": r(64, 4), blk + "attn1_to_v.hada_w1_b": r(4, 64), blk + "attn1_to_v.hada_w2_a": r(64, 4),
+        blk + "attn1_to_v.hada_w2_b": r(4, 64), blk + "attn1_to_v.alpha": torch.tensor(4.0),
+        # LoKr on the feed-forward output (256 -> 64): kron([8,16], [8,16])
+        blk + "ff_net_2.lokr_w1": r(8, 16), blk + "ff_net_2.lokr_w2": r(8, 16), blk + "ff_net_2.alpha": torch.tensor(1.0),
+        # IA3 on the cross-attention k projection (64 <- 64), per output row
+        blk + "attn2_to_k.weight": r(64) * 0.5, blk + "attn2_to_k.on_input": torch.tensor(False),
+        # DoRA LoCon on a 3x3 conv of the middle block
+        "lora_unet_mid_block_resnets_0_conv1.lora_up.weight": r(128, 4, 1, 1), "lora_unet_mid_block_resnets_0_conv1.lora_down.weight": r(4, 128, 3, 3) * 0.3,
+        "lora_unet_mid_block_resnets_0_conv1.alpha": torch.tensor(4.0),
+        "lora_unet_mid_block_resnets_0_conv1.dora_scale": torch.rand(1, 128, 1, 1, generator=g) * 0.2 + 0.55,
+        # full diff on the 1x1 proj_out
+        "lora_unet_down_blocks_0_attentions_0_proj_out.diff": r(64, 64, 1, 1) * 0.2,
+    }
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    assert shapes[schema.UNET_PREFIX + "middle_block.0.in_layers.2.weight"] == (128, 128, 3, 3)
+    la = _tiny_lora(schema.unet_schema(schema.tiny_unet()), 9)
+    try:
+        loaded = nets.load_networks(model, ["lyco", "a"], [lyco, la], unet_multipliers=[0.7, 0.5])
+        assert sorted(m.kind for m in loaded[0].modules.values()) == ["full", "hada", "ia3", "lokr", "lora"]
+        got = fwd()
+        ref_sd = olora.merge({k: v.float() for k, v in sd.items()}, [(lyco, 0.7), (la, 0.5)])
+        ref = ou.build_unet(ou.tiny_config(), ref_sd)(x.cpu(), t.cpu(), ctx.cpu())
+        assert rel_l2(got, ref) < 8e-3 and rel_l2(got, base) > 5e-2
     finally:
         nets.load_networks(model, [], [])
     assert torch.equal(fwd(), base)

@@ -307,6 +307,23 @@ def test_refiner_switch_decision_matches_reference(golden_dir):
         assert bool(got) == bool(want), (step, sigma, switch_at, by_steps, enable_hr, is_hr, hopt)
 
 
+def test_lycoris_calc_updown_matches_reference(golden_dir):
+    """oracle.lora.calc_updown == NetworkModule*.calc_updown of extensions-builtin/Lora/network_*.py (loaded by make_golden) for 19
+    cases: LoRA / LoCon incl. cp-decomposition, DoRA, dyn_dim; LoHa; LoKr; GLoRA; IA3; full; norm — and the type dispatch."""
+    from oracle import lora as olora
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "lyco.npz"))
+    cases = mg.lyco_cases()
+    assert len(cases) == 19
+    for k, (name, (kind, spec, build)) in enumerate(cases.items()):
+        orig, w = mg.lyco_orig_weight(spec, k), build(9000 + 10 * k)
+        assert olora.module_kind(w) == kind
+        updown, ex_bias = olora.calc_updown(w, orig, 0.8, dyn_dim=3 if name == "lora_dyn" else None, with_bias=True)
+        np.testing.assert_allclose(updown.numpy(), z[name + "_updown"], rtol=0, atol=1e-6, err_msg=name)
+        if ex_bias is not None:
+            np.testing.assert_allclose(ex_bias.numpy(), z[name + "_ex_bias"], rtol=0, atol=1e-6, err_msg=name)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
