@@ -174,6 +174,8 @@ def apply_refiner(cfg_denoiser, sigma=None):
     conds encoded by ITS text encoder, and the switch is a pointer swap on the sampler."""
     opts = shared.opts
     p = cfg_denoiser.p
+    if getattr(p, "refiner_sd_model", None) is None:          # (the reference evaluates the progress first; without a refiner the
+        return False                                          #  answer is False either way and the device read-back is saved)
     if opts.refiner_switch_by_sample_steps or sigma is None:
         completed_ratio = cfg_denoiser.step / cfg_denoiser.total_steps
     else:

@@ -788,6 +788,35 @@ def test_sdxl_shaped_unet_vs_oracle(dev):
     eng.close()
 
 
+@pytest.mark.parametrize("s_min_uncond", [0.0, 20.0])
+def test_sdxl_shaped_sampling_with_vector_conditioning_vs_oracle(dev, s_min_uncond):
+    """C3-shaped path at test size: the SDXL vector conditioning (y | uy -> label_emb) travels through sampler_extra_args and the
+    CFG denoiser for every UNet row, also when skip-uncond drops the uncond rows (and their uy) on alternate steps."""
+    from oracle import pipeline as opipe, unet as ou
+    schema, processing = sub("schema"), sub("processing")
+    kw = dict(model_channels=64, channel_mult=(1, 2, 4), num_res_blocks=2, attention_resolutions=(2, 4), num_heads=-1,
+              num_head_channels=64, transformer_depth=(1, 2, 3), context_dim=128, use_linear_in_transformer=True,
+              adm_in_channels=192)
+    cfg = schema.UNetConfig(**kw)
+    sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
+    model = sub("sd_models").SdModel(sd, cfg, None, device=0, load_vae=False)
+    assert model.is_sdxl
+    om = opipe.OracleModel(sd, ou.UNetConfig(**kw), None)
+    g = torch.Generator().manual_seed(15)
+    cond, uncond = torch.randn(2, 77, 128, generator=g), torch.randn(2, 77, 128, generator=g)
+    y, uy = torch.randn(2, 192, generator=g), torch.randn(2, 192, generator=g)
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond, uc=uncond, seed=600, batch_size=2, steps=5, cfg_scale=5.0,
+                                                    width=256, height=256, sampler_name="Euler a", s_min_uncond=s_min_uncond)
+    p.y, p.uy = y.to(dev), uy.to(dev)
+    p.rng = sub("rng").ImageRNG((4, 32, 32), [600, 601], device=dev)
+    p.seeds = [600, 601]
+    sampler_obj = sub("sd_samplers").create_sampler("Euler a", model)
+    got = sampler_obj.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev))
+    lat = opipe.sample(om, cond, uncond, [600, 601], 5, "euler_a", 5.0, (32, 32), y=y, uy=uy, s_min_uncond=s_min_uncond)
+    assert rel_l2(got.cpu(), lat) < 1e-2
+    model.engine.close()
+
+
 def test_c0_shape_sd15_256px_b1_euler_a_5_steps(dev):
     """BASELINE.json configs[0]: SD1.5 txt2img 256x256, 5-step Euler-a, batch 1 — full architecture, final latent vs oracle."""
     schema, processing = sub("schema"), sub("processing")
