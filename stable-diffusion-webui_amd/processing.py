@@ -14,7 +14,7 @@ from typing import Any, List, Optional
 import numpy as np
 import torch
 
-from . import ops, sd_samplers, shared
+from . import ops, prompt_parser, sd_samplers, shared
 from .rng import ImageRNG
 
 opt_C = 4
@@ -255,8 +255,8 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
                             device=samples.device)
         noise = self.rng.next()
         lo = self.iteration * self.batch_size
-        hr_c = conditioning if self.hr_c is None else self.hr_c[lo:lo + self.batch_size].to(samples.device)
-        hr_uc = unconditional_conditioning if self.hr_uc is None else self.hr_uc[lo:lo + self.batch_size].to(samples.device)
+        hr_c = conditioning if self.hr_c is None else prompt_parser.slice_conds(self.hr_c, lo, lo + self.batch_size, samples.device)
+        hr_uc = unconditional_conditioning if self.hr_uc is None else prompt_parser.slice_conds(self.hr_uc, lo, lo + self.batch_size, samples.device)
         samples = self.sampler.sample_img2img(self, samples, noise, hr_c, hr_uc,
                                               steps=self.hr_second_pass_steps or self.steps, image_conditioning=image_conditioning)
         self.is_hr_pass = False
@@ -360,8 +360,7 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
         p.rng = ImageRNG((opt_C, p.height // opt_f, p.width // opt_f), p.seeds,
                          seed_resize_from_h=p.seed_resize_from_h, seed_resize_from_w=p.seed_resize_from_w,
                          eta_noise_seed_delta=shared.opts.eta_noise_seed_delta, device=dev)      # :949
-        c = p.c[lo:hi].to(dev)
-        uc = p.uc[lo:hi].to(dev)
+        c, uc = prompt_parser.slice_conds(p.c, lo, hi, dev), prompt_parser.slice_conds(p.uc, lo, hi, dev)
         if p.y is not None:
             p_y_all, p_uy_all = p.y, p.uy
             p.y, p.uy = p_y_all[lo:hi].to(dev), p_uy_all[lo:hi].to(dev)

@@ -240,6 +240,8 @@ class CFGDenoiser:
         self._ctx_key = None
         self._x_in = None
         self._comb = None
+        self._cond_sel = None
+        self._uncond_sel = None
 
     @property
     def inner_model(self):
@@ -258,13 +260,43 @@ class CFGDenoiser:
             raise ValueError("p.refiner_c / p.refiner_uc (conds encoded for the refiner checkpoint) are required")
         dev = self.sampler.sd_model.device
         args = self.sampler.sampler_extra_args
-        args['cond'] = p.refiner_c[lo:lo + p.batch_size].to(dev)
-        args['uncond'] = p.refiner_uc[lo:lo + p.batch_size].to(dev)
+        from . import prompt_parser
+        args['cond'] = prompt_parser.slice_conds(p.refiner_c, lo, lo + p.batch_size, dev)
+        args['uncond'] = prompt_parser.slice_conds(p.refiner_uc, lo, lo + p.batch_size, dev)
+        self._cond_sel = self._uncond_sel = None
         if getattr(p, "refiner_y", None) is not None:
             args['y'], args['uy'] = p.refiner_y[lo:lo + p.batch_size].to(dev), p.refiner_uy[lo:lo + p.batch_size].to(dev)
         else:
             args.pop('y', None)
             args.pop('uy', None)
+
+    def _reconstruct_conds(self, cond, uncond, y, uy, device):
+        """prompt_parser.reconstruct_multicond_batch / reconstruct_cond_batch at this step (cfg_denoiser.py:169-170) when the
+        caller hands over the reference's containers (MulticondLearnedConditioning / per-image schedules) instead of ready
+        tensors; dict conds (SDXL) are split into the cross-attention context and the vector conditioning.  The reconstructed
+        batch is kept while the schedules select the same entries, so the cached K / V projections stay valid across steps."""
+        from . import prompt_parser
+        def on_device(t):
+            return {k: v.to(device) for k, v in t.items()} if isinstance(t, dict) else t.to(device)
+
+        if isinstance(cond, prompt_parser.MulticondLearnedConditioning):
+            key = prompt_parser.selection_key(cond, self.step)
+            if self._cond_sel is None or self._cond_sel[0] != key:
+                conds_list, stacked = prompt_parser.reconstruct_multicond_batch(cond, self.step)
+                self._cond_sel = (key, (conds_list, on_device(stacked)))
+            cond = self._cond_sel[1]
+        if isinstance(uncond, list):
+            key = prompt_parser.selection_key(uncond, self.step)
+            if self._uncond_sel is None or self._uncond_sel[0] != key:
+                self._uncond_sel = (key, on_device(prompt_parser.reconstruct_cond_batch(uncond, self.step)))
+            uncond = self._uncond_sel[1]
+        conds_list, tensor = cond if isinstance(cond, tuple) else (None, cond)
+        if isinstance(tensor, dict):
+            y, tensor = tensor.get("vector", y), tensor["crossattn"]
+            cond = tensor if conds_list is None else (conds_list, tensor)
+        if isinstance(uncond, dict):
+            uy, uncond = uncond.get("vector", uy), uncond["crossattn"]
+        return cond, uncond, y, uy
 
     def _ensure_context(self, ctx_parts):
         """Cache the cross-attention K / V projections of the UNet batch's context rows (cat of ``ctx_parts``)."""
@@ -310,6 +342,7 @@ class CFGDenoiser:
         if apply_refiner(self, sigma):                        # :160-162
             args = self.sampler.sampler_extra_args
             cond, uncond, y, uy = args['cond'], args['uncond'], args.get('y'), args.get('uy')
+        cond, uncond, y, uy = self._reconstruct_conds(cond, uncond, y, uy, x.device)     # :169-170
         opts = shared.opts
         sd_model = self.sampler.sd_model
         eng = sd_model.engine
@@ -410,8 +443,8 @@ class CFGDenoiser:
         ts = torch.full((rows,), t_model, dtype=torch.float32, device=x.device)
         yy = None
         if y is not None:
-            if conds_list is not None:
-                raise NotImplementedError("AND composition with vector conditioning (SDXL)")
+            if y.shape[0] != n_cond:
+                raise ValueError(f"vector conditioning has {y.shape[0]} rows for {n_cond} cond rows (dict conds carry one per sub-prompt)")
             yy = (y if skip_uncond else torch.cat([y, uy, uy] if is_edit_model else [y, uy])).float().contiguous()
         if split_calls:
             eng.unet_forward(x_in[:n_cond], ts[:n_cond], tensor.float().contiguous(), None if yy is None else yy[:n_cond], out=eps[:n_cond])
@@ -1061,6 +1094,7 @@ class Sampler:
         self.model_wrap_cfg.mask = p.mask if hasattr(p, 'mask') else None
         self.model_wrap_cfg.nmask = p.nmask if hasattr(p, 'nmask') else None
         self.model_wrap_cfg.step = 0
+        self.model_wrap_cfg._cond_sel = self.model_wrap_cfg._uncond_sel = None
         self.model_wrap_cfg.image_cfg_scale = getattr(p, 'image_cfg_scale', None)
         self.eta = p.eta if p.eta is not None else getattr(shared.opts, self.eta_option_field, 0.0)
         self.s_min_uncond = getattr(p, 's_min_uncond', 0.0)

@@ -889,6 +889,66 @@ def gen_lyco():
     print("lyco.npz", len(out))
 
 
+MULTICOND_PROMPTS = ["a cat", "a cat AND a dog :1.5", "castle :0.25 AND sky:-.5 AND a cat", "ANDROID and sand", "x:1. AND y : +2 AND z:abc",
+                     "  spaced   AND  out :3  ", "a: b :0.7"]
+
+
+def prompt_cond_schedules(dict_conds=False):
+    """Seeded schedules shared by the generator and the tests: 3 images; image 0 one prompt with two schedule entries, image 1
+    two AND-ed prompts (weights 1.0 / 0.6; the second has 3 entries and more tokens), image 2 one constant prompt."""
+    def cond(seed, tokens=8):
+        c = seeded((tokens, 6), seed, 0.5)
+        return {"crossattn": c, "vector": seeded((10,), seed + 500, 0.5)} if dict_conds else c
+    S = lambda end, seed, tokens=8: (end, cond(seed, tokens))
+    multi = [[([S(4, 7001), S(20, 7002)], 1.0)],
+             [([S(20, 7003)], 1.0), ([S(2, 7004, 16), S(9, 7005, 16), S(20, 7006, 16)], 0.6)],
+             [([S(20, 7007)], 0.8)]]
+    uncond = [[S(6, 7011), S(20, 7012)], [S(20, 7013)], [S(3, 7014), S(20, 7015)]]
+    return multi, uncond
+
+
+def gen_prompt_cond():
+    """Exec, from modules/prompt_parser.py's own text (the module itself needs lark), the conditioning containers and
+    get_multicond_prompt_list / reconstruct_cond_batch / stack_conds / reconstruct_multicond_batch (:136-154, 205-349)."""
+    import json
+    import re
+    from collections import namedtuple
+    src = open(os.path.join(REF, "modules/prompt_parser.py")).read()
+    ns = {"re": re, "torch": torch, "namedtuple": namedtuple, "annotations": None}
+    a = src.index("ScheduledPromptConditioning = namedtuple")
+    b = src.index("def get_learned_conditioning(model")
+    exec("from __future__ import annotations\n" + src[a:b], ns)
+    a = src.index("re_AND = re.compile")
+    b = src.index("def get_multicond_learned_conditioning(")
+    exec("from __future__ import annotations\n" + src[a:b], ns)
+    a = src.index("class DictWithShape(dict)")
+    exec("from __future__ import annotations\n" + src[a:], ns)
+    res_indexes, flat, idx = ns["get_multicond_prompt_list"](MULTICOND_PROMPTS)
+    meta = {"res_indexes": res_indexes, "flat": list(flat), "indexes": idx}
+    out = {}
+    for dict_conds in (False, True):
+        tag = "dict_" if dict_conds else ""
+        multi, uncond = prompt_cond_schedules(dict_conds)
+        SPC, CSPC, MLC = ns["ScheduledPromptConditioning"], ns["ComposableScheduledPromptConditioning"], ns["MulticondLearnedConditioning"]
+        c = MLC(shape=(3,), batch=[[CSPC([SPC(e, t) for e, t in sch], w) for sch, w in img] for img in multi])
+        uc = [[SPC(e, t) for e, t in sch] for sch in uncond]
+        for step in (0, 2, 3, 4, 5, 9, 10, 25):
+            conds_list, stacked = ns["reconstruct_multicond_batch"](c, step)
+            u = ns["reconstruct_cond_batch"](uc, step)
+            meta[f"{tag}conds_list_{step}"] = conds_list
+            if dict_conds:
+                for k in ("crossattn", "vector"):
+                    out[f"{tag}c_{k}_{step}"] = stacked[k].numpy()
+                    out[f"{tag}uc_{k}_{step}"] = u[k].numpy()
+                assert tuple(stacked.shape) == tuple(stacked["crossattn"].shape)
+            else:
+                out[f"c_{step}"] = stacked.numpy()
+                out[f"uc_{step}"] = u.numpy()
+    np.savez_compressed(os.path.join(OUT, "prompt_cond.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "prompt_cond.json"), "w"), indent=0, sort_keys=True)
+    print("prompt_cond.npz prompt_cond.json")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -906,3 +966,4 @@ if __name__ == "__main__":
     gen_resize_image()
     gen_refiner()
     gen_lyco()
+    gen_prompt_cond()

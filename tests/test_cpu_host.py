@@ -242,6 +242,57 @@ def test_host_upscaler_handoff_matches_reference(golden_dir):
         p.init(None, None, None)
 
 
+def test_host_prompt_parser_containers_match_reference(golden_dir):
+    """prompt_parser (host mirror): same results as the reference-generated fixture for AND splitting and the per-step
+    reconstruction; get_learned_conditioning / get_multicond_learned_conditioning build the containers from an encoder and
+    share the encoding of equal prompts; selection_key changes exactly when the selected entries change."""
+    import json
+    from tests.test_oracle_pins import _golden_module
+    hp = sub("prompt_parser")
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "prompt_cond.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "prompt_cond.json")))
+    r = hp.get_multicond_prompt_list(mg.MULTICOND_PROMPTS)
+    assert [[list(x) for x in e] for e in r[0]] == meta["res_indexes"] and list(r[1]) == meta["flat"] and r[2] == meta["indexes"]
+    for dict_conds in (False, True):
+        tag = "dict_" if dict_conds else ""
+        multi, uncond = mg.prompt_cond_schedules(dict_conds)
+        c = hp.MulticondLearnedConditioning((3,), [[hp.ComposableScheduledPromptConditioning(
+            [hp.ScheduledPromptConditioning(e, t) for e, t in sch], w) for sch, w in img] for img in multi])
+        uc = [[hp.ScheduledPromptConditioning(e, t) for e, t in sch] for sch in uncond]
+        keys = []
+        for step in (0, 2, 3, 4, 5, 9, 10, 25):
+            conds_list, stacked = hp.reconstruct_multicond_batch(c, step)
+            u = hp.reconstruct_cond_batch(uc, step)
+            keys.append((hp.selection_key(c, step), hp.selection_key(uc, step)))
+            assert [[list(x) for x in e] for e in conds_list] == meta[f"{tag}conds_list_{step}"]
+            if dict_conds:
+                assert tuple(stacked.shape) == tuple(stacked["crossattn"].shape)
+                for k in ("crossattn", "vector"):
+                    assert np.array_equal(stacked[k].numpy(), z[f"{tag}c_{k}_{step}"]) and np.array_equal(u[k].numpy(), z[f"{tag}uc_{k}_{step}"])
+            else:
+                assert np.array_equal(stacked.numpy(), z[f"c_{step}"]) and np.array_equal(u.numpy(), z[f"uc_{step}"])
+        # cond selection: steps {0,2} | 3 | 4 | {5..9} | 10 | 25 (past every end: back to entry 0); uncond changes after step 3
+        assert keys[0][0] == keys[1][0] != keys[2][0] and keys[3][0] != keys[4][0] and keys[6][0] != keys[7][0]
+        assert keys[0][1] == keys[1][1] == keys[2][1] != keys[3][1]
+        sl = hp.slice_conds(c, 1, 3, "cpu")
+        assert isinstance(sl, hp.MulticondLearnedConditioning) and sl.shape == (2,) and sl.batch[0] is c.batch[1]
+
+    class Enc:
+        calls = []
+
+        def get_learned_conditioning(self, texts):
+            self.calls.append(list(texts))
+            return torch.stack([torch.full((4, 2), float(len(t))) for t in texts])
+    enc = Enc()
+    mc = hp.get_multicond_learned_conditioning(enc, ["a cat AND a dog :0.5", "a cat"], 20)
+    assert mc.shape == (2,) and [len(x) for x in mc.batch] == [2, 1] and mc.batch[0][1].weight == 0.5
+    assert mc.batch[0][0].schedules is mc.batch[1][0].schedules and mc.batch[0][0].schedules[0].end_at_step == 20
+    assert enc.calls == [["a cat"], [" a dog"]]
+    sch = hp.get_learned_conditioning(enc, ["x"], 20, prompt_schedules=[[[5, "ab"], [20, "abcd"]]])
+    assert [e.end_at_step for e in sch[0]] == [5, 20] and float(sch[0][1].cond[0, 0]) == 4.0
+
+
 def test_host_lora_names_and_grouping_match_reference(golden_dir):
     """networks.convert_diffusers_name_to_compvis against the reference-generated fixture, and load_network's grouping /
     layer lookup (extensions-builtin/Lora/networks.py:183-240) on the tiny UNet's layer map."""

@@ -648,6 +648,50 @@ def test_img2img_masked_content_fills_and_noise_multiplier(dev, tiny):
     assert rel_l2(res.latents.cpu(), lat) < 1.5e-2
 
 
+def test_prompt_editing_and_composition_containers_vs_oracle(dev, tiny):
+    """The reference's conditioning containers straight into the sampler: p.c = MulticondLearnedConditioning
+    with prompt-editing schedules and an AND-ed sub-prompt of twice the token count, p.uc = per-image schedules; the denoiser
+    reconstructs them per step (modules/sd_samplers_cfg_denoiser.py:169-170) and re-projects K / V only when the selection changes."""
+    from oracle import pipeline as opipe, prompt_cond as opc, kdiffusion as okd
+    hp, processing, ss = sub("prompt_parser"), sub("processing"), sub("sd_samplers")
+    g = torch.Generator().manual_seed(55)
+    T = lambda tokens=77: torch.randn(tokens, 64, generator=g)
+    S = hp.ScheduledPromptConditioning
+    c0a, c0b, c1a, c1b1, c1b2, u0, u1a, u1b = T(), T(), T(), T(154), T(154), T(154), T(154), T(154)
+    c = hp.MulticondLearnedConditioning((2,), [
+        [hp.ComposableScheduledPromptConditioning([S(2, c0a), S(6, c0b)], 1.0)],
+        [hp.ComposableScheduledPromptConditioning([S(6, c1a)], 1.0), hp.ComposableScheduledPromptConditioning([S(3, c1b1), S(6, c1b2)], 0.6)]])
+    uc = [[S(6, u0)], [S(1, u1a), S(6, u1b)]]
+    calls = []
+    eng = tiny["model"].engine
+    orig_set = eng.set_context
+    eng.set_context = lambda ctx: (calls.append(tuple(ctx.shape)), orig_set(ctx))[1]
+    try:
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=c, uc=uc, seed=5000, batch_size=2, steps=6, cfg_scale=6.0,
+                                                        width=128, height=128, sampler_name="Euler")
+        res = processing.process_images(p)
+    finally:
+        eng.set_context = orig_set
+    assert len(calls) == 4 and all(s == (5, 154, 64) for s in calls)      # the selection changes at steps 2 (uncond), 3 and 4 (cond)
+
+    batch = [[opc.Composable([opc.Scheduled(e.end_at_step, e.cond) for e in cp.schedules], cp.weight) for cp in img] for img in c.batch]
+    unc = [[opc.Scheduled(e.end_at_step, e.cond) for e in sch] for sch in uc]
+    om = tiny["oracle"]
+    wrap = okd.CompVisDenoiser(lambda xi, t, cc: om.apply_model(xi, t, cc), om.alphas_cumprod)
+    cfg = okd.CFGDenoiser(wrap)
+
+    def model(x, sigma, **kw):                                            # the reference reconstructs inside forward, per step
+        step = cfg.step
+        u = opc.reconstruct_cond_batch(unc, step)
+        pair = opc.reconstruct_multicond_batch(batch, step)
+        return cfg(x, sigma, u, pair, 6.0)
+    from oracle.rng import ImageRNG as ORNG
+    sig = wrap.get_sigmas(6)
+    x = ORNG((4, 16, 16), [5000, 5001]).next() * sig[0]
+    lat = okd.sample_euler(model, x, sig, {})
+    assert rel_l2(res.latents.cpu(), lat) < 1e-2
+
+
 def test_txt2img_batch_split_matches(dev, tiny):
     """Sharding contract of the multi-GPU runner: images [0,4) generated as 4, as 2+2 (n_iter) or as the tail pair are the
     same images — per-image Philox streams (modules/rng.py:108) + per-image arithmetic everywhere.  Bitwise when the per-call

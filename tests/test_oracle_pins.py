@@ -324,6 +324,33 @@ def test_lycoris_calc_updown_matches_reference(golden_dir):
             np.testing.assert_allclose(ex_bias.numpy(), z[name + "_ex_bias"], rtol=0, atol=1e-6, err_msg=name)
 
 
+def test_prompt_conditioning_containers_match_reference(golden_dir):
+    """oracle/prompt_cond.py == modules/prompt_parser.py (get_multicond_prompt_list, reconstruct_cond_batch, stack_conds,
+    reconstruct_multicond_batch; exec'd from the file's text by make_golden): AND splitting / weights of 7 prompts, and the
+    per-step selection over prompt-editing schedules for tensor and dict (SDXL) conds, incl. padding of shorter conds."""
+    import json
+    from oracle import prompt_cond as opc
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "prompt_cond.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "prompt_cond.json")))
+    per_prompt, flat, _ = opc.multicond_prompt_list(mg.MULTICOND_PROMPTS)
+    assert [[list(x) for x in e] for e in per_prompt] == meta["res_indexes"] and flat == meta["flat"]
+    for dict_conds in (False, True):
+        tag = "dict_" if dict_conds else ""
+        multi, uncond = mg.prompt_cond_schedules(dict_conds)
+        batch = [[opc.Composable([opc.Scheduled(e, t) for e, t in sch], w) for sch, w in img] for img in multi]
+        unc = [[opc.Scheduled(e, t) for e, t in sch] for sch in uncond]
+        for step in (0, 2, 3, 4, 5, 9, 10, 25):
+            conds_list, stacked = opc.reconstruct_multicond_batch(batch, step)
+            u = opc.reconstruct_cond_batch(unc, step)
+            assert [[list(x) for x in e] for e in conds_list] == meta[f"{tag}conds_list_{step}"]
+            if dict_conds:
+                for k in ("crossattn", "vector"):
+                    assert np.array_equal(stacked[k].numpy(), z[f"{tag}c_{k}_{step}"]) and np.array_equal(u[k].numpy(), z[f"{tag}uc_{k}_{step}"])
+            else:
+                assert np.array_equal(stacked.numpy(), z[f"c_{step}"]) and np.array_equal(u.numpy(), z[f"uc_{step}"])
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
