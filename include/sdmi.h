@@ -120,6 +120,12 @@ int sdmi_layernorm(const void* x, const void* gamma_f32, const void* beta_f32, v
  * (modules/rng_philox.py:32-102): out[i] = randn(counter=[offset,0,i,0], key=seed). */
 int sdmi_philox_randn(void* out_f32, int64_t n, uint64_t seed, uint32_t offset, void* stream);
 
+/* Variation seeds: slerp(val, low, high) of modules/rng.py:85-96 on ONE image's noise tensors [C][H][W] (fp32) — the angle per
+ * (c, w) column along H, linear fallback low*val + high*(1-val) when the mean cosine exceeds 0.9995 (sic: the reference's weights).
+ * scratch: C*W floats.  Called from ImageRNG.first (modules/rng.py:120-127) when subseed_strength != 0. */
+int sdmi_slerp(void* out_f32, const void* low_f32, const void* high_f32, float val, int C, int H, int W, void* scratch_f32,
+               void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Sampler arithmetic (boundary B3): the elementwise work of CFGDenoiser + CompVisDenoiser + the k-diffusion /
  * DDIM update, fused.  x is the fp32 sampler state [B,4,h,w] (NCHW, as the webui keeps it).

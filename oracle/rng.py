@@ -3,8 +3,8 @@
 Restates modules/rng_philox.py:32-102 (randn_source "NV": the CPU emulation of CUDA torch.randn) and the
 plain path of modules/rng.py:99-163 (ImageRNG: one generator per image seeded ``seed + i`` by the caller,
 ``first()`` draws the initial latent, every later ``next()`` draws one more tensor per generator;
-eta_noise_seed_delta re-seeds after the first draw, :147-149).  Subseed slerp / seed-resize are out of
-scope for the synthetic configs and not restated.
+eta_noise_seed_delta re-seeds after the first draw, :147-149), the variation-seed slerp (:85-96, 120-127) and seed-resize
+(:131-143) — the whole class pinned by tests/golden/image_rng.npz.
 
 Arithmetic notes that matter for bit-exactness (all visible in rng_philox.py):
   * counter = [offset, 0, index, 0]; key = (seed lo32, seed hi32); 10 rounds, key += (0x9E3779B9, 0xBB67AE85)
@@ -65,16 +65,56 @@ class Generator:
         return box_muller_first(g0, g1).reshape(shape)
 
 
+def slerp(val, low, high):
+    """modules/rng.py:85-96: spherical interpolation of two [C, H, W] noise tensors, direction measured along dim 1; nearly
+    parallel inputs fall back to a (reversed-weight, as in the reference) linear blend."""
+    dot = ((low / torch.norm(low, dim=1, keepdim=True)) * (high / torch.norm(high, dim=1, keepdim=True))).sum(1)
+    if dot.mean() > 0.9995:
+        return low * val + high * (1 - val)
+    omega = torch.acos(dot)
+    so = torch.sin(omega)
+    return (torch.sin((1.0 - val) * omega) / so).unsqueeze(1) * low + (torch.sin(val * omega) / so).unsqueeze(1) * high
+
+
+def paste_centered(canvas, patch):
+    """modules/rng.py:131-143: copy the centre-aligned overlap of ``patch`` [C, h, w] into ``canvas`` [C, H, W] (in place)."""
+    (_, H, W), (_, h, w) = canvas.shape, patch.shape
+    oy, ox = (H - h) // 2, (W - w) // 2                     # negative: the patch is larger and is cropped instead
+    hh, ww = (h if oy >= 0 else h + 2 * oy), (w if ox >= 0 else w + 2 * ox)
+    cy, cx, py, px = max(oy, 0), max(ox, 0), max(-oy, 0), max(-ox, 0)
+    canvas[:, cy:cy + hh, cx:cx + ww] = patch[:, py:py + hh, px:px + ww]
+    return canvas
+
+
 class ImageRNG:
-    def __init__(self, shape, seeds, eta_noise_seed_delta: int = 0):
+    """modules/rng.py:99-163 for randn_source "NV", pinned by tests/golden/image_rng.npz (the reference class executed over the
+    real rng_philox.py): per-image generators; variation seeds (subseed slerp, :120-127), seed-resize (:114, 122-143: the noise of
+    another image size is drawn from FRESH generators and pasted centred over this size's own first draw), eta_noise_seed_delta
+    (:147-149)."""
+
+    def __init__(self, shape, seeds, eta_noise_seed_delta: int = 0, subseeds=None, subseed_strength=0.0, seed_resize_from_h=0,
+                 seed_resize_from_w=0):
         self.shape = tuple(map(int, shape))
         self.seeds = list(seeds)
         self.ensd = eta_noise_seed_delta
+        self.subseeds, self.subseed_strength = subseeds, subseed_strength
+        self.resize_from = (seed_resize_from_h, seed_resize_from_w)
         self.generators = [Generator(s) for s in self.seeds]
         self.is_first = True
 
     def first(self):
-        xs = [torch.from_numpy(g.randn(self.shape)) for g in self.generators]
+        rh, rw = self.resize_from
+        noise_shape = self.shape if rh <= 0 or rw <= 0 else (self.shape[0], int(rh) // 8, int(rw // 8))
+        draw = lambda seed: torch.from_numpy(Generator(seed).randn(noise_shape))
+        xs = []
+        for i, (seed, gen) in enumerate(zip(self.seeds, self.generators)):
+            resized = noise_shape != self.shape
+            noise = draw(seed) if resized else torch.from_numpy(gen.randn(self.shape))
+            if self.subseeds is not None and self.subseed_strength != 0:
+                noise = slerp(self.subseed_strength, noise, draw(self.subseeds[i] if i < len(self.subseeds) else 0))
+            if resized:
+                noise = paste_centered(torch.from_numpy(gen.randn(self.shape)), noise)
+            xs.append(noise)
         if self.ensd:
             self.generators = [Generator(s + self.ensd) for s in self.seeds]
         return torch.stack(xs)

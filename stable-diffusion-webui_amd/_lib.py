@@ -87,6 +87,7 @@ _SIGS = {
     "sdmi_groupnorm_workspace_bytes": (_i64, [_i, _i, _i]),
     "sdmi_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "sdmi_philox_randn": (_i, [_vp, _i64, C.c_uint64, C.c_uint32, _vp]),
+    "sdmi_slerp": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp]),
     "sdmi_cfg_prepare_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     "sdmi_cfg_prepare_concat": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _u32, _vp]),
     "sdmi_cfg_combine": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp]),

@@ -164,6 +164,13 @@ int sdmi_philox_randn(void* out, int64_t n, uint64_t seed, uint32_t offset, void
     API_GUARD_END
 }
 
+int sdmi_slerp(void* out, const void* low, const void* high, float val, int C, int H, int W, void* scratch, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(out && low && high && scratch && C > 0 && H > 0 && W > 0, "bad arguments");
+    return launch_slerp((float*)out, (const float*)low, (const float*)high, val, C, H, W, (float*)scratch, (hipStream_t)stream);
+    API_GUARD_END
+}
+
 int sdmi_cfg_prepare_input(const void* x, const void* c_in, void* x_in, int out_dtype, int B, int reps, int64_t chw, void* stream) {
     API_GUARD_BEGIN
     return launch_cfg_prepare((const float*)x, (const float*)c_in, x_in, out_dtype, B, reps, chw, (hipStream_t)stream);

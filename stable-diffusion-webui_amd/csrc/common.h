@@ -115,6 +115,7 @@ int launch_layernorm(const half_t* x, const float* gamma, const float* beta, hal
 // ---- elementwise / misc -----------------------------------------------------------------------------------
 int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t offset, hipStream_t s);
 int launch_cfg_prepare(const float* x, const float* c_in, void* xin, int out_dtype, int B, int reps, int64_t chw, hipStream_t s);
+int launch_slerp(float* out, const float* low, const float* high, float val, int C, int H, int W, float* scratch, hipStream_t s);
 int launch_weight_hadamard(float* out, const float* w, const float* a, const float* b, float scale, int64_t n, hipStream_t s);
 int launch_weight_kron(float* out, const float* w, const float* w1, const float* w2, int r1, int c1, int r2, int c2, int k, float scale,
                        hipStream_t s);

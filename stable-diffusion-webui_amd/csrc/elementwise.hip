@@ -416,6 +416,58 @@ int launch_lora_merge(float* out, const void* w, int w_dtype, const void* up, in
     return 0;
 }
 
+// Variation-seed slerp of modules/rng.py:85-96 for one image: low / high [C][H][W]; the angle is measured per (c, w) column
+// along H (the reference's dim 1), the mean cosine over all columns selects the (reversed-weight) lerp fallback.  One workgroup:
+// the tensors are a few hundred KB and this runs once per job.
+__global__ __launch_bounds__(256) void slerp_kernel(float* out, const float* low, const float* high, float val, int C, int H, int W,
+                                                    float* dots) {
+    __shared__ float red[256];
+    const int cols = C * W;
+    float part = 0.f;
+    for (int col = threadIdx.x; col < cols; col += 256) {
+        const int c = col / W, w = col - c * W;
+        const long base = (long)c * H * W + w;
+        float nl = 0.f, nh = 0.f;
+        for (int h = 0; h < H; ++h) {
+            const float l = low[base + (long)h * W], g = high[base + (long)h * W];
+            nl += l * l;
+            nh += g * g;
+        }
+        nl = sqrtf(nl);
+        nh = sqrtf(nh);
+        float dot = 0.f;
+        for (int h = 0; h < H; ++h) dot += (low[base + (long)h * W] / nl) * (high[base + (long)h * W] / nh);
+        dots[col] = dot;
+        part += dot;
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const bool lerp = red[0] / (float)cols > 0.9995f;
+    for (int col = threadIdx.x; col < cols; col += 256) {
+        const int c = col / W, w = col - c * W;
+        const long base = (long)c * H * W + w;
+        float a, b;
+        if (lerp) {
+            a = val;
+            b = 1.0f - val;
+        } else {
+            const float omega = acosf(dots[col]), so = sinf(omega);
+            a = sinf((1.0f - val) * omega) / so;
+            b = sinf(val * omega) / so;
+        }
+        for (int h = 0; h < H; ++h) out[base + (long)h * W] = a * low[base + (long)h * W] + b * high[base + (long)h * W];
+    }
+}
+int launch_slerp(float* out, const float* low, const float* high, float val, int C, int H, int W, float* scratch, hipStream_t s) {
+    hipLaunchKernelGGL(slerp_kernel, dim3(1), dim3(256), 0, s, out, low, high, val, C, H, W, scratch);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- LyCORIS weight deltas other than plain LoRA (extensions-builtin/Lora/network_{hada,lokr,ia3}.py, network.py:175-194).
 // All fp32, W = the layer's current weight viewed [rows][cols] (cols = Cin*kh*kw), done once per network change.
 

@@ -65,6 +65,8 @@ class StableDiffusionProcessing:
     rng: Any = None
     seeds: List[int] = None
     all_seeds: List[int] = None
+    subseeds: List[int] = None
+    all_subseeds: List[int] = None
     iteration: int = 0
     extra_generation_params: dict = field(default_factory=dict)
     keep_latents: bool = True
@@ -251,8 +253,9 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         if image_conditioning.shape[-2:] != (1, 1) and image_conditioning.shape[-2:] != samples.shape[-2:]:
             image_conditioning = image_conditioning[:, :, self.truncate_y // 2:image_conditioning.shape[2] - (self.truncate_y + 1) // 2,
                                                     self.truncate_x // 2:image_conditioning.shape[3] - (self.truncate_x + 1) // 2].contiguous()
-        self.rng = ImageRNG(samples.shape[1:], self.seeds, eta_noise_seed_delta=shared.opts.eta_noise_seed_delta,
-                            device=samples.device)
+        self.rng = ImageRNG(samples.shape[1:], self.seeds, subseeds=getattr(self, "subseeds", None), subseed_strength=self.subseed_strength,
+                            seed_resize_from_h=self.seed_resize_from_h, seed_resize_from_w=self.seed_resize_from_w,
+                            eta_noise_seed_delta=shared.opts.eta_noise_seed_delta, device=samples.device)     # :1429
         noise = self.rng.next()
         lo = self.iteration * self.batch_size
         hr_c = conditioning if self.hr_c is None else prompt_parser.slice_conds(self.hr_c, lo, lo + self.batch_size, samples.device)
@@ -350,6 +353,8 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
     n_total = p.batch_size * p.n_iter
     seed = int(p.seed) if p.seed is not None and p.seed != -1 else 1000
     p.all_seeds = [seed + i for i in range(n_total)]                 # :901-909
+    subseed = int(p.subseed) if p.subseed is not None and p.subseed != -1 else 2000
+    p.all_subseeds = list(p.subseed) if isinstance(p.subseed, (list, tuple)) else [subseed + i for i in range(n_total)]
     p.init(None, p.all_seeds, None)
     images, latents = [], []
     dev = p.sd_model.device
@@ -357,7 +362,8 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
         p.iteration = n
         lo, hi = n * p.batch_size, (n + 1) * p.batch_size
         p.seeds = p.all_seeds[lo:hi]
-        p.rng = ImageRNG((opt_C, p.height // opt_f, p.width // opt_f), p.seeds,
+        p.subseeds = p.all_subseeds[lo:hi]
+        p.rng = ImageRNG((opt_C, p.height // opt_f, p.width // opt_f), p.seeds, subseeds=p.subseeds, subseed_strength=p.subseed_strength,
                          seed_resize_from_h=p.seed_resize_from_h, seed_resize_from_w=p.seed_resize_from_w,
                          eta_noise_seed_delta=shared.opts.eta_noise_seed_delta, device=dev)      # :949
         c, uc = prompt_parser.slice_conds(p.c, lo, hi, dev), prompt_parser.slice_conds(p.uc, lo, hi, dev)

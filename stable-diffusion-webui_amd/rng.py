@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from ._lib import lib, check, ptr, stream_ptr
 
 
 class Generator:
@@ -27,15 +28,23 @@ class Generator:
 
 
 def slerp(val, low, high):
-    """modules/rng.py:85-96"""
-    low_norm = low / torch.norm(low, dim=1, keepdim=True)
-    high_norm = high / torch.norm(high, dim=1, keepdim=True)
-    dot = (low_norm * high_norm).sum(1)
-    if dot.mean() > 0.9995:
-        return low * val + high * (1 - val)
-    omega = torch.acos(dot)
-    so = torch.sin(omega)
-    return (torch.sin((1.0 - val) * omega) / so).unsqueeze(1) * low + (torch.sin(val * omega) / so).unsqueeze(1) * high
+    """modules/rng.py:85-96 on one image's [C, H, W] noise pair (sdmi_slerp)."""
+    low, high = low.contiguous(), high.contiguous()
+    c, h, w = low.shape
+    out = torch.empty_like(low)
+    scratch = torch.empty((c * w,), dtype=torch.float32, device=low.device)
+    check(lib.sdmi_slerp(ptr(out), ptr(low), ptr(high), float(val), c, h, w, ptr(scratch), stream_ptr()), "sdmi_slerp")
+    return out
+
+
+def _paste_centered(canvas, patch):
+    """modules/rng.py:131-143: the centre-aligned overlap of ``patch`` replaces that part of ``canvas`` (both [C, h, w])."""
+    (_, big_h, big_w), (_, h, w) = canvas.shape, patch.shape
+    oy, ox = (big_h - h) // 2, (big_w - w) // 2            # negative offset: the patch is the larger one and gets cropped
+    hh, ww = (h if oy >= 0 else h + 2 * oy), (w if ox >= 0 else w + 2 * ox)
+    cy, cx, py, px = max(oy, 0), max(ox, 0), max(-oy, 0), max(-ox, 0)
+    canvas[:, cy:cy + hh, cx:cx + ww] = patch[:, py:py + hh, px:px + ww]
+    return canvas
 
 
 class ImageRNG:
@@ -53,32 +62,21 @@ class ImageRNG:
         self.is_first = True
 
     def first(self):
-        noise_shape = self.shape if self.seed_resize_from_h <= 0 or self.seed_resize_from_w <= 0 else \
-            (self.shape[0], int(self.seed_resize_from_h) // 8, int(self.seed_resize_from_w // 8))
+        """modules/rng.py:113-151.  With seed-resize the noise of the OTHER image size comes from fresh generators (so it equals
+        what a job of that size would start from) and is pasted over this size's own first draw; the variation seed is blended
+        in before the paste."""
+        resize = self.seed_resize_from_h > 0 and self.seed_resize_from_w > 0
+        noise_shape = (self.shape[0], int(self.seed_resize_from_h) // 8, int(self.seed_resize_from_w // 8)) if resize else self.shape
+        resized = noise_shape != self.shape
+        vary = self.subseeds is not None and self.subseed_strength != 0
         xs = []
         for i, (seed, generator) in enumerate(zip(self.seeds, self.generators)):
-            subnoise = None
-            if self.subseeds is not None and self.subseed_strength != 0:
-                subseed = 0 if i >= len(self.subseeds) else self.subseeds[i]
-                subnoise = Generator(subseed, self.device).randn(noise_shape)
-            if noise_shape != self.shape:
-                noise = Generator(seed, self.device).randn(noise_shape)
-            else:
-                noise = generator.randn(self.shape)
-            if subnoise is not None:
-                noise = slerp(self.subseed_strength, noise, subnoise)
-            if noise_shape != self.shape:
-                x = generator.randn(self.shape)
-                dx = (self.shape[2] - noise_shape[2]) // 2
-                dy = (self.shape[1] - noise_shape[1]) // 2
-                w = noise_shape[2] if dx >= 0 else noise_shape[2] + 2 * dx
-                h = noise_shape[1] if dy >= 0 else noise_shape[1] + 2 * dy
-                tx = 0 if dx < 0 else dx
-                ty = 0 if dy < 0 else dy
-                dx = max(-dx, 0)
-                dy = max(-dy, 0)
-                x[:, ty:ty + h, tx:tx + w] = noise[:, dy:dy + h, dx:dx + w]
-                noise = x
+            noise = Generator(seed, self.device).randn(noise_shape) if resized else generator.randn(self.shape)
+            if vary:
+                subseed = self.subseeds[i] if i < len(self.subseeds) else 0
+                noise = slerp(self.subseed_strength, noise, Generator(subseed, self.device).randn(noise_shape))
+            if resized:
+                noise = _paste_centered(generator.randn(self.shape), noise)
             xs.append(noise)
         if self.eta_noise_seed_delta:
             self.generators = [Generator(seed + self.eta_noise_seed_delta, self.device) for seed in self.seeds]

@@ -949,6 +949,44 @@ def gen_prompt_cond():
     print("prompt_cond.npz prompt_cond.json")
 
 
+IMAGE_RNG_CASES = [
+    # name, shape, seeds, kwargs, eta_noise_seed_delta
+    ("plain", (4, 8, 8), [10, 11], {}, 0),
+    ("ensd", (4, 8, 8), [10, 11], {}, 31337),
+    ("subseed", (4, 8, 8), [10, 11], dict(subseeds=[20, 21], subseed_strength=0.3), 0),
+    ("subseed_short_list", (4, 8, 8), [10, 11, 12], dict(subseeds=[20], subseed_strength=0.75), 0),
+    ("subseed_same", (4, 8, 8), [10, 11], dict(subseeds=[10, 11], subseed_strength=0.4), 0),       # dot = 1 -> the lerp branch
+    ("resize_smaller", (4, 8, 8), [10, 11], dict(seed_resize_from_h=48, seed_resize_from_w=32), 0),
+    ("resize_larger", (4, 8, 8), [10, 11], dict(seed_resize_from_h=96, seed_resize_from_w=80), 0),
+    ("resize_mixed", (4, 8, 10), [10], dict(seed_resize_from_h=40, seed_resize_from_w=112), 0),
+    ("subseed_resize_ensd", (4, 8, 8), [10, 11], dict(subseeds=[20, 21], subseed_strength=0.5, seed_resize_from_h=48, seed_resize_from_w=96), 7),
+]
+
+
+def gen_image_rng():
+    """Load modules/rng.py (+ the real modules/rng_philox.py) by path with randn_source "NV" and record ImageRNG.next() three
+    times for IMAGE_RNG_CASES: subseed slerp (both branches), seed-resize (smaller / larger / mixed), eta_noise_seed_delta."""
+    mods = sys.modules.setdefault("modules", types.ModuleType("modules"))
+    devices = types.ModuleType("modules.devices")
+    devices.device, devices.cpu = torch.device("cpu"), torch.device("cpu")
+    shared = types.ModuleType("modules.shared")
+    shared.opts = types.SimpleNamespace(randn_source="NV", eta_noise_seed_delta=0)
+    shared.device = torch.device("cpu")
+    philox = load_by_path("modules.rng_philox", "modules/rng_philox.py")
+    for n, m in (("devices", devices), ("shared", shared), ("rng_philox", philox)):
+        sys.modules["modules." + n] = m
+        setattr(mods, n, m)
+    ref = load_by_path("ref_rng", "modules/rng.py")
+    out = {}
+    for name, shape, seeds, kw, ensd in IMAGE_RNG_CASES:
+        shared.opts.eta_noise_seed_delta = ensd
+        r = ref.ImageRNG(shape, seeds, **kw)
+        for k in range(3):
+            out[f"{name}_{k}"] = r.next().numpy()
+    np.savez_compressed(os.path.join(OUT, "image_rng.npz"), **out)
+    print("image_rng.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -967,3 +1005,4 @@ if __name__ == "__main__":
     gen_refiner()
     gen_lyco()
     gen_prompt_cond()
+    gen_image_rng()

@@ -417,3 +417,22 @@ def test_sampler_kernels_match_oracle_formulas(dev):
     got = sub("ops").image_to_u8(img.to(dev)).cpu().numpy()
     from oracle.vae import to_uint8_hwc
     np.testing.assert_array_equal(got, to_uint8_hwc(img))
+
+
+def test_image_rng_variation_seeds_and_seed_resize_vs_reference(dev, golden_dir):
+    """Device ImageRNG (Philox kernel, sdmi_slerp, centred paste) against the reference-generated draws of
+    tests/golden/image_rng.npz: plain / ENSD / seed-resize are bit-exact, the slerp cases agree to fp32 rounding of sin / acos."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    rng = sub("rng")
+    z = np.load(os.path.join(golden_dir, "image_rng.npz"))
+    for name, shape, seeds, kw, ensd in mg.IMAGE_RNG_CASES:
+        r = rng.ImageRNG(shape, seeds, eta_noise_seed_delta=ensd, device=dev, **kw)
+        for k in range(3):
+            got = r.next().cpu().numpy()
+            if "subseed" in name and k == 0:
+                np.testing.assert_allclose(got, z[f"{name}_{k}"], rtol=0, atol=3e-6, err_msg=name)
+            else:
+                assert np.array_equal(got, z[f"{name}_{k}"]), (name, k)

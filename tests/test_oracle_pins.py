@@ -351,6 +351,19 @@ def test_prompt_conditioning_containers_match_reference(golden_dir):
                 assert np.array_equal(stacked.numpy(), z[f"c_{step}"]) and np.array_equal(u.numpy(), z[f"uc_{step}"])
 
 
+def test_image_rng_matches_reference(golden_dir):
+    """oracle ImageRNG == modules/rng.py ImageRNG over the real rng_philox.py (randn_source "NV"), three draws each: plain,
+    eta_noise_seed_delta, variation seeds (slerp branch, lerp branch, short subseed list), seed-resize (smaller, larger, mixed)
+    and all of them together — bit-exact."""
+    from oracle.rng import ImageRNG
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "image_rng.npz"))
+    for name, shape, seeds, kw, ensd in mg.IMAGE_RNG_CASES:
+        r = ImageRNG(shape, seeds, eta_noise_seed_delta=ensd, **kw)
+        for k in range(3):
+            assert np.array_equal(r.next().numpy(), z[f"{name}_{k}"]), (name, k)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
