@@ -4,11 +4,25 @@ where /root/reference exists; the GPU box only sees the committed .npz files).
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
 
-Reference files executed (loaded by path, unmodified):
-  modules/rng_philox.py                      -> philox.npz
-  modules/sub_quadratic_attention.py         -> subquad_attention.npz
-  modules/models/sd3/sd3_impls.py            -> vae_decoder.npz, vae_encoder.npz   (VAEDecoder / VAEEncoder, z_channels=4)
-  modules/sd_samplers_timesteps_impl.py      -> ddim.npz                            (ddim(), with stub modules)
+Reference files executed — loaded by path, unmodified, with the webui modules they import stubbed; where a file cannot be
+imported at all (lark / gradio / ldm at module level) the named functions are exec'd from the file's own text:
+  modules/rng_philox.py                          -> philox.npz
+  modules/rng.py (+ rng_philox.py)               -> image_rng.npz          (ImageRNG: variation seeds, seed-resize, ENSD)
+  modules/sub_quadratic_attention.py             -> subquad_attention.npz
+  modules/models/sd3/sd3_impls.py                -> vae_decoder.npz, vae_encoder.npz   (VAEDecoder / VAEEncoder, z_channels=4)
+  modules/models/sd3/other_impls.py              -> clip_text.npz          (CLIP text transformer)
+  modules/sd_samplers_timesteps_impl.py          -> ddim.npz, plms.npz     (ddim, ddim_cfgpp, plms)
+  ... + modules/models/diffusion/uni_pc/uni_pc.py -> unipc.npz              (unipc() / UniPCCFG over the real solver)
+  modules/sd_samplers_extra.py                   -> restart.npz
+  modules/sd_samplers_lcm.py                     -> lcm.npz
+  modules/sd_schedulers.py                       -> schedulers.npz
+  modules/sd_samplers_cfg_denoiser.py            -> cfg_denoiser.npz       (CFGDenoiser.forward, 20 scenarios)
+  modules/sd_samplers_common.py  [text]          -> refiner.npz            (apply_refiner), + images_tensor_to_samples below
+  modules/processing.py          [text]          -> image_conditioning.npz (txt2img / inpainting / edit image conditioning)
+  modules/images.py, upscaler.py [text]          -> resize_image.npz       (resize_image mode 0, Upscaler loop, PIL scalers)
+  modules/prompt_parser.py       [text]          -> prompt_cond.npz/.json  (AND splitting, reconstruct_*cond_batch)
+  extensions-builtin/Lora/networks.py [text]     -> lora_names.json        (convert_diffusers_name_to_compvis)
+  extensions-builtin/Lora/network*.py, lyco_helpers.py -> lyco.npz         (calc_updown of every module type but OFT)
 Weights / inputs are produced by ``seeded()`` below (CPU torch.Generator, N(0,1) scaled), so a fixture stores
 only seeds + the reference's outputs; tests regenerate the same inputs.
 """
