@@ -21,6 +21,8 @@ imported at all (lark / gradio / ldm at module level) the named functions are ex
   modules/processing.py          [text]          -> image_conditioning.npz (txt2img / inpainting / edit image conditioning)
   modules/images.py, upscaler.py [text]          -> resize_image.npz       (resize_image mode 0, Upscaler loop, PIL scalers)
   modules/prompt_parser.py       [text]          -> prompt_cond.npz/.json  (AND splitting, reconstruct_*cond_batch)
+  modules/sd_hijack_unet.py, hypernetworks/hypernetwork.py [text] -> unet_twins.npz (timestep embedding, SpatialTransformer and
+                                                    baseline attention forwards run on the oracle's modules)
   extensions-builtin/Lora/networks.py [text]     -> lora_names.json        (convert_diffusers_name_to_compvis)
   extensions-builtin/Lora/network*.py, lyco_helpers.py -> lyco.npz         (calc_updown of every module type but OFT)
 Weights / inputs are produced by ``seeded()`` below (CPU torch.Generator, N(0,1) scaled), so a fixture stores
@@ -1001,6 +1003,52 @@ def gen_image_rng():
     print("image_rng.npz")
 
 
+def unet_twin_modules():
+    """Oracle modules with seeded weights, shared by the generator and the test (constructed identically in both)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import unet as ou
+    torch.manual_seed(0)
+    attn_self = ou.CrossAttention(64, None, 4, 16)
+    attn_cross = ou.CrossAttention(64, 48, 4, 16)
+    st_conv = ou.SpatialTransformer(64, 4, 16, 2, 48, use_linear=False)
+    st_lin = ou.SpatialTransformer(64, 2, 32, 1, 48, use_linear=True)
+    for k, m in enumerate((attn_self, attn_cross, st_conv, st_lin)):
+        seeded_module_weights(m, 9500 + k)
+        m.eval().requires_grad_(False)
+    return attn_self, attn_cross, st_conv, st_lin
+
+
+def gen_unet_twins():
+    """The in-tree functions the webui patches over ldm's UNet, run on the ORACLE's module instances: timestep_embedding and
+    spatial_transformer_forward (modules/sd_hijack_unet.py:56-102), attention_CrossAttention_forward (the baseline attention,
+    modules/hypernetworks/hypernetwork.py:382-407, hypernetworks empty).  The fixture pins the oracle's own forwards of the
+    same modules (embedding order cos|sin, NCHW <-> token reshapes around proj_in / proj_out, head split / merge, softmax)."""
+    import math
+    from einops import rearrange, repeat
+    src = open(os.path.join(REF, "modules/sd_hijack_unet.py")).read()
+    ns = {"torch": torch, "math": math, "repeat": repeat}
+    exec(src[src.index("def timestep_embedding(_"):src.index("class GELUHijack")], ns)
+    src = open(os.path.join(REF, "modules/hypernetworks/hypernetwork.py")).read()
+    ns2 = {"torch": torch, "rearrange": rearrange, "repeat": repeat, "einsum": torch.einsum, "default": lambda a, b: a if a is not None else b,
+           "shared": types.SimpleNamespace(loaded_hypernetworks=[]), "apply_hypernetworks": lambda hn, context, layer=None: (context, context)}
+    a = src.index("def attention_CrossAttention_forward(")
+    exec(src[a:src.index("def stack_conds(")], ns2)
+    attn_self, attn_cross, st_conv, st_lin = unet_twin_modules()
+    out = {}
+    t = torch.tensor([999.0, 500.25, 37.5, 0.0])
+    out["temb_320"] = ns["timestep_embedding"](None, t, 320).numpy()
+    out["temb_65"] = ns["timestep_embedding"](None, t, 65).numpy()
+    x = seeded((2, 40, 64), 9600)
+    ctx = seeded((2, 77, 48), 9601)
+    out["attn_self"] = ns2["attention_CrossAttention_forward"](attn_self, x).numpy()
+    out["attn_cross"] = ns2["attention_CrossAttention_forward"](attn_cross, x, context=ctx).numpy()
+    img = seeded((2, 64, 6, 5), 9602)
+    out["st_conv"] = ns["spatial_transformer_forward"](None, st_conv, img, context=[ctx, ctx]).numpy()
+    out["st_lin"] = ns["spatial_transformer_forward"](None, st_lin, img, context=ctx).numpy()
+    np.savez_compressed(os.path.join(OUT, "unet_twins.npz"), **out)
+    print("unet_twins.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -1020,3 +1068,4 @@ if __name__ == "__main__":
     gen_lyco()
     gen_prompt_cond()
     gen_image_rng()
+    gen_unet_twins()

@@ -364,6 +364,26 @@ def test_image_rng_matches_reference(golden_dir):
             assert np.array_equal(r.next().numpy(), z[f"{name}_{k}"]), (name, k)
 
 
+def test_unet_pieces_match_in_tree_twins(golden_dir):
+    """The pieces of ldm's UNet the webui re-implements in-tree, executed by make_golden on the oracle's own module instances:
+    timestep_embedding and spatial_transformer_forward (modules/sd_hijack_unet.py:56-102) and the baseline
+    attention_CrossAttention_forward (modules/hypernetworks/hypernetwork.py:382-407) — the oracle's forwards of the same modules
+    give the same bits (conv and linear proj_in / proj_out, self- and cross-attention, even and odd embedding widths)."""
+    from oracle import unet as ou
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "unet_twins.npz"))
+    attn_self, attn_cross, st_conv, st_lin = mg.unet_twin_modules()
+    t = torch.tensor([999.0, 500.25, 37.5, 0.0])
+    assert np.array_equal(ou.timestep_embedding(t, 320).numpy(), z["temb_320"])
+    assert np.array_equal(ou.timestep_embedding(t, 65).numpy(), z["temb_65"])
+    x, ctx, img = seeded((2, 40, 64), 9600), seeded((2, 77, 48), 9601), seeded((2, 64, 6, 5), 9602)
+    with torch.no_grad():
+        np.testing.assert_allclose(attn_self(x).numpy(), z["attn_self"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(attn_cross(x, context=ctx).numpy(), z["attn_cross"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(st_conv(img, context=ctx).numpy(), z["st_conv"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(st_lin(img, context=ctx).numpy(), z["st_lin"], rtol=0, atol=1e-6)
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
