@@ -42,6 +42,7 @@ class Mi355xUnet(SdUnet):
         self._device_index = device_index
         self.engine = None
         self._ctx_key = None
+        self._last_ctx = None
 
     def activate(self):
         from . import schema
@@ -58,6 +59,7 @@ class Mi355xUnet(SdUnet):
         if self.engine is not None:
             self.engine.close()
             self.engine = None
+        self._ctx_key = self._last_ctx = None
 
     def forward(self, x, timesteps, context, *args, **kwargs):
         if kwargs.get("control") is not None or args:
@@ -65,13 +67,18 @@ class Mi355xUnet(SdUnet):
         if x.dtype not in (torch.float16, torch.float32):
             x = x.float()
         y = kwargs.get("y", None)
-        # context is step-invariant unless prompt editing swaps it: re-project only when the tensor changes
-        key = (context.data_ptr(), tuple(context.shape), context._version, context.dtype,
-               getattr(self.engine, "weights_version", 0))
+        # The context is step-invariant unless prompt editing swaps it, so its K / V projections are cached — validated by
+        # CONTENT: the webui re-catenates cond | uncond every step (sd_samplers_cfg_denoiser.py:246), and the caching allocator
+        # hands the next step's (or the next job's) tensor the same address, so an address / version key would go stale.
+        version = getattr(self.engine, "weights_version", 0)
+        last = self._last_ctx
+        same = (last is not None and self._ctx_key == version and last.shape == context.shape and last.dtype == context.dtype
+                and last.device == context.device and bool(torch.equal(last, context)))
         ctx = None
-        if key != self._ctx_key:
+        if not same:
+            self._last_ctx = context.detach().clone()
+            self._ctx_key = version
             ctx = context.to(x.dtype)
-            self._ctx_key = key
         return self.engine.unet_forward(x, timesteps, ctx, y)
 
 

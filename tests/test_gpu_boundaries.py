@@ -42,8 +42,19 @@ def test_sd_unet_adapter_forward_contract(dev):
         assert rel_l2(out.float().cpu(), ref) < 8e-3
         out2 = unet.forward(x, t, ctx)                     # same context tensor: cached projections, same bits
         assert torch.equal(out, out2)
+        # a NEW context that lands on the freed tensor's address (what the webui's per-step torch.cat does, and what the next
+        # job's prompt does): the cache is validated by content, so the projections are rebuilt
+        ctx_b = seeded((4, 77, 64), 3).to(dev).half()
+        del ctx
+        reused = torch.empty_like(ctx_b)
+        reused.copy_(ctx_b)
+        out3 = unet.forward(x, t, reused)
+        assert not torch.equal(out3, out)
+        ref3 = ou.build_unet(ou.tiny_config(), sd)(x.float().cpu(), t.float().cpu(), ctx_b.float().cpu())
+        assert rel_l2(out3.float().cpu(), ref3) < 8e-3
+        assert torch.equal(unet.forward(x, t, ctx_b), out3)      # equal content at another address: cache hit, same bits
         with pytest.raises(NotImplementedError):
-            unet.forward(x, t, ctx, control=[x])
+            unet.forward(x, t, reused, control=[x])
     finally:
         unet.deactivate()
 
