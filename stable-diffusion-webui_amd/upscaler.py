@@ -16,69 +16,69 @@ LANCZOS = (Image.Resampling.LANCZOS if hasattr(Image, 'Resampling') else Image.L
 NEAREST = (Image.Resampling.NEAREST if hasattr(Image, 'Resampling') else Image.NEAREST)
 
 
+class UpscalerData:
+    """A selectable upscaler: what shared.sd_upscalers holds (modules/upscaler.py:87-104)."""
+
+    def __init__(self, name, path, upscaler=None, scale=4, model=None):
+        self.name, self.data_path, self.local_data_path = name, path, path
+        self.scaler, self.scale, self.model = upscaler, scale, model
+
+    def __repr__(self):
+        return f"<UpscalerData name={self.name} path={self.data_path} scale={self.scale}>"
+
+
 class Upscaler:
+    """Base class with the reference's driver (modules/upscaler.py:54-76): a scaler may enlarge by less than asked for, so it
+    is applied up to three times until the (8-aligned) destination size is covered, then the result is fitted with LANCZOS."""
     name = None
-    scalers: list
 
     def __init__(self):
         self.scale = 1
+        self.scalers = []
 
     def do_upscale(self, img, selected_model=None):
         return img
 
     def upscale(self, img, scale, selected_model=None):
-        """modules/upscaler.py:54-76: up to three passes of the scaler, then an exact LANCZOS fit to (w*scale)//8*8."""
         self.scale = scale
-        dest_w = int((img.width * scale) // 8 * 8)
-        dest_h = int((img.height * scale) // 8 * 8)
-        for i in range(3):
-            if img.width >= dest_w and img.height >= dest_h and (i > 0 or scale != 1):
+        dest_w, dest_h = int((img.width * scale) // 8 * 8), int((img.height * scale) // 8 * 8)
+        for attempt in range(3):
+            covered = img.width >= dest_w and img.height >= dest_h
+            if (covered and (attempt > 0 or scale != 1)) or shared.state.interrupted:
                 break
-            if shared.state.interrupted:
-                break
-            shape = (img.width, img.height)
+            before = (img.width, img.height)
             img = self.do_upscale(img, selected_model)
-            if shape == (img.width, img.height):
+            if before == (img.width, img.height):
                 break
-        if img.width != dest_w or img.height != dest_h:
-            img = img.resize((int(dest_w), int(dest_h)), resample=LANCZOS)
+        if (img.width, img.height) != (dest_w, dest_h):
+            img = img.resize((dest_w, dest_h), resample=LANCZOS)
         return img
 
 
-class UpscalerData:
-    def __init__(self, name, path, upscaler=None, scale=4, model=None):
-        self.name, self.data_path, self.local_data_path = name, path, path
-        self.scaler, self.scale, self.model = upscaler, scale, model
+class _PilUpscaler(Upscaler):
+    """The built-in scalers that are one PIL resize (modules/upscaler.py:107-154): "None" (identity), "Lanczos", "Nearest"."""
+    resample = None
+
+    def __init__(self):
+        super().__init__()
+        self.scalers = [UpscalerData(self.name, None, self)]
+
+    def do_upscale(self, img, selected_model=None):
+        if self.resample is None:
+            return img
+        return img.resize((int(img.width * self.scale), int(img.height * self.scale)), resample=self.resample)
 
 
-class UpscalerNone(Upscaler):
+class UpscalerNone(_PilUpscaler):
     name = "None"
 
-    def __init__(self):
-        super().__init__()
-        self.scalers = [UpscalerData("None", None, self)]
+
+class UpscalerLanczos(_PilUpscaler):
+    name, resample = "Lanczos", LANCZOS
 
 
-class UpscalerLanczos(Upscaler):
-    name = "Lanczos"
-
-    def do_upscale(self, img, selected_model=None):
-        return img.resize((int(img.width * self.scale), int(img.height * self.scale)), resample=LANCZOS)
-
-    def __init__(self):
-        super().__init__()
-        self.scalers = [UpscalerData("Lanczos", None, self)]
-
-
-class UpscalerNearest(Upscaler):
-    name = "Nearest"
-
-    def do_upscale(self, img, selected_model=None):
-        return img.resize((int(img.width * self.scale), int(img.height * self.scale)), resample=NEAREST)
-
-    def __init__(self):
-        super().__init__()
-        self.scalers = [UpscalerData("Nearest", None, self)]
+class UpscalerNearest(_PilUpscaler):
+    name, resample = "Nearest", NEAREST
 
 
 def builtin_upscalers():
