@@ -83,6 +83,7 @@ int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hi
 // worst-case fp32 workspace a split-K launch of this shape may use (bytes); 0 when split-K would never be chosen
 size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch);
 extern int g_force_gemm_cfg;
+extern int g_shortk_gemm_cfg;
 extern int g_gemm_pipe;             // 0 = two-stage kernels, 1 = BK32 ring for the big tiles, 2 = also 128x128, 3 = ping-pong 256-row tiles, 4 = also 128x320
 extern int g_gemm_pipe_default;     // value restored by sdmi_debug_set("gemm_pipe", -1)
 extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = force k slices where allowed

@@ -1060,6 +1060,10 @@ static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f,
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
 int g_force_gemm_split = 0;
+// Experiment knob (default off): tile config forced for the short-K launches only (K / 64 < 8: the q / k / v / out projections and
+// proj_in / proj_out, ~5 % of the C1 job at 2-3x their HBM floor with one 256x320 tile per CU) — e.g. SDMI_SHORTK_CFG=<128x64 id>
+// to try several co-resident workgroups per CU in a same-box A/B (lead 2).
+int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e ? atoi(e) : -1; }();
 // 4 (default): ping-pong kernel for the 256-row tiles and the 128x320 tile (+5..22 % over the two-stage kernel per shape,
 // bit-identical results), two-stage kernels elsewhere.  3: ping-pong for the 256-row tiles only.  0: two-stage kernels only.  1: BK=32 ring kernels for the big tiles, 2: also
 // 128x128 — kept selectable; measured 7-25 % SLOWER than the two-stage kernels (profiles/r01_microbench_pipe.txt).
@@ -1112,6 +1116,7 @@ static int pick_cfg(const GemmP& p, int batch, int* split_out, bool allow_split)
         return g_force_gemm_cfg;
     }
     if (g_force_gemm_split == 1) allow_split = false;
+    if (g_shortk_gemm_cfg >= 0 && p.K / 64 < 8 && cfg_valid(g_shortk_gemm_cfg, p)) return g_shortk_gemm_cfg;
     const int cands[] = {CFG_256x320, CFG_256x256, CFG_128x320, CFG_128x128_K32, CFG_128x128, CFG_128x64, CFG_64x64};
     int best = -1;
     float best_score = -1.f;
