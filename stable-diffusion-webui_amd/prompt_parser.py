@@ -141,10 +141,16 @@ def reconstruct_multicond_batch(c: MulticondLearnedConditioning, current_step):
     return conds_list, stack_conds(rows).to(device=like.device, dtype=like.dtype)
 
 
+def is_multicond(c):
+    """True for a MulticondLearnedConditioning — this module's or the webui's own class (modules/prompt_parser.py:245-249):
+    inside the webui the conds arrive as the reference's objects, which have the same attributes."""
+    return isinstance(c, MulticondLearnedConditioning) or (hasattr(c, "batch") and hasattr(c, "shape") and not torch.is_tensor(c))
+
+
 def selection_key(c, current_step):
     """Identity of what reconstruct_* would pick at this step: equal keys = identical tensors, so the denoiser can keep the
     reconstructed batch (and the cross-attention K / V projected from it) instead of rebuilding them every step."""
-    if isinstance(c, MulticondLearnedConditioning):
+    if is_multicond(c):
         return tuple(tuple((_target_index(cp.schedules, current_step), id(cp.schedules), cp.weight) for cp in img) for img in c.batch)
     return tuple((_target_index(sch, current_step), id(sch)) for sch in c)
 
@@ -152,7 +158,7 @@ def selection_key(c, current_step):
 def slice_conds(c, lo, hi, device):
     """The conds of images [lo, hi) of a job: a ready tensor [N, T, C] (moved to ``device``), or the containers above —
     MulticondLearnedConditioning (p.c) / a list of per-image schedules (p.uc) — which the CFG denoiser unpacks on every step."""
-    if isinstance(c, MulticondLearnedConditioning):
+    if is_multicond(c):
         return MulticondLearnedConditioning((hi - lo,), c.batch[lo:hi])
     if isinstance(c, list):
         return c[lo:hi]

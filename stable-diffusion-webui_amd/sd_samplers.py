@@ -279,7 +279,7 @@ class CFGDenoiser:
         def on_device(t):
             return {k: v.to(device) for k, v in t.items()} if isinstance(t, dict) else t.to(device)
 
-        if isinstance(cond, prompt_parser.MulticondLearnedConditioning):
+        if prompt_parser.is_multicond(cond):
             key = prompt_parser.selection_key(cond, self.step)
             if self._cond_sel is None or self._cond_sel[0] != key:
                 conds_list, stacked = prompt_parser.reconstruct_multicond_batch(cond, self.step)

@@ -275,6 +275,10 @@ def test_host_prompt_parser_containers_match_reference(golden_dir):
         # cond selection: steps {0,2} | 3 | 4 | {5..9} | 10 | 25 (past every end: back to entry 0); uncond changes after step 3
         assert keys[0][0] == keys[1][0] != keys[2][0] and keys[3][0] != keys[4][0] and keys[6][0] != keys[7][0]
         assert keys[0][1] == keys[1][1] == keys[2][1] != keys[3][1]
+        foreign = type("MulticondLearnedConditioning", (), {})()          # the webui's own class: same attributes, other type
+        foreign.shape, foreign.batch = c.shape, c.batch
+        assert hp.is_multicond(foreign) and hp.selection_key(foreign, 3) == hp.selection_key(c, 3) and not hp.is_multicond(torch.zeros(2, 3))
+        assert hp.reconstruct_multicond_batch(foreign, 3)[0] == hp.reconstruct_multicond_batch(c, 3)[0]
         sl = hp.slice_conds(c, 1, 3, "cpu")
         assert isinstance(sl, hp.MulticondLearnedConditioning) and sl.shape == (2,) and sl.batch[0] is c.batch[1]
 
