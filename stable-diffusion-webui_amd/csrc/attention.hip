@@ -26,8 +26,11 @@ namespace sdmi {
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-template <int D, int KVT>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
+// OCC = workgroups per CU the register allocation is bounded for (launch bounds): 0 = the default budget (2 for D <= 80, else 1);
+// 4 caps the kernel at 128 VGPRs — an experiment for the d = 40 level-0 self-attention, which is VALU / exp bound (DESIGN.md
+// section 9) and may gain from a fourth wave per SIMD; selected with SDMI_ATTN_OCC=4, not the default until measured.
+template <int D, int KVT, int OCC = 0>
+__global__ __launch_bounds__(256, (OCC > 0 ? OCC : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
     constexpr int DK = (D + 15) / 16 * 16;   // contraction length of S^T, padded to the MFMA K step
     constexpr int NDC = DK / 16;
     constexpr int DV = (D + 31) / 32 * 32;   // rows of O^T, padded to the MFMA M
@@ -332,11 +335,13 @@ int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, 
 
 int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e) : 0; }();
 
-template <int D, int KVT>
+int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 0; }();
+
+template <int D, int KVT, int OCC = 0>
 static int launch_attn_d(const AttnP& p, hipStream_t s) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     constexpr int SMEM = 2 * (KVT * (DK * 2 + 16) + DV * (KVT * 2 + 16));
-    auto kern = attn_mfma_kernel<D, KVT>;
+    auto kern = attn_mfma_kernel<D, KVT, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -360,7 +365,9 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
         switch (p.D) {
             // KV tile: 128 keys where the register budget allows it (small heads: the per-tile barrier / staging
             // overhead is amortised over twice the MFMA work), 64 otherwise or when the key sequence is short
-            case 40: return (kvt128 && p.M > 64) ? launch_attn_d<40, 128>(p, s) : launch_attn_d<40, 64>(p, s);
+            case 40:
+                if (g_attn_occ == 4 && !(kvt128 && p.M > 64)) return launch_attn_d<40, 64, 4>(p, s);
+                return (kvt128 && p.M > 64) ? launch_attn_d<40, 128>(p, s) : launch_attn_d<40, 64>(p, s);
             case 64: return (kvt128 && p.M > 64) ? launch_attn_d<64, 128>(p, s) : launch_attn_d<64, 64>(p, s);
             case 80: return launch_attn_d<80, 64>(p, s);
             case 128: return launch_attn_d<128, 64>(p, s);

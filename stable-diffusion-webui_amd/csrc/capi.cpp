@@ -428,6 +428,7 @@ int sdmi_debug_set(const char* name, int value) {
     if (n == "gemm_cfg") g_force_gemm_cfg = value;
     else if (n == "gemm_shortk_cfg") g_shortk_gemm_cfg = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
+    else if (n == "attn_occ") g_attn_occ = value;
     else if (n == "gemm_split") g_force_gemm_split = value;
     else if (n == "gemm_pipe") g_gemm_pipe = value < 0 ? g_gemm_pipe_default : value;
     else if (n == "gemm_dbgflags") g_gemm_dbgflags = value & 0x1F00;

@@ -88,6 +88,7 @@ extern int g_gemm_pipe;             // 0 = two-stage kernels, 1 = BK32 ring for 
 extern int g_gemm_pipe_default;     // value restored by sdmi_debug_set("gemm_pipe", -1)
 extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = force k slices where allowed
 extern int g_attn_kvt;
+extern int g_attn_occ;
 extern int g_gemm_dbgflags;
 extern unsigned long long g_gemm_dbg;   // device pointer (0 = off): 5 x int64 per wave of section cycle sums
 
