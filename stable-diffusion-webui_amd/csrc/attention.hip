@@ -26,11 +26,16 @@ namespace sdmi {
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-// OCC = workgroups per CU the register allocation is bounded for (launch bounds): 0 = the default budget (2 for D <= 80, else 1);
-// 4 caps the kernel at 128 VGPRs — an experiment for the d = 40 level-0 self-attention, which is VALU / exp bound (DESIGN.md
-// section 9) and may gain from a fourth wave per SIMD; selected with SDMI_ATTN_OCC=4, not the default until measured.
-template <int D, int KVT, int OCC = 0>
-__global__ __launch_bounds__(256, (OCC > 0 ? OCC : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
+// VAR = experiment variants of the d = 40 level-0 self-attention, which is VALU / exp bound; selected with
+// SDMI_ATTN_OCC=<VAR>, none is the default until measured in a same-box A/B:
+//   0  production: register budget for 2 workgroups per CU (D <= 80) or 1
+//   4  register budget for 4 workgroups per CU (128 VGPRs: a fourth wave per SIMD to hide the exp latency)
+//   5  4 + lazy rescale: the O accumulators are multiplied by alpha only when some lane's running max moved (alpha == 1 otherwise,
+//      so the result is unchanged; after the first few KV tiles the max rarely moves) — 16 v_pk_mul_f32 less per tile
+//   6  lazy rescale with the production register budget
+template <int D, int KVT, int VAR = 0>
+__global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
+    constexpr bool LAZY_RESCALE = VAR >= 5;
     constexpr int DK = (D + 15) / 16 * 16;   // contraction length of S^T, padded to the MFMA K step
     constexpr int NDC = DK / 16;
     constexpr int DV = (D + 31) / 32 * 32;   // rows of O^T, padded to the MFMA M
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(256, (OCC > 0 ? OCC : D <= 80 ? 2 : 1)) void attn_m
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;      // scale > 0: max commutes with the scaling
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const bool max_moved = !LAZY_RESCALE || __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;   // wave-uniform
         m_run = m_new;
         const f2v mneg = {-m_new, -m_new};
         f2v rs = {0.f, 0.f};
@@ -223,10 +229,12 @@ __global__ __launch_bounds__(256, (OCC > 0 ? OCC : D <= 80 ? 2 : 1)) void attn_m
                 pb[kb][r >> 3][(r & 7) + 1] = (half_t)e.y;
             }
         if (!SUMROW) l_run = l_run * alpha + rs;
+        if (max_moved) {
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T ---------------------------------------------------------------------------------
 #pragma unroll
@@ -337,11 +345,11 @@ int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e
 
 int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 0; }();
 
-template <int D, int KVT, int OCC = 0>
+template <int D, int KVT, int VAR = 0>
 static int launch_attn_d(const AttnP& p, hipStream_t s) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     constexpr int SMEM = 2 * (KVT * (DK * 2 + 16) + DV * (KVT * 2 + 16));
-    auto kern = attn_mfma_kernel<D, KVT, OCC>;
+    auto kern = attn_mfma_kernel<D, KVT, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -366,7 +374,11 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
             // KV tile: 128 keys where the register budget allows it (small heads: the per-tile barrier / staging
             // overhead is amortised over twice the MFMA work), 64 otherwise or when the key sequence is short
             case 40:
-                if (g_attn_occ == 4 && !(kvt128 && p.M > 64)) return launch_attn_d<40, 64, 4>(p, s);
+                if (!(kvt128 && p.M > 64)) {
+                    if (g_attn_occ == 4) return launch_attn_d<40, 64, 4>(p, s);
+                    if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
+                    if (g_attn_occ == 6) return launch_attn_d<40, 64, 6>(p, s);
+                }
                 return (kvt128 && p.M > 64) ? launch_attn_d<40, 128>(p, s) : launch_attn_d<40, 64>(p, s);
             case 64: return (kvt128 && p.M > 64) ? launch_attn_d<64, 128>(p, s) : launch_attn_d<64, 64>(p, s);
             case 80: return launch_attn_d<80, 64>(p, s);

@@ -287,22 +287,23 @@ def test_attention_vs_oracle(dev, d, heads, n, m):
     assert rel_l2(got.float().cpu(), ref) < 1.5e-3, (d, heads, n, m)
 
 
-def test_attention_occupancy_variant_is_bit_identical(dev):
-    """The 128-VGPR instantiation of the d = 40 flash kernel (SDMI_ATTN_OCC=4 / sdmi_debug_set("attn_occ", 4): four workgroups
-    per CU, a tuning experiment kept off by default) runs the same arithmetic: self- and cross-attention shapes incl. ragged
-    tails agree with the default instantiation."""
+def test_attention_experiment_variants_match_production_kernel(dev):
+    """The default-off tuning variants of the d = 40 flash kernel (SDMI_ATTN_OCC / sdmi_debug_set("attn_occ", v): 128-VGPR register
+    budget for four workgroups per CU, lazy O rescale) run the same arithmetic: self- and cross-attention shapes incl. ragged
+    tails agree with the production instantiation."""
     ops, lib = sub("ops"), sub("_lib")
     for heads, n, m in ((8, 512, 512), (2, 200, 77), (1, 130, 333)):
         q, k, v = seeded((2, n, heads * 40), 41).half().to(dev), seeded((2, m, heads * 40), 42).half().to(dev), seeded((2, m, heads * 40), 43).half().to(dev)
         base = ops.attention(q, k, v, heads)
-        try:
-            lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 4))
-            got = ops.attention(q, k, v, heads)
-            torch.cuda.synchronize()
-        finally:
-            lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 0))
-        # same operation counts in the compiled loops (packed vs scalar forms of the same fp32 ops), so the bits are expected equal
-        assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (heads, n, m)
+        for variant in (4, 5, 6):       # 4: 128 VGPRs; 5: + lazy O rescale (skipped while alpha == 1); 6: lazy rescale alone
+            try:
+                lib.check(lib.lib.sdmi_debug_set(b"attn_occ", variant))
+                got = ops.attention(q, k, v, heads)
+                torch.cuda.synchronize()
+            finally:
+                lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 0))
+            # same operation counts in the compiled loops (packed vs scalar forms of the same fp32 ops): the bits are expected equal
+            assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (heads, n, m, variant)
 
 
 def test_attention_matches_reference_sub_quadratic_fixture(dev, golden_dir):
