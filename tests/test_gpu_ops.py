@@ -287,25 +287,6 @@ def test_attention_vs_oracle(dev, d, heads, n, m):
     assert rel_l2(got.float().cpu(), ref) < 1.5e-3, (d, heads, n, m)
 
 
-def test_attention_experiment_variants_match_production_kernel(dev):
-    """The default-off tuning variants of the d = 40 flash kernel (SDMI_ATTN_OCC / sdmi_debug_set("attn_occ", v): 128-VGPR register
-    budget for four workgroups per CU, lazy O rescale) run the same arithmetic: self- and cross-attention shapes incl. ragged
-    tails agree with the production instantiation."""
-    ops, lib = sub("ops"), sub("_lib")
-    for heads, n, m in ((8, 512, 512), (2, 200, 77), (1, 130, 333)):
-        q, k, v = seeded((2, n, heads * 40), 41).half().to(dev), seeded((2, m, heads * 40), 42).half().to(dev), seeded((2, m, heads * 40), 43).half().to(dev)
-        base = ops.attention(q, k, v, heads)
-        for variant in (4, 5, 6):       # 4: 128 VGPRs; 5: + lazy O rescale (skipped while alpha == 1); 6: lazy rescale alone
-            try:
-                lib.check(lib.lib.sdmi_debug_set(b"attn_occ", variant))
-                got = ops.attention(q, k, v, heads)
-                torch.cuda.synchronize()
-            finally:
-                lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 0))
-            # same operation counts in the compiled loops (packed vs scalar forms of the same fp32 ops): the bits are expected equal
-            assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (heads, n, m, variant)
-
-
 def test_attention_matches_reference_sub_quadratic_fixture(dev, golden_dir):
     """Against outputs of the reference's own modules/sub_quadratic_attention.py (tests/golden/make_golden.py)."""
     ops = sub("ops")
@@ -455,3 +436,23 @@ def test_image_rng_variation_seeds_and_seed_resize_vs_reference(dev, golden_dir)
                 np.testing.assert_allclose(got, z[f"{name}_{k}"], rtol=0, atol=3e-6, err_msg=name)
             else:
                 assert np.array_equal(got, z[f"{name}_{k}"]), (name, k)
+
+
+def test_attention_experiment_variants_match_production_kernel(dev):
+    """The default-off tuning variants of the d = 40 flash kernel (SDMI_ATTN_OCC / sdmi_debug_set("attn_occ", v): 128-VGPR register
+    budget for four workgroups per CU, lazy O rescale) run the same arithmetic: self- and cross-attention shapes incl. ragged
+    tails agree with the production instantiation."""
+    ops, lib = sub("ops"), sub("_lib")
+    for heads, n, m in ((8, 512, 512), (2, 200, 77), (1, 130, 333)):
+        q, k, v = seeded((2, n, heads * 40), 41).half().to(dev), seeded((2, m, heads * 40), 42).half().to(dev), seeded((2, m, heads * 40), 43).half().to(dev)
+        base = ops.attention(q, k, v, heads)
+        for variant in (4, 5, 6):       # 4: 128 VGPRs; 5: + lazy O rescale (skipped while alpha == 1); 6: lazy rescale alone
+            try:
+                lib.check(lib.lib.sdmi_debug_set(b"attn_occ", variant))
+                got = ops.attention(q, k, v, heads)
+                torch.cuda.synchronize()
+            finally:
+                lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 0))
+            # same operation counts in the compiled loops (packed vs scalar forms of the same fp32 ops): the bits are expected equal
+            assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (heads, n, m, variant)
+
