@@ -360,6 +360,7 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
     dev = p.sd_model.device
     for n in range(p.n_iter):
         p.iteration = n
+        shared.sd_model = p.sd_model                                 # :941 — the previous iteration may have ended on the refiner
         lo, hi = n * p.batch_size, (n + 1) * p.batch_size
         p.seeds = p.all_seeds[lo:hi]
         p.subseeds = p.all_subseeds[lo:hi]
