@@ -88,7 +88,9 @@ class SdModel:
         uses the mean for determinism."""
         mean, logvar = torch.chunk(moments, 2, dim=1)
         if not sample:
-            return (mean * self.scale_factor).contiguous()
+            from . import ops
+            mean = mean.contiguous()
+            return ops.lincomb(torch.empty_like(mean), [mean], [float(self.scale_factor)])
         std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
         eps = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
         return ((mean + std * eps) * self.scale_factor).contiguous()
