@@ -4,8 +4,8 @@ Follows /root/reference/extensions-builtin/Lora: key grouping and lookup network
 names networks.py:56-120 (pinned by tests/golden/lora_names.json, produced by executing that function), module creation
 network_lora.py:9-35, delta network_lora.py:65-80 + lyco_helpers.py:9-15, scaling network.py:161-173 / 196-216, weight
 rewrite networks.py:455-472 (W + updown per loaded network, in list order).  UNet layers only (the text encoder is not
-on the engine's path).  All LyCORIS module types of the reference except OFT / BOFT are restated (LoRA / LoCon incl.
-cp-decomposition and DoRA, LoHa, LoKr, GLoRA, IA3, full, norm) and pinned by tests/golden/lyco.npz, which make_golden produces by
+on the engine's path).  Every LyCORIS module type of the reference is restated (LoRA / LoCon incl. cp-decomposition and DoRA,
+LoHa, LoKr, GLoRA, IA3, full, norm, OFT / COFT / BOFT) and pinned by tests/golden/lyco.npz, which make_golden produces by
 loading the reference's network_*.py files."""
 from __future__ import annotations
 
@@ -133,10 +133,45 @@ def module_kind(w: dict) -> str:
     raise AssertionError(f"Could not find a module type that would accept those keys: {', '.join(w)}")
 
 
+def _oft_updown(w: dict, orig):
+    """network_oft.py:26-118 — orthogonal fine-tuning: the weight's output rows are rotated block-wise, updown = R W - W.
+    kohya / LyCORIS "oft_blocks" [k, n, n]: R = (I + Q)(I - Q)^-1 (Cayley) of the skew part Q = B - B^T, its norm clamped to
+    alpha * out_dim when alpha is given (COFT); old LyCORIS "oft_diag": the blocks are R already; BOFT (4-D blocks [m, k, n, n]):
+    m butterfly factors, factor i acting on rows regrouped with stride 2^i * n / 2; optional per-row "rescale"."""
+    out_dim = orig.shape[0]
+    is_r = "oft_blocks" not in w
+    blocks = w["oft_diag"] if is_r else w["oft_blocks"]
+    boft = blocks.dim() == 4
+    n = blocks.shape[1] if is_r else blocks.shape[2] if boft else out_dim // blocks.shape[0]
+    eye = torch.eye(n)
+    if not is_r:
+        q = blocks - blocks.transpose(-1, -2)
+        constraint = (0 if w.get("alpha") is None else w["alpha"]) * out_dim
+        if constraint != 0:
+            norm_q = torch.norm(q.flatten())
+            q = q * ((torch.clamp(norm_q, max=constraint) + 1e-8) / (norm_q + 1e-8))
+        blocks = torch.matmul(eye + q, (eye - q).float().inverse())
+    rest = orig.shape[1:]
+    if not boft:
+        k = out_dim // n
+        merged = torch.einsum('k n m, k n r -> k m r', blocks, orig.reshape(k, n, -1)).reshape(out_dim, *rest)
+    else:
+        merged = orig
+        for i in range(blocks.shape[0]):
+            stride = 2 ** i * (n // 2)
+            c = out_dim // (2 * stride)
+            x = merged.reshape(c, 2, stride, -1).transpose(1, 2).reshape(out_dim // n, n, -1)        # "(c g k) -> (c k g)", then blocks of n
+            x = torch.einsum("b i j, b j r -> b i r", blocks[i], x)
+            merged = x.reshape(c, stride, 2, -1).transpose(1, 2).reshape(out_dim, *rest)               # back to "(c g k)"
+    if w.get("rescale") is not None:
+        merged = w["rescale"].reshape(-1, *[1] * (orig.dim() - 1)) * merged
+    return merged - orig
+
+
 def calc_updown(w: dict, orig_weight, multiplier: float, dyn_dim=None, with_bias: bool = False):
-    """NetworkModule*.calc_updown + finalize_updown for every module type except OFT (network_lora.py:65-80, network_hada.py:28-55,
+    """NetworkModule*.calc_updown + finalize_updown for every module type (network_lora.py:65-80, network_hada.py:28-55,
     network_lokr.py:37-64, network_glora.py:21-33, network_ia3.py:18-30, network_full.py:17-27, network_norm.py:17-28,
-    network.py:175-216), pinned by tests/golden/lyco.npz.  ``orig_weight`` is the layer's current weight (a shape is accepted
+    network_oft.py:66-118, network.py:175-216), pinned by tests/golden/lyco.npz.  ``orig_weight`` is the layer's current weight (a shape is accepted
     where the type does not read it).  Returns updown, or (updown, ex_bias) with ``with_bias``."""
     if not torch.is_tensor(orig_weight):
         orig_weight = torch.zeros(tuple(orig_weight))
@@ -210,6 +245,9 @@ def calc_updown(w: dict, orig_weight, multiplier: float, dyn_dim=None, with_bias
         updown, output_shape, ex_bias = w["diff"], w["diff"].shape, w.get("diff_b")
     elif kind == "norm":
         updown, output_shape, ex_bias = w["w_norm"], w["w_norm"].shape, w.get("b_norm")
+    elif kind == "oft":
+        updown, output_shape = _oft_updown(w, orig), orig.shape
+        w = dict(w, scale=torch.tensor(1.0))                              # NetworkModuleOFT fixes self.scale = 1.0 (:23)
     else:
         raise NotImplementedError(kind)
 

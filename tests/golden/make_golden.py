@@ -835,6 +835,20 @@ def lyco_cases():
     return cases
 
 
+def lyco_oft_cases():
+    """OFT family (network_oft.py), kept apart from lyco_cases(): the oracle restates them, the engine host does not yet."""
+    lin, conv3 = ("linear", 24, 16), ("conv", 24, 16, 3)
+    t = lambda shape, seed, scale=0.2: seeded(shape, seed, scale)
+    return {
+        "oft_kohya": ("oft", lin, lambda k: {"oft_blocks": t((4, 6, 6), k)}),                                   # 4 blocks of 6: no constraint
+        "oft_kohya_constrained": ("oft", lin, lambda k: {"oft_blocks": t((4, 6, 6), k, 0.6), "alpha": torch.tensor(0.01)}),
+        "oft_conv": ("oft", conv3, lambda k: {"oft_blocks": t((3, 8, 8), k)}),
+        "oft_old_diag": ("oft", lin, lambda k: {"oft_diag": t((6, 4, 4), k) + torch.eye(4)}),                    # ready rotation blocks R
+        "boft": ("oft", lin, lambda k: {"oft_blocks": t((2, 6, 4, 4), k)}),                                     # 2 butterfly factors
+        "boft_rescale": ("oft", conv3, lambda k: {"oft_blocks": t((2, 6, 4, 4), k), "rescale": t((24, 1), k + 1, 0.1) + 1.0}),
+    }
+
+
 def lyco_orig_weight(spec, k):
     if spec[0] == "linear":
         return seeded((spec[1], spec[2]), 8000 + k, 0.2)
@@ -875,8 +889,10 @@ def gen_lyco():
                       ("ia3", "ModuleTypeIa3"), ("full", "ModuleTypeFull"), ("norm", "ModuleTypeNorm")):
         kinds[name] = getattr(load_by_path("network_" + name, lora_dir + "network_" + name + ".py"), cls)()
     network = sys.modules["network"]
+    kinds["oft"] = load_by_path("network_oft", lora_dir + "network_oft.py").ModuleTypeOFT()
     out = {}
-    for k, (name, (kind, spec, build)) in enumerate(lyco_cases().items()):
+    all_cases = list(lyco_cases().items()) + list(lyco_oft_cases().items())
+    for k, (name, (kind, spec, build)) in enumerate(all_cases):
         if spec[0] == "linear":
             sd_module = torch.nn.Linear(spec[2], spec[1])
         elif spec[0] == "conv":
@@ -894,7 +910,7 @@ def gen_lyco():
         module = kinds[kind].create_module(net, weights)
         assert module is not None, name
         for other, mt in kinds.items():          # the type dispatch order of networks.py:26-36 never mis-assigns these cases
-            if other != kind and other in ("hada", "lokr", "glora", "ia3", "full", "norm"):
+            if other != kind and other in ("hada", "lokr", "glora", "ia3", "full", "norm") and kind != "oft":
                 assert mt.create_module(net, network.NetworkWeights("a", "b", dict(w), sd_module)) is None or kind == "lora", (name, other)
         with torch.no_grad():
             updown, ex_bias = module.calc_updown(sd_module.weight)
