@@ -10,6 +10,7 @@ imported at all (lark / gradio / ldm at module level) the named functions are ex
   modules/rng.py (+ rng_philox.py)               -> image_rng.npz          (ImageRNG: variation seeds, seed-resize, ENSD)
   modules/sub_quadratic_attention.py             -> subquad_attention.npz
   modules/models/sd3/sd3_impls.py                -> vae_decoder.npz, vae_encoder.npz   (VAEDecoder / VAEEncoder, z_channels=4)
+  modules/models/sd3/sd3_impls.py (sample_euler) -> euler_twin.npz         (in-tree copy of k-diffusion's Euler sampler)
   modules/models/sd3/other_impls.py              -> clip_text.npz          (CLIP text transformer)
   modules/sd_samplers_timesteps_impl.py          -> ddim.npz, plms.npz     (ddim, ddim_cfgpp, plms)
   ... + modules/models/diffusion/uni_pc/uni_pc.py -> unipc.npz              (unipc() / UniPCCFG over the real solver)
@@ -1065,6 +1066,37 @@ def gen_unet_twins():
     print("unet_twins.npz")
 
 
+def gen_euler_twin():
+    """modules/models/sd3/sd3_impls.py:145-163 holds an in-tree copy of k-diffusion's to_d / sample_euler ("Algorithm 2 (Euler
+    steps) from Karras et al."): run it on an analytic denoiser over a Karras and a model-uniform schedule — the only in-tree
+    pin for the k-diffusion sampler family (the others are restated from the published code)."""
+    import warnings
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import kdiffusion as okd
+    stub = types.ModuleType("modules.models.sd3.mmdit")
+    stub.MMDiT = object
+    for name in ("modules", "modules.models", "modules.models.sd3"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["modules.models.sd3.mmdit"] = stub
+    m = load_by_path("ref_sd3_impls_euler", "modules/models/sd3/sd3_impls.py")
+    den = okd.CompVisDenoiser(None, okd.make_alphas_cumprod())
+    smin, smax = den.sigmas[0].item(), den.sigmas[-1].item()
+
+    def model(x, sigma, **kw):
+        s = sigma[:, None, None, None]
+        return x / (1 + s * s) + torch.tanh(0.5 * x) * (s * s / (1 + s * s)) * 0.3
+
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ci, sigmas in enumerate((okd.get_sigmas_karras(10, smin, smax), den.get_sigmas(7))):
+            x0 = seeded((2, 4, 8, 8), 9700 + ci) * sigmas[0]
+            out[f"c{ci}_sigmas"] = sigmas.numpy()
+            out[f"c{ci}_out"] = m.sample_euler(model, x0.clone(), sigmas).numpy()
+    np.savez_compressed(os.path.join(OUT, "euler_twin.npz"), **out)
+    print("euler_twin.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -1085,3 +1117,4 @@ if __name__ == "__main__":
     gen_prompt_cond()
     gen_image_rng()
     gen_unet_twins()
+    gen_euler_twin()

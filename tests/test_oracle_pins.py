@@ -385,6 +385,21 @@ def test_unet_pieces_match_in_tree_twins(golden_dir):
         np.testing.assert_allclose(st_lin(img, context=ctx).numpy(), z["st_lin"], rtol=0, atol=1e-6)
 
 
+def test_euler_sampler_matches_in_tree_twin(golden_dir):
+    """oracle sample_euler / to_d == the copy of k-diffusion's Euler sampler the reference carries in-tree
+    (modules/models/sd3/sd3_impls.py:145-163), on a Karras and a model-uniform schedule — same bits."""
+    z = np.load(os.path.join(golden_dir, "euler_twin.npz"))
+
+    def model(x, sigma, **kw):
+        s = sigma[:, None, None, None]
+        return x / (1 + s * s) + torch.tanh(0.5 * x) * (s * s / (1 + s * s)) * 0.3
+
+    for ci in range(2):
+        sigmas = torch.from_numpy(z[f"c{ci}_sigmas"])
+        out = kd.sample_euler(model, seeded((2, 4, 8, 8), 9700 + ci) * sigmas[0], sigmas, {})
+        assert np.array_equal(out.numpy(), z[f"c{ci}_out"]), ci
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
