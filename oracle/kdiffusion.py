@@ -30,6 +30,18 @@ def make_alphas_cumprod(linear_start=0.00085, linear_end=0.0120, n=1000) -> torc
     return torch.tensor(np.cumprod(alphas, axis=0), dtype=torch.float32)
 
 
+def rescale_zero_terminal_snr_abar(alphas_cumprod):
+    """modules/sd_models.py:628-644 (pinned by tests/golden/zsnr.npz): shift sqrt(alpha_bar) to end at zero, rescale to keep its
+    first value, square, and set the last entry to the reference's constant."""
+    s = alphas_cumprod.sqrt()
+    s0, sT = s[0].clone(), s[-1].clone()
+    s = s - sT
+    s = s * (s0 / (s0 - sT))
+    out = s ** 2
+    out[-1] = 4.8973451890853435e-08
+    return out
+
+
 def append_zero(x):
     return torch.cat([x, x.new_zeros([1])])
 

@@ -14,7 +14,7 @@ from typing import Any, List, Optional
 import numpy as np
 import torch
 
-from . import ops, prompt_parser, sd_samplers, shared
+from . import ops, prompt_parser, sd_models, sd_samplers, shared
 from .rng import ImageRNG
 
 opt_C = 4
@@ -355,6 +355,7 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
     p.all_seeds = [seed + i for i in range(n_total)]                 # :901-909
     subseed = int(p.subseed) if p.subseed is not None and p.subseed != -1 else 2000
     p.all_subseeds = list(p.subseed) if isinstance(p.subseed, (list, tuple)) else [subseed + i for i in range(n_total)]
+    sd_models.apply_alpha_schedule_override(p.sd_model, p)           # :930
     p.init(None, p.all_seeds, None)
     images, latents = [], []
     dev = p.sd_model.device

@@ -60,6 +60,7 @@ class SdModel:
         self.device = torch.device("cuda", device)
         ac = state_dict.get("alphas_cumprod")
         self.alphas_cumprod = (ac.float().cpu() if ac is not None else schema.make_alphas_cumprod())
+        self.alphas_cumprod_original = self.alphas_cumprod.clone()       # modules/sd_models.py:441 (what the schedule overrides start from)
         self.engine = Engine(device)
         self.engine.load_unet(self.unet_cfg, state_dict)
         self._checkpoint = state_dict                     # kept by reference: the "weights backup" LoRA rewrites start from
@@ -94,6 +95,36 @@ class SdModel:
         std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
         eps = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
         return ((mean + std * eps) * self.scale_factor).contiguous()
+
+
+def rescale_zero_terminal_snr_abar(alphas_cumprod: torch.Tensor) -> torch.Tensor:
+    """modules/sd_models.py:628-644 ("Zero Terminal SNR", arXiv 2305.08891): sqrt(alpha_bar) is shifted so that the last timestep
+    carries no signal and rescaled so that the first keeps its value; the last entry is then pinned to 4.8973451890853435e-08
+    (not exactly zero: sigma stays finite)."""
+    root = alphas_cumprod.sqrt()
+    first, last = root[0].clone(), root[-1].clone()
+    root = (root - last) * (first / (first - last))
+    out = root ** 2
+    out[-1] = 4.8973451890853435e-08
+    return out
+
+
+def apply_alpha_schedule_override(sd_model, p=None):
+    """modules/sd_models.py:647-668, called once per job (modules/processing.py:930): start from the checkpoint's schedule,
+    optionally round it through fp16 (opts.use_downcasted_alpha_bar), optionally rescale it to zero terminal SNR
+    (opts.sd_noise_schedule).  The samplers read sd_model.alphas_cumprod when their denoiser wrapper is built."""
+    if not hasattr(sd_model, 'alphas_cumprod') or not hasattr(sd_model, 'alphas_cumprod_original'):
+        return
+    opts = shared.opts
+    sd_model.alphas_cumprod = sd_model.alphas_cumprod_original.clone()
+    if opts.use_downcasted_alpha_bar:
+        if p is not None:
+            p.extra_generation_params['Downcast alphas_cumprod'] = opts.use_downcasted_alpha_bar
+        sd_model.alphas_cumprod = sd_model.alphas_cumprod.half()
+    if opts.sd_noise_schedule == "Zero Terminal SNR":
+        if p is not None:
+            p.extra_generation_params['Noise Schedule'] = opts.sd_noise_schedule
+        sd_model.alphas_cumprod = rescale_zero_terminal_snr_abar(sd_model.alphas_cumprod)
 
 
 def load_model(checkpoint_file: Optional[str] = None, state_dict: Optional[dict] = None, device: int = 0, **kw) -> SdModel:

@@ -42,6 +42,8 @@ class Options:
     initial_noise_multiplier: float = 1.0          # :217
     img2img_fix_steps: bool = False
     enable_quantization: bool = False              # :176
+    use_downcasted_alpha_bar: bool = False         # :255
+    sd_noise_schedule: str = "Default"             # :406 ("Default" | "Zero Terminal SNR")
     live_previews_enable: bool = False             # :374 (fused path requires previews off)
     CLIP_stop_at_last_layers: int = 1              # :170 ("Clip skip")
     sdxl_clip_l_skip: bool = False                 # :222

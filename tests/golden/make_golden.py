@@ -18,6 +18,7 @@ imported at all (lark / gradio / ldm at module level) the named functions are ex
   modules/sd_samplers_lcm.py                     -> lcm.npz
   modules/sd_schedulers.py                       -> schedulers.npz
   modules/sd_samplers_cfg_denoiser.py            -> cfg_denoiser.npz       (CFGDenoiser.forward, 20 scenarios)
+  modules/sd_models.py           [text]          -> zsnr.npz               (rescale_zero_terminal_snr_abar)
   modules/sd_samplers_common.py  [text]          -> refiner.npz            (apply_refiner), + images_tensor_to_samples below
   modules/processing.py          [text]          -> image_conditioning.npz (txt2img / inpainting / edit image conditioning)
   modules/images.py, upscaler.py [text]          -> resize_image.npz       (resize_image mode 0, Upscaler loop, PIL scalers)
@@ -1097,6 +1098,21 @@ def gen_euler_twin():
     print("euler_twin.npz")
 
 
+def gen_zsnr():
+    """Exec rescale_zero_terminal_snr_abar from modules/sd_models.py (:628-644) on the SD schedule, in fp32 and after the fp16
+    round trip of opts.use_downcasted_alpha_bar (:659-662)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import kdiffusion as okd
+    src = open(os.path.join(REF, "modules/sd_models.py")).read()
+    ns = {"torch": torch}
+    exec(src[src.index("def rescale_zero_terminal_snr_abar("):src.index("def apply_alpha_schedule_override(")], ns)
+    ac = okd.make_alphas_cumprod()
+    out = {"fp32": ns["rescale_zero_terminal_snr_abar"](ac.clone()).numpy(),
+           "downcast": ns["rescale_zero_terminal_snr_abar"](ac.clone().half()).float().numpy()}
+    np.savez_compressed(os.path.join(OUT, "zsnr.npz"), **out)
+    print("zsnr.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -1118,3 +1134,4 @@ if __name__ == "__main__":
     gen_image_rng()
     gen_unet_twins()
     gen_euler_twin()
+    gen_zsnr()

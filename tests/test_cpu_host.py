@@ -297,6 +297,34 @@ def test_host_prompt_parser_containers_match_reference(golden_dir):
     assert [e.end_at_step for e in sch[0]] == [5, 20] and float(sch[0][1].cond[0, 0]) == 4.0
 
 
+def test_host_alpha_schedule_override_matches_reference(golden_dir):
+    """sd_models.apply_alpha_schedule_override (modules/sd_models.py:647-668): "Zero Terminal SNR" and the fp16 downcast start
+    from alphas_cumprod_original every time, reproduce the reference-generated schedule, and change what the samplers see
+    (sigma_max of the wrapped model)."""
+    sdm, shared, ss = sub("sd_models"), sub("shared"), sub("sd_samplers")
+    z = np.load(os.path.join(golden_dir, "zsnr.npz"))
+    ac = sub("schema").make_alphas_cumprod()
+    M = type("M", (), {})
+    m = M()
+    m.alphas_cumprod, m.alphas_cumprod_original, m.engine = ac.clone(), ac.clone(), None
+    keep = (shared.opts.sd_noise_schedule, shared.opts.use_downcasted_alpha_bar)
+    try:
+        p = type("P", (), {"extra_generation_params": {}})()
+        shared.opts.sd_noise_schedule = "Zero Terminal SNR"
+        sdm.apply_alpha_schedule_override(m, p)
+        np.testing.assert_allclose(m.alphas_cumprod.numpy(), z["fp32"], rtol=1e-6, atol=0)
+        assert p.extra_generation_params == {"Noise Schedule": "Zero Terminal SNR"}
+        assert float(ss.CompVisDenoiser(m).sigmas[-1]) > 4000          # sqrt((1 - a) / a) at a = 4.9e-8
+        shared.opts.use_downcasted_alpha_bar = True
+        sdm.apply_alpha_schedule_override(m)
+        np.testing.assert_allclose(m.alphas_cumprod.float().numpy(), z["downcast"], rtol=2e-3, atol=1e-7)
+        shared.opts.sd_noise_schedule, shared.opts.use_downcasted_alpha_bar = "Default", False
+        sdm.apply_alpha_schedule_override(m)
+        assert torch.equal(m.alphas_cumprod, ac) and abs(float(ss.CompVisDenoiser(m).sigmas[-1]) - 14.6146) < 1e-3
+    finally:
+        shared.opts.sd_noise_schedule, shared.opts.use_downcasted_alpha_bar = keep
+
+
 def test_host_lora_names_and_grouping_match_reference(golden_dir):
     """networks.convert_diffusers_name_to_compvis against the reference-generated fixture, and load_network's grouping /
     layer lookup (extensions-builtin/Lora/networks.py:183-240) on the tiny UNet's layer map."""

@@ -400,6 +400,16 @@ def test_euler_sampler_matches_in_tree_twin(golden_dir):
         assert np.array_equal(out.numpy(), z[f"c{ci}_out"]), ci
 
 
+def test_zero_terminal_snr_schedule_matches_reference(golden_dir):
+    """oracle rescale_zero_terminal_snr_abar == modules/sd_models.py:628-644 exec'd by make_golden (fp32 and fp16-downcast input);
+    the rescaled schedule ends at the reference's constant and keeps its first entry."""
+    z = np.load(os.path.join(golden_dir, "zsnr.npz"))
+    ac = kd.make_alphas_cumprod()
+    np.testing.assert_array_equal(kd.rescale_zero_terminal_snr_abar(ac.clone()).numpy(), z["fp32"])
+    np.testing.assert_array_equal(kd.rescale_zero_terminal_snr_abar(ac.clone().half()).float().numpy(), z["downcast"])
+    assert z["fp32"][-1] == np.float32(4.8973451890853435e-08) and abs(z["fp32"][0] - float(ac[0])) < 1e-7
+
+
 def test_schedulers_match_reference_functions(golden_dir):
     """oracle/schedulers.py == the functions of modules/sd_schedulers.py executed by tests/golden/make_golden.py (sgm_uniform,
     kl_optimal, align_your_steps incl. the SDXL table, simple, normal, ddim, beta, uniform), same table of names / labels /
