@@ -351,8 +351,9 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
     """modules/processing.py:819-1150 (process_images -> process_images_inner) for the engine path."""
     assert p.c is not None and p.uc is not None, "conditioning tensors p.c / p.uc are required (text encoder is out of scope)"
     n_total = p.batch_size * p.n_iter
-    seed = int(p.seed) if p.seed is not None and p.seed != -1 else 1000
-    p.all_seeds = [seed + i for i in range(n_total)]                 # :901-909
+    seed = 1000 if p.seed is None or isinstance(p.seed, (list, tuple)) or p.seed == -1 else int(p.seed)
+    # :901-909 — with a variation seed every image keeps the SAME seed and the subseeds count up instead
+    p.all_seeds = list(p.seed) if isinstance(p.seed, (list, tuple)) else [seed + (i if p.subseed_strength == 0 else 0) for i in range(n_total)]
     subseed = int(p.subseed) if p.subseed is not None and p.subseed != -1 else 2000
     p.all_subseeds = list(p.subseed) if isinstance(p.subseed, (list, tuple)) else [subseed + i for i in range(n_total)]
     sd_models.apply_alpha_schedule_override(p.sd_model, p)           # :930
