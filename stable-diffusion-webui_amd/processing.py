@@ -354,7 +354,7 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
     seed = 1000 if p.seed is None or isinstance(p.seed, (list, tuple)) or p.seed == -1 else int(p.seed)
     # :901-909 — with a variation seed every image keeps the SAME seed and the subseeds count up instead
     p.all_seeds = list(p.seed) if isinstance(p.seed, (list, tuple)) else [seed + (i if p.subseed_strength == 0 else 0) for i in range(n_total)]
-    subseed = int(p.subseed) if p.subseed is not None and p.subseed != -1 else 2000
+    subseed = 2000 if p.subseed is None or isinstance(p.subseed, (list, tuple)) or p.subseed == -1 else int(p.subseed)
     p.all_subseeds = list(p.subseed) if isinstance(p.subseed, (list, tuple)) else [subseed + i for i in range(n_total)]
     sd_models.apply_alpha_schedule_override(p.sd_model, p)           # :930
     p.init(None, p.all_seeds, None)
