@@ -1222,8 +1222,9 @@ class KDiffusionSampler(Sampler):
         xi = torch.empty_like(x)
         check(lib.sdmi_axpby(ptr(xi), ptr(x.contiguous()), 1.0, ptr(noise.contiguous()), float(sigma_sched[0]), x.numel(),
                              stream_ptr()), "x + noise*sigma")
-        if shared.opts.img2img_extra_noise > 0:
-            raise NotImplementedError("img2img_extra_noise")
+        if shared.opts.img2img_extra_noise > 0:               # :146-151 (the extra_noise script callback is not called)
+            p.extra_generation_params["Extra noise"] = shared.opts.img2img_extra_noise
+            xi = _lc(xi, [xi, noise], [1.0, float(shared.opts.img2img_extra_noise)])
         extra_params_kwargs = self.initialize(p)
         parameters = inspect.signature(self.func).parameters
         if 'sigmas' in parameters:
@@ -1338,6 +1339,9 @@ class CompVisSampler(Sampler):
         xi = torch.empty_like(x)
         check(lib.sdmi_axpby(ptr(xi), ptr(x.contiguous()), float(sqrt_alpha_cumprod), ptr(noise.contiguous()),
                              float(sqrt_one_minus_alpha_cumprod), x.numel(), stream_ptr()), "ddim img2img noise")
+        if shared.opts.img2img_extra_noise > 0:               # sd_samplers_timesteps.py:109-114
+            p.extra_generation_params["Extra noise"] = shared.opts.img2img_extra_noise
+            xi = _lc(xi, [xi, noise], [1.0, float(shared.opts.img2img_extra_noise) * float(sqrt_alpha_cumprod)])
         extra_params_kwargs = self.initialize(p)
         extra_params_kwargs['timesteps'] = timesteps_sched
         if 'is_img2img' in inspect.signature(self.func).parameters:       # sd_samplers_timesteps.py:122-123 (UniPC start time)
