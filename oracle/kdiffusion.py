@@ -17,6 +17,8 @@ Karras rho=7 n=50 endpoints (hints at modules/shared_opt
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 
@@ -377,6 +379,95 @@ def sample_euler_ancestral(model, x, sigmas, extra_args, noise_fn, eta=1.0, s_no
         if sigmas[i + 1] > 0:
             x = x + noise_fn() * s_noise * sigma_up
     return x
+
+
+class DPMSolver:
+    """k-diffusion sampling.DPMSolver (third-party, crowsonkb/k-diffusion @ ab527a9 — restated from the published code, not
+    pinned; call site modules/sd_samplers_kdiffusion.py:24): DPM-Solver-1/2/3 steps in t = -log(sigma) on the eps prediction
+    eps = (x - denoised) / sigma, with a per-step cache so the first evaluation is shared by the orders."""
+
+    def __init__(self, model, extra_args=None, info_callback=None):
+        self.model, self.extra_args, self.info_callback = model, ({} if extra_args is None else extra_args), info_callback
+
+    @staticmethod
+    def t(sigma):
+        return -sigma.log()
+
+    @staticmethod
+    def sigma(t):
+        return t.neg().exp()
+
+    def eps(self, eps_cache, key, x, t):
+        if key in eps_cache:
+            return eps_cache[key], eps_cache
+        sigma = self.sigma(t) * x.new_ones([x.shape[0]])
+        eps = (x - self.model(x, sigma, **self.extra_args)) / self.sigma(t)
+        return eps, {key: eps, **eps_cache}
+
+    def dpm_solver_1_step(self, x, t, t_next, eps_cache=None):
+        eps_cache = {} if eps_cache is None else eps_cache
+        h = t_next - t
+        eps, eps_cache = self.eps(eps_cache, 'eps', x, t)
+        return x - self.sigma(t_next) * h.expm1() * eps, eps_cache
+
+    def dpm_solver_2_step(self, x, t, t_next, r1=1 / 2, eps_cache=None):
+        eps_cache = {} if eps_cache is None else eps_cache
+        h = t_next - t
+        eps, eps_cache = self.eps(eps_cache, 'eps', x, t)
+        s1 = t + r1 * h
+        u1 = x - self.sigma(s1) * (r1 * h).expm1() * eps
+        eps_r1, eps_cache = self.eps(eps_cache, 'eps_r1', u1, s1)
+        x_2 = x - self.sigma(t_next) * h.expm1() * eps - self.sigma(t_next) / (2 * r1) * h.expm1() * (eps_r1 - eps)
+        return x_2, eps_cache
+
+    def dpm_solver_3_step(self, x, t, t_next, r1=1 / 3, r2=2 / 3, eps_cache=None):
+        eps_cache = {} if eps_cache is None else eps_cache
+        h = t_next - t
+        eps, eps_cache = self.eps(eps_cache, 'eps', x, t)
+        s1, s2 = t + r1 * h, t + r2 * h
+        u1 = x - self.sigma(s1) * (r1 * h).expm1() * eps
+        eps_r1, eps_cache = self.eps(eps_cache, 'eps_r1', u1, s1)
+        u2 = x - self.sigma(s2) * (r2 * h).expm1() * eps - self.sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1) * (eps_r1 - eps)
+        eps_r2, eps_cache = self.eps(eps_cache, 'eps_r2', u2, s2)
+        x_3 = x - self.sigma(t_next) * h.expm1() * eps - self.sigma(t_next) / r2 * (h.expm1() / h - 1) * (eps_r2 - eps)
+        return x_3, eps_cache
+
+    def dpm_solver_fast(self, x, t_start, t_end, nfe, noise_fn, eta=0., s_noise=1.):
+        m = math.floor(nfe / 3) + 1
+        ts = torch.linspace(t_start, t_end, m + 1)
+        orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
+        for i in range(len(orders)):
+            eps_cache = {}
+            t, t_next = ts[i], ts[i + 1]
+            if eta:
+                sd, su = get_ancestral_step(self.sigma(t), self.sigma(t_next), eta)
+                t_next_ = torch.minimum(t_end, self.t(sd))
+                su = (self.sigma(t_next) ** 2 - self.sigma(t_next_) ** 2) ** 0.5
+            else:
+                t_next_, su = t_next, 0.
+            eps, eps_cache = self.eps(eps_cache, 'eps', x, t)
+            denoised = x - self.sigma(t) * eps
+            if self.info_callback is not None:
+                self.info_callback({'x': x, 'i': i, 't': ts[i], 't_up': t, 'denoised': denoised})
+            if orders[i] == 1:
+                x, eps_cache = self.dpm_solver_1_step(x, t, t_next_, eps_cache=eps_cache)
+            elif orders[i] == 2:
+                x, eps_cache = self.dpm_solver_2_step(x, t, t_next_, eps_cache=eps_cache)
+            else:
+                x, eps_cache = self.dpm_solver_3_step(x, t, t_next_, eps_cache=eps_cache)
+            x = x + su * s_noise * noise_fn()
+        return x
+
+
+def sample_dpm_fast(model, x, sigma_min, sigma_max, n, extra_args, noise_fn, eta=0., s_noise=1., callback=None):
+    """k-diffusion sample_dpm_fast: DPM-Solver-Fast with a fixed budget of n model evaluations between sigma_max and sigma_min
+    (modules/sd_samplers_kdiffusion.py:203-210 passes the wrapped model's sigma range and n = steps)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    solver = DPMSolver(model, extra_args)
+    if callback is not None:
+        solver.info_callback = lambda info: callback({'sigma': solver.sigma(info['t']), 'sigma_hat': solver.sigma(info['t_up']), **info})
+    return solver.dpm_solver_fast(x, solver.t(torch.tensor(sigma_max)), solver.t(torch.tensor(sigma_min)), n, noise_fn, eta, s_noise)
 
 
 def sample_lcm(model, x, sigmas, extra_args, noise_fn, callback=None):

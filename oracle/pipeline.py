@@ -32,7 +32,7 @@ class OracleModel:
 SAMPLER_OPTIONS = {
     "euler_a": (None, False), "euler": (None, False), "lms": (None, False), "heun": (None, False),
     "dpmpp_2m": ("karras", False), "dpmpp_2s_a": ("karras", False), "dpm_2": ("karras", True), "dpm_2_a": ("karras", True),
-    "restart": ("karras", False), "lcm": (None, False),
+    "restart": ("karras", False), "lcm": (None, False), "dpm_fast": (None, False),
 }
 
 
@@ -149,6 +149,13 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
         return finish(kd.sample_dpm_2_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
     if sampler == "dpmpp_2s_a":
         return finish(kd.sample_dpmpp_2s_ancestral(cfg, x, sigmas, extra, rng.next, **anc))
+    if sampler == "dpm_fast":        # sigma range / budget as modules/sd_samplers_kdiffusion.py:155-161 (img2img) and :203-208 (txt2img)
+        if init_latent is None:
+            smin, smax, n = wrap.sigmas[0].item(), wrap.sigmas[-1].item(), steps
+        else:
+            smin, smax, n = sigmas[-2], sigmas[0], len(sigmas) - 1
+        return finish(kd.sample_dpm_fast(cfg, x, smin, smax, n, extra, rng.next, eta=1.0 if eta is None else eta, s_noise=s_noise,
+                                         callback=record))
     if sampler == "lcm":
         return finish(kd.sample_lcm(cfg, x, sigmas, extra, rng.next, callback=record))
     if sampler == "restart":

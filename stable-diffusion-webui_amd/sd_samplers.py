@@ -906,6 +906,68 @@ def ddim(model, x, timesteps, extra_args=None, callback=None, disable=None, eta=
     return x
 
 
+# ---- DPM fast (k-diffusion sample_dpm_fast / DPMSolver.dpm_solver_fast; table row modules/sd_samplers_kdiffusion.py:24) ----
+def sample_dpm_fast(model, x, sigma_min, sigma_max, n, extra_args=None, callback=None, disable=None, eta=0., s_noise=1.,
+                    noise_sampler=None):
+    """DPM-Solver-Fast: n model evaluations between sigma_max and sigma_min, in t = -log(sigma), as steps of order 3 (3
+    evaluations each) closed by orders 2 + 1 or by the remainder; with eta the step lands on the ancestral sigma_down and
+    fresh noise is added.  Step sizes and coefficients are host fp32 scalars, every tensor update one sdmi_lincomb over
+    (x, eps, eps_r1, eps_r2) with eps = (x - denoised) / sigma."""
+    import math
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    extra_args = {} if extra_args is None else extra_args
+    s_in = x.new_ones([x.shape[0]])
+    f32 = lambda v: torch.as_tensor(v, dtype=torch.float32)
+    sig = lambda t: t.neg().exp()
+    t_start, t_end = -f32(sigma_max).log(), -f32(sigma_min).log()
+    m = math.floor(n / 3) + 1
+    ts = torch.linspace(t_start, t_end, m + 1)
+    orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]
+    new = lambda: torch.empty_like(x)
+
+    def eps_at(xx, t):
+        den = model(xx, float(sig(t)) * s_in, **extra_args)
+        return _lc(new(), [xx, den], [1.0 / float(sig(t)), -1.0 / float(sig(t))]), den
+
+    for i, order in enumerate(orders):
+        t, t_next = ts[i], ts[i + 1]
+        if eta:
+            sd, _ = get_ancestral_step(sig(t), sig(t_next), eta)
+            t_next_ = torch.minimum(t_end, -sd.log())
+            su = (sig(t_next) ** 2 - sig(t_next_) ** 2) ** 0.5
+        else:
+            t_next_, su = t_next, 0.
+        eps, denoised = eps_at(x, t)
+        if callback is not None:
+            callback({'sigma': sig(ts[i]), 'sigma_hat': sig(t), 'x': x, 'i': i, 't': ts[i], 't_up': t, 'denoised': denoised})
+        h = t_next_ - t
+        a = float(sig(t_next_) * h.expm1())
+        if order == 1:
+            x = _lc(new(), [x, eps], [1.0, -a])
+        elif order == 2:
+            r1 = 1 / 2
+            s1 = t + r1 * h
+            u1 = _lc(new(), [x, eps], [1.0, -float(sig(s1) * (r1 * h).expm1())])
+            eps_r1, _ = eps_at(u1, s1)
+            b = float(sig(t_next_) / (2 * r1) * h.expm1())
+            x = _lc(new(), [x, eps, eps_r1], [1.0, -a + b, -b])
+        else:
+            r1, r2 = 1 / 3, 2 / 3
+            s1, s2 = t + r1 * h, t + r2 * h
+            u1 = _lc(new(), [x, eps], [1.0, -float(sig(s1) * (r1 * h).expm1())])
+            eps_r1, _ = eps_at(u1, s1)
+            c1 = float(sig(s2) * (r2 * h).expm1())
+            c2 = float(sig(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1))
+            u2 = _lc(new(), [x, eps, eps_r1], [1.0, -c1 + c2, -c2])
+            eps_r2, _ = eps_at(u2, s2)
+            b = float(sig(t_next_) / r2 * (h.expm1() / h - 1))
+            x = _lc(new(), [x, eps, eps_r2], [1.0, -a + b, -b])
+        if float(su) != 0.0:
+            x = _lc(new(), [x, noise_sampler(sig(t), sig(t_next))], [1.0, float(su) * s_noise])
+    return x
+
+
 # ---- UniPC (modules/models/diffusion/uni_pc/uni_pc.py, driven by unipc() at modules/sd_samplers_timesteps_impl.py:170-179) ----
 class _DiscreteVP:
     """NoiseScheduleVP('discrete') of uni_pc.py:96-175, on host fp32 scalars (the reference evaluates the same handful of
@@ -1138,8 +1200,8 @@ class Sampler:
         raise NotImplementedError()
 
 
-# the rows of modules/sd_samplers_kdiffusion.py:11-27 the engine implements (same labels, aliases and options); the SDE /
-# DPM fast / adaptive rows need BrownianTree noise or adaptive step control and are not implemented yet
+# the rows of modules/sd_samplers_kdiffusion.py:11-27 the engine implements (same labels, aliases and options); the SDE rows
+# need torchsde's BrownianTree noise and DPM adaptive an error-norm reduction per trial step: not implemented yet
 samplers_k_diffusion = [
     ('DPM++ 2M', sample_dpmpp_2m, ['k_dpmpp_2m'], {'scheduler': 'karras'}),
     ('DPM++ 2S a', sample_dpmpp_2s_ancestral, ['k_dpmpp_2s_a'], {'scheduler': 'karras', "uses_ensd": True, "second_order": True}),
@@ -1150,6 +1212,7 @@ samplers_k_diffusion = [
     ('DPM2', sample_dpm_2, ['k_dpm_2'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "second_order": True}),
     ('DPM2 a', sample_dpm_2_ancestral, ['k_dpm_2_a'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "uses_ensd": True, "second_order": True}),
     ('Restart', restart_sampler, ['restart'], {'scheduler': 'karras', "second_order": True}),
+    ('DPM fast', sample_dpm_fast, ['k_dpm_fast'], {"uses_ensd": True}),
 ]
 sampler_extra_params = {                                 # modules/sd_samplers_kdiffusion.py:36-46
     'sample_euler': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
@@ -1157,6 +1220,7 @@ sampler_extra_params = {                                 # modules/sd_samplers_k
     'sample_dpm_2': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
     'sample_dpm_2_ancestral': ['s_noise'],
     'sample_dpmpp_2s_ancestral': ['s_noise'],
+    'sample_dpm_fast': ['s_noise'],
 }
 
 class KDiffusionSampler(Sampler):
@@ -1227,6 +1291,12 @@ class KDiffusionSampler(Sampler):
             xi = _lc(xi, [xi, noise], [1.0, float(shared.opts.img2img_extra_noise)])
         extra_params_kwargs = self.initialize(p)
         parameters = inspect.signature(self.func).parameters
+        if 'sigma_min' in parameters:                         # :155-161 (the last sigma is zero, which DPM fast does not allow)
+            extra_params_kwargs['sigma_min'] = float(sigma_sched[-2])
+        if 'sigma_max' in parameters:
+            extra_params_kwargs['sigma_max'] = float(sigma_sched[0])
+        if 'n' in parameters:
+            extra_params_kwargs['n'] = len(sigma_sched) - 1
         if 'sigmas' in parameters:
             extra_params_kwargs['sigmas'] = sigma_sched
         self.model_wrap_cfg.init_latent = x
@@ -1246,6 +1316,11 @@ class KDiffusionSampler(Sampler):
         check(lib.sdmi_axpby(ptr(x0), ptr(x.contiguous()), mult, None, 0.0, x.numel(), stream_ptr()), "x * sigmas[0]")
         extra_params_kwargs = self.initialize(p)
         parameters = inspect.signature(self.func).parameters
+        if 'n' in parameters:                                 # :203-208
+            extra_params_kwargs['n'] = steps
+        if 'sigma_min' in parameters:
+            extra_params_kwargs['sigma_min'] = self.model_wrap.sigmas[0].item()
+            extra_params_kwargs['sigma_max'] = self.model_wrap.sigmas[-1].item()
         if 'sigmas' in parameters:
             extra_params_kwargs['sigmas'] = sigmas
         self.last_latent = x0

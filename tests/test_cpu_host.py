@@ -325,6 +325,33 @@ def test_host_alpha_schedule_override_matches_reference(golden_dir):
         shared.opts.sd_noise_schedule, shared.opts.use_downcasted_alpha_bar = keep
 
 
+def test_host_dpm_fast_matches_oracle_restatement(monkeypatch):
+    """sd_samplers.sample_dpm_fast (folded lincomb coefficients, host fp32 step sizes) against the oracle's op-by-op DPMSolver
+    restatement on an analytic denoiser — orders 3 / 2 / 1 and 3 / 3 / remainder, with and without the ancestral noise.  The
+    device launch is replaced by the same sum in torch for this test only."""
+    ss = sub("sd_samplers")
+    monkeypatch.setattr(ss, "_lc", lambda out, terms, coefs: out.copy_(sum(float(c) * t for c, t in zip(coefs, terms))))
+    from tests.test_oracle_pins import seeded
+    den = okd.CompVisDenoiser(None, okd.make_alphas_cumprod())
+    smin, smax = den.sigmas[0].item(), den.sigmas[-1].item()
+
+    def model(x, sigma, **kw):
+        s = sigma[:, None, None, None]
+        return x / (1 + s * s) + torch.tanh(0.5 * x) * (s * s / (1 + s * s)) * 0.3
+
+    for n, eta in ((6, 0.0), (6, 1.0), (8, 1.0), (10, 0.6), (3, 1.0)):
+        x0 = seeded((2, 4, 8, 8), 9800 + n) * smax
+        d1 = iter([seeded((2, 4, 8, 8), 9850 + i) for i in range(12)])
+        d2 = iter([seeded((2, 4, 8, 8), 9850 + i) for i in range(12)])
+        seen = []
+        want = okd.sample_dpm_fast(model, x0.clone(), smin, smax, n, {}, lambda: next(d1), eta=eta, s_noise=0.9)
+        got = ss.sample_dpm_fast(model, x0.clone(), smin, smax, n, extra_args={}, callback=lambda d: seen.append(float(d["sigma"])),
+                                 eta=eta, s_noise=0.9, noise_sampler=lambda *a: next(d2))
+        assert float((got - want).norm() / want.norm()) < 2e-5, (n, eta)
+        assert len(seen) == n // 3 + 1                        # floor(n / 3) + 1 solver steps, one callback each
+    assert ss.find_sampler_config("k_dpm_fast").name == "DPM fast" and ss.sampler_extra_params["sample_dpm_fast"] == ["s_noise"]
+
+
 def test_host_lora_names_and_grouping_match_reference(golden_dir):
     """networks.convert_diffusers_name_to_compvis against the reference-generated fixture, and load_network's grouping /
     layer lookup (extensions-builtin/Lora/networks.py:183-240) on the tiny UNet's layer map."""

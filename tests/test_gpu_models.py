@@ -131,7 +131,7 @@ def test_vae_decoder_against_reference_class_fixture(dev, golden_dir):
                                                 ("euler", "Euler", 4), ("heun", "Heun", 4), ("dpm_2", "DPM2", 4),
                                                 ("dpm_2_a", "DPM2 a", 4), ("lms", "LMS", 6), ("dpmpp_2s_a", "DPM++ 2S a", 4),
                                                 ("plms", "PLMS", 5), ("ddim_cfgpp", "DDIM CFG++", 5), ("restart", "Restart", 22),
-                                                ("unipc", "UniPC", 6), ("lcm", "LCM", 4)])
+                                                ("unipc", "UniPC", 6), ("lcm", "LCM", 4), ("dpm_fast", "DPM fast", 6)])
 def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     from oracle import pipeline as opipe
     processing = sub("processing")
