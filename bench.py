@@ -1,26 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py — images/sec of the txt2img hot path on MI355X (BASELINE.json metric).
+"""bench.py — images/sec of the txt2img / img2img hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4a|c4b]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one pass of the hot path over one batch of synthetic input = one full txt2img job of the workload
-(SD1.5, 512x512, 20-step Euler-a, batch 8 per GPU, cfg 7): Philox noise -> 20 x (CFG batch build, UNet on 16 latents,
-CFG combine, Euler-ancestral update) -> batched VAE decode -> uint8 HWC, everything resident in HBM (synthetic fp16
-weights in the SD1.5 state-dict schema, seeded N(0,1) conditioning; the text encoder is outside the path).
-Weak scaling: every rank runs the same per-GPU batch on its own images (seeds 1000 + global index), no per-step
-communication; weights are generated on rank 0 and broadcast over RCCL before the timed region.
+Launched WITHOUT a torchrun environment and with --gpus N > 1, bench.py spawns the N ranks itself (one process per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and `n_gpus` in the line is the world size RCCL
+reports — never the flag.
+
+A "step" = one pass of the hot path over one batch of synthetic input = one whole job of the workload; with N ranks the job is the
+global batch (batch per GPU x N images) sharded by `parallel.process_images_sharded` (contiguous split of the image index range,
+global seeds 1000 + index, no per-step communication, one RCCL gather of the uint8 images to rank 0 per job).  Workloads
+(BASELINE.json `configs`):
+    c1   SD1.5 txt2img 512x512, 20-step Euler a, batch 8 per GPU                      <- the metric (default)
+    c2   SD1.5 txt2img 512x512, 50-step DPM++ 2M Karras, batch 8 per GPU (64 over 8 GPUs)
+    c3   SDXL-base txt2img 1024x1024, 30-step Euler a, batch 4 per GPU
+    c4a  SD1.5 txt2img 512x512 + hires-fix x2 (Latent upscaler, denoise 0.75, 20 + 20 UNet evaluations), decode at 1024x1024, batch 8
+    c4b  SD1.5 img2img 512x512 (VAE encode, denoise 0.75 -> 16 evaluations, decode), batch 8
+Everything is resident in HBM when the timed region starts (synthetic fp16 weights in the checkpoint's state-dict schema, seeded
+N(0,1) conditioning; the text encoder is outside the path).  Weights are generated on rank 0 and broadcast over RCCL.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  "roofline":     dominant kernel (implicit-GEMM MFMA conv/linear family) achieved TFLOP/s vs the 2.5 PFLOP/s dense fp16 MFMA
-                  peak, measured with per-launch HIP events on the launch stream in a separate profiled pass
-  "cpu_baseline": the fp32 CPU oracle (restated reference path) timed on this host on a bounded sample.
+  "roofline":     the implicit-GEMM MFMA kernel family's achieved TFLOP/s vs the 2.5 PFLOP/s dense fp16 peak — per-launch HIP events
+                  on the launch stream in a separate profiled pass of the same job; "traffic" = HBM bytes per launch of that family
+                  from the rocprofv3 PMC passes of THIS workload when tools/gpu/profile.sh has produced them (else null)
+  "cpu_baseline": the fp32 CPU oracle (restated reference path) timed on this host on a bounded sample (BASELINE.md section 3).
 """
 import argparse
 import ctypes
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +40,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PKG = "stable-diffusion-webui_amd"
 MFMA_PEAK_TFLOPS = 2500.0          # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-UNET_TFLOP_PER_SAMPLE = 0.8033     # SD1.5 UNet forward @64x64 latent, per sample
-VAE_TFLOP_PER_IMAGE = 2.5145       # VAE decode @512^2
+
+# SURVEY.md section 8(d) / BASELINE.md section 2: algorithmic TFLOP per image
+CONFIGS = {
+    "c1": dict(model="sd15", size=512, sampler="Euler a", sampler_steps=20, batch=8, tflop_per_image=34.646,
+               metric="images/sec SD1.5 512x512 20-step Euler-a, batch 8 per GPU"),
+    "c2": dict(model="sd15", size=512, sampler="DPM++ 2M", scheduler="karras", sampler_steps=50, batch=8, tflop_per_image=82.84,
+               metric="images/sec SD1.5 512x512 50-step DPM++ 2M Karras, batch 8 per GPU (64 over 8 GPUs)"),
+    "c3": dict(model="sdxl", size=1024, sampler="Euler a", sampler_steps=30, batch=4, tflop_per_image=416.1,
+               metric="images/sec SDXL-base 1024x1024 30-step Euler-a, batch 4 per GPU"),
+    "c4a": dict(model="sd15", size=512, sampler="Euler a", sampler_steps=20, batch=8, hires=True, tflop_per_image=229.56,
+                metric="images/sec SD1.5 txt2img 512x512 + hires-fix x2 (Latent, denoise 0.75) -> 1024x1024, batch 8 per GPU"),
+    "c4b": dict(model="sd15", size=512, sampler="Euler a", sampler_steps=20, batch=8, img2img=True, tflop_per_image=29.34,
+                metric="images/sec SD1.5 img2img 512x512 denoise 0.75 (encode + 16 evaluations + decode), batch 8 per GPU"),
+}
 
 
 def sub(name):
@@ -43,46 +65,129 @@ def sub(name):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="timed jobs (one job = batch of images through the whole path)")
+    ap.add_argument("--steps", type=int, default=3, help="timed jobs (one job = the global batch through the whole path)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per job")
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--sampler-steps", type=int, default=20)
-    ap.add_argument("--sampler", default="Euler a")
-    ap.add_argument("--model", default="sd15", choices=["sd15", "tiny"])
+    ap.add_argument("--config", default="c1", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per job (default: the config's)")
+    ap.add_argument("--size", type=int, default=0)
+    ap.add_argument("--sampler-steps", type=int, default=0)
+    ap.add_argument("--sampler", default="")
+    ap.add_argument("--model", default="", choices=["", "sd15", "sdxl", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    args.model = args.model or cfg["model"]
+    args.size = args.size or cfg["size"]
+    args.sampler = args.sampler or cfg["sampler"]
+    args.sampler_steps = args.sampler_steps or cfg["sampler_steps"]
+    args.batch = args.batch or cfg["batch"]
+    args.scheduler = cfg.get("scheduler")
+    args.hires, args.img2img = bool(cfg.get("hires")), bool(cfg.get("img2img"))
+    args.named = (args.model == cfg["model"] and args.size == cfg["size"] and args.sampler == cfg["sampler"]
+                  and args.sampler_steps == cfg["sampler_steps"] and args.batch == cfg["batch"])
+    args.cfg = cfg
+    return args
 
 
-def make_job(args, model, rank, world):
-    processing = sub("processing")
+# ----------------------------------------------------------------------------------------------------------------------------
+# self-spawn: python bench.py --gpus N without torchrun
+# ----------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but {have} GPU(s) visible; refusing to report n_gpus={n}", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    sys.exit(rc)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+def model_configs(args):
+    schema = sub("schema")
+    if args.model == "tiny":
+        return schema.tiny_unet(), schema.tiny_vae()
+    if args.model == "sdxl":
+        return schema.sdxl_unet(), schema.sdxl_vae()
+    return schema.sd15_unet(), schema.sd15_vae()
+
+
+def make_job(args, model, rank, world, local_only=False):
+    """The GLOBAL job (batch per GPU x world images) as one processing object; every rank builds the same one and
+    process_images_sharded takes its slice."""
+    import torch
+    processing, par = sub("processing"), sub("parallel")
     ctx_dim = model.unet_cfg.context_dim
-    n = args.batch
-    lo = rank * n                                                 # global image index of this rank's first image
-    conds, unconds = [], []
-    for i in range(lo, lo + n):
-        g = torch.Generator().manual_seed(50_000 + i)             # "synthetic prompt" i
-        conds.append(torch.randn(77, ctx_dim, generator=g))
-        unconds.append(torch.randn(77, ctx_dim, generator=g))
-    c, uc = torch.stack(conds).cuda(), torch.stack(unconds).cuda()
+    n_total = args.batch * world
+    g = [torch.Generator().manual_seed(50_000 + i) for i in range(n_total)]      # "synthetic prompt" i
+    c = torch.stack([torch.randn(77, ctx_dim, generator=g[i]) for i in range(n_total)])
+    uc = torch.stack([torch.randn(77, ctx_dim, generator=g[i]) for i in range(n_total)])
+    y = uy = None
+    if model.is_sdxl:
+        adm = model.unet_cfg.adm_in_channels
+        y = torch.stack([torch.randn(adm, generator=g[i]) for i in range(n_total)])
+        uy = torch.stack([torch.randn(adm, generator=g[i]) for i in range(n_total)])
+    lo, hi = par.shard_range(n_total, world, rank)
+    dev = model.device
+    c_dev, uc_dev = c.to(dev), uc.to(dev)                       # resident in HBM before the timed region
+    if y is not None:
+        y, uy = y.to(dev), uy.to(dev)
+    kw = dict(sd_model=model, seed=1000, batch_size=args.batch, n_iter=world, steps=args.sampler_steps, cfg_scale=7.0,
+              width=args.size, height=args.size, sampler_name=args.sampler, scheduler=args.scheduler, keep_latents=False)
+    init = None
+    if args.img2img:
+        init = torch.stack([torch.rand(3, args.size, args.size, generator=g[i]) for i in range(n_total)]).to(dev)
 
     def run_once():
-        p = processing.StableDiffusionProcessingTxt2Img(
-            sd_model=model, c=c, uc=uc, seed=1000 + lo, batch_size=n, n_iter=1, steps=args.sampler_steps, cfg_scale=7.0,
-            width=args.size, height=args.size, sampler_name=args.sampler, keep_latents=False)
-        return processing.process_images(p)
-    return run_once
+        if args.img2img:
+            p = processing.StableDiffusionProcessingImg2Img(c=c_dev, uc=uc_dev, init_images=init, denoising_strength=0.75, **kw)
+        elif args.hires:
+            p = processing.StableDiffusionProcessingTxt2Img(c=c_dev, uc=uc_dev, enable_hr=True, hr_scale=2.0, hr_upscaler="Latent",
+                                                            denoising_strength=0.75, **kw)
+        else:
+            p = processing.StableDiffusionProcessingTxt2Img(c=c_dev, uc=uc_dev, **kw)
+        if y is not None:
+            p.y, p.uy = y, uy
+        return par.process_images_sharded(p, world=1, rank=0) if local_only else par.process_images_sharded(p)
+    return run_once, (lo, hi)
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the gemm_mfma family from the rocprofv3 PMC passes of this same workload
+    (tools/gpu/profile.sh -> tools/pmc_summary.py -> profiles/r02_pmc_traffic.json); null when absent or another workload."""
+    for path in (os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")):
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                if d.get("workload") == f"{args.config}:{args.sampler_steps}":
+                    return d.get("gemm_mfma_bytes_per_launch")
+            except Exception:
+                pass
+    return None
 
 
 def roofline_block(args, run_once):
     """Profiled pass (separate from the timed region): HIP events around every launch on its stream."""
+    import torch
     lib = sub("_lib")
     lib.check(lib.lib.sdmi_profile_begin(), "profile_begin")
     run_once()
     torch.cuda.synchronize()
-    buf = ctypes.create_string_buffer(1 << 20)
+    buf = ctypes.create_string_buffer(1 << 21)
     lib.check(lib.lib.sdmi_profile_end(buf, len(buf)), "profile_end")
     kernels = json.loads(buf.value.decode())["kernels"]
     fam = [k for k in kernels if k["name"].startswith("gemm_mfma")]
@@ -91,38 +196,36 @@ def roofline_block(args, run_once):
     tot_ms = sum(k["ms"] for k in fam)
     tot_fl = sum(k["flops"] for k in fam)
     launches = sum(k["launches"] for k in fam)
+    all_ms = sum(k["ms"] for k in kernels)
     dom = max(fam, key=lambda k: k["ms"])
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-    pmc = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path)).get("gemm_mfma_bytes_per_launch")
-        except Exception:
-            pmc = None
     block = {
         "bound": "mfma", "kernel": "gemm_mfma_kernel (implicit-GEMM conv3x3 / 1x1 / linear, all tile configs)",
         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
         "launches_per_job": launches, "avg_launch_ms": round(tot_ms / max(launches, 1), 5),
         "algorithmic_tflop_per_job": round(tot_fl / 1e12, 3),
+        "family_ms_per_job": round(tot_ms, 2), "all_kernels_ms_per_job": round(all_ms, 2),
         "dominant_variant": {"name": dom["name"], "launches": dom["launches"], "avg_ms": round(dom["ms"] / dom["launches"], 5),
                              "tflops": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2)},
-        "traffic": pmc,
+        "traffic": pmc_traffic(args),
     }
     return block, kernels
 
 
 def cpu_baseline(args, sd=None):
-    """The restated reference path (fp32 CPU oracle = the CI configuration --use-cpu all --no-half) on this host, bounded
-    sample: ONE CFG pair of UNet forwards (batch 2 = one image's cond + uncond) + ONE VAE decode, extrapolated to the
-    workload (per image: sampler_steps x pair + decode).  Threads are capped: the oracle's small fp32 GEMMs stop scaling
-    (and oversubscribe) far below the 128-256 hardware threads of the GPU box's host."""
+    """the restated reference path (fp32 CPU oracle = the CI configuration --use-cpu all --no-half) on this
+    host, all cores, 1 warm-up + 3 timed runs of each measured piece.  C0 (256x256, 5-step Euler a, batch 1) is timed IN FULL;
+    the workload itself is a bounded sample — ONE CFG pair of UNet forwards (batch 2 = one image's cond + uncond) + ONE VAE decode
+    at the workload's size — extrapolated to evaluations x pair + decode per image."""
+    import torch
     from oracle import pipeline as opipe, unet as ou, vae as ov
     schema = sub("schema")
-    threads = args.cpu_baseline_threads or min(32, os.cpu_count() or 1)
+    threads = args.cpu_baseline_threads or (os.cpu_count() or 1)
     torch.set_num_threads(threads)
     if args.model == "tiny":
         ucfg, vcfg, ou_cfg, ov_cfg = schema.tiny_unet(), schema.tiny_vae(), ou.tiny_config(), ov.tiny_vae_config()
+    elif args.model == "sdxl":
+        ucfg, vcfg, ou_cfg, ov_cfg = schema.sdxl_unet(), schema.sdxl_vae(), ou.sdxl_base_config(), ov.VAEConfig(scale_factor=0.13025)
     else:
         ucfg, vcfg, ou_cfg, ov_cfg = schema.sd15_unet(), schema.sd15_vae(), ou.sd15_config(), ov.sd15_vae_config()
     if sd is None:
@@ -133,31 +236,73 @@ def cpu_baseline(args, sd=None):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 4, hw, hw, generator=g)
     ctx = torch.randn(2, 77, ucfg.context_dim, generator=g)
+    yv = torch.randn(2, ucfg.adm_in_channels, generator=g) if ucfg.adm_in_channels else None
     t = torch.tensor([500.0, 500.0])
+
+    big = args.model == "sdxl"                                 # a 13.5 TFLOP pair: one cold run each keeps the default run bounded
+
+    def timed(fn, runs=3):
+        if big:
+            runs = 1
+        else:
+            fn()                                               # warm-up
+        ts = []
+        for _ in range(runs):
+            t0 = time.time(); fn(); ts.append(time.time() - t0)
+        return sorted(ts)[len(ts) // 2]
     with torch.no_grad():
-        t0 = time.time(); om.apply_model(x, t, ctx); t_pair = time.time() - t0
-        t0 = time.time(); om.vae.decode_first_stage(x[:1]); t_dec = time.time() - t0
-    per_image = args.sampler_steps * t_pair + t_dec
-    return {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 CFG pair of UNet forwards (batch 2) = {t_pair:.2f}s + 1 VAE decode = {t_dec:.2f}s at "
-                      f"{args.size}x{args.size} (single cold run each), extrapolated to {args.sampler_steps} steps + decode per "
-                      f"image; fp32 torch CPU, {threads} threads"}
+        t_pair = timed(lambda: om.apply_model(x, t, ctx, yv))
+        t_dec = timed(lambda: om.vae.decode_first_stage(x[:1]))
+        if threads > 32 and not args.cpu_baseline_threads and not big:
+            # the oracle's fp32 GEMMs stop scaling well below 128+ hardware threads: keep whichever thread count is faster
+            torch.set_num_threads(32)
+            t_pair32 = timed(lambda: om.apply_model(x, t, ctx, yv), runs=1)
+            if t_pair32 < t_pair:
+                t_pair, threads = t_pair32, 32
+                t_dec = min(t_dec, timed(lambda: om.vae.decode_first_stage(x[:1]), runs=1))
+            else:
+                torch.set_num_threads(threads)
+        out = {}
+        if args.model == "sd15":                               # C0 in full: 256x256, 5-step Euler a, batch 1, decode included
+            c0c, c0u = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+
+            def c0():
+                lat = opipe.sample(om, c0c, c0u, [1000], 5, "euler_a", 7.0, (32, 32))
+                opipe.to_uint8_hwc(opipe.decode(om, lat))
+            t_c0 = timed(c0, runs=3)
+            out["c0_full"] = {"seconds": round(t_c0, 3), "images_per_s": round(1.0 / t_c0, 5),
+                              "what": "BASELINE.json configs[0]: SD1.5 256x256 5-step Euler a batch 1, noise -> uint8, median of 3 after 1 warm-up"}
+    evals = args.sampler_steps
+    if args.img2img:
+        evals = 16
+    per_image = evals * t_pair + t_dec
+    if args.hires:
+        per_image = None
+    out.update({"value": round(1.0 / per_image, 6) if per_image else None, "unit": "images/s", "cores": threads, "kind": "port",
+                "sample": f"1 CFG pair of UNet forwards (batch 2) = {t_pair:.2f}s + 1 VAE decode = {t_dec:.2f}s at "
+                          f"{args.size}x{args.size} (median of 3 after 1 warm-up), extrapolated to {evals} evaluations + decode per "
+                          f"image; fp32 torch CPU, {threads} threads of {os.cpu_count()} host cores"
+                          + ("; single cold run each" if big else "")})
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+    import torch
     par = sub("parallel")
     rank, local_rank, world = par.init_distributed()
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == world
     lib = sub("_lib")
     lib.require_device()
     torch.cuda.set_device(local_rank)
     schema, sd_models = sub("schema"), sub("sd_models")
 
     # ---- weights: synthetic checkpoint on rank 0, broadcast over RCCL (scatter + all-gather), packed per rank ----------
-    if args.model == "tiny":
-        ucfg, vcfg = schema.tiny_unet(), schema.tiny_vae()
-    else:
-        ucfg, vcfg = schema.sd15_unet(), schema.sd15_vae()
+    ucfg, vcfg = model_configs(args)
     t0 = time.time()
     sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16) if rank == 0 else None
     t_gen = time.time() - t0
@@ -166,10 +311,10 @@ def main():
         torch.cuda.synchronize(); par.barrier(); t0 = time.time()
         sd = par.broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank))
         torch.cuda.synchronize(); t_bcast = time.time() - t0
-    model = sd_models.SdModel(sd, ucfg, vcfg, device=local_rank, vae_decoder_only=True)
+    model = sd_models.SdModel(sd, ucfg, vcfg, device=local_rank, vae_decoder_only=not (args.img2img))
     keep_sd = sd if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     del sd
-    run_once = make_job(args, model, rank, world)
+    run_once, shard = make_job(args, model, rank, world)
 
     for _ in range(args.warmup):
         run_once()
@@ -182,7 +327,11 @@ def main():
 
     roof, kernels = (None, None)
     if rank == 0 and not args.no_roofline:
-        roof, kernels = roofline_block(args, run_once)
+        if world > 1:                                  # profile this rank's slice alone (no collective inside the profiled pass)
+            run_local, _ = make_job(args, model, 0, 1, local_only=True)
+            roof, kernels = roofline_block(args, run_local)
+        else:
+            roof, kernels = roofline_block(args, run_once)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, keep_sd)
@@ -191,26 +340,29 @@ def main():
         return
     images = args.batch * world * args.steps
     value = images / elapsed
-    tflop_per_image = args.sampler_steps * 2 * UNET_TFLOP_PER_SAMPLE + VAE_TFLOP_PER_IMAGE
+    tflop_per_image = args.cfg["tflop_per_image"] if args.named else None
+    names = {"sd15": "SD1.5", "sdxl": "SDXL-base", "tiny": "tiny"}
+    kind = "img2img (denoise 0.75)" if args.img2img else ("txt2img + hires-fix x2 (Latent, denoise 0.75)" if args.hires else "txt2img")
     out = {
-        "metric": "images/sec SD1.5 512x512 20-step Euler-a, batch 8 per GPU",
+        "metric": args.cfg["metric"] if args.named else f"images/sec {names[args.model]} {args.size}x{args.size} {args.sampler_steps}-step {args.sampler}, batch {args.batch} per GPU",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"{'SD1.5' if args.model == 'sd15' else 'tiny'} txt2img {args.size}x{args.size}, "
-                               f"{args.sampler_steps}-step {args.sampler}, batch {args.batch} per GPU, cfg 7.0, fp16 weights/activations, "
-                               f"fp32 accumulate + fp32 sampler state, Philox (NV) noise, VAE decode to uint8 included",
+        "config": {"workload": f"{args.config}: {names[args.model]} {kind} {args.size}x{args.size}, "
+                               f"{args.sampler_steps}-step {args.sampler}{' Karras' if args.scheduler == 'karras' else ''}, batch {args.batch} per GPU, cfg 7.0, "
+                               f"fp16 weights/activations, fp32 accumulate + fp32 sampler state, Philox (NV) noise, VAE decode to uint8 included",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "weights": "synthetic N(0,1/fan_in) in the SD1.5 state-dict schema (seed 0x5D15)",
+                   "sharding": "process_images_sharded: contiguous image ranges, seeds 1000 + global index, uint8 gather to rank 0 per job",
+                   "weights": "synthetic N(0,1/fan_in) in the checkpoint's state-dict schema (seed 0x5D15)",
                    "weights_broadcast_ms": round(t_bcast * 1e3, 1), "weights_generate_s": round(t_gen, 1),
-                   "algorithmic_tflop_per_image": round(tflop_per_image, 3),
-                   "whole_job_mfma_frac": round(value / world * tflop_per_image / MFMA_PEAK_TFLOPS, 4)},
+                   "algorithmic_tflop_per_image": tflop_per_image,
+                   "whole_job_mfma_frac": round(value / world * tflop_per_image / MFMA_PEAK_TFLOPS, 4) if tflop_per_image else None},
         "roofline": roof,
         "cpu_baseline": cpu,
     }
     if kernels is not None:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_{args.config}.json"), "w") as f:
             json.dump(kernels, f, indent=1)
     print(json.dumps(out), flush=True)
 

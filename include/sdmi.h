@@ -273,6 +273,12 @@ int sdmi_vae_finalize(sdmi_engine* e);
  * x [Bn, Cin, h, w] NCHW (io_dtype), timesteps [Bn] (io_dtype), context [Bn, L, context_dim] (io_dtype) or NULL to reuse
  * the K/V projections cached by the previous call / sdmi_unet_set_context, y [Bn, adm] or NULL, out [Bn, Cout, h, w]. */
 int sdmi_unet_set_context(sdmi_engine* e, const void* context, int io_dtype, int Bn, int L, void* stream);
+/* The same for a caller that cannot tell whether `context` changed since the previous call — the webui hands SdUnet.forward a
+ * freshly catenated cond | uncond tensor on every sampling step (modules/sd_samplers_cfg_denoiser.py:246; it only really changes
+ * when a prompt-editing schedule switches).  The decision is taken ON THE DEVICE, without a host synchronisation: a compare kernel
+ * raises a flag if any fp16-converted element differs from the cached copy, and the copy and all K / V^T projection launches are
+ * predicated on that flag (empty launches otherwise).  Follow with sdmi_unet_forward(..., context = NULL, ...). */
+int sdmi_unet_set_context_cached(sdmi_engine* e, const void* context, int io_dtype, int Bn, int L, void* stream);
 int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y,
                       void* out, int io_dtype, int Bn, int h, int w, int L, void* stream);
 
@@ -288,7 +294,15 @@ int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out_f32, 
 
 /* Introspection for tests / bench. */
 int64_t sdmi_engine_arena_bytes(sdmi_engine* e);
-int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "use_graph", "glds" */
+int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "use_graph", "glds", "trace" */
+
+/* Activation taps for the parity error budget (tests/test_gpu_c1_parity.py): with option "trace" = 1 the engine records, by
+ * the reference's module name ("input_blocks.4.1", "middle_block.1.transformer_blocks.0", "decoder.up.2.block.1", ...), the
+ * NHWC fp16 output of every block of the LAST UNet forward / VAE decode; the tensors stay valid until the next forward
+ * (the activation arena never reuses memory within one).  tap_read copies tap `index` ([B][H][W][C] fp16) to a device buffer. */
+int sdmi_engine_tap_count(sdmi_engine* e);
+int sdmi_engine_tap_info(sdmi_engine* e, int index, char* name_out, int capacity, int64_t* dims_bhwc);
+int sdmi_engine_tap_read(sdmi_engine* e, int index, void* out_f16_nhwc, void* stream);
 
 /* Tuning knobs for benchmarks: "gemm_cfg" (-1 heuristic, 0..7 force a tile configuration when it fits the shape),
  * "attn_kvt" (0 heuristic, 64 force 64-key tiles). */

@@ -119,6 +119,7 @@ _SIGS = {
     "sdmi_vae_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
     "sdmi_vae_finalize": (_i, [_vp]),
     "sdmi_unet_set_context": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sdmi_unet_set_context_cached": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sdmi_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sdmi_vae_decode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sdmi_vae_encode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
@@ -127,6 +128,9 @@ _SIGS = {
     "sdmi_profile_end": (_i, [C.c_char_p, _i]),
     "sdmi_engine_arena_bytes": (_i64, [_vp]),
     "sdmi_engine_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "sdmi_engine_tap_count": (_i, [_vp]),
+    "sdmi_engine_tap_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_int64)]),
+    "sdmi_engine_tap_read": (_i, [_vp, _i, _vp, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)       # AttributeError here == the .so does not export a declared symbol

@@ -18,7 +18,7 @@ int engine_clip_forward(sdmi_engine* e, int slot, const int* tokens, const float
                         int apply_final_ln, float* out, float* pooled, hipStream_t s);
 int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_vae_finalize(sdmi_engine* e);
-int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s);
+int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s, bool conditional = false);
 }  // namespace sdmi
 
 using namespace sdmi;
@@ -404,6 +404,11 @@ int sdmi_unet_set_context(sdmi_engine* e, const void* context, int io_dtype, int
     return engine_set_context(e, context, io_dtype, Bn, L, (hipStream_t)stream);
     API_GUARD_END
 }
+int sdmi_unet_set_context_cached(sdmi_engine* e, const void* context, int io_dtype, int Bn, int L, void* stream) {
+    API_GUARD_BEGIN
+    return engine_set_context(e, context, io_dtype, Bn, L, (hipStream_t)stream, true);
+    API_GUARD_END
+}
 int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y, void* out,
                       int io_dtype, int Bn, int h, int w, int L, void* stream) {
     API_GUARD_BEGIN
@@ -427,6 +432,9 @@ int sdmi_debug_set(const char* name, int value) {
     const std::string n(name);
     if (n == "gemm_cfg") g_force_gemm_cfg = value;
     else if (n == "gemm_shortk_cfg") g_shortk_gemm_cfg = value;
+    else if (n == "gemm_shortk_maxk") g_shortk_max_k = value;
+    else if (n == "gemm_geglu_cfg") g_geglu_gemm_cfg = value;
+    else if (n == "vt_mode") g_vt_mode = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "attn_occ") g_attn_occ = value;
     else if (n == "gemm_split") g_force_gemm_split = value;
@@ -462,7 +470,29 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     if (n == "force_generic") e->force_generic = value != 0;
     else if (n == "glds") e->use_glds = value != 0;
     else if (n == "use_graph") e->use_graph = value != 0;
+    else if (n == "trace") { e->trace = value != 0; e->taps.clear(); }
     else { set_error("unknown option " + n); return 1; }
+    return 0;
+    API_GUARD_END
+}
+
+int sdmi_engine_tap_count(sdmi_engine* e) { return e ? (int)e->taps.size() : 0; }
+int sdmi_engine_tap_info(sdmi_engine* e, int index, char* name_out, int capacity, int64_t* dims_bhwc) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e && name_out && dims_bhwc && index >= 0 && index < (int)e->taps.size(), "bad tap index / null argument");
+    const auto& t = e->taps[index];
+    SDMI_REQUIRE((int)t.name.size() < capacity, "tap name buffer too small");
+    std::memcpy(name_out, t.name.c_str(), t.name.size() + 1);
+    dims_bhwc[0] = t.B; dims_bhwc[1] = t.H; dims_bhwc[2] = t.W; dims_bhwc[3] = t.C;
+    return 0;
+    API_GUARD_END
+}
+int sdmi_engine_tap_read(sdmi_engine* e, int index, void* out_f16_nhwc, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e && out_f16_nhwc && index >= 0 && index < (int)e->taps.size(), "bad tap index / null argument");
+    const auto& t = e->taps[index];
+    SDMI_CHECK_HIP(hipMemcpyAsync(out_f16_nhwc, t.ptr, (size_t)t.B * t.H * t.W * t.C * sizeof(half_t), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
     return 0;
     API_GUARD_END
 }

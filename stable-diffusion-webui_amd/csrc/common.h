@@ -71,10 +71,15 @@ struct GemmP {
     int splitk;
     int splitk_steps;     // BK-steps per slice
     long long* dbg;       // tuning only: per-wave section timers of the ping-pong kernel (sdmi_debug_set gemm_dbg_lo/hi)
+    const int* gate;      // optional device flag: the launch is a no-op when *gate == 0 (context re-projection only if the context
+                          // changed, decided on the device: no host synchronisation — engine.cpp unet_set_context)
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
        EP_QUICK_GELU = 16, EP_GELU = 32,               // activation on the biased result (CLIP MLP: x*sigmoid(1.702x) / erf GELU)
+       EP_TRANSPOSE = 64,                              // store out^T per image: out[b][n][m - b*rows_per_batch] (row stride ldo): the V
+                                                       // projection written as V^T [C][tokens] for the attention kernel — the MFMA
+                                                       // operands swap roles so a lane owns 4 consecutive TOKENS of one channel
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000 };    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
 
@@ -84,7 +89,10 @@ int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hi
 size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch);
 extern int g_force_gemm_cfg;
 extern int g_shortk_gemm_cfg;
-extern int g_gemm_pipe;             // 0 = two-stage kernels, 1 = BK32 ring for the big tiles, 2 = also 128x128, 3 = ping-pong 256-row tiles, 4 = also 128x320
+extern int g_shortk_max_k;          // the launches g_shortk_gemm_cfg applies to: taps == 1 and K <= this (default 448)
+extern int g_geglu_gemm_cfg;        // tile config forced on the GEGLU (ff.net.0.proj) launches, -1 = heuristic
+extern int g_vt_mode;               // 1 (default): V^T through EP_TRANSPOSE on token-major tiles; 0: weights-as-rows GEMM (round 1)
+extern int g_gemm_pipe;             // 0 = two-stage kernels only, 3 = ping-pong 256-row tiles, 4 = also 128x320 (default)
 extern int g_gemm_pipe_default;     // value restored by sdmi_debug_set("gemm_pipe", -1)
 extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = force k slices where allowed
 extern int g_attn_kvt;
@@ -157,6 +165,10 @@ int launch_nchw_to_nhwc(const void* x, int dtype, half_t* out, int B, int C, int
 int launch_copy_out(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
 int launch_convert_to_f16(const void* src, int dtype, half_t* dst, int64_t n, hipStream_t s);
 int launch_convert_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s);
+// context cache validation on the device: *gate = 1 if any element of fp16(src[b][l][c]) differs from cached[b][l (stride Lpad)][c]
+// (gate must be zeroed before), then — when *gate != 0 — the cached copy is overwritten with the new rows
+int launch_ctx_compare(const void* src, int dtype, const half_t* cached, int B, int L, int Lpad, int C, int* gate, hipStream_t s);
+int launch_ctx_update_gated(const void* src, int dtype, half_t* cached, int B, int L, int Lpad, int C, const int* gate, hipStream_t s);
 // sinusoidal timestep embedding (cos first): t [B] (f16|f32) -> out fp32 [B, dim]
 int launch_timestep_embedding(const void* t, int dtype, float* out, int B, int dim, hipStream_t s);
 // out[b][n] = act_out( sum_k act_in(a[b][k]) * w[n][k] + bias[n] ) (+ add[b][n]); a fp32, w fp16, out fp32

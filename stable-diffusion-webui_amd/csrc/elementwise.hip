@@ -623,6 +623,44 @@ int launch_convert_to_f16(const void* src, int dtype, half_t* dst, int64_t n, hi
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
+template <typename TI>
+__global__ __launch_bounds__(256) void ctx_compare_kernel(const TI* src, const half_t* cached, int L, int Lpad, int C, long n, int* gate) {
+    bool diff = false;
+    const long per = (long)L * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / per, r = i - b * per;
+        const half_t v = (half_t)src[i], c = cached[b * (long)Lpad * C + r];
+        diff |= __builtin_bit_cast(unsigned short, v) != __builtin_bit_cast(unsigned short, c);
+    }
+    if (__any(diff) && (threadIdx.x & 63) == 0) *gate = 1;      // racing writers all store the same value
+}
+template <typename TI>
+__global__ __launch_bounds__(256) void ctx_update_gated_kernel(const TI* src, half_t* cached, int L, int Lpad, int C, long n, const int* gate) {
+    if (*gate == 0) return;
+    const long per = (long)L * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / per, r = i - b * per;
+        cached[b * (long)Lpad * C + r] = (half_t)src[i];
+    }
+}
+int launch_ctx_compare(const void* src, int dtype, const half_t* cached, int B, int L, int Lpad, int C, int* gate, hipStream_t s) {
+    const long n = (long)B * L * C;
+    if (dtype == 0)
+        hipLaunchKernelGGL(ctx_compare_kernel<half_t>, dim3(ew_blocks(n)), dim3(256), 0, s, (const half_t*)src, cached, L, Lpad, C, n, gate);
+    else
+        hipLaunchKernelGGL(ctx_compare_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)src, cached, L, Lpad, C, n, gate);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_ctx_update_gated(const void* src, int dtype, half_t* cached, int B, int L, int Lpad, int C, const int* gate, hipStream_t s) {
+    const long n = (long)B * L * C;
+    if (dtype == 0)
+        hipLaunchKernelGGL(ctx_update_gated_kernel<half_t>, dim3(ew_blocks(n)), dim3(256), 0, s, (const half_t*)src, cached, L, Lpad, C, n, gate);
+    else
+        hipLaunchKernelGGL(ctx_update_gated_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, s, (const float*)src, cached, L, Lpad, C, n, gate);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int launch_convert_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s) {
     if (dtype == 0)
         hipLaunchKernelGGL((convert_kernel<half_t, float>), dim3(ew_blocks(n)), dim3(256), 0, s, (const half_t*)src, dst, (long)n);

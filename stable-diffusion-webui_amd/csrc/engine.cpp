@@ -48,6 +48,9 @@ struct Run {
     bool dry;
     half_t* H(size_t n) { return (half_t*)e->arena.take(n * sizeof(half_t)); }
     float* F(size_t n) { return (float*)e->arena.take(n * sizeof(float)); }
+    void tap(const std::string& name, const half_t* p, int B, int H, int W, int C) {
+        if (!dry && e->trace) e->taps.push_back({name, p, B, H, W, C});
+    }
 };
 
 #define TRY(x)                  \
@@ -60,7 +63,7 @@ struct Run {
 // ------------------------------------------------------------------------------------------------------------
 static int dev_alloc(sdmi_engine* e, void** p, size_t bytes) {
     SDMI_CHECK_HIP(hipMalloc(p, std::max<size_t>(bytes, 256)));
-    e->owned.push_back(*p);
+    (e->alloc_sink ? *e->alloc_sink : e->owned).push_back(*p);
     return 0;
 }
 
@@ -336,6 +339,7 @@ struct ConvArgs {
     float alpha = 1.f;
     int batch = 1;
     long a_bs = 0, w_bs = 0, o_bs = 0, r_bs = 0;
+    const int* gate = nullptr;
 };
 
 static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
@@ -360,6 +364,7 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.flags = a.flags | (W.geglu ? EP_GEGLU : 0);
     p.alpha = a.alpha;
     p.a_bs = a.a_bs; p.w_bs = a.w_bs; p.o_bs = a.o_bs; p.r_bs = a.r_bs;
+    p.gate = a.gate;
     return launch_gemm(p, a.batch, r.e->force_generic, r.e->use_glds, r.s);
 }
 
@@ -437,10 +442,26 @@ static int run_attn(Run& r, const half_t* q, const half_t* k, const half_t* vt, 
 // V^T[b] = Wv x X[b]^T :  the weight matrix plays the "activation" role, the tokens of image b the "weight" role.
 // Columns [tokens, tokens_pad) of V^T are written as zeros (n_valid), so the attention kernel's padded keys are finite.
 static int run_vt(Run& r, const ConvW& Wv, const half_t* x, int ldx, int B, int tokens, int tokens_pad, half_t* vt,
-                  bool bias_row) {
+                  bool bias_row, const int* gate = nullptr) {
     if (r.dry) return 0;
     GemmP p{};
     const int C = Wv.n_pad, K = Wv.cin_pad;
+    if (g_vt_mode == 1 && tokens == tokens_pad && tokens % 4 == 0 && ldx == K && gate == nullptr) {
+        // token-major tiles (M = B*tokens rows: full 256 / 128-row tiles whatever C is) with the MFMA operand roles swapped, so the
+        // epilogue stores V^T[b][c][token] in 8-byte pieces along the token dimension (EP_TRANSPOSE).  Same products, same K order
+        // as the ordinary projection.  (The weights-as-rows form below pads M = C = 320 up to 512 tile rows.)
+        p.a0 = x; p.c0 = K; p.cin = K; p.lda0 = ldx;
+        p.w = Wv.w; p.ldw = K;
+        p.bias = bias_row ? Wv.b : nullptr;                  // per output channel n
+        p.out = vt;
+        p.Hi = B * tokens; p.Wi = 1; p.Ho = B * tokens; p.Wo = 1;
+        p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
+        p.M = B * tokens; p.N = C; p.K = K; p.n_valid = C;
+        p.ldo = tokens_pad; p.rows_per_batch = tokens; p.n_real = C;
+        p.flags = EP_TRANSPOSE;
+        p.alpha = 1.f;
+        return launch_gemm(p, 1, r.e->force_generic, r.e->use_glds, r.s);
+    }
     p.a0 = Wv.w; p.c0 = K; p.cin = K; p.lda0 = K;
     p.w = x; p.ldw = ldx;
     p.bias = bias_row ? Wv.b : nullptr;
@@ -453,10 +474,12 @@ static int run_vt(Run& r, const ConvW& Wv, const half_t* x, int ldx, int B, int 
     p.alpha = 1.f;
     p.a_bs = 0; p.w_bs = (long)tokens * ldx;
     p.o_bs = (long)C * tokens_pad;
+    p.gate = gate;
     return launch_gemm(p, B, r.e->force_generic, r.e->use_glds, r.s);
 }
 
-static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, int L, half_t** out) {
+static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, int L, half_t** out,
+                  const std::string& name = std::string()) {
     sdmi_engine* e = r.e;
     const int C = st.ch, HW = H * Wd;
     const size_t M = (size_t)B * HW;
@@ -465,7 +488,9 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     TRY(run_gn(r, st.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
     half_t* cur = r.H(M * C);
     TRY(run_linear(r, st.proj_in, n0, (int)M, nullptr, cur, C));
+    int bi = 0;
     for (const TBlockW& b : st.blocks) {
+        const std::string bname = name + ".transformer_blocks." + std::to_string(bi++);
         // --- self attention
         half_t* n1 = r.H(M * C);
         TRY(run_ln(r, b.ln1, cur, M, n1));
@@ -477,6 +502,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
         half_t* x1 = r.H(M * C);
         TRY(run_linear(r, b.o1, a1, (int)M, cur, x1, C));
+        r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
         half_t* n2 = r.H(M * C);
         TRY(run_ln(r, b.ln2, x1, M, n2));
@@ -497,6 +523,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         }
         half_t* x2 = r.H(M * C);
         TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C));
+        r.tap(bname + ".attn2+x", x2, B, H, Wd, C);
         // --- feed forward (GEGLU fused in the first GEMM's epilogue)
         half_t* n3 = r.H(M * C);
         TRY(run_ln(r, b.ln3, x2, M, n3));
@@ -504,6 +531,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
         half_t* x3 = r.H(M * C);
         TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
+        r.tap(bname, x3, B, H, Wd, C);
         cur = x3;
     }
     half_t* o = r.H(M * C);
@@ -528,11 +556,25 @@ static void collect_st(const UNetW& u, std::vector<const STW*>* out) {
     for (auto& blk : u.output) for (auto& L : blk) if (L.kind == UNetLayer::ST) out->push_back(&L.st);
 }
 
-static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s) {
+// `conditional`: the caller does not know whether `ctx` differs from the context of the previous call (the webui re-catenates
+// cond | uncond on every step, modules/sd_samplers_cfg_denoiser.py:246).  The decision is taken ON THE DEVICE: a compare kernel
+// raises a flag when any fp16-converted element differs from the cached copy, and the copy + every K / V^T projection launch
+// below is gated on that flag (GemmP::gate) — an unchanged context costs ~35 empty launches and no host synchronisation.
+static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s, bool conditional = false) {
     UNetW& u = e->unet;
     SDMI_REQUIRE(u.ready, "unet not finalized");
     const int cd = u.cfg.context_dim;
     const int Lpad = rup(L, 64);
+    const int* gate = nullptr;
+    if (conditional && e->ctx_valid && e->ctx_B == Bn && e->ctx_L == L && !e->ctx_k.empty()) {
+        if (!e->ctx_gate) {
+            SDMI_CHECK_HIP(hipMalloc((void**)&e->ctx_gate, 256));
+            e->owned.push_back(e->ctx_gate);
+        }
+        SDMI_CHECK_HIP(hipMemsetAsync(e->ctx_gate, 0, sizeof(int), s));
+        TRY(launch_ctx_compare(ctx, dtype, e->ctx_f16, Bn, L, Lpad, cd, e->ctx_gate, s));
+        gate = e->ctx_gate;
+    }
     if (e->ctx_B != Bn || e->ctx_L != L || e->ctx_k.empty()) {
         SDMI_CHECK_HIP(hipStreamSynchronize(s));
         ctx_free(e);
@@ -557,9 +599,13 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
         e->ctx_B = Bn; e->ctx_L = L; e->ctx_Lpad = Lpad;
     }
     // context -> fp16 rows [Bn][Lpad][cd] (padding rows stay zero)
-    for (int b = 0; b < Bn; ++b) {
-        const char* src = (const char*)ctx + (size_t)b * L * cd * (dtype == SDMI_F16 ? 2 : 4);
-        TRY(launch_convert_to_f16(src, dtype, e->ctx_f16 + (size_t)b * Lpad * cd, (int64_t)L * cd, s));
+    if (gate) {
+        TRY(launch_ctx_update_gated(ctx, dtype, e->ctx_f16, Bn, L, Lpad, cd, gate, s));
+    } else {
+        for (int b = 0; b < Bn; ++b) {
+            const char* src = (const char*)ctx + (size_t)b * L * cd * (dtype == SDMI_F16 ? 2 : 4);
+            TRY(launch_convert_to_f16(src, dtype, e->ctx_f16 + (size_t)b * Lpad * cd, (int64_t)L * cd, s));
+        }
     }
     Run r{e, s, false};
     std::vector<const STW*> sts;
@@ -571,9 +617,10 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
             c.a0 = e->ctx_f16; c.c0 = cd; c.B = 1; c.Hi = L; c.Wi = 1; c.Ho = L; c.Wo = 1;
             c.out = e->ctx_k[b.ctx_slot]; c.ldo = st->ch;
             c.batch = Bn; c.a_bs = (long)Lpad * cd; c.o_bs = (long)L * st->ch;
+            c.gate = gate;
             TRY(run_conv(r, b.k2, c));
             // V^T[b] = Wv ctx[b]^T : [C][Lpad]
-            TRY(run_vt(r, b.v2, e->ctx_f16, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false));
+            TRY(run_vt(r, b.v2, e->ctx_f16, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false, gate));
         }
     e->ctx_valid = true;
     return 0;
@@ -625,9 +672,11 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
 
     std::vector<Act> hs;
     Act cur{nullptr, 0, h, w};
-    auto run_block = [&](const std::vector<UNetLayer>& blk, const Act* skip) -> int {
+    auto run_block = [&](const std::vector<UNetLayer>& blk, const Act* skip, const std::string& bname) -> int {
         bool first = true;
+        int li = 0;
         for (const UNetLayer& Lr : blk) {
+            const std::string lname = bname + "." + std::to_string(li++);
             switch (Lr.kind) {
                 case UNetLayer::CONV_IN: {
                     half_t* o = r.H((size_t)Bn * cur.H * cur.W * Lr.conv.n_pad);
@@ -652,7 +701,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                 }
                 case UNetLayer::ST: {
                     half_t* o = nullptr;
-                    TRY(run_st(r, Lr.st, cur.p, Bn, cur.H, cur.W, L, &o));
+                    TRY(run_st(r, Lr.st, cur.p, Bn, cur.H, cur.W, L, &o, lname));
                     cur.p = o;
                     break;
                 }
@@ -678,18 +727,22 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                 }
             }
             first = false;
+            r.tap(lname, cur.p, Bn, cur.H, cur.W, cur.C);
         }
         return 0;
     };
+    if (!r.dry) e->taps.clear();
+    int bidx = 0;
     for (auto& blk : u.input) {
-        TRY(run_block(blk, nullptr));
+        TRY(run_block(blk, nullptr, "input_blocks." + std::to_string(bidx++)));
         hs.push_back(cur);
     }
-    TRY(run_block(u.middle, nullptr));
+    TRY(run_block(u.middle, nullptr, "middle_block"));
+    bidx = 0;
     for (auto& blk : u.output) {
         Act sk = hs.back();
         hs.pop_back();
-        TRY(run_block(blk, &sk));
+        TRY(run_block(blk, &sk, "output_blocks." + std::to_string(bidx++)));
     }
     // ---- out: GroupNorm32 + SiLU + conv 3x3 -> fp32 NCHW ---------------------------------------------------
     const size_t M = (size_t)Bn * cur.H * cur.W;
@@ -911,14 +964,21 @@ static int vae_decode_run(Run& r, const void* z, int io_dtype, float* out, int B
         a.out = cur; a.ldo = C;
         TRY(run_conv(r, v.d_conv_in, a));
     }
+    if (!r.dry) e->taps.clear();
+    r.tap("decoder.conv_in", cur, B, H, W, C);
     half_t* o = nullptr;
     TRY(run_res(r, v.d_mid1, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    r.tap("decoder.mid.block_1", cur, B, H, W, C);
     TRY(run_vae_attn(r, v.d_attn, cur, B, H, W, &o)); cur = o;
+    r.tap("decoder.mid.attn_1", cur, B, H, W, C);
     TRY(run_res(r, v.d_mid2, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    r.tap("decoder.mid.block_2", cur, B, H, W, C);
     for (int i = c.num_levels - 1; i >= 0; --i) {
+        int bj = 0;
         for (const ResW& rb : v.d_up[i].blocks) {
             TRY(run_res(r, rb, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o));
             cur = o; C = rb.cout;
+            r.tap("decoder.up." + std::to_string(i) + ".block." + std::to_string(bj++), cur, B, H, W, C);
         }
         if (v.d_up[i].has_resample) {
             half_t* u = r.H((size_t)B * (2 * H) * (2 * W) * C);
@@ -927,6 +987,7 @@ static int vae_decode_run(Run& r, const void* z, int io_dtype, float* out, int B
             a.out = u; a.ldo = C;
             TRY(run_conv(r, v.d_up[i].resample, a));
             cur = u; H *= 2; W *= 2;
+            r.tap("decoder.up." + std::to_string(i) + ".upsample", cur, B, H, W, C);
         }
     }
     half_t* tn = r.H((size_t)B * H * W * C);
@@ -1224,17 +1285,25 @@ int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data,
     }
     SDMI_CHECK_HIP(hipDeviceSynchronize());
     if (tmp) (void)hipFree(tmp);
+    e->ctx_valid = false;                                     // cached K / V^T depend on attn2.to_k / to_v
     return rc;
 }
 int engine_vae_finalize(sdmi_engine* e) {
     SDMI_CHECK_HIP(hipSetDevice(e->device));
+    // a second finalize replaces the first stage (external VAE file / checkpoint reload): drop the previous packed weights
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    for (void* p : e->owned_vae) (void)hipFree(p);
+    e->owned_vae.clear();
+    e->vae.ready = false;
+    e->alloc_sink = &e->owned_vae;
     const int rc = vae_build(e);
+    e->alloc_sink = nullptr;
     free_raw(e->raw_vae);
     return rc;
 }
-int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s) {
+int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s, bool conditional) {
     SDMI_CHECK_HIP(hipSetDevice(e->device));
-    return unet_set_context(e, ctx, dtype, Bn, L, s);
+    return unet_set_context(e, ctx, dtype, Bn, L, s, conditional);
 }
 
 }  // namespace sdmi
@@ -1248,5 +1317,6 @@ sdmi_engine::~sdmi_engine() {
     sdmi::free_raw(raw_clip[1]);
     sdmi::ctx_free(this);
     for (void* p : owned) (void)hipFree(p);
+    for (void* p : owned_vae) (void)hipFree(p);
     if (arena.base) (void)hipFree(arena.base);
 }

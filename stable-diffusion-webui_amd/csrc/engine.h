@@ -144,6 +144,8 @@ struct sdmi_engine {
     std::map<std::string, std::vector<PackSite>> unet_sites;
     bool recording_unet_sites = false;
     std::vector<void*> owned;                 // persistent device allocations (weights)
+    std::vector<void*> owned_vae;             // the VAE's packed weights: freed when another VAE is loaded (sd_vae.load_vae)
+    std::vector<void*>* alloc_sink = nullptr; // where dev_alloc records (null = owned)
     sdmi::UNetW unet;
     sdmi::VAEW vae;
     sdmi::ClipW clip[2];
@@ -153,6 +155,11 @@ struct sdmi_engine {
     bool force_generic = false;
     bool use_glds = true;
     bool use_graph = false;
+    // activation taps (parity error budget): with `trace` on, every block output of the last forward is recorded by name
+    // — the arena never reuses memory within a forward, so the tensors stay readable until the next forward
+    bool trace = false;
+    struct Tap { std::string name; const half_t* ptr; int B, H, W, C; };
+    std::vector<Tap> taps;
     // context cache (persistent between forwards)
     half_t* ctx_f16 = nullptr;                // [Bn][Lpad][ctx_dim]
     std::vector<half_t*> ctx_k;               // per slot [Bn*Lpad][C]
@@ -160,6 +167,7 @@ struct sdmi_engine {
     std::vector<void*> ctx_owned;
     int ctx_B = 0, ctx_L = 0, ctx_Lpad = 0;
     bool ctx_valid = false;
+    int* ctx_gate = nullptr;                  // device flag of the conditional re-projection (sdmi_unet_set_context_cached)
 
     ~sdmi_engine();
 };

@@ -64,8 +64,31 @@ __device__ __forceinline__ float gelu_erf(float g) {
 
 // Epilogue shared by the GEMM kernels.  Lane holds, for accumulator tile (i, j):
 //   m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive channels)
-template <int TM, int TN, int WTM, int WTN, bool GEGLU>
+template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z) {
+    if constexpr (TR) {
+        // transposed store (EP_TRANSPOSE): the MFMAs ran with swapped operand roles, so for tile (i, j) the lane holds
+        //   n = n0 + wc*WTN + j*16 + (lane & 15),  m = m0 + wr*WTM + i*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive tokens)
+        // out[b][n][m - b*rows_per_batch], 8-byte packed stores along the token dimension (rows_per_batch % 4 == 0).
+        const long ob = z * p.o_bs;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wr * WTM + i * 16 + (lane >> 4) * 4;
+            if (m >= p.M) continue;
+            const int b = m / p.rows_per_batch;
+            const int ml = m - b * p.rows_per_batch;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * WTN + j * 16 + (lane & 15);
+                const float bb = p.bias ? p.bias[n] : 0.f;
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)fmaf(acc[i][j][r], p.alpha, bb);
+                *reinterpret_cast<h4*>((half_t*)p.out + ob + ((long)b * p.N + n) * p.ldo + ml) = o;
+            }
+        }
+        return;
+    }
     // ---- epilogue ----------------------------------------------------------------------------------------
     // lane holds, for tile (i, j):  m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r
     const int flags = p.flags;
@@ -177,8 +200,9 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
+    if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
     constexpr int WTM = BM / WR, WTN = BN / WC;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -321,7 +345,8 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -340,181 +365,11 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wr, wc, lane, z);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR>(p, acc, m0, n0, wr, wc, lane, z);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Deep-pipelined variant (selectable with sdmi_debug_set("gemm_pipe", 1); NOT the default, see g_gemm_pipe).  The two-stage kernel above drains every load
-// (s_waitcnt vmcnt(0)) once per K step, so each step pays a full L2/HBM round trip that one workgroup per CU cannot
-// hide (measured 2.9 us per 64-deep step of a 256x320 tile = 37 % of the MFMA rate).  Here K advances in BK = 32
-// stages through an NS-deep LDS ring with NS-1 stages of LDS-direct loads in flight at all times:
-//   iteration kt:  s_waitcnt vmcnt((NS-2) * loads_per_stage)   -- only stage kt has to have landed (COUNTED, never 0
-//                                                                  in steady state)
-//                  s_barrier                                    -- every wave's share of stage kt is visible; every wave
-//                                                                  has finished reading stage kt-1's buffer
-//                  issue stage kt+NS-1 into the buffer stage kt-1 just vacated
-//                  MFMAs of stage kt
-// One raw s_barrier per stage, no __syncthreads() (which would drain the DMA queue).  RAW: a stage is read only after
-// the issuing waves' counted vmcnt + a barrier; WAR: a buffer is refilled only after the barrier that follows its
-// last read.  The ISA of the loop is checked for the absence of vmcnt(0) in tests/ (CPU side, llvm-objdump).
-// ---------------------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int BM, int BN, int WR, int WC, int NS, bool GEGLU>
-__global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_pipe_kernel(GemmP p) {
-    constexpr int BK = 32, NT = WR * WC * 64;
-    constexpr int WTM = BM / WR, WTN = BN / WC;
-    constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int CPR = 4, ROWB = 64;
-    constexpr int A_CH = BM * CPR, B_CH = BN * CPR;
-    constexpr int A_IT = (A_CH + NT - 1) / NT, B_IT = (B_CH + NT - 1) / NT;
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    constexpr bool A_EVEN = A_CH % NT == 0, B_EVEN = B_CH % NT == 0;
-    static_assert(A_EVEN || B_EVEN, "at most one operand may have a partial last load iteration");
-    static_assert((A_CH % 64 == 0) && (B_CH % 64 == 0), "whole waves only");
-    constexpr int LPT_FULL = A_IT + B_IT;                 // loads per thread per stage (waves in the partial tail: one less)
-    static_assert((NS - 2) * LPT_FULL < 64, "vmcnt field");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: scalar branches, SGPR LDS bases
-    const int wr = wave / WC, wc = wave % WC;
-
-    const int tiles_n = p.N / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, sub = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sub;
-    }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const long z = blockIdx.z;
-    const half_t* a0 = p.a0 + z * p.a_bs;
-    const half_t* a1 = p.a1 ? p.a1 + z * p.a_bs : nullptr;
-    const half_t* wbase = p.w + z * p.w_bs;
-
-    // wave-uniform: does this wave take part in the (possibly partial) last load iteration of A / B ?
-    const bool a_last = A_EVEN || ((A_IT - 1) * NT + wave * 64 < A_CH);
-    const bool b_last = B_EVEN || ((B_IT - 1) * NT + wave * 64 < B_CH);
-    const bool full_wave = a_last && b_last;
-
-    GRow rows[A_IT];
-    const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int idx = it * NT + tid;
-        const int m = m0 + idx / CPR;
-        GRow gr;
-        gr.ok = m < p.M && idx < A_CH;
-        const int mm = gr.ok ? m : 0;
-        const int b = mm / p.rows_per_batch;
-        const int rem = mm - b * p.rows_per_batch;
-        const int yo = rem / p.Wo;
-        const int xo = rem - yo * p.Wo;
-        gr.yb = p.up ? yo - 1 : yo * p.stride - p.pad;
-        gr.xb = p.up ? xo - 1 : xo * p.stride - p.pad;
-        gr.pixbase = b * p.Hi * p.Wi;
-        rows[it] = gr;
-    }
-
-    f4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    int nk = p.K / BK;
-    int k_first = 0;
-    if (p.splitk > 1) {
-        k_first = blockIdx.y * p.splitk_steps;
-        nk = min(nk - k_first, p.splitk_steps);
-    }
-    int nx_tap = 0, nx_cbase = 0, nx_k0 = 0;
-    if (k_first > 0) {
-        nx_k0 = k_first * BK;
-        nx_tap = nx_k0 / p.cin;
-        nx_cbase = nx_k0 - nx_tap * p.cin;
-    }
-
-    auto stage_issue = [&](int sb) {
-        const int tap = nx_tap, cbase = nx_cbase, k0 = nx_k0;
-        nx_k0 += BK;
-        nx_cbase += BK;
-        if (nx_cbase >= p.cin) { nx_cbase = 0; ++nx_tap; }
-        const bool first = cbase < p.c0;
-        const half_t* src = first ? a0 : a1;
-        const int cch = first ? cbase : cbase - p.c0;
-        const int lda = first ? p.lda0 : p.lda1;
-        int dy = 0, dx = 0;
-        if (p.taps == 9) { dy = (tap * 11) >> 5; dx = tap - dy * 3; }
-        char* abuf = smem + sb * STAGE;
-        char* bbuf = abuf + A_BYTES;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            if (it == A_IT - 1 && !a_last) break;                     // wave-uniform
-            const int idx = it * NT + tid;
-            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
-            const GRow gr = rows[it];
-            const int yr = gr.yb + dy, xr = gr.xb + dx;
-            const bool ok = gr.ok && (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
-            const int pix = gr.pixbase + (yr >> p.up) * p.Wi + (xr >> p.up);
-            const half_t* g = ok ? src + (long)pix * lda + (cch + c * 8) : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (it * NT + wave * 64) * 16), 16, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            if (it == B_IT - 1 && !b_last) break;                     // wave-uniform
-            const int idx = it * NT + tid;
-            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
-            const half_t* g = (n0 + r < p.n_valid) ? wbase + (long)(n0 + r) * p.ldw + k0 + c * 8 : p.zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(bbuf + (it * NT + wave * 64) * 16), 16, 0, 0);
-        }
-    };
-    auto compute = [&](int sb) {
-        const char* abuf = smem + sb * STAGE;
-        const char* bbuf = abuf + A_BYTES;
-        const int lr = lane & 15, lk = lane >> 4;
-        const int sw = (lk ^ swz<BK>(lr)) << 4;
-        h8 af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(abuf + (wr * WTM + i * 16 + lr) * ROWB + sw);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(bbuf + (wc * WTN + j * 16 + lr) * ROWB + sw);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    };
-
-    // ---- prologue: NS-1 stages in flight ---------------------------------------------------------------------
-    const int pre = nk < NS - 1 ? nk : NS - 1;
-    for (int st = 0; st < pre; ++st) stage_issue(st);
-    // ---- main loop ---------------------------------------------------------------------------------------------
-    int buf = 0;                                          // ring slot of stage kt
-    int nxt = pre % NS;                                   // ring slot the next issued stage goes to
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + NS - 2 <= nk - 1) {                      // steady state: NS-2 younger stages may stay in flight
-            if (full_wave) wait_vmcnt<(NS - 2) * LPT_FULL>();
-            else wait_vmcnt<(NS - 2) * (LPT_FULL - 1)>();
-        } else {
-            wait_vmcnt<0>();                              // tail: fewer stages were issued behind this one
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + NS - 1 < nk) {
-            stage_issue(nxt);
-            nxt = nxt + 1 == NS ? 0 : nxt + 1;
-        }
-        compute(buf);
-        buf = buf + 1 == NS ? 0 : buf + 1;
-    }
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wr, wc, lane, z);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Ping-pong kernel for the 256-row tiles: BK = 64, 8 waves as 2 (M) x 4 (N).  Every SIMD holds one wave of each
@@ -550,8 +405,9 @@ __device__ __forceinline__ long long stamp() {           // s_memtime; callers s
     return t;
 }
 
-template <int BM, int BN, bool GEGLU, bool TIMING = false>
+template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false>
 __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
+    if (p.gate && *p.gate == 0) return;
     constexpr int BK = 64, WC = 4, ROWB = 128;
     constexpr int WTM = BM / 2, WTN = BN / WC, TM = WTM / 16, TN = WTN / 16;
     constexpr int RP = 32, TMP = 2;                          // rows / MFMA row-tiles of the wave tile per phase
@@ -796,7 +652,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                 for (int i = 0; i < TMP; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[ph * TMP + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j], af[ks][i], acc[ph * TMP + i][j], 0, 0, 0);
+                        acc[ph * TMP + i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][i], bf[ks][j], acc[ph * TMP + i][j], 0, 0, 0)
+                                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j], af[ks][i], acc[ph * TMP + i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (TIMING) t3 = stamp();
@@ -819,7 +676,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             for (int i = 0; i < 5; ++i) d[i] = tm[i];
         }
     }
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU>(p, acc, m0, n0, wr, wc, lane, z);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR>(p, acc, m0, n0, wr, wc, lane, z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -860,6 +717,7 @@ __device__ __forceinline__ float dot_row(const GemmP& p, const half_t* a0, const
 }
 
 __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
+    if (p.gate && *p.gate == 0) return;
     const long z = blockIdx.z;
     const half_t* a0 = p.a0 + z * p.a_bs;
     const half_t* a1 = p.a1 ? p.a1 + z * p.a_bs : nullptr;
@@ -890,7 +748,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
         if (p.flags & EP_QUICK_GELU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
         if (p.flags & EP_GELU) v = gelu_erf(v);
         if (p.resid) v += (float)p.resid[z * p.r_bs + (long)m * p.ldr + no];
-        if (p.flags & EP_NCHW) {
+        if (p.flags & EP_TRANSPOSE) {
+            ((half_t*)p.out)[z * p.o_bs + ((long)ri.b * p.N + no) * p.ldo + rem] = (half_t)v;
+        } else if (p.flags & EP_NCHW) {
             ((float*)p.out)[z * p.o_bs + ((long)ri.b * p.n_real + no) * p.rows_per_batch + rem] = v;
         } else if (p.flags & EP_OUT_F32) {
             ((float*)p.out)[z * p.o_bs + (long)m * p.ldo + no] = v;
@@ -902,6 +762,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
 
 // Split-K second pass: out = epilogue(sum over slices, in slice order => bit-reproducible).  One thread per 4 columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) {
+    if (p.gate && *p.gate == 0) return;
     const long quads = (long)p.M * (p.N / 4);
     const long total = quads * batch;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -945,11 +806,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -961,33 +822,10 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, int WR, int WC, int NS, bool GEGLU>
-static int launch_pipe2(const GemmP& p, int batch, hipStream_t s) {
-    constexpr int SMEM = NS * (BM + BN) * 64;
-    constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_pipe_kernel<BM, BN, WR, WC, NS, GEGLU>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
-    const int tiles = cdiv(p.M, BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(NT), SMEM, s, p);
-    SDMI_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-template <int BM, int BN, int WR, int WC, int NS>
-static int launch_pipe(const GemmP& p, int batch, hipStream_t s) {
-    if constexpr ((BN / WC) % 64 == 0) {
-        if (p.flags & EP_GEGLU) return launch_pipe2<BM, BN, WR, WC, NS, true>(p, batch, s);
-    }
-    return launch_pipe2<BM, BN, WR, WC, NS, false>(p, batch, s);
-}
-
-template <int BM, int BN, bool GEGLU>
+template <int BM, int BN, bool GEGLU, bool TR = false>
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
-    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU>;
+    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1016,6 +854,7 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
     if constexpr ((BN / 4) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true>(p, batch, s);
     }
+    if (p.flags & EP_TRANSPOSE) return launch_pingpong2<BM, BN, false, true>(p, batch, s);
     return launch_pingpong2<BM, BN, false>(p, batch, s);
 }
 
@@ -1024,6 +863,7 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
     if constexpr ((BN / WC) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true>(p, batch, s);
     }
+    if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, true>(p, batch, s);
     return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false>(p, batch, s);
 }
 
@@ -1047,15 +887,17 @@ enum GemmCfg {
     CFG_256x128 = 6,      // 8 waves, BK 64, 96 KB
     CFG_128x64 = 7,       // 4 waves, BK 64, 48 KB
     CFG_128x320 = 8,      // 8 waves, BK 64, 112 KB     (mid levels: twice the tiles of 256x320 at 91 flop/B)
-    CFG_COUNT = 9
+    CFG_128x160 = 9,      // 4 waves, BK 64, 72 KB      (2 blocks/CU; the HBM-bound short-K 1x1 layers with N = 320 / 640 / 1280:
+                          //                             one block's epilogue / prologue overlaps the other's K loop)
+    CFG_COUNT = 10
 };
-static const int kCfgBM[CFG_COUNT] = {128, 256, 64, 128, 256, 256, 256, 128, 128};
-static const int kCfgBN[CFG_COUNT] = {128, 64, 64, 128, 256, 320, 128, 64, 320};
+static const int kCfgBM[CFG_COUNT] = {128, 256, 64, 128, 256, 256, 256, 128, 128, 128};
+static const int kCfgBN[CFG_COUNT] = {128, 64, 64, 128, 256, 320, 128, 64, 320, 160};
 static const char* kCfgName[CFG_COUNT] = {"gemm_mfma_128x128", "gemm_mfma_256x64", "gemm_mfma_64x64", "gemm_mfma_128x128k32",
                                           "gemm_mfma_256x256", "gemm_mfma_256x320", "gemm_mfma_256x128", "gemm_mfma_128x64",
-                                          "gemm_mfma_128x320"};
+                                          "gemm_mfma_128x320", "gemm_mfma_128x160"};
 // relative MFMA efficiency of each tile once the chip is full (measured, profiles/): used only to rank candidates
-static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f, 0.60f, 0.64f, 0.95f};
+static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f, 0.60f, 0.64f, 0.95f, 0.70f};
 
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
@@ -1064,9 +906,13 @@ int g_force_gemm_split = 0;
 // proj_in / proj_out, ~5 % of the C1 job at 2-3x their HBM floor with one 256x320 tile per CU) — e.g. SDMI_SHORTK_CFG=<128x64 id>
 // to try several co-resident workgroups per CU in a same-box A/B (lead 2).
 int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e ? atoi(e) : -1; }();
+int g_shortk_max_k = [] { const char* e = getenv("SDMI_SHORTK_MAXK"); return e ? atoi(e) : 448; }();
+int g_geglu_gemm_cfg = [] { const char* e = getenv("SDMI_GEGLU_CFG"); return e ? atoi(e) : -1; }();
+int g_vt_mode = [] { const char* e = getenv("SDMI_VT_MODE"); return e ? atoi(e) : 1; }();
 // 4 (default): ping-pong kernel for the 256-row tiles and the 128x320 tile (+5..22 % over the two-stage kernel per shape,
-// bit-identical results), two-stage kernels elsewhere.  3: ping-pong for the 256-row tiles only.  0: two-stage kernels only.  1: BK=32 ring kernels for the big tiles, 2: also
-// 128x128 — kept selectable; measured 7-25 % SLOWER than the two-stage kernels (profiles/r01_microbench_pipe.txt).
+// bit-identical results), two-stage kernels elsewhere.  3: ping-pong for the 256-row tiles only.  0: two-stage kernels only.
+// (A BK = 32 ring-buffer kernel was measured 7-25 % SLOWER than the two-stage kernels in round 1 — profiles/r01_microbench_pipe.txt —
+// and has been removed.)
 int g_gemm_pipe_default = [] { const char* e = getenv("SDMI_GEMM_PIPE"); return e ? atoi(e) : 4; }();
 int g_gemm_pipe = g_gemm_pipe_default;
 
@@ -1074,12 +920,12 @@ static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;
     if (p.N % kCfgBN[cfg]) return false;
     if (cfg == CFG_256x64 || cfg == CFG_256x128) return false;         // measured never best: not instantiated
-    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320)) return false;   // wave tile not a multiple of 64
+    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160)) return false;   // wave tile not a multiple of 64
     return true;
 }
 
 // workgroups of each config that fit on one CU (LDS-limited)
-static const int kCfgOcc[CFG_COUNT] = {2, 2, 4, 3, 1, 1, 1, 3, 1};
+static const int kCfgOcc[CFG_COUNT] = {2, 2, 4, 3, 1, 1, 1, 3, 1, 2};
 
 // Expected relative throughput of (cfg, split): tile efficiency x chip fill / split-K overhead.  Fitted to the sweeps in
 // profiles/ (tools/bench_kernels.py): the first workgroup per CU brings ~80 % of a config's rate, co-resident ones the
@@ -1116,7 +962,9 @@ static int pick_cfg(const GemmP& p, int batch, int* split_out, bool allow_split)
         return g_force_gemm_cfg;
     }
     if (g_force_gemm_split == 1) allow_split = false;
-    if (g_shortk_gemm_cfg >= 0 && p.K / 64 < 8 && cfg_valid(g_shortk_gemm_cfg, p)) return g_shortk_gemm_cfg;
+    if (g_shortk_gemm_cfg >= 0 && p.taps == 1 && p.K <= g_shortk_max_k && !(p.flags & EP_GEGLU) && cfg_valid(g_shortk_gemm_cfg, p))
+        return g_shortk_gemm_cfg;
+    if (g_geglu_gemm_cfg >= 0 && (p.flags & EP_GEGLU) && cfg_valid(g_geglu_gemm_cfg, p)) return g_geglu_gemm_cfg;
     const int cands[] = {CFG_256x320, CFG_256x256, CFG_128x320, CFG_128x128_K32, CFG_128x128, CFG_128x64, CFG_64x64};
     int best = -1;
     float best_score = -1.f;
@@ -1160,7 +1008,10 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         return 0;
     }
     int split = 1;
-    const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW)) && p.N % 4 == 0;
+    const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE)) && p.N % 4 == 0;
+    SDMI_REQUIRE(!(p.flags & EP_TRANSPOSE) || (p.rows_per_batch % 4 == 0 && p.M % 4 == 0 && !(p.flags & (EP_GEGLU | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW)) &&
+                                               !p.resid && !p.rowbias),
+                 "EP_TRANSPOSE: rows per image must be a multiple of 4; no residual / GEGLU / fp32 output");
     const int cfg = pick_cfg(p, batch, &split, can_split);
     // ping-pong kernel: every weight row must exist (no n_valid masking) and a (tap, source) segment must fit the zero page
     const bool phase = use_glds && (g_gemm_pipe == 3 || g_gemm_pipe == 4) &&
@@ -1169,10 +1020,8 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
                        ((p.taps == 1 && p.stride == 1 && !p.up && p.Ho == p.Hi && p.Wo == p.Wi) ||
                         (p.M / p.rows_per_batch < 128 && (p.up ? 2 : 1) * p.Hi < 2040 && (p.up ? 2 : 1) * p.Wi < 2040 &&
                          p.stride * p.Ho < 2040 && p.stride * p.Wo < 2040));
-    const bool pipe = !phase && use_glds && g_gemm_pipe != 0 && g_gemm_pipe < 3 && (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_128x320 ||
-                                                                 (g_gemm_pipe > 1 && cfg == CFG_128x128));
     if (split > 1) {
-        const int nk = p.K / ((cfg == CFG_128x128_K32 || pipe) ? 32 : 64);
+        const int nk = p.K / (cfg == CFG_128x128_K32 ? 32 : 64);
         p.splitk_steps = cdiv(nk, split);
         p.splitk = cdiv(nk, p.splitk_steps);
         if (p.splitk <= 1) { p.splitk = 0; split = 1; }
@@ -1181,8 +1030,8 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     }
     std::string pname;
     if (prof_enabled()) {
-        pname = std::string(kCfgName[cfg]) + (pipe ? "p" : "") + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
-                ((p.flags & EP_GEGLU) ? "_geglu" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
+        pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
+                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 (batch > 1 ? " x" + std::to_string(batch) : "");
     }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);
@@ -1212,18 +1061,6 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         if (rc) return 1;
         return reduce.run();
     }
-    if (pipe) {
-        int rc = 1;
-        switch (cfg) {
-            case CFG_256x320: rc = launch_pipe<256, 320, 4, 2, 4>(p, batch, s); break;
-            case CFG_256x256: rc = launch_pipe<256, 256, 4, 2, 4>(p, batch, s); break;
-            case CFG_128x320: rc = launch_pipe<128, 320, 2, 4, 4>(p, batch, s); break;
-            case CFG_128x128: rc = launch_pipe<128, 128, 2, 2, 4>(p, batch, s); break;
-            default: break;
-        }
-        if (rc) return 1;
-        return reduce.run();
-    }
     switch (cfg) {
         SDMI_CASE(CFG_128x128, 128, 128, 2, 2, 64)
         SDMI_CASE(CFG_64x64, 64, 64, 4, 1, 64)
@@ -1232,6 +1069,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_CASE(CFG_256x320, 256, 320, 4, 2, 64)
         SDMI_CASE(CFG_128x64, 128, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x320, 128, 320, 2, 4, 64)
+        SDMI_CASE(CFG_128x160, 128, 160, 2, 2, 64)
     }
 #undef SDMI_CASE
     set_error("bad gemm config");

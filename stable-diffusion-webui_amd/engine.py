@@ -155,6 +155,16 @@ class Engine:
         check(lib.sdmi_unet_set_context(self.handle, ptr(context), dtype_code(context), bn, l, stream_ptr()), "set_context")
         self._ctx_shape = (bn, l)
 
+    def set_context_cached(self, context: torch.Tensor):
+        """set_context for callers that cannot know whether the context changed (SdUnet.forward inside the webui): compared with
+        the cached copy on the device, re-projected only if different — no host synchronisation (sdmi_unet_set_context_cached)."""
+        if context.dtype not in (torch.float16, torch.float32):
+            context = context.float()
+        context = context.contiguous()
+        bn, l, _ = context.shape
+        check(lib.sdmi_unet_set_context_cached(self.handle, ptr(context), dtype_code(context), bn, l, stream_ptr()), "set_context_cached")
+        self._ctx_shape = (bn, l)
+
     def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
                      y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections."""
@@ -194,6 +204,21 @@ class Engine:
         f = 2 ** (nlev - 1)
         out = torch.empty((b, 2 * self.vae_cfg.z_channels, hh // f, ww // f), dtype=torch.float32, device=x.device)
         check(lib.sdmi_vae_encode(self.handle, ptr(x), dtype_code(x), ptr(out), b, hh, ww, stream_ptr()), "vae_encode")
+        return out
+
+    def taps(self) -> dict:
+        """Block outputs of the last UNet forward / VAE decode recorded under option "trace": {reference module name: fp16 NCHW
+        tensor} (parity error budget; see sdmi_engine_tap_*)."""
+        out = {}
+        dev = torch.device("cuda", self.device)
+        for i in range(int(lib.sdmi_engine_tap_count(self.handle))):
+            name = C.create_string_buffer(256)
+            dims = (C.c_int64 * 4)()
+            check(lib.sdmi_engine_tap_info(self.handle, i, name, 256, dims), "tap_info")
+            b, h, w, c = (int(d) for d in dims)
+            t = torch.empty((b, h, w, c), dtype=torch.float16, device=dev)
+            check(lib.sdmi_engine_tap_read(self.handle, i, ptr(t), stream_ptr()), "tap_read")
+            out[name.value.decode()] = t.permute(0, 3, 1, 2)
         return out
 
     def arena_bytes(self) -> int:

@@ -134,3 +134,112 @@ def max_over_ranks(value: float, device="cpu") -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# sharded job entry: split all_seeds = [0, batch_size * n_iter) across ranks, gather the uint8 images
+# ------------------------------------------------------------------------------------------------------------------------------
+_PER_IMAGE_FIELDS = ("c", "uc", "y", "uy", "hr_c", "hr_uc", "refiner_c", "refiner_uc", "refiner_y", "refiner_uy", "init_images")
+
+
+def _slice_rows(v, lo, hi, n_total):
+    """Rows [lo, hi) of a per-image field: tensors / lists with a leading dimension of n_total, or the prompt_parser containers."""
+    if v is None:
+        return None
+    from . import prompt_parser
+    if prompt_parser.is_multicond(v):
+        return prompt_parser.MulticondLearnedConditioning((hi - lo,), v.batch[lo:hi])
+    if isinstance(v, (list, tuple)):
+        return list(v[lo:hi]) if len(v) == n_total else v
+    if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n_total:
+        return v[lo:hi]
+    return v
+
+
+def shard_job(p, world: int, rank: int):
+    """The sub-job of rank ``rank``: a shallow copy of ``p`` holding images [lo, hi) of the global job with their global seeds
+    (``seed + global_index``, modules/processing.py:901-909) — so a rank's images are the single-process images (own generator per
+    image, modules/rng.py:108; per-image CFG combine, modules/sd_samplers_cfg_denoiser.py:78-80).  The per-call batch size is kept
+    at ``p.batch_size`` (bit-identity with a single process running the same batch size holds call by call); a rank with fewer
+    than batch_size images left runs one smaller last batch, exactly like the reference's last iteration would."""
+    import copy
+    n_total = p.batch_size * p.n_iter
+    lo, hi = shard_range(n_total, world, rank)
+    seed = 1000 if p.seed is None or isinstance(p.seed, (list, tuple)) or p.seed == -1 else int(p.seed)
+    all_seeds = list(p.seed) if isinstance(p.seed, (list, tuple)) else [seed + (i if p.subseed_strength == 0 else 0) for i in range(n_total)]
+    subseed = 2000 if p.subseed is None or isinstance(p.subseed, (list, tuple)) or p.subseed == -1 else int(p.subseed)
+    all_subseeds = list(p.subseed) if isinstance(p.subseed, (list, tuple)) else [subseed + i for i in range(n_total)]
+    q = copy.copy(p)
+    count = hi - lo
+    for f in _PER_IMAGE_FIELDS:
+        if hasattr(q, f):
+            setattr(q, f, _slice_rows(getattr(p, f), lo, hi, n_total))
+    for f in ("latent_mask",):
+        if hasattr(q, f) and torch.is_tensor(getattr(p, f)) and getattr(p, f).shape[0] == n_total and n_total > 1:
+            setattr(q, f, getattr(p, f)[lo:hi])
+    q.seed, q.subseed = all_seeds[lo:hi], all_subseeds[lo:hi]
+    q.batch_size = max(1, min(p.batch_size, count))
+    q.n_iter = (count + q.batch_size - 1) // q.batch_size if count else 0
+    q.extra_generation_params = dict(p.extra_generation_params)
+    return q, lo, hi, all_seeds
+
+
+def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Optional[int] = None, gather: bool = True):
+    """``process_images`` for a job sharded by independent images over the ranks of the default process group (one process per
+    GPU).  No per-step communication: each rank runs its contiguous slice of the job, then ONE gather of the uint8 images to
+    rank 0 (RCCL gather of [count, H, W, 3] bytes).  Returns the ``Processed`` of the whole job on rank 0 and of the rank's own
+    slice elsewhere.  ``runner`` defaults to processing.process_images; ``world`` / ``rank`` override the process group (used to
+    replay one rank's slice in a single process; implies no gather)."""
+    from . import processing
+    runner = runner or processing.process_images
+    explicit = world is not None
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    q, lo, hi, all_seeds = shard_job(p, world, rank)
+    n_total = p.batch_size * p.n_iter
+    if hi > lo:
+        if q.n_iter * q.batch_size != hi - lo:                # ragged tail: full batches first, then the remainder as its own job
+            full = (hi - lo) // q.batch_size * q.batch_size
+            parts = []
+            for a, b in ((0, full), (full, hi - lo)):
+                if b > a:
+                    parts.append(runner(_with_rows(q, a, b, hi - lo)))
+            res = parts[0]
+            for extra in parts[1:]:
+                res.images = list(res.images) + list(extra.images)
+                if res.latents is not None and extra.latents is not None:
+                    res.latents = torch.cat([res.latents, extra.latents])
+        else:
+            res = runner(q)
+    else:
+        res = processing.Processed(p, [], all_seeds[0] if all_seeds else -1, [], None)
+    res.shard = (lo, hi)
+    if explicit or world == 1 or not gather:
+        return res
+    counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    if res.images:
+        mine = torch.from_numpy(np.stack(res.images)).to(dev)
+    else:
+        mine = torch.zeros((0, p.height, p.width, 3), dtype=torch.uint8, device=dev)
+    allv = gather_to_rank0(mine, counts)
+    if dist.get_rank() == 0:
+        res.images = list(allv.cpu().numpy())
+        res.all_seeds = all_seeds
+        res.shard = (0, n_total)
+    return res
+
+
+def _with_rows(q, a, b, n):
+    """Copy of sub-job ``q`` (n images) restricted to its rows [a, b), as a batch_size x n_iter job of its own."""
+    import copy
+    r = copy.copy(q)
+    for f in _PER_IMAGE_FIELDS:
+        if hasattr(r, f):
+            setattr(r, f, _slice_rows(getattr(q, f), a, b, n))
+    r.seed, r.subseed = list(q.seed[a:b]), list(q.subseed[a:b])
+    r.batch_size = min(q.batch_size, b - a)
+    r.n_iter = (b - a) // r.batch_size
+    return r

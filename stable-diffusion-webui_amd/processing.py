@@ -208,7 +208,8 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
             return samples
         decoded_samples = None
         if self.latent_scale_mode is None:                   # image-space upscaler: the first pass is decoded (:1353-1354)
-            decoded_samples = decode_latent_batch(self.sd_model, samples)
+            # decoded by the model that is loaded NOW (the refiner, if it switched in during the first pass): :1353-1354 use shared.sd_model
+            decoded_samples = decode_latent_batch(self.sampler.sd_model if self.sampler is not None else self.sd_model, samples)
         first_model = self.sd_model
         if self.hr_sd_model is not None:                     # :1360-1361 reload_model_weights(hr_checkpoint_info): both stay resident
             self.sd_model = self.hr_sd_model
@@ -370,12 +371,13 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
                          seed_resize_from_h=p.seed_resize_from_h, seed_resize_from_w=p.seed_resize_from_w,
                          eta_noise_seed_delta=shared.opts.eta_noise_seed_delta, device=dev)      # :949
         c, uc = prompt_parser.slice_conds(p.c, lo, hi, dev), prompt_parser.slice_conds(p.uc, lo, hi, dev)
-        if p.y is not None:
-            p_y_all, p_uy_all = p.y, p.uy
-            p.y, p.uy = p_y_all[lo:hi].to(dev), p_uy_all[lo:hi].to(dev)
-        samples = p.sample(conditioning=c, unconditional_conditioning=uc, seeds=p.seeds, subseeds=None,
-                           subseed_strength=0, prompts=None)                                      # :987-988
-        if p.y is not None:
+        p_y_all, p_uy_all = p.y, p.uy
+        try:
+            if p_y_all is not None:
+                p.y, p.uy = p_y_all[lo:hi].to(dev), p_uy_all[lo:hi].to(dev)
+            samples = p.sample(conditioning=c, unconditional_conditioning=uc, seeds=p.seeds, subseeds=None,
+                               subseed_strength=0, prompts=None)                                  # :987-988
+        finally:                                                     # an interrupt / error must not leave p holding the batch slice
             p.y, p.uy = p_y_all, p_uy_all
         # the model that finished the sampling decodes (a hires checkpoint or the refiner is still "loaded" at :1002 / :1459)
         decode_model = p.sampler.sd_model if getattr(p, "sampler", None) is not None else p.sd_model

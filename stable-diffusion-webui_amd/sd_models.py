@@ -18,17 +18,69 @@ from . import schema, shared
 from .engine import Engine
 
 
-def read_state_dict(checkpoint_file: str, map_location="cpu") -> dict:
-    """modules/sd_models.py:312-329: .safetensors via safetensors, anything else via torch.load (weights_only)."""
+# modules/sd_models.py:243-251 — old SD1 checkpoints store the CLIP text model one level up; SD 2.1 Turbo ships in SGM layout
+checkpoint_dict_replacements_sd1 = {
+    'cond_stage_model.transformer.embeddings.': 'cond_stage_model.transformer.text_model.embeddings.',
+    'cond_stage_model.transformer.encoder.': 'cond_stage_model.transformer.text_model.encoder.',
+    'cond_stage_model.transformer.final_layer_norm.': 'cond_stage_model.transformer.text_model.final_layer_norm.',
+}
+checkpoint_dict_replacements_sd2_turbo = {
+    'conditioner.embedders.0.': 'cond_stage_model.',
+}
+
+
+def transform_checkpoint_dict_key(k, replacements):
+    """modules/sd_models.py:254-259"""
+    for text, replacement in replacements.items():
+        if k.startswith(text):
+            k = replacement + k[len(text):]
+    return k
+
+
+def get_state_dict_from_checkpoint(pl_sd: dict) -> dict:
+    """modules/sd_models.py:262-281: unwrap a pytorch-lightning "state_dict" and apply the key fix-ups, in place."""
+    pl_sd = pl_sd.pop("state_dict", pl_sd)
+    pl_sd.pop("state_dict", None)
+    ln = pl_sd.get('conditioner.embedders.0.model.ln_final.weight')
+    is_sd2_turbo = ln is not None and ln.size()[0] == 1024
+    table = checkpoint_dict_replacements_sd2_turbo if is_sd2_turbo else checkpoint_dict_replacements_sd1
+    sd = {}
+    for k, v in pl_sd.items():
+        new_key = transform_checkpoint_dict_key(k, table)
+        if new_key is not None:
+            sd[new_key] = v
+    pl_sd.clear()
+    pl_sd.update(sd)
+    return pl_sd
+
+
+def read_state_dict(checkpoint_file: str, print_global_state=False, map_location=None) -> dict:
+    """modules/sd_models.py:312-329: .safetensors through safetensors (mmap load_file, or a whole-file read when
+    opts.disable_mmap_load_safetensors), anything else through torch.load; then the key fix-ups of :262-281."""
     _, ext = os.path.splitext(checkpoint_file)
+    device = map_location or getattr(shared, "weight_load_location", None) or "cpu"
     if ext.lower() == ".safetensors":
         import safetensors.torch
-        sd = safetensors.torch.load_file(checkpoint_file, device=map_location)
+        if not getattr(shared.opts, "disable_mmap_load_safetensors", False):
+            pl_sd = safetensors.torch.load_file(checkpoint_file, device=str(device))
+        else:
+            pl_sd = safetensors.torch.load(open(checkpoint_file, 'rb').read())
+            pl_sd = {k: v.to(device) for k, v in pl_sd.items()}
     else:
-        sd = torch.load(checkpoint_file, map_location=map_location, weights_only=True)
-    sd = sd.pop("state_dict", sd)
-    sd.pop("state_dict", None)
-    return sd
+        pl_sd = torch.load(checkpoint_file, map_location=device, weights_only=True)
+    if print_global_state and "global_step" in pl_sd:
+        print(f"Global Step: {pl_sd['global_step']}")
+    return get_state_dict_from_checkpoint(pl_sd)
+
+
+# modules/sd_vae.py:13 — keys of a standalone VAE file that are not weights
+vae_ignore_keys = {"model_ema.decay", "model_ema.num_updates"}
+
+
+def load_vae_dict(filename: str, map_location=None) -> dict:
+    """modules/sd_vae.py:188-191"""
+    vae_ckpt = read_state_dict(filename, map_location=map_location)
+    return {k: v for k, v in vae_ckpt.items() if k[0:4] != "loss" and k not in vae_ignore_keys}
 
 
 def guess_unet_config(sd: dict) -> schema.UNetConfig:
@@ -65,10 +117,29 @@ class SdModel:
         self.engine.load_unet(self.unet_cfg, state_dict)
         self._checkpoint = state_dict                     # kept by reference: the "weights backup" LoRA rewrites start from
         self.has_vae = False
+        self.loaded_vae_file = None
+        self._vae_decoder_only = vae_decoder_only
         if load_vae and any(k.startswith(schema.VAE_PREFIX) for k in state_dict):
             self.engine.load_vae(self.vae_cfg, state_dict, decoder_only=vae_decoder_only)
             self.has_vae = True
         self.scale_factor = self.vae_cfg.scale_factor
+
+    # --- external VAE (modules/sd_vae.py:194-280): "SD VAE" setting / per-checkpoint .vae.safetensors ----------------------------
+    def load_vae(self, vae_file: Optional[str] = None, vae_source: str = "from unknown source", vae_dict: Optional[dict] = None):
+        """modules/sd_vae.py:194-235 load_vae: replace the first stage's weights by a standalone VAE file (keys WITHOUT the
+        ``first_stage_model.`` prefix, "loss*" and EMA bookkeeping keys dropped); ``vae_file=None`` restores the checkpoint's own
+        VAE (restore_base_vae, :246-252).  The engine re-packs the decoder (and encoder) in place."""
+        if vae_file is None and vae_dict is None:
+            if self.loaded_vae_file is not None:
+                self.engine.load_vae(self.vae_cfg, self._checkpoint, decoder_only=self._vae_decoder_only)
+            self.loaded_vae_file = None
+            return
+        if vae_dict is None:
+            assert os.path.isfile(vae_file), f"VAE {vae_source} doesn't exist: {vae_file}"
+            vae_dict = load_vae_dict(vae_file)
+        self.engine.load_vae(self.vae_cfg, vae_dict, prefix="", decoder_only=self._vae_decoder_only)
+        self.has_vae = True
+        self.loaded_vae_file = vae_file or "<dict>"
 
     def unet_checkpoint_tensor(self, engine_key: str) -> torch.Tensor:
         """The unmodified checkpoint weight of a UNet layer (extensions-builtin/Lora/networks.py:423-432 keeps the same thing

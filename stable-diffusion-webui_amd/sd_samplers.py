@@ -298,9 +298,13 @@ class CFGDenoiser:
             uy, uncond = uncond.get("vector", uy), uncond["crossattn"]
         return cond, uncond, y, uy
 
-    def _ensure_context(self, ctx_parts):
-        """Cache the cross-attention K / V projections of the UNet batch's context rows (cat of ``ctx_parts``)."""
-        key = (tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ctx_parts),
+    def _ensure_context(self, ctx_parts, key_parts=None, tag=()):
+        """Cache the cross-attention K / V projections of the UNet batch's context rows (cat of ``ctx_parts``).  The cache is keyed
+        on ``key_parts`` — the tensors the rows were derived from: when opts.pad_cond_uncond(_v0) pads, ``ctx_parts`` are per-step
+        torch.cat temporaries whose address can be recycled by a DIFFERENT prompt-editing selection with the same shape, so the
+        key names the un-padded selections (+ the padding mode in ``tag``) instead."""
+        key_parts = ctx_parts if key_parts is None else key_parts
+        key = (tuple((t.data_ptr(), tuple(t.shape), t._version) for t in key_parts), tuple(tuple(t.shape) for t in ctx_parts), tag,
                getattr(self.sampler.sd_model.engine, "weights_version", 0))      # a LoRA rewrite invalidates the cached K / V
         if key != self._ctx_key:
             ctx = torch.cat([t.float() for t in ctx_parts]).contiguous()
@@ -372,10 +376,11 @@ class CFGDenoiser:
         skip_uncond = False                                   # :218-230
         if opts.skip_early_cond != 0. and self.step / self.total_steps <= opts.skip_early_cond:
             skip_uncond = True
-        elif (self.step % 2 or opts.s_min_uncond_all) and s_min_uncond > 0 and float(sigma[0]) < s_min_uncond:
-            skip_uncond = True
+        elif (self.step % 2 or opts.s_min_uncond_all) and s_min_uncond > 0 and float(sigma[0]) < s_min_uncond and not is_edit_model:
+            skip_uncond = True                                # NGMS; never for edit models (the reference's `and not is_edit_model`, :224)
         self.padded_cond_uncond = False
         self.padded_cond_uncond_v0 = False
+        src_tensor, src_uncond = tensor, uncond               # the selections before any padding temporaries (context-cache key)
         if opts.pad_cond_uncond_v0 and tensor.shape[1] != uncond.shape[1]:
             tensor, uncond = self.pad_cond_uncond_v0(tensor, uncond)
         elif opts.pad_cond_uncond and tensor.shape[1] != uncond.shape[1]:
@@ -383,7 +388,6 @@ class CFGDenoiser:
         if is_edit_model:
             if conds_list is not None:
                 raise AssertionError("AND is not supported for InstructPix2Pix checkpoint (unless using Image CFG scale = 1.0)")
-            skip_uncond = skip_uncond and opts.skip_early_cond != 0.         # NGMS is off for edit models (:224)
         split_calls = tensor.shape[1] != uncond.shape[1] and not skip_uncond      # :253-268: one UNet call per context length
         if is_edit_model and (split_calls or skip_uncond):
             raise NotImplementedError("InstructPix2Pix with skip-uncond or cond / uncond of different token counts")
@@ -451,7 +455,9 @@ class CFGDenoiser:
             eng.unet_forward(x_in[n_cond:], ts[n_cond:], uncond.float().contiguous(), None if yy is None else yy[n_cond:], out=eps[n_cond:])
             self._ctx_key = None
         else:
-            self._ensure_context([tensor] if skip_uncond else [tensor, uncond, uncond] if is_edit_model else [tensor, uncond])
+            self._ensure_context([tensor] if skip_uncond else [tensor, uncond, uncond] if is_edit_model else [tensor, uncond],
+                                 [src_tensor] if skip_uncond else [src_tensor, src_uncond, src_uncond] if is_edit_model else [src_tensor, src_uncond],
+                                 (self.padded_cond_uncond, self.padded_cond_uncond_v0))
             eng.unet_forward(x_in, ts, None, yy, out=eps)
 
         # ---- combine (:73-82, :270-290).  The fused kernel takes eps = [cond(B) | uncond(B)]; the general cases are reduced to it
@@ -1223,6 +1229,17 @@ sampler_extra_params = {                                 # modules/sd_samplers_k
     'sample_dpm_fast': ['s_noise'],
 }
 
+def _sampler_extra_args(sampler, p, conditioning, unconditional_conditioning, image_conditioning):
+    """The extra_args both sampler families hand to the CFG denoiser (modules/sd_samplers_kdiffusion.py:215-221,
+    modules/sd_samplers_timesteps.py:136-143).  In the reference the SDXL vector conditioning travels inside the cond dicts; here it
+    is p.y / p.uy, for the k-diffusion AND the timestep samplers (DDIM, DDIM CFG++, PLMS, UniPC)."""
+    args = {'cond': conditioning, 'image_cond': image_conditioning, 'uncond': unconditional_conditioning,
+            'cond_scale': p.cfg_scale, 's_min_uncond': sampler.s_min_uncond}
+    if getattr(p, 'y', None) is not None:
+        args['y'], args['uy'] = p.y, p.uy
+    return args
+
+
 class KDiffusionSampler(Sampler):
     def __init__(self, func, sd_model, options=None):
         super().__init__(func.__name__, sd_model)
@@ -1267,16 +1284,7 @@ class KDiffusionSampler(Sampler):
         return sigmas.cpu()
 
     def _extra(self, p, conditioning, unconditional_conditioning, image_conditioning):
-        self.sampler_extra_args = {
-            'cond': conditioning,
-            'image_cond': image_conditioning,
-            'uncond': unconditional_conditioning,
-            'cond_scale': p.cfg_scale,
-            's_min_uncond': self.s_min_uncond,
-        }
-        if getattr(p, 'y', None) is not None:
-            self.sampler_extra_args['y'] = p.y
-            self.sampler_extra_args['uy'] = p.uy
+        self.sampler_extra_args = _sampler_extra_args(self, p, conditioning, unconditional_conditioning, image_conditioning)
         return self.sampler_extra_args
 
     def sample_img2img(self, p, x, noise, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
@@ -1396,9 +1404,7 @@ class CompVisSampler(Sampler):
         extra_params_kwargs = self.initialize(p)
         extra_params_kwargs['timesteps'] = timesteps
         self.last_latent = x
-        self.sampler_extra_args = {'cond': conditioning, 'image_cond': image_conditioning,
-                                   'uncond': unconditional_conditioning, 'cond_scale': p.cfg_scale,
-                                   's_min_uncond': self.s_min_uncond}
+        self.sampler_extra_args = _sampler_extra_args(self, p, conditioning, unconditional_conditioning, image_conditioning)
         extra = self.sampler_extra_args
         x0 = x.clone()
         return self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,
@@ -1423,9 +1429,7 @@ class CompVisSampler(Sampler):
             extra_params_kwargs['is_img2img'] = True
         self.model_wrap_cfg.init_latent = x
         self.last_latent = x
-        self.sampler_extra_args = {'cond': conditioning, 'image_cond': image_conditioning,
-                                   'uncond': unconditional_conditioning, 'cond_scale': p.cfg_scale,
-                                   's_min_uncond': self.s_min_uncond}
+        self.sampler_extra_args = _sampler_extra_args(self, p, conditioning, unconditional_conditioning, image_conditioning)
         extra = self.sampler_extra_args
         return self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=extra, disable=False,
                                                                   callback=self.callback_state, **extra_params_kwargs))

@@ -68,17 +68,12 @@ class Mi355xUnet(SdUnet):
             x = x.float()
         y = kwargs.get("y", None)
         # The context is step-invariant unless prompt editing swaps it, so its K / V projections are cached — validated by
-        # CONTENT: the webui re-catenates cond | uncond every step (sd_samplers_cfg_denoiser.py:246), and the caching allocator
-        # hands the next step's (or the next job's) tensor the same address, so an address / version key would go stale.
-        version = getattr(self.engine, "weights_version", 0)
-        last = self._last_ctx
-        same = (last is not None and self._ctx_key == version and last.shape == context.shape and last.dtype == context.dtype
-                and last.device == context.device and bool(torch.equal(last, context)))
+        # CONTENT, on the DEVICE: the webui re-catenates cond | uncond every step (sd_samplers_cfg_denoiser.py:246) and the caching
+        # allocator hands the next step's (or the next job's) tensor the same address, so an address / version key would go stale,
+        # and a host-side torch.equal would cost a device -> host synchronisation per UNet evaluation.  The engine compares the
+        # new rows with its cached fp16 copy in a kernel and predicates the re-projection launches on the result.
+        self.engine.set_context_cached(context)
         ctx = None
-        if not same:
-            self._last_ctx = context.detach().clone()
-            self._ctx_key = version
-            ctx = context.to(x.dtype)
         return self.engine.unet_forward(x, timesteps, ctx, y)
 
 

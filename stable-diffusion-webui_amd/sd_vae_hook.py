@@ -13,7 +13,12 @@ from .engine import Engine
 
 
 def install(sd_model, device_index: int = 0):
+    """Idempotent: the webui fires on_model_loaded again on the SAME sd_model object after every in-place checkpoint reload
+    (modules/sd_models.py:994) and every VAE switch (modules/sd_vae.py:280).  A re-install closes the previous engine, keeps the
+    ORIGINAL torch decode as the thing uninstall() restores, and packs the (possibly new) first-stage weights afresh."""
     fsm = sd_model.first_stage_model
+    if hasattr(fsm, "_mi355x_engine"):
+        uninstall(sd_model)
     sd = {schema.VAE_PREFIX + k: v for k, v in fsm.state_dict().items()}
     cfg = schema.sdxl_vae() if getattr(sd_model, "is_sdxl", False) else schema.sd15_vae()
     cfg.scale_factor = 1.0                         # the caller already divided by scale_factor (ddpm_edit.py:734 twin)

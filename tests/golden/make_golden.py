@@ -122,6 +122,24 @@ def gen_vae():
     print("vae_decoder.npz vae_encoder.npz")
 
 
+def gen_vae_512():
+    """The reference's own full-size VAEDecoder at the BENCH shape (64x64 latent -> 512x512 image); the fixture keeps every 4th
+    pixel of each axis (3 x 128 x 128 fp32, ~190 KB) — tests/test_gpu_c1_parity.py compares the same sub-lattice."""
+    stub = types.ModuleType("modules.models.sd3.mmdit")
+    stub.MMDiT = object
+    for name in ("modules", "modules.models", "modules.models.sd3"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["modules.models.sd3.mmdit"] = stub
+    m = load_by_path("ref_sd3_impls", "modules/models/sd3/sd3_impls.py")
+    with torch.no_grad():
+        dec = m.VAEDecoder(z_channels=4)
+        seeded_module_weights(dec, 777)
+        out = dec(seeded((1, 4, 64, 64), 778))
+        np.savez_compressed(os.path.join(OUT, "vae_decoder_512.npz"), full_out_512_sub4=out[:, :, ::4, ::4].contiguous().numpy(),
+                            full_out_512_mean=np.array(float(out.mean())), full_out_512_std=np.array(float(out.std())))
+    print("vae_decoder_512.npz")
+
+
 def gen_ddim():
     # stub the modules sd_samplers_timesteps_impl imports (k_diffusion is third-party and absent here)
     kd = types.ModuleType("k_diffusion")
@@ -1118,6 +1136,7 @@ if __name__ == "__main__":
     gen_philox()
     gen_subquad()
     gen_vae()
+    gen_vae_512()
     gen_ddim()
     gen_schedulers()
     gen_lora_names()

@@ -83,27 +83,78 @@ def test_sd_optimization_attention_inside_torch_module(dev):
         assert rel_l2(got.float().cpu(), ref) < 4e-3
 
 
-def test_vae_decode_hook_replaces_first_stage_decode(dev):
-    schema, hook = sub("schema"), sub("sd_vae_hook")
+def test_vae_decode_hook_install_uninstall_and_reinstall(dev):
+    """Boundary B4 executed: sd_vae_hook.install() on a stand-in sd_model whose first_stage_model is a torch AutoencoderKL (the
+    oracle's class has ldm's state-dict layout) — decode_first_stage -> first_stage_model.decode(z / scale) now runs the engine;
+    install() again (the webui re-fires on_model_loaded on the SAME object after a checkpoint reload, modules/sd_models.py:994, or a
+    VAE switch, modules/sd_vae.py:280) closes the previous engine, picks up the new weights, and uninstall() restores torch's decode."""
+    schema, hook, engine_mod = sub("schema"), sub("sd_vae_hook"), sub("engine")
     from oracle import vae as ov
-    cfg = schema.tiny_vae()
-    sd = schema.synthetic_state_dict(None, cfg, dtype=torch.float16)
-    okl = ov.build_vae(ov.tiny_vae_config(), sd)
+    cfg = ov.sd15_vae_config()                             # the hook assumes the real SD VAE geometry (ch 128, 4 levels)
+    okl = ov.AutoencoderKL(cfg).eval().requires_grad_(False)
+    from helpers import seeded_module_weights
+    seeded_module_weights(okl, 31)
+    original_decode = okl.decode
 
     class FakeSdModel:
         is_sdxl = False
         first_stage_model = okl
     m = FakeSdModel()
-    # the hook builds the engine with the default SD1.5 VAE config unless the model says otherwise: use the tiny config here
-    eng = sub("engine").Engine(0)
-    cfg1 = schema.tiny_vae(scale_factor=1.0)
-    eng.load_vae(cfg1, {schema.VAE_PREFIX + k: v for k, v in okl.state_dict().items()}, decoder_only=True)
-    z = seeded((2, 4, 16, 16), 3)
+    z = seeded((1, 4, 8, 8), 3)
     with torch.no_grad():
-        ref = okl.decode(z)                                # caller already divided by scale_factor
-    got = eng.vae_decode(z.to(dev))
-    assert rel_l2(got.cpu(), ref) < 5e-3
-    assert callable(hook.install) and callable(hook.uninstall)
+        ref = original_decode(z)                           # the caller already divided by scale_factor
+    eng1 = hook.install(m)
+    assert okl.decode is not original_decode and okl._torch_decode == original_decode
+    got = okl.decode(z.to(dev))
+    assert got.dtype == torch.float32 and rel_l2(got.cpu(), ref) < 2.5e-3
+    got16 = okl.decode(z.to(dev).half())                   # dtype_vae = fp16 callers get fp16 back
+    assert got16.dtype == torch.float16
+    # in-place weight change + second on_model_loaded: new engine, old one closed, original decode still remembered
+    seeded_module_weights(okl, 32)
+    with torch.no_grad():
+        ref2 = original_decode(z)
+    eng2 = hook.install(m)
+    assert eng1.handle is None and eng2 is not eng1 and okl._torch_decode == original_decode
+    got2 = okl.decode(z.to(dev))
+    assert rel_l2(got2.cpu(), ref2) < 2.5e-3 and rel_l2(got2.cpu(), ref) > 1e-2
+    hook.uninstall(m)
+    assert okl.decode == original_decode and eng2.handle is None and not hasattr(okl, "_mi355x_engine")
+
+
+def test_checkpoint_file_to_engine_and_external_vae(dev, tmp_path):
+    """Row a15: a synthetic SD1.x-schema checkpoint written as .safetensors (with the OLD CLIP key layout the reference fixes up,
+    modules/sd_models.py:243-281) -> read_state_dict -> load_model -> same UNet / VAE bits as the in-memory dict; then an external
+    VAE file (modules/sd_vae.py:194-235) replaces the first stage and None restores the checkpoint's own."""
+    import safetensors.torch
+    schema, sd_models = sub("schema"), sub("sd_models")
+    ucfg, vcfg = schema.tiny_unet(), schema.tiny_vae()
+    sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16)
+    disk = dict(sd)
+    disk["cond_stage_model.transformer.embeddings.position_ids"] = torch.arange(77)[None]
+    path = tmp_path / "tiny.safetensors"
+    safetensors.torch.save_file({k: v.contiguous() for k, v in disk.items()}, str(path))
+    a = sd_models.load_model(checkpoint_file=str(path), unet_cfg=ucfg, vae_cfg=vcfg, device=0)
+    b = sd_models.SdModel(sd, ucfg, vcfg, device=0)
+    assert "cond_stage_model.transformer.text_model.embeddings.position_ids" in a._checkpoint
+    x, t, ctx = seeded((2, 4, 16, 16), 1).to(dev), torch.tensor([500.0, 10.0]).to(dev), seeded((2, 77, 64), 2).to(dev)
+    assert torch.equal(a.engine.unet_forward(x, t, ctx), b.engine.unet_forward(x, t, ctx))
+    z = seeded((2, 4, 16, 16), 5).to(dev)
+    own = a.decode_first_stage(z)
+    assert torch.equal(own, b.decode_first_stage(z))
+    # external VAE with other weights
+    sd2 = schema.synthetic_state_dict(None, vcfg, dtype=torch.float16, seed=0xABCD)
+    ext = {k[len(schema.VAE_PREFIX):]: v.contiguous() for k, v in sd2.items() if k.startswith(schema.VAE_PREFIX)}
+    ext["model_ema.decay"] = torch.zeros(1)
+    vpath = tmp_path / "other.vae.safetensors"
+    safetensors.torch.save_file(ext, str(vpath))
+    a.load_vae(str(vpath), "from test")
+    swapped = a.decode_first_stage(z)
+    c = sd_models.SdModel({**sd, **sd2}, ucfg, vcfg, device=0)
+    assert torch.equal(swapped, c.decode_first_stage(z)) and not torch.equal(swapped, own)
+    a.load_vae(None)
+    assert torch.equal(a.decode_first_stage(z), own) and a.loaded_vae_file is None
+    for m in (a, b, c):
+        m.engine.close()
 
 
 def test_sampler_registry_drives_engine(dev):

@@ -80,6 +80,17 @@ def test_vae_decoder_matches_reference_full_size(golden_dir):
     assert rel_l2(out, z["full_out"]) < 1e-5
 
 
+def test_vae_decoder_matches_reference_at_bench_shape_512(golden_dir):
+    """oracle Decoder == the reference's VAEDecoder on a 64x64 latent (the 512x512 decode bench.py times); every 4th pixel kept."""
+    z = np.load(os.path.join(golden_dir, "vae_decoder_512.npz"))
+    dec = ovae.Decoder(ovae.sd15_vae_config())
+    seeded_module_weights(dec, 777)
+    with torch.no_grad():
+        out = dec(seeded((1, 4, 64, 64), 778))
+    assert rel_l2(out[:, :, ::4, ::4], z["full_out_512_sub4"]) < 1e-5
+    assert abs(float(out.mean()) - float(z["full_out_512_mean"])) < 1e-5 and abs(float(out.std()) - float(z["full_out_512_std"])) < 1e-5
+
+
 def test_vae_decoder_and_encoder_match_reference_small(golden_dir):
     z = np.load(os.path.join(golden_dir, "vae_decoder.npz"))
     cfg = ovae.tiny_vae_config()
