@@ -95,7 +95,10 @@ enum {
     SDMI_EP_OUT_F32  = 1,   /* store fp32 instead of fp16 */
     SDMI_EP_GEGLU    = 2,   /* W rows packed in (32 value | 32 gate) groups; out has N/2 columns: a*gelu(g) */
     SDMI_EP_NCHW     = 4,   /* store fp32 NCHW [B][n_real][Ho][Wo] */
-    SDMI_EP_BIAS_ROW = 8    /* bias indexed by output row m instead of column n */
+    SDMI_EP_BIAS_ROW = 8,   /* bias indexed by output row m instead of column n */
+    SDMI_EP_WRAP = 128,     /* 3x3 taps wrap around the image (Conv2d padding_mode = 'circular') instead of reading zero padding */
+    SDMI_EP_TRANSPOSE = 64  /* store out^T per image: out[b][n][m - b*Ho*Wo], row stride ldo (fp16; Ho*Wo % 4 == 0; no residual /
+                               rowbias): how the V projection is handed to the attention kernel as V^T [C][tokens] */
 };
 int sdmi_conv_gemm(const sdmi_conv_desc* d, void* stream);
 int64_t sdmi_conv_splitk_workspace_bytes(int M, int N, int K, int batch);
@@ -242,6 +245,11 @@ int sdmi_unet_finalize(sdmi_engine* e);            /* packs layouts; errors if a
 int sdmi_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim,
                             const int64_t* shape, int on_device);
 
+/* The same for a 1-D parameter: "<layer>.bias" of a conv / linear layer, "<norm>.weight" / "<norm>.bias" of a GroupNorm / LayerNorm.
+ * Where the bias deltas (`ex_bias`: network_full.py diff_b) and the LyCORIS norm modules (network_norm.py w_norm / b_norm) of
+ * extensions-builtin/Lora/networks.py:411-480 land. */
+int sdmi_unet_update_vector(sdmi_engine* e, const char* key, const void* data, int dtype, int64_t n, int on_device);
+
 /* out[rows*cols] fp32 = W + scale * (up[rows][rank] @ down[rank][cols]); W / up / down fp16 or fp32 device tensors.
  * The LoRA delta of extensions-builtin/Lora/network_lora.py:65-80 with lyco_helpers.rebuild_conventional (:9-15) and
  * network.py:196-216 finalize_updown (scale = alpha / rank * multiplier) folded into the weight in one pass. */
@@ -294,7 +302,10 @@ int sdmi_vae_encode(sdmi_engine* e, const void* x, int io_dtype, void* out_f32, 
 
 /* Introspection for tests / bench. */
 int64_t sdmi_engine_arena_bytes(sdmi_engine* e);
-int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "use_graph", "glds", "trace" */
+int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "glds", "trace" (activation taps),
+                                                                               "tiling" (p.tiling: padded 3x3 convs wrap around, modules/sd_hijack.py:311-318),
+                                                                               "vae_range_extend" (VAE decoder residual stream at 1/64 scale: the
+                                                                               engine's form of the fp16 -> fp32 VAE fallback, modules/processing.py:636-665) */
 
 /* Activation taps for the parity error budget (tests/test_gpu_c1_parity.py): with option "trace" = 1 the engine records, by
  * the reference's module name ("input_blocks.4.1", "middle_block.1.transformer_blocks.0", "decoder.up.2.block.1", ...), the

@@ -13,6 +13,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sdmi.h")
 
 F16, F32 = 0, 1
 EP_OUT_F32, EP_GEGLU, EP_NCHW, EP_BIAS_ROW = 1, 2, 4, 8
+EP_TRANSPOSE = 64
+EP_WRAP = 128
 
 
 class SdmiError(RuntimeError):
@@ -110,6 +112,7 @@ _SIGS = {
     "sdmi_clip_finalize": (_i, [_vp, _i]),
     "sdmi_clip_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sdmi_unet_update_weight": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
+    "sdmi_unet_update_vector": (_i, [_vp, C.c_char_p, _vp, _i, _i64, _i]),
     "sdmi_lora_merge": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sdmi_weight_hadamard": (_i, [_vp, _vp, _vp, _vp, _f, _i64, _vp]),
     "sdmi_weight_kron": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

@@ -26,9 +26,9 @@ namespace sdmi {
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-// VAR = experiment variants of the d = 40 level-0 self-attention, which is VALU / exp bound; selected with
-// SDMI_ATTN_OCC=<VAR>, none is the default until measured in a same-box A/B:
-//   0  production: register budget for 2 workgroups per CU (D <= 80) or 1
+// VAR = variants of the d = 40 level-0 self-attention, which is VALU / exp bound; selected with
+// SDMI_ATTN_OCC=<VAR> / sdmi_debug_set("attn_occ", VAR); 5 is the default for d = 40 (measured, see g_attn_occ):
+//   0  round-1 kernel: register budget for 2 workgroups per CU (D <= 80) or 1
 //   4  register budget for 4 workgroups per CU (128 VGPRs: a fourth wave per SIMD to hide the exp latency)
 //   5  4 + lazy rescale: the O accumulators are multiplied by alpha only when some lane's running max moved (alpha == 1 otherwise,
 //      so the result is unchanged; after the first few KV tiles the max rarely moves) — 16 v_pk_mul_f32 less per tile
@@ -343,7 +343,8 @@ int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, 
 
 int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e) : 0; }();
 
-int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 0; }();
+// default 5 since round 2: same-box A/B on the C1 job (profiles/r02_knob_sweep.md) — self-attention 72.4 -> 69.5 ms per job
+int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 5; }();
 
 template <int D, int KVT, int VAR = 0>
 static int launch_attn_d(const AttnP& p, hipStream_t s) {

@@ -18,6 +18,7 @@ int engine_clip_forward(sdmi_engine* e, int slot, const int* tokens, const float
                         int apply_final_ln, float* out, float* pooled, hipStream_t s);
 int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_vae_finalize(sdmi_engine* e);
+int engine_unet_update_vector(sdmi_engine* e, const char* key, const void* data, int dtype, int64_t n, int on_device);
 int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s, bool conditional = false);
 }  // namespace sdmi
 
@@ -377,6 +378,12 @@ int sdmi_clip_forward(sdmi_engine* e, int slot, const void* tokens, const void* 
                                (float*)pooled, (hipStream_t)stream);
     API_GUARD_END
 }
+int sdmi_unet_update_vector(sdmi_engine* e, const char* key, const void* data, int dtype, int64_t n, int on_device) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_unet_update_vector(e, key, data, dtype, n, on_device);
+    API_GUARD_END
+}
 int sdmi_vae_configure(sdmi_engine* e, const sdmi_vae_config* cfg) {
     API_GUARD_BEGIN
     SDMI_REQUIRE(e && cfg, "null argument");
@@ -435,6 +442,8 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "gemm_shortk_maxk") g_shortk_max_k = value;
     else if (n == "gemm_geglu_cfg") g_geglu_gemm_cfg = value;
     else if (n == "vt_mode") g_vt_mode = value;
+    else if (n == "tile_order") g_tile_order = value;
+    else if (n == "conv_korder") g_conv_korder = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "attn_occ") g_attn_occ = value;
     else if (n == "gemm_split") g_force_gemm_split = value;
@@ -469,8 +478,9 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     const std::string n(name);
     if (n == "force_generic") e->force_generic = value != 0;
     else if (n == "glds") e->use_glds = value != 0;
-    else if (n == "use_graph") e->use_graph = value != 0;
     else if (n == "trace") { e->trace = value != 0; e->taps.clear(); }
+    else if (n == "tiling") e->tiling = value != 0;
+    else if (n == "vae_range_extend") e->vae_stream_scale = value ? 1.0f / 64.0f : 1.0f;
     else { set_error("unknown option " + n); return 1; }
     return 0;
     API_GUARD_END

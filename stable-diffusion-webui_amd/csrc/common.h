@@ -71,6 +71,15 @@ struct GemmP {
     int splitk;
     int splitk_steps;     // BK-steps per slice
     long long* dbg;       // tuning only: per-wave section timers of the ping-pong kernel (sdmi_debug_set gemm_dbg_lo/hi)
+    int korder;           // K walk of a 3x3 conv: 0 = tap-major (tap outer, channels inner: round 1), 1 = channel-block-major (64 channels
+                          // outer, the 9 taps inner): the 9 shifted reads of one channel block follow each other, so they are served by the
+                          // XCD's L2 instead of nine passes over the whole tile set's rows (PMC round 1: 2.3-3x the algorithmic fetch).
+                          // Weights stay [N][tap][Cin]; only the order of the K tiles (and so the fp32 summation order) changes.
+    int tile_order;       // 0: consecutive tile ids walk N first (they share the gathered A panel: the large-M layers); 1: M first
+                          // (they share the WEIGHT panel: small-M / deep-K layers, where the weights are the HBM traffic and an
+                          // XCD-local run of tiles must reuse them out of its own L2).  Chosen per launch in launch_gemm.
+    float bias_scale;     // bias is added as bias * bias_scale (0 is read as 1): range-extended VAE decode, where the residual stream
+                          // is carried at 1/64 scale (alpha scales the accumulator, bias_scale the bias)
     const int* gate;      // optional device flag: the launch is a no-op when *gate == 0 (context re-projection only if the context
                           // changed, decided on the device: no host synchronisation — engine.cpp unet_set_context)
 };
@@ -80,6 +89,8 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
        EP_TRANSPOSE = 64,                              // store out^T per image: out[b][n][m - b*rows_per_batch] (row stride ldo): the V
                                                        // projection written as V^T [C][tokens] for the attention kernel — the MFMA
                                                        // operands swap roles so a lane owns 4 consecutive TOKENS of one channel
+       EP_WRAP = 128,                                  // 3x3 taps wrap around the image instead of reading zero padding (p.tiling:
+                                                       // Conv2d padding_mode = 'circular', modules/sd_hijack.py:311-318)
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000 };    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
 
@@ -91,6 +102,8 @@ extern int g_force_gemm_cfg;
 extern int g_shortk_gemm_cfg;
 extern int g_shortk_max_k;          // the launches g_shortk_gemm_cfg applies to: taps == 1 and K <= this (default 448)
 extern int g_geglu_gemm_cfg;        // tile config forced on the GEGLU (ff.net.0.proj) launches, -1 = heuristic
+extern int g_conv_korder;           // 1 (default) channel-block-major, 0 tap-major
+extern int g_tile_order;            // -1 heuristic (default), 0 / 1 force
 extern int g_vt_mode;               // 1 (default): V^T through EP_TRANSPOSE on token-major tiles; 0: weights-as-rows GEMM (round 1)
 extern int g_gemm_pipe;             // 0 = two-stage kernels only, 3 = ping-pong 256-row tiles, 4 = also 128x320 (default)
 extern int g_gemm_pipe_default;     // value restored by sdmi_debug_set("gemm_pipe", -1)

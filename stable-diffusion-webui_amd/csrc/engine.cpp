@@ -116,6 +116,7 @@ static int pack_stack(sdmi_engine* e, const std::map<std::string, RawTensor>& m,
                                                            out->cin_pad, geglu ? 1 : 0});
         const RawTensor* b = find_raw(m, names[i] + ".bias");
         if (b) TRY(launch_pack_bias(b->ptr, b->dtype, out->b + row, O, Opad, geglu ? 1 : 0, 0));
+        if (b && e->recording_unet_sites) e->unet_vec_sites[names[i] + ".bias"].push_back({out->b + row, O, Opad, geglu ? 1 : 0});
         row += Opad;
     }
     return 0;
@@ -134,6 +135,10 @@ static int pack_norm(sdmi_engine* e, const std::map<std::string, RawTensor>& m, 
     TRY(dev_alloc(e, (void**)&out->b, c * sizeof(float)));
     TRY(launch_convert_to_f32(g->ptr, g->dtype, out->g, c, 0));
     TRY(launch_convert_to_f32(b->ptr, b->dtype, out->b, c, 0));
+    if (e->recording_unet_sites) {
+        e->unet_vec_sites[name + ".weight"].push_back({out->g, c, c, 0});
+        e->unet_vec_sites[name + ".bias"].push_back({out->b, c, c, 0});
+    }
     return 0;
 }
 
@@ -337,6 +342,7 @@ struct ConvArgs {
     int flags = 0;
     int n_real = 0;
     float alpha = 1.f;
+    float bias_scale = 1.f;
     int batch = 1;
     long a_bs = 0, w_bs = 0, o_bs = 0, r_bs = 0;
     const int* gate = nullptr;
@@ -362,15 +368,18 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.rows_per_batch = a.Ho * a.Wo;
     p.n_real = a.n_real ? a.n_real : W.n_pad;
     p.flags = a.flags | (W.geglu ? EP_GEGLU : 0);
+    if (r.e->tiling && W.taps == 9 && a.pad == 1) p.flags |= EP_WRAP;    // Conv2d(padding=1, padding_mode='circular')
     p.alpha = a.alpha;
+    p.bias_scale = a.bias_scale;
     p.a_bs = a.a_bs; p.w_bs = a.w_bs; p.o_bs = a.o_bs; p.r_bs = a.r_bs;
     p.gate = a.gate;
     return launch_gemm(p, a.batch, r.e->force_generic, r.e->use_glds, r.s);
 }
 
 // plain [rows, K] x W^T GEMM on token matrices
-static int run_linear(Run& r, const ConvW& W, const half_t* a, int rows, const half_t* resid, half_t* out, int ldo) {
+static int run_linear(Run& r, const ConvW& W, const half_t* a, int rows, const half_t* resid, half_t* out, int ldo, float ss = 1.f) {
     ConvArgs c;
+    c.alpha = ss; c.bias_scale = ss;
     c.a0 = a; c.c0 = W.cin_pad;
     c.B = 1; c.Hi = rows; c.Wi = 1; c.Ho = rows; c.Wo = 1;
     c.resid = resid; c.ldr = ldo; c.out = out; c.ldo = ldo;
@@ -390,12 +399,15 @@ static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t*
 }
 
 // ResBlock (UNet: GroupNorm32 eps 1e-5 + emb add; VAE: eps 1e-6, no emb).  Returns the output buffer.
+// `ss` (VAE range-extended decode only): the residual stream — x0 / x1 in, *out out — is stored multiplied by ss; GroupNorm is
+// scale-invariant once eps is multiplied by ss^2, the block-internal tensors stay at true scale, and the two layers that write the
+// stream scale their accumulator (alpha) and / or bias (bias_scale).
 static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, int c0, int c1, int B, int H, int Wd,
-                   float eps, const float* embs, int emb_ld, half_t** out) {
+                   float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f) {
     const int HW = H * Wd;
     const size_t M = (size_t)B * HW;
     half_t* t1 = r.H(M * w.cin);
-    TRY(run_gn(r, w.n1, x0, x1, c0, c1, B, HW, eps, true, t1));
+    TRY(run_gn(r, w.n1, x0, x1, c0, c1, B, HW, eps * ss * ss, true, t1));
     half_t* h1 = r.H(M * w.cout);
     {
         ConvArgs c;
@@ -412,6 +424,7 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
         ConvArgs c;
         c.a0 = x0; c.a1 = x1; c.c0 = c0; c.c1 = c1; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd;
         c.out = sk; c.ldo = w.cout;
+        c.bias_scale = ss;                                    // the input already carries ss
         TRY(run_conv(r, w.skip, c));
         resid = sk;
     } else {
@@ -422,6 +435,7 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
         ConvArgs c;
         c.a0 = t2; c.c0 = w.cout; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
         c.resid = resid; c.ldr = w.cout; c.out = o; c.ldo = w.cout;
+        c.alpha = ss; c.bias_scale = ss;
         TRY(run_conv(r, w.c2, c));
     }
     *out = o;
@@ -454,7 +468,7 @@ static int run_vt(Run& r, const ConvW& Wv, const half_t* x, int ldx, int B, int 
         p.w = Wv.w; p.ldw = K;
         p.bias = bias_row ? Wv.b : nullptr;                  // per output channel n
         p.out = vt;
-        p.Hi = B * tokens; p.Wi = 1; p.Ho = B * tokens; p.Wo = 1;
+        p.Hi = tokens; p.Wi = 1; p.Ho = tokens; p.Wo = 1;      // B "images" of tokens x 1 pixels: the gather's image stride
         p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
         p.M = B * tokens; p.N = C; p.K = K; p.n_valid = C;
         p.ldo = tokens_pad; p.rows_per_batch = tokens; p.n_real = C;
@@ -906,11 +920,11 @@ static int vae_build(sdmi_engine* e) {
 
 // single-head spatial attention of the VAE mid block (N = H*W tokens, d = C = 512): scores materialised through the
 // GEMM kernel (fp32), row softmax, then P V — modules/sd_hijack_optimizations.py:554-610 computes the same product chunked.
-static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H, int Wd, half_t** out) {
+static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H, int Wd, half_t** out, float ss = 1.f) {
     const int C = a.c, HW = H * Wd, Npad = rup(HW, 64);
     const size_t M = (size_t)B * HW;
     half_t* n0 = r.H(M * C);
-    TRY(run_gn(r, a.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
+    TRY(run_gn(r, a.norm, x, nullptr, C, 0, B, HW, 1e-6f * ss * ss, false, n0));
     half_t* qk = r.H(M * 2 * C);
     TRY(run_linear(r, a.qk, n0, (int)M, nullptr, qk, 2 * C));
     half_t* vt = r.H((size_t)B * C * Npad);
@@ -941,7 +955,7 @@ static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H
         TRY(launch_gemm(g, B, r.e->force_generic, r.e->use_glds, r.s));
     }
     half_t* y = r.H(M * C);
-    TRY(run_linear(r, a.proj, o, (int)M, x, y, C));
+    TRY(run_linear(r, a.proj, o, (int)M, x, y, C, ss));
     *out = y;
     return 0;
 }
@@ -951,6 +965,7 @@ static int vae_decode_run(Run& r, const void* z, int io_dtype, float* out, int B
     VAEW& v = e->vae;
     const sdmi_vae_config& c = v.cfg;
     e->arena.reset();
+    const float ss = e->vae_stream_scale;                    // 1, or 1/64 in the range-extended mode (see engine.h)
     half_t* zin = r.H((size_t)B * h * w * v.d_conv_in.cin_pad);
     if (!r.dry)
         TRY(launch_nchw_to_nhwc(z, io_dtype, zin, B, c.z_channels, h * w, v.d_conv_in.cin_pad, 1.0f / c.scale_factor,
@@ -962,21 +977,22 @@ static int vae_decode_run(Run& r, const void* z, int io_dtype, float* out, int B
         ConvArgs a;
         a.a0 = zin; a.c0 = v.d_conv_in.cin_pad; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pad = 1;
         a.out = cur; a.ldo = C;
+        a.alpha = ss; a.bias_scale = ss;
         TRY(run_conv(r, v.d_conv_in, a));
     }
     if (!r.dry) e->taps.clear();
     r.tap("decoder.conv_in", cur, B, H, W, C);
     half_t* o = nullptr;
-    TRY(run_res(r, v.d_mid1, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    TRY(run_res(r, v.d_mid1, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o, ss)); cur = o;
     r.tap("decoder.mid.block_1", cur, B, H, W, C);
-    TRY(run_vae_attn(r, v.d_attn, cur, B, H, W, &o)); cur = o;
+    TRY(run_vae_attn(r, v.d_attn, cur, B, H, W, &o, ss)); cur = o;
     r.tap("decoder.mid.attn_1", cur, B, H, W, C);
-    TRY(run_res(r, v.d_mid2, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o)); cur = o;
+    TRY(run_res(r, v.d_mid2, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o, ss)); cur = o;
     r.tap("decoder.mid.block_2", cur, B, H, W, C);
     for (int i = c.num_levels - 1; i >= 0; --i) {
         int bj = 0;
         for (const ResW& rb : v.d_up[i].blocks) {
-            TRY(run_res(r, rb, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o));
+            TRY(run_res(r, rb, cur, nullptr, C, 0, B, H, W, 1e-6f, nullptr, 0, &o, ss));
             cur = o; C = rb.cout;
             r.tap("decoder.up." + std::to_string(i) + ".block." + std::to_string(bj++), cur, B, H, W, C);
         }
@@ -985,13 +1001,14 @@ static int vae_decode_run(Run& r, const void* z, int io_dtype, float* out, int B
             ConvArgs a;
             a.a0 = cur; a.c0 = C; a.B = B; a.Hi = H; a.Wi = W; a.Ho = 2 * H; a.Wo = 2 * W; a.up = 1; a.pad = 1;
             a.out = u; a.ldo = C;
+            a.bias_scale = ss;                                // stream in, stream out
             TRY(run_conv(r, v.d_up[i].resample, a));
             cur = u; H *= 2; W *= 2;
             r.tap("decoder.up." + std::to_string(i) + ".upsample", cur, B, H, W, C);
         }
     }
     half_t* tn = r.H((size_t)B * H * W * C);
-    TRY(run_gn(r, v.d_norm_out, cur, nullptr, C, 0, B, H * W, 1e-6f, true, tn));
+    TRY(run_gn(r, v.d_norm_out, cur, nullptr, C, 0, B, H * W, 1e-6f * ss * ss, true, tn));
     {
         ConvArgs a;
         a.a0 = tn; a.c0 = C; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H; a.Wo = W; a.pad = 1;
@@ -1246,6 +1263,7 @@ int engine_load_vae_tensor(sdmi_engine* e, const char* key, const void* data, in
 int engine_unet_finalize(sdmi_engine* e) {
     SDMI_CHECK_HIP(hipSetDevice(e->device));
     e->unet_sites.clear();
+    e->unet_vec_sites.clear();
     e->recording_unet_sites = true;
     const int rc = unet_build(e);
     e->recording_unet_sites = false;
@@ -1286,6 +1304,32 @@ int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data,
     SDMI_CHECK_HIP(hipDeviceSynchronize());
     if (tmp) (void)hipFree(tmp);
     e->ctx_valid = false;                                     // cached K / V^T depend on attn2.to_k / to_v
+    return rc;
+}
+// Replace one 1-D parameter of the finalized UNet (a conv / linear bias, a GroupNorm / LayerNorm gain or shift) in place.
+int engine_unet_update_vector(sdmi_engine* e, const char* key, const void* data, int dtype, int64_t n, int on_device) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    SDMI_REQUIRE(e->unet.ready, "unet not finalized");
+    SDMI_REQUIRE(key && data && n > 0, "bad arguments");
+    SDMI_REQUIRE(dtype == SDMI_F16 || dtype == SDMI_F32, "dtype must be SDMI_F16 or SDMI_F32");
+    auto it = e->unet_vec_sites.find(key);
+    SDMI_REQUIRE(it != e->unet_vec_sites.end(), std::string("no bias / norm parameter named ") + key);
+    const void* src = data;
+    void* tmp = nullptr;
+    if (!on_device) {
+        const size_t bytes = (size_t)n * (dtype == SDMI_F16 ? 2 : 4);
+        SDMI_CHECK_HIP(hipMalloc(&tmp, bytes));
+        SDMI_CHECK_HIP(hipMemcpy(tmp, data, bytes, hipMemcpyHostToDevice));
+        src = tmp;
+    }
+    int rc = 0;
+    for (const auto& st : it->second) {
+        if (st.n != (int)n) { set_error(std::string("length of ") + key + " differs from the loaded parameter"); rc = 1; break; }
+        rc = launch_pack_bias(src, dtype, st.dst, st.n, st.n_pad, st.geglu, 0);
+        if (rc) break;
+    }
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    if (tmp) (void)hipFree(tmp);
     return rc;
 }
 int engine_vae_finalize(sdmi_engine* e) {

@@ -142,6 +142,10 @@ struct sdmi_engine {
     // layer can be re-packed in place when a LoRA changes it (sdmi_unet_update_weight)
     struct PackSite { half_t* dst; int O, cin, kh, Opad, cin_pad, geglu; };
     std::map<std::string, std::vector<PackSite>> unet_sites;
+    // the same for the 1-D parameters ("<layer>.bias", "<norm>.weight", "<norm>.bias"): LyCORIS norm modules and bias deltas
+    // (extensions-builtin/Lora/network_norm.py, network.py:196-216 ex_bias) rewrite them through sdmi_unet_update_vector
+    struct VecSite { float* dst; int n, n_pad, geglu; };
+    std::map<std::string, std::vector<VecSite>> unet_vec_sites;
     bool recording_unet_sites = false;
     std::vector<void*> owned;                 // persistent device allocations (weights)
     std::vector<void*> owned_vae;             // the VAE's packed weights: freed when another VAE is loaded (sd_vae.load_vae)
@@ -154,7 +158,10 @@ struct sdmi_engine {
     // options
     bool force_generic = false;
     bool use_glds = true;
-    bool use_graph = false;
+    // range-extended VAE decode (the engine's form of the reference's fp16 -> fp32 VAE fallback, modules/processing.py:636-665): the
+    // decoder's residual stream is stored at this scale (1/64 when on), every GroupNorm that reads it uses eps * scale^2
+    float vae_stream_scale = 1.f;
+    bool tiling = false;                      // p.tiling: every padded 3x3 conv wraps around (modules/sd_hijack.py:311-318)
     // activation taps (parity error budget): with `trace` on, every block output of the last forward is recorded by name
     // — the arena never reuses memory within a forward, so the tensors stay readable until the next forward
     bool trace = false;

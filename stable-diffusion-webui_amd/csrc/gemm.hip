@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wc * WTN + j * 16 + (lane & 15);
-                const float bb = p.bias ? p.bias[n] : 0.f;
+                const float bb = p.bias ? p.bias[n] * p.bias_scale : 0.f;
                 h4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)fmaf(acc[i][j][r], p.alpha, bb);
@@ -110,9 +110,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
     // Direct stores from the accumulator layout: each lane owns 4 consecutive output channels of one pixel (8-byte
     // packed stores).  An LDS-staged, fully row-coalesced variant was measured 5-15 % SLOWER on the memory-bound 1x1
     // layers (extra barriers + LDS round trip; L2 write-combining already merges the 8-byte pieces) — profiles/.
+    // Column bias is the same for every row tile: loaded once.  The residual of row tile i+1 is
+    // requested before row tile i is converted and stored, so its latency hides behind the stores instead of serialising
+    // TM x TN dependent load -> add -> store chains (measured: the K = 320 projections with a residual took 49 us against 31 us
+    // for the same shape without one).  Loads of rows past M are clamped to row M-1 and dropped.
+    // (wide wave tiles, TN > 5 — the two-stage 256x320 fallback — keep the plain per-use loads: no registers to spare)
+    constexpr bool PIPE = !GEGLU && TN <= 5;
+    const bool col_bias = p.bias && !(flags & EP_BIAS_ROW);
+    f4 bcol[PIPE ? TN : 1];
+    if constexpr (PIPE) {
+        if (col_bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bcol[j] = *reinterpret_cast<const f4*>(p.bias + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
+        }
+    }
+    h4 rres[2][PIPE ? TN : 1];
+    auto prefetch = [&](int i, int slot) {
+        if (!PIPE || !p.resid) return;
+        const int m = min(m0 + wr * WTM + i * 16 + (lane & 15), p.M - 1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            rres[slot][j] = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
+    };
+    if constexpr (PIPE) prefetch(0, 0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wr * WTM + i * 16 + (lane & 15);
+        if constexpr (PIPE) {
+            if (i + 1 < TM) prefetch(i + 1, (i + 1) & 1);
+        }
         if (m >= p.M) continue;
         const int b = m / p.rows_per_batch;
         if constexpr (GEGLU) {
@@ -155,21 +181,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += bb;
                 } else {
-                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
-                    v += bb;
+                    f4 bb;
+                    if constexpr (PIPE) bb = bcol[j];
+                    else bb = *reinterpret_cast<const f4*>(p.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(bb[r], p.bias_scale, v[r]);
                 }
             }
-            if (p.rowbias) {
-                const f4 bb = *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
-                v += bb;
-            }
+            if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);      // [B][N] fp32: cache-resident
             if (flags & (EP_QUICK_GELU | EP_GELU)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     v[r] = (flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
             }
             if (p.resid) {
-                const h4 rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
+                h4 rr;
+                if constexpr (PIPE) rr = rres[i & 1][j];
+                else rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
             }
@@ -200,7 +228,7 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
@@ -226,7 +254,13 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, sub = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sub;
     }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m, tile_n;
+    if (p.tile_order) {                                  // M first: an XCD's run of tiles shares the weight panel
+        const int tiles_m = (p.M + BM - 1) / BM;
+        tile_n = bid / tiles_m; tile_m = bid - tile_n * tiles_m;
+    } else {
+        tile_m = bid / tiles_n; tile_n = bid - tile_m * tiles_n;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const long z = blockIdx.z;
@@ -269,17 +303,26 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     uint4 ra[GLDS ? 1 : A_IT], rb[GLDS ? 1 : B_IT];
 
     // (tap, cbase) of the NEXT stage to issue; advanced incrementally (no integer division in the K loop)
-    int nx_tap = 0, nx_cbase = 0, nx_k0 = 0;
+    int nx_tap = 0, nx_cbase = 0;
     if (k_first > 0) {
-        nx_k0 = k_first * BK;
-        nx_tap = nx_k0 / p.cin;
-        nx_cbase = nx_k0 - nx_tap * p.cin;
+        if constexpr (KORD) {                            // channel block outer, tap inner (3x3 convs, GemmP::korder)
+            const int blk = k_first / 9;
+            nx_tap = k_first - blk * 9;
+            nx_cbase = blk * BK;
+        } else {
+            const int k0 = k_first * BK;
+            nx_tap = k0 / p.cin;
+            nx_cbase = k0 - nx_tap * p.cin;
+        }
     }
     auto stage_issue = [&](int sb) {
-        const int tap = nx_tap, cbase = nx_cbase, k0 = nx_k0;
-        nx_k0 += BK;
-        nx_cbase += BK;
-        if (nx_cbase >= p.cin) { nx_cbase = 0; ++nx_tap; }
+        const int tap = nx_tap, cbase = nx_cbase, k0 = nx_tap * p.cin + nx_cbase;
+        if constexpr (KORD) {
+            if (++nx_tap == 9) { nx_tap = 0; nx_cbase += BK; }
+        } else {
+            nx_cbase += BK;
+            if (nx_cbase >= p.cin) { nx_cbase = 0; ++nx_tap; }
+        }
         // block-uniform part of the address
         const bool first = cbase < p.c0;
         const half_t* src = first ? a0 : a1;
@@ -294,7 +337,11 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
             const int idx = it * NT + tid;
             const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
             const GRow gr = rows[it];
-            const int yr = gr.yb + dy, xr = gr.xb + dx;
+            int yr = gr.yb + dy, xr = gr.xb + dx;
+            if (p.flags & EP_WRAP) {                       // circular padding: one wrap is enough for a 3x3 window
+                yr = yr < 0 ? yr + ylim : (yr >= ylim ? yr - ylim : yr);
+                xr = xr < 0 ? xr + xlim : (xr >= xlim ? xr - xlim : xr);
+            }
             const bool ok = gr.ok && (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
             const int pix = gr.pixbase + (yr >> p.up) * p.Wi + (xr >> p.up);
             const half_t* g = ok ? src + (long)pix * lda + (cch + c * 8) : p.zero;
@@ -405,7 +452,7 @@ __device__ __forceinline__ long long stamp() {           // s_memtime; callers s
     return t;
 }
 
-template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false>
+template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false>
 __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int BK = 64, WC = 4, ROWB = 128;
@@ -436,7 +483,13 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, sub = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sub;
     }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m, tile_n;
+    if (p.tile_order) {                                  // M first: an XCD's run of tiles shares the weight panel
+        const int tiles_m = (p.M + BM - 1) / BM;
+        tile_n = bid / tiles_m; tile_m = bid - tile_n * tiles_m;
+    } else {
+        tile_m = bid / tiles_n; tile_n = bid - tile_m * tiles_n;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const long z = blockIdx.z;
@@ -497,11 +550,20 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     }
     // (tap, cbase) of K tiles T+1 and T+2; advanced once per tile, no division in the loop
     int tap1, cb1, tap2, cb2;
+    // KORD (compile time; launched for 3x3 convs when GemmP::korder is set): channel block outer, tap inner
     auto advance = [&](int& tap, int& cb) {
-        cb += BK;
-        if (cb >= p.cin) { cb = 0; ++tap; }
+        if constexpr (KORD) {
+            if (++tap == 9) { tap = 0; cb += BK; }
+        } else {
+            cb += BK;
+            if (cb >= p.cin) { cb = 0; ++tap; }
+        }
     };
-    {
+    if constexpr (KORD) {
+        const int blk = k_first / 9;
+        tap1 = k_first - blk * 9;
+        cb1 = blk * BK;
+    } else {
         const int k0 = k_first * BK;
         tap1 = k0 / p.cin;
         cb1 = k0 - tap1 * p.cin;
@@ -512,7 +574,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         char* base = smem + sb * STAGE + a_lds;
         const bool first = cbase < p.c0;
         const int seg0 = first ? 0 : p.c0;
-        if (force || cbase == seg0) {                    // block-uniform: the tile opens a new (tap, source) segment
+        if (force || KORD || cbase == seg0) {    // block-uniform: the tile opens a new (tap, source) segment
             const half_t* src = first ? a0 : a1;
             const int lda = first ? p.lda0 : p.lda1;
             int dy = 0, dx = 0;
@@ -526,7 +588,11 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                     ok = pix < p.M;
                 } else {
                     const int ri = rinfo[q * 512];
-                    const int yr = ((ri << 8) >> 20) + dy, xr = ((ri << 20) >> 20) + dx;     // sign-extended 12-bit fields
+                    int yr = ((ri << 8) >> 20) + dy, xr = ((ri << 20) >> 20) + dx;     // sign-extended 12-bit fields
+                    if ((p.flags & EP_WRAP) && yr > -1024) {   // circular padding (rows past M keep yb = -2048 and stay invalid)
+                        yr = yr < 0 ? yr + ylim : (yr >= ylim ? yr - ylim : yr);
+                        xr = xr < 0 ? xr + xlim : (xr >= xlim ? xr - xlim : xr);
+                    }
                     ok = (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
                     pix = (ri >> 24) * img_pix + (yr >> p.up) * p.Wi + (xr >> p.up);
                 }
@@ -538,10 +604,10 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         for (int q = q0; q < q0 + nq; ++q)
             __builtin_amdgcn_global_load_lds((gptr_t)(rptr[q] + coff), (lptr_t)(base + q * RP * ROWB), 16, 0, 0);
     };
-    // B pieces [i0, i0+n) of K tile kt (relative to k_first) into LDS buffer sb
-    auto issue_b = [&](int i0, int n, int kt, int sb) {
+    // B pieces [i0, i0+n) of the K tile at (tap, cbase) into LDS buffer sb
+    auto issue_b = [&](int i0, int n, int tap, int cbase, int sb) {
         char* base = smem + sb * STAGE + b_lds;
-        const half_t* bt = b_src + (long)(k_first + kt) * BK;
+        const half_t* bt = b_src + (long)tap * p.cin + cbase;
 #pragma unroll
         for (int i = i0; i < i0 + n; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(bt + i * b_piece), (lptr_t)(base + i * 64 * ROWB), 16, 0, 0);
@@ -567,15 +633,15 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     };
 
     // ---- prologue: all of tile 0; of tile 1 everything except the group the first L(0) issues -------------------------
-    issue_b(0, NB0, 0, 0);
-    issue_b(NB0, NB1, 0, 0);
+    issue_b(0, NB0, tap1, cb1, 0);
+    issue_b(NB0, NB1, tap1, cb1, 0);
     issue_a(0, PH / 2, tap1, cb1, 0, true);
     issue_a(PH / 2, PH / 2, tap1, cb1, 0, true);
     advance(tap1, cb1);                                  // (tap1, cb1) = tile 1
     tap2 = tap1; cb2 = cb1;
     if (nk > 1) {
-        issue_b(0, NB0, 1, 1);
-        issue_b(NB0, NB1, 1, 1);
+        issue_b(0, NB0, tap1, cb1, 1);
+        issue_b(NB0, NB1, tap1, cb1, 1);
         issue_a(0, PH / 2, tap1, cb1, 1, true);
         wait_vmcnt<(PH == 4 ? N1 : N3)>();
     } else {
@@ -608,9 +674,9 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                     if (ph == 0) {
                         if (t + 1 < nk) issue_a(2, 2, tap1, cb1, cur ^ 1, false);
                     } else if (ph == 1) {
-                        if (t + 2 < nk) issue_b(0, NB0, t + 2, cur);
+                        if (t + 2 < nk) issue_b(0, NB0, tap2, cb2, cur);
                     } else if (ph == 2) {
-                        if (t + 2 < nk) issue_b(NB0, NB1, t + 2, cur);
+                        if (t + 2 < nk) issue_b(NB0, NB1, tap2, cb2, cur);
                     } else {
                         if (t + 2 < nk) issue_a(0, 2, tap2, cb2, cur, false);
                     }
@@ -618,7 +684,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                     if (ph == 0) {
                         if (t + 1 < nk) issue_a(1, 1, tap1, cb1, cur ^ 1, false);
                     } else if (t + 2 < nk) {
-                        issue_b(0, BU, t + 2, cur);
+                        issue_b(0, BU, tap2, cb2, cur);
                         issue_a(0, 1, tap2, cb2, cur, false);
                     }
                 }
@@ -696,13 +762,16 @@ __device__ __forceinline__ float dot_row(const GemmP& p, const half_t* a0, const
             if (p.taps == 9) { dy = tap / 3; dx = tap - dy * 3; }
             int yi, xi;
             bool ok = true;
+            const bool wrap = p.flags & EP_WRAP;
             if (p.up) {
                 int yy = ri.yo + dy - 1, xx = ri.xo + dx - 1;
+                if (wrap) { yy = (yy + 2 * p.Hi) % (2 * p.Hi); xx = (xx + 2 * p.Wi) % (2 * p.Wi); }
                 ok = yy >= 0 && xx >= 0 && yy < 2 * p.Hi && xx < 2 * p.Wi;
                 yi = yy >> 1; xi = xx >> 1;
             } else {
                 yi = ri.yo * p.stride + dy - p.pad;
                 xi = ri.xo * p.stride + dx - p.pad;
+                if (wrap) { yi = (yi + p.Hi) % p.Hi; xi = (xi + p.Wi) % p.Wi; }
                 ok = yi >= 0 && xi >= 0 && yi < p.Hi && xi < p.Wi;
             }
             if (!ok) continue;
@@ -743,7 +812,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
             continue;
         }
         float v = no < p.n_valid ? dot_row(p, a0, a1, wbase + (long)no * p.ldw, ri) * p.alpha : 0.f;
-        if (p.bias) v += (p.flags & EP_BIAS_ROW) ? p.bias[m] : p.bias[no];
+        if (p.bias) v += (p.flags & EP_BIAS_ROW) ? p.bias[m] : p.bias[no] * p.bias_scale;
         if (p.rowbias) v += p.rowbias[(long)ri.b * p.ldrb + no];
         if (p.flags & EP_QUICK_GELU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
         if (p.flags & EP_GELU) v = gelu_erf(v);
@@ -781,7 +850,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += bb;
             } else {
-                v += *reinterpret_cast<const f4*>(p.bias + n);
+                const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(bb[r], p.bias_scale, v[r]);
             }
         }
         if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
@@ -806,11 +877,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -822,10 +893,10 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, bool GEGLU, bool TR = false>
+template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false>
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
-    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR>;
+    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -855,6 +926,7 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
         if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true>(p, batch, s);
     }
     if (p.flags & EP_TRANSPOSE) return launch_pingpong2<BM, BN, false, true>(p, batch, s);
+    if (p.korder && p.taps == 9) return launch_pingpong2<BM, BN, false, false, true>(p, batch, s);
     return launch_pingpong2<BM, BN, false>(p, batch, s);
 }
 
@@ -864,6 +936,7 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true>(p, batch, s);
     }
     if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, true>(p, batch, s);
+    if (p.korder && p.taps == 9) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, true>(p, batch, s);
     return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false>(p, batch, s);
 }
 
@@ -908,6 +981,8 @@ int g_force_gemm_split = 0;
 int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e ? atoi(e) : -1; }();
 int g_shortk_max_k = [] { const char* e = getenv("SDMI_SHORTK_MAXK"); return e ? atoi(e) : 448; }();
 int g_geglu_gemm_cfg = [] { const char* e = getenv("SDMI_GEGLU_CFG"); return e ? atoi(e) : -1; }();
+int g_conv_korder = [] { const char* e = getenv("SDMI_CONV_KORDER"); return e ? atoi(e) : 1; }();
+int g_tile_order = [] { const char* e = getenv("SDMI_TILE_ORDER"); return e ? atoi(e) : -1; }();
 int g_vt_mode = [] { const char* e = getenv("SDMI_VT_MODE"); return e ? atoi(e) : 1; }();
 // 4 (default): ping-pong kernel for the 256-row tiles and the 128x320 tile (+5..22 % over the two-stage kernel per shape,
 // bit-identical results), two-stage kernels elsewhere.  3: ping-pong for the 256-row tiles only.  0: two-stage kernels only.
@@ -990,6 +1065,8 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     GemmP p = p_in;
     p.flags |= g_gemm_dbgflags;
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
+    if (p.bias_scale == 0.f) p.bias_scale = 1.f;
+    p.korder = (p.taps == 9 && g_conv_korder) ? 1 : 0;
     p.zero = zero_page();
     SDMI_REQUIRE(p.zero != nullptr, "zero page allocation failed");
     SDMI_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
@@ -1028,10 +1105,26 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     } else {
         p.splitk = 0;
     }
+    {
+        // Which operand should an XCD-local run of consecutive tiles share?  One XCD (its own 4 MB L2) executes tiles/8 consecutive
+        // logical tiles.  N first: the run covers ~run/tiles_n row panels of A and min(run, tiles_n) weight panels; M first the
+        // other way round.  Bytes an XCD pulls across the fabric = panels x panel size (A panels count their RAW pixels: the 9 taps of
+        // a 3x3 conv re-read the same rows); pick the order that moves less.  (M = 1024, N = 1280, K = 11520 — the 8x8 level — read
+        // all 29.5 MB of weights into each of the 8 L2s under N-first: 236 MB per launch, fabric-bound at 4 TB/s.)
+        const int BMc = kCfgBM[cfg], BNc = kCfgBN[cfg];
+        const long tiles_m = cdiv(p.M, BMc), tiles_n = p.N / BNc;
+        const double run = std::max(1.0, (double)tiles_m * tiles_n / 8.0);
+        const double a_panel = (double)BMc * p.cin * 2.0 * (p.taps == 9 ? 1.3 : 1.0) / ((p.taps == 9 && p.up) ? 2.0 : 1.0);
+        const double w_panel = (double)BNc * p.K * 2.0 / (split > 1 ? split : 1);
+        const double n_first = std::ceil(run / tiles_n) * a_panel + std::min<double>(run, tiles_n) * w_panel;
+        const double m_first = std::ceil(run / tiles_m) * w_panel + std::min<double>(run, tiles_m) * a_panel;
+        p.tile_order = g_tile_order >= 0 ? g_tile_order : (m_first < 0.8 * n_first ? 1 : 0);
+        if (tiles_n == 1 || tiles_m == 1) p.tile_order = 0;
+    }
     std::string pname;
     if (prof_enabled()) {
         pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
-                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
+                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 (batch > 1 ? " x" + std::to_string(batch) : "");
     }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);

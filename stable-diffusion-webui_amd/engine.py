@@ -98,6 +98,15 @@ class Engine:
         self._ctx_key = None
         self.weights_version = getattr(self, "weights_version", 0) + 1
 
+    def update_unet_vector(self, key: str, t: torch.Tensor):
+        """Replace one bias / norm gain / norm shift of the loaded UNet (LyCORIS norm modules, bias deltas)."""
+        if t.dtype not in (torch.float16, torch.float32):
+            t = t.float()
+        t = t.contiguous().reshape(-1)
+        check(lib.sdmi_unet_update_vector(self.handle, key.encode(), C.c_void_p(t.data_ptr()), dtype_code(t), t.numel(), 1 if t.is_cuda else 0),
+              f"update_vector({key})")
+        self.weights_version = getattr(self, "weights_version", 0) + 1
+
     def load_vae(self, cfg: VAEConfig, state_dict: dict, prefix: str = VAE_PREFIX, decoder_only: bool = False):
         self.vae_cfg = cfg
         c = _vae_cfg_c(cfg)

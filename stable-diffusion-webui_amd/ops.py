@@ -80,7 +80,7 @@ def pack_bias(b: Optional[torch.Tensor], n_pad: int, geglu: bool = False) -> Opt
 def conv_gemm(a0: torch.Tensor, w_packed: torch.Tensor, *, a1: Optional[torch.Tensor] = None, bias=None, rowbias=None,
               resid=None, taps: int = 9, stride: int = 1, pad: int = 1, up: bool = False, Ho=None, Wo=None,
               geglu: bool = False, out_f32: bool = False, nchw_real: int = 0, bias_row: bool = False, alpha: float = 1.0,
-              impl: str = "mfma") -> torch.Tensor:
+              impl: str = "mfma", transpose: bool = False, wrap: bool = False) -> torch.Tensor:
     """Implicit-GEMM conv / linear on NHWC fp16 tensors a0 [B,Hi,Wi,c0] (+ a1 [B,Hi,Wi,c1]).
     impl: "mfma" (LDS-direct loads), "mfma_reg" (register-staged variant), "generic" (simple HIP kernel)."""
     _lib.require_device()
@@ -112,6 +112,8 @@ def conv_gemm(a0: torch.Tensor, w_packed: torch.Tensor, *, a1: Optional[torch.Te
         n_out = n // 2
     if bias_row:
         flags |= EP_BIAS_ROW
+    if wrap:
+        flags |= _lib.EP_WRAP
     if nchw_real:
         flags |= EP_NCHW
         out = torch.empty((b, nchw_real, Ho, Wo), dtype=torch.float32, device=a0.device)
@@ -119,10 +121,13 @@ def conv_gemm(a0: torch.Tensor, w_packed: torch.Tensor, *, a1: Optional[torch.Te
     elif out_f32:
         flags |= EP_OUT_F32
         out = torch.empty((b, Ho, Wo, n_out), dtype=torch.float32, device=a0.device)
+    elif transpose:
+        flags |= _lib.EP_TRANSPOSE
+        out = torch.empty((b, n_out, Ho * Wo), dtype=torch.float16, device=a0.device)       # out^T per image (V^T for attention)
     else:
         out = torch.empty((b, Ho, Wo, n_out), dtype=torch.float16, device=a0.device)
     d.out = out.data_ptr()
-    d.ldo = n_out
+    d.ldo = Ho * Wo if transpose else n_out
     d.ldr = resid.shape[-1] if resid is not None else 0
     d.flags = flags
     d.alpha = alpha

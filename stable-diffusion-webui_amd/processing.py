@@ -52,6 +52,7 @@ class StableDiffusionProcessing:
     s_noise: float = None
     sampler_noise_scheduler_override: Any = None
     is_hr_pass: bool = False
+    tiling: bool = None                               # :160 — None = opts.tiling; Conv2d padding_mode 'circular' for seamless textures
     inpainting_mask_weight: float = None              # opts.inpainting_mask_weight ("Conditional mask weight")
     refiner_sd_model: Any = None                      # p.refiner_checkpoint (:177, 882-885) as a second, resident SdModel
     refiner_switch_at: float = None                   # :178
@@ -338,11 +339,33 @@ class Processed:
 
 
 def decode_latent_batch(model, batch, target_device=None, check_for_nans=False):
-    """modules/processing.py:625-672.  The reference decodes one image at a time; the engine decodes the whole batch in
-    one batched pass (same per-image arithmetic, images are independent)."""
-    if check_for_nans and bool(torch.isnan(batch).all()):
-        raise RuntimeError("A tensor with all NaNs was produced in Unet.")
+    """modules/processing.py:625-672.  The reference decodes one image at a time; the engine decodes the whole batch in one batched
+    pass (same per-image arithmetic, images are independent).  NaN handling follows the reference: the latents are probed first
+    (NansException "unet"); a decoded image that probes NaN triggers the automatic precision fallback when
+    opts.auto_vae_precision(_bfloat16) is on — the reference converts the VAE to fp32 / bf16 because fp16 activations of the SD
+    decoders overflow on some images; the engine's equivalent is its RANGE-EXTENDED decode (sdmi option "vae_range_extend": the
+    decoder's residual stream is carried at 1/64 scale, fp16 range x64, GroupNorm eps rescaled — same function, no overflow) —
+    and the whole batch is decoded again; without the option the NansException propagates, as in the reference."""
+    from . import devices
+    if check_for_nans:
+        devices.test_for_nans(batch, "unet")
     out = model.decode_first_stage(batch)
+    if check_for_nans:
+        try:
+            # the reference probes element [0, 0, 0] of every decoded image; all B probes travel in ONE 4 * B byte read here
+            if not shared.cmd_opts.disable_nan_check:
+                bad = torch.isnan(out[:, 0, 0, 0]).nonzero()
+                if bad.numel():
+                    devices.test_for_nans(out[int(bad[0])], "vae")
+        except devices.NansException as e:
+            if not (shared.opts.auto_vae_precision_bfloat16 or shared.opts.auto_vae_precision):
+                raise e
+            if getattr(model, "vae_range_extended", False):          # already in the fallback mode (devices.dtype_vae == autofix_dtype)
+                raise e
+            print("A tensor with all NaNs was produced in VAE.\nThe engine will now switch the VAE decoder to its range-extended mode and retry.\n"
+                  "To disable this behavior, disable the 'Automatically revert VAE to 32-bit floats' setting.")
+            model.set_vae_range_extended(True)
+            out = model.decode_first_stage(batch)
     if target_device is not None:
         out = out.to(target_device)
     return out
@@ -357,6 +380,11 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
     p.all_seeds = list(p.seed) if isinstance(p.seed, (list, tuple)) else [seed + (i if p.subseed_strength == 0 else 0) for i in range(n_total)]
     subseed = 2000 if p.subseed is None or isinstance(p.subseed, (list, tuple)) or p.subseed == -1 else int(p.subseed)
     p.all_subseeds = list(p.subseed) if isinstance(p.subseed, (list, tuple)) else [subseed + i for i in range(n_total)]
+    if p.tiling is None:                                             # :879-880
+        p.tiling = shared.opts.tiling
+    for m in (p.sd_model, getattr(p, "refiner_sd_model", None), getattr(p, "hr_sd_model", None)):
+        if m is not None:                                            # :895 model_hijack.apply_circular(p.tiling): every padded conv
+            m.engine.set_option("tiling", 1 if p.tiling else 0)      # of the UNet and the VAE wraps around (sd_hijack.py:311-318)
     sd_models.apply_alpha_schedule_override(p.sd_model, p)           # :930
     p.init(None, p.all_seeds, None)
     images, latents = [], []
@@ -381,7 +409,7 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
             p.y, p.uy = p_y_all, p_uy_all
         # the model that finished the sampling decodes (a hires checkpoint or the refiner is still "loaded" at :1002 / :1459)
         decode_model = p.sampler.sd_model if getattr(p, "sampler", None) is not None else p.sd_model
-        x_samples = decode_latent_batch(decode_model, samples, check_for_nans=False)             # :1002 (hires: decoded inside sample_hr_pass, :1459)
+        x_samples = decode_latent_batch(decode_model, samples, check_for_nans=True)             # :1002 (hires: decoded inside sample_hr_pass, :1459)
         u8 = ops.image_to_u8(x_samples)                                                           # :1004-1005, 1034-1035
         images.extend(list(u8.cpu().numpy()))
         if p.keep_latents:

@@ -117,6 +117,7 @@ class SdModel:
         self.engine.load_unet(self.unet_cfg, state_dict)
         self._checkpoint = state_dict                     # kept by reference: the "weights backup" LoRA rewrites start from
         self.has_vae = False
+        self.vae_range_extended = False
         self.loaded_vae_file = None
         self._vae_decoder_only = vae_decoder_only
         if load_vae and any(k.startswith(schema.VAE_PREFIX) for k in state_dict):
@@ -140,6 +141,11 @@ class SdModel:
         self.engine.load_vae(self.vae_cfg, vae_dict, prefix="", decoder_only=self._vae_decoder_only)
         self.has_vae = True
         self.loaded_vae_file = vae_file or "<dict>"
+
+    def set_vae_range_extended(self, on: bool):
+        """The engine's stand-in for the reference's fp16 -> fp32 / bf16 VAE fallback (modules/processing.py:636-665)."""
+        self.engine.set_option("vae_range_extend", 1 if on else 0)
+        self.vae_range_extended = bool(on)
 
     def unet_checkpoint_tensor(self, engine_key: str) -> torch.Tensor:
         """The unmodified checkpoint weight of a UNet layer (extensions-builtin/Lora/networks.py:423-432 keeps the same thing

@@ -49,9 +49,25 @@ class Options:
     sdxl_clip_l_skip: bool = False                 # :222
     beta_dist_alpha: float = 0.6                   # :408
     beta_dist_beta: float = 0.6                    # :409
+    tiling: bool = False                           # :228
+    auto_vae_precision_bfloat16: bool = False      # :181  ("Automatically convert VAE to bfloat16")
+    auto_vae_precision: bool = True                # :182  ("Automatically revert VAE to 32-bit floats")
+    disable_mmap_load_safetensors: bool = False    # :285
 
 
 opts = Options()
+
+
+@dataclass
+class CmdOpts:
+    """modules/cmd_args.py flags the path reads."""
+    disable_nan_check: bool = False                # cmd_args.py:23
+    no_half: bool = False
+    no_half_vae: bool = False
+
+
+cmd_opts = CmdOpts()
+weight_load_location = None                        # modules/shared.py:20 (None = cpu for .ckpt, the device name for safetensors)
 
 
 class State:

@@ -621,8 +621,9 @@ def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):
     Cross-compile the kernel to gfx950 assembly and check the loop body."""
     import re
     text = _gfx950_assembly("gemm")
-    for bm, bn, waits, phases in ((256, 256, (8, 10), 4), (256, 320, (9, 11), 4), (128, 320, (7,), 2)):
-        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELi%dELb0ELb0ELb0EEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn), text, re.S | re.M)
+    for bm, bn, waits, phases, kord in [(bm, bn, w, ph, k) for (bm, bn, w, ph) in ((256, 256, (8, 10), 4), (256, 320, (9, 11), 4), (128, 320, (7,), 2))
+                                        for k in (0, 1)]:       # k = 1: the channel-block-major instantiation the 3x3 convs run
+        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELi%dELb0ELb0ELb0ELb%dEEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn, kord), text, re.S | re.M)
         assert m, f"ping-pong kernel <{bm},{bn}> not found in the assembly"
         body = m.group(1)
         first, last = body.index("s_setprio 1"), body.rindex("s_setprio 0")

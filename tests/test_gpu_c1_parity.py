@@ -286,8 +286,39 @@ def test_c1_euler_a_20_steps_512_final_latent_vs_oracle(dev, sd15, golden_dir):
         out["oracle_seconds"] = round(time.time() - t0, 1)
         out["fixture_vs_live_oracle"] = rel_l2(ref, live)
         out["engine_vs_live_fp32_oracle"] = rel_l2(got, live)
-        assert out["fixture_vs_live_oracle"] < 2e-4          # another host's BLAS summation order, amplified over 20 steps
+        assert out["fixture_vs_live_oracle"] < 1.5e-3        # another host's BLAS summation order, amplified over 20 chaotic steps
     report("euler_a_20_steps_c1", out)
     print(f"[c1 e2e] {out}")
     assert e < 5e-3
     assert e < 1.1 * out["reference_fp16_emulation_vs_fp32_oracle_final_latent"]
+
+
+def test_c3_sdxl_base_full_size_unet_forward_vs_oracle(dev):
+    """BASELINE.json configs[3] architecture at full size: the SDXL-base UNet (2,567,463,684 parameters; configs/sd_xl_inpaint.yaml:19-37
+    with 4 input channels, modules/sd_models_xl.py:12-43: y = pooled text + size embeddings, 2816 wide; context 2048 wide; transformer
+    depth 2 / 10, head size 64, linear proj_in / proj_out, no attention at level 0) — one forward, batch 2, at a 32x32 latent vs the
+    fp32 oracle, with the reference-fp16 yardstick."""
+    from fp16_emu import fp16_storage
+    from oracle import unet as ou
+    schema = sub("schema")
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg = schema.sdxl_unet()
+    sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
+    assert sum(v.numel() for k, v in sd.items() if k.startswith(schema.UNET_PREFIX)) == 2_567_463_684
+    eng = sub("engine").Engine(0)
+    eng.load_unet(cfg, sd)
+    x, t = seeded((2, 4, 32, 32), 301), torch.tensor([951.0, 123.5])
+    ctx, y = seeded((2, 77, 2048), 302), seeded((2, 2816), 303)
+    got = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev), y.to(dev)).cpu()
+    eng.close()
+    net = ou.build_unet(ou.sdxl_base_config(), sd)
+    del sd
+    with torch.no_grad():
+        ref = net(x, t, ctx.half().float(), y.half().float())
+        with fp16_storage(net):
+            emu = net(x.half().float(), t, ctx.half().float(), y.half().float())
+    e, e_emu = rel_l2(got, ref), rel_l2(emu, ref)
+    report("unet_c3_sdxl_forward", {"shape": "x [2,4,32,32], context [2,77,2048], y [2,2816]", "engine_vs_fp32_oracle_rel_l2": e,
+                                    "reference_fp16_emulation_vs_fp32_oracle": e_emu})
+    print(f"[c3 sdxl unet] engine {e:.3e}; reference fp16 emulation {e_emu:.3e}")
+    assert e < 3e-3 and e < 1.1 * e_emu

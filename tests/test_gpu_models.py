@@ -882,3 +882,84 @@ def test_c0_shape_sd15_256px_b1_euler_a_5_steps(dev):
     ref = opipe.sample(om, cond, uncond, [1000], 5, "euler_a", 7.0, (32, 32))
     assert rel_l2(got.cpu(), ref) < 1e-2
     model.engine.close()
+
+
+def test_nan_check_and_vae_range_extended_retry(dev, tiny):
+    """modules/processing.py:625-672 + modules/devices.py:236-265: NaN latents raise NansException("... Unet"); a decoder whose fp16
+    activations overflow (the real SD VAEs do on some images — why the reference re-runs the VAE in fp32 / bf16) produces a NaN
+    image, which triggers the engine's equivalent of that fallback: the range-extended decode (residual stream at 1/64 scale),
+    whose result matches the fp32 oracle; with opts.auto_vae_precision off the NansException propagates."""
+    from oracle import vae as ov
+    schema, processing, shared, devices = sub("schema"), sub("processing"), sub("shared"), sub("devices")
+    ucfg, vcfg = schema.tiny_unet(), schema.tiny_vae()
+    sd = dict(tiny["sd"])
+    key = schema.VAE_PREFIX + "decoder.mid.block_1.conv2.weight"
+    sd[key] = (sd[key].float() * 2.0e5).half()              # residual stream ~1e5 and beyond after this block: past fp16's 65504
+    model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0)
+    okl = ov.build_vae(ov.tiny_vae_config(), sd)
+    z = (seeded((2, 4, 16, 16), 8) * 0.18215 * 4).to(dev)
+    with torch.no_grad():
+        ref = okl.decode_first_stage(z.cpu())
+    assert torch.isfinite(ref).all()
+    plain = model.decode_first_stage(z)
+    assert torch.isnan(plain).any()                          # fp16 storage overflowed -> inf -> NaN after the next GroupNorm
+    with pytest.raises(devices.NansException, match="Unet"):
+        processing.decode_latent_batch(model, torch.full_like(z, float("nan")), check_for_nans=True)
+    keep = shared.opts.auto_vae_precision
+    try:
+        shared.opts.auto_vae_precision = False
+        with pytest.raises(devices.NansException, match="VAE"):
+            processing.decode_latent_batch(model, z, check_for_nans=True)
+        shared.opts.auto_vae_precision = True
+        out = processing.decode_latent_batch(model, z, check_for_nans=True)
+    finally:
+        shared.opts.auto_vae_precision = keep
+    assert model.vae_range_extended and torch.isfinite(out).all()
+    assert rel_l2(out.cpu(), ref) < 5e-3
+    # on an ordinary checkpoint the range-extended decode is the same function to fp16 rounding
+    m2 = tiny["model"]
+    a = m2.decode_first_stage(z)
+    m2.set_vae_range_extended(True)
+    try:
+        b = m2.decode_first_stage(z)
+    finally:
+        m2.set_vae_range_extended(False)
+    assert rel_l2(b.cpu(), a.cpu()) < 3e-3
+    model.engine.close()
+
+
+def test_tiling_circular_padding_unet_and_vae_vs_oracle(dev, tiny):
+    """p.tiling (modules/processing.py:879-895 -> sd_hijack.apply_circular): every Conv2d of the UNet and the VAE switches to
+    padding_mode='circular'.  Oracle = the same torch modules with that attribute set, exactly what the reference does."""
+    import copy
+    processing = sub("processing")
+    model, om = tiny["model"], tiny["oracle"]
+    unet_c, vae_c = copy.deepcopy(om.unet), copy.deepcopy(om.vae)
+    for net in (unet_c, vae_c):
+        for layer in net.modules():
+            if type(layer) == torch.nn.Conv2d:
+                layer.padding_mode = "circular"
+                layer._reversed_padding_repeated_twice = torch.nn.modules.utils._reverse_repeat_tuple(layer.padding, 2)
+    x, t, ctx = seeded((2, 4, 16, 16), 21), torch.tensor([640.0, 77.0]), tiny["cond"][:2]
+    z = seeded((2, 4, 16, 16), 22) * 0.8
+    with torch.no_grad():
+        ref_u = unet_c(x, t, ctx.half().float())
+        ref_v = vae_c.decode_first_stage(z)
+        plain_u = om.unet(x, t, ctx.half().float())
+    eng = model.engine
+    eng.set_option("tiling", 1)
+    try:
+        got_u = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev))
+        got_v = model.decode_first_stage(z.to(dev))
+    finally:
+        eng.set_option("tiling", 0)
+    assert rel_l2(got_u.cpu(), ref_u) < 5e-3 and rel_l2(got_v.cpu(), ref_v) < 5e-3
+    assert rel_l2(plain_u, ref_u) > 2e-2
+    # through process_images: p.tiling switches it on for the job and the next job (tiling None -> opts.tiling False) off again
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=tiny["cond"][:1], uc=tiny["uncond"][:1], seed=9, batch_size=1, steps=2,
+                                                    cfg_scale=3.0, width=128, height=128, sampler_name="Euler", tiling=True)
+    a = processing.process_images(p).latents
+    p2 = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=tiny["cond"][:1], uc=tiny["uncond"][:1], seed=9, batch_size=1, steps=2,
+                                                     cfg_scale=3.0, width=128, height=128, sampler_name="Euler")
+    b = processing.process_images(p2).latents
+    assert not torch.equal(a, b)
