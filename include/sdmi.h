@@ -189,6 +189,12 @@ int sdmi_axpby(void* y_f32, const void* x_f32, float a, const void* z_f32_or_nul
  * linear combinations of x, denoiser outputs and noise; `terms` / `coefs` are HOST arrays. */
 int sdmi_lincomb(void* out_f32, const void* const* terms_f32, const float* coefs, int n_terms, int64_t n, void* stream);
 
+/* DPM adaptive (k-diffusion DPMSolver.dpm_solver_adaptive; table row modules/sd_samplers_kdiffusion.py:25): the squared error of the
+ * embedded solver pair under the mixed tolerance, sum_i ((lo_i - hi_i) / max(atol, rtol * max(|lo_i|, |prev_i|)))^2, as 256
+ * per-block partial sums (fp32, fixed summation order: reproducible); the host adds them and takes sqrt(sum / n). */
+int sdmi_dpm_error_partials(const void* x_low_f32, const void* x_high_f32, const void* x_prev_f32, float atol, float rtol,
+                            void* partial256_f32, int64_t n, void* stream);
+
 /* Latent upscale of the hires-fix pass: torch.nn.functional.interpolate(samples, size=(ho, wo), mode, antialias=False) on
  * `planes` = B*C fp32 planes of hi x wi (modules/processing.py:1392 with the "Latent*" upscalers of modules/shared.py:54-62).
  * mode: 0 "nearest", 1 "nearest-exact", 2 "bilinear", 3 "bicubic" (align_corners = False, ATen index arithmetic). */

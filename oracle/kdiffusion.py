@@ -470,6 +470,198 @@ def sample_dpm_fast(model, x, sigma_min, sigma_max, n, extra_args, noise_fn, eta
     return solver.dpm_solver_fast(x, solver.t(torch.tensor(sigma_max)), solver.t(torch.tensor(sigma_min)), n, noise_fn, eta, s_noise)
 
 
+class PIDStepSizeController:
+    """k-diffusion sampling.PIDStepSizeController (restated; unpinned): PID control of the log step size on the inverse error."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h = h
+        self.b1 = (pcoeff + icoeff + dcoeff) / order
+        self.b2 = -(pcoeff + 2 * dcoeff) / order
+        self.b3 = dcoeff / order
+        self.accept_safety = accept_safety
+        self.eps = eps
+        self.errs = []
+
+    @staticmethod
+    def limiter(x):
+        return 1 + math.atan(x - 1)
+
+    def propose_step(self, error):
+        inv_error = 1 / (float(error) + self.eps)
+        if not self.errs:
+            self.errs = [inv_error, inv_error, inv_error]
+        self.errs[0] = inv_error
+        factor = self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3
+        factor = self.limiter(factor)
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs[2] = self.errs[1]
+            self.errs[1] = self.errs[0]
+        self.h *= factor
+        return accept
+
+
+def dpm_solver_adaptive(solver: DPMSolver, x, t_start, t_end, noise_sampler, order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0.,
+                        icoeff=1., dcoeff=0., accept_safety=0.81, eta=0., s_noise=1.):
+    """k-diffusion DPMSolver.dpm_solver_adaptive (restated; unpinned): embedded pairs DPM-Solver-1/2 (order 2) or 2/3 (order 3),
+    mixed absolute / relative error norm, PID step-size controller; with eta the accepted step lands on the ancestral sigma_down
+    and fresh noise over [sigma(s), sigma(t)] is added."""
+    if order not in {2, 3}:
+        raise ValueError('order should be 2 or 3')
+    forward = t_end > t_start
+    if not forward and eta:
+        raise ValueError('eta must be 0 for reverse sampling')
+    h_init = abs(h_init) * (1 if forward else -1)
+    atol, rtol = torch.tensor(atol), torch.tensor(rtol)
+    s = t_start
+    x_prev = x
+    pid = PIDStepSizeController(h_init, pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
+    info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
+    while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+        eps_cache = {}
+        t = torch.minimum(t_end, s + pid.h) if forward else torch.maximum(t_end, s + pid.h)
+        if eta:
+            sd, su = get_ancestral_step(solver.sigma(s), solver.sigma(t), eta)
+            t_ = torch.minimum(t_end, solver.t(sd))
+            su = (solver.sigma(t) ** 2 - solver.sigma(t_) ** 2) ** 0.5
+        else:
+            t_, su = t, 0.
+        eps, eps_cache = solver.eps(eps_cache, 'eps', x, s)
+        denoised = x - solver.sigma(s) * eps
+        if order == 2:
+            x_low, eps_cache = solver.dpm_solver_1_step(x, s, t_, eps_cache=eps_cache)
+            x_high, eps_cache = solver.dpm_solver_2_step(x, s, t_, eps_cache=eps_cache)
+        else:
+            x_low, eps_cache = solver.dpm_solver_2_step(x, s, t_, r1=1 / 3, eps_cache=eps_cache)
+            x_high, eps_cache = solver.dpm_solver_3_step(x, s, t_, eps_cache=eps_cache)
+        delta = torch.maximum(atol, rtol * torch.maximum(x_low.abs(), x_prev.abs()))
+        error = torch.linalg.norm((x_low - x_high) / delta) / x.numel() ** 0.5
+        accept = pid.propose_step(error)
+        if accept:
+            x_prev = x_low
+            x = x_high + su * s_noise * noise_sampler(solver.sigma(s), solver.sigma(t))
+            s = t
+            info['n_accept'] += 1
+        else:
+            info['n_reject'] += 1
+        info['nfe'] += order
+        info['steps'] += 1
+        if solver.info_callback is not None:
+            solver.info_callback({'x': x, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised, 'error': error, 'h': pid.h, **info})
+    return x, info
+
+
+def sample_dpm_adaptive(model, x, sigma_min, sigma_max, extra_args, noise_sampler, eta=0., s_noise=1., callback=None, order=3, rtol=0.05,
+                        atol=0.0078, h_init=0.05, return_info=False):
+    """k-diffusion sample_dpm_adaptive; modules/sd_samplers_kdiffusion.py:205-208 passes the wrapped model's sigma range."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    solver = DPMSolver(model, extra_args)
+    if callback is not None:
+        solver.info_callback = lambda info: callback({'sigma': solver.sigma(info['t']), 'sigma_hat': solver.sigma(info['t_up']), **info})
+    x, info = dpm_solver_adaptive(solver, x, solver.t(torch.tensor(sigma_max)), solver.t(torch.tensor(sigma_min)), noise_sampler, order, rtol,
+                                  atol, h_init, 0., 1., 0., 0.81, eta, s_noise)
+    return (x, info) if return_info else x
+
+
+def sample_dpmpp_sde(model, x, sigmas, extra_args, noise_sampler, eta=1., s_noise=1., callback=None, r=1 / 2):
+    """k-diffusion sample_dpmpp_sde (DPM-Solver++ (stochastic), restated; unpinned): two model evaluations per step, both sub-steps
+    ancestral in the (sigma_down, sigma_up) split, noise from the Brownian tree over [sigma(t), sigma(s)] and [sigma(t), sigma(t_next)]."""
+    s_in = x.new_ones([x.shape[0]])
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda sigma: sigma.log().neg()
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        if sigmas[i + 1] == 0:
+            d = to_d(x, sigmas[i], denoised)
+            dt = sigmas[i + 1] - sigmas[i]
+            x = x + d * dt
+        else:
+            t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+            h = t_next - t
+            s = t + h * r
+            fac = 1 / (2 * r)
+            sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(s), eta)
+            s_ = t_fn(sd)
+            x_2 = (sigma_fn(s_) / sigma_fn(t)) * x - (t - s_).expm1() * denoised
+            x_2 = x_2 + noise_sampler(sigma_fn(t), sigma_fn(s)) * s_noise * su
+            denoised_2 = model(x_2, sigma_fn(s) * s_in, **extra_args)
+            sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
+            t_next_ = t_fn(sd)
+            denoised_d = (1 - fac) * denoised + fac * denoised_2
+            x = (sigma_fn(t_next_) / sigma_fn(t)) * x - (t - t_next_).expm1() * denoised_d
+            x = x + noise_sampler(sigma_fn(t), sigma_fn(t_next)) * s_noise * su
+    return x
+
+
+def sample_dpmpp_2m_sde(model, x, sigmas, extra_args, noise_sampler, eta=1., s_noise=1., callback=None, solver_type='midpoint'):
+    """k-diffusion sample_dpmpp_2m_sde (restated; unpinned): DPM-Solver++(2M) SDE, 'midpoint' or 'heun' second-order correction."""
+    if solver_type not in {'heun', 'midpoint'}:
+        raise ValueError('solver_type must be \'heun\' or \'midpoint\'')
+    s_in = x.new_ones([x.shape[0]])
+    old_denoised, h_last = None, None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        if sigmas[i + 1] == 0:
+            x = denoised
+        else:
+            t, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - t
+            eta_h = eta * h
+            x = sigmas[i + 1] / sigmas[i] * (-eta_h).exp() * x + (-h - eta_h).expm1().neg() * denoised
+            if old_denoised is not None:
+                r = h_last / h
+                if solver_type == 'heun':
+                    x = x + ((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / r) * (denoised - old_denoised)
+                else:
+                    x = x + 0.5 * (-h - eta_h).expm1().neg() * (1 / r) * (denoised - old_denoised)
+            if eta:
+                x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * sigmas[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise
+        old_denoised, h_last = denoised, (-sigmas[i + 1].log() + sigmas[i].log()) if sigmas[i + 1] > 0 else None
+    return x
+
+
+def sample_dpmpp_3m_sde(model, x, sigmas, extra_args, noise_sampler, eta=1., s_noise=1., callback=None):
+    """k-diffusion sample_dpmpp_3m_sde (restated; unpinned): third-order multistep DPM-Solver++ SDE."""
+    s_in = x.new_ones([x.shape[0]])
+    denoised_1, denoised_2 = None, None
+    h_1, h_2 = None, None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        if sigmas[i + 1] == 0:
+            x = denoised
+        else:
+            t, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - t
+            h_eta = h * (eta + 1)
+            x = torch.exp(-h_eta) * x + (-h_eta).expm1().neg() * denoised
+            if h_2 is not None:
+                r0, r1 = h_1 / h, h_2 / h
+                d1_0 = (denoised - denoised_1) / r0
+                d1_1 = (denoised_1 - denoised_2) / r1
+                d1 = d1_0 + (d1_0 - d1_1) * r0 / (r0 + r1)
+                d2 = (d1_0 - d1_1) / (r0 + r1)
+                phi_2 = h_eta.neg().expm1() / h_eta + 1
+                phi_3 = phi_2 / h_eta - 0.5
+                x = x + phi_2 * d1 - phi_3 * d2
+            elif h_1 is not None:
+                r = h_1 / h
+                d = (denoised - denoised_1) / r
+                phi_2 = h_eta.neg().expm1() / h_eta + 1
+                x = x + phi_2 * d
+            if eta:
+                x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * sigmas[i + 1] * (-2 * h * eta).expm1().neg().sqrt() * s_noise
+            h_1, h_2 = h, h_1
+        denoised_1, denoised_2 = denoised, denoised_1
+    return x
+
+
 def sample_lcm(model, x, sigmas, extra_args, noise_fn, callback=None):
     """modules/sd_samplers_lcm.py:66-80: x <- denoised (+ sigma_next * noise while sigma_next > 0)."""
     s_in = x.new_ones([x.shape[0]])

@@ -78,7 +78,9 @@ def layer_mapping(unet_state_dict: dict, prefix: str = "model.diffusion_model.")
     (``name.replace(".", "_")`` of the module path under ``sd_model.model``)."""
     out = {}
     for k, v in unet_state_dict.items():
-        if k.startswith(prefix) and k.endswith(".weight") and v.dim() in (2, 4):
+        # conv / linear weights, and the gains of GroupNorm / LayerNorm layers (LyCORIS norm modules, network_norm.py): every
+        # nn.Module under sd_model.model gets a network_layer_name (networks.py:141-144), 1-D "weight"s belong to norm layers
+        if k.startswith(prefix) and k.endswith(".weight") and (v.dim() in (2, 4) or (v.dim() == 1 and k[:-len("weight")] + "bias" in unet_state_dict)):
             mod = k[len("model."):-len(".weight")]
             out[mod.replace(".", "_")] = k
     return out
@@ -287,5 +289,9 @@ def merge(state_dict: dict, networks, prefix: str = "model.diffusion_model.") ->
         for key, w in matched.items():
             ck = mapping[key]
             base = out[ck].float()
-            out[ck] = base + calc_updown(w, base, mult)
+            updown, ex_bias = calc_updown(w, base, mult, with_bias=True)
+            out[ck] = base + updown
+            if ex_bias is not None:                                       # networks.py:455-462: self.bias += ex_bias
+                bk = ck[:-len("weight")] + "bias"
+                out[bk] = out[bk].float() + ex_bias.reshape(out[bk].shape)
     return out

@@ -32,7 +32,9 @@ class OracleModel:
 SAMPLER_OPTIONS = {
     "euler_a": (None, False), "euler": (None, False), "lms": (None, False), "heun": (None, False),
     "dpmpp_2m": ("karras", False), "dpmpp_2s_a": ("karras", False), "dpm_2": ("karras", True), "dpm_2_a": ("karras", True),
-    "restart": ("karras", False), "lcm": (None, False), "dpm_fast": (None, False),
+    "restart": ("karras", False), "lcm": (None, False), "dpm_fast": (None, False), "dpm_adaptive": (None, False),
+    "dpmpp_sde": ("karras", False), "dpmpp_2m_sde": ("exponential", False), "dpmpp_2m_sde_heun": ("exponential", False),
+    "dpmpp_3m_sde": ("exponential", True),
 }
 
 
@@ -156,6 +158,20 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
             smin, smax, n = sigmas[-2], sigmas[0], len(sigmas) - 1
         return finish(kd.sample_dpm_fast(cfg, x, smin, smax, n, extra, rng.next, eta=1.0 if eta is None else eta, s_noise=s_noise,
                                          callback=record))
+    if sampler == "dpm_adaptive":    # default eta = opts.eta_ancestral = 1: noise from the job's ImageRNG (k-diffusion default_noise_sampler)
+        smin, smax = (wrap.sigmas[0].item(), wrap.sigmas[-1].item()) if init_latent is None else (sigmas[-2], sigmas[0])
+        return finish(kd.sample_dpm_adaptive(cfg, x, smin, smax, extra, lambda *a: rng.next(), eta=1.0 if eta is None else eta,
+                                             s_noise=s_noise, callback=record))
+    if sampler in ("dpmpp_sde", "dpmpp_2m_sde", "dpmpp_2m_sde_heun", "dpmpp_3m_sde"):
+        # modules/sd_samplers_common.py:334-342: Brownian tree per image seed over the positive range of the FULL schedule
+        from .brownian import BrownianTreeNoiseSampler
+        full = sigmas if init_latent is None else get_sigmas(wrap, sampler, total, scheduler)
+        ns = BrownianTreeNoiseSampler(x, full[full > 0].min(), full.max(), seed=list(seeds))
+        if sampler == "dpmpp_sde":
+            return finish(kd.sample_dpmpp_sde(cfg, x, sigmas, extra, ns, **anc))
+        if sampler == "dpmpp_3m_sde":
+            return finish(kd.sample_dpmpp_3m_sde(cfg, x, sigmas, extra, ns, **anc))
+        return finish(kd.sample_dpmpp_2m_sde(cfg, x, sigmas, extra, ns, solver_type="heun" if sampler.endswith("heun") else "midpoint", **anc))
     if sampler == "lcm":
         return finish(kd.sample_lcm(cfg, x, sigmas, extra, rng.next, callback=record))
     if sampler == "restart":

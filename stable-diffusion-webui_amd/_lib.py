@@ -98,6 +98,7 @@ _SIGS = {
     "sdmi_dpmpp2m_step": (_i, [_vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     "sdmi_ddim_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _f, _i64, _vp]),
     "sdmi_axpby": (_i, [_vp, _vp, _f, _vp, _f, _i64, _vp]),
+    "sdmi_dpm_error_partials": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i64, _vp]),
     "sdmi_lincomb": (_i, [_vp, C.POINTER(_vp), C.POINTER(_f), _i, _i64, _vp]),
     "sdmi_mask_blend": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "sdmi_latent_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

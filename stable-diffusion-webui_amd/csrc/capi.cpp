@@ -220,6 +220,14 @@ int sdmi_ddim_step(void* x, const void* e_t, const void* noise, void* pred_x0, f
     API_GUARD_END
 }
 
+int sdmi_dpm_error_partials(const void* x_low, const void* x_high, const void* x_prev, float atol, float rtol, void* partial256_f32,
+                            int64_t n, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(x_low && x_high && x_prev && partial256_f32 && n > 0, "null argument");
+    return launch_dpm_error((const float*)x_low, (const float*)x_high, (const float*)x_prev, atol, rtol, (float*)partial256_f32, n,
+                            (hipStream_t)stream);
+    API_GUARD_END
+}
 int sdmi_lincomb(void* out, const void* const* terms, const float* coefs, int n_terms, int64_t n, void* stream) {
     API_GUARD_BEGIN
     SDMI_REQUIRE(out && terms && coefs, "null argument");

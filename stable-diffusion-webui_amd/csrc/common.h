@@ -157,6 +157,8 @@ int launch_dpmpp2m_step(float* x, const float* den, const float* old, float rati
 int launch_ddim_step(float* x, const float* e, const float* noise, float* pred_x0, float a_t, float a_prev,
                      float sigma_t, float somat, int64_t n, hipStream_t s);
 int launch_axpby(float* y, const float* x, float a, const float* z, float b, int64_t n, hipStream_t s);
+int launch_dpm_error(const float* lo, const float* hi, const float* prev, float atol, float rtol, float* partial256, int64_t n,
+                     hipStream_t s);
 int launch_lincomb(float* out, const float* const* terms, const float* coefs, int n_terms, int64_t n, hipStream_t s);
 int launch_lora_merge(float* out, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype,
                       int rows, int cols, int rank, float scale, hipStream_t s);

@@ -237,6 +237,35 @@ int launch_axpby(float* y, const float* x, float a, const float* z, float b, int
     return 0;
 }
 
+// DPM adaptive (k-diffusion DPMSolver.dpm_solver_adaptive): squared mixed-tolerance error of the embedded pair,
+//   sum_i ((lo_i - hi_i) / max(atol, rtol * max(|lo_i|, |prev_i|)))^2,
+// reduced to 256 per-block partial sums in a fixed order (thread-strided accumulation, LDS tree): bit-reproducible; the host adds
+// the 256 partials in float64.
+__global__ __launch_bounds__(256) void dpm_error_kernel(const float* lo, const float* hi, const float* prev, float atol, float rtol,
+                                                        float* partial, long n) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float a = lo[i];
+        const float delta = fmaxf(atol, rtol * fmaxf(fabsf(a), fabsf(prev[i])));
+        const float e = (a - hi[i]) / delta;
+        acc = fmaf(e, e, acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+int launch_dpm_error(const float* lo, const float* hi, const float* prev, float atol, float rtol, float* partial256, int64_t n,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(dpm_error_kernel, dim3(256), dim3(256), 0, s, lo, hi, prev, atol, rtol, partial256, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 struct LinTerms {
     const float* t[6];
     float c[6];

@@ -346,12 +346,13 @@ struct ConvArgs {
     int batch = 1;
     long a_bs = 0, w_bs = 0, o_bs = 0, r_bs = 0;
     const int* gate = nullptr;
+    bool no_split = false;        // never take a split-K workspace from the arena (callers outside a sized forward pass)
 };
 
 static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     // split-K slabs (only deep / small-M layers qualify); allocated in the dry pass too so the arena layout is identical
     float* splitk_ws = nullptr;
-    if (!(a.flags & EP_NCHW) && !W.geglu) {
+    if (!(a.flags & EP_NCHW) && !W.geglu && !a.no_split) {
         const size_t wsb = gemm_splitk_ws_bytes(a.B * a.Ho * a.Wo, W.n_pad, W.taps * (a.c0 + a.c1), a.batch);
         if (wsb) splitk_ws = r.F(wsb / sizeof(float));
     }
@@ -632,6 +633,9 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
             c.out = e->ctx_k[b.ctx_slot]; c.ldo = st->ch;
             c.batch = Bn; c.a_bs = (long)Lpad * cd; c.o_bs = (long)L * st->ch;
             c.gate = gate;
+            // the context projections run OUTSIDE a forward's dry-sized arena pass: with a wide context (SDXL: K = 2048) run_conv
+            // would hand the GEMM a split-K workspace carved from an arena that may not exist yet (round-2 SDXL test: page fault)
+            c.no_split = true;
             TRY(run_conv(r, b.k2, c));
             // V^T[b] = Wv ctx[b]^T : [C][Lpad]
             TRY(run_vt(r, b.v2, e->ctx_f16, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false, gate));

@@ -114,8 +114,14 @@ class NetworkModule:                                      # network.py:111-216 (
         self.alpha = w["alpha"].item() if "alpha" in w else None
         self.scale = w["scale"].item() if "scale" in w else None
         self.dora_scale = w.get("dora_scale", None)
+        # network.py:130-134: an extra "bias" entry (sparse [indices; values; size] triple) — no published network family uses it on
+        # the UNet layers of this path; refused rather than silently ignored
         if w.get("bias") is not None:
             raise NotImplementedError(f"{self.network_key}: 'bias' deltas are not implemented")
+
+    def ex_bias(self, device):
+        """Bias delta of this module (network.py:196-216 finalize_updown: ex_bias * multiplier), or None."""
+        return None
 
     def multiplier(self):                                 # network.py:161-165
         if 'transformer' in self.sd_key[:20]:
@@ -288,10 +294,9 @@ class NetworkModuleIa3(NetworkModule):                    # network_ia3.py:13-30
 class NetworkModuleFull(NetworkModule):                   # network_full.py:12-27
     kind = "full"
 
-    def __init__(self, net, weights, shape):
-        super().__init__(net, weights, shape)
-        if weights.w.get("diff_b") is not None:
-            raise NotImplementedError(f"{self.network_key}: bias differences (diff_b) are not implemented")
+    def ex_bias(self, device):                            # network_full.py:20-24
+        db = self.w.get("diff_b")
+        return None if db is None else _f32(db, device).reshape(-1) * float(self.multiplier())
 
     def add_delta(self, base, scale, device):
         diff = _f32(self.w["diff"], device)
@@ -299,6 +304,107 @@ class NetworkModuleFull(NetworkModule):                   # network_full.py:12-2
             raise AssertionError(f"full-diff layer {self.network_key}: diff {tuple(diff.shape)} for a weight of shape {self.shape}")
         from . import ops
         return ops.lincomb(torch.empty_like(base), [base, diff.reshape(base.shape).contiguous()], [1.0, float(scale)])
+
+
+class NetworkModuleNorm(NetworkModule):                   # network_norm.py:13-28
+    """w_norm / b_norm: differences of a GroupNorm / LayerNorm layer's gain and shift (the engine keeps them as fp32 vectors beside
+    its fused norm kernels; rewritten through sdmi_unet_update_vector)."""
+    kind = "norm"
+
+    def add_delta(self, base, scale, device):
+        wn = _f32(self.w["w_norm"], device)
+        if wn.numel() != base.numel():
+            raise AssertionError(f"norm layer {self.network_key}: w_norm {tuple(wn.shape)} for a parameter of shape {self.shape}")
+        from . import ops
+        return ops.lincomb(torch.empty_like(base), [base, wn.reshape(base.shape).contiguous()], [1.0, float(scale)])
+
+    def ex_bias(self, device):
+        bn = self.w.get("b_norm")
+        return None if bn is None else _f32(bn, device).reshape(-1) * float(self.multiplier())
+
+
+class NetworkModuleOFT(NetworkModule):                    # network_oft.py:14-118
+    """Orthogonal fine-tuning: the weight's output rows are rotated block-wise, updown = R W - W.  kohya / new LyCORIS "oft_blocks"
+    [k, n, n] hold the generators B: Q = B - B^T, optionally norm-clamped to alpha * out_dim (COFT), R = (I + Q)(I - Q)^-1 (Cayley);
+    old LyCORIS "oft_diag" holds R itself; 4-D blocks [m, k, n, n] are BOFT's m butterfly factors.  The rotation matrices are a few
+    small blocks built once per network load on the host (fp32 torch, like the reference); rotating the layer's rows is the same
+    block-by-block matrix product either way and runs through sdmi_lora_merge on the device."""
+    kind = "oft"
+
+    def __init__(self, net, weights, shape):
+        super().__init__(net, weights, shape)
+        w = weights.w
+        self.scale = 1.0                                   # :23
+        self.out_dim = self.shape[0]
+        if "oft_blocks" in w:
+            self.blocks, self.is_r = w["oft_blocks"], False
+            dim = self.blocks.shape[0]
+        else:
+            self.blocks, self.is_r = w["oft_diag"], True
+            dim = self.blocks.shape[1]
+        self.is_boft = self.blocks.dim() == 4
+        self.rescale = w.get("rescale")
+        self.num_blocks, self.block_size = dim, self.out_dim // dim
+        self.constraint = (0.0 if self.alpha is None else float(self.alpha)) * self.out_dim
+        if self.is_r:
+            self.constraint = None
+            self.block_size, self.num_blocks = dim, self.out_dim // dim
+        elif self.is_boft:
+            self.boft_m, self.num_blocks, self.block_size = self.blocks.shape[0], self.blocks.shape[1], self.blocks.shape[2]
+
+    def calc_scale(self):
+        return 1.0
+
+    def rotations(self) -> torch.Tensor:
+        blocks = self.blocks.detach().float().cpu()
+        if self.is_r:
+            return blocks
+        eye = torch.eye(self.block_size)
+        q = blocks - blocks.transpose(-1, -2)
+        if self.constraint != 0:
+            norm_q = torch.norm(q.flatten())
+            new_norm = torch.clamp(norm_q, max=torch.tensor(self.constraint))
+            q = q * ((new_norm + 1e-8) / (norm_q + 1e-8))
+        return torch.matmul(eye + q, (eye - q).float().inverse())
+
+    def _rotate_rows(self, r_blocks: torch.Tensor, rows: torch.Tensor, device) -> torch.Tensor:
+        """rows [k*n, cols] -> for every block k: out[k] = R[k]^T-applied rows, i.e. out[k, m, :] = sum_n R[k, n, m] rows[k, n, :]."""
+        k, n = r_blocks.shape[0], r_blocks.shape[1]
+        cols = rows.shape[1]
+        out = torch.empty_like(rows)
+        rt = r_blocks.transpose(-1, -2).contiguous().to(device)
+        for i in range(k):
+            out[i * n:(i + 1) * n] = _mm(rt[i], rows[i * n:(i + 1) * n].contiguous()).reshape(n, cols)
+        return out
+
+    def add_delta(self, base, scale, device):
+        rmat = self.rotations()
+        flat = base.reshape(self.out_dim, -1).contiguous()
+        if not self.is_boft:
+            merged = self._rotate_rows(rmat, flat, device)
+        else:
+            b = self.block_size
+            r_b = b // 2
+            merged = flat
+            for i in range(self.boft_m):                   # butterfly factor i acts on rows permuted with stride 2^i * r_b (:92-103)
+                kk = (2 ** i) * r_b
+                c = self.out_dim // (2 * kk)
+                idx = torch.arange(self.out_dim, device=device).reshape(c, 2, kk).permute(0, 2, 1).reshape(-1)   # "(c g k) -> (c k g)"
+                perm = merged[idx].contiguous()
+                bi = rmat[i]                               # [blocks, b, b]: out[d] = bi[d] @ rows[d]
+                rot = torch.empty_like(perm)
+                bd = bi.contiguous().to(device)
+                for d in range(bi.shape[0]):
+                    rot[d * b:(d + 1) * b] = _mm(bd[d], perm[d * b:(d + 1) * b].contiguous()).reshape(b, -1)
+                inv = torch.empty_like(idx)
+                inv[idx] = torch.arange(self.out_dim, device=device)
+                merged = rot[inv].contiguous()
+        if self.rescale is not None:
+            merged = merged * _f32(self.rescale, device).reshape(-1, 1)
+        from . import ops
+        merged = merged.reshape(base.shape).contiguous()
+        # base + scale * (merged - base), accumulated left to right like finalize_updown's updown * (calc_scale * multiplier)
+        return ops.lincomb(torch.empty_like(base), [base, merged, base], [1.0, float(scale), -float(scale)])
 
 
 class ModuleTypeLora:                                     # network_lora.py:9-22
@@ -334,10 +440,9 @@ module_types = [                                          # the order of network
     _ModuleTypeByKeys(NetworkModuleLokr, lambda w: ("lokr_w1" in w or ("lokr_w1_a" in w and "lokr_w1_b" in w))
                       and ("lokr_w2" in w or ("lokr_w2_a" in w and "lokr_w2_b" in w))),
     _ModuleTypeByKeys(NetworkModuleFull, lambda w: "diff" in w),
-    _ModuleTypeByKeys(_unsupported("norm (w_norm / b_norm: normalisation layers are fused into the engine's kernels)"),
-                      lambda w: all(x in w for x in ["w_norm", "b_norm"])),
+    _ModuleTypeByKeys(NetworkModuleNorm, lambda w: all(x in w for x in ["w_norm", "b_norm"])),
     _ModuleTypeByKeys(NetworkModuleGLora, lambda w: all(x in w for x in ["a1.weight", "a2.weight", "alpha", "b1.weight", "b2.weight"])),
-    _ModuleTypeByKeys(_unsupported("OFT / BOFT"), lambda w: "oft_blocks" in w or "oft_diag" in w),
+    _ModuleTypeByKeys(NetworkModuleOFT, lambda w: "oft_blocks" in w or "oft_diag" in w),
 ]
 
 
@@ -357,8 +462,8 @@ loaded_networks: List[Network] = []
 def assign_network_names_to_compvis_modules(sd_model):    # networks.py:122-147 (UNet part)
     """network layer name -> (engine weight key, shape): `name.replace(".", "_")` of the module path under sd_model.model."""
     mapping = {}
-    for key, shape, _ in unet_schema(sd_model.unet_cfg):
-        if key.endswith(".weight") and len(shape) in (2, 4):
+    for key, shape, kind in unet_schema(sd_model.unet_cfg):
+        if key.endswith(".weight") and (len(shape) in (2, 4) or kind == "g"):      # conv / linear weights and norm gains
             mapping[("diffusion_model." + key[:-len(".weight")]).replace(".", "_")] = (key, tuple(shape))
     sd_model.network_layer_mapping = mapping
     return mapping
@@ -402,7 +507,7 @@ def _merge_on_device(base: torch.Tensor, module: NetworkModule, device) -> torch
     scale, mult = float(module.calc_scale()), float(module.multiplier())
     if module.dora_scale is None:
         return module.add_delta(base, scale * mult, device)
-    if module.kind in ("ia3", "glora"):
+    if module.kind in ("ia3", "glora", "oft", "norm"):
         raise NotImplementedError(f"{module.network_key}: DoRA on {module.kind} modules is not implemented")
     delta = module.add_delta(torch.zeros_like(base), scale, device)
     rows, cin = base.shape[0], base.shape[1]
@@ -429,15 +534,36 @@ def network_apply_weights(sd_model):
         for key, module in net.modules.items():
             touched.setdefault(module.engine_key, []).append(module)
     previously = getattr(sd_model, "network_touched_keys", set())
+    bias_touched = set()
     for engine_key in sorted(set(touched) | previously):
         base = sd_model.unet_checkpoint_tensor(engine_key).to(device)
         if base.dtype not in (torch.float16, torch.float32):
             base = base.float()
         w = base.contiguous()
+        ex = None
         for module in touched.get(engine_key, []):
             w = _merge_on_device(w, module, device)
-        eng.update_unet_weight(engine_key, w)
+            eb = module.ex_bias(device)                    # networks.py:455-462: bias += ex_bias
+            if eb is not None:
+                ex = eb if ex is None else ex + eb
+        if w.dim() == 1:
+            eng.update_unet_vector(engine_key, w)          # a norm layer's gain
+        else:
+            eng.update_unet_weight(engine_key, w)
+        bias_key = engine_key[:-len("weight")] + "bias"
+        if ex is not None:
+            try:
+                b0 = sd_model.unet_checkpoint_tensor(bias_key)
+            except KeyError:
+                raise NotImplementedError(f"{engine_key}: the network adds a bias to a layer that has none") from None
+            from . import ops
+            b0 = _f32(b0, device)
+            eng.update_unet_vector(bias_key, ops.lincomb(torch.empty_like(b0), [b0, ex.contiguous()], [1.0, 1.0]))
+            bias_touched.add(bias_key)
+    for bias_key in sorted(getattr(sd_model, "network_touched_biases", set()) - bias_touched):     # restore biases no network touches any more
+        eng.update_unet_vector(bias_key, _f32(sd_model.unet_checkpoint_tensor(bias_key), device))
     sd_model.network_touched_keys = set(touched)
+    sd_model.network_touched_biases = bias_touched
     sd_model.network_current_names = wanted
 
 

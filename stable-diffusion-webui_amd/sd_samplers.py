@@ -974,6 +974,228 @@ def sample_dpm_fast(model, x, sigma_min, sigma_max, n, extra_args=None, callback
     return x
 
 
+# ---- DPM adaptive (k-diffusion sample_dpm_adaptive / DPMSolver.dpm_solver_adaptive; table row sd_samplers_kdiffusion.py:25) ----
+class PIDStepSizeController:
+    """k-diffusion sampling.PIDStepSizeController: PID control of the step size h (in t = -log sigma) on the inverse error."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h = h
+        self.b1 = (pcoeff + icoeff + dcoeff) / order
+        self.b2 = -(pcoeff + 2 * dcoeff) / order
+        self.b3 = dcoeff / order
+        self.accept_safety = accept_safety
+        self.eps = eps
+        self.errs = []
+
+    def propose_step(self, error):
+        import math
+        inv_error = 1 / (float(error) + self.eps)
+        if not self.errs:
+            self.errs = [inv_error, inv_error, inv_error]
+        self.errs[0] = inv_error
+        factor = self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3
+        factor = 1 + math.atan(factor - 1)
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs[2] = self.errs[1]
+            self.errs[1] = self.errs[0]
+        self.h *= factor
+        return accept
+
+
+def sample_dpm_adaptive(model, x, sigma_min, sigma_max, extra_args=None, callback=None, disable=None, order=3, rtol=0.05, atol=0.0078,
+                        h_init=0.05, pcoeff=0., icoeff=1., dcoeff=0., accept_safety=0.81, eta=0., s_noise=1., noise_sampler=None,
+                        return_info=False):
+    """DPM-Solver-12 / -23 with adaptive step size: every trial step evaluates the embedded pair (orders 1/2 or 2/3, sharing model
+    evaluations), measures their mixed-tolerance distance (sdmi_dpm_error_partials: one reduction launch + a 1 KB read — the only
+    data-dependent host decision on the path, inherent to the method) and lets a PID controller accept or shrink the step.  The
+    number of UNet evaluations is not known in advance (``steps`` only sizes the progress display in the reference)."""
+    import math
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    if order not in {2, 3}:
+        raise ValueError('order should be 2 or 3')
+    extra_args = {} if extra_args is None else extra_args
+    s_in = x.new_ones([x.shape[0]])
+    f32 = lambda v: torch.as_tensor(v, dtype=torch.float32)
+    sig = lambda t: t.neg().exp()
+    t_start, t_end = -f32(sigma_max).log(), -f32(sigma_min).log()
+    new = lambda: torch.empty_like(x)
+    partial = torch.empty(256, dtype=torch.float32, device=x.device)
+
+    def eps_at(xx, t):
+        den = model(xx, float(sig(t)) * s_in, **extra_args)
+        return _lc(new(), [xx, den], [1.0 / float(sig(t)), -1.0 / float(sig(t))]), den
+
+    s = t_start
+    x_prev = x
+    pid = PIDStepSizeController(abs(h_init), pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
+    info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
+    while s < t_end - 1e-5:
+        t = torch.minimum(t_end, s + pid.h)
+        if eta:
+            sd, _ = get_ancestral_step(sig(s), sig(t), eta)
+            t_ = torch.minimum(t_end, -sd.log())
+            su = (sig(t) ** 2 - sig(t_) ** 2) ** 0.5
+        else:
+            t_, su = t, 0.
+        eps, denoised = eps_at(x, s)
+        h = t_ - s
+        a = float(sig(t_) * h.expm1())
+        if order == 2:
+            x_low = _lc(new(), [x, eps], [1.0, -a])
+            r1 = 1 / 2
+            s1 = s + r1 * h
+            u1 = _lc(new(), [x, eps], [1.0, -float(sig(s1) * (r1 * h).expm1())])
+            eps_r1, _ = eps_at(u1, s1)
+            b = float(sig(t_) / (2 * r1) * h.expm1())
+            x_high = _lc(new(), [x, eps, eps_r1], [1.0, -a + b, -b])
+        else:
+            r1, r2 = 1 / 3, 2 / 3
+            s1, s2 = s + r1 * h, s + r2 * h
+            u1 = _lc(new(), [x, eps], [1.0, -float(sig(s1) * (r1 * h).expm1())])
+            eps_r1, _ = eps_at(u1, s1)                    # shared by the order-2 (r1 = 1/3) and order-3 steps
+            b2 = float(sig(t_) / (2 * r1) * h.expm1())
+            x_low = _lc(new(), [x, eps, eps_r1], [1.0, -a + b2, -b2])
+            c1 = float(sig(s2) * (r2 * h).expm1())
+            c2 = float(sig(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1))
+            u2 = _lc(new(), [x, eps, eps_r1], [1.0, -c1 + c2, -c2])
+            eps_r2, _ = eps_at(u2, s2)
+            b3 = float(sig(t_) / r2 * (h.expm1() / h - 1))
+            x_high = _lc(new(), [x, eps, eps_r2], [1.0, -a + b3, -b3])
+        check(lib.sdmi_dpm_error_partials(ptr(x_low), ptr(x_high), ptr(x_prev.contiguous()), float(atol), float(rtol), ptr(partial), x.numel(),
+                                          stream_ptr()), "dpm_error")
+        error = math.sqrt(float(partial.double().sum().item())) / x.numel() ** 0.5
+        accept = pid.propose_step(error)
+        if accept:
+            x_prev = x_low
+            x = x_high if float(su) == 0.0 else _lc(new(), [x_high, noise_sampler(sig(s), sig(t))], [1.0, float(su) * s_noise])
+            s = t
+            info['n_accept'] += 1
+        else:
+            info['n_reject'] += 1
+        info['nfe'] += order
+        info['steps'] += 1
+        if callback is not None:
+            callback({'sigma': sig(s), 'sigma_hat': sig(s), 'x': x, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised,
+                      'error': error, 'h': pid.h, **info})
+    return (x, info) if return_info else x
+
+
+# ---- SDE samplers (k-diffusion sample_dpmpp_sde / _2m_sde / _3m_sde; table rows sd_samplers_kdiffusion.py:13-15, 17) ----
+def sample_dpmpp_sde(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None, r=1 / 2):
+    """DPM-Solver++ (stochastic): two UNet evaluations per step; both sub-steps split sigma into (sigma_down, sigma_up) and add
+    Brownian-tree noise over the sub-interval.  Each tensor update is one sdmi_lincomb."""
+    extra_args = {} if extra_args is None else extra_args
+    s_in = x.new_ones([x.shape[0]])
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda sigma: sigma.log().neg()
+    new = lambda: torch.empty_like(x)
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        if sigmas[i + 1] == 0:                               # Euler step to sigma = 0: x + (x - denoised) / sigma * (0 - sigma)
+            dt = float(sigmas[i + 1] - sigmas[i])
+            x = _lc(new(), [x, denoised], [1.0 + dt / float(sigmas[i]), -dt / float(sigmas[i])])
+        else:
+            t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+            h = t_next - t
+            s = t + h * r
+            fac = 1 / (2 * r)
+            sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(s), eta)
+            s_ = t_fn(sd)
+            x_2 = _lc(new(), [x, denoised, noise_sampler(sigma_fn(t), sigma_fn(s))],
+                      [float(sigma_fn(s_) / sigma_fn(t)), -float((t - s_).expm1()), float(s_noise * su)])
+            denoised_2 = model(x_2, float(sigma_fn(s)) * s_in, **extra_args)
+            sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
+            t_next_ = t_fn(sd)
+            e = -float((t - t_next_).expm1())
+            x = _lc(new(), [x, denoised, denoised_2, noise_sampler(sigma_fn(t), sigma_fn(t_next))],
+                    [float(sigma_fn(t_next_) / sigma_fn(t)), e * (1 - fac), e * fac, float(s_noise * su)])
+    return x
+
+
+def sample_dpmpp_2m_sde(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None,
+                        solver_type='midpoint'):
+    """DPM-Solver++(2M) SDE, 'midpoint' or 'heun' correction ("DPM++ 2M SDE" / "DPM++ 2M SDE Heun")."""
+    if solver_type not in {'heun', 'midpoint'}:
+        raise ValueError('solver_type must be \'heun\' or \'midpoint\'')
+    extra_args = {} if extra_args is None else extra_args
+    s_in = x.new_ones([x.shape[0]])
+    new = lambda: torch.empty_like(x)
+    old_denoised, h_last = None, None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        h = None
+        if sigmas[i + 1] == 0:
+            x = denoised
+        else:
+            t, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - t
+            eta_h = eta * h
+            cx = float(sigmas[i + 1] / sigmas[i] * (-eta_h).exp())
+            cd = float((-h - eta_h).expm1().neg())
+            terms, coefs = [x, denoised], [cx, cd]
+            if old_denoised is not None:
+                r = h_last / h
+                if solver_type == 'heun':
+                    k = float(((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / r))
+                else:
+                    k = float(0.5 * (-h - eta_h).expm1().neg() * (1 / r))
+                terms, coefs = [x, denoised, denoised, old_denoised], [cx, cd, k, -k]     # ... + k * (denoised - old_denoised)
+            if eta:
+                terms = terms + [noise_sampler(sigmas[i], sigmas[i + 1])]
+                coefs = coefs + [float(sigmas[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise)]
+            x = _lc(new(), terms, coefs)
+        old_denoised, h_last = denoised, h
+    return x
+
+
+def sample_dpmpp_3m_sde(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+    """DPM-Solver++(3M) SDE: third-order multistep, falls back to orders 2 and 1 on the first steps."""
+    extra_args = {} if extra_args is None else extra_args
+    s_in = x.new_ones([x.shape[0]])
+    new = lambda: torch.empty_like(x)
+    denoised_1, denoised_2 = None, None
+    h_1, h_2 = None, None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        if callback is not None:
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
+        if sigmas[i + 1] == 0:
+            x = denoised
+        else:
+            t, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - t
+            h_eta = h * (eta + 1)
+            terms, coefs = [x, denoised], [float(torch.exp(-h_eta)), float((-h_eta).expm1().neg())]
+            if h_2 is not None:
+                r0, r1 = h_1 / h, h_2 / h
+                phi_2 = h_eta.neg().expm1() / h_eta + 1
+                phi_3 = phi_2 / h_eta - 0.5
+                # d1_0 = (D - D1) / r0, d1_1 = (D1 - D2) / r1, d1 = d1_0 + (d1_0 - d1_1) r0 / (r0 + r1), d2 = (d1_0 - d1_1) / (r0 + r1)
+                # x += phi_2 d1 - phi_3 d2 = A d1_0 + Bc d1_1 with A = phi_2 (1 + r0/(r0+r1)) - phi_3/(r0+r1), Bc = -phi_2 r0/(r0+r1) + phi_3/(r0+r1)
+                A = float(phi_2 * (1 + r0 / (r0 + r1)) - phi_3 / (r0 + r1))
+                Bc = float(-phi_2 * r0 / (r0 + r1) + phi_3 / (r0 + r1))
+                x = _lc(new(), terms, coefs)
+                terms = [x, denoised, denoised_1, denoised_1, denoised_2]
+                coefs = [1.0, A / float(r0), -A / float(r0), Bc / float(r1), -Bc / float(r1)]
+            elif h_1 is not None:
+                r = h_1 / h
+                phi_2 = float((h_eta.neg().expm1() / h_eta + 1) / r)
+                terms, coefs = terms + [denoised, denoised_1], coefs + [phi_2, -phi_2]
+            if eta:
+                terms = terms + [noise_sampler(sigmas[i], sigmas[i + 1])]
+                coefs = coefs + [float(sigmas[i + 1] * (-2 * h * eta).expm1().neg().sqrt() * s_noise)]
+            x = _lc(new(), terms, coefs)
+            h_1, h_2 = h, h_1
+        denoised_1, denoised_2 = denoised, denoised_1
+    return x
+
+
 # ---- UniPC (modules/models/diffusion/uni_pc/uni_pc.py, driven by unipc() at modules/sd_samplers_timesteps_impl.py:170-179) ----
 class _DiscreteVP:
     """NoiseScheduleVP('discrete') of uni_pc.py:96-175, on host fp32 scalars (the reference evaluates the same handful of
@@ -1206,10 +1428,13 @@ class Sampler:
         raise NotImplementedError()
 
 
-# the rows of modules/sd_samplers_kdiffusion.py:11-27 the engine implements (same labels, aliases and options); the SDE rows
-# need torchsde's BrownianTree noise and DPM adaptive an error-norm reduction per trial step: not implemented yet
+# every row of modules/sd_samplers_kdiffusion.py:11-27, with the same labels, aliases and options
 samplers_k_diffusion = [
     ('DPM++ 2M', sample_dpmpp_2m, ['k_dpmpp_2m'], {'scheduler': 'karras'}),
+    ('DPM++ SDE', sample_dpmpp_sde, ['k_dpmpp_sde'], {'scheduler': 'karras', "second_order": True, "brownian_noise": True}),
+    ('DPM++ 2M SDE', sample_dpmpp_2m_sde, ['k_dpmpp_2m_sde'], {'scheduler': 'exponential', "brownian_noise": True}),
+    ('DPM++ 2M SDE Heun', sample_dpmpp_2m_sde, ['k_dpmpp_2m_sde_heun'], {'scheduler': 'exponential', "brownian_noise": True, "solver_type": "heun"}),
+    ('DPM++ 3M SDE', sample_dpmpp_3m_sde, ['k_dpmpp_3m_sde'], {'scheduler': 'exponential', 'discard_next_to_last_sigma': True, "brownian_noise": True}),
     ('DPM++ 2S a', sample_dpmpp_2s_ancestral, ['k_dpmpp_2s_a'], {'scheduler': 'karras', "uses_ensd": True, "second_order": True}),
     ('Euler a', sample_euler_ancestral, ['k_euler_a', 'k_euler_ancestral'], {"uses_ensd": True}),
     ('Euler', sample_euler, ['k_euler'], {}),
@@ -1219,6 +1444,7 @@ samplers_k_diffusion = [
     ('DPM2 a', sample_dpm_2_ancestral, ['k_dpm_2_a'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "uses_ensd": True, "second_order": True}),
     ('Restart', restart_sampler, ['restart'], {'scheduler': 'karras', "second_order": True}),
     ('DPM fast', sample_dpm_fast, ['k_dpm_fast'], {"uses_ensd": True}),
+    ('DPM adaptive', sample_dpm_adaptive, ['k_dpm_ad'], {"uses_ensd": True}),
 ]
 sampler_extra_params = {                                 # modules/sd_samplers_kdiffusion.py:36-46
     'sample_euler': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
@@ -1227,6 +1453,9 @@ sampler_extra_params = {                                 # modules/sd_samplers_k
     'sample_dpm_2_ancestral': ['s_noise'],
     'sample_dpmpp_2s_ancestral': ['s_noise'],
     'sample_dpm_fast': ['s_noise'],
+    'sample_dpmpp_sde': ['s_noise'],
+    'sample_dpmpp_2m_sde': ['s_noise'],
+    'sample_dpmpp_3m_sde': ['s_noise'],
 }
 
 def _sampler_extra_args(sampler, p, conditioning, unconditional_conditioning, image_conditioning):
@@ -1283,6 +1512,29 @@ class KDiffusionSampler(Sampler):
             sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
         return sigmas.cpu()
 
+    def create_noise_sampler(self, x, sigmas, p):
+        """modules/sd_samplers_common.py:334-342: a Brownian tree per image SEED, so DPM++ SDE results do not depend on the batch
+        an image is generated in (nor, here, on the rank); None = the sampler's default (fresh Philox noise per step) when
+        opts.no_dpmpp_sde_batch_determinism asks for the pre-1.x behaviour."""
+        if getattr(shared.opts, "no_dpmpp_sde_batch_determinism", False):
+            return None
+        from .brownian import BrownianTreeNoiseSampler
+        sigma_min, sigma_max = sigmas[sigmas > 0].min(), sigmas.max()
+        current_iter_seeds = p.all_seeds[p.iteration * p.batch_size:(p.iteration + 1) * p.batch_size]
+        return BrownianTreeNoiseSampler(x, sigma_min, sigma_max, seed=current_iter_seeds)
+
+    def _sde_options(self, extra_params_kwargs, x, sigmas, p):
+        options = self.config.options if self.config is not None else {}
+        if options.get('brownian_noise', False):
+            ns = self.create_noise_sampler(x, sigmas, p)
+            if ns is not None:
+                extra_params_kwargs['noise_sampler'] = ns
+            else:                                             # k-diffusion's default_noise_sampler: randn_like, i.e. p.rng
+                rng = p.rng
+                extra_params_kwargs['noise_sampler'] = (lambda *a: rng.next())
+        if options.get('solver_type', None) == 'heun':
+            extra_params_kwargs['solver_type'] = 'heun'
+
     def _extra(self, p, conditioning, unconditional_conditioning, image_conditioning):
         self.sampler_extra_args = _sampler_extra_args(self, p, conditioning, unconditional_conditioning, image_conditioning)
         return self.sampler_extra_args
@@ -1307,6 +1559,7 @@ class KDiffusionSampler(Sampler):
             extra_params_kwargs['n'] = len(sigma_sched) - 1
         if 'sigmas' in parameters:
             extra_params_kwargs['sigmas'] = sigma_sched
+        self._sde_options(extra_params_kwargs, x, sigmas, p)   # :163-168 (the noise sampler spans the FULL schedule, as the reference's)
         self.model_wrap_cfg.init_latent = x
         self.last_latent = x
         extra = self._extra(p, conditioning, unconditional_conditioning, image_conditioning)
@@ -1331,6 +1584,7 @@ class KDiffusionSampler(Sampler):
             extra_params_kwargs['sigma_max'] = self.model_wrap.sigmas[-1].item()
         if 'sigmas' in parameters:
             extra_params_kwargs['sigmas'] = sigmas
+        self._sde_options(extra_params_kwargs, x0, sigmas, p)  # :213-218
         self.last_latent = x0
         extra = self._extra(p, conditioning, unconditional_conditioning, image_conditioning)
         return self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,

@@ -49,6 +49,7 @@ class Options:
     sdxl_clip_l_skip: bool = False                 # :222
     beta_dist_alpha: float = 0.6                   # :408
     beta_dist_beta: float = 0.6                    # :409
+    no_dpmpp_sde_batch_determinism: bool = False   # :252 (compatibility: DPM++ SDE noise from the batch generator instead of per-seed trees)
     tiling: bool = False                           # :228
     auto_vae_precision_bfloat16: bool = False      # :181  ("Automatically convert VAE to bfloat16")
     auto_vae_precision: bool = True                # :182  ("Automatically revert VAE to 32-bit floats")

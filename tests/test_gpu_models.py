@@ -131,7 +131,10 @@ def test_vae_decoder_against_reference_class_fixture(dev, golden_dir):
                                                 ("euler", "Euler", 4), ("heun", "Heun", 4), ("dpm_2", "DPM2", 4),
                                                 ("dpm_2_a", "DPM2 a", 4), ("lms", "LMS", 6), ("dpmpp_2s_a", "DPM++ 2S a", 4),
                                                 ("plms", "PLMS", 5), ("ddim_cfgpp", "DDIM CFG++", 5), ("restart", "Restart", 22),
-                                                ("unipc", "UniPC", 6), ("lcm", "LCM", 4), ("dpm_fast", "DPM fast", 6)])
+                                                ("unipc", "UniPC", 6), ("lcm", "LCM", 4), ("dpm_fast", "DPM fast", 6),
+                                                ("dpmpp_sde", "DPM++ SDE", 4), ("dpmpp_2m_sde", "DPM++ 2M SDE", 6),
+                                                ("dpmpp_2m_sde_heun", "DPM++ 2M SDE Heun", 6), ("dpmpp_3m_sde", "DPM++ 3M SDE", 7),
+                                                ("dpm_adaptive", "DPM adaptive", 6)])
 def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     from oracle import pipeline as opipe
     processing = sub("processing")
@@ -254,23 +257,19 @@ def test_lora_merge_into_engine_vs_oracle_and_restore(dev, tiny):
 
 def test_lycoris_module_types_vs_reference_fixture(dev, golden_dir):
     """Every module type of networks.module_types on the reference-generated cases of tests/golden/lyco.npz (LoRA / LoCon with
-    cp-decomposition, DoRA and dyn_dim, LoHa with and without Tucker cores, LoKr in its four forms, GLoRA, IA3, full diff):
-    W + updown computed by the HIP kernels equals W + the reference's calc_updown."""
+    cp-decomposition, DoRA and dyn_dim, LoHa with and without Tucker cores, LoKr in its four forms, GLoRA, IA3, full diff with a
+    bias difference, norm, OFT / COFT / old-LyCORIS OFT / BOFT with rescale): W + updown computed through the HIP kernels equals
+    W + the reference's calc_updown, and the bias deltas equal its ex_bias."""
     from tests.test_oracle_pins import _golden_module
     nets = sub("networks")
     mg = _golden_module()
     z = np.load(os.path.join(golden_dir, "lyco.npz"))
     seen = set()
-    for k, (name, (kind, spec, build)) in enumerate(mg.lyco_cases().items()):
+    cases = list(mg.lyco_cases().items()) + list(mg.lyco_oft_cases().items())       # same indexing as gen_lyco (seeds derive from k)
+    for k, (name, (kind, spec, build)) in enumerate(cases):
         orig, w = mg.lyco_orig_weight(spec, k), build(9000 + 10 * k)
         net = nets.Network("n", unet_multiplier=0.8, te_multiplier=0.3, dyn_dim=3 if name == "lora_dyn" else None)
         weights = nets.NetworkWeights(network_key="lora_unet_x", sd_key="diffusion_model_x", w=dict(w), engine_key="x.weight")
-        if kind == "norm" or "diff_b" in w:
-            with pytest.raises(NotImplementedError):
-                for mt in nets.module_types:
-                    if mt.create_module(net, weights, tuple(orig.shape)) is not None:
-                        break
-            continue
         module = None
         for mt in nets.module_types:
             module = mt.create_module(net, weights, tuple(orig.shape))
@@ -281,8 +280,13 @@ def test_lycoris_module_types_vs_reference_fixture(dev, golden_dir):
         torch.cuda.synchronize()
         want = orig + torch.from_numpy(z[name + "_updown"])
         assert got.shape == want.shape and float((got.cpu() - want).abs().max()) < 2e-6, name
+        if name + "_ex_bias" in z.files:                     # bias deltas: full diff_b, norm b_norm (x multiplier)
+            eb = module.ex_bias(dev)
+            assert float((eb.cpu() - torch.from_numpy(z[name + "_ex_bias"])).abs().max()) < 1e-7, name
+        else:
+            assert module.ex_bias(dev) is None
         seen.add(kind)
-    assert seen == {"lora", "hada", "lokr", "glora", "ia3", "full"}
+    assert seen == {"lora", "hada", "lokr", "glora", "ia3", "full", "norm", "oft"}
 
 
 def test_lycoris_networks_into_engine_vs_oracle(dev, tiny):
@@ -315,15 +319,22 @@ def test_lycoris_networks_into_engine_vs_oracle(dev, tiny):
         "lora_unet_mid_block_resnets_0_conv1.lora_up.weight": r(128, 4, 1, 1), "lora_unet_mid_block_resnets_0_conv1.lora_down.weight": r(4, 128, 3, 3) * 0.3,
         "lora_unet_mid_block_resnets_0_conv1.alpha": torch.tensor(4.0),
         "lora_unet_mid_block_resnets_0_conv1.dora_scale": torch.rand(1, 128, 1, 1, generator=g) * 0.2 + 0.55,
-        # full diff on the 1x1 proj_out
+        # full diff on the 1x1 proj_out, with a bias difference
         "lora_unet_down_blocks_0_attentions_0_proj_out.diff": r(64, 64, 1, 1) * 0.2,
+        "lora_unet_down_blocks_0_attentions_0_proj_out.diff_b": r(64) * 0.3,
+        # norm modules: a ResBlock GroupNorm and a transformer LayerNorm (gain and shift differences)
+        "lora_unet_down_blocks_0_resnets_0_norm1.w_norm": r(64) * 0.4, "lora_unet_down_blocks_0_resnets_0_norm1.b_norm": r(64) * 0.4,
+        blk + "norm2.w_norm": r(64) * 0.4, blk + "norm2.b_norm": r(64) * 0.4,
+        # OFT (4 blocks of 16 rows) on the cross-attention q projection, BOFT (2 butterfly factors, blocks of 8) on attn1 to_q
+        blk + "attn2_to_q.oft_blocks": r(4, 16, 16) * 0.4,
+        blk + "attn1_to_q.oft_blocks": r(2, 8, 8, 8) * 0.4,
     }
     shapes = {k: tuple(v.shape) for k, v in sd.items()}
     assert shapes[schema.UNET_PREFIX + "middle_block.0.in_layers.2.weight"] == (128, 128, 3, 3)
     la = _tiny_lora(schema.unet_schema(schema.tiny_unet()), 9)
     try:
         loaded = nets.load_networks(model, ["lyco", "a"], [lyco, la], unet_multipliers=[0.7, 0.5])
-        assert sorted(m.kind for m in loaded[0].modules.values()) == ["full", "hada", "ia3", "lokr", "lora"]
+        assert sorted(m.kind for m in loaded[0].modules.values()) == ["full", "hada", "ia3", "lokr", "lora", "norm", "norm", "oft", "oft"]
         got = fwd()
         ref_sd = olora.merge({k: v.float() for k, v in sd.items()}, [(lyco, 0.7), (la, 0.5)])
         ref = ou.build_unet(ou.tiny_config(), ref_sd)(x.cpu(), t.cpu(), ctx.cpu())
