@@ -368,7 +368,8 @@ def test_host_lora_names_and_grouping_match_reference(golden_dir):
     m = M()
     mapping = nets.assign_network_names_to_compvis_modules(m)
     assert mapping["diffusion_model_input_blocks_1_1_transformer_blocks_0_attn1_to_q"][0] == "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"
-    assert "diffusion_model_input_blocks_1_0_in_layers_0" not in mapping            # norms are not conv / linear sites
+    # norm layers are addressable too (LyCORIS norm modules rewrite their gain / shift through sdmi_unet_update_vector)
+    assert mapping["diffusion_model_input_blocks_1_0_in_layers_0"] == ("input_blocks.1.0.in_layers.0.weight", (64,))
     g = torch.Generator().manual_seed(0)
     c = mapping["diffusion_model_input_blocks_1_1_proj_in"][1][0]
     sd = {"lora_unet_down_blocks_0_attentions_0_proj_in.lora_up.weight": torch.randn(c, 4, 1, 1, generator=g),
