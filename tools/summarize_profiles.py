@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs under gpurun_out/ (rocpd sqlite) into the committed summaries under profiles/.
 
-    python tools/summarize_profiles.py r01     # reads gpurun_out/prof_stats, prof_pmc_fetch, prof_pmc_write
+    python tools/summarize_profiles.py r02     # reads gpurun_out/prof_stats, prof_pmc_fetch, prof_pmc_write (+ *_k0 A/B passes)
 
 Writes profiles/<round>_kernel_stats.md   (rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1`)
-       profiles/<round>_pmc_traffic.md     (separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per
-                                            MI355X_MICROARCH.md "HBM": gfx950 reports half the bytes of wide coalesced reads)
-       profiles/pmc_traffic.json           (per-launch HBM bytes of the implicit-GEMM family; read by bench.py)
+       profiles/<round>_pmc_traffic.md     (separate --pmc FETCH_SIZE / WRITE_SIZE passes over the SAME workload bench.py times;
+                                            FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 reports half the bytes of
+                                            wide coalesced reads); 3x3-conv launches (the KORD = true ping-pong instantiations) are
+                                            set against their algorithmic bytes from gpurun_out/bench_kernels_c1.json
+       profiles/<round>_pmc_traffic.json   (per-launch HBM bytes of the implicit-GEMM family + the workload key; read by bench.py)
 """
 import collections
 import json
@@ -37,7 +39,7 @@ def first_db(d):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     os.makedirs(P, exist_ok=True)
     con = sqlite3.connect(first_db(os.path.join(G, "prof_stats")))
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
@@ -63,8 +65,7 @@ def main():
     fam = {"calls": 0, "fetch_kb": 0.0, "write_kb": 0.0}
     with open(os.path.join(P, f"{rnd}_pmc_traffic.md"), "w") as f:
         f.write(f"# HBM traffic from PMC counters ({rnd})\n\n`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and a separate `--pmc WRITE_SIZE` pass over "
-                "`python bench.py --steps 1 --warmup 0 --sampler-steps 2 --no-cpu-baseline --no-roofline` (per-launch traffic does not depend on "
-                "the number of sampler steps).  FETCH_SIZE is DOUBLED below (gfx950 tallies 128-byte requests at 64 B — "
+                "`python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline` — the whole C1 job bench.py times (20 sampler steps).  FETCH_SIZE is DOUBLED below (gfx950 tallies 128-byte requests at 64 B — "
                 "MI355X_MICROARCH.md, HBM section); WRITE_SIZE is reported as counted (uncalibrated).\n\n"
                 "| kernel | launches | HBM read MB / launch (corrected) | HBM write MB / launch | avg us (profiled pass) |\n|---|---:|---:|---:|---:|\n")
         for n in names[:24]:
@@ -74,9 +75,50 @@ def main():
             if "gemm_mfma" in n:
                 fam["calls"] += c; fam["fetch_kb"] += 2 * fv; fam["write_kb"] += wv[1] * c / max(wv[0], 1)
     per_launch = (fam["fetch_kb"] + fam["write_kb"]) * 1024 / max(fam["calls"], 1)
-    json.dump({"round": rnd, "gemm_mfma_bytes_per_launch": round(per_launch), "gemm_mfma_launches": fam["calls"],
-               "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over every gemm_mfma_* (two-stage + ping-pong) launch of the PMC pass"},
-              open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    # 3x3 convolutions: the channel-block-major ping-pong instantiations (last template flag true) run nothing else
+    conv = {"calls": 0, "fetch_kb": 0.0, "write_kb": 0.0}
+    for n in fe:
+        if "pingpong" in n and ("true>" in n.replace(" ", "") or n.rstrip().endswith("Lb1EEEvNS_5GemmPE")):
+            c, fv, _ = fe[n]
+            wv = wr.get(n, [1, 0.0, 0.0])
+            conv["calls"] += c; conv["fetch_kb"] += 2 * fv; conv["write_kb"] += wv[1] * c / max(wv[0], 1)
+    alg = None
+    bk = os.path.join(G, "bench_kernels_c1.json")
+    if os.path.exists(bk):
+        ks = [k for k in json.load(open(bk)) if k["name"].startswith("gemm_mfma") and "pp" in k["name"].split(" ")[0] and "conv3x3" in k["name"]]
+        if ks:
+            alg = sum(k["bytes"] for k in ks) / max(sum(k["launches"] for k in ks), 1)
+    out = {"round": rnd, "workload": os.environ.get("SDMI_PMC_WORKLOAD", "c1:20"),
+           "gemm_mfma_bytes_per_launch": round(per_launch), "gemm_mfma_launches": fam["calls"],
+           "conv3x3_pingpong_bytes_per_launch": round((conv["fetch_kb"] + conv["write_kb"]) * 1024 / max(conv["calls"], 1)) if conv["calls"] else None,
+           "conv3x3_pingpong_launches": conv["calls"], "conv3x3_pingpong_algorithmic_bytes_per_launch": round(alg) if alg else None,
+           "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged per launch over the PMC passes of the named workload"}
+    if out["conv3x3_pingpong_bytes_per_launch"] and alg:
+        out["conv3x3_traffic_over_algorithmic"] = round(out["conv3x3_pingpong_bytes_per_launch"] / alg, 3)
+    # optional A/B passes with the round-1 tap-major K order (SDMI_CONV_KORDER=0): the same convs run the KORD = false instantiation
+    k0f, k0w = os.path.join(G, "prof_pmc_fetch_k0"), os.path.join(G, "prof_pmc_write_k0")
+    if os.path.isdir(k0f) and os.path.isdir(k0w):
+        f0, w0 = agg(first_db(k0f), "FETCH_SIZE"), agg(first_db(k0w), "WRITE_SIZE")
+        tot = {"calls": 0, "kb": 0.0}
+        for n in f0:
+            if "gemm_mfma" in n:
+                c, fv, _ = f0[n]
+                wv = w0.get(n, [1, 0.0, 0.0])
+                tot["calls"] += c; tot["kb"] += 2 * fv + wv[1] * c / max(wv[0], 1)
+        out["tap_major_ab"] = {"gemm_mfma_bytes_per_launch": round(tot["kb"] * 1024 / max(tot["calls"], 1)), "launches": tot["calls"],
+                               "workload": "c1 with --sampler-steps 2 (both K orders measured on this shortened job for the A/B)"}
+    k1f, k1w = os.path.join(G, "prof_pmc_fetch_k1"), os.path.join(G, "prof_pmc_write_k1")
+    if os.path.isdir(k1f) and os.path.isdir(k1w):
+        f1, w1 = agg(first_db(k1f), "FETCH_SIZE"), agg(first_db(k1w), "WRITE_SIZE")
+        tot = {"calls": 0, "kb": 0.0}
+        for n in f1:
+            if "gemm_mfma" in n:
+                c, fv, _ = f1[n]
+                wv = w1.get(n, [1, 0.0, 0.0])
+                tot["calls"] += c; tot["kb"] += 2 * fv + wv[1] * c / max(wv[0], 1)
+        out["channel_major_ab"] = {"gemm_mfma_bytes_per_launch": round(tot["kb"] * 1024 / max(tot["calls"], 1)), "launches": tot["calls"]}
+    json.dump(out, open(os.path.join(P, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(G, "pmc_traffic.json"), "w"), indent=1)
     # MFMA utilisation / effective clock per kernel (third PMC pass, optional)
     mdir = os.path.join(G, "prof_pmc_mfma")
     if os.path.isdir(mdir):
