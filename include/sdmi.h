@@ -251,6 +251,21 @@ int sdmi_unet_finalize(sdmi_engine* e);            /* packs layouts; errors if a
 int sdmi_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim,
                             const int64_t* shape, int on_device);
 
+/* Hypernetworks (modules/hypernetworks/hypernetwork.py): per feature width (320 / 640 / 768 / 1280 ...) a pair of small MLPs that
+ * transform the attention context before to_k / to_v — context_k = x + multiplier * MLP_k(x) (HypernetworkModule.forward :104-105,
+ * apply_hypernetworks :358-379, called from every CrossAttention.forward: sd_hijack_optimizations.py:231, hypernetwork.py:388).  The
+ * engine applies them inside its attention layers (self-attention: on the normalised tokens; cross-attention: on the text context
+ * when its K / V are projected).  Hand-over: clear, then per loaded hypernetwork `begin(multiplier)` followed, for every width `dim`
+ * and `which` (0 = K module, 1 = V module), by its op sequence in order: linear ([out, in] weight + bias, nn.Linear layout),
+ * activation (1 relu, 2 leakyrelu, 3 elu, 4 hardswish = the webui's "swish", 5 tanh, 6 sigmoid, 7 silu, 8 gelu, 9 mish, 10 relu6,
+ * 11 selu, 12 softplus, 13 softsign, 14 hardtanh, 15 hardsigmoid), layer norm.  Dropout layers are the identity at inference. */
+int sdmi_unet_hypernet_clear(sdmi_engine* e);
+int sdmi_unet_hypernet_begin(sdmi_engine* e, float multiplier);
+int sdmi_unet_hypernet_linear(sdmi_engine* e, int dim, int which, const void* w, const void* b, int dtype, int out_features,
+                              int in_features, int on_device);
+int sdmi_unet_hypernet_act(sdmi_engine* e, int dim, int which, int act);
+int sdmi_unet_hypernet_layernorm(sdmi_engine* e, int dim, int which, const void* gamma, const void* beta, int dtype, int n, int on_device);
+
 /* The same for a 1-D parameter: "<layer>.bias" of a conv / linear layer, "<norm>.weight" / "<norm>.bias" of a GroupNorm / LayerNorm.
  * Where the bias deltas (`ex_bias`: network_full.py diff_b) and the LyCORIS norm modules (network_norm.py w_norm / b_norm) of
  * extensions-builtin/Lora/networks.py:411-480 land. */

@@ -100,8 +100,11 @@ class ResBlock(nn.Module):
         return self.skip_connection(x) + h
 
 
+LOADED_HYPERNETWORKS: list = []       # oracle.hypernetwork.Hypernetwork objects (shared.loaded_hypernetworks of the reference)
+
+
 class CrossAttention(nn.Module):
-    """modules/hypernetworks/hypernetwork.py:382-407 (baseline forward, no hypernetworks, no mask)."""
+    """modules/hypernetworks/hypernetwork.py:382-407 (baseline forward incl. apply_hypernetworks on the context; no mask)."""
 
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
         super().__init__()
@@ -117,7 +120,11 @@ class CrossAttention(nn.Module):
     def forward(self, x, context=None):
         h = self.heads
         context = x if context is None else context
-        q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
+        context_k = context_v = context
+        if LOADED_HYPERNETWORKS:
+            from .hypernetwork import apply_hypernetworks
+            context_k, context_v = apply_hypernetworks(LOADED_HYPERNETWORKS, context)
+        q, k, v = self.to_q(x), self.to_k(context_k), self.to_v(context_v)
         b, n, _ = q.shape
         split = lambda t: t.reshape(b, t.shape[1], h, -1).permute(0, 2, 1, 3).reshape(b * h, t.shape[1], -1)
         q, k, v = split(q), split(k), split(v)

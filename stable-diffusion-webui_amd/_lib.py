@@ -113,6 +113,11 @@ _SIGS = {
     "sdmi_clip_finalize": (_i, [_vp, _i]),
     "sdmi_clip_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sdmi_unet_update_weight": (_i, [_vp, C.c_char_p, _vp, _i, _i, C.POINTER(C.c_int64), _i]),
+    "sdmi_unet_hypernet_clear": (_i, [_vp]),
+    "sdmi_unet_hypernet_begin": (_i, [_vp, _f]),
+    "sdmi_unet_hypernet_linear": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i]),
+    "sdmi_unet_hypernet_act": (_i, [_vp, _i, _i, _i]),
+    "sdmi_unet_hypernet_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i]),
     "sdmi_unet_update_vector": (_i, [_vp, C.c_char_p, _vp, _i, _i64, _i]),
     "sdmi_lora_merge": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sdmi_weight_hadamard": (_i, [_vp, _vp, _vp, _vp, _f, _i64, _vp]),

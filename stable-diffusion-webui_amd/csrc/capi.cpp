@@ -18,6 +18,11 @@ int engine_clip_forward(sdmi_engine* e, int slot, const int* tokens, const float
                         int apply_final_ln, float* out, float* pooled, hipStream_t s);
 int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data, int dtype, int ndim, const int64_t* shape, int on_device);
 int engine_vae_finalize(sdmi_engine* e);
+int engine_hypernet_clear(sdmi_engine* e);
+int engine_hypernet_begin(sdmi_engine* e, float multiplier);
+int engine_hypernet_linear(sdmi_engine* e, int dim, int which, const void* w, const void* b, int dtype, int out_f, int in_f, int on_device);
+int engine_hypernet_act(sdmi_engine* e, int dim, int which, int act);
+int engine_hypernet_layernorm(sdmi_engine* e, int dim, int which, const void* g, const void* b, int dtype, int n, int on_device);
 int engine_unet_update_vector(sdmi_engine* e, const char* key, const void* data, int dtype, int64_t n, int on_device);
 int engine_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, int L, hipStream_t s, bool conditional = false);
 }  // namespace sdmi
@@ -384,6 +389,37 @@ int sdmi_clip_forward(sdmi_engine* e, int slot, const void* tokens, const void* 
     SDMI_REQUIRE(e != nullptr, "null engine");
     return engine_clip_forward(e, slot, (const int*)tokens, (const float*)inputs_embeds, B, L, skip, apply_final_ln, (float*)out,
                                (float*)pooled, (hipStream_t)stream);
+    API_GUARD_END
+}
+int sdmi_unet_hypernet_clear(sdmi_engine* e) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_hypernet_clear(e);
+    API_GUARD_END
+}
+int sdmi_unet_hypernet_begin(sdmi_engine* e, float multiplier) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_hypernet_begin(e, multiplier);
+    API_GUARD_END
+}
+int sdmi_unet_hypernet_linear(sdmi_engine* e, int dim, int which, const void* w, const void* b, int dtype, int out_features, int in_features,
+                              int on_device) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_hypernet_linear(e, dim, which, w, b, dtype, out_features, in_features, on_device);
+    API_GUARD_END
+}
+int sdmi_unet_hypernet_act(sdmi_engine* e, int dim, int which, int act) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_hypernet_act(e, dim, which, act);
+    API_GUARD_END
+}
+int sdmi_unet_hypernet_layernorm(sdmi_engine* e, int dim, int which, const void* gamma, const void* beta, int dtype, int n, int on_device) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    return engine_hypernet_layernorm(e, dim, which, gamma, beta, dtype, n, on_device);
     API_GUARD_END
 }
 int sdmi_unet_update_vector(sdmi_engine* e, const char* key, const void* data, int dtype, int64_t n, int on_device) {

@@ -169,6 +169,8 @@ int launch_latent_resize(const float* in, float* out, int planes, int hi, int wi
 int launch_cfg_combine_affine(const float* x, const float* out, const float* c_out, const float* c_skip, float cond_scale,
                               const float* mask, const float* nmask, const float* init_latent, float* den, int B, int64_t chw,
                               hipStream_t s);
+int launch_act_f16(half_t* x, int64_t n, int kind, hipStream_t s);                 // in place; kinds: hn_act in elementwise.hip
+int launch_axpy_f16(half_t* y, const half_t* x, const half_t* h, float a, int64_t n, hipStream_t s);   // y = x + a * h
 int launch_silu_f32(const float* x, float* y, int64_t n, hipStream_t s);
 int launch_mask_blend(float* x, const float* init, const float* mask, const float* nmask, int64_t n, hipStream_t s);
 int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W, hipStream_t s);

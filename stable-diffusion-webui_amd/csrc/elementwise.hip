@@ -781,6 +781,44 @@ int launch_silu_f32(const float* x, float* y, int64_t n, hipStream_t s) {
     return 0;
 }
 
+// ---- hypernetwork MLP pieces (modules/hypernetworks/hypernetwork.py:25-113): activation in place on fp16 rows, y = x + a * h ----
+__device__ __forceinline__ float hn_act(float v, int kind) {
+    switch (kind) {
+        case 1: return fmaxf(v, 0.f);                                            // relu
+        case 2: return v > 0.f ? v : 0.01f * v;                                  // leakyrelu (default slope)
+        case 3: return v > 0.f ? v : expm1f(v);                                  // elu (alpha 1)
+        case 4: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);        // hardswish ("swish" in the webui's table)
+        case 5: return tanhf(v);
+        case 6: return 1.f / (1.f + expf(-v));                                   // sigmoid
+        case 7: return v / (1.f + expf(-v));                                     // silu
+        case 8: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));        // gelu (erf)
+        case 9: return v * tanhf(log1pf(expf(fminf(v, 20.f))));                  // mish (softplus threshold 20)
+        case 10: return fminf(fmaxf(v, 0.f), 6.f);                               // relu6
+        case 11: return 1.0507009873554805f * (v > 0.f ? v : 1.6732632423543772f * expm1f(v));   // selu
+        case 12: return v > 20.f ? v : log1pf(expf(v));                          // softplus (beta 1, threshold 20)
+        case 13: return v / (1.f + fabsf(v));                                    // softsign
+        case 14: return fminf(fmaxf(v, -1.f), 1.f);                              // hardtanh
+        case 15: return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f);          // hardsigmoid
+        default: return v;
+    }
+}
+__global__ __launch_bounds__(256) void act_f16_kernel(half_t* x, long n, int kind) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] = (half_t)hn_act((float)x[i], kind);
+}
+int launch_act_f16(half_t* x, int64_t n, int kind, hipStream_t s) {
+    hipLaunchKernelGGL(act_f16_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, (long)n, kind);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ __launch_bounds__(256) void axpy_f16_kernel(half_t* y, const half_t* x, const half_t* h, float a, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = (half_t)((float)x[i] + a * (float)h[i]);
+}
+int launch_axpy_f16(half_t* y, const half_t* x, const half_t* h, float a, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_f16_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, y, x, h, a, (long)n);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_small_linear(const float* a, const half_t* w, const float* bias, const float* add, float* out, int B, int N, int K,
                         int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s) {
     SDMI_REQUIRE(K % 8 == 0 && lda % 4 == 0, "small_linear: K % 8 == 0, lda % 4 == 0");

@@ -378,9 +378,11 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
 }
 
 // plain [rows, K] x W^T GEMM on token matrices
-static int run_linear(Run& r, const ConvW& W, const half_t* a, int rows, const half_t* resid, half_t* out, int ldo, float ss = 1.f) {
+static int run_linear(Run& r, const ConvW& W, const half_t* a, int rows, const half_t* resid, half_t* out, int ldo, float ss = 1.f,
+                      bool no_split = false) {
     ConvArgs c;
     c.alpha = ss; c.bias_scale = ss;
+    c.no_split = no_split;
     c.a0 = a; c.c0 = W.cin_pad;
     c.B = 1; c.Hi = rows; c.Wi = 1; c.Ho = rows; c.Wo = 1;
     c.resid = resid; c.ldr = ldo; c.out = out; c.ldo = ldo;
@@ -493,6 +495,61 @@ static int run_vt(Run& r, const ConvW& Wv, const half_t* x, int ldx, int B, int 
     return launch_gemm(p, B, r.e->force_generic, r.e->use_glds, r.s);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// hypernetworks: context_k / context_v = x + multiplier * MLP(x), chained over the loaded networks (hypernetwork.py:358-379)
+// ------------------------------------------------------------------------------------------------------------
+static bool hn_has_dim(const sdmi_engine* e, int dim) {
+    for (const auto& n : e->hypernets)
+        if (n.by_dim.count(dim)) return true;
+    return false;
+}
+
+// `alloc(n)` hands out n halfs (the forward's arena, or the persistent context scratch).  Returns x itself when no loaded network
+// has modules for this width.  Intermediates stay fp16 (the reference runs the small MLPs in fp32 and casts back, :366-367).
+template <typename Alloc>
+static int run_hn(Run& r, int dim, int which, const half_t* x, size_t rows, Alloc alloc, bool no_split, const half_t** out) {
+    const half_t* cur = x;
+    for (const HnNet& net : r.e->hypernets) {
+        auto it = net.by_dim.find(dim);
+        if (it == net.by_dim.end()) continue;
+        const HnModule& mod = which ? it->second.second : it->second.first;
+        const half_t* h = cur;
+        int width = dim;
+        half_t* y = nullptr;
+        for (size_t i = 0; i < mod.ops.size(); ++i) {
+            const HnOp& op = mod.ops[i];
+            const bool last = i + 1 == mod.ops.size();
+            if (op.kind == 0) {
+                SDMI_REQUIRE(op.lin.cin_pad == width || r.dry, "hypernetwork layer widths do not chain");
+                half_t* t = alloc(rows * (size_t)op.lin.n_pad);
+                if (last) {                                   // x + multiplier * (h W^T + b): folded into the GEMM epilogue
+                    SDMI_REQUIRE(op.lin.n_pad == dim, "hypernetwork output width must equal its input width");
+                    TRY(run_linear(r, op.lin, h, (int)rows, cur, t, op.lin.n_pad, net.multiplier, no_split));
+                    y = t;
+                } else {
+                    TRY(run_linear(r, op.lin, h, (int)rows, nullptr, t, op.lin.n_pad, 1.f, no_split));
+                }
+                h = t;
+                width = op.lin.n_pad;
+            } else if (op.kind == 1) {
+                if (!r.dry) TRY(launch_act_f16(const_cast<half_t*>(h), (int64_t)rows * width, op.act, r.s));   // h is never x itself here
+            } else {
+                half_t* t = alloc(rows * (size_t)width);
+                if (!r.dry) TRY(launch_layernorm(h, op.ln.g, op.ln.b, t, (int64_t)rows, width, 1e-5f, r.s));
+                h = t;
+            }
+        }
+        if (y == nullptr) {                                    // the module ends in an activation / LayerNorm: separate x + m * h
+            SDMI_REQUIRE(width == dim, "hypernetwork output width must equal its input width");
+            y = alloc(rows * (size_t)dim);
+            if (!r.dry) TRY(launch_axpy_f16(y, cur, h, net.multiplier, (int64_t)rows * dim, r.s));
+        }
+        cur = y;
+    }
+    *out = cur;
+    return 0;
+}
+
 static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, int L, half_t** out,
                   const std::string& name = std::string()) {
     sdmi_engine* e = r.e;
@@ -509,12 +566,34 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         // --- self attention
         half_t* n1 = r.H(M * C);
         TRY(run_ln(r, b.ln1, cur, M, n1));
-        half_t* qk = r.H(M * 2 * C);
-        TRY(run_linear(r, b.qk1, n1, (int)M, nullptr, qk, 2 * C));
-        half_t* vt = r.H((size_t)B * C * Npad);
-        TRY(run_vt(r, b.v1, n1, C, B, HW, Npad, vt, false));
-        half_t* a1 = r.H(M * C);
-        TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
+        half_t* a1 = nullptr;
+        if (!hn_has_dim(e, C)) {
+            half_t* qk = r.H(M * 2 * C);
+            TRY(run_linear(r, b.qk1, n1, (int)M, nullptr, qk, 2 * C));
+            half_t* vt = r.H((size_t)B * C * Npad);
+            TRY(run_vt(r, b.v1, n1, C, B, HW, Npad, vt, false));
+            a1 = r.H(M * C);
+            TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
+        } else {
+            // hypernetworks loaded for this width: K and V are projected from their own transformed copies of the context (= n1),
+            // so the stacked q|k GEMM splits into its two halves (views into the same packed weight)
+            auto alloc = [&](size_t n) { return r.H(n); };
+            const half_t *xk = nullptr, *xv = nullptr;
+            TRY(run_hn(r, C, 0, n1, M, alloc, false, &xk));
+            TRY(run_hn(r, C, 1, n1, M, alloc, false, &xv));
+            ConvW wq = b.qk1, wk = b.qk1;
+            wq.n_pad = wk.n_pad = C; wq.cout = wk.cout = C;
+            wk.w = b.qk1.w + (size_t)C * b.qk1.cin_pad;
+            if (b.qk1.b) wk.b = b.qk1.b + C;
+            half_t* q = r.H(M * C);
+            half_t* k = r.H(M * C);
+            TRY(run_linear(r, wq, n1, (int)M, nullptr, q, C));
+            TRY(run_linear(r, wk, xk, (int)M, nullptr, k, C));
+            half_t* vt = r.H((size_t)B * C * Npad);
+            TRY(run_vt(r, b.v1, xv, C, B, HW, Npad, vt, false));
+            a1 = r.H(M * C);
+            TRY(run_attn(r, q, k, vt, a1, B, st.heads, HW, HW, st.dhead, C, C, Npad, C));
+        }
         half_t* x1 = r.H(M * C);
         TRY(run_linear(r, b.o1, a1, (int)M, cur, x1, C));
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
@@ -581,7 +660,7 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
     const int cd = u.cfg.context_dim;
     const int Lpad = rup(L, 64);
     const int* gate = nullptr;
-    if (conditional && e->ctx_valid && e->ctx_B == Bn && e->ctx_L == L && !e->ctx_k.empty()) {
+    if (conditional && e->ctx_valid && e->ctx_B == Bn && e->ctx_L == L && !e->ctx_k.empty() && !hn_has_dim(e, cd)) {
         if (!e->ctx_gate) {
             SDMI_CHECK_HIP(hipMalloc((void**)&e->ctx_gate, 256));
             e->owned.push_back(e->ctx_gate);
@@ -623,13 +702,37 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
         }
     }
     Run r{e, s, false};
+    // hypernetworks of the context width: context_k / context_v replace the context in the K / V projections of every layer
+    const half_t *ctx_k_src = e->ctx_f16, *ctx_v_src = e->ctx_f16;
+    if (hn_has_dim(e, cd)) {
+        SDMI_REQUIRE(gate == nullptr, "internal: gated context update with hypernetworks");
+        const size_t rows = (size_t)Bn * Lpad;
+        for (int pass = 0; pass < 2; ++pass) {               // pass 0 sizes the persistent scratch, pass 1 runs
+            size_t off = 0;
+            const bool dry = pass == 0;
+            auto alloc = [&](size_t n) {
+                const size_t a = (off + 255) & ~size_t(255);
+                off = a + n * sizeof(half_t);
+                return (half_t*)(dry ? (char*)0x1000 + a : e->hn_ctx_scratch + a);
+            };
+            Run rr{e, s, dry};
+            TRY(run_hn(rr, cd, 0, e->ctx_f16, rows, alloc, true, &ctx_k_src));
+            TRY(run_hn(rr, cd, 1, e->ctx_f16, rows, alloc, true, &ctx_v_src));
+            if (dry && off > e->hn_ctx_scratch_bytes) {
+                SDMI_CHECK_HIP(hipStreamSynchronize(s));
+                if (e->hn_ctx_scratch) (void)hipFree(e->hn_ctx_scratch);
+                SDMI_CHECK_HIP(hipMalloc((void**)&e->hn_ctx_scratch, off + 256));
+                e->hn_ctx_scratch_bytes = off;
+            }
+        }
+    }
     std::vector<const STW*> sts;
     collect_st(u, &sts);
     for (const STW* st : sts)
         for (const TBlockW& b : st->blocks) {
             // K[b] = ctx[b] Wk^T : rows L per image, batched over images (compact [Bn*L][C] output)
             ConvArgs c;
-            c.a0 = e->ctx_f16; c.c0 = cd; c.B = 1; c.Hi = L; c.Wi = 1; c.Ho = L; c.Wo = 1;
+            c.a0 = ctx_k_src; c.c0 = cd; c.B = 1; c.Hi = L; c.Wi = 1; c.Ho = L; c.Wo = 1;
             c.out = e->ctx_k[b.ctx_slot]; c.ldo = st->ch;
             c.batch = Bn; c.a_bs = (long)Lpad * cd; c.o_bs = (long)L * st->ch;
             c.gate = gate;
@@ -638,7 +741,7 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
             c.no_split = true;
             TRY(run_conv(r, b.k2, c));
             // V^T[b] = Wv ctx[b]^T : [C][Lpad]
-            TRY(run_vt(r, b.v2, e->ctx_f16, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false, gate));
+            TRY(run_vt(r, b.v2, ctx_v_src, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false, gate));
         }
     e->ctx_valid = true;
     return 0;
@@ -1310,6 +1413,78 @@ int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data,
     e->ctx_valid = false;                                     // cached K / V^T depend on attn2.to_k / to_v
     return rc;
 }
+// ---- hypernetwork hand-over ------------------------------------------------------------------------------------------------
+int engine_hypernet_clear(sdmi_engine* e) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    for (void* p : e->owned_hn) (void)hipFree(p);
+    e->owned_hn.clear();
+    e->hypernets.clear();
+    e->ctx_valid = false;                                     // cached context K / V^T depend on the loaded hypernetworks
+    return 0;
+}
+int engine_hypernet_begin(sdmi_engine* e, float multiplier) {
+    HnNet n;
+    n.multiplier = multiplier;
+    e->hypernets.push_back(n);
+    e->ctx_valid = false;
+    return 0;
+}
+static HnModule* hn_module(sdmi_engine* e, int dim, int which) {
+    if (e->hypernets.empty()) return nullptr;
+    auto& pr = e->hypernets.back().by_dim[dim];
+    return which ? &pr.second : &pr.first;
+}
+int engine_hypernet_linear(sdmi_engine* e, int dim, int which, const void* w, const void* b, int dtype, int out_f, int in_f, int on_device) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    HnModule* m = hn_module(e, dim, which);
+    SDMI_REQUIRE(m != nullptr, "sdmi_unet_hypernet_begin first");
+    SDMI_REQUIRE(w && out_f > 0 && in_f > 0 && in_f % 8 == 0, "hypernetwork linear: bad shape");
+    std::map<std::string, RawTensor> tmp;
+    const int64_t ws[2] = {out_f, in_f}, bs[1] = {out_f};
+    TRY(load_raw(tmp, "l.weight", w, dtype, 2, ws, on_device));
+    if (b) TRY(load_raw(tmp, "l.bias", b, dtype, 1, bs, on_device));
+    HnOp op;
+    op.kind = 0;
+    e->alloc_sink = &e->owned_hn;
+    const int rc = pack_one(e, tmp, "l", true, false, &op.lin);
+    e->alloc_sink = nullptr;
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    free_raw(tmp);
+    TRY(rc);
+    m->ops.push_back(op);
+    return 0;
+}
+int engine_hypernet_act(sdmi_engine* e, int dim, int which, int act) {
+    HnModule* m = hn_module(e, dim, which);
+    SDMI_REQUIRE(m != nullptr, "sdmi_unet_hypernet_begin first");
+    SDMI_REQUIRE(act >= 1 && act <= 15, "unknown hypernetwork activation");
+    HnOp op;
+    op.kind = 1; op.act = act;
+    m->ops.push_back(op);
+    return 0;
+}
+int engine_hypernet_layernorm(sdmi_engine* e, int dim, int which, const void* g, const void* b, int dtype, int n, int on_device) {
+    SDMI_CHECK_HIP(hipSetDevice(e->device));
+    HnModule* m = hn_module(e, dim, which);
+    SDMI_REQUIRE(m != nullptr, "sdmi_unet_hypernet_begin first");
+    SDMI_REQUIRE(g && b && n % 64 == 0 && n <= 2048, "hypernetwork LayerNorm: width must be a multiple of 64 and <= 2048");
+    std::map<std::string, RawTensor> tmp;
+    const int64_t sh[1] = {n};
+    TRY(load_raw(tmp, "n.weight", g, dtype, 1, sh, on_device));
+    TRY(load_raw(tmp, "n.bias", b, dtype, 1, sh, on_device));
+    HnOp op;
+    op.kind = 2;
+    e->alloc_sink = &e->owned_hn;
+    const int rc = pack_norm(e, tmp, "n", &op.ln);
+    e->alloc_sink = nullptr;
+    SDMI_CHECK_HIP(hipDeviceSynchronize());
+    free_raw(tmp);
+    TRY(rc);
+    m->ops.push_back(op);
+    return 0;
+}
+
 // Replace one 1-D parameter of the finalized UNet (a conv / linear bias, a GroupNorm / LayerNorm gain or shift) in place.
 int engine_unet_update_vector(sdmi_engine* e, const char* key, const void* data, int dtype, int64_t n, int on_device) {
     SDMI_CHECK_HIP(hipSetDevice(e->device));
@@ -1366,5 +1541,7 @@ sdmi_engine::~sdmi_engine() {
     sdmi::ctx_free(this);
     for (void* p : owned) (void)hipFree(p);
     for (void* p : owned_vae) (void)hipFree(p);
+    for (void* p : owned_hn) (void)hipFree(p);
+    if (hn_ctx_scratch) (void)hipFree(hn_ctx_scratch);
     if (arena.base) (void)hipFree(arena.base);
 }

@@ -118,6 +118,23 @@ struct VAEW {
     bool ready = false;
 };
 
+// Hypernetworks (modules/hypernetworks/hypernetwork.py): per feature width a pair of small MLPs (one for the K path, one for the V path)
+// applied to the attention CONTEXT before to_k / to_v: context_k = x + multiplier * MLP_k(x) (forward, :104-105; apply_hypernetworks
+// :358-379).  An MLP is a sequence of Linear / activation / LayerNorm ops (dropout is the identity at inference).
+struct HnOp {
+    int kind = 0;                 // 0 linear, 1 activation, 2 layer norm
+    ConvW lin;
+    int act = 0;
+    NormW ln;
+};
+struct HnModule {
+    std::vector<HnOp> ops;
+};
+struct HnNet {
+    float multiplier = 1.f;
+    std::map<int, std::pair<HnModule, HnModule>> by_dim;    // feature width -> (K module, V module)
+};
+
 class Arena {
 public:
     char* base = nullptr;
@@ -150,6 +167,10 @@ struct sdmi_engine {
     std::vector<void*> owned;                 // persistent device allocations (weights)
     std::vector<void*> owned_vae;             // the VAE's packed weights: freed when another VAE is loaded (sd_vae.load_vae)
     std::vector<void*>* alloc_sink = nullptr; // where dev_alloc records (null = owned)
+    std::vector<sdmi::HnNet> hypernets;       // loaded hypernetworks, in application order (shared.loaded_hypernetworks)
+    std::vector<void*> owned_hn;
+    char* hn_ctx_scratch = nullptr;           // intermediates of the hypernetwork pass over the text context (set_context)
+    size_t hn_ctx_scratch_bytes = 0;
     sdmi::UNetW unet;
     sdmi::VAEW vae;
     sdmi::ClipW clip[2];

@@ -1131,6 +1131,53 @@ def gen_zsnr():
     print("zsnr.npz")
 
 
+HN_CASES = {            # name -> (dim, layer_structure, activation_func, add_layer_norm, activate_output, dropout_structure)
+    "lin_121": (64, [1, 2, 1], "linear", False, False, None),
+    "relu_121": (64, [1, 2, 1], "relu", False, False, None),
+    "swish_ln_1221_ao": (64, [1, 2, 2, 1], "swish", True, True, None),
+    "elu_drop_1221": (128, [1, 2, 2, 1], "elu", False, False, [0, 0.3, 0.3, 0]),
+    "tanh_131_ao": (64, [1, 3, 1], "tanh", False, True, None),
+    "sigmoid_121": (128, [1, 2, 1], "sigmoid", False, False, None),
+    "leakyrelu_121": (64, [1, 2, 1], "leakyrelu", False, False, None),
+    "mish_ln_121": (64, [1, 2, 1], "mish", True, False, None),
+}
+
+
+def gen_hypernetwork():
+    """HypernetworkModule / apply_hypernetworks of modules/hypernetworks/hypernetwork.py, exec'd from the file's own text (the module
+    imports half of the webui at import time): module outputs at multiplier 0.7 for HN_CASES on seeded weights, and two chained
+    networks over a context (K and V paths)."""
+    import inspect as _inspect
+    src = open(os.path.join(REF, "modules/hypernetworks/hypernetwork.py")).read()
+    a, b = src.index("class HypernetworkModule"), src.index("#param layer_structure")
+    c, d = src.index("def apply_single_hypernetwork"), src.index("def attention_CrossAttention_forward")
+    from torch.nn.init import normal_, xavier_normal_, xavier_uniform_, kaiming_normal_, kaiming_uniform_, zeros_
+    devices = types.SimpleNamespace(torch_npu_set_device=lambda: None, device=torch.device("cpu"), cond_cast_unet=lambda x: x,
+                                    cond_cast_float=lambda x: x.float())
+    ns = dict(torch=torch, inspect=_inspect, normal_=normal_, xavier_normal_=xavier_normal_, xavier_uniform_=xavier_uniform_,
+              kaiming_normal_=kaiming_normal_, kaiming_uniform_=kaiming_uniform_, zeros_=zeros_, devices=devices)
+    exec(src[a:b] + "\n" + src[c:d], ns)
+    out = {}
+    mods = {}
+    with torch.no_grad():
+        for k, (name, (dim, ls, act, ln, ao, ds)) in enumerate(HN_CASES.items()):
+            m = ns["HypernetworkModule"](dim, None, ls, act, "Normal", ln, ao, dropout_structure=ds)
+            m.eval()
+            seeded_module_weights(m, 6000 + k)
+            m.multiplier = 0.7
+            x = seeded((2, 10, dim), 6100 + k)
+            out[name] = m(x).numpy()
+            mods[name] = m
+        # two networks chained over a width-64 context (K module, V module of each)
+        hn_a = types.SimpleNamespace(layers={64: (mods["relu_121"], mods["lin_121"])})
+        hn_b = types.SimpleNamespace(layers={64: (mods["tanh_131_ao"], mods["swish_ln_1221_ao"]), 128: (mods["elu_drop_1221"], mods["sigmoid_121"])})
+        ctx = seeded((2, 7, 64), 6200)
+        ck, cv = ns["apply_hypernetworks"]([hn_a, hn_b], ctx)
+        out["chain_k"], out["chain_v"] = ck.numpy(), cv.numpy()
+    np.savez_compressed(os.path.join(OUT, "hypernetwork.npz"), **out)
+    print("hypernetwork.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -1154,3 +1201,4 @@ if __name__ == "__main__":
     gen_unet_twins()
     gen_euler_twin()
     gen_zsnr()
+    gen_hypernetwork()

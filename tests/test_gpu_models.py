@@ -976,3 +976,55 @@ def test_tiling_circular_padding_unet_and_vae_vs_oracle(dev, tiny):
                                                      cfg_scale=3.0, width=128, height=128, sampler_name="Euler")
     b = processing.process_images(p2).latents
     assert not torch.equal(a, b)
+
+
+def _hn_state(dims, ls, act, ln, ao, ds, seed, name):
+    """A hypernetwork file's content (what torch.load returns, modules/hypernetworks/hypernetwork.py:246-300) with seeded weights."""
+    from oracle import hypernetwork as ohn
+    from helpers import seeded_module_weights
+    sd = {"layer_structure": ls, "activation_func": act, "is_layer_norm": ln, "activate_output": ao, "dropout_structure": ds, "name": name}
+    for j, dim in enumerate(dims):
+        pair = []
+        for w in (0, 1):
+            m = ohn.HypernetworkModule(dim, None, ls, act, ln, ao, ds)
+            seeded_module_weights(m, seed + 10 * j + w)
+            with torch.no_grad():
+                for p in m.parameters():                     # trained hypernetworks are small perturbations of the identity map
+                    if p.dim() == 2:
+                        p.mul_(0.5)
+            pair.append({k: v.clone() for k, v in m.state_dict().items()})
+        sd[dim] = tuple(pair)
+    return sd
+
+
+def test_hypernetworks_in_engine_vs_oracle(dev, tiny):
+    """shared.loaded_hypernetworks inside the engine's attention layers (modules/hypernetworks/hypernetwork.py:358-379): two
+    networks chained, modules for the self-attention widths (64, 128) and the text-context width (64 in the tiny model), different
+    structures (activation, LayerNorm, activate_output, dropout index shift), multipliers; unloading restores the original bits."""
+    from oracle import hypernetwork as ohn, unet as ou
+    hn_mod = sub("hypernetwork")
+    model, om = tiny["model"], tiny["oracle"]
+    eng = model.engine
+    x, t, ctx = seeded((2, 4, 16, 16), 61).to(dev), torch.tensor([650.0, 40.0], device=dev), seeded((2, 77, 64), 62).to(dev)
+
+    def fwd():
+        eng.set_context(ctx)
+        return eng.unet_forward(x, t, None, None).float().cpu()
+    base = fwd()
+    a = _hn_state([64, 128], [1, 2, 1], "relu", False, False, None, 7000, "hn_a")
+    b = _hn_state([64], [1, 2, 2, 1], "swish", True, True, [0, 0.3, 0.3, 0], 7100, "hn_b")
+    try:
+        loaded = hn_mod.load_hypernetworks(model, [a, b], [0.8, 0.5])
+        assert [h.name for h in loaded] == ["hn_a", "hn_b"] and loaded[0].multiplier == 0.8
+        got = fwd()
+        ou.LOADED_HYPERNETWORKS[:] = [ohn.Hypernetwork(a, 0.8), ohn.Hypernetwork(b, 0.5)]
+        with torch.no_grad():
+            ref = om.unet(x.cpu(), t.cpu(), ctx.cpu().half().float())
+        assert rel_l2(got, ref) < 8e-3 and rel_l2(got, base) > 3e-2
+        # the SdUnet adapter's device-side context cache must not skip the hypernetwork pass over the text context
+        eng.set_context_cached(ctx)
+        assert torch.equal(eng.unet_forward(x, t, None, None).float().cpu(), got)
+    finally:
+        ou.LOADED_HYPERNETWORKS[:] = []
+        hn_mod.load_hypernetworks(model, [], [])
+    assert torch.equal(fwd(), base)

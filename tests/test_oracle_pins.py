@@ -607,3 +607,24 @@ def test_cfg_combine_and_euler_ancestral_step():
     xo = torch.stack([torch.full((1,), 3.0), torch.full((1,), 5.0), torch.full((1,), 1.0), torch.full((1,), 2.0)])
     den = kd.CFGDenoiser.combine_denoised(xo, [[(0, 1.0)], [(1, 1.0)]], 2, 7.0)
     assert den.flatten().tolist() == [1.0 + (3.0 - 1.0) * 7.0, 2.0 + (5.0 - 2.0) * 7.0]
+
+
+def test_hypernetwork_module_and_chain_match_reference(golden_dir):
+    """oracle.hypernetwork.HypernetworkModule / apply_hypernetworks == the reference's class and functions
+    (modules/hypernetworks/hypernetwork.py:25-113, 358-379), exec'd from its own text by tests/golden/make_golden.py:gen_hypernetwork."""
+    from oracle import hypernetwork as ohn
+    mg = _golden_module()
+    z = np.load(os.path.join(golden_dir, "hypernetwork.npz"))
+    mods = {}
+    with torch.no_grad():
+        for k, (name, (dim, ls, act, ln, ao, ds)) in enumerate(mg.HN_CASES.items()):
+            m = ohn.HypernetworkModule(dim, None, ls, act, ln, ao, ds)
+            seeded_module_weights(m, 6000 + k)
+            m.multiplier = 0.7
+            assert rel_l2(m(seeded((2, 10, dim), 6100 + k)), z[name]) < 1e-6, name
+            mods[name] = m
+        a, b = ohn.Hypernetwork({}), ohn.Hypernetwork({})
+        a.layers = {64: (mods["relu_121"], mods["lin_121"])}
+        b.layers = {64: (mods["tanh_131_ao"], mods["swish_ln_1221_ao"]), 128: (mods["elu_drop_1221"], mods["sigmoid_121"])}
+        ck, cv = ohn.apply_hypernetworks([a, b], seeded((2, 7, 64), 6200))
+        assert rel_l2(ck, z["chain_k"]) < 1e-6 and rel_l2(cv, z["chain_v"]) < 1e-6
