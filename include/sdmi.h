@@ -339,6 +339,9 @@ int sdmi_engine_tap_read(sdmi_engine* e, int index, void* out_f16_nhwc, void* st
 /* Tuning knobs for benchmarks: "gemm_cfg" (-1 heuristic, 0..7 force a tile configuration when it fits the shape),
  * "attn_kvt" (0 heuristic, 64 force 64-key tiles). */
 int sdmi_debug_set(const char* name, int value);
+/* String-valued knob: "gemm_override" = "M,N,K,taps,kind:cfg:split;..." forces a tile configuration / split-K factor for exact GEMM
+ * shapes (kind 0 plain epilogue, 1 GEGLU, 2 transposed output; "" clears) — the in-engine shape autotuner tools/gpu/shape_tune.py. */
+int sdmi_debug_set_str(const char* name, const char* value);
 
 /* Optional per-launch HIP-event profiler: between begin and end every kernel launch of the library is bracketed by events
  * on its own stream; end() synchronises once and writes {"kernels":[{"name","launches","ms","flops","bytes"},...]} with the

@@ -133,6 +133,7 @@ _SIGS = {
     "sdmi_vae_decode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sdmi_vae_encode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sdmi_debug_set": (_i, [C.c_char_p, _i]),
+    "sdmi_debug_set_str": (_i, [C.c_char_p, C.c_char_p]),
     "sdmi_profile_begin": (_i, []),
     "sdmi_profile_end": (_i, [C.c_char_p, _i]),
     "sdmi_engine_arena_bytes": (_i64, [_vp]),

@@ -500,6 +500,18 @@ int sdmi_debug_set(const char* name, int value) {
     API_GUARD_END
 }
 
+int sdmi_debug_set_str(const char* name, const char* value) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(name != nullptr, "null name");
+    if (std::string(name) == "gemm_override") {
+        SDMI_REQUIRE(gemm_set_override(value) == 0, "gemm_override: expected M,N,K,taps,kind:cfg:split;...");
+        return 0;
+    }
+    set_error(std::string("unknown debug knob ") + name);
+    return 1;
+    API_GUARD_END
+}
+
 int sdmi_profile_begin(void) {
     prof_begin();
     return 0;

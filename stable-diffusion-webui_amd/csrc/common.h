@@ -98,6 +98,7 @@ int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hi
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)
 // worst-case fp32 workspace a split-K launch of this shape may use (bytes); 0 when split-K would never be chosen
 size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch);
+int gemm_set_override(const char* spec);   // "M,N,K,taps,kind:cfg:split;..." (kind 0 plain / 1 GEGLU / 2 transposed); "" clears
 extern int g_force_gemm_cfg;
 extern int g_shortk_gemm_cfg;
 extern int g_shortk_max_k;          // the launches g_shortk_gemm_cfg applies to: taps == 1 and K <= this (default 448)

@@ -1030,6 +1030,41 @@ static float cfg_score(const GemmP& p, int batch, int cfg, int split) {
     return score;
 }
 
+// Per-shape choices.  (1) a runtime override list for in-engine autotuning (sdmi_debug_set_str("gemm_override", ...),
+// tools/gpu/shape_tune.py: every candidate tile / split of a shape is timed INSIDE the whole job, where its operands sit in the
+// cache state they really have — isolated micro-benchmarks mis-ranked tiles twice in round 1); (2) the table those runs produced
+// for the shapes of the benchmarked workload.  Anything not listed falls through to the score model below.
+struct ShapeKey { int M, N, K, taps, kind; };            // kind: 0 plain epilogue, 1 GEGLU, 2 transposed output
+struct ShapeChoice { ShapeKey k; int cfg, split; };
+static std::vector<ShapeChoice> g_gemm_override;
+static const ShapeChoice kTunedShapes[] = {
+    // {M, N, K, taps, kind}, cfg, split      — filled from profiles/r02_shape_tuning.md
+#include "gemm_tuned_shapes.inc"
+    {{0, 0, 0, 0, 0}, -1, 1}
+};
+int gemm_set_override(const char* spec) {
+    g_gemm_override.clear();
+    if (!spec) return 0;
+    const char* c = spec;
+    while (*c) {
+        ShapeChoice sc{};
+        int n = 0;
+        if (sscanf(c, "%d,%d,%d,%d,%d:%d:%d%n", &sc.k.M, &sc.k.N, &sc.k.K, &sc.k.taps, &sc.k.kind, &sc.cfg, &sc.split, &n) != 7) return 1;
+        g_gemm_override.push_back(sc);
+        c += n;
+        if (*c == ';') ++c;
+    }
+    return 0;
+}
+static const ShapeChoice* find_shape(const GemmP& p) {
+    const int kind = (p.flags & EP_GEGLU) ? 1 : (p.flags & EP_TRANSPOSE) ? 2 : 0;
+    for (const ShapeChoice& sc : g_gemm_override)
+        if (sc.k.M == p.M && sc.k.N == p.N && sc.k.K == p.K && sc.k.taps == p.taps && sc.k.kind == kind) return &sc;
+    for (const ShapeChoice& sc : kTunedShapes)
+        if (sc.cfg >= 0 && sc.k.M == p.M && sc.k.N == p.N && sc.k.K == p.K && sc.k.taps == p.taps && sc.k.kind == kind) return &sc;
+    return nullptr;
+}
+
 static int pick_cfg(const GemmP& p, int batch, int* split_out, bool allow_split) {
     *split_out = 1;
     if (g_force_gemm_cfg >= 0 && cfg_valid(g_force_gemm_cfg, p)) {
@@ -1040,6 +1075,14 @@ static int pick_cfg(const GemmP& p, int batch, int* split_out, bool allow_split)
     if (g_shortk_gemm_cfg >= 0 && p.taps == 1 && p.K <= g_shortk_max_k && !(p.flags & EP_GEGLU) && cfg_valid(g_shortk_gemm_cfg, p))
         return g_shortk_gemm_cfg;
     if (g_geglu_gemm_cfg >= 0 && (p.flags & EP_GEGLU) && cfg_valid(g_geglu_gemm_cfg, p)) return g_geglu_gemm_cfg;
+    if (batch == 1) {
+        if (const ShapeChoice* sc = find_shape(p)) {
+            if (cfg_valid(sc->cfg, p) && (sc->split <= 1 || (allow_split && p.K / 64 / sc->split >= 2))) {
+                *split_out = sc->split > 1 ? sc->split : 1;
+                return sc->cfg;
+            }
+        }
+    }
     const int cands[] = {CFG_256x320, CFG_256x256, CFG_128x320, CFG_128x128_K32, CFG_128x128, CFG_128x64, CFG_64x64};
     int best = -1;
     float best_score = -1.f;
