@@ -71,6 +71,13 @@ struct GemmP {
     int splitk;
     int splitk_steps;     // BK-steps per slice
     long long* dbg;       // tuning only: per-wave section timers of the ping-pong kernel (sdmi_debug_set gemm_dbg_lo/hi)
+    // GroupNorm statistics of the OUTPUT tensor from this launch's epilogue (drops the consumer's statistics pass): per
+    // (image, row chunk = this tile's BM rows, group) the sum and sum of squares of the fp16-rounded outputs, written to
+    // stats_out[((b * stats_nchunk + chunk) * (N / stats_cpg) + g) * 2 + {0, 1}] — the layout gn_apply's prologue reduces.
+    // Deterministic: registers -> 16-lane shuffle tree -> LDS -> one thread per group, all in fixed order.
+    float* stats_out;
+    int stats_cpg;        // channels per group of the consumer's GroupNorm
+    int stats_nchunk;     // rows_per_batch / BM, set by launch_gemm when the fusion applies (0 = not produced)
     int korder;           // K walk of a 3x3 conv: 0 = tap-major (tap outer, channels inner: round 1), 1 = channel-block-major (64 channels
                           // outer, the 9 taps inner): the 9 shifted reads of one channel block follow each other, so they are served by the
                           // XCD's L2 instead of nine passes over the whole tile set's rows (PMC round 1: 2.3-3x the algorithmic fetch).
@@ -94,7 +101,10 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000 };    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
 
-int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s);
+// stats_nchunk_out (optional): the number of row chunks per image of the GroupNorm partial sums written to p.stats_out, or 0 when the
+// launch could not produce them (split-K, a tile spanning two images, a group straddling column tiles ...)
+int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out = nullptr);
+extern int g_gn_fuse;               // 1 (default): GroupNorm statistics from the producing GEMM's epilogue where possible; 0: always a stats pass
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)
 // worst-case fp32 workspace a split-K launch of this shape may use (bytes); 0 when split-K would never be chosen
 size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch);
@@ -130,8 +140,9 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, int ldv, int Mpad, hipStream_t s);
 
 // ---- norms ------------------------------------------------------------------------------------------------
+// pre_nchunk > 0: `ws` already holds partial sums [B][pre_nchunk][groups][2] (written by the producing GEMM): skip the statistics pass
 int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
-                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s);
+                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int pre_nchunk = 0);
 int64_t groupnorm_ws_bytes(int B, int HW, int groups);
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
                      float eps, hipStream_t s);

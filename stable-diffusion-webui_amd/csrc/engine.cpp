@@ -51,6 +51,10 @@ struct Run {
     void tap(const std::string& name, const half_t* p, int B, int H, int W, int C) {
         if (!dry && e->trace) e->taps.push_back({name, p, B, H, W, C});
     }
+    // GroupNorm statistics handed from a producing GEMM's epilogue to the norm that reads its output (launch_gemm: stats_out)
+    const half_t* st_tensor = nullptr;
+    float* st_ws = nullptr;
+    int st_nchunk = 0;
 };
 
 #define TRY(x)                  \
@@ -346,6 +350,7 @@ struct ConvArgs {
     int batch = 1;
     long a_bs = 0, w_bs = 0, o_bs = 0, r_bs = 0;
     const int* gate = nullptr;
+    int stats_C = 0;              // > 0: the output feeds a GroupNorm(32) over stats_C channels: emit its partial sums from the epilogue
     bool no_split = false;        // never take a split-K workspace from the arena (callers outside a sized forward pass)
 };
 
@@ -356,6 +361,10 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
         const size_t wsb = gemm_splitk_ws_bytes(a.B * a.Ho * a.Wo, W.n_pad, W.taps * (a.c0 + a.c1), a.batch);
         if (wsb) splitk_ws = r.F(wsb / sizeof(float));
     }
+    // room for the GroupNorm partial sums of the output ([B][<= 64 chunks][32 groups][2]); allocated in the dry pass too
+    float* stats_ws = nullptr;
+    if (a.stats_C > 0 && W.n_pad == a.stats_C && a.stats_C % 32 == 0) stats_ws = r.F((size_t)a.B * 64 * 32 * 2);
+    r.st_tensor = nullptr; r.st_nchunk = 0;
     if (r.dry) return 0;
     GemmP p{};
     p.splitk_ws = splitk_ws;
@@ -374,7 +383,11 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.bias_scale = a.bias_scale;
     p.a_bs = a.a_bs; p.w_bs = a.w_bs; p.o_bs = a.o_bs; p.r_bs = a.r_bs;
     p.gate = a.gate;
-    return launch_gemm(p, a.batch, r.e->force_generic, r.e->use_glds, r.s);
+    int nchunk = 0;
+    if (stats_ws) { p.stats_out = stats_ws; p.stats_cpg = a.stats_C / 32; }
+    TRY(launch_gemm(p, a.batch, r.e->force_generic, r.e->use_glds, r.s, &nchunk));
+    if (nchunk > 0) { r.st_tensor = (const half_t*)a.out; r.st_ws = stats_ws; r.st_nchunk = nchunk; }
+    return 0;
 }
 
 // plain [rows, K] x W^T GEMM on token matrices
@@ -394,6 +407,8 @@ static int run_gn(Run& r, const NormW& n, const half_t* x0, const half_t* x1, in
     float* ws = r.F(groupnorm_ws_bytes(B, HW, 32) / sizeof(float));
     if (r.dry) return 0;
     SDMI_REQUIRE(n.c == c0 + c1, "GroupNorm channel mismatch");
+    if (x1 == nullptr && r.st_nchunk > 0 && r.st_tensor == x0)      // the producing GEMM already summed this tensor
+        return launch_groupnorm(x0, nullptr, c0, 0, n.g, n.b, out, B, HW, 32, eps, silu, r.st_ws, r.s, r.st_nchunk);
     return launch_groupnorm(x0, x1, c0, c1, n.g, n.b, out, B, HW, 32, eps, silu, ws, r.s);
 }
 static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t* out) {
@@ -417,6 +432,7 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
         c.a0 = t1; c.c0 = w.cin; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
         if (embs) { c.rowbias = embs + w.emb_off; c.ldrb = emb_ld; }
         c.out = h1; c.ldo = w.cout;
+        c.stats_C = w.cout;                                   // h1 is read by norm2 only
         TRY(run_conv(r, w.c1, c));
     }
     half_t* t2 = r.H(M * w.cout);
@@ -439,6 +455,7 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
         c.a0 = t2; c.c0 = w.cout; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
         c.resid = resid; c.ldr = w.cout; c.out = o; c.ldo = w.cout;
         c.alpha = ss; c.bias_scale = ss;
+        c.stats_C = ss == 1.f ? w.cout : 0;                   // the block output usually feeds the next GroupNorm (ignored if not)
         TRY(run_conv(r, w.c2, c));
     }
     *out = o;

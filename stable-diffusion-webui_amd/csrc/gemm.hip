@@ -64,8 +64,9 @@ __device__ __forceinline__ float gelu_erf(float g) {
 
 // Epilogue shared by the GEMM kernels.  Lane holds, for accumulator tile (i, j):
 //   m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive channels)
-template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z) {
+template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z,
+                                              char* smem = nullptr) {
     if constexpr (TR) {
         // transposed store (EP_TRANSPOSE): the MFMAs ran with swapped operand roles, so for tile (i, j) the lane holds
         //   n = n0 + wc*WTN + j*16 + (lane & 15),  m = m0 + wr*WTM + i*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive tokens)
@@ -104,6 +105,85 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
                 *reinterpret_cast<f4*>(slab + (long)m * p.N + n) = acc[i][j];
             }
+        }
+        return;
+    }
+    if constexpr (STATS && !GEGLU) {
+        // ---- GroupNorm-statistics variant (GemmP::stats_out; launch_gemm admits only fp16 row-major outputs with a column bias,
+        // an optional [B][N] row bias and an optional residual).  Column tile OUTER, row tile inner: the lane's column sums over
+        // its TM rows are then 8 live values (one column tile at a time) instead of 8 x TN next to the accumulators, and the
+        // residual pipeline is a 4-deep ring of 8-byte loads.  After each column tile: 16-lane shuffle tree over the rows of the
+        // wave (lanes sharing lane >> 4 own the same 4 channels), LDS [WR][BN] per wave row; at the end one thread per group adds
+        // its WR x cpg slots in a fixed order and writes (sum, sum of squares) for (image, row chunk, group).
+        // The sums are taken from the fp16-ROUNDED outputs: exactly what gn_stats would have read back.
+        float* cs = reinterpret_cast<float*>(smem);          // [WR_][BN_] sums, then [WR_][BN_] sums of squares
+        float* cq = cs + WR_ * BN_;
+        __syncthreads();                                     // every wave is done reading the operand tiles that lived here
+        const int mrow = m0 + wr * WTM + (lane & 15);
+        const int b = m0 / p.rows_per_batch;                 // (a tile lies inside one image: launch_gemm's admission rule)
+        constexpr int RD = TM < 4 ? TM : 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+            f4 bb = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                bb = *reinterpret_cast<const f4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bb[r] *= p.bias_scale;
+            }
+            if (p.rowbias) bb += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+            h4 ring[RD];
+            if (p.resid) {
+#pragma unroll
+                for (int i = 0; i < RD; ++i)
+                    ring[i] = *reinterpret_cast<const h4*>(p.resid + rbs + (long)min(mrow + i * 16, p.M - 1) * p.ldr + n);
+            }
+            f4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mrow + i * 16;
+                f4 v = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(v[r], p.alpha, bb[r]);
+                if (p.resid) {
+                    const h4 rr = ring[i % RD];
+                    if (i + RD < TM)
+                        ring[i % RD] = *reinterpret_cast<const h4*>(p.resid + rbs + (long)min(m + RD * 16, p.M - 1) * p.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                }
+                if (m < p.M) {
+                    h4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o[r] = (half_t)v[r];
+                        const float f = (float)o[r];
+                        sv[r] += f;
+                        qv[r] = fmaf(f, f, qv[r]);
+                    }
+                    *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sv[r] += __shfl_xor(sv[r], off); qv[r] += __shfl_xor(qv[r], off); }
+            if ((lane & 15) == 0) {
+                const int c = wc * WTN + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<f4*>(cs + wr * BN_ + c) = sv;
+                *reinterpret_cast<f4*>(cq + wr * BN_ + c) = qv;
+            }
+        }
+        __syncthreads();
+        const int tid = threadIdx.x, cpg = p.stats_cpg, ngl = BN_ / cpg;
+        if (tid < ngl) {
+            float a = 0.f, q = 0.f;
+            for (int w = 0; w < WR_; ++w)
+                for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[w * BN_ + c]; q += cq[w * BN_ + c]; }
+            const int chunk = (m0 - b * p.rows_per_batch) / (TM * 16 * WR_);
+            const int G = p.N / cpg, g = n0 / cpg + tid;
+            float* dst = p.stats_out + (((long)b * p.stats_nchunk + chunk) * G + g) * 2;
+            dst[0] = a; dst[1] = q;
         }
         return;
     }
@@ -228,7 +308,7 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
@@ -412,7 +492,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR>(p, acc, m0, n0, wr, wc, lane, z);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 template <int N>
@@ -452,7 +532,7 @@ __device__ __forceinline__ long long stamp() {           // s_memtime; callers s
     return t;
 }
 
-template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false>
+template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int BK = 64, WC = 4, ROWB = 128;
@@ -742,7 +822,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             for (int i = 0; i < 5; ++i) d[i] = tm[i];
         }
     }
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR>(p, acc, m0, n0, wr, wc, lane, z);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -877,11 +957,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -893,10 +973,10 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false>
+template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
-    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD>;
+    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -926,6 +1006,9 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
         if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true>(p, batch, s);
     }
     if (p.flags & EP_TRANSPOSE) return launch_pingpong2<BM, BN, false, true>(p, batch, s);
+    if (p.stats_nchunk > 0)
+        return (p.korder && p.taps == 9) ? launch_pingpong2<BM, BN, false, false, true, true>(p, batch, s)
+                                         : launch_pingpong2<BM, BN, false, false, false, true>(p, batch, s);
     if (p.korder && p.taps == 9) return launch_pingpong2<BM, BN, false, false, true>(p, batch, s);
     return launch_pingpong2<BM, BN, false>(p, batch, s);
 }
@@ -936,6 +1019,11 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true>(p, batch, s);
     }
     if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, true>(p, batch, s);
+    if constexpr (GLDS) {                                  // GroupNorm statistics epilogue (LDS-direct path only)
+        if (p.stats_nchunk > 0)
+            return (p.korder && p.taps == 9) ? launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, true, true>(p, batch, s)
+                                             : launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, false, true>(p, batch, s);
+    }
     if (p.korder && p.taps == 9) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, true>(p, batch, s);
     return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false>(p, batch, s);
 }
@@ -982,6 +1070,7 @@ int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e
 int g_shortk_max_k = [] { const char* e = getenv("SDMI_SHORTK_MAXK"); return e ? atoi(e) : 448; }();
 int g_geglu_gemm_cfg = [] { const char* e = getenv("SDMI_GEGLU_CFG"); return e ? atoi(e) : -1; }();
 int g_conv_korder = [] { const char* e = getenv("SDMI_CONV_KORDER"); return e ? atoi(e) : 1; }();
+int g_gn_fuse = [] { const char* e = getenv("SDMI_GN_FUSE"); return e ? atoi(e) : 1; }();
 int g_tile_order = [] { const char* e = getenv("SDMI_TILE_ORDER"); return e ? atoi(e) : -1; }();
 int g_vt_mode = [] { const char* e = getenv("SDMI_VT_MODE"); return e ? atoi(e) : 1; }();
 // 4 (default): ping-pong kernel for the 256-row tiles and the 128x320 tile (+5..22 % over the two-stage kernel per shape,
@@ -1104,8 +1193,10 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch) {
     return (size_t)8 * M * N * batch * sizeof(float);
 }
 
-int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s) {
+int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out) {
     GemmP p = p_in;
+    p.stats_nchunk = 0;
+    if (stats_nchunk_out) *stats_nchunk_out = 0;
     p.flags |= g_gemm_dbgflags;
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     if (p.bias_scale == 0.f) p.bias_scale = 1.f;
@@ -1164,10 +1255,19 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         p.tile_order = g_tile_order >= 0 ? g_tile_order : (m_first < 0.8 * n_first ? 1 : 0);
         if (tiles_n == 1 || tiles_m == 1) p.tile_order = 0;
     }
+    if (p.stats_out && g_gn_fuse && use_glds && split <= 1 && batch == 1 && !(p.flags & (EP_GEGLU | EP_TRANSPOSE | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW | EP_QUICK_GELU | EP_GELU)) && p.stats_cpg > 0) {
+        const int BMc = kCfgBM[cfg], BNc = kCfgBN[cfg];
+        // a tile must lie inside one image, a group inside one column tile; few enough chunks that gn_apply's prologue stays short
+        if (p.rows_per_batch % BMc == 0 && BNc % p.stats_cpg == 0 && p.N % p.stats_cpg == 0 && p.rows_per_batch / BMc <= 64 &&
+            p.M % p.rows_per_batch == 0) {
+            p.stats_nchunk = p.rows_per_batch / BMc;
+            if (stats_nchunk_out) *stats_nchunk_out = p.stats_nchunk;
+        }
+    }
     std::string pname;
     if (prof_enabled()) {
         pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
-                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
+                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 (batch > 1 ? " x" + std::to_string(batch) : "");
     }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);

@@ -169,17 +169,19 @@ static inline int gn_chunks(int B, int HW) {
 int64_t groupnorm_ws_bytes(int B, int HW, int groups) { return (int64_t)B * gn_chunks(B, HW) * groups * 2 * sizeof(float); }
 
 int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
-                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s) {
+                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int pre_nchunk) {
     const int C = c0 + c1;
     SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
-    const int nchunk = gn_chunks(B, HW);
+    const int nchunk = pre_nchunk > 0 ? pre_nchunk : gn_chunks(B, HW);
     const int rows = cdiv(HW, nchunk);
     char pname[64];
-    snprintf(pname, sizeof pname, "groupnorm_silu B%d HW%d C%d", B, HW, C);
-    ProfScope ps(pname, 0.0, 3.0 * B * (double)HW * C * 2.0, s);      // read twice + write once
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
-    SDMI_CHECK_HIP(hipGetLastError());
+    snprintf(pname, sizeof pname, pre_nchunk > 0 ? "groupnorm_silu_apply B%d HW%d C%d" : "groupnorm_silu B%d HW%d C%d", B, HW, C);
+    ProfScope ps(pname, 0.0, (pre_nchunk > 0 ? 2.0 : 3.0) * B * (double)HW * C * 2.0, s);      // read (twice) + write once
+    if (pre_nchunk <= 0) {
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
+        SDMI_CHECK_HIP(hipGetLastError());
+    }
     const long nvec = (long)HW * (C / 8);
     // >= 16 vectors per thread so the per-workgroup prologue (partials -> mean/rstd -> per-channel scale/shift in LDS) is
     // amortised, while keeping ~4 workgroups per CU in flight

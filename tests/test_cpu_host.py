@@ -608,7 +608,15 @@ def test_kernels_compile_without_scratch_or_spills():
             assert field("private_segment_fixed_size") == 0, f"{kname} uses scratch"
             # (SGPR spills go to VGPR lanes, not memory; tolerated only in the one-thread-per-output cross-check kernel, whose
             # kernel-argument struct alone crowds the scalar file)
-            assert field("vgpr_spill_count") == 0 and (field("sgpr_spill_count") == 0 or "generic" in kname), f"{kname} spills registers"
+            # ... and in the GroupNorm-statistics instantiations of the ping-pong GEMM (last template flag), where a handful of
+            # kernel-argument SGPRs are parked in VGPR lanes BEFORE the K loop and read back after it — checked below)
+            stats_pp = re.search(r"gemm_mfma_pingpong_kernelILi\d+ELi\d+E(Lb[01]E){4}Lb1EEEv", kname) is not None
+            assert field("vgpr_spill_count") == 0, f"{kname} spills registers"
+            assert field("sgpr_spill_count") == 0 or "generic" in kname or (stats_pp and field("sgpr_spill_count") <= 8), f"{kname} spills registers"
+            if stats_pp and field("sgpr_spill_count"):
+                body = re.search(r"^%s:[^\n]*\n(.*?)\.Lfunc_end" % re.escape(kname), text, re.S | re.M).group(1)
+                loop = body[body.index("s_setprio 1"):body.rindex("s_setprio 0")]
+                assert "v_readlane" not in loop and "v_writelane" not in loop, f"{kname}: SGPR spill traffic inside the K loop"
             assert field("vgpr_count") <= (256 if "pingpong" in kname else 512), kname     # 8-wave workgroups: 2 waves per SIMD
             if "gn_" in kname or "layernorm" in kname:
                 assert field("vgpr_count") <= 128, (kname, field("vgpr_count"))
@@ -622,9 +630,10 @@ def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):
     Cross-compile the kernel to gfx950 assembly and check the loop body."""
     import re
     text = _gfx950_assembly("gemm")
-    for bm, bn, waits, phases, kord in [(bm, bn, w, ph, k) for (bm, bn, w, ph) in ((256, 256, (8, 10), 4), (256, 320, (9, 11), 4), (128, 320, (7,), 2))
-                                        for k in (0, 1)]:       # k = 1: the channel-block-major instantiation the 3x3 convs run
-        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELi%dELb0ELb0ELb0ELb%dEEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn, kord), text, re.S | re.M)
+    for bm, bn, waits, phases, kord, st in [(bm, bn, w, ph, k, st) for (bm, bn, w, ph) in ((256, 256, (8, 10), 4), (256, 320, (9, 11), 4), (128, 320, (7,), 2))
+                                            for k in (0, 1) for st in (0, 1)]:  # k = 1: the channel-block-major instantiation the 3x3 convs run;
+                                                                                # st = 1: the GroupNorm-statistics epilogue variant
+        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELi%dELb0ELb0ELb0ELb%dELb%dEEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn, kord, st), text, re.S | re.M)
         assert m, f"ping-pong kernel <{bm},{bn}> not found in the assembly"
         body = m.group(1)
         first, last = body.index("s_setprio 1"), body.rindex("s_setprio 0")

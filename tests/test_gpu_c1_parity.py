@@ -160,6 +160,58 @@ def test_c1_unet_cfg_forward_16_rows_vs_oracle(dev, sd15):
     assert e_engine_4 < e_emu * 1.05
 
 
+def test_c1_groupnorm_statistics_fused_into_producing_gemm(dev, sd15):
+    """The GroupNorm partial sums taken in the producing conv's epilogue (GemmP::stats_out, kernels with the `_gn` profile suffix)
+    against the separate gn_stats pass (debug knob gn_fuse = 0) on the bench-shaped CFG forward: same statistics of the same
+    fp16-rounded tensor, only the summation order differs (fp32 reassociation in mean / variance).  One norm deep — the output of
+    the first ResBlock, whose second norm is the first to take fused sums — the two agree to 3e-4; at the UNet output every fp16
+    rounding downstream has been re-rolled by then, so the two runs are two independent draws of the engine's 1.5e-3 rounding
+    noise around the fp32 oracle (any launch-order knob moves the output by the same amount: profiles/r02_knob_sweep.md) and the
+    bound is that of two such draws.  A wrong group, chunk or count would show as >= 1e-1 at either point.  The fused path's
+    distance from the oracle itself is test_c1_unet_cfg_forward_16_rows_vs_oracle (the default configuration)."""
+    import ctypes
+    import json
+    lib = sub("_lib")
+    eng = sd15["model"].engine
+    B = 16
+    x, t, ctx = seeded((B, 4, 64, 64), 111).to(dev), torch.linspace(999.0, 1.0, B).to(dev), seeded((B, 77, 768), 112).to(dev)
+
+    def run(fuse):
+        lib.check(lib.lib.sdmi_debug_set(b"gn_fuse", fuse), "debug_set")
+        eng.unet_forward(x, t, ctx)
+        lib.check(lib.lib.sdmi_profile_begin(), "profile_begin")
+        out = eng.unet_forward(x, t, ctx).cpu()
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 21)
+        lib.check(lib.lib.sdmi_profile_end(buf, len(buf)), "profile_end")
+        eng.set_option("trace", 1)
+        try:
+            eng.unet_forward(x, t, ctx)
+            torch.cuda.synchronize()
+            first = eng.taps()["input_blocks.1.0"].float().cpu()
+        finally:
+            eng.set_option("trace", 0)
+        return out, json.loads(buf.value.decode())["kernels"], first
+    try:
+        plain, k0, first0 = run(0)
+        fused, k1, first1 = run(1)
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gn_fuse", 1), "debug_set")
+    n_gn = sum(k["launches"] for k in k1 if "_gn " in k["name"])
+    n_stats0 = sum(k["launches"] for k in k0 if k["name"].startswith("groupnorm_silu ") or k["name"].startswith("groupnorm "))
+    n_apply1 = sum(k["launches"] for k in k1 if "groupnorm_silu_apply" in k["name"] or "groupnorm_apply" in k["name"])
+    assert not any("_gn " in k["name"] for k in k0)
+    # (a producer whose tensor goes on to a concat or a downsample has its sums ignored)
+    assert n_apply1 >= 20 and n_gn >= n_apply1, (n_gn, n_apply1, n_stats0)
+    assert torch.isfinite(fused).all()
+    e, e1 = rel_l2(fused, plain), rel_l2(first1, first0)
+    report("groupnorm_stats_fusion", {"fused_producer_launches": n_gn, "norms_reading_fused_sums": n_apply1,
+                                      "fused_vs_separate_first_resblock_rel_l2": e1, "fused_vs_separate_unet_output_rel_l2": e})
+    print(f"[c1 gn fusion] {n_gn} producers carry the statistics, {n_apply1} norms read them; fused vs separate: first ResBlock {e1:.3e}, UNet output {e:.3e}")
+    assert e1 < 3e-4
+    assert e < 2.5e-3
+
+
 @pytest.mark.parametrize("d,heads,n,b", [(40, 8, 4096, 2), (80, 8, 1024, 2), (160, 8, 256, 2)])
 def test_c1_attention_shapes_vs_fp32(dev, d, heads, n, b):
     """Self-attention of the three SD1.5 levels at a 64x64 latent (the N = 4096, d = 40 launch is 13 % of the bench job), and
