@@ -33,8 +33,10 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 //   5  4 + lazy rescale: the O accumulators are multiplied by alpha only when some lane's running max moved (alpha == 1 otherwise,
 //      so the result is unchanged; after the first few KV tiles the max rarely moves) — 16 v_pk_mul_f32 less per tile
 //   6  lazy rescale with the production register budget
+//   7  5 with the PV MFMAs issued key-block-major (the O^T row blocks alternate, so consecutive MFMAs never share an accumulator;
+//      same summation order per accumulator => bit-identical to 5)
 template <int D, int KVT, int VAR = 0>
-__global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
+__global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
     constexpr bool LAZY_RESCALE = VAR >= 5;
     constexpr int DK = (D + 15) / 16 * 16;   // contraction length of S^T, padded to the MFMA K step
     constexpr int NDC = DK / 16;
@@ -237,14 +239,28 @@ __global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5) ? 4 : D <= 80 ? 2 : 1)
         }
 
         // ---- O^T += V^T P^T ---------------------------------------------------------------------------------
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) {
+        if constexpr (VAR == 7) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
-                    const h8 va = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[kb][sb], o[db], 0, 0, 0);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db) {
+                        const h8 va = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[kb][sb], o[db], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        const h8 va = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[kb][sb], o[db], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -379,6 +395,7 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
                     if (g_attn_occ == 4) return launch_attn_d<40, 64, 4>(p, s);
                     if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
                     if (g_attn_occ == 6) return launch_attn_d<40, 64, 6>(p, s);
+                    if (g_attn_occ == 7) return launch_attn_d<40, 64, 7>(p, s);
                 }
                 return (kvt128 && p.M > 64) ? launch_attn_d<40, 128>(p, s) : launch_attn_d<40, 64>(p, s);
             case 64: return (kvt128 && p.M > 64) ? launch_attn_d<64, 128>(p, s) : launch_attn_d<64, 64>(p, s);

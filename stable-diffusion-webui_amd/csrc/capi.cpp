@@ -489,6 +489,7 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "tile_order") g_tile_order = value;
     else if (n == "conv_korder") g_conv_korder = value;
     else if (n == "gn_fuse") g_gn_fuse = value;
+    else if (n == "ep_wide") g_ep_wide = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "attn_occ") g_attn_occ = value;
     else if (n == "gemm_split") g_force_gemm_split = value;

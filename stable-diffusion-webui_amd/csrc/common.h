@@ -99,11 +99,14 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
        EP_WRAP = 128,                                  // 3x3 taps wrap around the image instead of reading zero padding (p.tiling:
                                                        // Conv2d padding_mode = 'circular', modules/sd_hijack.py:311-318)
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
-       EP_DBG_NO_DSREAD = 0x1000 };    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
+       EP_DBG_NO_DSREAD = 0x1000,
+       EP_NARROW = 0x2000 };           // 8-byte epilogue accesses (set by launch_gemm when the 16-byte form's alignment rules fail, or
+                                       // by the "ep_wide" knob): gemm_epilogue's swap16 note    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
 
 // stats_nchunk_out (optional): the number of row chunks per image of the GroupNorm partial sums written to p.stats_out, or 0 when the
 // launch could not produce them (split-K, a tile spanning two images, a group straddling column tiles ...)
 int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out = nullptr);
+extern int g_ep_wide;               // 1 (default): 16-byte epilogue accesses where the alignment allows; 0: always 8-byte
 extern int g_gn_fuse;               // 1 (default): GroupNorm statistics from the producing GEMM's epilogue where possible; 0: always a stats pass
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)
 // worst-case fp32 workspace a split-K launch of this shape may use (bytes); 0 when split-K would never be chosen

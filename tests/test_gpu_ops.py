@@ -312,6 +312,43 @@ def test_pingpong_geglu_bit_identical(dev):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("cfg,pipe", [(-1, -1), (0, -1), (3, -1), (4, 3), (4, 0), (5, 3), (5, 0), (7, -1), (8, 4), (8, 0), (9, -1)])
+def test_wide_epilogue_is_bit_identical_to_the_8_byte_epilogue(dev, cfg, pipe):
+    """16-byte epilogue accesses (v_permlane16_swap_b32 pairs two row tiles; gemm.hip swap16) are pure data movement: bias + row
+    bias + residual, ragged M, GEGLU and the transposed store must give the same bits as the 8-byte form on every tile family;
+    a misaligned output (channel offset of 4) must fall back by itself."""
+    ops, lib = sub("ops"), sub("_lib")
+    B, H, W, cin, cout = 3, 15, 10, 128, 320                       # M = 450: ragged in every row-tile size
+    x, w = seeded((B, H, W, cin), 1), seeded((cout, cin, 3, 3), 2, scale=(cin * 9) ** -0.5)
+    b, rb, res = seeded((cout,), 3, 0.1), seeded((B, cout), 4), seeded((B, H, W, cout), 5)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    xl = seeded((2, 712, 1, 320), 6)                               # 1424 rows (712 per image: a multiple of 8 for the transposed form)
+    wl, bl = seeded((2560, 320), 7, scale=320 ** -0.5), seeded((2560,), 8, 0.1)
+    wg = ops.pack_conv_weight(wl.half().to(dev), geglu=True)
+    bg = ops.pack_bias(bl.to(dev), 2560, geglu=True)
+    wt = ops.pack_conv_weight(wl[:640].half().to(dev))
+    bt = ops.pack_bias(bl[:640].to(dev), wt.shape[0])
+    outs = {}
+    try:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", pipe))
+        for wide in (1, 0):
+            lib.check(lib.lib.sdmi_debug_set(b"ep_wide", wide))
+            o = [ops.conv_gemm(x.half().to(dev), wp, bias=b.to(dev), rowbias=rb.to(dev).contiguous(), resid=res.half().to(dev)),
+                 ops.conv_gemm(x.half().to(dev), wp, bias=b.to(dev)),
+                 ops.conv_gemm(xl.half().to(dev), wt, bias=bt, taps=1, transpose=True)]
+            if cfg in (-1, 4):
+                o.append(ops.conv_gemm(xl.half().to(dev), wg, bias=bg, taps=1, geglu=True))
+            outs[wide] = o
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1))
+        lib.check(lib.lib.sdmi_debug_set(b"ep_wide", 1))
+    torch.cuda.synchronize()
+    for a, c in zip(outs[1], outs[0]):
+        assert torch.equal(a, c), (cfg, pipe, tuple(a.shape))
+    ref = _conv_ref(h(x), h(w), b) + rb[:, None, None, :] + h(res)
+    assert rel_l2(outs[1][0].float().cpu(), ref) < 6e-4
+
+
 def test_mfma_glds_and_register_staging_agree_bitwise(dev):
     """Same LDS image, same MFMA order => identical bits; catches any mismatch in the LDS-direct load path."""
     ops = sub("ops")
@@ -510,7 +547,7 @@ def test_attention_experiment_variants_match_production_kernel(dev):
         q, k, v = seeded((2, n, heads * 40), 41).half().to(dev), seeded((2, m, heads * 40), 42).half().to(dev), seeded((2, m, heads * 40), 43).half().to(dev)
         lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 0))
         base = ops.attention(q, k, v, heads)
-        for variant in (4, 5, 6):       # 4: 128 VGPRs; 5: + lazy O rescale (skipped while alpha == 1); 6: lazy rescale alone
+        for variant in (4, 5, 6, 7):    # 4: 128 VGPRs; 5: + lazy O rescale (skipped while alpha == 1); 6: lazy rescale alone; 7: 5 with PV issued key-block-major
             try:
                 lib.check(lib.lib.sdmi_debug_set(b"attn_occ", variant))
                 got = ops.attention(q, k, v, heads)
