@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdmi.so")
+LIB_PATH = os.environ.get("SDMI_LIB") or os.path.join(_HERE, "lib", "libsdmi.so")      # SDMI_LIB: A/B of two builds (tools/gpu)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sdmi.h")
 
 F16, F32 = 0, 1

@@ -26,18 +26,30 @@ namespace sdmi {
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-// VAR = variants of the d = 40 level-0 self-attention, which is VALU / exp bound; selected with
-// SDMI_ATTN_OCC=<VAR> / sdmi_debug_set("attn_occ", VAR); 5 is the default for d = 40 (measured, see g_attn_occ):
-//   0  round-1 kernel: register budget for 2 workgroups per CU (D <= 80) or 1
-//   4  register budget for 4 workgroups per CU (128 VGPRs: a fourth wave per SIMD to hide the exp latency)
-//   5  4 + lazy rescale: the O accumulators are multiplied by alpha only when some lane's running max moved (alpha == 1 otherwise,
-//      so the result is unchanged; after the first few KV tiles the max rarely moves) — 16 v_pk_mul_f32 less per tile
-//   6  lazy rescale with the production register budget
-//   7  5 with the PV MFMAs issued key-block-major (the O^T row blocks alternate, so consecutive MFMAs never share an accumulator;
-//      same summation order per accumulator => bit-identical to 5)
+// VAR = forms of the d = 40 level-0 self-attention loop (profiles/r02_attention_experiments.md); selected
+// with SDMI_ATTN_OCC=<VAR> / sdmi_debug_set("attn_occ", VAR); 15 is the default for d = 40 (see g_attn_occ):
+//   0  round-1 kernel: register budget for 2 workgroups per CU (D <= 80) or 1; one ds_read -> wait -> MFMA chain per MFMA
+//   5  128 VGPRs (4 workgroups per CU) + lazy rescale: the O accumulators are multiplied by alpha only when some lane's running
+//      max moved (alpha == 1 otherwise: the result is unchanged; after the first few KV tiles the max rarely moves)
+//  15  lazy rescale + all MFMA operand fragments of a phase read from LDS up front (the 6 K fragments before the first S^T MFMA, the
+//      8 V^T fragments right after the last one, landing under the softmax): 14 exposed LDS latencies per KV tile become 2; the
+//      half-wave max exchange is one v_permlane32_swap instead of a ds_bpermute round trip; 160 VGPRs, 3 workgroups per CU.
+//      Same products in the same order per accumulator: bit-identical to 0 and 5 (tests/test_gpu_ops.py).
+//  10..14, 18  (-DSDMI_ATTN_PARTS builds only, tools/gpu/attn_parts.py) 5 with one component removed / 15 with section timers
 template <int D, int KVT, int VAR = 0>
-__global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
+__global__ __launch_bounds__(256, ((VAR == 15 || VAR == 18) ? 3 : (VAR == 5 || VAR >= 10) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
     constexpr bool LAZY_RESCALE = VAR >= 5;
+    constexpr bool PREF = VAR == 15 || VAR == 18;
+    constexpr bool TIMING = VAR == 18;       // s_memtime stamps around the sections of an iteration (AttnP::dbg)
+    long long tm[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&]() -> long long {
+        if constexpr (!TIMING) return 0;
+        const long long t = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return t;
+    };
+    // timing-only variants: results are wrong
+    constexpr bool NO_EXP = VAR == 10, NO_S = VAR == 11, NO_PV = VAR == 12, NO_MAX = VAR == 13, NO_STAGE = VAR == 14;
     constexpr int DK = (D + 15) / 16 * 16;   // contraction length of S^T, padded to the MFMA K step
     constexpr int NDC = DK / 16;
     constexpr int DV = (D + 31) / 32 * 32;   // rows of O^T, padded to the MFMA M
@@ -173,9 +185,10 @@ __global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <=
     const f2v sl2 = {p.scale_log2, p.scale_log2};
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        const bool more = t + 1 < ntiles;
+        const bool more = !NO_STAGE && t + 1 < ntiles;
+        const long long ta = stamp();
         if (more) load_tile(t + 1);
-        const char* tile = smem + cur * TILE_BYTES;
+        const char* tile = smem + (NO_STAGE ? 0 : cur) * TILE_BYTES;
 
         // ---- S^T for the NKB 32-key blocks of this tile --------------------------------------------------------
         f16v sc[NKB];
@@ -183,15 +196,39 @@ __global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <=
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+        h8 vaf[PREF ? NDB : 1][PREF ? NKB : 1][2];
+        if constexpr (PREF) {
+            h8 kaf[NDC][NKB];
+#pragma unroll
+            for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) kaf[dc][kb] = *reinterpret_cast<const h8*>(tile + ka_off + kb * 32 * KSTR + dc * 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kaf[dc][kb], qf[dc], sc[kb], 0, 0, 0);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+                        vaf[db][kb][sb] = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int dc = 0; dc < NDC; ++dc) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 const h8 ka = *reinterpret_cast<const h8*>(tile + ka_off + kb * 32 * KSTR + dc * 32);
-                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[dc], sc[kb], 0, 0, 0);
+                if constexpr (NO_S) { asm volatile("" : "+v"(sc[kb]) : "v"(ka), "v"(qf[dc])); }
+                else sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[dc], sc[kb], 0, 0, 0);
             }
         }
+        }
 
+        const long long tb = stamp();
         // ---- online softmax (per lane: one query row, KVT/2 of the tile's keys) -----------------------------------
         // register r of block kb <-> local key 32*kb + 16*(r>>3) + 8*half + (r&7)
         if (t >= nfull || p.causal) {
@@ -207,12 +244,25 @@ __global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <=
                     if (32 * kb + 16 * (r >> 3) + (r & 7) >= lim) sc[kb][r] = -INFINITY;
         }
         float mx = -INFINITY;
+        if constexpr (NO_MAX) { mx = sc[0][0] * p.scale_log2; }
+        else {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+        if constexpr (PREF) {
+            // the other half-wave's maximum without the LDS round trip of ds_bpermute: v_permlane32_swap_b32 on two copies leaves
+            // (lower-half value, upper-half value) of the same query in every lane
+            // (inline asm: with both operands the same value the builtin's two results were folded into one by the compiler)
+            float mlo = mx, mhi = mx;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mlo), "+v"(mhi));
+            mx = fmaxf(mlo, mhi) * p.scale_log2;
+        } else
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;      // scale > 0: max commutes with the scaling
+        }
         const float m_new = fmaxf(m_run, mx);
+        long long tc = 0;
+        if constexpr (TIMING) { asm volatile("" :: "v"(m_new)); tc = stamp(); }
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         const bool max_moved = !LAZY_RESCALE || __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;   // wave-uniform
         m_run = m_new;
@@ -225,7 +275,8 @@ __global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <=
             for (int r = 0; r < 16; r += 2) {
                 const f2v s2 = {sc[kb][r], sc[kb][r + 1]};
                 const f2v y = __builtin_elementwise_fma(s2, sl2, mneg);          // v_pk_fma_f32
-                const f2v e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+                f2v e;
+                if constexpr (NO_EXP) e = y; else e = f2v{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
                 if (!SUMROW) rs += e;                                            // v_pk_add_f32
                 pb[kb][r >> 3][r & 7] = (half_t)e.x;
                 pb[kb][r >> 3][(r & 7) + 1] = (half_t)e.y;
@@ -239,18 +290,14 @@ __global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <=
         }
 
         // ---- O^T += V^T P^T ---------------------------------------------------------------------------------
-        if constexpr (VAR == 7) {
+        if constexpr (PREF) {
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                    for (int db = 0; db < NDB; ++db) {
-                        const h8 va = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[kb][sb], o[db], 0, 0, 0);
-                    }
-                }
-            }
+                    for (int sb = 0; sb < 2; ++sb)
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vaf[db][kb][sb], pb[kb][sb], o[db], 0, 0, 0);
         } else {
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
@@ -259,14 +306,30 @@ __global__ __launch_bounds__(256, ((VAR == 4 || VAR == 5 || VAR == 7) ? 4 : D <=
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb) {
                         const h8 va = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
+                        if constexpr (NO_PV) { asm volatile("" : "+v"(o[db]) : "v"(va), "v"(pb[kb][sb])); }
+                        else
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pb[kb][sb], o[db], 0, 0, 0);
                     }
                 }
             }
         }
         // double-buffered LDS: the other buffer was last read in iteration t-1 (all waves passed its barrier)
+        long long td = 0, te = 0;
+        if constexpr (TIMING) { __builtin_amdgcn_sched_barrier(0); td = stamp(); }
         if (more) write_tile(cur ^ 1);
-        __syncthreads();
+        if constexpr (TIMING) { __builtin_amdgcn_sched_barrier(0); te = stamp(); }
+        if constexpr (!NO_STAGE) __syncthreads();
+        if constexpr (TIMING) {
+            const long long tf = stamp();
+            tm[0] += tb - ta; tm[1] += tc - tb; tm[2] += td - tc; tm[3] += te - td; tm[4] += tf - te; tm[5] += 1;
+        }
+    }
+    if constexpr (TIMING) {
+        if (p.dbg && lane == 0) {
+            long long* dst = p.dbg + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dst[i] = tm[i];
+        }
     }
 
     // ---- normalise and store: o[db][r] is O[q][db*32 + (r&3) + 8*(r>>2) + 4*half] ----------------------------
@@ -357,10 +420,12 @@ int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, 
     return 0;
 }
 
+unsigned long long g_attn_dbg = 0;
 int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e) : 0; }();
 
-// default 5 since round 2: same-box A/B on the C1 job (profiles/r02_knob_sweep.md) — self-attention 72.4 -> 69.5 ms per job
-int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 5; }();
+// default 15 since round 2: same-box A/Bs on the C1 job — 0 -> 5: self-attention 72.4 -> 69.5 ms per job (profiles/r02_knob_sweep.md);
+// 5 -> 15: 68.2 -> 66.6 and 70.0 -> 68.7 ms on two boxes (profiles/r02_attention_experiments.md)
+int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 15; }();
 
 template <int D, int KVT, int VAR = 0>
 static int launch_attn_d(const AttnP& p, hipStream_t s) {
@@ -392,10 +457,16 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
             // overhead is amortised over twice the MFMA work), 64 otherwise or when the key sequence is short
             case 40:
                 if (!(kvt128 && p.M > 64)) {
-                    if (g_attn_occ == 4) return launch_attn_d<40, 64, 4>(p, s);
                     if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
-                    if (g_attn_occ == 6) return launch_attn_d<40, 64, 6>(p, s);
-                    if (g_attn_occ == 7) return launch_attn_d<40, 64, 7>(p, s);
+                    if (g_attn_occ == 15) return launch_attn_d<40, 64, 15>(p, s);
+#ifdef SDMI_ATTN_PARTS
+                    if (g_attn_occ == 10) return launch_attn_d<40, 64, 10>(p, s);
+                    if (g_attn_occ == 11) return launch_attn_d<40, 64, 11>(p, s);
+                    if (g_attn_occ == 12) return launch_attn_d<40, 64, 12>(p, s);
+                    if (g_attn_occ == 13) return launch_attn_d<40, 64, 13>(p, s);
+                    if (g_attn_occ == 14) return launch_attn_d<40, 64, 14>(p, s);
+                    if (g_attn_occ == 18) { AttnP q = p; q.dbg = (long long*)g_attn_dbg; return launch_attn_d<40, 64, 18>(q, s); }
+#endif
                 }
                 return (kvt128 && p.M > 64) ? launch_attn_d<40, 128>(p, s) : launch_attn_d<40, 64>(p, s);
             case 64: return (kvt128 && p.M > 64) ? launch_attn_d<64, 128>(p, s) : launch_attn_d<64, 64>(p, s);

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" build
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -Wno-unused-result ${SDMI_EXTRA_FLAGS}"     # e.g. -DSDMI_ATTN_PARTS (tools/gpu/attn_parts.py)
 pids=()
 for f in gemm.hip attention.hip norm.hip elementwise.hip; do
   hipcc $FLAGS -c "$f" -o "build/${f%.hip}.o" & pids+=($!)

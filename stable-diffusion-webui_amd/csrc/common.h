@@ -99,9 +99,10 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
        EP_WRAP = 128,                                  // 3x3 taps wrap around the image instead of reading zero padding (p.tiling:
                                                        // Conv2d padding_mode = 'circular', modules/sd_hijack.py:311-318)
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
-       EP_DBG_NO_DSREAD = 0x1000,
-       EP_NARROW = 0x2000 };           // 8-byte epilogue accesses (set by launch_gemm when the 16-byte form's alignment rules fail, or
-                                       // by the "ep_wide" knob): gemm_epilogue's swap16 note    // tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
+       EP_DBG_NO_DSREAD = 0x1000,      // 0x100..0x1000: tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
+       EP_NARROW = 0x2000              // 8-byte epilogue accesses (set by launch_gemm when the 16-byte form's alignment rules fail, or
+                                       // by the "ep_wide" knob): gemm_epilogue's swap16 note
+     };
 
 // stats_nchunk_out (optional): the number of row chunks per image of the GroupNorm partial sums written to p.stats_out, or 0 when the
 // launch could not produce them (split-K, a tile spanning two images, a group straddling column tiles ...)
@@ -116,7 +117,7 @@ extern int g_force_gemm_cfg;
 extern int g_shortk_gemm_cfg;
 extern int g_shortk_max_k;          // the launches g_shortk_gemm_cfg applies to: taps == 1 and K <= this (default 448)
 extern int g_geglu_gemm_cfg;        // tile config forced on the GEGLU (ff.net.0.proj) launches, -1 = heuristic
-extern int g_conv_korder;           // 1 (default) channel-block-major, 0 tap-major
+extern int g_conv_korder;           // 0 (default) tap-major, 1 channel-block-major (less HBM traffic, ~2.5 % slower convs)
 extern int g_tile_order;            // -1 heuristic (default), 0 / 1 force
 extern int g_vt_mode;               // 1 (default): V^T through EP_TRANSPOSE on token-major tiles; 0: weights-as-rows GEMM (round 1)
 extern int g_gemm_pipe;             // 0 = two-stage kernels only, 3 = ping-pong 256-row tiles, 4 = also 128x320 (default)
@@ -124,6 +125,7 @@ extern int g_gemm_pipe_default;     // value restored by sdmi_debug_set("gemm_pi
 extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = force k slices where allowed
 extern int g_attn_kvt;
 extern int g_attn_occ;
+extern unsigned long long g_attn_dbg;   // device pointer (0 = off) for AttnP::dbg
 extern int g_gemm_dbgflags;
 extern unsigned long long g_gemm_dbg;   // device pointer (0 = off): 5 x int64 per wave of section cycle sums
 
@@ -137,6 +139,7 @@ struct AttnP {
     int ldq, ldk, vt_ld, ldo;
     float scale_log2;      // softmax scale * log2(e)
     int causal;            // 1: key j is visible to query i only if j <= i (CLIP text encoder; requires N == M)
+    long long* dbg;        // tuning only (SDMI_ATTN_PARTS builds, attn_occ = 18): per-wave section cycle sums, 8 x int64 per wave
 };
 int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 // v [B, M, ldv] (head h at h*D) -> vt [B, H*D, Mpad] (zero padded)

@@ -52,14 +52,17 @@ struct GRow {
 // the K = 320 feed-forward GEMMs.
 __device__ __forceinline__ float gelu_erf(float g) {
     const float x = fabsf(g) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    // v_rcp_f32 (1 ulp) — __frcp_rn expands to the ten-instruction IEEE division sequence, and the GEGLU epilogue is VALU-bound
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float erf_abs = 1.0f - poly * t * __expf(-x * x);
+    const float e = __builtin_amdgcn_exp2f(x * x * -1.4426950408889634f);     // exp(-x^2)
+    const float erf_abs = fmaf(-(poly * t), e, 1.0f);
     const float erf_v = copysignf(erf_abs, g);
-    return 0.5f * g * (1.0f + erf_v);
+    const float hg = 0.5f * g;
+    return fmaf(hg, erf_v, hg);
 }
 
 // 16-byte epilogue accesses out of the 8-byte accumulator layout (v_permlane16_swap_b32, gfx950).  The MFMA leaves a lane with
@@ -862,16 +865,75 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         cb1 = k0 - tap1 * p.cin;
     }
 
+    // KORD fast path (stride-1/2 3x3 convs without the fused upsample / circular padding: every UNet and VAE conv but the six
+    // upsampling ones).  With the channel-block-major K order EVERY K tile is a new tap, and the per-tile rebuild below (an LDS read,
+    // two quarter-rate integer multiplies and a 64-bit multiply-add per staged row) was the longest thing in the L(0) / L(3)
+    // sections (section timers, profiles/r02_gemm_sections.md).  A tap only shifts the source pixel by a block-uniform offset
+    // (dy * Wi + dx) * lda, so the row keeps ONE pointer for the whole K loop — the window-origin pixel of the current source, with
+    // the 9 tap-validity bits packed into address bits 48..56 — and a tile costs a bit test, a 64-bit add and a select per row.
+    // (launch_gemm keeps the tap-major order — and so the non-KORD instantiation — for the upsampling / wrapping convs.)
+    const int chunk8 = ((tid & 7) ^ (lane >> 3)) * 8;
+    // KORD: source addresses of A units [q0, q0+nq) of the K tile at (tap, cbase).  In the steady state the loop calls this from the
+    // M section BEFORE the L section that issues the loads (the MFMA stream has VALU issue slots to spare; the L sections are the
+    // long pole of a phase: every VALU instruction there showed up 1:1 in the K-tile time).
+    auto prep_a = [&](int q0, int nq, int tap, int cbase, bool force, const half_t* (&out)[PH / 2]) {
+        const bool first = cbase < p.c0;
+        const int seg0 = first ? 0 : p.c0;
+        const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+        const half_t* src = first ? a0 : a1;
+        const int lda = first ? p.lda0 : p.lda1;
+        if (force || (tap == 0 && cbase == seg0)) {       // block-uniform: first tile of a source (or of this K slice)
+            asm volatile("");                             // keep this a real (scalar) branch: if-converted, the rebuild would run on every tile
+#pragma unroll
+            for (int q = q0; q < q0 + nq; ++q) {
+                const int ri = rinfo[q * 512];
+                const int yb = (ri << 8) >> 20, xb = (ri << 20) >> 20;
+                unsigned colm = 0, mask = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) colm |= ((unsigned)(xb + d) < (unsigned)xlim ? 1u : 0u) << d;
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    if ((unsigned)(yb + d) < (unsigned)ylim) mask |= colm << (3 * d);      // rows past M: yb = -2048, no bit set
+                const long pix = (long)(ri >> 24) * img_pix + (long)yb * p.Wi + xb;          // may lie outside the image: only
+                const unsigned long long addr = (unsigned long long)(src + pix * lda + chunk8);   // dereferenced under its bit
+                rptr[q] = reinterpret_cast<const half_t*>((addr & 0xFFFFFFFFFFFFull) | ((unsigned long long)mask << 48));
+            }
+        }
+        const long toff = (long)(dy * p.Wi + dx) * lda + (cbase - seg0);      // uniform: tap shift + channel offset (elements)
+        // padding lanes read zeros from a line of the 32 KB zero page that moves with the tile: one fixed line would be
+        // a hot spot of a single L2 channel for every border row of every workgroup
+        const half_t* zp = p.zero + (((cbase - seg0) + tap * 64) & 0x3FC0) + chunk8;
+#pragma unroll
+        for (int q = q0; q < q0 + nq; ++q) {
+            const unsigned long long raw = reinterpret_cast<unsigned long long>(rptr[q]);
+            const bool ok = ((unsigned)(raw >> 48) >> tap) & 1u;
+            out[q - q0] = ok ? reinterpret_cast<const half_t*>(raw & 0xFFFFFFFFFFFFull) + toff : zp;
+        }
+    };
+    auto issue_a_at = [&](int q0, int nq, int sb, const half_t* (&np)[PH / 2]) {
+        char* base = smem + sb * STAGE + a_lds;
+#pragma unroll
+        for (int q = q0; q < q0 + nq; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)np[q - q0], (lptr_t)(base + q * RP * ROWB), 16, 0, 0);
+    };
     // A units [q0, q0+nq) of the K tile at (tap, cbase) into LDS buffer sb
     auto issue_a = [&](int q0, int nq, int tap, int cbase, int sb, bool force) {
         char* base = smem + sb * STAGE + a_lds;
         const bool first = cbase < p.c0;
         const int seg0 = first ? 0 : p.c0;
-        if (force || KORD || cbase == seg0) {    // block-uniform: the tile opens a new (tap, source) segment
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = (tap * 11) >> 5; dx = tap - dy * 3; }
+        if constexpr (KORD) {
+            const half_t* np[PH / 2];
+            prep_a(q0, nq, tap, cbase, force, np);
+#pragma unroll
+            for (int q = q0; q < q0 + nq; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)np[q - q0], (lptr_t)(base + q * RP * ROWB), 16, 0, 0);
+            return;
+        }
+        if (force || cbase == seg0) {            // block-uniform: the tile opens a new (tap, source) segment
             const half_t* src = first ? a0 : a1;
             const int lda = first ? p.lda0 : p.lda1;
-            int dy = 0, dx = 0;
-            if (p.taps == 9) { dy = (tap * 11) >> 5; dx = tap - dy * 3; }
 #pragma unroll
             for (int q = q0; q < q0 + nq; ++q) {
                 bool ok;
@@ -889,7 +951,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                     ok = (unsigned)yr < (unsigned)ylim && (unsigned)xr < (unsigned)xlim;
                     pix = (ri >> 24) * img_pix + (yr >> p.up) * p.Wi + (xr >> p.up);
                 }
-                rptr[q] = (ok ? src + (long)pix * lda : p.zero) + ((tid & 7) ^ (lane >> 3)) * 8;
+                rptr[q] = (ok ? src + (long)pix * lda : p.zero) + chunk8;
             }
         }
         const int coff = cbase - seg0;                   // uniform channel offset inside the segment
@@ -940,6 +1002,12 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     } else {
         wait_vmcnt<0>();
     }
+    const half_t* anext[PH / 2];
+#pragma unroll
+    for (int q = 0; q < PH / 2; ++q) anext[q] = p.zero;
+    if constexpr (KORD && !TIMING) {
+        if (nk > 1) prep_a(PH / 2, PH / 2, tap1, cb1, true, anext);      // what the first L(0) issues: the second half of tile 1
+    }
     advance(tap2, cb2);                                  // (tap2, cb2) = tile 2
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -947,7 +1015,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    long long tm[5] = {0, 0, 0, 0, 0};                   // TIMING: cycles in L work, barrier a, M issue, barrier b; phases
+    long long tm[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // TIMING: per phase index: cycles in L work, barrier a, M issue, barrier b; [16] K tiles
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         const char* sbuf = smem + cur * STAGE;
@@ -965,20 +1033,20 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             if (!(TIMING && (p.flags & EP_DBG_NO_GLDS))) {
                 if (PH == 4) {
                     if (ph == 0) {
-                        if (t + 1 < nk) issue_a(2, 2, tap1, cb1, cur ^ 1, false);
+                        if (t + 1 < nk) { if constexpr (KORD && !TIMING) issue_a_at(2, 2, cur ^ 1, anext); else issue_a(2, 2, tap1, cb1, cur ^ 1, false); }
                     } else if (ph == 1) {
                         if (t + 2 < nk) issue_b(0, NB0, tap2, cb2, cur);
                     } else if (ph == 2) {
                         if (t + 2 < nk) issue_b(NB0, NB1, tap2, cb2, cur);
                     } else {
-                        if (t + 2 < nk) issue_a(0, 2, tap2, cb2, cur, false);
+                        if (t + 2 < nk) { if constexpr (KORD && !TIMING) issue_a_at(0, 2, cur, anext); else issue_a(0, 2, tap2, cb2, cur, false); }
                     }
                 } else {
                     if (ph == 0) {
-                        if (t + 1 < nk) issue_a(1, 1, tap1, cb1, cur ^ 1, false);
+                        if (t + 1 < nk) { if constexpr (KORD && !TIMING) issue_a_at(1, 1, cur ^ 1, anext); else issue_a(1, 1, tap1, cb1, cur ^ 1, false); }
                     } else if (t + 2 < nk) {
                         issue_b(0, BU, tap2, cb2, cur);
-                        issue_a(0, 1, tap2, cb2, cur, false);
+                        if constexpr (KORD && !TIMING) issue_a_at(0, 1, cur, anext); else issue_a(0, 1, tap2, cb2, cur, false);
                     }
                 }
             }
@@ -998,6 +1066,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this phase's fragments are in registers
+            // (the 8-phase template's order — barrier first, LDS wait behind it — was measured: C1 job -0.35 %, conv class -1.2 %;
+            // it is only provably WAR-safe with the weight refills one phase later: profiles/r02_attention_experiments.md section 5)
             if (TIMING) t1 = stamp();
             if (!(TIMING && (p.flags & EP_DBG_NO_BAR_A))) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1005,6 +1075,16 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             if (TIMING) t2 = stamp();
             // ================= M section: MFMAs only =================
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (KORD && !TIMING) {
+                // addresses of the A loads the NEXT L section issues (both belong to tile t+2 = (tap2, cb2))
+                if (PH == 4) {
+                    if (ph == 2) { if (t + 2 < nk) prep_a(0, 2, tap2, cb2, false, anext); }
+                    else if (ph == 3) { if (t + 2 < nk) prep_a(2, 2, tap2, cb2, false, anext); }
+                } else {
+                    if (ph == 0) { if (t + 2 < nk) prep_a(0, 1, tap2, cb2, false, anext); }
+                    else { if (t + 2 < nk) prep_a(1, 1, tap2, cb2, false, anext); }
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1023,7 +1103,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             __builtin_amdgcn_sched_barrier(0);
             if (TIMING) {
                 const long long t4 = stamp();
-                tm[0] += t1 - t0; tm[1] += t2 - t1; tm[2] += t3 - t2; tm[3] += t4 - t3; tm[4] += 1;
+                tm[ph * 4 + 0] += t1 - t0; tm[ph * 4 + 1] += t2 - t1; tm[ph * 4 + 2] += t3 - t2; tm[ph * 4 + 3] += t4 - t3;
+                if (ph == 0) tm[16] += 1;
             }
         }
         tap1 = tap2; cb1 = cb2;
@@ -1031,8 +1112,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     }
     if (TIMING) {
         if (lane == 0 && p.dbg) {
-            long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 5;
-            for (int i = 0; i < 5; ++i) d[i] = tm[i];
+            long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 17;
+            for (int i = 0; i < 17; ++i) d[i] = tm[i];
         }
     }
     gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
@@ -1209,7 +1290,8 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
         GemmP q = p;
         q.dbg = (long long*)g_gemm_dbg;
         constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;
-        auto kern = gemm_mfma_pingpong_kernel<BM, BN, false, true>;
+        auto kern = (p.korder && p.taps == 9) ? gemm_mfma_pingpong_kernel<BM, BN, false, true, false, true>      // production K order of the 3x3 convs
+                                              : gemm_mfma_pingpong_kernel<BM, BN, false, true>;
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         hipLaunchKernelGGL(kern, dim3(cdiv(q.M, BM) * (q.N / BN), q.splitk > 1 ? q.splitk : 1, batch), dim3(512), SMEM, s, q);
         SDMI_CHECK_HIP(hipGetLastError());
@@ -1282,7 +1364,11 @@ int g_force_gemm_split = 0;
 int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e ? atoi(e) : -1; }();
 int g_shortk_max_k = [] { const char* e = getenv("SDMI_SHORTK_MAXK"); return e ? atoi(e) : 448; }();
 int g_geglu_gemm_cfg = [] { const char* e = getenv("SDMI_GEGLU_CFG"); return e ? atoi(e) : -1; }();
-int g_conv_korder = [] { const char* e = getenv("SDMI_CONV_KORDER"); return e ? atoi(e) : 1; }();
+// 0 (default): tap-major K walk; 1: channel-block-major (-31 % HBM traffic on the 3x3 convs, PMC profiles/r02_pmc_traffic.md).  Same-box,
+// two-build A/B on the C1 job (profiles/r02_conv_korder.md): tap-major 161.4 ms of 3x3 convs per job, channel-block-major 165.5 ms with
+// the per-source pointer + tap-mask addressing, 188.3 ms with the per-tile address rebuild it shipped with first — the traffic it saves
+// is L2-hit traffic that was not the bound, and its one cold tile per channel block stalls the 1.5-tile prefetch window.
+int g_conv_korder = [] { const char* e = getenv("SDMI_CONV_KORDER"); return e ? atoi(e) : 0; }();
 int g_ep_wide = [] { const char* e = getenv("SDMI_EP_WIDE"); return e ? atoi(e) : 1; }();
 int g_gn_fuse = [] { const char* e = getenv("SDMI_GN_FUSE"); return e ? atoi(e) : 1; }();
 int g_tile_order = [] { const char* e = getenv("SDMI_TILE_ORDER"); return e ? atoi(e) : -1; }();
@@ -1414,7 +1500,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     p.flags |= g_gemm_dbgflags;
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     if (p.bias_scale == 0.f) p.bias_scale = 1.f;
-    p.korder = (p.taps == 9 && g_conv_korder) ? 1 : 0;
+    p.korder = (p.taps == 9 && g_conv_korder && !p.up && !(p.flags & EP_WRAP)) ? 1 : 0;     // (the ping-pong kernel's KORD form has no upsample / wrap addressing)
     p.zero = zero_page();
     SDMI_REQUIRE(p.zero != nullptr, "zero page allocation failed");
     SDMI_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");

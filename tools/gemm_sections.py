@@ -17,7 +17,7 @@ def run(name, B, H, W, cin, cout, taps, cfg, bm=256):
     wp = ops.pack_conv_weight(w)
     bn = {4: 256, 5: 320}[cfg]
     nblk = (B * H * W + bm - 1) // bm * (cout // bn)
-    dbg = torch.zeros(nblk * 8 * 5, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(nblk * 8 * 17, dtype=torch.int64, device=dev)
     lib.check(L.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(L.sdmi_debug_set(b"gemm_pipe", 3))
     for _ in range(3):
         ops.conv_gemm(x, wp, taps=taps)
@@ -29,17 +29,23 @@ def run(name, B, H, W, cin, cout, taps, cfg, bm=256):
     torch.cuda.synchronize()
     lib.check(L.sdmi_debug_set(b"gemm_dbg_lo", 0)); lib.check(L.sdmi_debug_set(b"gemm_dbg_hi", 0))
     lib.check(L.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(L.sdmi_debug_set(b"gemm_pipe", -1))
-    d = dbg.cpu().view(nblk, 8, 5).double()
-    print(f"{name}: {nblk} blocks; cycles per phase (mean over blocks), MFMA floor per wave-phase = {2 * 2 * (bn // 64) * 16}")
+    d = dbg.cpu().view(nblk, 8, 17).double()
+    print(f"{name}: {nblk} blocks; cycles per phase (mean over blocks and K tiles), MFMA floor per wave-phase = {2 * 2 * (bn // 64) * 16}")
     for g in (0, 1):
         v = d[:, 4 * g:4 * g + 4, :]
-        n = v[..., 4].mean()
-        m = v[..., :4].sum(dim=(0, 1)) / v[..., 4].sum()
-        print(f"  group {g}: phases={n:.0f}  L={m[0]:7.1f}  barrier_a={m[1]:7.1f}  M={m[2]:7.1f}  barrier_b={m[3]:7.1f}  total={m.sum():7.1f}")
+        nt = v[..., 16].sum()
+        tot = 0.0
+        for ph in range(4):
+            m = v[..., ph * 4:ph * 4 + 4].sum(dim=(0, 1)) / nt
+            tot += float(m.sum())
+            print(f"  group {g} phase {ph}: L={m[0]:7.1f}  barrier_a={m[1]:7.1f}  M={m[2]:7.1f}  barrier_b={m[3]:7.1f}  sum={m.sum():7.1f}")
+        print(f"  group {g}: K tile = {tot:7.1f} cycles (MFMA floor {4 * 2 * 2 * 2 * (bn // 64) * 16})")
 
 
 if __name__ == "__main__":
     lib.require_device()
-    run("vae conv3x3 512->512 @128^2 B2", 2, 128, 128, 512, 512, 9, 4)
-    run("gemm 8192^3", 1, 8192, 1, 8192, 8192, 1, 4)
-    run("linear 512->512 tok65536 (K=512)", 16, 64, 64, 512, 512, 1, 4)
+    run("unet conv3x3 320->320 @64^2 B16 (256x320)", 16, 64, 64, 320, 320, 9, 5)
+    run("unet conv3x3 640->640 @32^2 B16 (256x320)", 16, 32, 32, 640, 640, 9, 5)
+    run("unet conv3x3 1280->1280 @16^2 B16 (256x320)", 16, 16, 16, 1280, 1280, 9, 5)
+    run("unet 1x1 320->320 @64^2 B16 (256x320, K = 320)", 16, 64, 64, 320, 320, 1, 5)
+    run("vae conv3x3 512->512 @128^2 B2 (256x256)", 2, 128, 128, 512, 512, 9, 4)
