@@ -231,6 +231,37 @@ def test_pingpong_gemm_is_bit_identical_to_two_stage_kernel(dev, case):
         assert torch.equal(o, outs[0][0]), case
 
 
+@pytest.mark.parametrize("case", [c for c in PHASE_CASES if c[7] == 9 and not c[9]])
+def test_channel_block_major_k_order_pingpong_equals_two_stage(dev, case):
+    """conv_korder = 1 (channel blocks outer, the 9 taps inner: 31 % less HBM traffic, selectable — tap-major is the default again,
+    profiles/r02_conv_korder.md): the ping-pong kernel addresses a tap as ONE per-row pointer + a block-uniform tap offset under a
+    9-bit validity mask carried in address bits 48..56 (computed in the M section); the two-stage kernel rebuilds the address per
+    tile.  Same K-tile order => same bits, on padding / stride 2 / two sources / split-K; and equal to torch within the usual bound."""
+    ops, lib = sub("ops"), sub("_lib")
+    cfg, B, H, W, c0, c1, cout, taps, stride, up, split = case
+    x0 = seeded((B, H, W, c0), 1)
+    x1 = seeded((B, H, W, c1), 2) if c1 else None
+    w = seeded((cout, c0 + c1, 3, 3), 3, scale=((c0 + c1) * 9) ** -0.5)
+    b = seeded((cout,), 4, 0.1)
+    xin = torch.cat([x0, x1], dim=3) if c1 else x0
+    ref = _conv_ref(h(xin), h(w), b, stride=stride)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    args = dict(a1=None if x1 is None else x1.half().to(dev), bias=ops.pack_bias(b.to(dev), wp.shape[0]), taps=9, stride=stride)
+    outs = []
+    try:
+        lib.check(lib.lib.sdmi_debug_set(b"conv_korder", 1))
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
+        for pipe in (0, 4 if cfg == 8 else 3):
+            lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", pipe))
+            outs.append(ops.conv_gemm(x0.half().to(dev), wp, **args))
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1)); lib.check(lib.lib.sdmi_debug_set(b"conv_korder", 0))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), case
+    assert rel_l2(outs[1].float().cpu(), ref) < 6e-4, case
+
+
 @pytest.mark.parametrize("rows,cin,cout,cfg", [(4096, 320, 320, -1), (1024, 640, 640, -1), (256, 1280, 1280, -1), (1024, 320, 320, 9),
                                                (512, 64, 128, 0), (4096, 320, 320, 5)])
 def test_transposed_output_gemm_is_the_same_bits_transposed(dev, rows, cin, cout, cfg):

@@ -18,7 +18,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $REPO/gpurun_out/prof_p
 echo "pmc write rc=$?" >> $REPO/gpurun_out/prof_pmc_write.log
 timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $REPO/gpurun_out/prof_pmc_mfma -o pmc -- python $REPO/bench.py --steps 1 --warmup 0 --sampler-steps 2 --no-cpu-baseline --no-roofline > $REPO/gpurun_out/prof_pmc_mfma.log 2>&1
 echo "pmc mfma rc=$?" >> $REPO/gpurun_out/prof_pmc_mfma.log
-# (3) K-order A/B of the conv traffic on a 2-step job: tap-major (round 1) vs channel-block-major (round 2 default)
+# (3) K-order A/B of the conv traffic on a 2-step job: tap-major (default) vs channel-block-major (SDMI_CONV_KORDER=1)
 for k in 0 1; do
   SDMI_CONV_KORDER=$k timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $REPO/gpurun_out/prof_pmc_fetch_k$k -o pmc -- python $REPO/bench.py --steps 1 --warmup 0 --sampler-steps 2 --no-cpu-baseline --no-roofline > $REPO/gpurun_out/prof_pmc_fetch_k$k.log 2>&1
   SDMI_CONV_KORDER=$k timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $REPO/gpurun_out/prof_pmc_write_k$k -o pmc -- python $REPO/bench.py --steps 1 --warmup 0 --sampler-steps 2 --no-cpu-baseline --no-roofline > $REPO/gpurun_out/prof_pmc_write_k$k.log 2>&1

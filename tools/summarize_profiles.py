@@ -75,27 +75,35 @@ def main():
             if "gemm_mfma" in n:
                 fam["calls"] += c; fam["fetch_kb"] += 2 * fv; fam["write_kb"] += wv[1] * c / max(wv[0], 1)
     per_launch = (fam["fetch_kb"] + fam["write_kb"]) * 1024 / max(fam["calls"], 1)
-    # 3x3 convolutions: the channel-block-major ping-pong instantiations (last template flag true) run nothing else
+    # the ping-pong instantiations (3x3 convs and the large 1x1 / linear layers share them under the tap-major K order): measured
+    # bytes per launch against the algorithmic bytes of the same launches (HIP-event names carry "pp")
     conv = {"calls": 0, "fetch_kb": 0.0, "write_kb": 0.0}
     for n in fe:
-        if "pingpong" in n and ("true>" in n.replace(" ", "") or n.rstrip().endswith("Lb1EEEvNS_5GemmPE")):
+        if "pingpong" in n:
             c, fv, _ = fe[n]
             wv = wr.get(n, [1, 0.0, 0.0])
             conv["calls"] += c; conv["fetch_kb"] += 2 * fv; conv["write_kb"] += wv[1] * c / max(wv[0], 1)
-    alg = None
+    alg = alg_all = None
     bk = os.path.join(G, "bench_kernels_c1.json")
     if os.path.exists(bk):
-        ks = [k for k in json.load(open(bk)) if k["name"].startswith("gemm_mfma") and "pp" in k["name"].split(" ")[0] and "conv3x3" in k["name"]]
+        allk = [k for k in json.load(open(bk)) if k["name"].startswith("gemm_mfma")]
+        ks = [k for k in allk if "pp" in k["name"].split(" ")[0]]
         if ks:
             alg = sum(k["bytes"] for k in ks) / max(sum(k["launches"] for k in ks), 1)
+        if allk:
+            alg_all = sum(k["bytes"] for k in allk) / max(sum(k["launches"] for k in allk), 1)
     out = {"round": rnd, "workload": os.environ.get("SDMI_PMC_WORKLOAD", "c1:20"),
            "gemm_mfma_bytes_per_launch": round(per_launch), "gemm_mfma_launches": fam["calls"],
-           "conv3x3_pingpong_bytes_per_launch": round((conv["fetch_kb"] + conv["write_kb"]) * 1024 / max(conv["calls"], 1)) if conv["calls"] else None,
-           "conv3x3_pingpong_launches": conv["calls"], "conv3x3_pingpong_algorithmic_bytes_per_launch": round(alg) if alg else None,
-           "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged per launch over the PMC passes of the named workload"}
-    if out["conv3x3_pingpong_bytes_per_launch"] and alg:
-        out["conv3x3_traffic_over_algorithmic"] = round(out["conv3x3_pingpong_bytes_per_launch"] / alg, 3)
-    # optional A/B passes with the round-1 tap-major K order (SDMI_CONV_KORDER=0): the same convs run the KORD = false instantiation
+           "gemm_mfma_algorithmic_bytes_per_launch": round(alg_all) if alg_all else None,
+           "pingpong_bytes_per_launch": round((conv["fetch_kb"] + conv["write_kb"]) * 1024 / max(conv["calls"], 1)) if conv["calls"] else None,
+           "pingpong_launches": conv["calls"], "pingpong_algorithmic_bytes_per_launch": round(alg) if alg else None,
+           "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged per launch over the PMC passes of the named workload; algorithmic = "
+                   "activations read once + weights + output written once per launch (launch_gemm's ProfScope bytes)"}
+    if out["pingpong_bytes_per_launch"] and alg:
+        out["pingpong_traffic_over_algorithmic"] = round(out["pingpong_bytes_per_launch"] / alg, 3)
+    if alg_all:
+        out["gemm_mfma_traffic_over_algorithmic"] = round(per_launch / alg_all, 3)
+    # optional A/B passes of the two K orders of the 3x3 convs (SDMI_CONV_KORDER=0 tap-major, the default; 1 channel-block-major)
     k0f, k0w = os.path.join(G, "prof_pmc_fetch_k0"), os.path.join(G, "prof_pmc_write_k0")
     if os.path.isdir(k0f) and os.path.isdir(k0w):
         f0, w0 = agg(first_db(k0f), "FETCH_SIZE"), agg(first_db(k0w), "WRITE_SIZE")
