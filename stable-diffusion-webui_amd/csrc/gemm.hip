@@ -868,7 +868,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     // KORD fast path (stride-1/2 3x3 convs without the fused upsample / circular padding: every UNet and VAE conv but the six
     // upsampling ones).  With the channel-block-major K order EVERY K tile is a new tap, and the per-tile rebuild below (an LDS read,
     // two quarter-rate integer multiplies and a 64-bit multiply-add per staged row) was the longest thing in the L(0) / L(3)
-    // sections (section timers, profiles/r02_gemm_sections.md).  A tap only shifts the source pixel by a block-uniform offset
+    // sections (section timers, profiles/r02_gemm_sections_korder_timing.txt; A/B in profiles/r02_conv_korder.md).  A tap only shifts the source pixel by a block-uniform offset
     // (dy * Wi + dx) * lda, so the row keeps ONE pointer for the whole K loop — the window-origin pixel of the current source, with
     // the 9 tap-validity bits packed into address bits 48..56 — and a tile costs a bit test, a 64-bit add and a select per row.
     // (launch_gemm keeps the tap-major order — and so the non-KORD instantiation — for the upsampling / wrapping convs.)

@@ -25,3 +25,14 @@ def rel_l2(a, b):
     a = torch.as_tensor(a).double().flatten()
     b = torch.as_tensor(b).double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def usable_cpus(cap=32):
+    """Hardware threads this process may use (affinity mask; os.cpu_count() reports the host's even on a restricted box, and
+    oversubscribing the oracle's fp32 GEMMs is pathological), capped where they stop scaling."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(cap, n))

@@ -29,7 +29,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_l2, seeded, seeded_module_weights
+from helpers import rel_l2, seeded, seeded_module_weights, usable_cpus
 
 pytestmark = pytest.mark.gpu
 FULL = os.environ.get("SDMI_PARITY_FULL") == "1"
@@ -62,7 +62,7 @@ def dev():
 
 @pytest.fixture(scope="module")
 def sd15(dev):
-    torch.set_num_threads(min(32, os.cpu_count() or 1))      # the oracle's fp32 GEMMs stop scaling (and oversubscribe) beyond ~32 threads
+    torch.set_num_threads(usable_cpus(32))      # the oracle's fp32 GEMMs stop scaling (and oversubscribe) beyond ~32 threads
     schema = sub("schema")
     from oracle import unet as ou, vae as ov
     ucfg, vcfg = schema.sd15_unet(), schema.sd15_vae()
@@ -353,7 +353,7 @@ def test_c3_sdxl_base_full_size_unet_forward_vs_oracle(dev):
     from fp16_emu import fp16_storage
     from oracle import unet as ou
     schema = sub("schema")
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(usable_cpus(32))
     cfg = schema.sdxl_unet()
     sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
     assert sum(v.numel() for k, v in sd.items() if k.startswith(schema.UNET_PREFIX)) == 2_567_463_684
