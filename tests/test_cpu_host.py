@@ -568,6 +568,30 @@ def test_bench_refuses_to_claim_gpus_it_does_not_have():
         assert r.returncode == 2 and b"refusing" in r.stderr and b"n_gpus" not in r.stdout
 
 
+def test_bench_cpu_baseline_is_bounded_and_isolated(monkeypatch):
+    """bench.py's CPU baseline runs in a child process under a wall limit, with as many threads as the process may really use: a host
+    that reports 256 hardware threads but grants 16 (a GPU box of round 2) hung the all-host-threads version for the whole bench
+    timeout.  (a) the thread count honours the affinity mask; (b) the child produces the baseline object (tiny model); (c) a child that
+    exceeds the wall limit costs that limit and yields a null value instead of losing the bench line."""
+    import json
+    import time
+    monkeypatch.syspath_prepend(ROOT)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--model", "tiny", "--size", "128", "--sampler-steps", "3", "--cpu-baseline-budget", "20"])
+    bench = importlib.import_module("bench")
+    assert 1 <= bench.usable_cpus() <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert bench.usable_cpus() <= len(os.sched_getaffinity(0))
+    args = bench.parse()
+    out = bench.cpu_baseline_isolated(args)
+    assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] and out["value"] > 0, out
+    assert out["cores"] == bench.usable_cpus() and "usable" in out["sample"]
+    json.dumps(out)
+    args.cpu_baseline_timeout = 0.05
+    t0 = time.time()
+    late = bench.cpu_baseline_isolated(args)
+    assert late["value"] is None and "wall limit" in late["sample"] and time.time() - t0 < 30
+
+
 _ASM_CACHE = {}
 
 
