@@ -170,17 +170,20 @@ def make_job(args, model, rank, world, local_only=False):
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch of the gemm_mfma family from the rocprofv3 PMC passes of this same workload
-    (tools/gpu/profile.sh -> tools/pmc_summary.py -> profiles/r02_pmc_traffic.json); null when absent or another workload."""
-    for path in (os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")):
+    """HBM bytes per launch of the gemm_mfma family from rocprofv3 PMC passes of this same workload (tools/gpu/profile.sh ->
+    tools/summarize_profiles.py) and where they were taken: on this box in this session (gpurun_out/pmc_traffic.json) or the committed
+    passes of an earlier box (profiles/r02_pmc_traffic.json: same code path and workload, another GPU).  (None, None) when absent."""
+    for path, src in ((os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "PMC passes of this workload on this box (gpurun_out/pmc_traffic.json)"),
+                      (os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"),
+                       "committed PMC passes of this workload from another run / box (profiles/r02_pmc_traffic.json) - not measured in this run")):
         if os.path.exists(path):
             try:
                 d = json.load(open(path))
                 if d.get("workload") == f"{args.config}:{args.sampler_steps}":
-                    return d.get("gemm_mfma_bytes_per_launch")
+                    return d.get("gemm_mfma_bytes_per_launch"), src
             except Exception:
                 pass
-    return None
+    return None, None
 
 
 def roofline_block(args, run_once):
@@ -210,7 +213,7 @@ def roofline_block(args, run_once):
         "family_ms_per_job": round(tot_ms, 2), "all_kernels_ms_per_job": round(all_ms, 2),
         "dominant_variant": {"name": dom["name"], "launches": dom["launches"], "avg_ms": round(dom["ms"] / dom["launches"], 5),
                              "tflops": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2)},
-        "traffic": pmc_traffic(args),
+        "traffic": pmc_traffic(args)[0], "traffic_source": pmc_traffic(args)[1],
     }
     return block, kernels
 
