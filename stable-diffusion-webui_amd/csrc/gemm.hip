@@ -1206,47 +1206,53 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
 // Split-K second pass: out = epilogue(sum over slices, in slice order => bit-reproducible).  One thread per 4 columns.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) {
     if (p.gate && *p.gate == 0) return;
-    const long quads = (long)p.M * (p.N / 4);
-    const long total = quads * batch;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int z = (int)(idx / quads);
-        const long q = idx - (long)z * quads;
-        const int m = (int)(q / (p.N / 4)), n = (int)(q - (long)m * (p.N / 4)) * 4;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.splitk; ++s)
-            v += *reinterpret_cast<const f4*>(p.splitk_ws + ((long)s * batch + z) * (long)p.M * p.N + (long)m * p.N + n);
-        const int b = m / p.rows_per_batch;
+    // (row, column-quad) pairs walked by the grid stride's quotient / remainder: no 64-bit division per element (static ISA review,
+    // DESIGN.md section 9)
+    const int NQ = p.N / 4;
+    const int stride = (int)gridDim.x * 256;                 // M * N / 4 < 2^31: split-K is admitted for the small-M layers only
+    const int sp = stride / NQ, sr = stride - sp * NQ;
+    const int i_init = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    for (int z = 0; z < batch; ++z) {
+        int m = i_init / NQ, nq = i_init - m * NQ;
+        for (; m < p.M; m += sp, nq += sr) {
+            if (nq >= NQ) { nq -= NQ; if (++m >= p.M) break; }
+            const int n = nq * 4;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.splitk; ++s)
+                v += *reinterpret_cast<const f4*>(p.splitk_ws + ((long)s * batch + z) * (long)p.M * p.N + (long)m * p.N + n);
+            const int b = m / p.rows_per_batch;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-        if (p.bias) {
-            if (p.flags & EP_BIAS_ROW) {
-                const float bb = p.bias[m];
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if (p.bias) {
+                if (p.flags & EP_BIAS_ROW) {
+                    const float bb = p.bias[m];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bb;
-            } else {
-                const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
+                    for (int r = 0; r < 4; ++r) v[r] += bb;
+                } else {
+                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(bb[r], p.bias_scale, v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(bb[r], p.bias_scale, v[r]);
+                }
             }
-        }
-        if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
-        if (p.flags & (EP_QUICK_GELU | EP_GELU)) {
+            if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+            if (p.flags & (EP_QUICK_GELU | EP_GELU)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = (p.flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
-        }
-        if (p.resid) {
-            const h4 rr = *reinterpret_cast<const h4*>(p.resid + z * p.r_bs + (long)m * p.ldr + n);
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (p.flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
+            }
+            if (p.resid) {
+                const h4 rr = *reinterpret_cast<const h4*>(p.resid + z * p.r_bs + (long)m * p.ldr + n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-        }
-        if (p.flags & EP_OUT_F32) {
-            *reinterpret_cast<f4*>((float*)p.out + z * p.o_bs + (long)m * p.ldo + n) = v;
-        } else {
-            h4 o;
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (p.flags & EP_OUT_F32) {
+                *reinterpret_cast<f4*>((float*)p.out + z * p.o_bs + (long)m * p.ldo + n) = v;
+            } else {
+                h4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-            *reinterpret_cast<h4*>((half_t*)p.out + z * p.o_bs + (long)m * p.ldo + n) = o;
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                *reinterpret_cast<h4*>((half_t*)p.out + z * p.o_bs + (long)m * p.ldo + n) = o;
+            }
         }
     }
 }
