@@ -89,6 +89,12 @@ struct GemmP {
                           // is carried at 1/64 scale (alpha scales the accumulator, bias_scale the bias)
     const int* gate;      // optional device flag: the launch is a no-op when *gate == 0 (context re-projection only if the context
                           // changed, decided on the device: no host synchronisation — engine.cpp unet_set_context)
+    // EP_LNFOLD: the A operand is the UN-normalised input x of a LayerNorm whose affine part is folded into the weights
+    // (w = fp16(W * gamma), bias = beta . W^T + b): the epilogue finishes the normalisation per row,
+    //     out[m][n] = rstd[m] * (acc[m][n] - mean[m] * ln_s[n]) + bias[n],   ln_s[n] = sum_k w[n][k]
+    // so the normalised tensor never exists in HBM (engine.cpp run_st, option "ln_fold").
+    const float* ln_stats;   // [M][2]: (mean, rstd) of the input rows (launch_ln_rowstats)
+    const float* ln_s;       // [N]
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
@@ -100,6 +106,7 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
                                                        // Conv2d padding_mode = 'circular', modules/sd_hijack.py:311-318)
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000,      // 0x100..0x1000: tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
+       EP_LNFOLD = 0x4000,             // see GemmP::ln_stats
        EP_NARROW = 0x2000              // 8-byte epilogue accesses (set by launch_gemm when the 16-byte form's alignment rules fail, or
                                        // by the "ep_wide" knob): gemm_epilogue's swap16 note
      };
@@ -152,6 +159,12 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
 int64_t groupnorm_ws_bytes(int B, int HW, int groups);
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
                      float eps, hipStream_t s);
+// LayerNorm folded into the consuming GEMMs (GemmP::ln_stats): per-row (mean, rstd) of x [rows][C] -> stats [rows][2] ...
+int launch_ln_rowstats(const half_t* x, float* stats, int64_t rows, int C, float eps, hipStream_t s);
+// ... and the one-off weight fold: wf[n][k] = fp16(w[n][k] * gamma[k]) (k < C, 0 beyond), s[n] = sum_k wf[n][k],
+// c[n] = sum_k beta[k] * w[n][k] + (bias ? bias[n] : 0); w / wf are packed [n_rows][K] (GEGLU row order included)
+int launch_ln_fold_weights(const half_t* w, const float* gamma, const float* beta, const float* bias, half_t* wf, float* s_out,
+                           float* c_out, int n_rows, int K, int C, hipStream_t s);
 
 // ---- elementwise / misc -----------------------------------------------------------------------------------
 int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t offset, hipStream_t s);

@@ -416,6 +416,73 @@ static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t*
     return launch_layernorm(x, n.g, n.b, out, rows, n.c, 1e-5f, r.s);
 }
 
+// ---- LayerNorm folded into the consuming GEMM (option "ln_fold") -----------------------------------------------------------
+// (mean, rstd) per row of x -> [rows][2] in the arena
+static int run_ln_stats(Run& r, const NormW& n, const half_t* x, int64_t rows, float** stats) {
+    *stats = r.F((size_t)rows * 2);
+    if (r.dry) return 0;
+    return launch_ln_rowstats(x, *stats, rows, n.c, 1e-5f, r.s);
+}
+// folded copy of W for the LayerNorm `n` in front of it; persistent, rebuilt after weight updates
+static int ensure_ln_fold(sdmi_engine* e, const ConvW& W, const NormW& n, hipStream_t s) {
+    if (W.w_ln && W.fold_epoch == e->weights_epoch) return 0;
+    SDMI_REQUIRE(W.taps == 1 && n.c <= W.cin_pad, "LayerNorm fold: linear layers only");
+    if (!W.w_ln) {
+        void* p = nullptr;
+        SDMI_CHECK_HIP(hipMalloc(&p, (size_t)W.n_pad * W.cin_pad * sizeof(half_t))); e->owned.push_back(p); W.w_ln = (half_t*)p;
+        SDMI_CHECK_HIP(hipMalloc(&p, (size_t)W.n_pad * sizeof(float))); e->owned.push_back(p); W.s_ln = (float*)p;
+        SDMI_CHECK_HIP(hipMalloc(&p, (size_t)W.n_pad * sizeof(float))); e->owned.push_back(p); W.c_ln = (float*)p;
+    }
+    TRY(launch_ln_fold_weights(W.w, n.g, n.b, W.b, W.w_ln, W.s_ln, W.c_ln, W.n_pad, W.cin_pad, n.c, s));
+    W.fold_epoch = e->weights_epoch;
+    return 0;
+}
+// out = LN_n(x) W^T + b through the folded weights: x is the UN-normalised input, `stats` its row statistics
+static int run_linear_ln(Run& r, const ConvW& W, const NormW& n, const half_t* x, const float* stats, int rows, half_t* out, int ldo) {
+    if (!r.dry) TRY(ensure_ln_fold(r.e, W, n, r.s));
+    // same split-K workspace bookkeeping as run_conv (dry pass included): the arena layout must not depend on the option's timing
+    float* splitk_ws = nullptr;
+    if (!W.geglu) {
+        const size_t wsb = gemm_splitk_ws_bytes(rows, W.n_pad, W.cin_pad, 1);
+        if (wsb) splitk_ws = r.F(wsb / sizeof(float));
+    }
+    r.st_tensor = nullptr; r.st_nchunk = 0;
+    if (r.dry) return 0;
+    GemmP p{};
+    p.splitk_ws = splitk_ws;
+    p.a0 = x; p.w = W.w_ln; p.bias = W.c_ln; p.out = out;
+    p.c0 = W.cin_pad; p.cin = W.cin_pad; p.lda0 = W.cin_pad;
+    p.Hi = rows; p.Wi = 1; p.Ho = rows; p.Wo = 1;
+    p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
+    p.M = rows; p.N = W.n_pad; p.K = W.cin_pad;
+    p.ldo = ldo; p.ldw = p.K;
+    p.rows_per_batch = rows; p.n_real = W.n_pad;
+    p.flags = EP_LNFOLD | (W.geglu ? EP_GEGLU : 0);
+    p.alpha = 1.f; p.bias_scale = 1.f;
+    p.ln_stats = stats; p.ln_s = W.s_ln;
+    return launch_gemm(p, 1, false, true, r.s);
+}
+// V^T [B][C][tokens_pad] = (LN_n(x) Wv^T + bv)^T through the folded weights (the token-major EP_TRANSPOSE form of run_vt)
+static int run_vt_ln(Run& r, const ConvW& Wv, const NormW& n, const half_t* x, const float* stats, int B, int tokens, int tokens_pad,
+                     half_t* vt) {
+    if (r.dry) return 0;
+    TRY(ensure_ln_fold(r.e, Wv, n, r.s));
+    GemmP p{};
+    const int C = Wv.n_pad, K = Wv.cin_pad;
+    p.a0 = x; p.c0 = K; p.cin = K; p.lda0 = K;
+    p.w = Wv.w_ln; p.ldw = K;
+    p.bias = Wv.c_ln;                                    // beta . Wv^T (+ bv): per output channel
+    p.out = vt;
+    p.Hi = tokens; p.Wi = 1; p.Ho = tokens; p.Wo = 1;
+    p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
+    p.M = B * tokens; p.N = C; p.K = K; p.n_valid = C;
+    p.ldo = tokens_pad; p.rows_per_batch = tokens; p.n_real = C;
+    p.flags = EP_TRANSPOSE | EP_LNFOLD;
+    p.alpha = 1.f; p.bias_scale = 1.f;
+    p.ln_stats = stats; p.ln_s = Wv.s_ln;
+    return launch_gemm(p, 1, false, true, r.s);
+}
+
 // ResBlock (UNet: GroupNorm32 eps 1e-5 + emb add; VAE: eps 1e-6, no emb).  Returns the output buffer.
 // `ss` (VAE range-extended decode only): the residual stream — x0 / x1 in, *out out — is stored multiplied by ss; GroupNorm is
 // scale-invariant once eps is multiplied by ss^2, the block-internal tensors stay at true scale, and the two layers that write the
@@ -581,10 +648,26 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     for (const TBlockW& b : st.blocks) {
         const std::string bname = name + ".transformer_blocks." + std::to_string(bi++);
         // --- self attention
-        half_t* n1 = r.H(M * C);
-        TRY(run_ln(r, b.ln1, cur, M, n1));
+        // option "ln_fold": the three LayerNorms are finished inside the GEMMs that read them (folded weights + per-row statistics):
+        // not with hypernetworks (they transform the normalised tokens) nor while block outputs are being tapped or cross-checked
+        // on the generic kernels, and only when V^T takes the token-major transposed form (run_vt)
+        const bool fold = e->ln_fold && !hn_has_dim(e, C) && !e->force_generic && e->use_glds && g_vt_mode == 1 && HW == Npad &&
+                          HW % 4 == 0;
         half_t* a1 = nullptr;
-        if (!hn_has_dim(e, C)) {
+        if (fold) {
+            float* st1 = nullptr;
+            TRY(run_ln_stats(r, b.ln1, cur, M, &st1));
+            half_t* qk = r.H(M * 2 * C);
+            TRY(run_linear_ln(r, b.qk1, b.ln1, cur, st1, (int)M, qk, 2 * C));
+            half_t* vt = r.H((size_t)B * C * Npad);
+            TRY(run_vt_ln(r, b.v1, b.ln1, cur, st1, B, HW, Npad, vt));
+            a1 = r.H(M * C);
+            TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
+        }
+        half_t* n1 = fold ? nullptr : r.H(M * C);
+        if (!fold) TRY(run_ln(r, b.ln1, cur, M, n1));
+        if (fold) {
+        } else if (!hn_has_dim(e, C)) {
             half_t* qk = r.H(M * 2 * C);
             TRY(run_linear(r, b.qk1, n1, (int)M, nullptr, qk, 2 * C));
             half_t* vt = r.H((size_t)B * C * Npad);
@@ -615,10 +698,18 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         TRY(run_linear(r, b.o1, a1, (int)M, cur, x1, C));
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
-        half_t* n2 = r.H(M * C);
-        TRY(run_ln(r, b.ln2, x1, M, n2));
-        half_t* q2 = r.H(M * C);
-        TRY(run_linear(r, b.q2, n2, (int)M, nullptr, q2, C));
+        half_t* q2 = nullptr;
+        if (fold) {
+            float* st2 = nullptr;
+            TRY(run_ln_stats(r, b.ln2, x1, M, &st2));
+            q2 = r.H(M * C);
+            TRY(run_linear_ln(r, b.q2, b.ln2, x1, st2, (int)M, q2, C));
+        } else {
+            half_t* n2 = r.H(M * C);
+            TRY(run_ln(r, b.ln2, x1, M, n2));
+            q2 = r.H(M * C);
+            TRY(run_linear(r, b.q2, n2, (int)M, nullptr, q2, C));
+        }
         half_t* a2 = r.H(M * C);
         if (!r.dry) {
             SDMI_REQUIRE(e->ctx_valid && e->ctx_B == B, "context not set for this batch size");
@@ -636,10 +727,18 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C));
         r.tap(bname + ".attn2+x", x2, B, H, Wd, C);
         // --- feed forward (GEGLU fused in the first GEMM's epilogue)
-        half_t* n3 = r.H(M * C);
-        TRY(run_ln(r, b.ln3, x2, M, n3));
-        half_t* g = r.H(M * 4 * C);
-        TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
+        half_t* g = nullptr;
+        if (fold) {
+            float* st3 = nullptr;
+            TRY(run_ln_stats(r, b.ln3, x2, M, &st3));
+            g = r.H(M * 4 * C);
+            TRY(run_linear_ln(r, b.ff1, b.ln3, x2, st3, (int)M, g, 4 * C));
+        } else {
+            half_t* n3 = r.H(M * C);
+            TRY(run_ln(r, b.ln3, x2, M, n3));
+            g = r.H(M * 4 * C);
+            TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
+        }
         half_t* x3 = r.H(M * C);
         TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
         r.tap(bname, x3, B, H, Wd, C);
@@ -1428,6 +1527,7 @@ int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data,
     SDMI_CHECK_HIP(hipDeviceSynchronize());
     if (tmp) (void)hipFree(tmp);
     e->ctx_valid = false;                                     // cached K / V^T depend on attn2.to_k / to_v
+    ++e->weights_epoch;                                       // LayerNorm-folded copies of this weight are stale
     return rc;
 }
 // ---- hypernetwork hand-over ------------------------------------------------------------------------------------------------
@@ -1526,6 +1626,7 @@ int engine_unet_update_vector(sdmi_engine* e, const char* key, const void* data,
     }
     SDMI_CHECK_HIP(hipDeviceSynchronize());
     if (tmp) (void)hipFree(tmp);
+    ++e->weights_epoch;                                       // a LayerNorm gain / shift or a folded bias may have changed
     return rc;
 }
 int engine_vae_finalize(sdmi_engine* e) {

@@ -85,9 +85,14 @@ __device__ __forceinline__ h8 join8(h4 lo, h4 hi) { return h8{lo[0], lo[1], lo[2
 
 // Epilogue shared by the GEMM kernels.  Lane holds, for accumulator tile (i, j):
 //   m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive channels)
-template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false>
+typedef float f2e __attribute__((ext_vector_type(2)));
+// LNF (EP_LNFOLD launches): finish a LayerNorm whose affine part is folded into the weights — v = rstd[m] * (v - mean[m] * s[n]) on the
+// alpha-scaled accumulator, before the (folded) bias is added (GemmP::ln_stats).
+template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z,
                                               char* smem = nullptr) {
+    static_assert(!(STATS && LNF), "the GroupNorm-statistics epilogue never follows a LayerNorm");
+    [[maybe_unused]] const f2e* lnst = reinterpret_cast<const f2e*>(p.ln_stats);
     if constexpr (TR) {
         // transposed store (EP_TRANSPOSE): the MFMAs ran with swapped operand roles, so for tile (i, j) the lane holds
         //   n = n0 + wc*WTN + j*16 + (lane & 15),  m = m0 + wr*WTM + i*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive tokens)
@@ -102,15 +107,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                     const int m = m0 + wr * WTM + (2 * a + sel) * 16 + tw;
                     const int b = min(m, p.M - 1) / p.rows_per_batch;
                     const int ml = m - b * p.rows_per_batch;
+                    f2e stx[LNF ? 4 : 1], sty[LNF ? 4 : 1];      // (mean, rstd) of the 4 + 4 tokens this lane holds before the exchange
+                    if constexpr (LNF) {
+                        const int tx = m0 + wr * WTM + 2 * a * 16 + (lane >> 4) * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { stx[r] = lnst[min(tx + r, p.M - 1)]; sty[r] = lnst[min(tx + 16 + r, p.M - 1)]; }
+                    }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int n = n0 + wc * WTN + j * 16 + (lane & 15);
                         const float bb = p.bias ? p.bias[n] * p.bias_scale : 0.f;
                         h4 ox, oy;
+                        if constexpr (LNF) {
+                            const float sn = p.ln_s[n];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                ox[r] = (half_t)(stx[r][1] * (acc[2 * a][j][r] * p.alpha - stx[r][0] * sn) + bb);
+                                oy[r] = (half_t)(sty[r][1] * (acc[2 * a + 1][j][r] * p.alpha - sty[r][0] * sn) + bb);
+                            }
+                        } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             ox[r] = (half_t)fmaf(acc[2 * a][j][r], p.alpha, bb);
                             oy[r] = (half_t)fmaf(acc[2 * a + 1][j][r], p.alpha, bb);
+                        }
                         }
                         swap16(ox, oy);
                         if (m < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + ((long)b * p.N + n) * p.ldo + ml) = join8(ox, oy);
@@ -125,13 +145,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             if (m >= p.M) continue;
             const int b = m / p.rows_per_batch;
             const int ml = m - b * p.rows_per_batch;
+            f2e stn[LNF ? 4 : 1];
+            if constexpr (LNF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stn[r] = lnst[min(m + r, p.M - 1)];
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wc * WTN + j * 16 + (lane & 15);
                 const float bb = p.bias ? p.bias[n] * p.bias_scale : 0.f;
                 h4 o;
+                if constexpr (LNF) {
+                    const float sn = p.ln_s[n];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(stn[r][1] * (acc[i][j][r] * p.alpha - stn[r][0] * sn) + bb);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)fmaf(acc[i][j][r], p.alpha, bb);
+                }
                 *reinterpret_cast<h4*>((half_t*)p.out + ob + ((long)b * p.N + n) * p.ldo + ml) = o;
             }
         }
@@ -318,12 +349,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                     bg = *reinterpret_cast<const f4*>(p.bias + npk + 32);
                                 }
                                 h4 o[2];
+                                [[maybe_unused]] f4 sva, svg;
+                                if constexpr (LNF) {
+                                    sva = *reinterpret_cast<const f4*>(p.ln_s + npk);
+                                    svg = *reinterpret_cast<const f4*>(p.ln_s + npk + 32);
+                                }
 #pragma unroll
                                 for (int t = 0; t < 2; ++t) {
                                     const f4 va = acc[2 * a + t][jg * 4 + j], vg = acc[2 * a + t][jg * 4 + j + 2];
+                                    [[maybe_unused]] f2e st;
+                                    if constexpr (LNF) st = lnst[min(m0 + wr * WTM + (2 * a + t) * 16 + lr, p.M - 1)];
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
-                                        const float av = fmaf(va[r], p.alpha, ba[r]), g = fmaf(vg[r], p.alpha, bg[r]);
+                                        float av, g;
+                                        if constexpr (LNF) {
+                                            av = st[1] * (va[r] * p.alpha - st[0] * sva[r]) + ba[r];
+                                            g = st[1] * (vg[r] * p.alpha - st[0] * svg[r]) + bg[r];
+                                        } else {
+                                            av = fmaf(va[r], p.alpha, ba[r]); g = fmaf(vg[r], p.alpha, bg[r]);
+                                        }
                                         o[t][r] = (half_t)(av * gelu_erf(g));
                                     }
                                 }
@@ -335,7 +379,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 }
                 return;
             } else {
-                constexpr bool PIPEW = TN <= 5;
+                constexpr bool PIPEW = TN <= 5 && !LNF;             // (LayerNorm-folded layers never carry a residual: no ring registers)
                 const bool colb = p.bias && !(flags & EP_BIAS_ROW);
                 f4 bcw[PIPEW ? TN : 1];
                 if constexpr (PIPEW) {
@@ -367,6 +411,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         f4 vx = acc[2 * a][j], vy = acc[2 * a + 1][j];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { vx[r] *= p.alpha; vy[r] *= p.alpha; }
+                        if constexpr (LNF) {
+                            const f2e sx = lnst[mx], sy = lnst[my];
+                            const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { vx[r] = sx[1] * (vx[r] - sx[0] * sv[r]); vy[r] = sy[1] * (vy[r] - sy[0] * sv[r]); }
+                        }
                         if (p.bias) {
                             if (flags & EP_BIAS_ROW) {
                                 const float b0 = p.bias[mx], b1 = p.bias[my];
@@ -391,7 +441,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                 vy[r] = (flags & EP_QUICK_GELU) ? vy[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * vy[r])) : gelu_erf(vy[r]);
                             }
                         }
-                        if (p.resid) {
+                        if (!LNF && p.resid) {
                             h8 rr;
                             if constexpr (PIPEW) rr = rw[a & 1][j];
                             else rr = *reinterpret_cast<const h8*>(p.resid + rbs + (long)min(ms, p.M - 1) * p.ldr + n0 + wc * WTN + j * 16 + nw);
@@ -411,7 +461,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             }
         }
     }
-    constexpr bool PIPE = !GEGLU && TN <= 5;
+    constexpr bool PIPE = !GEGLU && TN <= 5 && !LNF;
     const bool col_bias = p.bias && !(flags & EP_BIAS_ROW);
     f4 bcol[PIPE ? TN : 1];
     if constexpr (PIPE) {
@@ -454,10 +504,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                             bg = *reinterpret_cast<const f4*>(p.bias + npk + 32);
                         }
                         h4 o;
+                        if constexpr (LNF) {
+                            const f2e st = lnst[m];
+                            const f4 sva = *reinterpret_cast<const f4*>(p.ln_s + npk), svg = *reinterpret_cast<const f4*>(p.ln_s + npk + 32);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float a = st[1] * (va[r] * p.alpha - st[0] * sva[r]) + ba[r];
+                                const float g = st[1] * (vg[r] * p.alpha - st[0] * svg[r]) + bg[r];
+                                o[r] = (half_t)(a * gelu_erf(g));
+                            }
+                        } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float a = fmaf(va[r], p.alpha, ba[r]), g = fmaf(vg[r], p.alpha, bg[r]);
                             o[r] = (half_t)(a * gelu_erf(g));
+                        }
                         }
                         *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
                     }
@@ -471,6 +532,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             f4 v = acc[i][j];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if constexpr (LNF) {
+                const f2e st = lnst[m];
+                const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = st[1] * (v[r] - st[0] * sv[r]);
+            }
             if (p.bias) {
                 if (flags & EP_BIAS_ROW) {
                     const float bb = p.bias[m];
@@ -490,7 +557,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 for (int r = 0; r < 4; ++r)
                     v[r] = (flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
             }
-            if (p.resid) {
+            if (!LNF && p.resid) {
                 h4 rr;
                 if constexpr (PIPE) rr = rres[i & 1][j];
                 else rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
@@ -524,7 +591,7 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
@@ -708,7 +775,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS, LNF>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 template <int N>
@@ -748,7 +815,7 @@ __device__ __forceinline__ long long stamp() {           // s_memtime; callers s
     return t;
 }
 
-template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int BK = 64, WC = 4, ROWB = 128;
@@ -1116,7 +1183,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             for (int i = 0; i < 17; ++i) d[i] = tm[i];
         }
     }
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS, LNF>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1204,6 +1271,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
 }
 
 // Split-K second pass: out = epilogue(sum over slices, in slice order => bit-reproducible).  One thread per 4 columns.
+template <bool LNF = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) {
     if (p.gate && *p.gate == 0) return;
     // (row, column-quad) pairs walked by the grid stride's quotient / remainder: no 64-bit division per element (static ISA review,
@@ -1223,6 +1291,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
             const int b = m / p.rows_per_batch;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if constexpr (LNF) {
+                const float mean = p.ln_stats[2 * m], rstd = p.ln_stats[2 * m + 1];
+                const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * sv[r]);
+            }
             if (p.bias) {
                 if (p.flags & EP_BIAS_ROW) {
                     const float bb = p.bias[m];
@@ -1257,11 +1331,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNF>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1273,10 +1347,10 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
-    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS>;
+    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS, LNF>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1303,6 +1377,13 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
         SDMI_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    if (p.flags & EP_LNFOLD) {                             // LayerNorm folded into this GEMM
+        if constexpr ((BN / 4) % 64 == 0) {
+            if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true, false, false, false, true>(p, batch, s);
+        }
+        if (p.flags & EP_TRANSPOSE) return launch_pingpong2<BM, BN, false, true, false, false, true>(p, batch, s);
+        return launch_pingpong2<BM, BN, false, false, false, false, true>(p, batch, s);
+    }
     if constexpr ((BN / 4) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true>(p, batch, s);
     }
@@ -1316,6 +1397,15 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
 
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
+    if constexpr (GLDS) {                                  // LayerNorm folded into this GEMM (LDS-direct path only; launch_gemm checks)
+        if (p.flags & EP_LNFOLD) {
+            if constexpr ((BN / WC) % 64 == 0) {
+                if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true, false, false, false, true>(p, batch, s);
+            }
+            if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, true, false, false, true>(p, batch, s);
+            return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, false, false, true>(p, batch, s);
+        }
+    }
     if constexpr ((BN / WC) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true>(p, batch, s);
     }
@@ -1515,6 +1605,11 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     const double pf_flops = 2.0 * p.M * (double)p.N * p.K * batch;
     const double pf_in = (p.taps == 9 ? (double)p.M / (p.stride * p.stride) * (p.up ? 0.25 : 1.0) : (double)p.M) * p.cin * 2.0;
     const double pf_bytes = (pf_in + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.flags & EP_OUT_F32) ? 4.0 : 2.0)) * batch;
+    if (p.flags & EP_LNFOLD) {
+        SDMI_REQUIRE(p.ln_stats && p.ln_s && p.taps == 1 && !p.a1 && !p.stats_out && !(p.flags & (EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW)),
+                     "EP_LNFOLD: 1x1 / linear layers with fp16 row-major (or transposed) output only");
+        SDMI_REQUIRE(!force_generic && use_glds && gemm_mfma_supported(p), "EP_LNFOLD runs on the LDS-direct MFMA kernels only");
+    }
     if (force_generic || !gemm_mfma_supported(p)) {
         const bool geglu = p.flags & EP_GEGLU;
         const long total = (long)p.M * (geglu ? p.N / 2 : p.N);
@@ -1582,15 +1677,17 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     if (prof_enabled()) {
         pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
                 ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
-                (batch > 1 ? " x" + std::to_string(batch) : "");
+                ((p.flags & EP_LNFOLD) ? " ln" : "") + (batch > 1 ? " x" + std::to_string(batch) : "");
     }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);
     struct Reduce {     // second pass of split-K runs when the main kernel has been enqueued (scope exit of the switch)
         const GemmP& p; int batch; hipStream_t s; bool on;
         int run() const {
             if (!on) return 0;
-            const long total = (long)p.M * (p.N / 4) * batch;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, p, batch);
+            const long total = (long)p.M * (p.N / 4);      // per batch element: the kernel loops over the batch itself
+            const dim3 grid((unsigned)std::min<long>((total + 255) / 256, 8192));
+            if (p.flags & EP_LNFOLD) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, dim3(256), 0, s, p, batch);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, dim3(256), 0, s, p, batch);
             SDMI_CHECK_HIP(hipGetLastError());
             return 0;
         }
