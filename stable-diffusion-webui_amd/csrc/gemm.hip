@@ -1479,8 +1479,10 @@ int g_gemm_pipe = g_gemm_pipe_default;
 static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;
     if (p.N % kCfgBN[cfg]) return false;
-    if (cfg == CFG_256x64 || cfg == CFG_256x128) return false;         // measured never best: not instantiated
-    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160)) return false;   // wave tile not a multiple of 64
+    if (cfg == CFG_256x64) return false;                               // measured never best: not instantiated
+    // 256x128: not in pick_cfg's candidate list (the two-stage form was never best in round 1); instantiated for the ping-pong kernel
+    // so that the shape tuner / gemm_cfg=6 can try it on the N = 128 VAE convs (now 128x128 two-stage at ~750 TFLOP/s)
+    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_256x128)) return false;   // wave tile not a multiple of 64
     return true;
 }
 
@@ -1635,7 +1637,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     const int cfg = pick_cfg(p, batch, &split, can_split);
     // ping-pong kernel: every weight row must exist (no n_valid masking) and a (tap, source) segment must fit the zero page
     const bool phase = use_glds && (g_gemm_pipe == 3 || g_gemm_pipe == 4) &&
-                       (cfg == CFG_256x320 || cfg == CFG_256x256 || (cfg == CFG_128x320 && g_gemm_pipe == 4)) && p.n_valid == p.N &&
+                       (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_256x128 || (cfg == CFG_128x320 && g_gemm_pipe == 4)) && p.n_valid == p.N &&
                        p.cin + 64 <= kZeroPageHalfs &&
                        ((p.taps == 1 && p.stride == 1 && !p.up && p.Ho == p.Hi && p.Wo == p.Wi) ||
                         (p.M / p.rows_per_batch < 128 && (p.up ? 2 : 1) * p.Hi < 2040 && (p.up ? 2 : 1) * p.Wi < 2040 &&
@@ -1702,6 +1704,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         switch (cfg) {
             case CFG_256x320: rc = launch_pingpong<256, 320>(p, batch, s); break;
             case CFG_256x256: rc = launch_pingpong<256, 256>(p, batch, s); break;
+            case CFG_256x128: rc = launch_pingpong<256, 128>(p, batch, s); break;
             case CFG_128x320: rc = launch_pingpong<128, 320>(p, batch, s); break;
             default: break;
         }
@@ -1713,6 +1716,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_CASE(CFG_64x64, 64, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x128_K32, 128, 128, 2, 2, 32)
         SDMI_CASE(CFG_256x256, 256, 256, 4, 2, 64)
+        SDMI_CASE(CFG_256x128, 256, 128, 4, 2, 64)
         SDMI_CASE(CFG_256x320, 256, 320, 4, 2, 64)
         SDMI_CASE(CFG_128x64, 128, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x320, 128, 320, 2, 4, 64)
