@@ -93,8 +93,15 @@ struct GemmP {
     // (w = fp16(W * gamma), bias = beta . W^T + b): the epilogue finishes the normalisation per row,
     //     out[m][n] = rstd[m] * (acc[m][n] - mean[m] * ln_s[n]) + bias[n],   ln_s[n] = sum_k w[n][k]
     // so the normalised tensor never exists in HBM (engine.cpp run_st, option "ln_fold").
-    const float* ln_stats;   // [M][2]: (mean, rstd) of the input rows (launch_ln_rowstats)
+    const float* ln_stats;   // [M][2]: (mean, rstd) of the input rows (launch_ln_rowstats) — or, with ln_np > 0, [M][ln_np][2] partial
+                             // (sum, sum of squares) pairs written by the producing GEMM's epilogue (lnp_out), finished per row here
     const float* ln_s;       // [N]
+    int ln_np;               // 0: ln_stats holds (mean, rstd); > 0: that many partial pairs per row
+    float ln_inv_c, ln_eps;  // 1 / C and the LayerNorm eps, used with ln_np > 0
+    // producer side: when lnp_out is set and the launch qualifies (16-byte plain epilogue, no split-K), the epilogue also writes the
+    // per-row sums of its fp16-ROUNDED outputs over the tile's BN columns to lnp_out[(m * lnp_np + tile_n) * 2 + {0, 1}]
+    float* lnp_out;
+    int lnp_np;              // set by launch_gemm: N / BN of the chosen tile when the partials are produced, else 0
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
@@ -113,7 +120,8 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
 
 // stats_nchunk_out (optional): the number of row chunks per image of the GroupNorm partial sums written to p.stats_out, or 0 when the
 // launch could not produce them (split-K, a tile spanning two images, a group straddling column tiles ...)
-int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out = nullptr);
+int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out = nullptr,
+                int* lnp_np_out = nullptr);      // lnp_np_out: partial pairs per row written to p.lnp_out, 0 when not produced
 extern int g_ep_wide;               // 1 (default): 16-byte epilogue accesses where the alignment allows; 0: always 8-byte
 extern int g_gn_fuse;               // 1 (default): GroupNorm statistics from the producing GEMM's epilogue where possible; 0: always a stats pass
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)

@@ -88,11 +88,23 @@ __device__ __forceinline__ h8 join8(h4 lo, h4 hi) { return h8{lo[0], lo[1], lo[2
 typedef float f2e __attribute__((ext_vector_type(2)));
 // LNF (EP_LNFOLD launches): finish a LayerNorm whose affine part is folded into the weights — v = rstd[m] * (v - mean[m] * s[n]) on the
 // alpha-scaled accumulator, before the (folded) bias is added (GemmP::ln_stats).
-template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false, bool LNF = false>
+template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false, int LNM = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z,
                                               char* smem = nullptr) {
-    static_assert(!(STATS && LNF), "the GroupNorm-statistics epilogue never follows a LayerNorm");
+    constexpr bool LNF = LNM == 1;       // LayerNorm consumer (EP_LNFOLD)
+    constexpr bool LNS = LNM == 2;       // LayerNorm producer: per-row partial sums of the output (GemmP::lnp_out)
+    static_assert(!(STATS && LNM != 0), "the GroupNorm-statistics epilogue neither follows nor feeds a LayerNorm");
+    static_assert(!(LNS && (GEGLU || TR)), "row partial sums are taken by the plain epilogue only");
     [[maybe_unused]] const f2e* lnst = reinterpret_cast<const f2e*>(p.ln_stats);
+    // (mean, rstd) of input row m: stored as such, or finished here from the producer's per-tile partial sums (fixed order)
+    [[maybe_unused]] auto row_stat = [&](int m) -> f2e {
+        if (p.ln_np == 0) return lnst[m];
+        const float* pp = p.ln_stats + (long)m * p.ln_np * 2;
+        float sm = 0.f, q = 0.f;
+        for (int t = 0; t < p.ln_np; ++t) { sm += pp[2 * t]; q += pp[2 * t + 1]; }
+        const float mean = sm * p.ln_inv_c;
+        return f2e{mean, rsqrtf(fmaxf(fmaf(-mean, mean, q * p.ln_inv_c), 0.f) + p.ln_eps)};
+    };
     if constexpr (TR) {
         // transposed store (EP_TRANSPOSE): the MFMAs ran with swapped operand roles, so for tile (i, j) the lane holds
         //   n = n0 + wc*WTN + j*16 + (lane & 15),  m = m0 + wr*WTM + i*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive tokens)
@@ -111,7 +123,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                     if constexpr (LNF) {
                         const int tx = m0 + wr * WTM + 2 * a * 16 + (lane >> 4) * 4;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { stx[r] = lnst[min(tx + r, p.M - 1)]; sty[r] = lnst[min(tx + 16 + r, p.M - 1)]; }
+                        for (int r = 0; r < 4; ++r) { stx[r] = row_stat(min(tx + r, p.M - 1)); sty[r] = row_stat(min(tx + 16 + r, p.M - 1)); }
                     }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
@@ -148,7 +160,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             f2e stn[LNF ? 4 : 1];
             if constexpr (LNF) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stn[r] = lnst[min(m + r, p.M - 1)];
+                for (int r = 0; r < 4; ++r) stn[r] = row_stat(min(m + r, p.M - 1));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -358,7 +370,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                 for (int t = 0; t < 2; ++t) {
                                     const f4 va = acc[2 * a + t][jg * 4 + j], vg = acc[2 * a + t][jg * 4 + j + 2];
                                     [[maybe_unused]] f2e st;
-                                    if constexpr (LNF) st = lnst[min(m0 + wr * WTM + (2 * a + t) * 16 + lr, p.M - 1)];
+                                    if constexpr (LNF) st = row_stat(min(m0 + wr * WTM + (2 * a + t) * 16 + lr, p.M - 1));
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
                                         float av, g;
@@ -381,14 +393,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             } else {
                 constexpr bool PIPEW = TN <= 5 && !LNF;             // (LayerNorm-folded layers never carry a residual: no ring registers)
                 const bool colb = p.bias && !(flags & EP_BIAS_ROW);
-                f4 bcw[PIPEW ? TN : 1];
-                if constexpr (PIPEW) {
+                constexpr bool HOISTB = PIPEW && !LNS;               // (the row-sum variant needs the 20 registers of the hoisted bias)
+                f4 bcw[HOISTB ? TN : 1];
+                if constexpr (HOISTB) {
                     if (colb) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) bcw[j] = *reinterpret_cast<const f4*>(p.bias + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
                     }
                 }
-                h8 rw[2][PIPEW ? TN : 1];
+                // (row-sum variant on the 5-column-tile wave tiles: a one-deep ring — the pair a+1 residual is requested once pair a's
+                // accumulators are dead, or the 256x320 instantiation spills; the other variants prefetch one pair ahead)
+                constexpr int RWD = (LNS && TN > 4) ? 1 : 2;
+                h8 rw[RWD][PIPEW ? TN : 1];
                 auto prefetch_w = [&](int a, int slot) {
                     if (!PIPEW || !p.resid) return;
                     const int m = min(mw + a * 32, p.M - 1);
@@ -397,10 +413,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         rw[slot][j] = *reinterpret_cast<const h8*>(p.resid + rbs + (long)m * p.ldr + n0 + wc * WTN + j * 16 + nw);
                 };
                 if constexpr (PIPEW) prefetch_w(0, 0);
+                // LNS: per-row (sum, sum of squares) of the fp16-rounded outputs over this tile's columns, for the LayerNorm that
+                // reads this tensor: lane -> 16-lane-stride shuffles (the 4 lanes of a row) -> LDS [wave column][row] -> one thread
+                // per row adds the wave columns in a fixed order.  Deterministic.
+                constexpr int BMt = WR_ * WTM, WCn = BN_ / WTN;
+                [[maybe_unused]] float* red = reinterpret_cast<float*>(smem);
+                if constexpr (LNS) __syncthreads();                   // every wave is done reading the operand tiles that lived here
 #pragma unroll
                 for (int a = 0; a < TM / 2; ++a) {
+                    [[maybe_unused]] float lsx = 0.f, lqx = 0.f, lsy = 0.f, lqy = 0.f;
                     if constexpr (PIPEW) {
-                        if (a + 1 < TM / 2) prefetch_w(a + 1, (a + 1) & 1);
+                        if (RWD == 2 && a + 1 < TM / 2) prefetch_w(a + 1, (a + 1) & 1);
                     }
                     const int ms = mw + a * 32;
                     const int mx = min(m0 + wr * WTM + 2 * a * 16 + lr, p.M - 1), my = min(m0 + wr * WTM + (2 * a + 1) * 16 + lr, p.M - 1);
@@ -412,7 +435,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { vx[r] *= p.alpha; vy[r] *= p.alpha; }
                         if constexpr (LNF) {
-                            const f2e sx = lnst[mx], sy = lnst[my];
+                            const f2e sx = row_stat(mx), sy = row_stat(my);
                             const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { vx[r] = sx[1] * (vx[r] - sx[0] * sv[r]); vy[r] = sy[1] * (vy[r] - sy[0] * sv[r]); }
@@ -424,7 +447,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                 for (int r = 0; r < 4; ++r) { vx[r] += b0; vy[r] += b1; }
                             } else {
                                 f4 bb;
-                                if constexpr (PIPEW) bb = bcw[j];
+                                if constexpr (HOISTB) bb = bcw[j];
                                 else bb = *reinterpret_cast<const f4*>(p.bias + n);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { vx[r] = fmaf(bb[r], p.bias_scale, vx[r]); vy[r] = fmaf(bb[r], p.bias_scale, vy[r]); }
@@ -443,7 +466,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         }
                         if (!LNF && p.resid) {
                             h8 rr;
-                            if constexpr (PIPEW) rr = rw[a & 1][j];
+                            if constexpr (PIPEW) rr = rw[a & (RWD - 1)][j];
                             else rr = *reinterpret_cast<const h8*>(p.resid + rbs + (long)min(ms, p.M - 1) * p.ldr + n0 + wc * WTN + j * 16 + nw);
                             h4 rx = {rr[0], rr[1], rr[2], rr[3]}, ry = {rr[4], rr[5], rr[6], rr[7]};
                             swap16(rx, ry);
@@ -453,8 +476,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         h4 ox, oy;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { ox[r] = (half_t)vx[r]; oy[r] = (half_t)vy[r]; }
+                        if constexpr (LNS) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float fx = (float)ox[r], fy = (float)oy[r];
+                                lsx += fx; lqx = fmaf(fx, fx, lqx); lsy += fy; lqy = fmaf(fy, fy, lqy);
+                            }
+                        }
                         swap16(ox, oy);
                         if (ms < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + (long)ms * p.ldo + n0 + wc * WTN + j * 16 + nw) = join8(ox, oy);
+                    }
+                    if constexpr (PIPEW && RWD == 1) {
+                        if (a + 1 < TM / 2) prefetch_w(a + 1, 0);
+                    }
+                    if constexpr (LNS) {
+                        lsx += __shfl_xor(lsx, 16); lqx += __shfl_xor(lqx, 16); lsy += __shfl_xor(lsy, 16); lqy += __shfl_xor(lqy, 16);
+                        lsx += __shfl_xor(lsx, 32); lqx += __shfl_xor(lqx, 32); lsy += __shfl_xor(lsy, 32); lqy += __shfl_xor(lqy, 32);
+                        if ((lane >> 4) == 0) {
+                            const int rx = wr * WTM + 2 * a * 16 + lr;
+                            float* d = red + ((long)wc * BMt + rx) * 2;
+                            d[0] = lsx; d[1] = lqx; d[32] = lsy; d[33] = lqy;          // row rx + 16
+                        }
+                    }
+                }
+                if constexpr (LNS) {
+                    __syncthreads();
+                    const int tid = threadIdx.x;
+                    if (tid < BMt && m0 + tid < p.M) {
+                        float sm = 0.f, q = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WCn; ++w) { sm += red[((long)w * BMt + tid) * 2]; q += red[((long)w * BMt + tid) * 2 + 1]; }
+                        float* dst = p.lnp_out + ((long)(m0 + tid) * p.lnp_np + n0 / BN_) * 2;
+                        dst[0] = sm; dst[1] = q;
                     }
                 }
                 return;
@@ -505,7 +558,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         }
                         h4 o;
                         if constexpr (LNF) {
-                            const f2e st = lnst[m];
+                            const f2e st = row_stat(m);
                             const f4 sva = *reinterpret_cast<const f4*>(p.ln_s + npk), svg = *reinterpret_cast<const f4*>(p.ln_s + npk + 32);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -533,7 +586,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
             if constexpr (LNF) {
-                const f2e st = lnst[m];
+                const f2e st = row_stat(m);
                 const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = st[1] * (v[r] - st[0] * sv[r]);
@@ -591,7 +644,7 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
@@ -775,7 +828,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS, LNF>(p, acc, m0, n0, wr, wc, lane, z, smem);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS, LNM>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 template <int N>
@@ -815,7 +868,7 @@ __device__ __forceinline__ long long stamp() {           // s_memtime; callers s
     return t;
 }
 
-template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
+template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int BK = 64, WC = 4, ROWB = 128;
@@ -1183,7 +1236,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             for (int i = 0; i < 17; ++i) d[i] = tm[i];
         }
     }
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS, LNF>(p, acc, m0, n0, wr, wc, lane, z, smem);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS, LNM>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1292,7 +1345,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
             if constexpr (LNF) {
-                const float mean = p.ln_stats[2 * m], rstd = p.ln_stats[2 * m + 1];
+                float mean, rstd;
+                if (p.ln_np == 0) { mean = p.ln_stats[2 * m]; rstd = p.ln_stats[2 * m + 1]; }
+                else {
+                    const float* pp = p.ln_stats + (long)m * p.ln_np * 2;
+                    float sm = 0.f, q = 0.f;
+                    for (int t = 0; t < p.ln_np; ++t) { sm += pp[2 * t]; q += pp[2 * t + 1]; }
+                    mean = sm * p.ln_inv_c;
+                    rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * p.ln_inv_c), 0.f) + p.ln_eps);
+                }
                 const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * sv[r]);
@@ -1331,11 +1392,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNF>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1347,10 +1408,10 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, bool LNF = false>
+template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
-    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS, LNF>;
+    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS, LNM>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1379,11 +1440,12 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
     }
     if (p.flags & EP_LNFOLD) {                             // LayerNorm folded into this GEMM
         if constexpr ((BN / 4) % 64 == 0) {
-            if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true, false, false, false, true>(p, batch, s);
+            if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true, false, false, false, 1>(p, batch, s);
         }
-        if (p.flags & EP_TRANSPOSE) return launch_pingpong2<BM, BN, false, true, false, false, true>(p, batch, s);
-        return launch_pingpong2<BM, BN, false, false, false, false, true>(p, batch, s);
+        if (p.flags & EP_TRANSPOSE) return launch_pingpong2<BM, BN, false, true, false, false, 1>(p, batch, s);
+        return launch_pingpong2<BM, BN, false, false, false, false, 1>(p, batch, s);
     }
+    if (p.lnp_np > 0) return launch_pingpong2<BM, BN, false, false, false, false, 2>(p, batch, s);
     if constexpr ((BN / 4) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true>(p, batch, s);
     }
@@ -1397,14 +1459,18 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
 
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
-    if constexpr (GLDS) {                                  // LayerNorm folded into this GEMM (LDS-direct path only; launch_gemm checks)
+    if constexpr (BM >= 256) {                             // the two-stage 256-row tiles (the ping-pong kernel's fallback) carry no LayerNorm forms
+        if (p.flags & EP_LNFOLD) { set_error("EP_LNFOLD on a 256-row tile needs the ping-pong kernel (gemm_pipe 3 / 4)"); return 1; }
+    }
+    if constexpr (GLDS && BM < 256) {                      // LayerNorm folded into this GEMM (LDS-direct path only; launch_gemm checks)
         if (p.flags & EP_LNFOLD) {
             if constexpr ((BN / WC) % 64 == 0) {
-                if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true, false, false, false, true>(p, batch, s);
+                if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true, false, false, false, 1>(p, batch, s);
             }
-            if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, true, false, false, true>(p, batch, s);
-            return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, false, false, true>(p, batch, s);
+            if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, true, false, false, 1>(p, batch, s);
+            return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, false, false, 1>(p, batch, s);
         }
+        if (p.lnp_np > 0) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, false, false, 2>(p, batch, s);
     }
     if constexpr ((BN / WC) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true>(p, batch, s);
@@ -1591,10 +1657,12 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch) {
     return (size_t)8 * M * N * batch * sizeof(float);
 }
 
-int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out) {
+int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out, int* lnp_np_out) {
     GemmP p = p_in;
     p.stats_nchunk = 0;
+    p.lnp_np = 0;
     if (stats_nchunk_out) *stats_nchunk_out = 0;
+    if (lnp_np_out) *lnp_np_out = 0;
     p.flags |= g_gemm_dbgflags;
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     if (p.bias_scale == 0.f) p.bias_scale = 1.f;
@@ -1674,6 +1742,14 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
             p.stats_nchunk = p.rows_per_batch / BMc;
             if (stats_nchunk_out) *stats_nchunk_out = p.stats_nchunk;
         }
+    }
+    // LayerNorm row partials from this launch's epilogue (GemmP::lnp_out): the 16-byte plain epilogue of an unsplit fp16 launch only
+    if (p.lnp_out && use_glds && split <= 1 && batch == 1 && p.stats_nchunk == 0 &&
+        !(p.flags & (EP_NARROW | EP_GEGLU | EP_TRANSPOSE | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW | EP_QUICK_GELU | EP_GELU | EP_LNFOLD)) &&
+        kCfgBM[cfg] % 32 == 0 && cfg != CFG_64x64 && (phase || kCfgBM[cfg] < 256)) {   // (64x64: one 16-row tile per wave, no row-tile
+                                                                                         // pairs; two-stage 256-row tiles: not instantiated)
+        p.lnp_np = p.N / kCfgBN[cfg];
+        if (lnp_np_out) *lnp_np_out = p.lnp_np;
     }
     std::string pname;
     if (prof_enabled()) {
