@@ -540,6 +540,7 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     else if (n == "glds") e->use_glds = value != 0;
     else if (n == "trace") { e->trace = value != 0; e->taps.clear(); }
     else if (n == "tiling") e->tiling = value != 0;
+    else if (n == "ln_fold") e->ln_fold = value != 0;
     else if (n == "vae_range_extend") e->vae_stream_scale = value ? 1.0f / 64.0f : 1.0f;
     else { set_error("unknown option " + n); return 1; }
     return 0;

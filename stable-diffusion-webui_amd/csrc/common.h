@@ -89,6 +89,19 @@ struct GemmP {
                           // is carried at 1/64 scale (alpha scales the accumulator, bias_scale the bias)
     const int* gate;      // optional device flag: the launch is a no-op when *gate == 0 (context re-projection only if the context
                           // changed, decided on the device: no host synchronisation — engine.cpp unet_set_context)
+    // EP_LNFOLD: the A operand is the UN-normalised input x of a LayerNorm whose affine part is folded into the weights
+    // (w = fp16(W * gamma), bias = beta . W^T + b): the epilogue finishes the normalisation per row,
+    //     out[m][n] = rstd[m] * (acc[m][n] - mean[m] * ln_s[n]) + bias[n],   ln_s[n] = sum_k w[n][k]
+    // so the normalised tensor never exists in HBM (engine.cpp run_st, option "ln_fold").
+    const float* ln_stats;   // [M][2]: (mean, rstd) of the input rows (launch_ln_rowstats) — or, with ln_np > 0, [M][ln_np][2] partial
+                             // (sum, sum of squares) pairs written by the producing GEMM's epilogue (lnp_out), finished per row here
+    const float* ln_s;       // [N]
+    int ln_np;               // 0: ln_stats holds (mean, rstd); > 0: that many partial pairs per row
+    float ln_inv_c, ln_eps;  // 1 / C and the LayerNorm eps, used with ln_np > 0
+    // producer side: when lnp_out is set and the launch qualifies (16-byte plain epilogue, no split-K), the epilogue also writes the
+    // per-row sums of its fp16-ROUNDED outputs over the tile's BN columns to lnp_out[(m * lnp_np + tile_n) * 2 + {0, 1}]
+    float* lnp_out;
+    int lnp_np;              // set by launch_gemm: N / BN of the chosen tile when the partials are produced, else 0
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
@@ -100,13 +113,15 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
                                                        // Conv2d padding_mode = 'circular', modules/sd_hijack.py:311-318)
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000,      // 0x100..0x1000: tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
+       EP_LNFOLD = 0x4000,             // see GemmP::ln_stats
        EP_NARROW = 0x2000              // 8-byte epilogue accesses (set by launch_gemm when the 16-byte form's alignment rules fail, or
                                        // by the "ep_wide" knob): gemm_epilogue's swap16 note
      };
 
 // stats_nchunk_out (optional): the number of row chunks per image of the GroupNorm partial sums written to p.stats_out, or 0 when the
 // launch could not produce them (split-K, a tile spanning two images, a group straddling column tiles ...)
-int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out = nullptr);
+int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out = nullptr,
+                int* lnp_np_out = nullptr);      // lnp_np_out: partial pairs per row written to p.lnp_out, 0 when not produced
 extern int g_ep_wide;               // 1 (default): 16-byte epilogue accesses where the alignment allows; 0: always 8-byte
 extern int g_gn_fuse;               // 1 (default): GroupNorm statistics from the producing GEMM's epilogue where possible; 0: always a stats pass
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)
@@ -152,6 +167,12 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
 int64_t groupnorm_ws_bytes(int B, int HW, int groups);
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
                      float eps, hipStream_t s);
+// LayerNorm folded into the consuming GEMMs (GemmP::ln_stats): per-row (mean, rstd) of x [rows][C] -> stats [rows][2] ...
+int launch_ln_rowstats(const half_t* x, float* stats, int64_t rows, int C, float eps, hipStream_t s);
+// ... and the one-off weight fold: wf[n][k] = fp16(w[n][k] * gamma[k]) (k < C, 0 beyond), s[n] = sum_k wf[n][k],
+// c[n] = sum_k beta[k] * w[n][k] + (bias ? bias[n] : 0); w / wf are packed [n_rows][K] (GEGLU row order included)
+int launch_ln_fold_weights(const half_t* w, const float* gamma, const float* beta, const float* bias, half_t* wf, float* s_out,
+                           float* c_out, int n_rows, int K, int C, hipStream_t s);
 
 // ---- elementwise / misc -----------------------------------------------------------------------------------
 int launch_philox(float* out, int64_t n, uint64_t seed, uint32_t offset, hipStream_t s);

@@ -55,6 +55,12 @@ struct Run {
     const half_t* st_tensor = nullptr;
     float* st_ws = nullptr;
     int st_nchunk = 0;
+    // LayerNorm row partial sums handed from a producing GEMM's epilogue to the folded consumers of its output (option "ln_fold"):
+    // set lnp_want before the producer's run_conv; lnp_tensor / lnp_ws / lnp_np describe what the last run_conv produced
+    bool lnp_want = false;
+    const half_t* lnp_tensor = nullptr;
+    float* lnp_ws = nullptr;
+    int lnp_np = 0;
 };
 
 #define TRY(x)                  \
@@ -365,9 +371,16 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     float* stats_ws = nullptr;
     if (a.stats_C > 0 && W.n_pad == a.stats_C && a.stats_C % 32 == 0) stats_ws = r.F((size_t)a.B * 64 * 32 * 2);
     r.st_tensor = nullptr; r.st_nchunk = 0;
+    // room for the LayerNorm row partials of the output ([M][N / 64 tiles at most][2]); allocated in the dry pass too
+    float* lnp_ws = nullptr;
+    const bool want_lnp = r.lnp_want && W.taps == 1 && !W.geglu && !(a.flags & (EP_NCHW | EP_OUT_F32 | EP_TRANSPOSE));
+    r.lnp_want = false;
+    if (want_lnp) lnp_ws = r.F((size_t)a.B * a.Ho * a.Wo * (W.n_pad / 64) * 2);
+    r.lnp_tensor = nullptr; r.lnp_np = 0;
     if (r.dry) return 0;
     GemmP p{};
     p.splitk_ws = splitk_ws;
+    p.lnp_out = lnp_ws;
     p.a0 = a.a0; p.a1 = a.a1; p.w = W.w; p.bias = W.b; p.rowbias = a.rowbias; p.resid = a.resid; p.out = a.out;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1; p.lda0 = a.c0; p.lda1 = a.c1;
     SDMI_REQUIRE(p.cin == W.cin_pad, "conv input channels do not match the packed weight");
@@ -385,8 +398,10 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.gate = a.gate;
     int nchunk = 0;
     if (stats_ws) { p.stats_out = stats_ws; p.stats_cpg = a.stats_C / 32; }
-    TRY(launch_gemm(p, a.batch, r.e->force_generic, r.e->use_glds, r.s, &nchunk));
+    int lnp_np = 0;
+    TRY(launch_gemm(p, a.batch, r.e->force_generic, r.e->use_glds, r.s, &nchunk, &lnp_np));
     if (nchunk > 0) { r.st_tensor = (const half_t*)a.out; r.st_ws = stats_ws; r.st_nchunk = nchunk; }
+    if (lnp_np > 0) { r.lnp_tensor = (const half_t*)a.out; r.lnp_ws = lnp_ws; r.lnp_np = lnp_np; }
     return 0;
 }
 
@@ -414,6 +429,78 @@ static int run_gn(Run& r, const NormW& n, const half_t* x0, const half_t* x1, in
 static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t* out) {
     if (r.dry) return 0;
     return launch_layernorm(x, n.g, n.b, out, rows, n.c, 1e-5f, r.s);
+}
+
+// ---- LayerNorm folded into the consuming GEMM (option "ln_fold") -----------------------------------------------------------
+// Row statistics of a LayerNorm input: the producer's per-tile partial sums when the GEMM that wrote x left them (np > 0), else
+// (mean, rstd) from the row-statistics kernel (np == 0).  The arena slot of the kernel's output is taken in both cases, so the
+// arena layout does not depend on which producer tile was chosen.
+struct LnStats { const float* ptr = nullptr; int np = 0; };
+static int run_ln_stats(Run& r, const NormW& n, const half_t* x, int64_t rows, LnStats* out) {
+    float* own = r.F((size_t)rows * 2);
+    if (r.dry) { out->ptr = own; out->np = 0; return 0; }
+    if (r.lnp_tensor == x && r.lnp_np > 0) { out->ptr = r.lnp_ws; out->np = r.lnp_np; return 0; }
+    out->ptr = own; out->np = 0;
+    return launch_ln_rowstats(x, own, rows, n.c, 1e-5f, r.s);
+}
+// folded copy of W for the LayerNorm `n` in front of it; persistent, rebuilt after weight updates
+static int ensure_ln_fold(sdmi_engine* e, const ConvW& W, const NormW& n, hipStream_t s) {
+    if (W.w_ln && W.fold_epoch == e->weights_epoch) return 0;
+    SDMI_REQUIRE(W.taps == 1 && n.c <= W.cin_pad, "LayerNorm fold: linear layers only");
+    if (!W.w_ln) {
+        void* p = nullptr;
+        SDMI_CHECK_HIP(hipMalloc(&p, (size_t)W.n_pad * W.cin_pad * sizeof(half_t))); e->owned.push_back(p); W.w_ln = (half_t*)p;
+        SDMI_CHECK_HIP(hipMalloc(&p, (size_t)W.n_pad * sizeof(float))); e->owned.push_back(p); W.s_ln = (float*)p;
+        SDMI_CHECK_HIP(hipMalloc(&p, (size_t)W.n_pad * sizeof(float))); e->owned.push_back(p); W.c_ln = (float*)p;
+    }
+    TRY(launch_ln_fold_weights(W.w, n.g, n.b, W.b, W.w_ln, W.s_ln, W.c_ln, W.n_pad, W.cin_pad, n.c, s));
+    W.fold_epoch = e->weights_epoch;
+    return 0;
+}
+// out = LN_n(x) W^T + b through the folded weights: x is the UN-normalised input, `stats` its row statistics
+static int run_linear_ln(Run& r, const ConvW& W, const NormW& n, const half_t* x, const LnStats& stats, int rows, half_t* out, int ldo) {
+    if (!r.dry) TRY(ensure_ln_fold(r.e, W, n, r.s));
+    // same split-K workspace bookkeeping as run_conv (dry pass included): the arena layout must not depend on the option's timing
+    float* splitk_ws = nullptr;
+    if (!W.geglu) {
+        const size_t wsb = gemm_splitk_ws_bytes(rows, W.n_pad, W.cin_pad, 1);
+        if (wsb) splitk_ws = r.F(wsb / sizeof(float));
+    }
+    r.st_tensor = nullptr; r.st_nchunk = 0;
+    if (r.dry) return 0;
+    GemmP p{};
+    p.splitk_ws = splitk_ws;
+    p.a0 = x; p.w = W.w_ln; p.bias = W.c_ln; p.out = out;
+    p.c0 = W.cin_pad; p.cin = W.cin_pad; p.lda0 = W.cin_pad;
+    p.Hi = rows; p.Wi = 1; p.Ho = rows; p.Wo = 1;
+    p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
+    p.M = rows; p.N = W.n_pad; p.K = W.cin_pad;
+    p.ldo = ldo; p.ldw = p.K;
+    p.rows_per_batch = rows; p.n_real = W.n_pad;
+    p.flags = EP_LNFOLD | (W.geglu ? EP_GEGLU : 0);
+    p.alpha = 1.f; p.bias_scale = 1.f;
+    p.ln_stats = stats.ptr; p.ln_np = stats.np; p.ln_inv_c = 1.0f / (float)n.c; p.ln_eps = 1e-5f; p.ln_s = W.s_ln;
+    return launch_gemm(p, 1, false, true, r.s);
+}
+// V^T [B][C][tokens_pad] = (LN_n(x) Wv^T + bv)^T through the folded weights (the token-major EP_TRANSPOSE form of run_vt)
+static int run_vt_ln(Run& r, const ConvW& Wv, const NormW& n, const half_t* x, const LnStats& stats, int B, int tokens, int tokens_pad,
+                     half_t* vt) {
+    if (r.dry) return 0;
+    TRY(ensure_ln_fold(r.e, Wv, n, r.s));
+    GemmP p{};
+    const int C = Wv.n_pad, K = Wv.cin_pad;
+    p.a0 = x; p.c0 = K; p.cin = K; p.lda0 = K;
+    p.w = Wv.w_ln; p.ldw = K;
+    p.bias = Wv.c_ln;                                    // beta . Wv^T (+ bv): per output channel
+    p.out = vt;
+    p.Hi = tokens; p.Wi = 1; p.Ho = tokens; p.Wo = 1;
+    p.taps = 1; p.stride = 1; p.pad = 0; p.up = 0;
+    p.M = B * tokens; p.N = C; p.K = K; p.n_valid = C;
+    p.ldo = tokens_pad; p.rows_per_batch = tokens; p.n_real = C;
+    p.flags = EP_TRANSPOSE | EP_LNFOLD;
+    p.alpha = 1.f; p.bias_scale = 1.f;
+    p.ln_stats = stats.ptr; p.ln_np = stats.np; p.ln_inv_c = 1.0f / (float)n.c; p.ln_eps = 1e-5f; p.ln_s = Wv.s_ln;
+    return launch_gemm(p, 1, false, true, r.s);
 }
 
 // ResBlock (UNet: GroupNorm32 eps 1e-5 + emb add; VAE: eps 1e-6, no emb).  Returns the output buffer.
@@ -576,15 +663,33 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     half_t* n0 = r.H(M * C);
     TRY(run_gn(r, st.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
     half_t* cur = r.H(M * C);
+    // with "ln_fold" the GEMMs that write a LayerNorm's input also leave its row sums (Run::lnp_want; a no-op otherwise)
+    const bool fold_any = e->ln_fold && !hn_has_dim(e, C) && !e->force_generic && e->use_glds && g_vt_mode == 1 && HW == Npad && HW % 4 == 0;
+    r.lnp_want = fold_any;
     TRY(run_linear(r, st.proj_in, n0, (int)M, nullptr, cur, C));
     int bi = 0;
     for (const TBlockW& b : st.blocks) {
         const std::string bname = name + ".transformer_blocks." + std::to_string(bi++);
         // --- self attention
-        half_t* n1 = r.H(M * C);
-        TRY(run_ln(r, b.ln1, cur, M, n1));
+        // option "ln_fold": the three LayerNorms are finished inside the GEMMs that read them (folded weights + per-row statistics):
+        // not with hypernetworks (they transform the normalised tokens) nor while block outputs are being tapped or cross-checked
+        // on the generic kernels, and only when V^T takes the token-major transposed form (run_vt)
+        const bool fold = fold_any;
         half_t* a1 = nullptr;
-        if (!hn_has_dim(e, C)) {
+        if (fold) {
+            LnStats st1;
+            TRY(run_ln_stats(r, b.ln1, cur, M, &st1));
+            half_t* qk = r.H(M * 2 * C);
+            TRY(run_linear_ln(r, b.qk1, b.ln1, cur, st1, (int)M, qk, 2 * C));
+            half_t* vt = r.H((size_t)B * C * Npad);
+            TRY(run_vt_ln(r, b.v1, b.ln1, cur, st1, B, HW, Npad, vt));
+            a1 = r.H(M * C);
+            TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
+        }
+        half_t* n1 = fold ? nullptr : r.H(M * C);
+        if (!fold) TRY(run_ln(r, b.ln1, cur, M, n1));
+        if (fold) {
+        } else if (!hn_has_dim(e, C)) {
             half_t* qk = r.H(M * 2 * C);
             TRY(run_linear(r, b.qk1, n1, (int)M, nullptr, qk, 2 * C));
             half_t* vt = r.H((size_t)B * C * Npad);
@@ -612,13 +717,22 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(run_attn(r, q, k, vt, a1, B, st.heads, HW, HW, st.dhead, C, C, Npad, C));
         }
         half_t* x1 = r.H(M * C);
+        r.lnp_want = fold;
         TRY(run_linear(r, b.o1, a1, (int)M, cur, x1, C));
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
-        half_t* n2 = r.H(M * C);
-        TRY(run_ln(r, b.ln2, x1, M, n2));
-        half_t* q2 = r.H(M * C);
-        TRY(run_linear(r, b.q2, n2, (int)M, nullptr, q2, C));
+        half_t* q2 = nullptr;
+        if (fold) {
+            LnStats st2;
+            TRY(run_ln_stats(r, b.ln2, x1, M, &st2));
+            q2 = r.H(M * C);
+            TRY(run_linear_ln(r, b.q2, b.ln2, x1, st2, (int)M, q2, C));
+        } else {
+            half_t* n2 = r.H(M * C);
+            TRY(run_ln(r, b.ln2, x1, M, n2));
+            q2 = r.H(M * C);
+            TRY(run_linear(r, b.q2, n2, (int)M, nullptr, q2, C));
+        }
         half_t* a2 = r.H(M * C);
         if (!r.dry) {
             SDMI_REQUIRE(e->ctx_valid && e->ctx_B == B, "context not set for this batch size");
@@ -633,14 +747,24 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(launch_attention(p, e->force_generic, r.s));
         }
         half_t* x2 = r.H(M * C);
+        r.lnp_want = fold;
         TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C));
         r.tap(bname + ".attn2+x", x2, B, H, Wd, C);
         // --- feed forward (GEGLU fused in the first GEMM's epilogue)
-        half_t* n3 = r.H(M * C);
-        TRY(run_ln(r, b.ln3, x2, M, n3));
-        half_t* g = r.H(M * 4 * C);
-        TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
+        half_t* g = nullptr;
+        if (fold) {
+            LnStats st3;
+            TRY(run_ln_stats(r, b.ln3, x2, M, &st3));
+            g = r.H(M * 4 * C);
+            TRY(run_linear_ln(r, b.ff1, b.ln3, x2, st3, (int)M, g, 4 * C));
+        } else {
+            half_t* n3 = r.H(M * C);
+            TRY(run_ln(r, b.ln3, x2, M, n3));
+            g = r.H(M * 4 * C);
+            TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
+        }
         half_t* x3 = r.H(M * C);
+        r.lnp_want = fold;                                   // read by the next block's norm1 (SDXL: depth > 1); unused after the last
         TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
         r.tap(bname, x3, B, H, Wd, C);
         cur = x3;
@@ -1428,6 +1552,7 @@ int engine_unet_update_weight(sdmi_engine* e, const char* key, const void* data,
     SDMI_CHECK_HIP(hipDeviceSynchronize());
     if (tmp) (void)hipFree(tmp);
     e->ctx_valid = false;                                     // cached K / V^T depend on attn2.to_k / to_v
+    ++e->weights_epoch;                                       // LayerNorm-folded copies of this weight are stale
     return rc;
 }
 // ---- hypernetwork hand-over ------------------------------------------------------------------------------------------------
@@ -1526,6 +1651,7 @@ int engine_unet_update_vector(sdmi_engine* e, const char* key, const void* data,
     }
     SDMI_CHECK_HIP(hipDeviceSynchronize());
     if (tmp) (void)hipFree(tmp);
+    ++e->weights_epoch;                                       // a LayerNorm gain / shift or a folded bias may have changed
     return rc;
 }
 int engine_vae_finalize(sdmi_engine* e) {

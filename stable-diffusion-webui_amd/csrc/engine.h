@@ -25,6 +25,13 @@ struct ConvW {
     float* b = nullptr;
     int cin = 0, cin_pad = 0, cout = 0, n_pad = 0, taps = 1;
     bool geglu = false;
+    // LayerNorm folded into this layer (engine option "ln_fold"; GemmP::ln_stats): w_ln = fp16(w * gamma), s_ln[n] = sum_k w_ln[n][k],
+    // c_ln = beta . w^T + b.  Built lazily by ensure_ln_fold, rebuilt when fold_epoch falls behind the engine's weights_epoch (any
+    // sdmi_unet_update_weight / _vector).  mutable: the packed model is const during a forward, the cache is not part of it.
+    mutable half_t* w_ln = nullptr;
+    mutable float* s_ln = nullptr;
+    mutable float* c_ln = nullptr;
+    mutable long fold_epoch = -1;
 };
 struct NormW {
     float* g = nullptr;
@@ -182,6 +189,10 @@ struct sdmi_engine {
     // range-extended VAE decode (the engine's form of the reference's fp16 -> fp32 VAE fallback, modules/processing.py:636-665): the
     // decoder's residual stream is stored at this scale (1/64 when on), every GroupNorm that reads it uses eps * scale^2
     float vae_stream_scale = 1.f;
+    // LayerNorm folded into the consuming GEMMs of the transformer blocks (norm1 -> to_q|to_k, to_v; norm2 -> attn2.to_q; norm3 ->
+    // ff.net.0): only the per-row (mean, rstd) are computed, the normalised tensors never reach HBM.  Off by default until measured.
+    bool ln_fold = false;
+    long weights_epoch = 0;                   // bumped by every in-place weight / vector update: folded copies older than this are stale
     bool tiling = false;                      // p.tiling: every padded 3x3 conv wraps around (modules/sd_hijack.py:311-318)
     // activation taps (parity error budget): with `trace` on, every block output of the last forward is recorded by name
     // — the arena never reuses memory within a forward, so the tensors stay readable until the next forward

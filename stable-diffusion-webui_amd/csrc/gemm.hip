@@ -85,9 +85,26 @@ __device__ __forceinline__ h8 join8(h4 lo, h4 hi) { return h8{lo[0], lo[1], lo[2
 
 // Epilogue shared by the GEMM kernels.  Lane holds, for accumulator tile (i, j):
 //   m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive channels)
-template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false>
+typedef float f2e __attribute__((ext_vector_type(2)));
+// LNF (EP_LNFOLD launches): finish a LayerNorm whose affine part is folded into the weights — v = rstd[m] * (v - mean[m] * s[n]) on the
+// alpha-scaled accumulator, before the (folded) bias is added (GemmP::ln_stats).
+template <int TM, int TN, int WTM, int WTN, bool GEGLU, bool TR = false, int WR_ = 1, int BN_ = 64, bool STATS = false, int LNM = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z,
                                               char* smem = nullptr) {
+    constexpr bool LNF = LNM == 1;       // LayerNorm consumer (EP_LNFOLD)
+    constexpr bool LNS = LNM == 2;       // LayerNorm producer: per-row partial sums of the output (GemmP::lnp_out)
+    static_assert(!(STATS && LNM != 0), "the GroupNorm-statistics epilogue neither follows nor feeds a LayerNorm");
+    static_assert(!(LNS && (GEGLU || TR)), "row partial sums are taken by the plain epilogue only");
+    [[maybe_unused]] const f2e* lnst = reinterpret_cast<const f2e*>(p.ln_stats);
+    // (mean, rstd) of input row m: stored as such, or finished here from the producer's per-tile partial sums (fixed order)
+    [[maybe_unused]] auto row_stat = [&](int m) -> f2e {
+        if (p.ln_np == 0) return lnst[m];
+        const float* pp = p.ln_stats + (long)m * p.ln_np * 2;
+        float sm = 0.f, q = 0.f;
+        for (int t = 0; t < p.ln_np; ++t) { sm += pp[2 * t]; q += pp[2 * t + 1]; }
+        const float mean = sm * p.ln_inv_c;
+        return f2e{mean, rsqrtf(fmaxf(fmaf(-mean, mean, q * p.ln_inv_c), 0.f) + p.ln_eps)};
+    };
     if constexpr (TR) {
         // transposed store (EP_TRANSPOSE): the MFMAs ran with swapped operand roles, so for tile (i, j) the lane holds
         //   n = n0 + wc*WTN + j*16 + (lane & 15),  m = m0 + wr*WTM + i*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive tokens)
@@ -102,15 +119,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                     const int m = m0 + wr * WTM + (2 * a + sel) * 16 + tw;
                     const int b = min(m, p.M - 1) / p.rows_per_batch;
                     const int ml = m - b * p.rows_per_batch;
+                    f2e stx[LNF ? 4 : 1], sty[LNF ? 4 : 1];      // (mean, rstd) of the 4 + 4 tokens this lane holds before the exchange
+                    if constexpr (LNF) {
+                        const int tx = m0 + wr * WTM + 2 * a * 16 + (lane >> 4) * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { stx[r] = row_stat(min(tx + r, p.M - 1)); sty[r] = row_stat(min(tx + 16 + r, p.M - 1)); }
+                    }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int n = n0 + wc * WTN + j * 16 + (lane & 15);
                         const float bb = p.bias ? p.bias[n] * p.bias_scale : 0.f;
                         h4 ox, oy;
+                        if constexpr (LNF) {
+                            const float sn = p.ln_s[n];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                ox[r] = (half_t)(stx[r][1] * (acc[2 * a][j][r] * p.alpha - stx[r][0] * sn) + bb);
+                                oy[r] = (half_t)(sty[r][1] * (acc[2 * a + 1][j][r] * p.alpha - sty[r][0] * sn) + bb);
+                            }
+                        } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             ox[r] = (half_t)fmaf(acc[2 * a][j][r], p.alpha, bb);
                             oy[r] = (half_t)fmaf(acc[2 * a + 1][j][r], p.alpha, bb);
+                        }
                         }
                         swap16(ox, oy);
                         if (m < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + ((long)b * p.N + n) * p.ldo + ml) = join8(ox, oy);
@@ -125,13 +157,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             if (m >= p.M) continue;
             const int b = m / p.rows_per_batch;
             const int ml = m - b * p.rows_per_batch;
+            f2e stn[LNF ? 4 : 1];
+            if constexpr (LNF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stn[r] = row_stat(min(m + r, p.M - 1));
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wc * WTN + j * 16 + (lane & 15);
                 const float bb = p.bias ? p.bias[n] * p.bias_scale : 0.f;
                 h4 o;
+                if constexpr (LNF) {
+                    const float sn = p.ln_s[n];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (half_t)(stn[r][1] * (acc[i][j][r] * p.alpha - stn[r][0] * sn) + bb);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)fmaf(acc[i][j][r], p.alpha, bb);
+                }
                 *reinterpret_cast<h4*>((half_t*)p.out + ob + ((long)b * p.N + n) * p.ldo + ml) = o;
             }
         }
@@ -318,12 +361,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                     bg = *reinterpret_cast<const f4*>(p.bias + npk + 32);
                                 }
                                 h4 o[2];
+                                [[maybe_unused]] f4 sva, svg;
+                                if constexpr (LNF) {
+                                    sva = *reinterpret_cast<const f4*>(p.ln_s + npk);
+                                    svg = *reinterpret_cast<const f4*>(p.ln_s + npk + 32);
+                                }
 #pragma unroll
                                 for (int t = 0; t < 2; ++t) {
                                     const f4 va = acc[2 * a + t][jg * 4 + j], vg = acc[2 * a + t][jg * 4 + j + 2];
+                                    [[maybe_unused]] f2e st;
+                                    if constexpr (LNF) st = row_stat(min(m0 + wr * WTM + (2 * a + t) * 16 + lr, p.M - 1));
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
-                                        const float av = fmaf(va[r], p.alpha, ba[r]), g = fmaf(vg[r], p.alpha, bg[r]);
+                                        float av, g;
+                                        if constexpr (LNF) {
+                                            av = st[1] * (va[r] * p.alpha - st[0] * sva[r]) + ba[r];
+                                            g = st[1] * (vg[r] * p.alpha - st[0] * svg[r]) + bg[r];
+                                        } else {
+                                            av = fmaf(va[r], p.alpha, ba[r]); g = fmaf(vg[r], p.alpha, bg[r]);
+                                        }
                                         o[t][r] = (half_t)(av * gelu_erf(g));
                                     }
                                 }
@@ -335,16 +391,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 }
                 return;
             } else {
-                constexpr bool PIPEW = TN <= 5;
+                constexpr bool PIPEW = TN <= 5 && !LNF;             // (LayerNorm-folded layers never carry a residual: no ring registers)
                 const bool colb = p.bias && !(flags & EP_BIAS_ROW);
-                f4 bcw[PIPEW ? TN : 1];
-                if constexpr (PIPEW) {
+                constexpr bool HOISTB = PIPEW && !LNS;               // (the row-sum variant needs the 20 registers of the hoisted bias)
+                f4 bcw[HOISTB ? TN : 1];
+                if constexpr (HOISTB) {
                     if (colb) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) bcw[j] = *reinterpret_cast<const f4*>(p.bias + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
                     }
                 }
-                h8 rw[2][PIPEW ? TN : 1];
+                // (row-sum variant on the 5-column-tile wave tiles: a one-deep ring — the pair a+1 residual is requested once pair a's
+                // accumulators are dead, or the 256x320 instantiation spills; the other variants prefetch one pair ahead)
+                constexpr int RWD = (LNS && TN > 4) ? 1 : 2;
+                h8 rw[RWD][PIPEW ? TN : 1];
                 auto prefetch_w = [&](int a, int slot) {
                     if (!PIPEW || !p.resid) return;
                     const int m = min(mw + a * 32, p.M - 1);
@@ -353,10 +413,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         rw[slot][j] = *reinterpret_cast<const h8*>(p.resid + rbs + (long)m * p.ldr + n0 + wc * WTN + j * 16 + nw);
                 };
                 if constexpr (PIPEW) prefetch_w(0, 0);
+                // LNS: per-row (sum, sum of squares) of the fp16-rounded outputs over this tile's columns, for the LayerNorm that
+                // reads this tensor: lane -> 16-lane-stride shuffles (the 4 lanes of a row) -> LDS [wave column][row] -> one thread
+                // per row adds the wave columns in a fixed order.  Deterministic.
+                constexpr int BMt = WR_ * WTM, WCn = BN_ / WTN;
+                [[maybe_unused]] float* red = reinterpret_cast<float*>(smem);
+                if constexpr (LNS) __syncthreads();                   // every wave is done reading the operand tiles that lived here
 #pragma unroll
                 for (int a = 0; a < TM / 2; ++a) {
+                    [[maybe_unused]] float lsx = 0.f, lqx = 0.f, lsy = 0.f, lqy = 0.f;
                     if constexpr (PIPEW) {
-                        if (a + 1 < TM / 2) prefetch_w(a + 1, (a + 1) & 1);
+                        if (RWD == 2 && a + 1 < TM / 2) prefetch_w(a + 1, (a + 1) & 1);
                     }
                     const int ms = mw + a * 32;
                     const int mx = min(m0 + wr * WTM + 2 * a * 16 + lr, p.M - 1), my = min(m0 + wr * WTM + (2 * a + 1) * 16 + lr, p.M - 1);
@@ -367,6 +434,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         f4 vx = acc[2 * a][j], vy = acc[2 * a + 1][j];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { vx[r] *= p.alpha; vy[r] *= p.alpha; }
+                        if constexpr (LNF) {
+                            const f2e sx = row_stat(mx), sy = row_stat(my);
+                            const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { vx[r] = sx[1] * (vx[r] - sx[0] * sv[r]); vy[r] = sy[1] * (vy[r] - sy[0] * sv[r]); }
+                        }
                         if (p.bias) {
                             if (flags & EP_BIAS_ROW) {
                                 const float b0 = p.bias[mx], b1 = p.bias[my];
@@ -374,7 +447,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                 for (int r = 0; r < 4; ++r) { vx[r] += b0; vy[r] += b1; }
                             } else {
                                 f4 bb;
-                                if constexpr (PIPEW) bb = bcw[j];
+                                if constexpr (HOISTB) bb = bcw[j];
                                 else bb = *reinterpret_cast<const f4*>(p.bias + n);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { vx[r] = fmaf(bb[r], p.bias_scale, vx[r]); vy[r] = fmaf(bb[r], p.bias_scale, vy[r]); }
@@ -391,9 +464,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                 vy[r] = (flags & EP_QUICK_GELU) ? vy[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * vy[r])) : gelu_erf(vy[r]);
                             }
                         }
-                        if (p.resid) {
+                        if (!LNF && p.resid) {
                             h8 rr;
-                            if constexpr (PIPEW) rr = rw[a & 1][j];
+                            if constexpr (PIPEW) rr = rw[a & (RWD - 1)][j];
                             else rr = *reinterpret_cast<const h8*>(p.resid + rbs + (long)min(ms, p.M - 1) * p.ldr + n0 + wc * WTN + j * 16 + nw);
                             h4 rx = {rr[0], rr[1], rr[2], rr[3]}, ry = {rr[4], rr[5], rr[6], rr[7]};
                             swap16(rx, ry);
@@ -403,15 +476,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         h4 ox, oy;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { ox[r] = (half_t)vx[r]; oy[r] = (half_t)vy[r]; }
+                        if constexpr (LNS) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float fx = (float)ox[r], fy = (float)oy[r];
+                                lsx += fx; lqx = fmaf(fx, fx, lqx); lsy += fy; lqy = fmaf(fy, fy, lqy);
+                            }
+                        }
                         swap16(ox, oy);
                         if (ms < p.M) *reinterpret_cast<h8*>((half_t*)p.out + ob + (long)ms * p.ldo + n0 + wc * WTN + j * 16 + nw) = join8(ox, oy);
+                    }
+                    if constexpr (PIPEW && RWD == 1) {
+                        if (a + 1 < TM / 2) prefetch_w(a + 1, 0);
+                    }
+                    if constexpr (LNS) {
+                        lsx += __shfl_xor(lsx, 16); lqx += __shfl_xor(lqx, 16); lsy += __shfl_xor(lsy, 16); lqy += __shfl_xor(lqy, 16);
+                        lsx += __shfl_xor(lsx, 32); lqx += __shfl_xor(lqx, 32); lsy += __shfl_xor(lsy, 32); lqy += __shfl_xor(lqy, 32);
+                        if ((lane >> 4) == 0) {
+                            const int rx = wr * WTM + 2 * a * 16 + lr;
+                            float* d = red + ((long)wc * BMt + rx) * 2;
+                            d[0] = lsx; d[1] = lqx; d[32] = lsy; d[33] = lqy;          // row rx + 16
+                        }
+                    }
+                }
+                if constexpr (LNS) {
+                    __syncthreads();
+                    const int tid = threadIdx.x;
+                    if (tid < BMt && m0 + tid < p.M) {
+                        float sm = 0.f, q = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WCn; ++w) { sm += red[((long)w * BMt + tid) * 2]; q += red[((long)w * BMt + tid) * 2 + 1]; }
+                        float* dst = p.lnp_out + ((long)(m0 + tid) * p.lnp_np + n0 / BN_) * 2;
+                        dst[0] = sm; dst[1] = q;
                     }
                 }
                 return;
             }
         }
     }
-    constexpr bool PIPE = !GEGLU && TN <= 5;
+    constexpr bool PIPE = !GEGLU && TN <= 5 && !LNF;
     const bool col_bias = p.bias && !(flags & EP_BIAS_ROW);
     f4 bcol[PIPE ? TN : 1];
     if constexpr (PIPE) {
@@ -454,10 +557,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                             bg = *reinterpret_cast<const f4*>(p.bias + npk + 32);
                         }
                         h4 o;
+                        if constexpr (LNF) {
+                            const f2e st = row_stat(m);
+                            const f4 sva = *reinterpret_cast<const f4*>(p.ln_s + npk), svg = *reinterpret_cast<const f4*>(p.ln_s + npk + 32);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float a = st[1] * (va[r] * p.alpha - st[0] * sva[r]) + ba[r];
+                                const float g = st[1] * (vg[r] * p.alpha - st[0] * svg[r]) + bg[r];
+                                o[r] = (half_t)(a * gelu_erf(g));
+                            }
+                        } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float a = fmaf(va[r], p.alpha, ba[r]), g = fmaf(vg[r], p.alpha, bg[r]);
                             o[r] = (half_t)(a * gelu_erf(g));
+                        }
                         }
                         *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
                     }
@@ -471,6 +585,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             f4 v = acc[i][j];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if constexpr (LNF) {
+                const f2e st = row_stat(m);
+                const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = st[1] * (v[r] - st[0] * sv[r]);
+            }
             if (p.bias) {
                 if (flags & EP_BIAS_ROW) {
                     const float bb = p.bias[m];
@@ -490,7 +610,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 for (int r = 0; r < 4; ++r)
                     v[r] = (flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
             }
-            if (p.resid) {
+            if (!LNF && p.resid) {
                 h4 rr;
                 if constexpr (PIPE) rr = rres[i & 1][j];
                 else rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
@@ -524,7 +644,7 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
@@ -708,7 +828,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS, LNM>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 template <int N>
@@ -748,7 +868,7 @@ __device__ __forceinline__ long long stamp() {           // s_memtime; callers s
     return t;
 }
 
-template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, bool GEGLU, bool TIMING = false, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int BK = 64, WC = 4, ROWB = 128;
@@ -1116,7 +1236,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
             for (int i = 0; i < 17; ++i) d[i] = tm[i];
         }
     }
-    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
+    gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, 2, BN, STATS, LNM>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1204,58 +1324,79 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
 }
 
 // Split-K second pass: out = epilogue(sum over slices, in slice order => bit-reproducible).  One thread per 4 columns.
+template <bool LNF = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) {
     if (p.gate && *p.gate == 0) return;
-    const long quads = (long)p.M * (p.N / 4);
-    const long total = quads * batch;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int z = (int)(idx / quads);
-        const long q = idx - (long)z * quads;
-        const int m = (int)(q / (p.N / 4)), n = (int)(q - (long)m * (p.N / 4)) * 4;
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.splitk; ++s)
-            v += *reinterpret_cast<const f4*>(p.splitk_ws + ((long)s * batch + z) * (long)p.M * p.N + (long)m * p.N + n);
-        const int b = m / p.rows_per_batch;
+    // (row, column-quad) pairs walked by the grid stride's quotient / remainder: no 64-bit division per element (static ISA review,
+    // DESIGN.md section 9)
+    const int NQ = p.N / 4;
+    const int stride = (int)gridDim.x * 256;                 // M * N / 4 < 2^31: split-K is admitted for the small-M layers only
+    const int sp = stride / NQ, sr = stride - sp * NQ;
+    const int i_init = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    for (int z = 0; z < batch; ++z) {
+        int m = i_init / NQ, nq = i_init - m * NQ;
+        for (; m < p.M; m += sp, nq += sr) {
+            if (nq >= NQ) { nq -= NQ; if (++m >= p.M) break; }
+            const int n = nq * 4;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.splitk; ++s)
+                v += *reinterpret_cast<const f4*>(p.splitk_ws + ((long)s * batch + z) * (long)p.M * p.N + (long)m * p.N + n);
+            const int b = m / p.rows_per_batch;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-        if (p.bias) {
-            if (p.flags & EP_BIAS_ROW) {
-                const float bb = p.bias[m];
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if constexpr (LNF) {
+                float mean, rstd;
+                if (p.ln_np == 0) { mean = p.ln_stats[2 * m]; rstd = p.ln_stats[2 * m + 1]; }
+                else {
+                    const float* pp = p.ln_stats + (long)m * p.ln_np * 2;
+                    float sm = 0.f, q = 0.f;
+                    for (int t = 0; t < p.ln_np; ++t) { sm += pp[2 * t]; q += pp[2 * t + 1]; }
+                    mean = sm * p.ln_inv_c;
+                    rstd = rsqrtf(fmaxf(fmaf(-mean, mean, q * p.ln_inv_c), 0.f) + p.ln_eps);
+                }
+                const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bb;
-            } else {
-                const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(bb[r], p.bias_scale, v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * sv[r]);
             }
-        }
-        if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
-        if (p.flags & (EP_QUICK_GELU | EP_GELU)) {
+            if (p.bias) {
+                if (p.flags & EP_BIAS_ROW) {
+                    const float bb = p.bias[m];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                v[r] = (p.flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
-        }
-        if (p.resid) {
-            const h4 rr = *reinterpret_cast<const h4*>(p.resid + z * p.r_bs + (long)m * p.ldr + n);
+                    for (int r = 0; r < 4; ++r) v[r] += bb;
+                } else {
+                    const f4 bb = *reinterpret_cast<const f4*>(p.bias + n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-        }
-        if (p.flags & EP_OUT_F32) {
-            *reinterpret_cast<f4*>((float*)p.out + z * p.o_bs + (long)m * p.ldo + n) = v;
-        } else {
-            h4 o;
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(bb[r], p.bias_scale, v[r]);
+                }
+            }
+            if (p.rowbias) v += *reinterpret_cast<const f4*>(p.rowbias + (long)b * p.ldrb + n);
+            if (p.flags & (EP_QUICK_GELU | EP_GELU)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-            *reinterpret_cast<h4*>((half_t*)p.out + z * p.o_bs + (long)m * p.ldo + n) = o;
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (p.flags & EP_QUICK_GELU) ? v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[r])) : gelu_erf(v[r]);
+            }
+            if (p.resid) {
+                const h4 rr = *reinterpret_cast<const h4*>(p.resid + z * p.r_bs + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (p.flags & EP_OUT_F32) {
+                *reinterpret_cast<f4*>((float*)p.out + z * p.o_bs + (long)m * p.ldo + n) = v;
+            } else {
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                *reinterpret_cast<h4*>((half_t*)p.out + z * p.o_bs + (long)m * p.ldo + n) = o;
+            }
         }
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1267,10 +1408,10 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false>
+template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
-    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS>;
+    auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS, LNM>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1297,6 +1438,14 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
         SDMI_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    if (p.flags & EP_LNFOLD) {                             // LayerNorm folded into this GEMM
+        if constexpr ((BN / 4) % 64 == 0) {
+            if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true, false, false, false, 1>(p, batch, s);
+        }
+        if (p.flags & EP_TRANSPOSE) return launch_pingpong2<BM, BN, false, true, false, false, 1>(p, batch, s);
+        return launch_pingpong2<BM, BN, false, false, false, false, 1>(p, batch, s);
+    }
+    if (p.lnp_np > 0) return launch_pingpong2<BM, BN, false, false, false, false, 2>(p, batch, s);
     if constexpr ((BN / 4) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_pingpong2<BM, BN, true>(p, batch, s);
     }
@@ -1310,6 +1459,19 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
 
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
+    if constexpr (BM >= 256) {                             // the two-stage 256-row tiles (the ping-pong kernel's fallback) carry no LayerNorm forms
+        if (p.flags & EP_LNFOLD) { set_error("EP_LNFOLD on a 256-row tile needs the ping-pong kernel (gemm_pipe 3 / 4)"); return 1; }
+    }
+    if constexpr (GLDS && BM < 256) {                      // LayerNorm folded into this GEMM (LDS-direct path only; launch_gemm checks)
+        if (p.flags & EP_LNFOLD) {
+            if constexpr ((BN / WC) % 64 == 0) {
+                if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true, false, false, false, 1>(p, batch, s);
+            }
+            if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, true, false, false, 1>(p, batch, s);
+            return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, false, false, 1>(p, batch, s);
+        }
+        if (p.lnp_np > 0) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false, false, false, false, 2>(p, batch, s);
+    }
     if constexpr ((BN / WC) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, GLDS, true>(p, batch, s);
     }
@@ -1383,8 +1545,10 @@ int g_gemm_pipe = g_gemm_pipe_default;
 static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg < 0 || cfg >= CFG_COUNT) return false;
     if (p.N % kCfgBN[cfg]) return false;
-    if (cfg == CFG_256x64 || cfg == CFG_256x128) return false;         // measured never best: not instantiated
-    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160)) return false;   // wave tile not a multiple of 64
+    if (cfg == CFG_256x64) return false;                               // measured never best: not instantiated
+    // 256x128: not in pick_cfg's candidate list (the two-stage form was never best in round 1); instantiated for the ping-pong kernel
+    // so that the shape tuner / gemm_cfg=6 can try it on the N = 128 VAE convs (now 128x128 two-stage at ~750 TFLOP/s)
+    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_256x128)) return false;   // wave tile not a multiple of 64
     return true;
 }
 
@@ -1493,10 +1657,12 @@ size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch) {
     return (size_t)8 * M * N * batch * sizeof(float);
 }
 
-int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out) {
+int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out, int* lnp_np_out) {
     GemmP p = p_in;
     p.stats_nchunk = 0;
+    p.lnp_np = 0;
     if (stats_nchunk_out) *stats_nchunk_out = 0;
+    if (lnp_np_out) *lnp_np_out = 0;
     p.flags |= g_gemm_dbgflags;
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     if (p.bias_scale == 0.f) p.bias_scale = 1.f;
@@ -1509,6 +1675,11 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     const double pf_flops = 2.0 * p.M * (double)p.N * p.K * batch;
     const double pf_in = (p.taps == 9 ? (double)p.M / (p.stride * p.stride) * (p.up ? 0.25 : 1.0) : (double)p.M) * p.cin * 2.0;
     const double pf_bytes = (pf_in + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.flags & EP_OUT_F32) ? 4.0 : 2.0)) * batch;
+    if (p.flags & EP_LNFOLD) {
+        SDMI_REQUIRE(p.ln_stats && p.ln_s && p.taps == 1 && !p.a1 && !p.stats_out && !(p.flags & (EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW)),
+                     "EP_LNFOLD: 1x1 / linear layers with fp16 row-major (or transposed) output only");
+        SDMI_REQUIRE(!force_generic && use_glds && gemm_mfma_supported(p), "EP_LNFOLD runs on the LDS-direct MFMA kernels only");
+    }
     if (force_generic || !gemm_mfma_supported(p)) {
         const bool geglu = p.flags & EP_GEGLU;
         const long total = (long)p.M * (geglu ? p.N / 2 : p.N);
@@ -1534,7 +1705,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     const int cfg = pick_cfg(p, batch, &split, can_split);
     // ping-pong kernel: every weight row must exist (no n_valid masking) and a (tap, source) segment must fit the zero page
     const bool phase = use_glds && (g_gemm_pipe == 3 || g_gemm_pipe == 4) &&
-                       (cfg == CFG_256x320 || cfg == CFG_256x256 || (cfg == CFG_128x320 && g_gemm_pipe == 4)) && p.n_valid == p.N &&
+                       (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_256x128 || (cfg == CFG_128x320 && g_gemm_pipe == 4)) && p.n_valid == p.N &&
                        p.cin + 64 <= kZeroPageHalfs &&
                        ((p.taps == 1 && p.stride == 1 && !p.up && p.Ho == p.Hi && p.Wo == p.Wi) ||
                         (p.M / p.rows_per_batch < 128 && (p.up ? 2 : 1) * p.Hi < 2040 && (p.up ? 2 : 1) * p.Wi < 2040 &&
@@ -1572,19 +1743,29 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
             if (stats_nchunk_out) *stats_nchunk_out = p.stats_nchunk;
         }
     }
+    // LayerNorm row partials from this launch's epilogue (GemmP::lnp_out): the 16-byte plain epilogue of an unsplit fp16 launch only
+    if (p.lnp_out && use_glds && split <= 1 && batch == 1 && p.stats_nchunk == 0 &&
+        !(p.flags & (EP_NARROW | EP_GEGLU | EP_TRANSPOSE | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW | EP_QUICK_GELU | EP_GELU | EP_LNFOLD)) &&
+        kCfgBM[cfg] % 32 == 0 && cfg != CFG_64x64 && (phase || kCfgBM[cfg] < 256)) {   // (64x64: one 16-row tile per wave, no row-tile
+                                                                                         // pairs; two-stage 256-row tiles: not instantiated)
+        p.lnp_np = p.N / kCfgBN[cfg];
+        if (lnp_np_out) *lnp_np_out = p.lnp_np;
+    }
     std::string pname;
     if (prof_enabled()) {
         pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
                 ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
-                (batch > 1 ? " x" + std::to_string(batch) : "");
+                ((p.flags & EP_LNFOLD) ? " ln" : "") + (batch > 1 ? " x" + std::to_string(batch) : "");
     }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);
     struct Reduce {     // second pass of split-K runs when the main kernel has been enqueued (scope exit of the switch)
         const GemmP& p; int batch; hipStream_t s; bool on;
         int run() const {
             if (!on) return 0;
-            const long total = (long)p.M * (p.N / 4) * batch;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, p, batch);
+            const long total = (long)p.M * (p.N / 4);      // per batch element: the kernel loops over the batch itself
+            const dim3 grid((unsigned)std::min<long>((total + 255) / 256, 8192));
+            if (p.flags & EP_LNFOLD) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, dim3(256), 0, s, p, batch);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, dim3(256), 0, s, p, batch);
             SDMI_CHECK_HIP(hipGetLastError());
             return 0;
         }
@@ -1599,6 +1780,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         switch (cfg) {
             case CFG_256x320: rc = launch_pingpong<256, 320>(p, batch, s); break;
             case CFG_256x256: rc = launch_pingpong<256, 256>(p, batch, s); break;
+            case CFG_256x128: rc = launch_pingpong<256, 128>(p, batch, s); break;
             case CFG_128x320: rc = launch_pingpong<128, 320>(p, batch, s); break;
             default: break;
         }
@@ -1610,6 +1792,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_CASE(CFG_64x64, 64, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x128_K32, 128, 128, 2, 2, 32)
         SDMI_CASE(CFG_256x256, 256, 256, 4, 2, 64)
+        SDMI_CASE(CFG_256x128, 256, 128, 4, 2, 64)
         SDMI_CASE(CFG_256x320, 256, 320, 4, 2, 64)
         SDMI_CASE(CFG_128x64, 128, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x320, 128, 320, 2, 4, 64)

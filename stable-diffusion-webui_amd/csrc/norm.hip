@@ -117,26 +117,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
         s_shift[c] = beta[c] - s_mean[g] * sc;
     }
     __syncthreads();
-    const long nvec = (long)HW * VP;
-    const long stride = (long)gridDim.x * 256;
-    for (long i0 = (long)blockIdx.x * 256 + tid; i0 < nvec; i0 += 2 * stride) {
+    // grid-stride walk over the (pixel, 8-channel vector) pairs of image b, two vectors per thread in flight.  The pair is advanced
+    // by the stride's quotient / remainder instead of dividing the linear index each time: the 64-bit divisions by the runtime VP
+    // were ~130 of the loop's 330 VALU instructions (23 of them quarter-rate multiplies) — static ISA review, DESIGN.md section 9.
+    const int stride = (int)gridDim.x * 256;                       // HW * C < 2^31, HW < 2^24 (launch_groupnorm)
+    const int sp = stride / VP, sr = stride - sp * VP;
+    const int sp2 = (2 * stride) / VP, sr2 = 2 * stride - sp2 * VP;
+    const int i_init = (int)blockIdx.x * 256 + tid;
+    int pix_u[2], cv_u[2];
+    unsigned iv[2] = {(unsigned)i_init, (unsigned)(i_init + stride)};      // linear vector index: the output offset is iv * 8
+    pix_u[0] = i_init / VP; cv_u[0] = i_init - pix_u[0] * VP;
+    pix_u[1] = pix_u[0] + sp; cv_u[1] = cv_u[0] + sr;
+    if (cv_u[1] >= VP) { cv_u[1] -= VP; ++pix_u[1]; }
+    const half_t* x0b = x0 + (long)b * HW * c0;
+    const half_t* x1b = x1 ? x1 + (long)b * HW * c1 : nullptr;
+    half_t* outb = out + (long)b * HW * C;
+    while (pix_u[0] < HW) {
         h8 v[2];
         int cs[2];
-        long po[2];
         bool ok[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const long i = i0 + u * stride;
-            ok[u] = i < nvec;
-            const long ii = ok[u] ? i : 0;
-            const int pix = (int)(ii / VP), cv = (int)(ii - (long)pix * VP);
-            const int c = cv * 8;
+            ok[u] = pix_u[u] < HW;
+            const unsigned pix = ok[u] ? (unsigned)pix_u[u] : 0u;
+            const int c = (ok[u] ? cv_u[u] : 0) * 8;
             cs[u] = c;
-            po[u] = ((long)b * HW + pix) * C + c;
             const half_t* src;
-            int cc, ld;
-            if (c < c0) { src = x0; cc = c; ld = c0; } else { src = x1; cc = c - c0; ld = c1; }
-            v[u] = *reinterpret_cast<const h8*>(src + ((long)b * HW + pix) * ld + cc);
+            unsigned cc, ld;
+            if (c < c0) { src = x0b; cc = (unsigned)c; ld = (unsigned)c0; } else { src = x1b; cc = (unsigned)(c - c0); ld = (unsigned)c1; }
+            v[u] = *reinterpret_cast<const h8*>(src + (__umul24(pix, ld) + cc));
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -151,7 +160,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
                 if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
                 o[e] = (half_t)y;
             }
-            *reinterpret_cast<h8*>(out + po[u]) = o;
+            *reinterpret_cast<h8*>(outb + iv[u] * 8u) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            iv[u] += 2u * (unsigned)stride;
+            pix_u[u] += sp2; cv_u[u] += sr2;
+            if (cv_u[u] >= VP) { cv_u[u] -= VP; ++pix_u[u]; }
         }
     }
 }
@@ -173,6 +188,7 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     const int C = c0 + c1;
     SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
+    SDMI_REQUIRE((long)HW * C < (1L << 31) && HW < (1 << 24), "GroupNorm: HW * C must stay below 2^31 elements per image (32-bit offsets)");
     const int nchunk = pre_nchunk > 0 ? pre_nchunk : gn_chunks(B, HW);
     const int rows = cdiv(HW, nchunk);
     char pname[64];
@@ -268,6 +284,120 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const f
             }
         }
     }
+}
+
+// Row statistics only (LayerNorm folded into the consuming GEMMs, GemmP::ln_stats): the same two-pass arithmetic as
+// layernorm_kernel — mean, then the centred sum of squares, both from the fp16 values the GEMM will read — but nothing is written
+// back except (mean, rstd) per row.
+template <int K, int RPW>
+__global__ __launch_bounds__(256) void ln_rowstats_kernel(const half_t* x, float* stats, long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row0 = ((long)blockIdx.x * 4 + wave) * RPW;
+    if (row0 >= rows) return;
+    const int VP = C / 8;
+    const float inv_c = 1.0f / (float)C;
+    h8 v[RPW][K];
+    float sum[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const long row = min(row0 + r, rows - 1);
+        const half_t* src = x + row * C;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int cv = lane + k * 64;
+            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            v[r][k] = cv < VP ? *reinterpret_cast<const h8*>(src + cv * 8) : z;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += (float)v[r][k][e];
+        sum[r] = a;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) sum[r] += __shfl_xor(sum[r], off);
+    float mean[RPW], sq[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        mean[r] = sum[r] * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int cv = lane + k * 64;
+            if (cv < VP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[r][k][e] - mean[r]; q = fmaf(d, d, q); }
+            }
+        }
+        sq[r] = q;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) sq[r] += __shfl_xor(sq[r], off);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            if (row0 + r < rows) {
+                stats[(row0 + r) * 2 + 0] = mean[r];
+                stats[(row0 + r) * 2 + 1] = rsqrtf(fmaf(sq[r], inv_c, eps));
+            }
+    }
+}
+
+int launch_ln_rowstats(const half_t* x, float* stats, int64_t rows, int C, float eps, hipStream_t s) {
+    SDMI_REQUIRE(C % 8 == 0 && C <= 2048, "LayerNorm statistics: C % 8 == 0 and C <= 2048");
+    char pname[48];
+    snprintf(pname, sizeof pname, "ln_rowstats rows%ld C%d", (long)rows, C);
+    ProfScope ps(pname, 0.0, (double)rows * C * 2.0, s);
+    const int K = cdiv(C / 8, 64);
+#define SDMI_LNS(KK, RR)                                                                                             \
+    hipLaunchKernelGGL((ln_rowstats_kernel<KK, RR>), dim3(cdiv(rows, 4 * RR)), dim3(256), 0, s, x, stats, (long)rows, C, eps)
+    if (K == 1) SDMI_LNS(1, 4);
+    else if (K == 2) SDMI_LNS(2, 2);
+    else if (K == 3) SDMI_LNS(3, 1);
+    else SDMI_LNS(4, 1);
+#undef SDMI_LNS
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// One workgroup per packed weight row: fold gamma into the row, sum the folded (fp16-rounded) row and dot the original row with
+// beta.  Fixed reduction order (per-thread strided partials -> wave shuffles -> LDS -> thread 0): bit-reproducible.
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const half_t* w, const float* gamma, const float* beta, const float* bias,
+                                                              half_t* wf, float* s_out, float* c_out, int K, int C) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const half_t* src = w + (long)n * K;
+    half_t* dst = wf + (long)n * K;
+    float s = 0.f, c = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float wv = (float)src[k];
+        const float g = k < C ? gamma[k] : 0.f, bt = k < C ? beta[k] : 0.f;
+        const half_t f = (half_t)(wv * g);
+        dst[k] = f;
+        s += (float)f;
+        c = fmaf(bt, wv, c);
+    }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); c += __shfl_xor(c, off); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        s_out[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        c_out[n] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + (bias ? bias[n] : 0.f);
+    }
+}
+
+int launch_ln_fold_weights(const half_t* w, const float* gamma, const float* beta, const float* bias, half_t* wf, float* s_out,
+                           float* c_out, int n_rows, int K, int C, hipStream_t s) {
+    SDMI_REQUIRE(n_rows > 0 && K >= C && C > 0, "LayerNorm weight fold: bad shape");
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3(n_rows), dim3(256), 0, s, w, gamma, beta, bias, wf, s_out, c_out, K, C);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,

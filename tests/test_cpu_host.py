@@ -634,10 +634,12 @@ def test_kernels_compile_without_scratch_or_spills():
             # kernel-argument struct alone crowds the scalar file)
             # ... and in the GroupNorm-statistics instantiations of the ping-pong GEMM (last template flag), where a handful of
             # kernel-argument SGPRs are parked in VGPR lanes BEFORE the K loop and read back after it — checked below)
-            stats_pp = re.search(r"gemm_mfma_pingpong_kernelILi\d+ELi\d+E(Lb[01]E){4}Lb1EEEv", kname) is not None
+            stats_pp = re.search(r"gemm_mfma_pingpong_kernelILi\d+ELi\d+E(Lb[01]E){4}Lb1ELi0EEEv", kname) is not None
+            # ... and in the LayerNorm consumer / producer forms (last template argument 1 / 2), same rule: parked before the K loop
+            ln_pp = re.search(r"gemm_mfma_pingpong_kernelILi\d+ELi\d+E(Lb[01]E){5}Li[12]EEEv", kname) is not None
             assert field("vgpr_spill_count") == 0, f"{kname} spills registers"
-            assert field("sgpr_spill_count") == 0 or "generic" in kname or (stats_pp and field("sgpr_spill_count") <= 8), f"{kname} spills registers"
-            if stats_pp and field("sgpr_spill_count"):
+            assert field("sgpr_spill_count") == 0 or "generic" in kname or (stats_pp and field("sgpr_spill_count") <= 8) or (ln_pp and field("sgpr_spill_count") <= 24), f"{kname} spills registers"
+            if (stats_pp or ln_pp) and field("sgpr_spill_count"):
                 body = re.search(r"^%s:[^\n]*\n(.*?)\.Lfunc_end" % re.escape(kname), text, re.S | re.M).group(1)
                 loop = body[body.index("s_setprio 1"):body.rindex("s_setprio 0")]
                 assert "v_readlane" not in loop and "v_writelane" not in loop, f"{kname}: SGPR spill traffic inside the K loop"
@@ -657,7 +659,7 @@ def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):
     for bm, bn, waits, phases, kord, st in [(bm, bn, w, ph, k, st) for (bm, bn, w, ph) in ((256, 256, (8, 10), 4), (256, 320, (9, 11), 4), (128, 320, (7,), 2))
                                             for k in (0, 1) for st in (0, 1)]:  # k = 1: the channel-block-major instantiation the 3x3 convs run;
                                                                                 # st = 1: the GroupNorm-statistics epilogue variant
-        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELi%dELb0ELb0ELb0ELb%dELb%dEEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn, kord, st), text, re.S | re.M)
+        m = re.search(r"^_ZN4sdmi25gemm_mfma_pingpong_kernelILi%dELi%dELb0ELb0ELb0ELb%dELb%dELi0EEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn, kord, st), text, re.S | re.M)
         assert m, f"ping-pong kernel <{bm},{bn}> not found in the assembly"
         body = m.group(1)
         first, last = body.index("s_setprio 1"), body.rindex("s_setprio 0")

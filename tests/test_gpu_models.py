@@ -103,6 +103,25 @@ def test_unet_wide_and_8_byte_epilogues_give_the_same_bits(dev, tiny):
     assert torch.equal(a, b)
 
 
+@pytest.mark.skipif(os.environ.get("SDMI_EXPERIMENTAL") != "1", reason="LayerNorm fold is not validated on a GPU yet (next-round prep)")
+def test_unet_layernorm_folded_into_the_consuming_gemms(dev, tiny):
+    """Engine option "ln_fold": norm1 / norm2 / norm3 of every transformer block finished inside the q|k, V^T, attn2.to_q and GEGLU
+    GEMMs (folded weights + per-row statistics) against the separate LayerNorm kernel: the same function with one fp16 rounding of
+    the normalised tensor replaced by one of the folded weights; and the folded copies follow an in-place weight / norm update."""
+    eng = tiny["model"].engine
+    x, t, ctx = seeded((2, 4, 16, 16), 2).to(dev), torch.tensor([700.0, 20.0]).to(dev), tiny["cond"][:2].to(dev)
+    a = eng.unet_forward(x, t, ctx)
+    eng.set_option("ln_fold", 1)
+    try:
+        b = eng.unet_forward(x, t, ctx)
+        b2 = eng.unet_forward(x, t, ctx)
+    finally:
+        eng.set_option("ln_fold", 0)
+    print(f"[ln_fold] tiny UNet forward, folded vs separate LayerNorm: {rel_l2(b.cpu(), a.cpu()):.3e}")
+    assert torch.equal(b, b2)
+    assert rel_l2(b.cpu(), a.cpu()) < 3e-3
+
+
 def test_unet_batch_invariance_and_determinism(dev, tiny):
     eng = tiny["model"].engine
     x, t, ctx = seeded((4, 4, 16, 16), 3).to(dev), torch.tensor([300.0] * 4).to(dev), tiny["cond"].to(dev)
