@@ -69,7 +69,7 @@ def tiny_config(**kw) -> UNetConfig:
 def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
     """modules/sd_hijack_unet.py:58-78 (cos first, then sin; computed in fp32)."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=timesteps.device) / half)
     args = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
@@ -101,6 +101,10 @@ class ResBlock(nn.Module):
 
 
 LOADED_HYPERNETWORKS: list = []       # oracle.hypernetwork.Hypernetwork objects (shared.loaded_hypernetworks of the reference)
+# Rows of the score matrix evaluated at a time (None = all at once).  Softmax rows are independent, so the result is the one of the
+# unchunked product; the full-size fixtures (N = 16384 tokens at a 128x128 latent: 17 GB of fp32 scores per forward) are generated
+# with a bound — the same memory bound modules/sub_quadratic_attention.py:54-113 puts on the reference's own product.
+QUERY_CHUNK = None
 
 
 class CrossAttention(nn.Module):
@@ -128,9 +132,13 @@ class CrossAttention(nn.Module):
         b, n, _ = q.shape
         split = lambda t: t.reshape(b, t.shape[1], h, -1).permute(0, 2, 1, 3).reshape(b * h, t.shape[1], -1)
         q, k, v = split(q), split(k), split(v)
-        sim = torch.einsum('bid,bjd->bij', q, k) * self.scale
-        attn = sim.softmax(dim=-1)
-        out = torch.einsum('bij,bjd->bid', attn, v)
+        if QUERY_CHUNK and n > QUERY_CHUNK:
+            out = torch.cat([torch.einsum('bij,bjd->bid', (torch.einsum('bid,bjd->bij', q[:, i:i + QUERY_CHUNK], k) * self.scale).softmax(dim=-1), v)
+                             for i in range(0, n, QUERY_CHUNK)], dim=1)
+        else:
+            sim = torch.einsum('bid,bjd->bij', q, k) * self.scale
+            attn = sim.softmax(dim=-1)
+            out = torch.einsum('bij,bjd->bid', attn, v)
         out = out.reshape(b, h, n, -1).permute(0, 2, 1, 3).reshape(b, n, -1)
         return self.to_out(out)
 

@@ -42,6 +42,9 @@ def tiny_vae_config(**kw) -> VAEConfig:
     return VAEConfig(**base)
 
 
+QUERY_CHUNK = None                     # see oracle/unet.py
+
+
 def Normalize(c):
     return nn.GroupNorm(32, c, eps=1e-6, affine=True)   # sd3_impls.py:171-172
 
@@ -79,8 +82,14 @@ class AttnBlock(nn.Module):                              # sd3_impls.py:205-224;
         q, k, v = self.q(h), self.k(h), self.v(h)
         b, c, hh, ww = q.shape
         q, k, v = [t.reshape(b, c, hh * ww).permute(0, 2, 1) for t in (q, k, v)]
-        w = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (int(c) ** -0.5), dim=-1)
-        o = torch.bmm(w, v).permute(0, 2, 1).reshape(b, c, hh, ww)
+        n = q.shape[1]
+        if QUERY_CHUNK and n > QUERY_CHUNK:                  # row blocks of the same product (softmax rows are independent)
+            o = torch.cat([torch.bmm(torch.softmax(torch.bmm(q[:, i:i + QUERY_CHUNK], k.transpose(1, 2)) * (int(c) ** -0.5), dim=-1), v)
+                           for i in range(0, n, QUERY_CHUNK)], dim=1)
+        else:
+            w = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (int(c) ** -0.5), dim=-1)
+            o = torch.bmm(w, v)
+        o = o.permute(0, 2, 1).reshape(b, c, hh, ww)
         return x + self.proj_out(o)
 
 

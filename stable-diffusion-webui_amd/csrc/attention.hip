@@ -356,6 +356,377 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 18) ? 3 : (VAR == 5 || V
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Role-offset ("ping-pong") form of the flash kernel for long key sequences (round 3).
+//
+// Round 2's section timers (profiles/r02_attention_experiments.md) showed a wave-tile costing 921 SIMD cycles against 448 cycles of
+// MFMA issue and ~450 of VALU issue: with three independent workgroups per CU the MFMA and VALU phases of the resident waves
+// do not arrange themselves to coincide.  Here they are MADE to: 8 waves = two groups of 4 (one wave of each group per SIMD, as in
+// the ping-pong GEMM) run the same two-section program ONE SECTION APART,
+//     V(t): softmax of S(t) -> P(t) (VALU only), then the LDS reads of the MFMA operands of M(t)
+//     M(t): O += V^T(t) P^T(t)  and  S(t+1) = K(t+1) Q^T   (14 MFMAs of d = 40, four independent accumulator chains), the LDS
+//           writes of tile pair t+2 and the global loads of pair t+3 (register staged, two sections of flight time)
+// with one s_barrier per section boundary for all 8 waves: whenever one wave of a SIMD is in its MFMA section the other one is in
+// its VALU section.  The loop is software-pipelined by one tile (S(t+1) is issued before softmax(t+1) needs it), so the score tile
+// of a wave is live across one barrier only.  LDS holds three {V^T(u), K(u+1)} pairs: a pair is written two sections or more before
+// its first read and overwritten two sections or more after its last (schedule in the body).
+//
+// FOLD (head sizes with a spare contraction column, d = 40 -> 48): the softmax shift costs no VALU.  Q is multiplied by
+// scale * log2(e) when its fragments are loaded (one fp16 rounding of q * c instead of q), K's padding column holds 1.0 and Q's padding
+// element holds -shift, so the S^T MFMA itself delivers s * c - shift: the 16 v_pk_fma_f32 per tile (a fifth of the VALU section; the
+// most expensive VALU form beside another wave's MFMAs, profiles/r02_valu_rates.txt) disappear and exp2 is applied to the accumulators
+// directly.  The shift is an fp16 number (softmax is invariant to it as long as O, the denominator and P use the same one); it is
+// raised — scores re-based, O rescaled, Q's padding element rewritten — only when a tile's maximum exceeds it (lazy, wave-uniform).
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, bool FOLD>
+__global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
+    constexpr int KVT = 64;
+    constexpr int DK = (D + 15) / 16 * 16, NDC = DK / 16;
+    constexpr int DV = (D + 31) / 32 * 32, NDB = DV / 32;
+    constexpr int NKB = KVT / 32;
+    constexpr int KSTR = DK * 2 + 16, VSTR = KVT * 2 + 16;       // odd numbers of 16-byte slots: conflict-free ds_read_b128
+    constexpr int K_BYTES = KVT * KSTR, V_BYTES = DV * VSTR, SLOT = K_BYTES + V_BYTES;
+    constexpr int NSLOT = 3;
+    constexpr int KCR = D / 8;               // 16-byte chunks of a K row that exist in memory (D % 8 == 0)
+    constexpr int KCPR = DK / 8;             // ... of its LDS image (padding chunks are constants written once)
+    constexpr int VCPR = KVT / 8;
+    constexpr int KCH = KVT * KCR, VCH = D * VCPR;
+    constexpr int K_IT = (KCH + 511) / 512, V_IT = (VCH + 511) / 512;
+    constexpr bool SUMROW = DV > D;          // see attn_mfma_kernel: row D of V^T is all ones, the PV MFMA accumulates the softmax denominator
+    constexpr int L_RR = D - (D / 32) * 32, L_DB = D / 32;
+    constexpr int L_HALF = (L_RR >> 2) & 1, L_R = (L_RR & 3) + 4 * (L_RR >> 3);
+    static_assert(D % 8 == 0, "head size must be a multiple of 8");
+    static_assert(!FOLD || DK > D, "FOLD needs a padding column in the contraction");
+    constexpr int PDC = D / 16, PHALF = (D % 16) / 8;            // where column D sits in the Q^T / K fragments (element 0 of that chunk)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NSLOT x (K tile | V^T tile), then one more K tile (K(0))
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;               // 0: leading group, 1: one section behind
+    const int half = lane >> 5, lq = lane & 31;
+    int bh, qb;
+    {
+        const int nqb = gridDim.x, nbh = gridDim.y;
+        const int id = blockIdx.y * nqb + blockIdx.x;
+        if ((nbh & 7) == 0) {                // all query blocks of a head on one XCD (see attn_mfma_kernel)
+            const int xcd = id & 7, slot = id >> 3;
+            qb = slot % nqb;
+            bh = (slot / nqb) * 8 + xcd;
+        } else {
+            bh = blockIdx.y; qb = blockIdx.x;
+        }
+    }
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q = qb * 256 + wave * 32 + lq;
+    const bool qok = q < p.N;
+
+    // ---- Q^T fragments (B operand of S^T): lane holds Q[q][dc*16 + half*8 .. +8); FOLD: times scale * log2(e) ------------------
+    h8 qf[NDC];
+    {
+        const half_t* qptr = p.q + ((long)b * p.N + (qok ? q : 0)) * p.ldq + h * D;
+#pragma unroll
+        for (int dc = 0; dc < NDC; ++dc) {
+            const int d = dc * 16 + half * 8;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qok && d < D) v = *reinterpret_cast<const h8*>(qptr + d);
+            if constexpr (FOLD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * p.scale_log2);
+            }
+            qf[dc] = v;
+        }
+    }
+    const half_t* kbase = p.k + (long)b * p.M * p.ldk + h * D;
+    const half_t* vbase = p.vt + ((long)b * p.H + h) * D * (long)p.vt_ld;
+
+    // Register-staged tiles, addresses clamped instead of predicated (attn_mfma_kernel's rules): K rows >= M re-read row M-1 (masked in
+    // the ragged tile), V^T columns stay below vt_ld for every tile that exists.
+    u4v kr[K_IT], vr[V_IT];
+    auto load_k = [&](int key0) {
+#pragma unroll
+        for (int it = 0; it < K_IT; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx / KCR, c = idx - row * KCR;
+            const int rr = min(key0 + row, p.M - 1);
+            kr[it] = *reinterpret_cast<const u4v*>(kbase + (long)rr * p.ldk + c * 8);
+        }
+    };
+    auto load_v = [&](int key0) {
+#pragma unroll
+        for (int it = 0; it < V_IT; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx / VCPR, c = idx - row * VCPR;
+            const int col = min(key0 + c * 8, p.vt_ld - 8);
+            vr[it] = *reinterpret_cast<const u4v*>(vbase + (long)min(row, D - 1) * p.vt_ld + col);
+        }
+    };
+    char* const dump = smem + NSLOT * SLOT + K_BYTES + tid * 16;     // 8 KB behind the tile images
+    auto write_k = [&](char* Ks) {
+#pragma unroll
+        for (int it = 0; it < K_IT; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx / KCR, c = idx - row * KCR;
+            // (threads past the end of the tile store into a per-thread dump slot instead of being predicated off: an exec-mask branch
+            // here splits the M section into basic blocks, and the compiler then sinks the softmax VALU work across the barrier into them)
+            char* dst = (KCH % 512 == 0 || idx < KCH) ? Ks + row * KSTR + c * 16 : dump;
+            *reinterpret_cast<u4v*>(dst) = kr[it];
+        }
+    };
+    auto write_v = [&](char* Vs) {
+#pragma unroll
+        for (int it = 0; it < V_IT; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx / VCPR, c = idx - row * VCPR;
+            char* dst = (VCH % 512 == 0 || idx < VCH) ? Vs + row * VSTR + c * 16 : dump;
+            *reinterpret_cast<u4v*>(dst) = vr[it];
+        }
+    };
+    // wait_lds: this wave's LDS writes must have landed before the others pass (end of an M section).  The V section ends with the
+    // operand READS of the following M section still in flight: they return under the barrier wait (their slot is overwritten two
+    // barriers later at the earliest), the compiler's own counted lgkmcnt waits precede the MFMAs that use them.
+    auto section_barrier = [&](bool wait_lds = true) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (wait_lds) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int T = (p.M + KVT - 1) / KVT;
+    const int nfull = p.M / KVT;
+    char* const K0s = smem + NSLOT * SLOT;
+
+    // ---- prologue: constants, K(0), pairs 0 and 1 ----------------------------------------------------------------------------
+    {
+        // padding chunks of every K image (columns D .. DK-1): zeros — FOLD: column D = 1.0 (fp16 0x3C00), so Q's padding element is
+        // added to every score; written once, the staging writes never touch them
+        constexpr int KPAD = KCPR - KCR;
+        if constexpr (KPAD > 0) {
+            for (int i = tid; i < (NSLOT + 1) * KVT * KPAD; i += 512) {
+                const int img = i / (KVT * KPAD), j = i - img * (KVT * KPAD);
+                const int row = j / KPAD, c = KCR + j % KPAD;
+                char* base = img < NSLOT ? smem + img * SLOT : K0s;
+                const unsigned w0 = (FOLD && c == KCR) ? 0x00003C00u : 0u;
+                *reinterpret_cast<uint4*>(base + row * KSTR + c * 16) = make_uint4(w0, 0u, 0u, 0u);
+            }
+        }
+        if constexpr (SUMROW) {              // V^T rows D .. DV-1 of every slot: row D = 1.0, the rest 0
+            constexpr int PADCH = (DV - D) * VCPR;
+            for (int i = tid; i < NSLOT * PADCH; i += 512) {
+                const int img = i / PADCH, j = i - img * PADCH;
+                const int row = D + j / VCPR, c = j % VCPR;
+                const unsigned w = row == D ? 0x3C003C00u : 0u;
+                *reinterpret_cast<uint4*>(smem + img * SLOT + K_BYTES + row * VSTR + c * 16) = make_uint4(w, w, w, w);
+            }
+        }
+        load_k(0);
+        write_k(K0s);
+        load_v(0); load_k(KVT);
+        write_v(smem + K_BYTES); write_k(smem);
+        if (T > 1) {
+            load_v(KVT); load_k(2 * KVT);
+            write_v(smem + SLOT + K_BYTES); write_k(smem + SLOT);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // K row read by this lane as MFMA row (lane & 31): bits 2 and 3 swapped, so that the 8 scores a lane packs for one PV MFMA are 8
+    // consecutive keys (attn_mfma_kernel's header)
+    const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
+    const int ka_off = krow * KSTR + half * 16;
+    const int va_off = K_BYTES + lq * VSTR + half * 16;
+
+    f16v o[NDB], sc[NKB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+    // S(0) from the extra K image
+    {
+        h8 kaf0[NDC][NKB];
+#pragma unroll
+        for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) kaf0[dc][kb] = *reinterpret_cast<const h8*>(K0s + ka_off + kb * 32 * KSTR + dc * 32);
+#pragma unroll
+        for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kaf0[dc][kb], qf[dc], sc[kb], 0, 0, 0);
+    }
+    load_v(2 * KVT); load_k(3 * KVT);                         // pair 2: written in M(0) (clamped addresses when it does not exist)
+
+    // FOLD: `shift` is the fp16 number currently subtracted by the MFMA (Q's padding element holds -shift); else the running maximum
+    // in the scaled (log2) domain
+    float shift = FOLD ? 0.f : -1e30f;
+    f2v l_run = {0.f, 0.f};
+    const f2v sl2 = {p.scale_log2, p.scale_log2};
+    h8 pb[NKB][2];
+    h8 kaf[NDC][NKB], vaf[NDB][NKB][2];
+
+    section_barrier();
+    if (grp == 1) section_barrier();                          // the second group runs one section behind from here on
+
+    for (int t = 0; t < T; ++t) {
+        // ================================ V section: softmax of S(t), operand reads for M(t) ================================
+        if (t >= nfull || p.causal) {
+            asm volatile("");                                 // a real (wave-uniform) branch, see attn_mfma_kernel
+            int lim = p.M - t * KVT - 8 * half;
+            if (p.causal) lim = min(lim, q + 1 - t * KVT - 8 * half);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * kb + 16 * (r >> 3) + (r & 7) >= lim) sc[kb][r] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+        {
+            float mlo = mx, mhi = mx;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mlo), "+v"(mhi));
+            mx = fmaxf(mlo, mhi);
+        }
+        if constexpr (FOLD) {
+            // mx is relative to the current shift.  Raise the shift when some query's maximum exceeds it (first tile: set it).
+            const bool raise = t == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0;
+            if (raise) {
+                asm volatile("");
+                const float want = shift + mx;
+                const float ns = (t == 0 || mx > 0.f) ? (float)(half_t)fminf(fmaxf(want, -60000.f), 60000.f) : shift;
+                const float delta = ns - shift;               // exact: both are fp16 numbers
+                shift = ns;
+                if (t > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                    if (!SUMROW) l_run = l_run * alpha;
+                }
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+                if (half == PHALF) qf[PDC][0] = (half_t)(-ns);
+            }
+            f2v rs = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float e0 = __builtin_amdgcn_exp2f(sc[kb][r]), e1 = __builtin_amdgcn_exp2f(sc[kb][r + 1]);
+                    if (!SUMROW) { rs.x += e0; rs.y += e1; }
+                    pb[kb][r >> 3][r & 7] = (half_t)e0;
+                    pb[kb][r >> 3][(r & 7) + 1] = (half_t)e1;
+                }
+            if (!SUMROW) l_run += rs;
+        } else {
+            mx *= p.scale_log2;                               // scale > 0: max commutes with the scaling
+            const float m_new = fmaxf(shift, mx);
+            const float alpha = __builtin_amdgcn_exp2f(shift - m_new);
+            const bool moved = __builtin_amdgcn_ballot_w64(m_new > shift) != 0;
+            shift = m_new;
+            const f2v mneg = {-m_new, -m_new};
+            f2v rs = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f2v s2 = {sc[kb][r], sc[kb][r + 1]};
+                    const f2v y = __builtin_elementwise_fma(s2, sl2, mneg);
+                    const f2v e = f2v{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+                    if (!SUMROW) rs += e;
+                    pb[kb][r >> 3][r & 7] = (half_t)e.x;
+                    pb[kb][r >> 3][(r & 7) + 1] = (half_t)e.y;
+                }
+            if (!SUMROW) l_run = l_run * alpha + rs;
+            if (moved) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            }
+        }
+        // operands of M(t) from pair t (slot t % 3: complete since the end of section M(t-2) of the second group)
+        {
+            const char* tile = smem + (t % NSLOT) * SLOT;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+                        vaf[db][kb][sb] = *reinterpret_cast<const h8*>(tile + va_off + db * 32 * VSTR + (kb * 32 + sb * 16) * 2);
+#pragma unroll
+            for (int dc = 0; dc < NDC; ++dc)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) kaf[dc][kb] = *reinterpret_cast<const h8*>(tile + ka_off + kb * 32 * KSTR + dc * 32);
+        }
+        // P(t) must exist BEFORE the barrier: without a use here the compiler sinks the exponentials into the M section
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) asm volatile("" :: "v"(pb[kb][0]), "v"(pb[kb][1]));
+        section_barrier(false);
+        // ================================ M section: O += V^T(t) P^T(t), S(t+1) = K(t+1) Q^T ================================
+        // (S(T) of the last iteration is computed from clamped rows and never used: no branch in the MFMA stream)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+        // staging, in the shadow of the MFMAs (no branch: the scheduler is free to interleave): pair t+2 (loaded one M section ago)
+        // into slot (t+2) % 3 — last read in V(t-1) of the second group, two barriers back —, then the loads of pair t+3.  Pairs past
+        // the end are loaded from clamped addresses and written like the others: nothing reads them.
+        {
+            char* slot = smem + ((t + 2) % NSLOT) * SLOT;
+            write_v(slot + K_BYTES); write_k(slot);
+            load_v((t + 3) * KVT); load_k((t + 4) * KVT);
+        }
+        // four independent accumulator chains, round robin
+#pragma unroll
+        for (int step = 0; step < (NDC > 2 * NKB ? NDC : 2 * NKB); ++step) {
+            if (step < 2 * NKB) {
+                const int kb = step >> 1, sb = step & 1;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vaf[db][kb][sb], pb[kb][sb], o[db], 0, 0, 0);
+            }
+            if (step < NDC) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kaf[step][kb], qf[step], sc[kb], 0, 0, 0);
+            }
+        }
+        if (!(grp == 1 && t + 1 == T)) section_barrier();     // (the second group's last barrier would have no partner)
+    }
+
+    // ---- normalise and store: o[db][r] is O[q][db*32 + (r&3) + 8*(r>>2) + 4*half] ----------------------------
+    float l_tot;
+    if (SUMROW) l_tot = __shfl(o[L_DB][L_R], lq + 32 * L_HALF);
+    else l_tot = (l_run.x + l_run.y) + __shfl_xor(l_run.x + l_run.y, 32);
+    const float inv = 1.0f / l_tot;
+    if (qok) {
+        half_t* optr = p.out + ((long)b * p.N + q) * p.ldo + h * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + g * 8 + half * 4;
+                if (d0 < D) {
+                    h4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[db][g * 4 + e] * inv);
+                    *reinterpret_cast<h4*>(optr + d0) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Generic kernel (any D <= 512, M <= 16384): one wave per query row, scores kept in LDS.  Slow; used for head sizes the
 // MFMA kernel is not instantiated for and as the independent HIP cross-check in the parity tests.
 // ---------------------------------------------------------------------------------------------------------------
@@ -426,6 +797,7 @@ int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e
 // default 15 since round 2: same-box A/Bs on the C1 job — 0 -> 5: self-attention 72.4 -> 69.5 ms per job (profiles/r02_knob_sweep.md);
 // 5 -> 15: 68.2 -> 66.6 and 70.0 -> 68.7 ms on two boxes (profiles/r02_attention_experiments.md)
 int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 15; }();
+int g_attn_pp_min_m = [] { const char* e = getenv("SDMI_ATTN_PP_MIN_M"); return e ? atoi(e) : 256; }();   // shortest key sequence the 8-wave kernel takes
 
 template <int D, int KVT, int VAR = 0>
 static int launch_attn_d(const AttnP& p, hipStream_t s) {
@@ -443,6 +815,22 @@ static int launch_attn_d(const AttnP& p, hipStream_t s) {
     return 0;
 }
 
+template <int D, bool FOLD>
+static int launch_attn_pp(const AttnP& p, hipStream_t s) {
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
+    constexpr int SMEM = 3 * (64 * (DK * 2 + 16) + DV * (64 * 2 + 16)) + 64 * (DK * 2 + 16) + 512 * 16;   // 3 pairs, K(0), dump slots
+    auto kern = attn_pp_kernel<D, FOLD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.N, 256), p.B * p.H);
+    hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, p);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
     SDMI_REQUIRE(p.B > 0 && p.H > 0 && p.N > 0 && p.M > 0 && p.D > 0, "empty attention");
     SDMI_REQUIRE(p.vt_ld >= (p.M + 63) / 64 * 64, "vt_ld must be >= M rounded up to 64");
@@ -456,6 +844,9 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
             // KV tile: 128 keys where the register budget allows it (small heads: the per-tile barrier / staging
             // overhead is amortised over twice the MFMA work), 64 otherwise or when the key sequence is short
             case 40:
+                // 20 / 21: the role-offset 8-wave kernel (21: softmax shift folded into the S^T MFMA) for the long self-attention launches
+                if ((g_attn_occ == 20 || g_attn_occ == 21) && p.M >= g_attn_pp_min_m && p.N >= 256)
+                    return g_attn_occ == 21 ? launch_attn_pp<40, true>(p, s) : launch_attn_pp<40, false>(p, s);
                 if (!(kvt128 && p.M > 64)) {
                     if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
                     if (g_attn_occ == 15) return launch_attn_d<40, 64, 15>(p, s);
@@ -469,7 +860,9 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
 #endif
                 }
                 return (kvt128 && p.M > 64) ? launch_attn_d<40, 128>(p, s) : launch_attn_d<40, 64>(p, s);
-            case 64: return (kvt128 && p.M > 64) ? launch_attn_d<64, 128>(p, s) : launch_attn_d<64, 64>(p, s);
+            case 64:
+                if ((g_attn_occ == 20 || g_attn_occ == 21) && p.M >= g_attn_pp_min_m && p.N >= 256) return launch_attn_pp<64, false>(p, s);
+                return (kvt128 && p.M > 64) ? launch_attn_d<64, 128>(p, s) : launch_attn_d<64, 64>(p, s);
             case 80: return launch_attn_d<80, 64>(p, s);
             case 128: return launch_attn_d<128, 64>(p, s);
             case 160: return launch_attn_d<160, 64>(p, s);

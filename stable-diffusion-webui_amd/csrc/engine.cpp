@@ -46,8 +46,12 @@ struct Run {
     sdmi_engine* e;
     hipStream_t s;
     bool dry;
-    half_t* H(size_t n) { return (half_t*)e->arena.take(n * sizeof(half_t)); }
-    float* F(size_t n) { return (float*)e->arena.take(n * sizeof(float)); }
+    Arena* ar;                     // the activation arena this pass bump-allocates from (one per concurrent batch slice: option "streams")
+    int b0 = 0, Btot = 0;          // UNet batch slices: first row of this slice / rows of the whole call (indexes the context cache)
+    Run(sdmi_engine* e_, hipStream_t s_, bool dry_, Arena* ar_ = nullptr, int b0_ = 0, int Btot_ = 0)
+        : e(e_), s(s_), dry(dry_), ar(ar_ ? ar_ : &e_->arena), b0(b0_), Btot(Btot_) {}
+    half_t* H(size_t n) { return (half_t*)ar->take(n * sizeof(half_t)); }
+    float* F(size_t n) { return (float*)ar->take(n * sizeof(float)); }
     void tap(const std::string& name, const half_t* p, int B, int H, int W, int C) {
         if (!dry && e->trace) e->taps.push_back({name, p, B, H, W, C});
     }
@@ -735,10 +739,12 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         }
         half_t* a2 = r.H(M * C);
         if (!r.dry) {
-            SDMI_REQUIRE(e->ctx_valid && e->ctx_B == B, "context not set for this batch size");
+            SDMI_REQUIRE(e->ctx_valid && e->ctx_B == (r.Btot ? r.Btot : B), "context not set for this batch size");
             // K rows of image b start at b*Lpad: express through ldk and a per-batch offset = Lpad*C
             AttnP p{};
-            p.q = q2; p.k = e->ctx_k[b.ctx_slot]; p.vt = e->ctx_vt[b.ctx_slot]; p.out = a2;
+            p.q = q2; p.out = a2;
+            p.k = e->ctx_k[b.ctx_slot] + (size_t)r.b0 * e->ctx_L * C;          // (a batch slice starts at its own rows of the cache)
+            p.vt = e->ctx_vt[b.ctx_slot] + (size_t)r.b0 * C * e->ctx_Lpad;
             p.B = B; p.H = st.heads; p.N = HW; p.M = e->ctx_L; p.D = st.dhead;
             p.ldq = C; p.ldk = C; p.vt_ld = e->ctx_Lpad; p.ldo = C;
             p.scale_log2 = (1.0f / sqrtf((float)st.dhead)) * 1.4426950408889634f;
@@ -902,7 +908,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     UNetW& u = e->unet;
     const sdmi_unet_config& c = u.cfg;
     const int mc = c.model_channels, ted = mc * 4;
-    e->arena.reset();
+    r.ar->reset();
     // ---- embeddings (fp32 activations, fp16 weights): time_embed(sinusoid(t)) [+ label_emb(y)] --------------
     float* sinus = r.F((size_t)Bn * mc);
     float* e1 = r.F((size_t)Bn * ted);
@@ -1021,15 +1027,29 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     return 0;
 }
 
-static int ensure_arena(sdmi_engine* e, size_t need, hipStream_t s) {
-    if (need <= e->arena.cap) return 0;
+static int ensure_arena(Arena& ar, size_t need, hipStream_t s) {
+    if (need <= ar.cap) return 0;
     SDMI_CHECK_HIP(hipStreamSynchronize(s));
-    if (e->arena.base) SDMI_CHECK_HIP(hipFree(e->arena.base));
-    e->arena.base = nullptr; e->arena.cap = 0;
+    if (ar.base) SDMI_CHECK_HIP(hipFree(ar.base));
+    ar.base = nullptr; ar.cap = 0;
     const size_t cap = need + (need >> 4) + (1 << 20);
-    SDMI_CHECK_HIP(hipMalloc((void**)&e->arena.base, cap));
-    e->arena.cap = cap;
+    SDMI_CHECK_HIP(hipMalloc((void**)&ar.base, cap));
+    ar.cap = cap;
     return 0;
+}
+static int ensure_arena(sdmi_engine* e, size_t need, hipStream_t s) { return ensure_arena(e->arena, need, s); }
+
+// one UNet pass over rows [b0, b0 + Bn) of a call of Btot rows, on stream s out of arena ar: dry pass to size the arena (pure host
+// arithmetic), then the launches
+static int unet_forward_slice(sdmi_engine* e, Arena& ar, const void* x, const void* t, const void* y, void* out, int io_dtype,
+                              int Bn, int b0, int Btot, int h, int w, int L, hipStream_t s) {
+    Run dry(e, s, true, &ar, b0, Btot);
+    ar.dry = true; ar.high = 0;
+    TRY(unet_run(dry, x, t, y, out, io_dtype, Bn, h, w, L));
+    ar.dry = false;
+    TRY(ensure_arena(ar, ar.high, s));
+    Run run(e, s, false, &ar, b0, Btot);
+    return unet_run(run, x, t, y, out, io_dtype, Bn, h, w, L);
 }
 
 int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, const void* y, void* out, int io_dtype,
@@ -1037,14 +1057,41 @@ int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, 
     SDMI_REQUIRE(e->unet.ready, "unet not finalized");
     SDMI_CHECK_HIP(hipSetDevice(e->device));
     if (ctx) TRY(unet_set_context(e, ctx, io_dtype, Bn, L, s));
-    // pass 1: dry run to size the arena (pure host arithmetic), pass 2: launch
-    Run dry{e, s, true};
-    e->arena.dry = true; e->arena.high = 0;
-    TRY(unet_run(dry, x, t, y, out, io_dtype, Bn, h, w, L));
-    e->arena.dry = false;
-    TRY(ensure_arena(e, e->arena.high, s));
-    Run run{e, s, false};
-    return unet_run(run, x, t, y, out, io_dtype, Bn, h, w, L);
+    // Option "streams" = n > 1: the rows of a call are independent (own timestep, own context rows), so the batch is cut into n
+    // equal slices that run the same launch sequence on n HIP streams out of n arenas.  The GPU then always has a second, independent
+    // kernel queue to draw workgroups from: the HBM-bound norm / elementwise launches of one slice run under the MFMA-bound GEMMs of
+    // the other, and a launch that leaves CUs idle (tail wave, small-M levels) no longer idles them.  Same arithmetic per row; the tile
+    // configuration follows the slice's M, so the bits are those of a call with Bn / n rows.  Not while block outputs are tapped.
+    const int ns = (e->n_streams > 1 && !e->trace && Bn % e->n_streams == 0) ? e->n_streams : 1;
+    if (ns == 1) return unet_forward_slice(e, e->arena, x, t, y, out, io_dtype, Bn, 0, Bn, h, w, L, s);
+    const sdmi_unet_config& c = e->unet.cfg;
+    while ((int)e->aux_streams.size() < ns - 1) {
+        hipStream_t st;
+        SDMI_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        e->aux_streams.push_back(st);
+        hipEvent_t ev;
+        SDMI_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->ev_join.push_back(ev);
+        e->aux_arenas.emplace_back();
+    }
+    if (!e->ev_fork) SDMI_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    const int Bc = Bn / ns;
+    const size_t elt = io_dtype == SDMI_F16 ? 2 : 4;
+    const size_t xs = (size_t)Bc * c.in_channels * h * w * elt, os = (size_t)Bc * c.out_channels * h * w * elt;
+    const size_t ts = (size_t)Bc * elt, ys = (size_t)Bc * (c.adm_in_channels > 0 ? c.adm_in_channels : 0) * elt;
+    SDMI_CHECK_HIP(hipEventRecord(e->ev_fork, s));           // the inputs (and the context cache) are ready on the caller's stream
+    for (int i = 1; i < ns; ++i) SDMI_CHECK_HIP(hipStreamWaitEvent(e->aux_streams[i - 1], e->ev_fork, 0));
+    for (int i = 0; i < ns; ++i) {
+        hipStream_t st = i == 0 ? s : e->aux_streams[i - 1];
+        Arena& ar = i == 0 ? e->arena : e->aux_arenas[i - 1];
+        TRY(unet_forward_slice(e, ar, (const char*)x + i * xs, (const char*)t + i * ts, y ? (const char*)y + i * ys : nullptr,
+                               (char*)out + i * os, io_dtype, Bc, i * Bc, Bn, h, w, L, st));
+    }
+    for (int i = 1; i < ns; ++i) {
+        SDMI_CHECK_HIP(hipEventRecord(e->ev_join[i - 1], e->aux_streams[i - 1]));
+        SDMI_CHECK_HIP(hipStreamWaitEvent(s, e->ev_join[i - 1], 0));
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1687,4 +1734,8 @@ sdmi_engine::~sdmi_engine() {
     for (void* p : owned_hn) (void)hipFree(p);
     if (hn_ctx_scratch) (void)hipFree(hn_ctx_scratch);
     if (arena.base) (void)hipFree(arena.base);
+    for (auto& a : aux_arenas) if (a.base) (void)hipFree(a.base);
+    for (hipStream_t st : aux_streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : ev_join) (void)hipEventDestroy(ev);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
 }

@@ -183,6 +183,12 @@ struct sdmi_engine {
     sdmi::ClipW clip[2];
     std::map<std::string, sdmi::RawTensor> raw_clip[2];
     sdmi::Arena arena;
+    // option "streams" (> 1): a UNet call's rows are cut into that many slices, each on its own HIP stream / arena (engine.cpp unet_forward)
+    int n_streams = 1;
+    std::vector<hipStream_t> aux_streams;
+    std::vector<sdmi::Arena> aux_arenas;
+    std::vector<hipEvent_t> ev_join;
+    hipEvent_t ev_fork = nullptr;
     // options
     bool force_generic = false;
     bool use_glds = true;

@@ -1,0 +1,207 @@
+"""GPU parity at the full-size shapes that `bench.py --config c2 | c3 | c4a | c4b` times (BASELINE.json configs[2..4]) — everything
+bench.py measures outside the headline configuration (tests/test_gpu_c1_parity.py covers that one):
+
+  * SD1.5 UNet, one CFG pair at a 128x128 latent — the hires pass of c4a (modules/processing.py:1364-1464): level-0 self-attention with
+    N = M = 16384 keys, the 256x320 / 128x320 tiles at 4x the rows;
+  * the attention launches of those jobs on their own: (d = 40, N = M = 16384), SDXL's (d = 64, 10 heads, N = 4096) and (d = 64, 20 heads,
+    N = 1024), plus their 77-key cross-attention forms;
+  * SDXL-base UNet (2.57 B parameters, configs/sd_xl_inpaint.yaml:19-37) at a 128x128 latent (1024x1024 images, c3);
+  * VAE decode at 1024x1024 (mid-block attention d = 512, N = 16384 through softmax_rows; modules/sd_hijack_optimizations.py:554-610), also
+    in the SDXL VAE configuration on a decoder that overflows fp16 without the range-extended decode (modules/processing.py:636-665);
+  * full-size VAE ENCODE at 512x512 (img2img, c4b; modules/sd_samplers_common.py:87-112);
+  * the c2 job at batch 1: 50-step DPM++ 2M on the Karras schedule, final latent (modules/sd_samplers_kdiffusion.py:12,18,116-127).
+
+The fp32 oracle outputs are committed fixtures (tests/golden/fullsize_*.npz, generated in the authoring container by
+tests/golden/make_fullsize_golden.py — minutes of CPU per leg); inputs are re-derived here from the same seeds.  Measured values go to
+gpurun_out/r03_parity_fullsize.json (copied to profiles/).  Stated tolerances (fp16 storage, fp32 accumulation — the same distance the
+C1 shapes have): UNet forward <= 2.5e-3, attention <= 5e-4, VAE decode <= 1.5e-3 (range-extended <= 5e-3: its
+residual stream carries 6 fewer mantissa-free exponent steps), VAE encode moments <= 2e-3, 50-step final latent <= 8e-3.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2, usable_cpus
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT_PATH = os.path.join(ROOT, "gpurun_out", "r03_parity_fullsize.json")
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_fullsize_golden as mfg  # noqa: E402  (input definitions: SPEC, seeded, xl_decoder_state_dict)
+
+
+def sub(name):
+    return importlib.import_module("stable-diffusion-webui_amd." + name)
+
+
+def report(section, value):
+    os.makedirs(os.path.dirname(REPORT_PATH), exist_ok=True)
+    data = {}
+    if os.path.exists(REPORT_PATH):
+        try:
+            data = json.load(open(REPORT_PATH))
+        except Exception:
+            data = {}
+    data[section] = value
+    with open(REPORT_PATH, "w") as f:
+        json.dump(data, f, indent=1)
+
+
+def fixture(golden_dir, name):
+    path = os.path.join(golden_dir, f"fullsize_{name}.npz")
+    assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullsize_golden.py {name}"
+    return np.load(path)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    sub("_lib").require_device()
+    torch.set_num_threads(usable_cpus(32))
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def sd15_unet_engine(dev):
+    schema = sub("schema")
+    sd = schema.synthetic_state_dict(schema.sd15_unet(), None, dtype=torch.float16)
+    eng = sub("engine").Engine(0)
+    eng.load_unet(schema.sd15_unet(), sd)
+    yield eng
+    eng.close()
+
+
+def test_c4_sd15_unet_forward_at_128x128_latent(dev, sd15_unet_engine, golden_dir):
+    s = mfg.SPEC["c4_unet128"]
+    want = torch.from_numpy(fixture(golden_dir, "c4_unet128")["out"])
+    x, t, ctx = mfg.seeded(*s["x"]), torch.tensor(s["t"]), mfg.seeded(*s["ctx"])
+    got = sd15_unet_engine.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
+    again = sd15_unet_engine.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
+    assert torch.equal(got, again)
+    e = rel_l2(got, want)
+    report("unet_c4_sd15_128x128_latent", {"shape": "x [2,4,128,128], context [2,77,768]", "engine_vs_fp32_oracle_rel_l2": e,
+                                           "per_row": [rel_l2(got[i], want[i]) for i in range(2)]})
+    print(f"[c4 unet 128x128] engine {e:.3e}")
+    assert e < 2.5e-3
+
+
+@pytest.mark.parametrize("d,heads,n", [(40, 8, 16384), (64, 10, 4096), (64, 20, 1024)])
+def test_fullsize_attention_shapes_vs_fp32(dev, d, heads, n):
+    """Self-attention at the hires / SDXL token counts and the 77-key cross-attention of the same level.  The fp32 reference is evaluated on
+    four 256-row windows of the queries (all keys): a window costs heads * 256 * n * d * 4 flops on the host."""
+    ops = sub("ops")
+    out = {}
+    for m, tag in ((n, "self"), (77, "cross")):
+        q, k, v = mfg.seeded((1, n, heads * d), 1 + d + n), mfg.seeded((1, m, heads * d), 2 + d + n), mfg.seeded((1, m, heads * d), 3 + d + n)
+        got = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads).float().cpu()
+        assert torch.isfinite(got).all()
+        qf, kf, vf = [z.half().float().reshape(1, -1, heads, d).permute(0, 2, 1, 3) for z in (q, k, v)]
+        errs = []
+        for lo in sorted({0, (n // 3) // 256 * 256, (2 * n // 3) // 256 * 256, n - 256}):
+            ref = torch.softmax(qf[:, :, lo:lo + 256] @ kf.transpose(-1, -2) * d ** -0.5, dim=-1) @ vf
+            ref = ref.permute(0, 2, 1, 3).reshape(1, 256, heads * d)
+            errs.append(rel_l2(got[:, lo:lo + 256], ref))
+        out[tag] = max(errs)
+        assert out[tag] < 5e-4, (tag, errs)
+    data = {}
+    if os.path.exists(REPORT_PATH):
+        data = json.load(open(REPORT_PATH)).get("attention_fullsize_shapes", {})
+    data[f"d{d}_H{heads}_N{n}"] = out
+    report("attention_fullsize_shapes", data)
+
+
+def test_c3_sdxl_base_unet_forward_at_128x128_latent(dev, golden_dir):
+    schema = sub("schema")
+    s = mfg.SPEC["c3_sdxl128"]
+    want = torch.from_numpy(fixture(golden_dir, "c3_sdxl128")["out"])
+    cfg = schema.sdxl_unet()
+    sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
+    eng = sub("engine").Engine(0)
+    eng.load_unet(cfg, sd)
+    del sd
+    x, t, ctx, y = mfg.seeded(*s["x"]), torch.tensor(s["t"]), mfg.seeded(*s["ctx"]), mfg.seeded(*s["y"])
+    got = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev), y.to(dev)).cpu()
+    eng.close()
+    e = rel_l2(got, want)
+    report("unet_c3_sdxl_128x128_latent", {"shape": "x [1,4,128,128], context [1,77,2048], y [1,2816]", "engine_vs_fp32_oracle_rel_l2": e})
+    print(f"[c3 sdxl 128x128] engine {e:.3e}")
+    assert e < 3e-3
+
+
+def _check_image(got, fx, tol):
+    sub4 = rel_l2(got[:, :, ::4, ::4], fx["out_sub4"])
+    win = rel_l2(got[:, :, 448:576, 448:576], fx["out_window"])
+    assert abs(float(got.norm()) / float(fx["norm"]) - 1.0) < 1e-3
+    assert sub4 < tol and win < tol, (sub4, win)
+    return {"every_4th_pixel_rel_l2": sub4, "dense_128x128_window_rel_l2": win}
+
+
+def test_c4_vae_decode_1024_and_encode_512(dev, golden_dir):
+    schema = sub("schema")
+    vcfg = schema.sd15_vae()
+    sd = schema.synthetic_state_dict(None, vcfg, dtype=torch.float16)
+    eng = sub("engine").Engine(0)
+    eng.load_vae(vcfg, sd)
+    s = mfg.SPEC["vae1024"]
+    z = mfg.seeded(*s["z"]) * s["z_scale"]
+    got = eng.vae_decode(z.to(dev)).cpu()
+    out = {"decode_1024": _check_image(got, fixture(golden_dir, "vae1024"), 1.5e-3)}
+    x = mfg.seeded(*mfg.SPEC["enc512"]["x"]).clamp(-1, 1)
+    mom = eng.vae_encode_moments(x.to(dev)).cpu()
+    want = torch.from_numpy(fixture(golden_dir, "enc512")["moments"])
+    out["encode_512_moments_rel_l2"] = rel_l2(mom, want)
+    out["encode_512_mean_rel_l2"] = rel_l2(mom[:, :4], want[:, :4])
+    eng.close()
+    report("vae_c4_decode_1024_encode_512", out)
+    print(f"[c4 vae] {out}")
+    assert out["encode_512_moments_rel_l2"] < 2e-3
+
+
+def test_c3_sdxl_vae_config_decode_1024_range_extended(dev, golden_dir):
+    """SDXL VAE configuration (scale_factor 0.13025) on a decoder whose residual stream passes 65504: the plain fp16 decode is NaN, the
+    range-extended decode (the engine's form of the reference's fp32 VAE retry) matches the fp32 oracle at 1024x1024."""
+    schema = sub("schema")
+    s = mfg.SPEC["vae1024_xl"]
+    sd = mfg.xl_decoder_state_dict(schema, s["weight_gain"])
+    eng = sub("engine").Engine(0)
+    eng.load_vae(schema.sdxl_vae(), sd, decoder_only=True)
+    z = (mfg.seeded(*s["z"]) * s["z_scale"]).to(dev)
+    plain = eng.vae_decode(z)
+    assert not torch.isfinite(plain).all()
+    eng.set_option("vae_range_extend", 1)
+    got = eng.vae_decode(z).cpu()
+    eng.close()
+    assert torch.isfinite(got).all()
+    out = _check_image(got, fixture(golden_dir, "vae1024_xl"), 5e-3)
+    report("vae_c3_sdxl_config_decode_1024_range_extended", out)
+    print(f"[c3 vae range-extended 1024] {out}")
+
+
+def test_c2_dpmpp_2m_karras_50_steps_final_latent(dev, golden_dir):
+    schema = sub("schema")
+    s = mfg.SPEC["c2_dpmpp2m"]
+    want = torch.from_numpy(fixture(golden_dir, "c2_dpmpp2m")["final_latent"])
+    ucfg, vcfg = schema.sd15_unet(), schema.sd15_vae()
+    sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16)
+    model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0, vae_decoder_only=True)
+    del sd
+    g = torch.Generator().manual_seed(s["prompt_seed"])
+    cond, uncond = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    sampler = sub("sd_samplers").create_sampler("DPM++ 2M", model)
+
+    class P:
+        steps, cfg_scale, eta, scheduler, is_hr_pass = s["steps"], s["cfg"], None, None, False      # Automatic = the sampler's own: karras
+        sampler_noise_scheduler_override = None
+        rng = sub("rng").ImageRNG((4, 64, 64), [s["seed"]], device=dev)
+    p = P()
+    got = sampler.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev)).cpu()
+    model.engine.close()
+    e = rel_l2(got, want)
+    report("dpmpp_2m_karras_50_steps_c2", {"config": "SD1.5 512x512, 50-step DPM++ 2M Karras, cfg 7, batch 1, seed 2000",
+                                           "engine_vs_fp32_oracle_final_latent_rel_l2": e})
+    print(f"[c2 e2e] engine {e:.3e}")
+    assert e < 8e-3

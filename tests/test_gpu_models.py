@@ -103,7 +103,6 @@ def test_unet_wide_and_8_byte_epilogues_give_the_same_bits(dev, tiny):
     assert torch.equal(a, b)
 
 
-@pytest.mark.skipif(os.environ.get("SDMI_EXPERIMENTAL") != "1", reason="LayerNorm fold is not validated on a GPU yet (next-round prep)")
 def test_unet_layernorm_folded_into_the_consuming_gemms(dev, tiny):
     """Engine option "ln_fold": norm1 / norm2 / norm3 of every transformer block finished inside the q|k, V^T, attn2.to_q and GEGLU
     GEMMs (folded weights + per-row statistics) against the separate LayerNorm kernel: the same function with one fp16 rounding of

@@ -443,6 +443,53 @@ def test_attention_softmax_is_shift_invariant_and_handles_spikes(dev):
     assert float((got[0, 5].float().cpu() - ref[0, 5]).abs().max()) < 2e-2
 
 
+@pytest.mark.parametrize("variant", [20, 21])
+def test_attention_role_offset_kernel(dev, variant):
+    """The 8-wave role-offset kernel (attn_occ 20; 21 = with the softmax shift folded into the S^T MFMA: Q pre-multiplied by
+    scale * log2 e, K's padding column at 1.0, Q's padding element at -shift): level-0 / hires shapes, ragged query and key counts, 1 to
+    9 KV tiles, d = 64 (SDXL; no padding column, so 21 runs the unfolded arithmetic there) — against fp32; the unfolded form runs
+    variant 15's arithmetic in variant 15's order and must give its bits.  Then the shift logic of 21 on adversarial rows: a spike
+    late in the sequence, scores that rise tile after tile (the shift is raised in every tile), all scores far below zero (first-tile
+    initialisation with a negative shift) and far above (shift near 100: fp16 spacing 0.06)."""
+    ops, lib = sub("ops"), sub("_lib")
+
+    def run(q, k, v, heads, occ):
+        lib.check(lib.lib.sdmi_debug_set(b"attn_occ", occ))
+        try:
+            out = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
+            torch.cuda.synchronize()
+        finally:
+            lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
+        return out
+
+    for d, heads, n, m in ((40, 8, 512, 512), (40, 2, 256, 256), (40, 1, 300, 333), (40, 2, 1024, 576), (40, 1, 256, 290), (40, 8, 4096, 4096),
+                           (64, 2, 512, 512), (64, 1, 260, 400)):
+        b = 1 if n >= 4096 else 2
+        q, k, v = seeded((b, n, heads * d), 61), seeded((b, m, heads * d), 62), seeded((b, m, heads * d), 63)
+        got = run(q, k, v, heads, variant)
+        e = rel_l2(got.float().cpu(), _attn_ref(h(q), h(k), h(v), heads))
+        assert e < 5e-4, (d, heads, n, m, e)
+        if variant == 20 or d != 40:
+            base = run(q, k, v, heads, 15 if d == 40 else 0)
+            assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (d, heads, n, m)
+    # adversarial rows for the shift bookkeeping
+    d, heads, n, m = 40, 1, 256, 576
+    q, k, v = seeded((1, n, d), 71), seeded((1, m, d), 72), seeded((1, m, d), 73)
+    k2 = k.clone()
+    k2[0, 500] = q[0, 5] * 6.0                                # spike for query 5 in the 8th KV tile
+    k3 = k.clone()
+    ramp = torch.linspace(-4.0, 6.0, m)[:, None]              # q . k rises along the sequence for query 7: a new maximum in every tile
+    k3[0] = k3[0] * 0.2 + ramp * q[0, 7][None, :] / q[0, 7].norm() * 2.0
+    k4 = k.clone() - 8.0 * q[0, 9][None, None, :] / q[0, 9].norm()      # every score of query 9 far below zero
+    k5 = k.clone() + 40.0 * q[0, 11][None, None, :] / q[0, 11].norm()   # ... of query 11 far above (shift ~ 90 in log2 units)
+    for kk, row in ((k2, 5), (k3, 7), (k4, 9), (k5, 11)):
+        ref = _attn_ref(h(q), h(kk), h(v), heads)
+        got = run(q, kk, v, heads, variant).float().cpu()
+        assert torch.isfinite(got).all()
+        assert rel_l2(got, ref) < 1.5e-3, row
+        assert float((got[0, row] - ref[0, row]).abs().max()) < 2e-2, row
+
+
 # ------------------------------------------------------------------------------------------------------------
 # norms
 # ------------------------------------------------------------------------------------------------------------
