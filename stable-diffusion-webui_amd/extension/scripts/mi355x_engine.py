@@ -22,11 +22,37 @@ def _list_optimizers(options):
 
 
 def _model_loaded(sd_model):
-    """Boundary B4: route decode_first_stage through the engine (same hook style as modules/lowvram.py:65-75)."""
+    """Boundary B4: route decode_first_stage through the engine (same hook style as modules/lowvram.py:65-75); boundary B6: the
+    text encoder's encode_with_transformers (modules/sd_hijack_clip.py:351-360) when shared.opts.mi355x_clip is set."""
     vae_amd = importlib.import_module("stable-diffusion-webui_amd.sd_vae_hook")
     vae_amd.install(sd_model)
+    if getattr(getattr(shared, "opts", None), "mi355x_clip", False):
+        bridge.install_clip_hook(sd_model)
+
+
+bridge = importlib.import_module("stable-diffusion-webui_amd.webui_bridge")
+
+
+def _register_samplers_and_lora():
+    """Boundaries B3 / B5.  Imported lazily and tolerant of a webui without those modules (API-only forks, Lora extension disabled):
+    the three callbacks above are the minimum, these two widen the drop-in to the fused CFG / sampler kernels and the GPU LoRA merge."""
+    done = {}
+    try:
+        from modules import sd_samplers, sd_unet
+        done["samplers"] = bridge.install_samplers(sd_samplers, sd_unet)      # modules/sd_samplers.py:11-16 all_samplers rows, same names
+    except ImportError:
+        sd_unet = None
+    try:
+        import networks as lora_networks                                      # extensions-builtin/Lora/networks.py (its dir is on sys.path)
+        from modules import sd_unet
+        bridge.install_lora_hook(lora_networks, sd_models, shared, sd_unet)   # wraps load_networks (extra_networks_lora.py:18-45)
+        done["lora"] = True
+    except ImportError:
+        pass
+    return done
 
 
 script_callbacks.on_list_unets(_list_unets)
 script_callbacks.on_list_optimizers(_list_optimizers)
 script_callbacks.on_model_loaded(_model_loaded)
+registered = _register_samplers_and_lora()

@@ -107,7 +107,9 @@ class Hypernetwork:
         self.filename = filename
         if self.name is None:
             self.name = os.path.splitext(os.path.basename(filename))[0]
-        return self.load_state(torch.load(filename, map_location='cpu', weights_only=False))
+        # weights_only: a hypernetwork .pt holds tensors, OrderedDicts, ints, strs, lists and bools only — never unpickle arbitrary objects
+        # from a user-supplied file (the reference routes torch.load through modules/safe.py's restricted unpickler)
+        return self.load_state(torch.load(filename, map_location='cpu', weights_only=True))
 
     def set_multiplier(self, multiplier):
         self.multiplier = float(multiplier)

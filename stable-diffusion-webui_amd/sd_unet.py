@@ -41,8 +41,15 @@ class Mi355xUnet(SdUnet):
         self._cfg = unet_cfg
         self._device_index = device_index
         self.engine = None
+        self.unet_cfg = unet_cfg
+        self._sd = None
         self._ctx_key = None
         self._last_ctx = None
+
+    def checkpoint(self) -> dict:
+        """The state dict the engine was packed from (kept by reference while active: the "weights backup" a LoRA rewrite starts
+        from, extensions-builtin/Lora/networks.py:423-432)."""
+        return self._sd
 
     def activate(self):
         from . import schema
@@ -54,11 +61,13 @@ class Mi355xUnet(SdUnet):
             cfg = guess_unet_config(sd)
         self.engine = Engine(self._device_index)
         self.engine.load_unet(cfg, sd, prefix=schema.UNET_PREFIX)
+        self.unet_cfg, self._sd = cfg, sd
 
     def deactivate(self):
         if self.engine is not None:
             self.engine.close()
             self.engine = None
+        self._sd = None
         self._ctx_key = self._last_ctx = None
 
     def forward(self, x, timesteps, context, *args, **kwargs):

@@ -773,3 +773,108 @@ def test_extension_script_registers_three_callbacks_against_stubbed_webui(monkey
     mod2 = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod2)
     assert len(reg["unets"]) == 2
+    assert mod.registered == {}                               # this stub webui has no sd_samplers / Lora modules: the script still loads
+
+
+def test_extension_script_registers_samplers_lora_and_clip_hooks_against_stubbed_webui(monkeypatch):
+    """Boundaries B3 / B5 / B6 as the shipped script installs them: the rows of modules.sd_samplers.all_samplers keep their names,
+    aliases and options but dispatch to the engine sampler while the engine UNet is sd_unet.current_unet (and to the stock constructor
+    otherwise); networks.load_networks of the built-in Lora extension is wrapped (stock call first, engine merge only with an active
+    engine UNet); a second import of the script does not stack wrappers."""
+    import collections
+    import types
+    amd = sub("sd_samplers")
+    SamplerData = collections.namedtuple("SamplerData", ["name", "constructor", "aliases", "options"])
+    stock_calls = []
+    mk = lambda name: (lambda model: stock_calls.append((name, model)) or types.SimpleNamespace(stock=name))
+    samplers_mod = types.ModuleType("modules.sd_samplers")
+    samplers_mod.all_samplers = [SamplerData("Euler a", mk("Euler a"), ["k_euler_a"], {"uses_ensd": True}),
+                                 SamplerData("DPM++ 2M", mk("DPM++ 2M"), ["k_dpmpp_2m"], {"scheduler": "karras"}),
+                                 SamplerData("Some third-party sampler", mk("x"), [], {})]
+    samplers_mod.all_samplers_map = {x.name: x for x in samplers_mod.all_samplers}
+    set_calls = []
+    samplers_mod.set_samplers = lambda: set_calls.append(len(samplers_mod.all_samplers))
+    unet_mod = types.ModuleType("modules.sd_unet")
+    unet_mod.current_unet = None
+    cb = types.ModuleType("modules.script_callbacks")
+    cb.on_list_unets = cb.on_list_optimizers = cb.on_model_loaded = lambda f: None
+    sdm = types.ModuleType("modules.sd_models")
+    sdm.checkpoints_list = {}
+    reads = []
+    sdm.read_state_dict = lambda fn, map_location=None: reads.append(fn) or {}
+    shared_stub = types.ModuleType("modules.shared")
+    shared_stub.sd_model = types.SimpleNamespace(alphas_cumprod=torch.linspace(0.99, 0.01, 1000))
+    lora = types.ModuleType("networks")
+    lora_calls = []
+    lora.load_networks = lambda names, te=None, un=None, dyn=None: lora_calls.append((tuple(names), te, un, dyn))
+    lora.available_network_aliases = {"myLora": types.SimpleNamespace(filename="/models/Lora/myLora.safetensors")}
+    lora.available_networks = {}
+    root = types.ModuleType("modules")
+    root.script_callbacks, root.sd_models, root.shared, root.sd_samplers, root.sd_unet = cb, sdm, shared_stub, samplers_mod, unet_mod
+    for name, m in (("modules", root), ("modules.script_callbacks", cb), ("modules.sd_models", sdm), ("modules.shared", shared_stub),
+                    ("modules.sd_samplers", samplers_mod), ("modules.sd_unet", unet_mod), ("networks", lora)):
+        monkeypatch.setitem(sys.modules, name, m)
+    import importlib.util
+    path = os.path.join(ROOT, "stable-diffusion-webui_amd", "extension", "scripts", "mi355x_engine.py")
+    spec = importlib.util.spec_from_file_location("mi355x_engine_script_b", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.registered == {"samplers": ["Euler a", "DPM++ 2M"], "lora": True} and set_calls == [3]
+    rows = samplers_mod.all_samplers
+    assert [r.name for r in rows] == ["Euler a", "DPM++ 2M", "Some third-party sampler"]
+    assert rows[0].aliases == ["k_euler_a"] and rows[1].options == {"scheduler": "karras"} and samplers_mod.all_samplers_map["Euler a"] is rows[0]
+    # no engine UNet active: the stock constructor
+    assert rows[0].constructor("torch-model").stock == "Euler a" and stock_calls == [("Euler a", "torch-model")]
+    # engine UNet active: the engine sampler over a view of (webui model, engine)
+    fake_engine = types.SimpleNamespace(device=0)
+    unet = sub("sd_unet").Mi355xUnet(lambda: {}, unet_cfg=sub("schema").tiny_unet())
+    unet.engine, unet._sd = fake_engine, {"model.diffusion_model.x.weight": torch.ones(2)}
+    unet_mod.current_unet = unet
+    s = rows[1].constructor(shared_stub.sd_model)
+    assert isinstance(s, amd.KDiffusionSampler) and s.sd_model.engine is fake_engine and len(stock_calls) == 1
+    assert torch.equal(s.sd_model.alphas_cumprod, shared_stub.sd_model.alphas_cumprod)
+    assert torch.equal(s.sd_model.unet_checkpoint_tensor("x.weight"), torch.ones(2))
+    # Lora: stock first; the engine merge reads the same file through the webui's own reader
+    amd_net = sub("networks")
+    merged = []
+    monkeypatch.setattr(amd_net, "load_networks", lambda view, names, sds, te, un, dyn: merged.append((view.engine, names, te, un, dyn)))
+    lora.load_networks(["myLora"], [0.5], [0.8], [None])
+    assert lora_calls == [(("myLora",), [0.5], [0.8], [None])] and reads == ["/models/Lora/myLora.safetensors"]
+    assert merged == [(fake_engine, ["myLora"], [0.5], [0.8], [None])]
+    unet_mod.current_unet = None
+    lora.load_networks(["myLora"], [1.0], [1.0], [None])
+    assert len(lora_calls) == 2 and len(merged) == 1          # torch UNet active: the stock path only
+    # "Reload UI": a second import wraps the ORIGINAL constructors / loader again, not the wrappers
+    mod2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod2)
+    assert samplers_mod.all_samplers[0].constructor("m2").stock == "Euler a"
+    lora.load_networks(["myLora"])
+    assert len(lora_calls) == 3
+    # B6: a model without the transformers CLIP wrapper is left alone
+    assert sub("webui_bridge").install_clip_hook(types.SimpleNamespace(cond_stage_model=None)) is None
+
+
+def test_hypernetwork_file_is_loaded_without_unpickling_arbitrary_objects(tmp_path):
+    """Hypernetwork.load reads a user-supplied .pt with torch.load(weights_only=True): a real hypernetwork file (tensors, tuples, ints,
+    strs, lists, bools — modules/hypernetworks/hypernetwork.py:246-300) loads, a pickle that would execute code on load is refused
+    (the reference routes torch.load through modules/safe.py's restricted unpickler for the same reason)."""
+    import pickle
+    hn = sub("hypernetwork")
+    g = torch.Generator().manual_seed(5)
+    mk = lambda dim: {"linear.0.weight": torch.randn(2 * dim, dim, generator=g), "linear.0.bias": torch.zeros(2 * dim),
+                      "linear.1.weight": torch.randn(dim, 2 * dim, generator=g), "linear.1.bias": torch.zeros(dim)}
+    state = {"layer_structure": [1, 2, 1], "activation_func": "linear", "is_layer_norm": False, "activate_output": False,
+             "dropout_structure": None, "name": "tiny_hn", "step": 100, "sd_checkpoint": "abc", "sd_checkpoint_name": "m",
+             64: (mk(64), mk(64)), 128: (mk(128), mk(128))}
+    good = tmp_path / "tiny_hn.pt"
+    torch.save(state, str(good))
+    h = hn.Hypernetwork().load(str(good))
+    assert h.name == "tiny_hn" and sorted(h.layers) == [64, 128] and len(h.layers[64]) == 2
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+    bad = tmp_path / "evil.pt"
+    torch.save({"layer_structure": [1, 2, 1], "payload": Evil()}, str(bad))
+    with pytest.raises(pickle.UnpicklingError):
+        hn.Hypernetwork().load(str(bad))
