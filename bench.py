@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--sampler-steps", type=int, default=0)
     ap.add_argument("--sampler", default="")
     ap.add_argument("--model", default="", choices=["", "sd15", "sdxl", "tiny"])
+    ap.add_argument("--no-dropin", action="store_true", help="skip timing the webui drop-in path (config.dropin_images_per_s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0)
@@ -167,6 +168,60 @@ def make_job(args, model, rank, world, local_only=False):
             p.y, p.uy = y, uy
         return par.process_images_sharded(p, world=1, rank=0) if local_only else par.process_images_sharded(p)
     return run_once, (lo, hi)
+
+
+def dropin_path(args, model, jobs=3):
+    """What a webui user gets WITHOUT the engine's own process_images / sampler mirror: the reference's Python loop around the plugin
+    boundaries.  A torch-side stand-in of that loop — per step `torch.cat` of cond | uncond and of x (modules/sd_samplers_cfg_denoiser.py:
+    236-246), x * c_in, fp16 `Mi355xUnet.forward` through the SdUnet boundary B1 with the context validated on the device
+    (modules/sd_unet.py:86-93), denoised = x - eps * sigma, the CFG combine and k-diffusion's sample_euler_ancestral update as
+    torch elementwise ops on the fp32 state, then `first_stage_model.decode` as the B4 hook binds it (engine decode of z / scale_factor) and
+    the clamp / x255 / uint8 conversion in torch (modules/processing.py:1004-1035).  Same UNet, same VAE kernels; what differs from `value`
+    is everything between them.  Returns images/s over `jobs` jobs after one warm-up job."""
+    import torch
+    sd_unet, smp, rng_mod = sub("sd_unet"), sub("sd_samplers"), sub("rng")
+    dev = model.device
+    unet = sd_unet.Mi355xUnet(lambda: None, unet_cfg=model.unet_cfg, device_index=dev.index)
+    unet.engine = model.engine                                 # the engine already holds this checkpoint: no second copy of the weights
+    wrap = smp.CompVisDenoiser(model)
+    sigmas = wrap.get_sigmas(args.sampler_steps).to(dev)
+    B, hw = args.batch, args.size // 8
+    g = torch.Generator().manual_seed(50_000)
+    c = torch.randn(B, 77, model.unet_cfg.context_dim, generator=g).to(dev).half()
+    uc = torch.randn(B, 77, model.unet_cfg.context_dim, generator=g).to(dev).half()
+    cfg_scale = 7.0
+
+    def job():
+        rng = rng_mod.ImageRNG((4, hw, hw), [1000 + i for i in range(B)], device=dev)
+        x = rng.next() * sigmas[0]
+        for i in range(len(sigmas) - 1):
+            sigma, sigma_next = sigmas[i], sigmas[i + 1]
+            x_in = torch.cat([x, x])
+            cond_in = torch.cat([c, uc])
+            sigma_in = sigma.expand(2 * B)
+            c_in = 1.0 / (sigma_in ** 2 + 1.0) ** 0.5
+            t_in = wrap.sigma_to_t(sigma_in.cpu()).to(dev)
+            eps = unet.forward((x_in * c_in[:, None, None, None]).half(), t_in.half(), cond_in)
+            den_in = x_in - eps.float() * sigma_in[:, None, None, None]
+            den_c, den_u = den_in[:B], den_in[B:]
+            denoised = den_u + (den_c - den_u) * cfg_scale
+            # sample_euler_ancestral (k-diffusion sampling.py): get_ancestral_step with eta = 1
+            s_up = torch.minimum(sigma_next, (sigma_next ** 2 * (sigma ** 2 - sigma_next ** 2) / sigma ** 2) ** 0.5)
+            s_down = (sigma_next ** 2 - s_up ** 2) ** 0.5
+            d = (x - denoised) / sigma
+            x = x + d * (s_down - sigma)
+            if float(sigma_next) > 0:
+                x = x + rng.next() * s_up
+        img = model.engine.vae_decode(x / model.scale_factor * model.scale_factor)    # decode_first_stage: z / scale_factor inside the engine config
+        u8 = (255.0 * torch.clamp((img + 1.0) / 2.0, 0.0, 1.0)).permute(0, 2, 3, 1).to(torch.uint8).cpu()
+        return u8
+    job()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(jobs):
+        job()
+    torch.cuda.synchronize()
+    return B * jobs / (time.time() - t0)
 
 
 def pmc_traffic(args):
@@ -396,6 +451,12 @@ def main():
             roof, kernels = roofline_block(args, run_local)
         else:
             roof, kernels = roofline_block(args, run_once)
+    dropin = None
+    if rank == 0 and world == 1 and not args.no_dropin and not (args.hires or args.img2img) and args.sampler == "Euler a":
+        try:
+            dropin = round(dropin_path(args, model, jobs=min(3, max(1, args.steps))), 4)
+        except Exception as ex:                                # the drop-in stand-in must never cost the bench line
+            dropin = f"failed: {type(ex).__name__}: {ex}"
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_isolated(args)
@@ -420,6 +481,8 @@ def main():
                    "weights": "synthetic N(0,1/fan_in) in the checkpoint's state-dict schema (seed 0x5D15)",
                    "weights_broadcast_ms": round(t_bcast * 1e3, 1), "weights_generate_s": round(t_gen, 1),
                    "algorithmic_tflop_per_image": tflop_per_image,
+                   "dropin_images_per_s": dropin,
+                   "dropin_path": "torch stand-in of the reference's CFGDenoiser + Euler-a loop calling Mi355xUnet.forward per step + engine VAE decode (bench.py dropin_path)",
                    "whole_job_mfma_frac": round(value / world * tflop_per_image / MFMA_PEAK_TFLOPS, 4) if tflop_per_image else None},
         "roofline": roof,
         "cpu_baseline": cpu,

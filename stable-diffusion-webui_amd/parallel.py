@@ -104,7 +104,9 @@ def broadcast_state_dict(sd: Optional[dict], src: int = 0, device="cpu", algo: s
 
 
 def gather_to_rank0(t: torch.Tensor, counts: List[int]) -> Optional[torch.Tensor]:
-    """Concatenate per-rank tensors (rank r contributes counts[r] leading rows) on rank 0."""
+    """Concatenate per-rank tensors (rank r contributes counts[r] leading rows) on rank 0.  The collective is chosen UP FRONT from the
+    backend, identically on every rank (gather on nccl = RCCL and gloo; all-gather-and-drop elsewhere) — never by catching an exception
+    on some ranks, which would leave the others in a different collective."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return t
@@ -112,10 +114,10 @@ def gather_to_rank0(t: torch.Tensor, counts: List[int]) -> Optional[torch.Tensor
     mx = max(counts)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
-    try:
+    if dist.get_backend() in ("nccl", "gloo"):
         bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
         dist.gather(pad, gather_list=bufs, dst=0)
-    except (RuntimeError, NotImplementedError, ValueError):           # a backend without gather: all-gather and drop
+    else:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad)
     if rank != 0:
@@ -210,6 +212,9 @@ def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Op
                 res.images = list(res.images) + list(extra.images)
                 if res.latents is not None and extra.latents is not None:
                     res.latents = torch.cat([res.latents, extra.latents])
+                for f in ("all_seeds", "all_subseeds"):
+                    if isinstance(getattr(res, f, None), list) and isinstance(getattr(extra, f, None), list):
+                        setattr(res, f, getattr(res, f) + getattr(extra, f))
         else:
             res = runner(q)
     else:
@@ -220,10 +225,14 @@ def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Op
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
     backend = dist.get_backend()
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    # the size of the job's FINAL images (a hires job's are not p.height x p.width) comes from rank 0, which owns at least as many
+    # images as any other rank: a rank with no images still has to offer a buffer of the right shape to the gather
+    hw = torch.tensor(list(res.images[0].shape[:2]) if res.images else [0, 0], dtype=torch.int64, device=dev)
+    dist.broadcast(hw, src=0)
     if res.images:
         mine = torch.from_numpy(np.stack(res.images)).to(dev)
     else:
-        mine = torch.zeros((0, p.height, p.width, 3), dtype=torch.uint8, device=dev)
+        mine = torch.zeros((0, int(hw[0]), int(hw[1]), 3), dtype=torch.uint8, device=dev)
     allv = gather_to_rank0(mine, counts)
     if dist.get_rank() == 0:
         res.images = list(allv.cpu().numpy())

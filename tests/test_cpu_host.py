@@ -493,14 +493,19 @@ SHARD_WORKER = textwrap.dedent("""
             calls.append(p.batch_size)
             for i in range(it * p.batch_size, (it + 1) * p.batch_size):
                 v = (seeds[i] * 7 + int(p.c[i].sum().item()) * 3 + int(p.uc[i].sum().item())) % 251
-                imgs.append(np.full((p.height, p.width, 3), v, dtype=np.uint8))
+                f = 2 if getattr(p, "enable_hr", False) else 1      # a hires job's final images are not p.height x p.width
+                imgs.append(np.full((p.height * f, p.width * f, 3), v, dtype=np.uint8))
         return processing.Processed(p, imgs, seeds[0], seeds, None)
 
-    def job(bs, n_iter):
+    def job(bs, n_iter, hr=False):
         n = bs * n_iter
         c = torch.arange(n, dtype=torch.float32)[:, None, None].repeat(1, 3, 2)
         return processing.StableDiffusionProcessingTxt2Img(sd_model=None, c=c, uc=c * 2 + 1, seed=4242, batch_size=bs, n_iter=n_iter,
-                                                           steps=2, width=8, height=8, sampler_name="Euler a")
+                                                           steps=2, width=8, height=8, sampler_name="Euler a", enable_hr=hr)
+    # hires job with fewer images than ranks: the empty rank's gather buffer must have the FINAL image size
+    res = par.process_images_sharded(job(1, 1, hr=True), runner=fake_runner)
+    if rank == 0:
+        assert len(res.images) == 1 and res.images[0].shape == (16, 16, 3)
     for bs, n_iter in ((2, 2), (2, 3), (1, 1), (4, 1)):
         calls.clear()
         whole = fake_runner(job(bs, n_iter))

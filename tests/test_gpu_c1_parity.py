@@ -217,9 +217,10 @@ def test_c1_executed_fp16_yardstick_unet_and_vae(dev, sd15):
     report("executed_fp16_yardstick", out)
     print(f"[c1 executed fp16 yardstick] {out}")
     u = out["unet_c1_rows0_3"]
-    assert u["engine_vs_fp32_oracle"] < 1.5 * u["torch_fp16_autocast_vs_fp32_oracle"]
+    # measured (round 3, profiles/r03_parity.json): UNet engine 1.57e-3 vs torch fp16 autocast 3.22e-3; VAE 1.12e-3 vs 1.83e-3
+    assert u["engine_vs_fp32_oracle"] < u["torch_fp16_autocast_vs_fp32_oracle"]
     v = out["vae_decode_512"]
-    assert v["engine_vs_fp32_oracle"] < 1.5 * v["torch_fp16_autocast_vs_fp32_oracle"]
+    assert v["engine_vs_fp32_oracle"] < v["torch_fp16_autocast_vs_fp32_oracle"]
 
 
 def test_c1_groupnorm_statistics_fused_into_producing_gemm(dev, sd15):

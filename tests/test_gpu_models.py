@@ -1073,3 +1073,42 @@ def test_hypernetworks_in_engine_vs_oracle(dev, tiny):
         ou.LOADED_HYPERNETWORKS[:] = []
         hn_mod.load_hypernetworks(model, [], [])
     assert torch.equal(fwd(), base)
+
+
+def test_sharded_job_replayed_rank_by_rank_equals_the_single_process_job(dev, tiny):
+    """SURVEY.md section 8e on ONE GPU with the REAL engine: parallel.process_images_sharded(p, world=2, rank=r) for r = 0, 1 run one
+    after the other in this process — what rank r of a 2-GPU job computes — and concatenated must be BIT-identical to the single-process
+    job at the same per-call batch size (global seeds, per-image generators, per-image CFG combine and decode): tiny model incl. a hires
+    job and a ragged split, then a C1-shaped full-size SD1.5 job (512x512, batch 2 x 2 iterations, 3 steps)."""
+    par, processing, schema = sub("parallel"), sub("processing"), sub("schema")
+
+    def check(model, cond, uncond, bs, n_iter, world=2, **kw):
+        n = bs * n_iter
+        mk = lambda: processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond[:n], uc=uncond[:n], seed=4321, batch_size=bs, n_iter=n_iter,
+                                                                 cfg_scale=6.0, sampler_name="Euler a", **kw)
+        whole = processing.process_images(mk())
+        parts = [par.process_images_sharded(mk(), world=world, rank=r) for r in range(world)]
+        imgs = [im for part in parts for im in part.images]
+        assert [part.shard for part in parts] == [par.shard_range(n, world, r) for r in range(world)]
+        assert len(imgs) == len(whole.images) == n
+        for i, (a, b) in enumerate(zip(imgs, whole.images)):
+            assert np.array_equal(a, b), (bs, n_iter, world, i, kw.get("enable_hr", False))
+        return whole
+
+    g = torch.Generator().manual_seed(13)
+    cond, uncond = torch.randn(6, 77, 64, generator=g), torch.randn(6, 77, 64, generator=g)
+    check(tiny["model"], cond, uncond, 2, 2, steps=3, width=128, height=128)
+    check(tiny["model"], cond, uncond, 1, 4, steps=3, width=128, height=128)
+    check(tiny["model"], cond, uncond, 2, 3, world=3, steps=2, width=128, height=128)
+    w = check(tiny["model"], cond, uncond, 1, 2, steps=2, width=64, height=64, enable_hr=True, hr_scale=2.0, hr_upscaler="Latent", denoising_strength=0.6)
+    assert w.images[0].shape[:2] == (128, 128)
+    ucfg, vcfg = schema.sd15_unet(), schema.sd15_vae()
+    sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16)
+    model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0, vae_decoder_only=True)
+    del sd
+    try:
+        c, uc = torch.randn(4, 77, 768, generator=g), torch.randn(4, 77, 768, generator=g)
+        check(model, c, uc, 2, 2, steps=3, width=512, height=512)
+    finally:
+        model.engine.close()
+        sub("shared").sd_model = tiny["model"]
