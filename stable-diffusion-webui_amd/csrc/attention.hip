@@ -377,9 +377,11 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 18) ? 3 : (VAR == 5 || V
 // directly.  The shift is an fp16 number (softmax is invariant to it as long as O, the denominator and P use the same one); it is
 // raised — scores re-based, O rescaled, Q's padding element rewritten — only when a tile's maximum exceeds it (lazy, wave-uniform).
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, bool FOLD>
-__global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
+template <int D, bool FOLD, int NG>
+__global__ __launch_bounds__(NG * 256, NG) void attn_pp_kernel(AttnP p) {
     constexpr int KVT = 64;
+    constexpr int NT = NG * 256;             // NG groups of 4 waves (one wave of each group per SIMD)
+    static_assert(NG == 2 || NG == 3, "two or three wave groups");
     constexpr int DK = (D + 15) / 16 * 16, NDC = DK / 16;
     constexpr int DV = (D + 31) / 32 * 32, NDB = DV / 32;
     constexpr int NKB = KVT / 32;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
     constexpr int KCPR = DK / 8;             // ... of its LDS image (padding chunks are constants written once)
     constexpr int VCPR = KVT / 8;
     constexpr int KCH = KVT * KCR, VCH = D * VCPR;
-    constexpr int K_IT = (KCH + 511) / 512, V_IT = (VCH + 511) / 512;
+    constexpr int K_IT = (KCH + NT - 1) / NT, V_IT = (VCH + NT - 1) / NT;
     constexpr bool SUMROW = DV > D;          // see attn_mfma_kernel: row D of V^T is all ones, the PV MFMA accumulates the softmax denominator
     constexpr int L_RR = D - (D / 32) * 32, L_DB = D / 32;
     constexpr int L_HALF = (L_RR >> 2) & 1, L_R = (L_RR & 3) + 4 * (L_RR >> 3);
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;               // 0: leading group, 1: one section behind
+    const int grp = wave >> 2;               // 0: leading group; group g runs g sections behind
     const int half = lane >> 5, lq = lane & 31;
     int bh, qb;
     {
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
         }
     }
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q = qb * 256 + wave * 32 + lq;
+    const int q = qb * (NG * 128) + wave * 32 + lq;
     const bool qok = q < p.N;
 
     // ---- Q^T fragments (B operand of S^T): lane holds Q[q][dc*16 + half*8 .. +8); FOLD: times scale * log2(e) ------------------
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
     auto load_k = [&](int key0) {
 #pragma unroll
         for (int it = 0; it < K_IT; ++it) {
-            const int idx = it * 512 + tid;
+            const int idx = it * NT + tid;
             const int row = idx / KCR, c = idx - row * KCR;
             const int rr = min(key0 + row, p.M - 1);
             kr[it] = *reinterpret_cast<const u4v*>(kbase + (long)rr * p.ldk + c * 8);
@@ -453,30 +455,30 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
     auto load_v = [&](int key0) {
 #pragma unroll
         for (int it = 0; it < V_IT; ++it) {
-            const int idx = it * 512 + tid;
+            const int idx = it * NT + tid;
             const int row = idx / VCPR, c = idx - row * VCPR;
             const int col = min(key0 + c * 8, p.vt_ld - 8);
             vr[it] = *reinterpret_cast<const u4v*>(vbase + (long)min(row, D - 1) * p.vt_ld + col);
         }
     };
-    char* const dump = smem + NSLOT * SLOT + K_BYTES + tid * 16;     // 8 KB behind the tile images
+    char* const dump = smem + NSLOT * SLOT + K_BYTES + tid * 16;     // NT x 16 bytes behind the tile images
     auto write_k = [&](char* Ks) {
 #pragma unroll
         for (int it = 0; it < K_IT; ++it) {
-            const int idx = it * 512 + tid;
+            const int idx = it * NT + tid;
             const int row = idx / KCR, c = idx - row * KCR;
             // (threads past the end of the tile store into a per-thread dump slot instead of being predicated off: an exec-mask branch
             // here splits the M section into basic blocks, and the compiler then sinks the softmax VALU work across the barrier into them)
-            char* dst = (KCH % 512 == 0 || idx < KCH) ? Ks + row * KSTR + c * 16 : dump;
+            char* dst = (KCH % NT == 0 || idx < KCH) ? Ks + row * KSTR + c * 16 : dump;
             *reinterpret_cast<u4v*>(dst) = kr[it];
         }
     };
     auto write_v = [&](char* Vs) {
 #pragma unroll
         for (int it = 0; it < V_IT; ++it) {
-            const int idx = it * 512 + tid;
+            const int idx = it * NT + tid;
             const int row = idx / VCPR, c = idx - row * VCPR;
-            char* dst = (VCH % 512 == 0 || idx < VCH) ? Vs + row * VSTR + c * 16 : dump;
+            char* dst = (VCH % NT == 0 || idx < VCH) ? Vs + row * VSTR + c * 16 : dump;
             *reinterpret_cast<u4v*>(dst) = vr[it];
         }
     };
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
         // added to every score; written once, the staging writes never touch them
         constexpr int KPAD = KCPR - KCR;
         if constexpr (KPAD > 0) {
-            for (int i = tid; i < (NSLOT + 1) * KVT * KPAD; i += 512) {
+            for (int i = tid; i < (NSLOT + 1) * KVT * KPAD; i += NT) {
                 const int img = i / (KVT * KPAD), j = i - img * (KVT * KPAD);
                 const int row = j / KPAD, c = KCR + j % KPAD;
                 char* base = img < NSLOT ? smem + img * SLOT : K0s;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
         }
         if constexpr (SUMROW) {              // V^T rows D .. DV-1 of every slot: row D = 1.0, the rest 0
             constexpr int PADCH = (DV - D) * VCPR;
-            for (int i = tid; i < NSLOT * PADCH; i += 512) {
+            for (int i = tid; i < NSLOT * PADCH; i += NT) {
                 const int img = i / PADCH, j = i - img * PADCH;
                 const int row = D + j / VCPR, c = j % VCPR;
                 const unsigned w = row == D ? 0x3C003C00u : 0u;
@@ -569,7 +571,9 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
     h8 kaf[NDC][NKB], vaf[NDB][NKB][2];
 
     section_barrier();
-    if (grp == 1) section_barrier();                          // the second group runs one section behind from here on
+    for (int i = 0; i < grp; ++i) section_barrier();          // group g runs g sections behind from here on
+    // barriers of the last iteration that have no partner: group g skips its final g (of NB per iteration)
+    constexpr int NB = NG;
 
     for (int t = 0; t < T; ++t) {
         // ================================ V section: softmax of S(t), operand reads for M(t) ================================
@@ -616,37 +620,13 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
                     for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
                 if (half == PHALF) qf[PDC][0] = (half_t)(-ns);
             }
-            f2v rs = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float e0 = __builtin_amdgcn_exp2f(sc[kb][r]), e1 = __builtin_amdgcn_exp2f(sc[kb][r + 1]);
-                    if (!SUMROW) { rs.x += e0; rs.y += e1; }
-                    pb[kb][r >> 3][r & 7] = (half_t)e0;
-                    pb[kb][r >> 3][(r & 7) + 1] = (half_t)e1;
-                }
-            if (!SUMROW) l_run += rs;
         } else {
             mx *= p.scale_log2;                               // scale > 0: max commutes with the scaling
             const float m_new = fmaxf(shift, mx);
             const float alpha = __builtin_amdgcn_exp2f(shift - m_new);
             const bool moved = __builtin_amdgcn_ballot_w64(m_new > shift) != 0;
             shift = m_new;
-            const f2v mneg = {-m_new, -m_new};
-            f2v rs = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f2v s2 = {sc[kb][r], sc[kb][r + 1]};
-                    const f2v y = __builtin_elementwise_fma(s2, sl2, mneg);
-                    const f2v e = f2v{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
-                    if (!SUMROW) rs += e;
-                    pb[kb][r >> 3][r & 7] = (half_t)e.x;
-                    pb[kb][r >> 3][(r & 7) + 1] = (half_t)e.y;
-                }
-            if (!SUMROW) l_run = l_run * alpha + rs;
+            if (!SUMROW) l_run = l_run * alpha;
             if (moved) {
 #pragma unroll
                 for (int db = 0; db < NDB; ++db)
@@ -654,6 +634,40 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
                     for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
             }
         }
+        // exponentials of one 32-key block -> P (fp16, packed for the PV MFMA).  FOLD: the accumulators already are s * c - shift
+        const f2v mneg = {-shift, -shift};
+        auto exp_block = [&](int kb) {
+            f2v rs = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f2v e;
+                if constexpr (FOLD) {
+                    e = f2v{__builtin_amdgcn_exp2f(sc[kb][r]), __builtin_amdgcn_exp2f(sc[kb][r + 1])};
+                } else {
+                    const f2v s2 = {sc[kb][r], sc[kb][r + 1]};
+                    const f2v y = __builtin_elementwise_fma(s2, sl2, mneg);
+                    e = f2v{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+                }
+                if (!SUMROW) rs += e;
+                pb[kb][r >> 3][r & 7] = (half_t)e.x;
+                pb[kb][r >> 3][(r & 7) + 1] = (half_t)e.y;
+            }
+            if (!SUMROW) l_run += rs;
+        };
+        // barrier k (0 .. NB-1) of this iteration; in the last iteration group g skips its final g barriers (they have no partner)
+        auto bar = [&](int k, bool wait_lds) {
+            if (!(t + 1 == T && k >= NB - grp)) section_barrier(wait_lds);
+        };
+        exp_block(0);
+        if constexpr (NG == 3) {
+            // three groups: the VALU work of a tile is split over two sections (max + first key block | second key block + operand
+            // reads), so that TWO waves of a SIMD are in VALU sections while the third is in its MFMA section — one wave alone issues a
+            // VALU instruction only every 6-9 cycles (profiles/r02_valu_rates.txt), which made the two-group form VALU-latency bound
+            asm volatile("" :: "v"(pb[0][0]), "v"(pb[0][1]));
+            bar(0, false);
+        }
+#pragma unroll
+        for (int kb = 1; kb < NKB; ++kb) exp_block(kb);
         // operands of M(t) from pair t (slot t % 3: complete since the end of section M(t-2) of the second group)
         {
             const char* tile = smem + (t % NSLOT) * SLOT;
@@ -672,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
         // P(t) must exist BEFORE the barrier: without a use here the compiler sinks the exponentials into the M section
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) asm volatile("" :: "v"(pb[kb][0]), "v"(pb[kb][1]));
-        section_barrier(false);
+        bar(NB - 2, false);
         // ================================ M section: O += V^T(t) P^T(t), S(t+1) = K(t+1) Q^T ================================
         // (S(T) of the last iteration is computed from clamped rows and never used: no branch in the MFMA stream)
 #pragma unroll
@@ -700,7 +714,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(AttnP p) {
                 for (int kb = 0; kb < NKB; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kaf[step][kb], qf[step], sc[kb], 0, 0, 0);
             }
         }
-        if (!(grp == 1 && t + 1 == T)) section_barrier();     // (the second group's last barrier would have no partner)
+        bar(NB - 1, true);
     }
 
     // ---- normalise and store: o[db][r] is O[q][db*32 + (r&3) + 8*(r>>2) + 4*half] ----------------------------
@@ -815,18 +829,18 @@ static int launch_attn_d(const AttnP& p, hipStream_t s) {
     return 0;
 }
 
-template <int D, bool FOLD>
+template <int D, bool FOLD, int NG = 2>
 static int launch_attn_pp(const AttnP& p, hipStream_t s) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
-    constexpr int SMEM = 3 * (64 * (DK * 2 + 16) + DV * (64 * 2 + 16)) + 64 * (DK * 2 + 16) + 512 * 16;   // 3 pairs, K(0), dump slots
-    auto kern = attn_pp_kernel<D, FOLD>;
+    constexpr int SMEM = 3 * (64 * (DK * 2 + 16) + DV * (64 * 2 + 16)) + 64 * (DK * 2 + 16) + NG * 256 * 16;   // 3 pairs, K(0), dump slots
+    auto kern = attn_pp_kernel<D, FOLD, NG>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    dim3 grid(cdiv(p.N, 256), p.B * p.H);
-    hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, p);
+    dim3 grid(cdiv(p.N, NG * 128), p.B * p.H);
+    hipLaunchKernelGGL(kern, grid, dim3(NG * 256), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -847,6 +861,9 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
                 // 20 / 21: the role-offset 8-wave kernel (21: softmax shift folded into the S^T MFMA) for the long self-attention launches
                 if ((g_attn_occ == 20 || g_attn_occ == 21) && p.M >= g_attn_pp_min_m && p.N >= 256)
                     return g_attn_occ == 21 ? launch_attn_pp<40, true>(p, s) : launch_attn_pp<40, false>(p, s);
+                // 30 / 31: the same with THREE groups (12 waves, 384 queries per workgroup; VALU work split over two sections)
+                if ((g_attn_occ == 30 || g_attn_occ == 31) && p.M >= g_attn_pp_min_m && p.N >= 384)
+                    return g_attn_occ == 31 ? launch_attn_pp<40, true, 3>(p, s) : launch_attn_pp<40, false, 3>(p, s);
                 if (!(kvt128 && p.M > 64)) {
                     if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
                     if (g_attn_occ == 15) return launch_attn_d<40, 64, 15>(p, s);

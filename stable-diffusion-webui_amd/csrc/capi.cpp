@@ -489,6 +489,7 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "tile_order") g_tile_order = value;
     else if (n == "conv_korder") g_conv_korder = value;
     else if (n == "gn_fuse") g_gn_fuse = value;
+    else if (n == "gn_small") g_gn_small = value;
     else if (n == "ep_wide") g_ep_wide = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "attn_occ") g_attn_occ = value;
@@ -540,7 +541,7 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     else if (n == "glds") e->use_glds = value != 0;
     else if (n == "trace") { e->trace = value != 0; e->taps.clear(); }
     else if (n == "tiling") e->tiling = value != 0;
-    else if (n == "ln_fold") e->ln_fold = value != 0;
+    else if (n == "ln_fold") e->ln_fold = value;
     else if (n == "streams") { if (value < 1 || value > 8) { sdmi::set_error("streams must be 1..8"); return 1; } e->n_streams = value; }
     else if (n == "vae_range_extend") e->vae_stream_scale = value ? 1.0f / 64.0f : 1.0f;
     else { set_error("unknown option " + n); return 1; }

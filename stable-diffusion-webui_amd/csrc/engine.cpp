@@ -669,7 +669,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     half_t* cur = r.H(M * C);
     // with "ln_fold" the GEMMs that write a LayerNorm's input also leave its row sums (Run::lnp_want; a no-op otherwise)
     const bool fold_any = e->ln_fold && !hn_has_dim(e, C) && !e->force_generic && e->use_glds && g_vt_mode == 1 && HW == Npad && HW % 4 == 0;
-    r.lnp_want = fold_any;
+    r.lnp_want = fold_any && e->ln_fold >= 2;
     TRY(run_linear(r, st.proj_in, n0, (int)M, nullptr, cur, C));
     int bi = 0;
     for (const TBlockW& b : st.blocks) {
@@ -721,7 +721,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(run_attn(r, q, k, vt, a1, B, st.heads, HW, HW, st.dhead, C, C, Npad, C));
         }
         half_t* x1 = r.H(M * C);
-        r.lnp_want = fold;
+        r.lnp_want = fold && e->ln_fold >= 2;
         TRY(run_linear(r, b.o1, a1, (int)M, cur, x1, C));
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
@@ -753,7 +753,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(launch_attention(p, e->force_generic, r.s));
         }
         half_t* x2 = r.H(M * C);
-        r.lnp_want = fold;
+        r.lnp_want = fold && e->ln_fold >= 2;
         TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C));
         r.tap(bname + ".attn2+x", x2, B, H, Wd, C);
         // --- feed forward (GEGLU fused in the first GEMM's epilogue)
@@ -770,7 +770,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
         }
         half_t* x3 = r.H(M * C);
-        r.lnp_want = fold;                                   // read by the next block's norm1 (SDXL: depth > 1); unused after the last
+        r.lnp_want = fold && e->ln_fold >= 2;                                   // read by the next block's norm1 (SDXL: depth > 1); unused after the last
         TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
         r.tap(bname, x3, B, H, Wd, C);
         cur = x3;

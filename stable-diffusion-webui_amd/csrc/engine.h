@@ -197,7 +197,7 @@ struct sdmi_engine {
     float vae_stream_scale = 1.f;
     // LayerNorm folded into the consuming GEMMs of the transformer blocks (norm1 -> to_q|to_k, to_v; norm2 -> attn2.to_q; norm3 ->
     // ff.net.0): only the per-row (mean, rstd) are computed, the normalised tensors never reach HBM.  Off by default until measured.
-    bool ln_fold = false;
+    int ln_fold = 0;                          // 1: row statistics from ln_rowstats_kernel; 2: also per-tile partial sums from the producing GEMMs' epilogues
     long weights_epoch = 0;                   // bumped by every in-place weight / vector update: folded copies older than this are stale
     bool tiling = false;                      // p.tiling: every padded 3x3 conv wraps around (modules/sd_hijack.py:311-318)
     // activation taps (parity error budget): with `trace` on, every block output of the last forward is recorded by name

@@ -183,6 +183,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
     // ---- epilogue ----------------------------------------------------------------------------------------
     // lane holds, for tile (i, j):  m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r
     const int flags = p.flags;
+    // LNF: (mean, rstd) of the lane's TM rows, fetched ONCE, all loads in flight together (round 3: fetched per column tile inside the
+    // j loops — TN dependent 8-byte loads per row pair — the folded layers ran 2x slower than LayerNorm + plain GEMM)
+    [[maybe_unused]] f2e lst[LNF ? TM : 1];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lst[i] = row_stat(min(m0 + wr * WTM + i * 16 + (lane & 15), p.M - 1));
+    }
     const long ob = z * p.o_bs, rbs = z * p.r_bs;
     if (p.splitk > 1) {
         float* slab = p.splitk_ws + ((long)blockIdx.y * gridDim.z + z) * (long)p.M * p.N;
@@ -370,7 +377,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                 for (int t = 0; t < 2; ++t) {
                                     const f4 va = acc[2 * a + t][jg * 4 + j], vg = acc[2 * a + t][jg * 4 + j + 2];
                                     [[maybe_unused]] f2e st;
-                                    if constexpr (LNF) st = row_stat(min(m0 + wr * WTM + (2 * a + t) * 16 + lr, p.M - 1));
+                                    if constexpr (LNF) st = lst[2 * a + t];
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
                                         float av, g;
@@ -435,7 +442,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { vx[r] *= p.alpha; vy[r] *= p.alpha; }
                         if constexpr (LNF) {
-                            const f2e sx = row_stat(mx), sy = row_stat(my);
+                            const f2e sx = lst[2 * a], sy = lst[2 * a + 1];
                             const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { vx[r] = sx[1] * (vx[r] - sx[0] * sv[r]); vy[r] = sy[1] * (vy[r] - sy[0] * sv[r]); }
@@ -558,7 +565,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         }
                         h4 o;
                         if constexpr (LNF) {
-                            const f2e st = row_stat(m);
+                            const f2e st = lst[i];
                             const f4 sva = *reinterpret_cast<const f4*>(p.ln_s + npk), svg = *reinterpret_cast<const f4*>(p.ln_s + npk + 32);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -586,7 +593,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
             if constexpr (LNF) {
-                const f2e st = row_stat(m);
+                const f2e st = lst[i];
                 const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = st[1] * (v[r] - st[0] * sv[r]);

@@ -16,6 +16,7 @@
 #include "prof.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace sdmi {
 
@@ -171,6 +172,81 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
     }
 }
 
+// Single-launch GroupNorm(+SiLU) for the small levels (8x8 / 16x16 / 32x32 latents: 2.6 - 40 MB tensors that the two-pass pair above
+// spends ~20 us on whatever their size — two dependent launches of 32 workgroups each, one pixel loop per thread): one workgroup per
+// (image, group) holds the group's HW x cpg values in registers (<= NVT 16-byte vectors per thread), so the tensor is read ONCE;
+// mean first, then the centred sum of squares (two-pass in registers), fixed reduction order (lane partials -> wave shuffle tree ->
+// LDS -> every thread adds the 4 wave sums in order): deterministic.  Needs cpg % 8 == 0 (C = 256, 512, 1280, 2560 at 32 groups).
+template <int NVT>
+__global__ __launch_bounds__(256) void gn_fused_small_kernel(const half_t* x0, const half_t* x1, int c0, int c1, int HW, int groups,
+                                                             const float* gamma, const float* beta, half_t* out, float eps, int silu) {
+    __shared__ float red[2][4];
+    const int C = c0 + c1, cpg = C / groups, VW = cpg / 8;
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cbase = g * cpg;
+    // the group lies in one source or straddles the concatenation point at a vector boundary (c0 % 8 == 0)
+    const half_t* x0b = x0 + (long)b * HW * c0;
+    const half_t* x1b = x1 ? x1 + (long)b * HW * c1 : nullptr;
+    h8 v[NVT];
+    int off[NVT], cch[NVT];                                  // element offset of the vector in the OUTPUT image (pixel * C + channel); channel
+    float s = 0.f;
+    // (pixel, vector) pairs advanced by the stride's quotient / remainder: no division by the runtime VW per vector
+    const int sp = 256 / VW, sr = 256 - sp * VW;
+    int pix = tid / VW, vc = tid - pix * VW;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+        const bool ok = pix < HW;
+        const int pp = ok ? pix : 0;
+        const int c = cbase + vc * 8;
+        off[k] = ok ? pp * C + c : -1;
+        cch[k] = c;
+        const half_t* src = c < c0 ? x0b + (long)pp * c0 + c : x1b + (long)pp * c1 + (c - c0);
+        h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        v[k] = ok ? *reinterpret_cast<const h8*>(src) : z;
+        pix += sp; vc += sr;
+        if (vc >= VW) { vc -= VW; ++pix; }
+    }
+#pragma unroll
+    for (int k = 0; k < NVT; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)v[k][e];      // vectors past the end hold zeros
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[0][tid >> 6] = s;
+    __syncthreads();
+    const float n = (float)cpg * (float)HW;
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k)
+        if (off[k] >= 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[k][e] - mean; q = fmaf(d, d, q); }
+        }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if ((tid & 63) == 0) red[1][tid >> 6] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n + eps);
+    half_t* outb = out + (long)b * HW * C;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+        if (off[k] < 0) continue;
+        const int c = cch[k];
+        const f4 g0 = *reinterpret_cast<const f4*>(gamma + c), g1 = *reinterpret_cast<const f4*>(gamma + c + 4);
+        const f4 b0 = *reinterpret_cast<const f4*>(beta + c), b1 = *reinterpret_cast<const f4*>(beta + c + 4);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gm = e < 4 ? g0[e] : g1[e - 4], bt = e < 4 ? b0[e] : b1[e - 4];
+            float y = fmaf(((float)v[k][e] - mean) * rstd, gm, bt);
+            if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+            o[e] = (half_t)y;
+        }
+        *reinterpret_cast<h8*>(outb + off[k]) = o;
+    }
+}
+
+int g_gn_small = [] { const char* e = getenv("SDMI_GN_SMALL"); return e ? atoi(e) : 1; }();
+
 static inline int gn_chunks(int B, int HW) {
     // ~1024 workgroups over the batch (4 per CU), >= 32 pixels per chunk, <= 64 chunks: few enough partials that the
     // apply kernel's prologue (a dependent chain of global loads per workgroup) stays short
@@ -189,9 +265,25 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
     SDMI_REQUIRE((long)HW * C < (1L << 31) && HW < (1 << 24), "GroupNorm: HW * C must stay below 2^31 elements per image (32-bit offsets)");
+    char pname[64];
+    {
+        const int cpg = C / groups;
+        const long nv = (long)HW * (cpg / 8);
+        if (pre_nchunk <= 0 && g_gn_small && cpg % 8 == 0 && nv <= 24 * 256) {
+            snprintf(pname, sizeof pname, "groupnorm_silu_fused B%d HW%d C%d", B, HW, C);
+            ProfScope ps(pname, 0.0, 2.0 * B * (double)HW * C * 2.0, s);                            // read once + write once
+            const dim3 grid(groups, B);
+#define SDMI_GNS(NVT) hipLaunchKernelGGL((gn_fused_small_kernel<NVT>), grid, dim3(256), 0, s, x0, x1, c0, c1, HW, groups, gamma, beta, out, eps, silu ? 1 : 0)
+            if (nv <= 4 * 256) SDMI_GNS(4);
+            else if (nv <= 12 * 256) SDMI_GNS(12);
+            else SDMI_GNS(24);
+#undef SDMI_GNS
+            SDMI_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     const int nchunk = pre_nchunk > 0 ? pre_nchunk : gn_chunks(B, HW);
     const int rows = cdiv(HW, nchunk);
-    char pname[64];
     snprintf(pname, sizeof pname, pre_nchunk > 0 ? "groupnorm_silu_apply B%d HW%d C%d" : "groupnorm_silu B%d HW%d C%d", B, HW, C);
     ProfScope ps(pname, 0.0, (pre_nchunk > 0 ? 2.0 : 3.0) * B * (double)HW * C * 2.0, s);      // read (twice) + write once
     if (pre_nchunk <= 0) {

@@ -649,7 +649,9 @@ def test_kernels_compile_without_scratch_or_spills():
                 loop = body[body.index("s_setprio 1"):body.rindex("s_setprio 0")]
                 assert "v_readlane" not in loop and "v_writelane" not in loop, f"{kname}: SGPR spill traffic inside the K loop"
             assert field("vgpr_count") <= (256 if "pingpong" in kname else 512), kname     # 8-wave workgroups: 2 waves per SIMD
-            if "gn_" in kname or "layernorm" in kname:
+            # (gn_fused_small_kernel is the opposite design on purpose: one (image, group) slice held entirely in registers, every load
+            # of a thread issued up front — its latency hiding is the 4 .. 24 loads in flight per thread, not the wave count)
+            if ("gn_" in kname and "gn_fused_small" not in kname) or "layernorm" in kname:
                 assert field("vgpr_count") <= 128, (kname, field("vgpr_count"))
     assert any("gemm_mfma_pingpong_kernel" in k for k in seen) and any("attn_mfma_kernel" in k for k in seen) and len(seen) > 40
 

@@ -443,11 +443,12 @@ def test_attention_softmax_is_shift_invariant_and_handles_spikes(dev):
     assert float((got[0, 5].float().cpu() - ref[0, 5]).abs().max()) < 2e-2
 
 
-@pytest.mark.parametrize("variant", [20, 21])
+@pytest.mark.parametrize("variant", [20, 21, 30, 31])
 def test_attention_role_offset_kernel(dev, variant):
     """The 8-wave role-offset kernel (attn_occ 20; 21 = with the softmax shift folded into the S^T MFMA: Q pre-multiplied by
     scale * log2 e, K's padding column at 1.0, Q's padding element at -shift): level-0 / hires shapes, ragged query and key counts, 1 to
-    9 KV tiles, d = 64 (SDXL; no padding column, so 21 runs the unfolded arithmetic there) — against fp32; the unfolded form runs
+    9 KV tiles, d = 64 (SDXL; no padding column, so 21 runs the unfolded arithmetic there); 30 / 31 = the same two forms with THREE wave
+    groups (12 waves, 384 queries per workgroup, the VALU work of a tile split over two sections) — against fp32; the unfolded form runs
     variant 15's arithmetic in variant 15's order and must give its bits.  Then the shift logic of 21 on adversarial rows: a spike
     late in the sequence, scores that rise tile after tile (the shift is raised in every tile), all scores far below zero (first-tile
     initialisation with a negative shift) and far above (shift near 100: fp16 spacing 0.06)."""
@@ -463,17 +464,17 @@ def test_attention_role_offset_kernel(dev, variant):
         return out
 
     for d, heads, n, m in ((40, 8, 512, 512), (40, 2, 256, 256), (40, 1, 300, 333), (40, 2, 1024, 576), (40, 1, 256, 290), (40, 8, 4096, 4096),
-                           (64, 2, 512, 512), (64, 1, 260, 400)):
+                           (40, 2, 384, 256), (40, 1, 768, 320), (40, 1, 700, 449), (64, 2, 512, 512), (64, 1, 260, 400)):
         b = 1 if n >= 4096 else 2
         q, k, v = seeded((b, n, heads * d), 61), seeded((b, m, heads * d), 62), seeded((b, m, heads * d), 63)
         got = run(q, k, v, heads, variant)
         e = rel_l2(got.float().cpu(), _attn_ref(h(q), h(k), h(v), heads))
         assert e < 5e-4, (d, heads, n, m, e)
-        if variant == 20 or d != 40:
+        if variant in (20, 30) or d != 40:
             base = run(q, k, v, heads, 15 if d == 40 else 0)
             assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (d, heads, n, m)
     # adversarial rows for the shift bookkeeping
-    d, heads, n, m = 40, 1, 256, 576
+    d, heads, n, m = 40, 1, 384, 576
     q, k, v = seeded((1, n, d), 71), seeded((1, m, d), 72), seeded((1, m, d), 73)
     k2 = k.clone()
     k2[0, 500] = q[0, 5] * 6.0                                # spike for query 5 in the 8th KV tile
@@ -494,7 +495,11 @@ def test_attention_role_offset_kernel(dev, variant):
 # norms
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("c0,c1,hw", [(320, 0, (8, 8)), (64, 0, (16, 16)), (1280, 640, (4, 4)), (128, 64, (32, 32)),
-                                      (2560, 0, (8, 8)), (128, 0, (64, 64))])
+                                      (2560, 0, (8, 8)), (128, 0, (64, 64)),
+                                      # the single-launch register-resident kernel (cpg % 8 == 0, <= 24 vectors per thread): one and two
+                                      # sources, 4 / 12 / 24 vectors per thread, a pixel count that is not a multiple of the stride
+                                      (1280, 0, (8, 8)), (1280, 1280, (16, 16)), (1280, 0, (32, 32)), (512, 0, (16, 16)), (256, 0, (8, 8)),
+                                      (1280, 1280, (5, 7)), (2560, 0, (16, 16))])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_silu_vs_torch(dev, c0, c1, hw, silu):
     ops = sub("ops")
