@@ -675,15 +675,21 @@ def sample_lcm(model, x, sigmas, extra_args, noise_fn, callback=None):
     return x
 
 
-def sample_euler(model, x, sigmas, extra_args, noise_fn=None, callback=None):
-    """s_churn = 0 (reference default, modules/sd_samplers_common.py:242): sigma_hat == sigma."""
+def sample_euler(model, x, sigmas, extra_args, noise_fn=None, callback=None, s_churn=0.0, s_tmin=0.0, s_tmax=float('inf'), s_noise=1.0):
+    """k-diffusion sample_euler (Algorithm 2 of Karras et al.).  s_churn = 0 is the reference default
+    (modules/sd_samplers_common.py:242): sigma_hat == sigma and the loop is the one pinned bit-exactly to
+    modules/models/sd3/sd3_impls.py:145-163 (tests/golden/euler_twin.npz); with s_churn > 0 the noise level is first raised to
+    sigma_hat = sigma * (1 + gamma) with fresh noise (drawn only for the churned steps, as k-diffusion @ ab527a9a does)."""
     s_in = x.new_ones([x.shape[0]])
     for i in range(len(sigmas) - 1):
-        denoised = model(x, sigmas[i] * s_in, **extra_args)
-        d = to_d(x, sigmas[i], denoised)
+        sigma_hat, gamma = _churn(sigmas, i, s_churn, s_tmin, s_tmax)
+        if gamma > 0:
+            x = x + noise_fn() * s_noise * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
+        denoised = model(x, sigma_hat * s_in, **extra_args)
+        d = to_d(x, sigma_hat, denoised)
         if callback is not None:
-            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
-        dt = sigmas[i + 1] - sigmas[i]
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        dt = sigmas[i + 1] - sigma_hat
         x = x + d * dt
     return x
 

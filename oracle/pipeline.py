@@ -60,7 +60,8 @@ def get_sigmas(model_wrap: kd.CompVisDenoiser, sampler: str, steps: int, schedul
 def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0,
            latent_hw=(64, 64), eta=None, s_noise=1.0, init_latent=None, denoising_strength=0.75,
            y=None, uy=None, record=None, img2img_steps_given=True, scheduler="automatic", mask=None, parameterization="eps",
-           s_min_uncond=0.0, image_cond=None, image_cfg_scale=None, noise_multiplier=1.0, refiner=None):
+           s_min_uncond=0.0, image_cond=None, image_cfg_scale=None, noise_multiplier=1.0, refiner=None, s_churn=0.0, s_tmin=0.0,
+           s_tmax=float("inf"), unipc_options=None):
     """Returns final latents (B,4,h,w) fp32.  ``init_latent`` switches to the img2img arithmetic
     (modules/sd_samplers_kdiffusion.py:134-143); ``mask`` (1 = keep the original latent) adds the inpainting blends of
     modules/sd_samplers_cfg_denoiser.py:186-187 / 292-293 and the final blend of modules/processing.py:1776-1784."""
@@ -120,7 +121,8 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
             ts = ts[:t_enc]
         if sampler == "unipc":                   # default opts.uni_pc_* (modules/shared_options.py:402-405)
             from . import unipc
-            return finish(unipc.sample_unipc(cfg, x, ts, model.alphas_cumprod, extra, callback=record, is_img2img=init_latent is not None))
+            return finish(unipc.sample_unipc(cfg, x, ts, model.alphas_cumprod, extra, callback=record, is_img2img=init_latent is not None,
+                                             **(unipc_options or {})))      # opts.uni_pc_variant / _skip_type / _order / _lower_order_final
         if sampler == "plms":
             return finish(kd.sample_plms(cfg, x, ts, model.alphas_cumprod, extra, callback=record))
         if sampler == "ddim_cfgpp":
@@ -180,6 +182,8 @@ def sample(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cf
           "lms": kd.sample_lms}.get(sampler)
     if fn is None:
         raise ValueError(sampler)
+    if sampler in ("euler", "heun", "dpm_2") and s_churn:     # opts.s_churn / s_tmin / s_tmax / s_noise (sd_samplers_kdiffusion.py:164-183)
+        return finish(fn(cfg, x, sigmas, extra, noise_fn=rng.next, callback=record, s_churn=s_churn, s_tmin=s_tmin, s_tmax=s_tmax, s_noise=s_noise))
     return finish(fn(cfg, x, sigmas, extra, callback=record))
 
 

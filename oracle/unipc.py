@@ -12,7 +12,8 @@ Restates, in fp32 torch on the CPU,
                                                        img2img start t = timesteps[-1]/1000 + 1/1000
 
 Pinned by tests/golden/unipc.npz, which tests/golden/make_golden.py::gen_unipc produces by executing those reference files.
-The 'vary_coeff' variant (uni_pc.py:522-623) is not restated.
+The 'vary_coeff' variant (uni_pc.py:522-623) is restated by _vary_update, including the reference's use of row K-2 of the inverted
+coefficient matrix for the corrector's newest-difference term (its loop variable after the loop).
 """
 import torch
 
@@ -121,6 +122,61 @@ def _bh_update(ns, model_fn, x, m_list, t_list, t, order, variant, use_corrector
     return x_t, model_t
 
 
+def _vary_update(ns, model_fn, x, m_list, t_list, t, order, use_corrector):
+    """uni_pc.py:522-623 (multistep_uni_pc_vary_update), predict_x0 branch."""
+    assert order <= len(m_list)
+    t_p0, m0 = t_list[-1], m_list[-1]
+    lam_p0, lam_t = ns.lam(t_p0), ns.lam(t)
+    sig_p0, sig_t = ns.std(t_p0), ns.std(t)
+    alpha_t = torch.exp(ns.log_mean_coeff(t))
+    h = lam_t - lam_p0
+    rks, d1s = [], []
+    for i in range(1, order):
+        rk = ((ns.lam(t_list[-(i + 1)]) - lam_p0) / h)[0]
+        rks.append(rk)
+        d1s.append((m_list[-(i + 1)] - m0) / rk)
+    rks.append(1.)
+    rks = torch.tensor(rks)
+    K = len(rks)
+    cols, col = [], torch.ones_like(rks)
+    for k in range(1, K + 1):                                            # C[i][k-1] = rks_i^(k-1) / k!
+        cols.append(col)
+        col = col * rks / (k + 1)
+    C = torch.stack(cols, dim=1)
+    a_p = torch.linalg.inv(C[:-1, :-1]) if d1s else None
+    a_c = torch.linalg.inv(C) if use_corrector else None
+    hh = -h[0]
+    h_phi_1 = torch.expm1(hh)
+    h_phi_ks, fact, h_phi_k = [], 1, h_phi_1
+    for k in range(1, K + 2):
+        h_phi_ks.append(h_phi_k)
+        h_phi_k = h_phi_k / hh - 1 / fact
+        fact *= (k + 1)
+    e4 = lambda v: v.reshape(-1, 1, 1, 1)
+    d1s = torch.stack(d1s, dim=1) if d1s else None                       # [B, K-1, C, H, W]
+    x_base = e4(sig_t / sig_p0) * x - e4(alpha_t * h_phi_1) * m0
+    x_t = x_base
+    if d1s is not None:
+        for k in range(K - 1):
+            x_t = x_t - e4(alpha_t * h_phi_ks[k + 1]) * torch.einsum('bkchw,k->bchw', d1s, a_p[k])
+    model_t = None
+    if use_corrector:
+        model_t = model_fn(x_t, t)
+        d1_t = model_t - m0
+        x_t = x_base
+        k = 0
+        for k in range(K - 1):
+            x_t = x_t - e4(alpha_t * h_phi_ks[k + 1]) * torch.einsum('bkchw,k->bchw', d1s, a_c[k][:-1])
+        x_t = x_t - e4(alpha_t * h_phi_ks[K]) * (d1_t * a_c[k][-1])     # (k = K-2 after the loop, 0 without one: as the reference)
+    return x_t, model_t
+
+
+def _update(ns, model_fn, x, m_list, t_list, t, order, variant, use_corrector):
+    if variant == 'vary_coeff':
+        return _vary_update(ns, model_fn, x, m_list, t_list, t, order, use_corrector)
+    return _bh_update(ns, model_fn, x, m_list, t_list, t, order, variant, use_corrector)
+
+
 def sample_unipc(model, x, timesteps, alphas_cumprod, extra_args, callback=None, is_img2img=False, variant='bh1',
                  skip_type='time_uniform', order=3, lower_order_final=True):
     """unipc() of modules/sd_samplers_timesteps_impl.py:170-179 + UniPC.sample(method='multistep') of uni_pc.py:746-805.
@@ -147,14 +203,14 @@ def sample_unipc(model, x, timesteps, alphas_cumprod, extra_args, callback=None,
     m_list, t_list = [model_fn(x, vec_t)], [vec_t]
     for init_order in range(1, order):                                   # warm-up with increasing order
         vec_t = ts[init_order].expand(bsz)
-        x, model_x = _bh_update(ns, model_fn, x, m_list, t_list, vec_t, init_order, variant, True)
+        x, model_x = _update(ns, model_fn, x, m_list, t_list, vec_t, init_order, variant, True)
         after_update(x, model_x)
         m_list.append(model_x)
         t_list.append(vec_t)
     for step in range(order, steps + 1):
         vec_t = ts[step].expand(bsz)
         step_order = min(order, steps + 1 - step) if lower_order_final else order
-        x, model_x = _bh_update(ns, model_fn, x, m_list, t_list, vec_t, step_order, variant, step != steps)
+        x, model_x = _update(ns, model_fn, x, m_list, t_list, vec_t, step_order, variant, step != steps)
         after_update(x, model_x)
         for i in range(order - 1):
             t_list[i], m_list[i] = t_list[i + 1], m_list[i + 1]

@@ -543,17 +543,22 @@ def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, dis
 
 
 def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0.,
-                 s_tmax=float('inf'), s_noise=1.):
-    if s_churn:
-        raise NotImplementedError("s_churn > 0 is not implemented (reference default 0.0)")
+                 s_tmax=float('inf'), s_noise=1., noise_sampler=None):
+    """Algorithm 2 of Karras et al. (k-diffusion sample_euler).  With s_churn > 0 (opts.s_churn / p.s_churn,
+    modules/sd_samplers_kdiffusion.py:36-39, 164-183) a step first raises the noise level to sigma_hat = sigma * (1 + gamma) by adding
+    s_noise * sqrt(sigma_hat^2 - sigma^2) * eps — eps from the job's ImageRNG, the randn_like k-diffusion draws through the webui's
+    TorchHijack — and then takes the Euler step from sigma_hat: one extra sdmi_lincomb per churned step, the step itself stays fused."""
     extra_args = {} if extra_args is None else extra_args
     x = x.contiguous()
     s_in = x.new_ones([x.shape[0]])
     for i in range(len(sigmas) - 1):
-        denoised = model(x, sigmas[i] * s_in, **extra_args)
+        sigma_hat, gamma = _churn(sigmas, i, s_churn, s_tmin, s_tmax)
+        if gamma > 0:
+            x = _lc(torch.empty_like(x), [x, noise_sampler(sigmas[i], sigmas[i + 1])], [1.0, s_noise * float((sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5)])
+        denoised = model(x, sigma_hat * s_in, **extra_args)
         if callback is not None:
-            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigmas[i], 'denoised': denoised})
-        check(lib.sdmi_euler_step(ptr(x), ptr(denoised), None, float(sigmas[i]), float(sigmas[i + 1]), 0.0, 0.0, x.numel(),
+            callback({'x': x, 'i': i, 'sigma': sigmas[i], 'sigma_hat': sigma_hat, 'denoised': denoised})
+        check(lib.sdmi_euler_step(ptr(x), ptr(denoised), None, float(sigma_hat), float(sigmas[i + 1]), 0.0, 0.0, x.numel(),
                                   stream_ptr()), "euler_step")
     return x
 
@@ -1268,7 +1273,7 @@ def _unipc_bh_coefs(ns, t_hist, t, order, variant, use_corrector):
     elif variant == 'bh2':
         b_h = torch.expm1(hh)
     else:
-        raise NotImplementedError(f"UniPC variant {variant!r} (only bh1 / bh2)")
+        raise ValueError(f"unknown UniPC variant {variant!r}")
     h_phi_k = h_phi_1 / hh - 1
     fact = 1
     rows, b = [], []
@@ -1289,6 +1294,48 @@ def _unipc_bh_coefs(ns, t_hist, t, order, variant, use_corrector):
         rhos_c = [0.5] if order == 1 else torch.linalg.solve(r_mat, b).tolist()
         corr = [c_x, c_m0 + ab * (sum(c / r for c, r in zip(rhos_c[:-1], rk)) + rhos_c[-1]),
                 *[-ab * c / r for c, r in zip(rhos_c[:-1], rk)], -ab * rhos_c[-1]]
+    return pred, corr
+
+
+def _unipc_vary_coefs(ns, t_hist, t, order, use_corrector):
+    """Scalar part of multistep_uni_pc_vary_update (uni_pc.py:522-623), predict_x0 form, folded like _unipc_bh_coefs.  With
+    C[i][k] = r_i^k / (k+1)!, A_p = inv(C[:-1, :-1]), A_c = inv(C) and h_phi_k the phi-function ladder:
+        x_pred = x_base - alpha_t sum_{k < K-1} h_phi_{k+1} (A_p[k] . D)
+        x_corr = x_base - alpha_t sum_{k < K-1} h_phi_{k+1} (A_c[k][:-1] . D) - alpha_t h_phi_K A_c[K-2][-1] (m_t - m_0)
+    (row K-2 — the reference's loop variable after the loop; row 0 when K = 1).  The reference multiplies its [B] schedule vectors into
+    x unexpanded (:584) and therefore only runs at batch 1; the folded coefficients are per step, so any batch works here."""
+    lam0, lam_t = ns.lam(t_hist[-1]), ns.lam(t)
+    (_, sig0), (alpha_t, sig_t) = ns.alpha_sigma(t_hist[-1]), ns.alpha_sigma(t)
+    h = lam_t - lam0
+    rks = [((ns.lam(t_hist[-(i + 1)]) - lam0) / h)[0] for i in range(1, order)]
+    rks_t = torch.tensor([*rks, 1.])
+    K = order
+    cols, col = [], torch.ones_like(rks_t)
+    for k in range(1, K + 1):
+        cols.append(col)
+        col = col * rks_t / (k + 1)
+    C = torch.stack(cols, dim=1)
+    hh = -h[0]
+    h_phi_1 = torch.expm1(hh)
+    h_phi_ks, fact, h_phi_k = [], 1, h_phi_1
+    for k in range(1, K + 2):
+        h_phi_ks.append(h_phi_k)
+        h_phi_k = h_phi_k / hh - 1 / fact
+        fact *= (k + 1)
+    c_x, c_m0 = float(sig_t / sig0), -float(alpha_t * h_phi_1)
+    rk = [float(r) for r in rks]
+    at = float(alpha_t)
+    w = [0.0] * (K - 1)
+    if K > 1:
+        a_p = torch.linalg.inv(C[:-1, :-1])
+        w = [sum(at * float(h_phi_ks[k + 1]) * float(a_p[k][j]) for k in range(K - 1)) for j in range(K - 1)]
+    pred = [c_x, c_m0 + sum(wj / r for wj, r in zip(w, rk)), *[-wj / r for wj, r in zip(w, rk)]]
+    corr = None
+    if use_corrector:
+        a_c = torch.linalg.inv(C)
+        v = [sum(at * float(h_phi_ks[k + 1]) * float(a_c[k][j]) for k in range(K - 1)) for j in range(K - 1)]
+        u = at * float(h_phi_ks[K]) * float(a_c[K - 2 if K >= 2 else 0][-1])
+        corr = [c_x, c_m0 + sum(vj / r for vj, r in zip(v, rk)) + u, *[-vj / r for vj, r in zip(v, rk)], -u]
     return pred, corr
 
 
@@ -1313,7 +1360,10 @@ def unipc(model, x, timesteps, extra_args=None, callback=None, disable=None, is_
         return _lc(torch.empty_like(xx), [xx, eps], [1.0 / float(alpha_t), -float(sigma_t) / float(alpha_t)])
 
     def update(xx, m_hist, t_hist, t, step_order, use_corrector):
-        pred, corr = _unipc_bh_coefs(ns, t_hist, t, step_order, variant, use_corrector)
+        if variant == 'vary_coeff':
+            pred, corr = _unipc_vary_coefs(ns, t_hist, t, step_order, use_corrector)
+        else:
+            pred, corr = _unipc_bh_coefs(ns, t_hist, t, step_order, variant, use_corrector)
         hist = [m_hist[-(i + 1)] for i in range(step_order)]              # m_0 (newest), m_1, ...
         x_t = _lc_long([xx, *hist], pred)
         model_t = None

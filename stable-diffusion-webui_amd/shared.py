@@ -14,7 +14,7 @@ class Options:
     eta_noise_seed_delta: int = 0                  # :399
     eta_ancestral: float = 1.0                     # :390
     eta_ddim: float = 0.0                          # :389
-    uni_pc_variant: str = "bh1"                    # :402  (bh1 | bh2; vary_coeff is not implemented)
+    uni_pc_variant: str = "bh1"                    # :402  (bh1 | bh2 | vary_coeff)
     uni_pc_skip_type: str = "time_uniform"         # :403
     uni_pc_order: int = 3                          # :404
     uni_pc_lower_order_final: bool = True          # :405

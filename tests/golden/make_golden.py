@@ -410,8 +410,8 @@ def gen_lora_names():
 
 def gen_unipc():
     """modules/sd_samplers_timesteps_impl.py:144-190 (UniPCCFG + unipc()) over the real modules/models/diffusion/uni_pc/uni_pc.py,
-    with a fixed analytic eps model; covers the three skip types, both B(h) variants, orders 1-4, lower_order_final off and the
-    img2img start."""
+    with a fixed analytic eps model; covers the three skip types, both B(h) variants and vary_coeff, orders 1-4, lower_order_final off
+    and the img2img start."""
     kd = types.ModuleType("k_diffusion")
     kds = types.ModuleType("k_diffusion.sampling")
     kd.sampling = kds
@@ -451,6 +451,12 @@ def gen_unipc():
         (6, "bh1", "time_uniform", 1, True, 0),
         (12, "bh1", "time_uniform", 4, True, 0),
         (20, "bh1", "time_uniform", 3, True, 11),
+        # vary_coeff: the reference's update multiplies the [B] schedule vectors into x without expanding them (uni_pc.py:584), so it
+        # only runs at batch 1 (it raises a broadcasting error otherwise): pinned at batch 1
+        (10, "vary_coeff", "time_uniform", 3, True, 0),
+        (8, "vary_coeff", "time_quadratic", 2, True, 0),
+        (7, "vary_coeff", "logSNR", 1, True, 0),
+        (9, "vary_coeff", "time_uniform", 4, False, 0),
     ]
     out = {}
     for ci, (steps, variant, skip, order, lof, t_enc) in enumerate(cases):
@@ -461,7 +467,9 @@ def gen_unipc():
             timesteps = timesteps[:t_enc]
         m = Model()
         dens = []
-        res = impl.unipc(m, seeded((2, 4, 8, 8), 990 + ci), timesteps, extra_args={}, disable=True,
+        batch = 1 if variant == "vary_coeff" else 2
+        out[f"c{ci}_batch"] = np.array([batch])
+        res = impl.unipc(m, seeded((batch, 4, 8, 8), 990 + ci), timesteps, extra_args={}, disable=True,
                          callback=lambda d: dens.append(None if d['denoised'] is None else d['denoised'].clone()),
                          is_img2img=bool(t_enc))
         out[f"c{ci}_cfg"] = np.array([steps, order, int(lof), t_enc])

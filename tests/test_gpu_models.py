@@ -197,6 +197,56 @@ def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     assert diff.mean() < 2.0          # uint8 images agree to rounding of a few levels
 
 
+@pytest.mark.parametrize("sampler,name", [("euler", "Euler"), ("heun", "Heun"), ("dpm_2", "DPM2")])
+def test_txt2img_stochastic_churn_vs_oracle(dev, tiny, sampler, name):
+    """opts.s_churn / s_tmin / s_tmax / s_noise (modules/sd_samplers_kdiffusion.py:36-39, 164-183; Karras et al. Algorithm 2): the
+    steps whose sigma lies in [s_tmin, s_tmax] first raise the noise level with fresh noise from the job's ImageRNG.  The churned
+    steps must draw from the generators in the oracle's order, the others must not draw at all."""
+    from oracle import pipeline as opipe
+    processing, shared = sub("processing"), sub("shared")
+    cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+    keep = (shared.opts.s_churn, shared.opts.s_tmin, shared.opts.s_tmax, shared.opts.s_noise)
+    try:
+        shared.opts.s_churn, shared.opts.s_tmin, shared.opts.s_tmax, shared.opts.s_noise = 8.0, 0.3, 9.0, 1.003
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=555, batch_size=2, steps=6,
+                                                        cfg_scale=5.0, width=128, height=128, sampler_name=name)
+        res = processing.process_images(p)
+        shared.opts.s_churn = 0.0
+        p0 = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=555, batch_size=2, steps=6,
+                                                         cfg_scale=5.0, width=128, height=128, sampler_name=name)
+        plain = processing.process_images(p0)
+    finally:
+        shared.opts.s_churn, shared.opts.s_tmin, shared.opts.s_tmax, shared.opts.s_noise = keep
+    lat = opipe.sample(tiny["oracle"], cond, uncond, [555, 556], 6, sampler, 5.0, (16, 16), s_churn=8.0, s_tmin=0.3, s_tmax=9.0, s_noise=1.003)
+    e = rel_l2(res.latents.cpu(), lat)
+    print(f"[churn {sampler}] final latent rel-L2 {e:.3e}; churned vs plain {rel_l2(res.latents.cpu(), plain.latents.cpu()):.3e}")
+    assert e < 1e-2, sampler
+    assert rel_l2(res.latents.cpu(), plain.latents.cpu()) > 5e-2         # the churn really changed the trajectory
+
+
+@pytest.mark.parametrize("variant,skip,order", [("vary_coeff", "time_uniform", 3), ("vary_coeff", "logSNR", 2), ("bh2", "time_quadratic", 3)])
+def test_txt2img_unipc_option_variants_vs_oracle(dev, tiny, variant, skip, order):
+    """opts.uni_pc_variant / uni_pc_skip_type / uni_pc_order (modules/shared_options.py:402-405): the vary_coeff solver
+    (modules/models/diffusion/uni_pc/uni_pc.py:522-623 — the oracle's restatement is pinned to the reference at batch 1, the only batch
+    size the reference's own code runs it at) and a non-default B(h) configuration, each update folded into sdmi_lincomb calls."""
+    from oracle import pipeline as opipe
+    processing, shared = sub("processing"), sub("shared")
+    cond, uncond = tiny["cond"][:1], tiny["uncond"][:1]
+    keep = (shared.opts.uni_pc_variant, shared.opts.uni_pc_skip_type, shared.opts.uni_pc_order)
+    try:
+        shared.opts.uni_pc_variant, shared.opts.uni_pc_skip_type, shared.opts.uni_pc_order = variant, skip, order
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=321, batch_size=1, steps=7,
+                                                        cfg_scale=4.0, width=128, height=128, sampler_name="UniPC")
+        res = processing.process_images(p)
+    finally:
+        shared.opts.uni_pc_variant, shared.opts.uni_pc_skip_type, shared.opts.uni_pc_order = keep
+    lat = opipe.sample(tiny["oracle"], cond, uncond, [321], 7, "unipc", 4.0, (16, 16),
+                       unipc_options=dict(variant=variant, skip_type=skip, order=order))
+    e = rel_l2(res.latents.cpu(), lat)
+    print(f"[unipc {variant} {skip} order {order}] final latent rel-L2 {e:.3e}")
+    assert e < 1e-2
+
+
 @pytest.mark.parametrize("sched,key", [("SGM Uniform", "sgm_uniform"), ("KL Optimal", "kl_optimal"), ("Exponential", "exponential"),
                                        ("Beta", "beta")])
 def test_txt2img_scheduler_choice_vs_oracle(dev, tiny, sched, key):

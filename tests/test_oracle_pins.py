@@ -177,7 +177,7 @@ def test_plms_matches_reference(golden_dir):
 
 
 def _unipc_cases(z):
-    for ci in range(7):
+    for ci in range(sum(1 for k in z.files if k.endswith("_cfg"))):
         steps, order, lof, t_enc = (int(v) for v in z[f"c{ci}_cfg"])
         variant, skip = (str(v) for v in z[f"c{ci}_variant_skip"])
         ts = kd.ddim_timesteps(steps)
@@ -187,7 +187,7 @@ def _unipc_cases(z):
 
 def test_unipc_matches_reference(golden_dir):
     """oracle/unipc.py == unipc() (modules/sd_samplers_timesteps_impl.py:144-179) over the real uni_pc.py: final latents, the
-    model times of every evaluation, the callback count and the last data prediction, for the three skip types, bh1 / bh2,
+    model times of every evaluation, the callback count and the last data prediction, for the three skip types, bh1 / bh2 / vary_coeff,
     orders 1-4, lower_order_final off and an img2img start."""
     from oracle import unipc
     z = np.load(os.path.join(golden_dir, "unipc.npz"))
@@ -199,7 +199,8 @@ def test_unipc_matches_reference(golden_dir):
             times.append(float(t[0]))
             return torch.tanh(0.7 * x + (t / 1000.0)[:, None, None, None]) * 0.9 + 0.05 * x
 
-        out = unipc.sample_unipc(model, seeded((2, 4, 8, 8), 990 + ci), ts, ac, {}, callback=lambda d: dens.append(d['denoised']), **kw)
+        batch = int(z[f"c{ci}_batch"][0])
+        out = unipc.sample_unipc(model, seeded((batch, 4, 8, 8), 990 + ci), ts, ac, {}, callback=lambda d: dens.append(d['denoised']), **kw)
         np.testing.assert_allclose(out.numpy(), z[f"c{ci}_out"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(np.array(times), z[f"c{ci}_model_t"], rtol=0, atol=1e-4)
         assert len(dens) == int(z[f"c{ci}_n_callbacks"][0]) and dens[-1] is None
