@@ -377,8 +377,18 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 18) ? 3 : (VAR == 5 || V
 // directly.  The shift is an fp16 number (softmax is invariant to it as long as O, the denominator and P use the same one); it is
 // raised — scores re-based, O rescaled, Q's padding element rewritten — only when a tile's maximum exceeds it (lazy, wave-uniform).
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, bool FOLD, int NG>
+template <int D, bool FOLD, int NG, bool TIMING = false>
 __global__ __launch_bounds__(NG * 256, NG) void attn_pp_kernel(AttnP p) {
+    // TIMING (attn_occ 28 / 38, tools/gpu/attn_pp_sections.py): s_memtime stamps on both sides of every section barrier; per wave the
+    // cycle sums of (V1 work, barrier wait, V2 work, wait, M work, wait) and the iteration count go to AttnP::dbg.  The stamp's own
+    // lgkmcnt(0) makes the V sections wait for their operand reads: read the V2 / M split with that in mind.
+    long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&]() -> long long {
+        if constexpr (!TIMING) return 0;
+        const long long t = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return t;
+    };
     constexpr int KVT = 64;
     constexpr int NT = NG * 256;             // NG groups of 4 waves (one wave of each group per SIMD)
     static_assert(NG == 2 || NG == 3, "two or three wave groups");
@@ -577,6 +587,8 @@ __global__ __launch_bounds__(NG * 256, NG) void attn_pp_kernel(AttnP p) {
 
     for (int t = 0; t < T; ++t) {
         // ================================ V section: softmax of S(t), operand reads for M(t) ================================
+        const long long ta = stamp();
+        long long tb = ta, tc = ta;
         if (t >= nfull || p.causal) {
             asm volatile("");                                 // a real (wave-uniform) branch, see attn_mfma_kernel
             int lim = p.M - t * KVT - 8 * half;
@@ -664,7 +676,9 @@ __global__ __launch_bounds__(NG * 256, NG) void attn_pp_kernel(AttnP p) {
             // reads), so that TWO waves of a SIMD are in VALU sections while the third is in its MFMA section — one wave alone issues a
             // VALU instruction only every 6-9 cycles (profiles/r02_valu_rates.txt), which made the two-group form VALU-latency bound
             asm volatile("" :: "v"(pb[0][0]), "v"(pb[0][1]));
+            tb = stamp();
             bar(0, false);
+            tc = stamp();
         }
 #pragma unroll
         for (int kb = 1; kb < NKB; ++kb) exp_block(kb);
@@ -686,7 +700,9 @@ __global__ __launch_bounds__(NG * 256, NG) void attn_pp_kernel(AttnP p) {
         // P(t) must exist BEFORE the barrier: without a use here the compiler sinks the exponentials into the M section
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) asm volatile("" :: "v"(pb[kb][0]), "v"(pb[kb][1]));
+        const long long td = stamp();
         bar(NB - 2, false);
+        const long long te = stamp();
         // ================================ M section: O += V^T(t) P^T(t), S(t+1) = K(t+1) Q^T ================================
         // (S(T) of the last iteration is computed from clamped rows and never used: no branch in the MFMA stream)
 #pragma unroll
@@ -714,7 +730,19 @@ __global__ __launch_bounds__(NG * 256, NG) void attn_pp_kernel(AttnP p) {
                 for (int kb = 0; kb < NKB; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kaf[step][kb], qf[step], sc[kb], 0, 0, 0);
             }
         }
+        const long long tf = stamp();
         bar(NB - 1, true);
+        if constexpr (TIMING) {
+            const long long tg = stamp();
+            tm[0] += tb - ta; tm[1] += tc - tb; tm[2] += td - tc; tm[3] += te - td; tm[4] += tf - te; tm[5] += tg - tf; tm[6] += 1;
+        }
+    }
+    if constexpr (TIMING) {
+        if (p.dbg && lane == 0) {
+            long long* dst = p.dbg + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * (4 * NG) + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) dst[i] = tm[i];
+        }
     }
 
     // ---- normalise and store: o[db][r] is O[q][db*32 + (r&3) + 8*(r>>2) + 4*half] ----------------------------
@@ -829,11 +857,11 @@ static int launch_attn_d(const AttnP& p, hipStream_t s) {
     return 0;
 }
 
-template <int D, bool FOLD, int NG = 2>
+template <int D, bool FOLD, int NG = 2, bool TIMING = false>
 static int launch_attn_pp(const AttnP& p, hipStream_t s) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     constexpr int SMEM = 3 * (64 * (DK * 2 + 16) + DV * (64 * 2 + 16)) + 64 * (DK * 2 + 16) + NG * 256 * 16;   // 3 pairs, K(0), dump slots
-    auto kern = attn_pp_kernel<D, FOLD, NG>;
+    auto kern = attn_pp_kernel<D, FOLD, NG, TIMING>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -861,6 +889,10 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
                 // 20 / 21: the role-offset 8-wave kernel (21: softmax shift folded into the S^T MFMA) for the long self-attention launches
                 if ((g_attn_occ == 20 || g_attn_occ == 21) && p.M >= g_attn_pp_min_m && p.N >= 256)
                     return g_attn_occ == 21 ? launch_attn_pp<40, true>(p, s) : launch_attn_pp<40, false>(p, s);
+                if ((g_attn_occ == 28 || g_attn_occ == 38) && p.M >= g_attn_pp_min_m && p.N >= 384) {      // section timers
+                    AttnP q = p; q.dbg = (long long*)g_attn_dbg;
+                    return g_attn_occ == 38 ? launch_attn_pp<40, true, 3, true>(q, s) : launch_attn_pp<40, true, 2, true>(q, s);
+                }
                 // 30 / 31: the same with THREE groups (12 waves, 384 queries per workgroup; VALU work split over two sections)
                 if ((g_attn_occ == 30 || g_attn_occ == 31) && p.M >= g_attn_pp_min_m && p.N >= 384)
                     return g_attn_occ == 31 ? launch_attn_pp<40, true, 3>(p, s) : launch_attn_pp<40, false, 3>(p, s);

@@ -114,10 +114,9 @@ class NetworkModule:                                      # network.py:111-216 (
         self.alpha = w["alpha"].item() if "alpha" in w else None
         self.scale = w["scale"].item() if "scale" in w else None
         self.dora_scale = w.get("dora_scale", None)
-        # network.py:130-134: an extra "bias" entry (sparse [indices; values; size] triple) — no published network family uses it on
-        # the UNet layers of this path; refused rather than silently ignored
-        if w.get("bias") is not None:
-            raise NotImplementedError(f"{self.network_key}: 'bias' deltas are not implemented")
+        # network.py:154, 196-199: an extra dense "bias" entry with as many elements as the weight delta, added to updown BEFORE the
+        # scale, the weight decomposition and the multiplier (finalize_updown)
+        self.bias = w.get("bias")
 
     def ex_bias(self, device):
         """Bias delta of this module (network.py:196-216 finalize_updown: ex_bias * multiplier), or None."""
@@ -505,11 +504,21 @@ def _merge_on_device(base: torch.Tensor, module: NetworkModule, device) -> torch
     W + updown * calc_scale * multiplier, or with a ``dora_scale`` the weight-decomposed form of network.py:175-194."""
     base = _f32(base, device)
     scale, mult = float(module.calc_scale()), float(module.multiplier())
+    bias = None
+    if module.bias is not None:                            # network.py:196-199: updown.reshape(bias.shape) + bias, then back
+        bias = _f32(module.bias, device).reshape(-1)
+        if bias.numel() != base.numel():
+            raise AssertionError(f"{module.network_key}: 'bias' has {bias.numel()} elements for a weight of {base.numel()}")
+        bias = bias.reshape(base.shape).contiguous()
+    from . import ops
     if module.dora_scale is None:
-        return module.add_delta(base, scale * mult, device)
+        out = module.add_delta(base, scale * mult, device)
+        return out if bias is None else ops.lincomb(torch.empty_like(out), [out, bias], [1.0, scale * mult])
     if module.kind in ("ia3", "glora", "oft", "norm"):
         raise NotImplementedError(f"{module.network_key}: DoRA on {module.kind} modules is not implemented")
     delta = module.add_delta(torch.zeros_like(base), scale, device)
+    if bias is not None:
+        delta = ops.lincomb(torch.empty_like(delta), [delta, bias], [1.0, scale])
     rows, cin = base.shape[0], base.shape[1]
     k = base.numel() // (rows * cin)
     dora_scale = _f32(module.dora_scale, device).reshape(-1)

@@ -877,6 +877,23 @@ def lyco_oft_cases():
     }
 
 
+def lyco_bias_cases():
+    """Modules carrying the extra dense "bias" entry of network.py:154, 196-199 (added to updown before scale / DoRA / multiplier).
+    Kept apart (and indexed after the other two tables) so that the seeds of the older cases do not move."""
+    lin, conv3 = ("linear", 24, 16), ("conv", 24, 16, 3)
+    t = lambda shape, seed, scale=0.3: seeded(shape, seed, scale)
+    return {
+        "lora_linear_bias": ("lora", lin, lambda k: {"lora_up.weight": t((24, 4), k), "lora_down.weight": t((4, 16), k + 1), "alpha": torch.tensor(2.0),
+                                                     "bias": t((24, 16), k + 2, 0.05)}),
+        "lora_conv3_bias": ("lora", conv3, lambda k: {"lora_up.weight": t((24, 4, 1, 1), k), "lora_down.weight": t((4, 16, 3, 3), k + 1),
+                                                      "alpha": torch.tensor(4.0), "bias": t((24, 16, 3, 3), k + 2, 0.05)}),
+        "lora_dora_bias": ("lora", lin, lambda k: {"lora_up.weight": t((24, 4), k), "lora_down.weight": t((4, 16), k + 1), "alpha": torch.tensor(2.0),
+                                                   "dora_scale": t((1, 16), k + 2, 0.2).abs() + 1.0, "bias": t((24, 16), k + 3, 0.05)}),
+        "hada_linear_bias": ("hada", lin, lambda k: {"hada_w1_a": t((24, 4), k), "hada_w1_b": t((4, 16), k + 1), "hada_w2_a": t((24, 4), k + 2),
+                                                     "hada_w2_b": t((4, 16), k + 3), "alpha": torch.tensor(2.0), "bias": t((24 * 16,), k + 4, 0.05)}),
+    }
+
+
 def lyco_orig_weight(spec, k):
     if spec[0] == "linear":
         return seeded((spec[1], spec[2]), 8000 + k, 0.2)
@@ -919,7 +936,7 @@ def gen_lyco():
     network = sys.modules["network"]
     kinds["oft"] = load_by_path("network_oft", lora_dir + "network_oft.py").ModuleTypeOFT()
     out = {}
-    all_cases = list(lyco_cases().items()) + list(lyco_oft_cases().items())
+    all_cases = list(lyco_cases().items()) + list(lyco_oft_cases().items()) + list(lyco_bias_cases().items())
     for k, (name, (kind, spec, build)) in enumerate(all_cases):
         if spec[0] == "linear":
             sd_module = torch.nn.Linear(spec[2], spec[1])

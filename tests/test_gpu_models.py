@@ -355,14 +355,14 @@ def test_lora_merge_into_engine_vs_oracle_and_restore(dev, tiny):
 def test_lycoris_module_types_vs_reference_fixture(dev, golden_dir):
     """Every module type of networks.module_types on the reference-generated cases of tests/golden/lyco.npz (LoRA / LoCon with
     cp-decomposition, DoRA and dyn_dim, LoHa with and without Tucker cores, LoKr in its four forms, GLoRA, IA3, full diff with a
-    bias difference, norm, OFT / COFT / old-LyCORIS OFT / BOFT with rescale): W + updown computed through the HIP kernels equals
+    bias difference, norm, OFT / COFT / old-LyCORIS OFT / BOFT with rescale, modules with the dense "bias" entry): W + updown computed through the HIP kernels equals
     W + the reference's calc_updown, and the bias deltas equal its ex_bias."""
     from tests.test_oracle_pins import _golden_module
     nets = sub("networks")
     mg = _golden_module()
     z = np.load(os.path.join(golden_dir, "lyco.npz"))
     seen = set()
-    cases = list(mg.lyco_cases().items()) + list(mg.lyco_oft_cases().items())       # same indexing as gen_lyco (seeds derive from k)
+    cases = list(mg.lyco_cases().items()) + list(mg.lyco_oft_cases().items()) + list(mg.lyco_bias_cases().items())   # same indexing as gen_lyco
     for k, (name, (kind, spec, build)) in enumerate(cases):
         orig, w = mg.lyco_orig_weight(spec, k), build(9000 + 10 * k)
         net = nets.Network("n", unet_multiplier=0.8, te_multiplier=0.3, dyn_dim=3 if name == "lora_dyn" else None)
@@ -1151,7 +1151,7 @@ def test_sharded_job_replayed_rank_by_rank_equals_the_single_process_job(dev, ti
     check(tiny["model"], cond, uncond, 1, 4, steps=3, width=128, height=128)
     check(tiny["model"], cond, uncond, 2, 3, world=3, steps=2, width=128, height=128)
     w = check(tiny["model"], cond, uncond, 1, 2, steps=2, width=64, height=64, enable_hr=True, hr_scale=2.0, hr_upscaler="Latent", denoising_strength=0.6)
-    assert w.images[0].shape[:2] == (128, 128)
+    assert w.images[0].shape[:2] == (32, 32)                  # 64 / 8 = 8x8 latent, hires x2 = 16x16, the two-level tiny VAE decodes x2
     ucfg, vcfg = schema.sd15_unet(), schema.sd15_vae()
     sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16)
     model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0, vae_decoder_only=True)

@@ -320,14 +320,15 @@ def test_refiner_switch_decision_matches_reference(golden_dir):
 
 
 def test_lycoris_calc_updown_matches_reference(golden_dir):
-    """oracle.lora.calc_updown == NetworkModule*.calc_updown of extensions-builtin/Lora/network_*.py (loaded by make_golden) for 25
+    """oracle.lora.calc_updown == NetworkModule*.calc_updown of extensions-builtin/Lora/network_*.py (loaded by make_golden) for 29
     cases: LoRA / LoCon incl. cp-decomposition, DoRA, dyn_dim; LoHa; LoKr; GLoRA; IA3; full; norm; OFT (kohya, constrained, conv,
-    old LyCORIS rotation blocks) and BOFT (with rescale) — and the type dispatch."""
+    old LyCORIS rotation blocks) and BOFT (with rescale), modules with the dense "bias" entry (network.py:154, 196-199) — and the type
+    dispatch."""
     from oracle import lora as olora
     mg = _golden_module()
     z = np.load(os.path.join(golden_dir, "lyco.npz"))
-    cases = {**mg.lyco_cases(), **mg.lyco_oft_cases()}
-    assert len(cases) == 25
+    cases = {**mg.lyco_cases(), **mg.lyco_oft_cases(), **mg.lyco_bias_cases()}
+    assert len(cases) == 29
     for k, (name, (kind, spec, build)) in enumerate(cases.items()):
         orig, w = mg.lyco_orig_weight(spec, k), build(9000 + 10 * k)
         assert olora.module_kind(w) == kind
