@@ -275,8 +275,22 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
     latent_mask: Optional[torch.Tensor] = None    # [N,4,h,w] latent-space mask (1 = keep original), optional
     image_mask: Optional[torch.Tensor] = None     # [1,1,H,W] image-space mask in [0,1] (1 = repaint): conditions inpainting checkpoints
     mask_round: bool = True
-    inpainting_fill: int = 1                      # 1 original, 2 latent noise, 3 latent nothing (0 "fill" is image-space: not here)
+    inpainting_fill: int = 1                      # 0 fill, 1 original, 2 latent noise, 3 latent nothing (0 needs the PIL inputs below)
     initial_noise_multiplier: float = None        # opts.initial_noise_multiplier
+    # The reference's own PIL front-end (modules/processing.py:1602-1728), taken when init_images is a list of PIL images: `mask_image`
+    # is the reference's `mask` argument (RGBA from the UI or an L / RGB image), `latent_mask_image` its PIL `latent_mask`
+    mask_image: Any = None
+    latent_mask_image: Any = None
+    mask_blur_x: int = 4
+    mask_blur_y: int = 4
+    mask_blur: int = None                         # sets both (the reference's property, :1592-1600)
+    inpainting_mask_invert: int = 0
+    inpaint_full_res: bool = True
+    inpaint_full_res_padding: int = 0
+    resize_mode: int = 0
+    overlay_images: Any = None
+    paste_to: Any = None
+    mask_for_overlay: Any = None
     image_cfg_scale: float = None                 # InstructPix2Pix
     init_latent: Optional[torch.Tensor] = None
     mask: Optional[torch.Tensor] = None
@@ -291,6 +305,8 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             self.image_cfg_scale = None                                                    # :1605
         if self.initial_noise_multiplier is None:
             self.initial_noise_multiplier = shared.opts.initial_noise_multiplier
+        if isinstance(self.init_images, (list, tuple)) and len(self.init_images) and not torch.is_tensor(self.init_images[0]):
+            self._init_from_pil()
         image = (self.init_images.to(self.sd_model.device, dtype=torch.float32) * 2.0 - 1.0).contiguous()
         moments = self.sd_model.encode_first_stage(image)
         self.init_latent_all = self.sd_model.get_first_stage_encoding(moments)
@@ -302,9 +318,94 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             else:                                 # init * mask
                 fill = torch.zeros_like(self.init_latent_all)
             self.init_latent_all = ops.mask_blend(fill.contiguous(), self.init_latent_all, keep, (1.0 - keep).contiguous())
-        elif self.inpainting_fill not in (1, 2, 3):
-            raise NotImplementedError("inpainting_fill 0 ('fill') works on the image before encoding and is not implemented")
+        elif self.inpainting_fill not in (0, 1, 2, 3):
+            raise ValueError(f"inpainting_fill {self.inpainting_fill!r}")
+        elif self.inpainting_fill == 0 and self.latent_mask is not None and self.mask_for_overlay is None:
+            raise ValueError("inpainting_fill 0 ('fill') repaints the IMAGE before encoding: pass PIL init_images / mask_image")
         self.image_conditioning_all = self.img2img_image_conditioning(image, self.init_latent_all, self.image_mask, self.mask_round)
+
+    def _init_from_pil(self):
+        """modules/processing.py:1608-1745, the image side: binary mask -> invert -> separable Gaussian blur -> either the "only
+        masked" crop (region grown to the processing aspect ratio, image and mask resized to it, paste_to remembered) or the plain resize
+        (mask doubled for the overlay), overlay images (the unmasked original with the mask as transparency), the "fill" repaint for
+        every masked-content mode but "original", uint8 -> [0, 1] tensors, and the latent mask (mask resized to the latent grid,
+        rounded, 1 = keep).  Leaves tensors in init_images / latent_mask / image_mask: the tensor path above continues from there."""
+        from PIL import Image, ImageOps
+        from . import masking, upscaler
+        if self.mask_blur is not None:
+            self.mask_blur_x = self.mask_blur_y = int(self.mask_blur)
+        crop_region = None
+        image_mask = self.mask_image
+        if image_mask is not None:
+            image_mask = masking.create_binary_mask(image_mask, round=self.mask_round)
+            if self.inpainting_mask_invert:
+                image_mask = ImageOps.invert(image_mask)
+                self.extra_generation_params["Mask mode"] = "Inpaint not masked"
+            image_mask = masking.blur_mask(image_mask, self.mask_blur_x, self.mask_blur_y)
+            if self.mask_blur_x > 0 or self.mask_blur_y > 0:
+                self.extra_generation_params["Mask blur"] = self.mask_blur_x if self.mask_blur_x == self.mask_blur_y else None
+            if self.inpaint_full_res:
+                self.mask_for_overlay = image_mask
+                mask = image_mask.convert('L')
+                crop_region = masking.get_crop_region_v2(mask, self.inpaint_full_res_padding)
+                if crop_region:
+                    crop_region = masking.expand_crop_region(crop_region, self.width, self.height, mask.width, mask.height)
+                    x1, y1, x2, y2 = crop_region
+                    image_mask = upscaler.resize_image(2, mask.crop(crop_region), self.width, self.height)
+                    self.paste_to = (x1, y1, x2 - x1, y2 - y1)
+                    self.extra_generation_params["Inpaint area"] = "Only masked"
+                    self.extra_generation_params["Masked area padding"] = self.inpaint_full_res_padding
+                else:                                         # blank mask: plain img2img (:1647-1654)
+                    crop_region, image_mask, self.mask_for_overlay, self.inpaint_full_res = None, None, None, False
+            else:
+                image_mask = upscaler.resize_image(self.resize_mode, image_mask, self.width, self.height)
+                doubled = np.clip(np.array(image_mask).astype(np.float32) * 2, 0, 255).astype(np.uint8)
+                self.mask_for_overlay = Image.fromarray(doubled)
+            self.overlay_images = []
+        latent_mask = self.latent_mask_image if self.latent_mask_image is not None else image_mask
+        imgs = []
+        for img in self.init_images:
+            image = img
+            if image.mode == "RGBA":                          # images.flatten (modules/images.py:841-849): transparency -> background colour
+                flat = Image.new('RGBA', image.size, getattr(shared.opts, "img2img_background_color", "#ffffff"))
+                flat.paste(image, mask=image)
+                image = flat
+            image = image.convert('RGB')
+            if crop_region is None and self.resize_mode != 3:
+                image = upscaler.resize_image(self.resize_mode, image, self.width, self.height)
+            if image_mask is not None:
+                if self.mask_for_overlay.size != (image.width, image.height):
+                    self.mask_for_overlay = upscaler.resize_image(self.resize_mode, self.mask_for_overlay, image.width, image.height)
+                kept = Image.new('RGBa', (image.width, image.height))
+                kept.paste(image.convert("RGBA").convert("RGBa"), mask=ImageOps.invert(self.mask_for_overlay.convert('L')))
+                self.overlay_images.append(kept.convert('RGBA'))
+            if crop_region is not None:
+                image = upscaler.resize_image(2, image.crop(crop_region), self.width, self.height)
+            if image_mask is not None and self.inpainting_fill != 1:
+                image = masking.fill(image, latent_mask)
+                if self.inpainting_fill == 0:
+                    self.extra_generation_params["Masked content"] = 'fill'
+            imgs.append(np.moveaxis(np.array(image).astype(np.float32) / 255.0, 2, 0))
+        if len(imgs) == 1:
+            batch = np.expand_dims(imgs[0], axis=0).repeat(self.batch_size * self.n_iter, axis=0)
+            if self.overlay_images is not None:
+                self.overlay_images = self.overlay_images * (self.batch_size * self.n_iter)
+        elif len(imgs) <= self.batch_size * self.n_iter:
+            batch = np.array(imgs)
+        else:
+            raise RuntimeError(f"bad number of images passed: {len(imgs)}; expecting {self.batch_size * self.n_iter} or less")
+        self.init_images = torch.from_numpy(batch)
+        if image_mask is not None:
+            h, w = self.height // opt_f, self.width // opt_f
+            latmask = latent_mask.convert('RGB').resize((w, h))
+            latmask = np.moveaxis(np.array(latmask, dtype=np.float32), 2, 0)[0] / 255
+            if self.mask_round:
+                latmask = np.around(latmask)
+            self.latent_mask = torch.from_numpy(1.0 - np.tile(latmask[None, None], (batch.shape[0], opt_C, 1, 1))).float()    # 1 = keep
+            cond = np.array(image_mask.convert("L")).astype(np.float32) / 255.0
+            self.image_mask = torch.from_numpy(cond[None, None])
+        else:
+            self.latent_mask = self.image_mask = None
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
         """modules/processing.py:1759-1789"""
@@ -411,7 +512,15 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
         decode_model = p.sampler.sd_model if getattr(p, "sampler", None) is not None else p.sd_model
         x_samples = decode_latent_batch(decode_model, samples, check_for_nans=True)             # :1002 (hires: decoded inside sample_hr_pass, :1459)
         u8 = ops.image_to_u8(x_samples)                                                           # :1004-1005, 1034-1035
-        images.extend(list(u8.cpu().numpy()))
+        batch_u8 = list(u8.cpu().numpy())
+        overlays = getattr(p, "overlay_images", None)
+        if overlays:                                                 # :1063-1068, 1086: paste the generated crop back, composite the unmasked original over it
+            from PIL import Image
+            from . import masking
+            for i, arr in enumerate(batch_u8):
+                ov = overlays[lo + i] if lo + i < len(overlays) else None
+                batch_u8[i] = np.array(masking.apply_overlay(Image.fromarray(arr), getattr(p, "paste_to", None), ov)[0])
+        images.extend(batch_u8)
         if p.keep_latents:
             latents.append(samples)
     p.close()

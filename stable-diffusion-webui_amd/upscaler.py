@@ -86,18 +86,40 @@ def builtin_upscalers():
     return [*UpscalerNone().scalers, *UpscalerLanczos().scalers, *UpscalerNearest().scalers]
 
 
-def resize_image(resize_mode, im, width, height, upscaler_name=None):
-    """modules/images.py:252-291, resize_mode 0 (plain resize to width x height; the hires fix uses no other mode)."""
-    if resize_mode != 0:
-        raise NotImplementedError("resize modes 1 / 2 (crop / fill) belong to the img2img front-end")
-    upscaler_name = upscaler_name or getattr(shared.opts, "upscaler_for_img2img", None)
+def _resize_to(im, w, h, upscaler_name):
+    """The inner `resize` of modules/images.py:269-288: Lanczos for masks / no upscaler, else the named upscaler for enlargements."""
     if upscaler_name is None or upscaler_name == "None" or im.mode == 'L':
-        return im.resize((width, height), resample=LANCZOS)
-    scale = max(width / im.width, height / im.height)
-    if scale > 1.0:
-        upscalers = [x for x in shared.sd_upscalers if x.name == upscaler_name]
-        upscaler = upscalers[0] if upscalers else shared.sd_upscalers[0]
-        im = upscaler.scaler.upscale(im, scale, upscaler.data_path)
-    if im.width != width or im.height != height:
-        im = im.resize((width, height), resample=LANCZOS)
-    return im
+        return im.resize((w, h), resample=LANCZOS)
+    if max(w / im.width, h / im.height) > 1.0:
+        named = [x for x in shared.sd_upscalers if x.name == upscaler_name]
+        chosen = named[0] if named else shared.sd_upscalers[0]
+        im = chosen.scaler.upscale(im, max(w / im.width, h / im.height), chosen.data_path)
+    return im if (im.width, im.height) == (w, h) else im.resize((w, h), resample=LANCZOS)
+
+
+def resize_image(resize_mode, im, width, height, upscaler_name=None):
+    """modules/images.py:252-326.  0: stretch to width x height (the hires fix); 1: cover the target keeping the aspect ratio, centred,
+    the excess cropped; 2: fit inside the target keeping the aspect ratio, centred, the empty bands filled by stretching the image's
+    own border row / column over them."""
+    from PIL import Image
+    upscaler_name = upscaler_name or getattr(shared.opts, "upscaler_for_img2img", None)
+    if resize_mode == 0:
+        return _resize_to(im, width, height, upscaler_name)
+    ratio, src_ratio = width / height, im.width / im.height
+    by_w, by_h = im.width * height // im.height, im.height * width // im.width      # the other side when one side is matched exactly
+    if resize_mode == 1:                                     # cover: match the side on which the scaled source would fall short
+        src_w, src_h = (width, by_h) if ratio > src_ratio else (by_w, height)
+    else:                                                    # fit: match the side on which the scaled source would overflow
+        src_w, src_h = (width, by_h) if ratio < src_ratio else (by_w, height)
+    resized = _resize_to(im, src_w, src_h, upscaler_name)
+    canvas = Image.new("RGB", (width, height))
+    x0, y0 = width // 2 - src_w // 2, height // 2 - src_h // 2
+    canvas.paste(resized, box=(x0, y0))
+    if resize_mode == 2:
+        if ratio < src_ratio and y0 > 0:                     # bands above / below: the first / last row stretched over them
+            canvas.paste(resized.resize((width, y0), box=(0, 0, width, 0)), box=(0, 0))
+            canvas.paste(resized.resize((width, y0), box=(0, resized.height, width, resized.height)), box=(0, y0 + src_h))
+        elif ratio > src_ratio and x0 > 0:                   # bands left / right: the first / last column
+            canvas.paste(resized.resize((x0, height), box=(0, 0, 0, height)), box=(0, 0))
+            canvas.paste(resized.resize((x0, height), box=(resized.width, 0, resized.width, height)), box=(x0 + src_w, 0))
+    return canvas

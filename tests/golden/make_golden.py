@@ -776,6 +776,80 @@ def gen_resize_image():
     print("resize_image.npz")
 
 
+FRONTEND_RESIZE_CASES = [(1, 48, 32, None), (1, 32, 48, None), (1, 40, 40, "Lanczos"), (2, 48, 20, None), (2, 20, 48, None), (2, 36, 24, None),
+                         (2, 50, 36, "Nearest"), (1, 12, 30, "None")]
+FRONTEND_CROP_CASES = [((10, 20, 40, 30), 64, 64, 96, 80), ((0, 0, 90, 10), 64, 64, 96, 80), ((50, 5, 60, 75), 128, 64, 96, 80),
+                       ((80, 60, 96, 80), 64, 96, 96, 80), ((3, 3, 5, 6), 512, 512, 96, 80)]
+
+
+def frontend_inputs():
+    """Seeded 96x80 RGB image, a soft two-blob L mask, an RGBA mask whose alpha is the mask, and an all-black mask."""
+    from PIL import Image
+    g = np.random.RandomState(4321)
+    img = Image.fromarray(g.randint(0, 256, size=(80, 96, 3)).astype(np.uint8))
+    m = np.zeros((80, 96), np.uint8)
+    m[20:45, 30:70] = 255
+    m[55:60, 5:15] = 200
+    m[30:35, 40:50] = 90
+    mask = Image.fromarray(m)
+    rgba = np.zeros((80, 96, 4), np.uint8)
+    rgba[..., :3] = 17
+    rgba[..., 3] = m
+    return img, mask, Image.fromarray(rgba, "RGBA"), Image.fromarray(np.zeros((80, 96), np.uint8))
+
+
+def gen_img2img_frontend():
+    """The PIL side of img2img / inpainting: images.resize_image modes 1 / 2 (modules/images.py:293-326), modules/masking.py loaded as a
+    module, and create_binary_mask / uncrop / apply_overlay exec'd from modules/processing.py's text (:70-98)."""
+    from PIL import Image
+    import abc
+    shared = types.SimpleNamespace(opts=types.SimpleNamespace(ESRGAN_tile=192, ESRGAN_tile_overlap=8, upscaler_for_img2img=None),
+                                   device="cpu", cmd_opts=types.SimpleNamespace(no_half=True), models_path="/nonexistent",
+                                   state=types.SimpleNamespace(interrupted=False), sd_upscalers=[])
+    ns = {"Image": Image, "PIL": __import__("PIL"), "os": os, "abstractmethod": abc.abstractmethod, "modules": types.SimpleNamespace(shared=shared),
+          "shared": shared, "modelloader": None}
+    src = open(os.path.join(REF, "modules/upscaler.py")).read()
+    exec(src[src.index("LANCZOS = "):], ns)
+    shared.sd_upscalers = [*ns["UpscalerNone"]().scalers, *ns["UpscalerLanczos"]().scalers, *ns["UpscalerNearest"]().scalers]
+    src = open(os.path.join(REF, "modules/images.py")).read()
+    a = src.index("def resize_image(")
+    ns["opts"] = shared.opts
+    exec(src[a:src.index("\nif not shared.cmd_opts.unix_filenames_sanitization", a)], ns)
+    resize_image = ns["resize_image"]
+    masking = load_by_path("ref_masking", "modules/masking.py")
+    img, mask, rgba, black = frontend_inputs()
+    out = {}
+    for k, (mode, w, h, name) in enumerate(FRONTEND_RESIZE_CASES):
+        out[f"resize{k}"] = np.array(resize_image(mode, img, w, h, upscaler_name=name))
+    out["resize_mask_m2"] = np.array(resize_image(2, mask, 64, 64))             # an L image comes back as RGB (the canvas is RGB)
+    for k, pad in enumerate((0, 4, 32)):
+        out[f"crop_v2_{k}"] = np.array(masking.get_crop_region_v2(mask, pad))
+        out[f"crop_{k}"] = np.array(masking.get_crop_region(mask, pad))
+        out[f"crop_black_{k}"] = np.array(masking.get_crop_region(black, pad))
+    assert masking.get_crop_region_v2(black, 3) is None
+    for k, (box, pw, ph, iw, ih) in enumerate(FRONTEND_CROP_CASES):
+        out[f"expand{k}"] = np.array(masking.expand_crop_region(box, pw, ph, iw, ih))
+    out["fill"] = np.array(masking.fill(img, mask))
+    psrc = open(os.path.join(REF, "modules/processing.py")).read()
+    pns = {"Image": Image, "images": types.SimpleNamespace(resize_image=resize_image)}
+    a = psrc.index("def uncrop(")
+    exec(psrc[a:psrc.index("def txt2img_image_conditioning(", a)], pns)
+    for tag, m, rnd in (("rgba_round", rgba, True), ("rgba_soft", rgba, False), ("l", mask, True), ("rgb", img, True)):
+        out[f"binary_{tag}"] = np.array(pns["create_binary_mask"](m, round=rnd))
+    overlay = Image.new('RGBa', (img.width, img.height))
+    from PIL import ImageOps
+    overlay.paste(img.convert("RGBA").convert("RGBa"), mask=ImageOps.invert(mask.convert('L')))
+    overlay = overlay.convert('RGBA')
+    gen = Image.fromarray(np.random.RandomState(99).randint(0, 256, size=(80, 96, 3)).astype(np.uint8))
+    a_img, a_orig = pns["apply_overlay"](gen, None, overlay)
+    out["overlay_full"], out["overlay_full_orig"] = np.array(a_img), np.array(a_orig)
+    small = Image.fromarray(np.random.RandomState(98).randint(0, 256, size=(64, 64, 3)).astype(np.uint8))
+    b_img, b_orig = pns["apply_overlay"](small, (30, 20, 40, 25), overlay)
+    out["overlay_paste"], out["overlay_paste_orig"] = np.array(b_img), np.array(b_orig)
+    np.savez_compressed(os.path.join(OUT, "img2img_frontend.npz"), **out)
+    print("img2img_frontend.npz", len(out))
+
+
 def refiner_cases():
     """(step, total_steps, sigma or None, sigma-space?, switch_at, by_steps, has_refiner, already_refiner, enable_hr, is_hr_pass, hires_pass_opt)"""
     cases = []
@@ -1219,6 +1293,7 @@ if __name__ == "__main__":
     gen_cfg_denoiser()
     gen_image_conditioning()
     gen_resize_image()
+    gen_img2img_frontend()
     gen_refiner()
     gen_lyco()
     gen_prompt_cond()

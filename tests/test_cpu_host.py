@@ -885,3 +885,67 @@ def test_hypernetwork_file_is_loaded_without_unpickling_arbitrary_objects(tmp_pa
     torch.save({"layer_structure": [1, 2, 1], "payload": Evil()}, str(bad))
     with pytest.raises(pickle.UnpicklingError):
         hn.Hypernetwork().load(str(bad))
+
+
+def test_img2img_frontend_helpers_match_reference_fixtures(golden_dir):
+    """The PIL side of img2img / inpainting against fixtures produced by the reference's own files (tests/golden/make_golden.py
+    gen_img2img_frontend): resize_image modes 1 (cover) and 2 (fit + border fill) incl. an L-mode mask and named upscalers
+    (modules/images.py:293-326), modules/masking.py (crop regions with padding, the all-black cases, the aspect-ratio expansion, the
+    blur-ladder fill — bit-identical uint8 images) and create_binary_mask / uncrop / apply_overlay (modules/processing.py:70-98)."""
+    from PIL import Image, ImageOps
+    from tests.test_oracle_pins import _golden_module
+    mg = _golden_module()
+    up, masking, shared = sub("upscaler"), sub("masking"), sub("shared")
+    z = np.load(os.path.join(golden_dir, "img2img_frontend.npz"))
+    img, mask, rgba, black = mg.frontend_inputs()
+    shared.sd_upscalers[:] = up.builtin_upscalers() if hasattr(up, "builtin_upscalers") else shared.sd_upscalers
+    for k, (mode, w, h, name) in enumerate(mg.FRONTEND_RESIZE_CASES):
+        assert np.array_equal(np.array(up.resize_image(mode, img, w, h, upscaler_name=name)), z[f"resize{k}"]), (mode, w, h, name)
+    assert np.array_equal(np.array(up.resize_image(2, mask, 64, 64)), z["resize_mask_m2"])
+    for k, pad in enumerate((0, 4, 32)):
+        assert tuple(z[f"crop_v2_{k}"]) == masking.get_crop_region_v2(mask, pad)
+        assert tuple(z[f"crop_{k}"]) == masking.get_crop_region(mask, pad)
+        assert tuple(z[f"crop_black_{k}"]) == masking.get_crop_region(black, pad)
+        assert tuple(z[f"crop_v2_{k}"]) == masking.get_crop_region_v2(np.array(mask), pad)        # arrays are accepted too
+    assert masking.get_crop_region_v2(black, 3) is None
+    for k, (box, pw, ph, iw, ih) in enumerate(mg.FRONTEND_CROP_CASES):
+        assert tuple(int(v) for v in z[f"expand{k}"]) == tuple(int(v) for v in masking.expand_crop_region(box, pw, ph, iw, ih)), k
+    assert np.array_equal(np.array(masking.fill(img, mask)), z["fill"])
+    for tag, m, rnd in (("rgba_round", rgba, True), ("rgba_soft", rgba, False), ("l", mask, True), ("rgb", img, True)):
+        assert np.array_equal(np.array(masking.create_binary_mask(m, round=rnd)), z[f"binary_{tag}"]), tag
+    overlay = Image.new('RGBa', (img.width, img.height))
+    overlay.paste(img.convert("RGBA").convert("RGBa"), mask=ImageOps.invert(mask.convert('L')))
+    overlay = overlay.convert('RGBA')
+    gen = Image.fromarray(np.random.RandomState(99).randint(0, 256, size=(80, 96, 3)).astype(np.uint8))
+    a_img, a_orig = masking.apply_overlay(gen, None, overlay)
+    assert np.array_equal(np.array(a_img), z["overlay_full"]) and np.array_equal(np.array(a_orig), z["overlay_full_orig"])
+    small = Image.fromarray(np.random.RandomState(98).randint(0, 256, size=(64, 64, 3)).astype(np.uint8))
+    b_img, b_orig = masking.apply_overlay(small, (30, 20, 40, 25), overlay)
+    assert np.array_equal(np.array(b_img), z["overlay_paste"]) and np.array_equal(np.array(b_orig), z["overlay_paste_orig"])
+    assert masking.apply_overlay(gen, None, None)[0] is gen
+
+
+def test_mask_blur_kernel_is_the_one_cv2_would_build():
+    """The separable Gaussian of the mask blur (modules/processing.py:1621-1631 calls cv2.GaussianBlur(mask, (k, 1), sigma) with
+    k = 2 * int(2.5 * sigma + 0.5) + 1; cv2 is absent here, so the reference itself cannot run this step — parity unpinned for it):
+    kernel size formula, normalisation, symmetry, BORDER_REFLECT_101 handling, and agreement with scipy's independently written
+    1-D Gaussian (same taps when truncated at the same radius, mirror border) to one grey level."""
+    from scipy.ndimage import correlate1d
+    masking = sub("masking")
+    for sigma, k in ((1, 7), (4, 21), (7, 37), (0.6, 5)):
+        w = masking.gaussian_kernel_1d(sigma)
+        assert len(w) == k and abs(w.sum() - 1.0) < 1e-12 and np.allclose(w, w[::-1])
+        assert np.allclose(w[k // 2 + 1] / w[k // 2], np.exp(-1.0 / (2 * sigma ** 2)))
+    g = np.random.RandomState(5)
+    m = (g.rand(40, 56) > 0.7).astype(np.uint8) * 255
+    for sigma in (2, 4):
+        for axis in (0, 1):
+            got = masking.gaussian_blur_axis(m, sigma, axis)
+            want = correlate1d(m.astype(np.float64), masking.gaussian_kernel_1d(sigma), axis=axis, mode="mirror")
+            assert got.dtype == np.uint8 and got.shape == m.shape
+            assert np.abs(got.astype(np.float64) - want).max() <= 0.5 + 1e-9
+    assert np.array_equal(masking.gaussian_blur_axis(np.full((8, 8), 200, np.uint8), 3, 1), np.full((8, 8), 200, np.uint8))
+    from PIL import Image
+    out = masking.blur_mask(Image.fromarray(m), 4, 4)
+    assert out.size == (56, 40) and np.array(out).max() <= 255 and 0 < np.array(out).mean() < 255
+    assert masking.blur_mask(Image.fromarray(m), 0, 0).tobytes() == Image.fromarray(m).tobytes()

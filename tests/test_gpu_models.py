@@ -1162,3 +1162,65 @@ def test_sharded_job_replayed_rank_by_rank_equals_the_single_process_job(dev, ti
     finally:
         model.engine.close()
         sub("shared").sd_model = tiny["model"]
+
+
+def test_img2img_pil_front_end_fill_only_masked_and_overlay(dev, tiny):
+    """The reference's PIL front-end of img2img / inpainting (modules/processing.py:1608-1745, 1063-1086) on the tiny model: mask
+    from an RGBA layer, blur, "fill" masked content, whole-picture and "only masked" modes, overlay compositing.  Checked: the job run
+    from PIL inputs equals the job run from the tensors the front-end derived (the tensor path is the one pinned against the oracle);
+    the unmasked part of every output IS the original image; "only masked" returns the full-size picture; an all-black mask turns the
+    job into plain img2img."""
+    from PIL import Image
+    processing = sub("processing")
+    model = tiny["model"]
+    g = np.random.RandomState(12)
+    W = H = 128
+    base = Image.fromarray(g.randint(0, 256, size=(H, W, 3)).astype(np.uint8))
+    m = np.zeros((H, W), np.uint8)
+    m[40:90, 30:100] = 255
+    rgba = np.zeros((H, W, 4), np.uint8)
+    rgba[..., 3] = m
+    mask = Image.fromarray(rgba, "RGBA")
+    cond, uncond = tiny["cond"][:2], tiny["uncond"][:2]
+
+    def job(**kw):
+        return processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=77, batch_size=2, steps=4, cfg_scale=4.0,
+                                                           width=W, height=H, sampler_name="Euler a", denoising_strength=0.6, **kw)
+    # whole picture, masked content "fill", no blur: unmasked output pixels are the original's
+    p = job(init_images=[base], mask_image=mask, inpainting_fill=0, inpaint_full_res=False, mask_blur=0)
+    res = processing.process_images(p)
+    assert len(res.images) == 2 and res.images[0].shape == (H, W, 3)
+    keep = m == 0
+    for im in res.images:
+        assert np.array_equal(im[keep], np.array(base)[keep])
+        assert not np.array_equal(im[~keep], np.array(base)[~keep])
+    assert p.extra_generation_params.get("Masked content") == "fill"
+    # the same job through the tensor API, from the tensors the front-end derived: identical latents
+    p2 = job(init_images=p.init_images.clone(), latent_mask=p.latent_mask.clone(), image_mask=p.image_mask.clone(), inpainting_fill=1)
+    res2 = processing.process_images(p2)
+    assert torch.equal(res.latents, res2.latents)
+    # masked content "original" starts from a different latent
+    p3 = job(init_images=[base], mask_image=mask, inpainting_fill=1, inpaint_full_res=False, mask_blur=0)
+    assert not torch.equal(processing.process_images(p3).latents, res.latents)
+    # blurred mask: soft edge, the far field still untouched
+    p4 = job(init_images=[base], mask_image=mask, inpainting_fill=1, inpaint_full_res=False, mask_blur=4)
+    r4 = processing.process_images(p4)
+    far = np.zeros((H, W), bool)
+    far[:20] = True
+    assert np.array_equal(r4.images[0][far], np.array(base)[far]) and p4.extra_generation_params["Mask blur"] == 4
+    # "only masked" on a larger picture: the crop is processed at 128x128 and pasted back into the full-size image
+    big = Image.fromarray(g.randint(0, 256, size=(192, 256, 3)).astype(np.uint8))
+    mb = np.zeros((192, 256), np.uint8)
+    mb[60:100, 100:180] = 255
+    p5 = job(init_images=[big], mask_image=Image.fromarray(mb), inpainting_fill=1, inpaint_full_res=True, inpaint_full_res_padding=8, mask_blur=0)
+    r5 = processing.process_images(p5)
+    assert r5.images[0].shape == (192, 256, 3) and p5.paste_to is not None and p5.extra_generation_params["Inpaint area"] == "Only masked"
+    assert np.array_equal(r5.images[0][mb == 0], np.array(big)[mb == 0])
+    # inverted mask mode and a blank mask
+    p6 = job(init_images=[base], mask_image=mask, inpainting_fill=1, inpaint_full_res=False, mask_blur=0, inpainting_mask_invert=1)
+    r6 = processing.process_images(p6)
+    assert np.array_equal(r6.images[0][~keep], np.array(base)[~keep]) and p6.extra_generation_params["Mask mode"] == "Inpaint not masked"
+    p7 = job(init_images=[base], mask_image=Image.fromarray(np.zeros((H, W), np.uint8)), inpaint_full_res=True)
+    r7 = processing.process_images(p7)
+    assert p7.latent_mask is None and p7.overlay_images == [] or p7.latent_mask is None
+    assert r7.images[0].shape == (H, W, 3)
