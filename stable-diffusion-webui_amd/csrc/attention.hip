@@ -26,6 +26,31 @@ namespace sdmi {
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
+// Maximum of the NKB x 16 scores a lane holds, as a TREE of v_max3_f32 (depth 4 for 32 values) instead of the 16-deep dependent chain
+// the running form `mx = fmaxf(mx, s[i])` compiles to: the resident waves of the flash kernels overlap each other so little (section
+// timers, profiles/r03_attn_pp_sections.txt) that a wave's serial latency, not the issue slots, is what the softmax section costs.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+template <int NKB>
+__device__ __forceinline__ float tree_max(const f16v (&sc)[NKB]) {
+    constexpr int N = NKB * 16;
+    float v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = sc[i >> 4][i & 15];
+    int n = N;
+#pragma unroll
+    for (int level = 0; level < 6; ++level) {
+        if (n <= 1) break;
+        const int m = (n + 2) / 3;
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            const int a = 3 * i, b = a + 1 < n ? a + 1 : a, c = a + 2 < n ? a + 2 : a;
+            v[i] = max3f(v[a], v[b], v[c]);
+        }
+        n = m;
+    }
+    return v[0];
+}
+
 // VAR = forms of the d = 40 level-0 self-attention loop (profiles/r02_attention_experiments.md); selected
 // with SDMI_ATTN_OCC=<VAR> / sdmi_debug_set("attn_occ", VAR); 15 is the default for d = 40 (see g_attn_occ):
 //   0  round-1 kernel: register budget for 2 workgroups per CU (D <= 80) or 1; one ds_read -> wait -> MFMA chain per MFMA
@@ -37,9 +62,10 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 //      Same products in the same order per accumulator: bit-identical to 0 and 5 (tests/test_gpu_ops.py).
 //  10..14, 18  (-DSDMI_ATTN_PARTS builds only, tools/gpu/attn_parts.py) 5 with one component removed / 15 with section timers
 template <int D, int KVT, int VAR = 0>
-__global__ __launch_bounds__(256, ((VAR == 15 || VAR == 18) ? 3 : (VAR == 5 || VAR >= 10) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
+__global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (VAR == 5 || VAR >= 10) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
     constexpr bool LAZY_RESCALE = VAR >= 5;
-    constexpr bool PREF = VAR == 15 || VAR == 18;
+    constexpr bool PREF = VAR == 15 || VAR == 16 || VAR == 18;
+    constexpr bool TREEMAX = VAR == 16;      // 16 = 15 with the tile maximum taken as a v_max3 tree (serial depth 4 instead of 16)
     constexpr bool TIMING = VAR == 18;       // s_memtime stamps around the sections of an iteration (AttnP::dbg)
     long long tm[6] = {0, 0, 0, 0, 0, 0};
     auto stamp = [&]() -> long long {
@@ -246,10 +272,13 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 18) ? 3 : (VAR == 5 || V
         float mx = -INFINITY;
         if constexpr (NO_MAX) { mx = sc[0][0] * p.scale_log2; }
         else {
+        if constexpr (TREEMAX) mx = tree_max<NKB>(sc);
+        else {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+        }
         if constexpr (PREF) {
             // the other half-wave's maximum without the LDS round trip of ds_bpermute: v_permlane32_swap_b32 on two copies leaves
             // (lower-half value, upper-half value) of the same query in every lane
@@ -599,11 +628,7 @@ __global__ __launch_bounds__(NG * 256, NG) void attn_pp_kernel(AttnP p) {
                 for (int r = 0; r < 16; ++r)
                     if (32 * kb + 16 * (r >> 3) + (r & 7) >= lim) sc[kb][r] = -INFINITY;
         }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+        float mx = tree_max<NKB>(sc);
         {
             float mlo = mx, mhi = mx;
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mlo), "+v"(mhi));
@@ -899,6 +924,7 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
                 if (!(kvt128 && p.M > 64)) {
                     if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
                     if (g_attn_occ == 15) return launch_attn_d<40, 64, 15>(p, s);
+                    if (g_attn_occ == 16) return launch_attn_d<40, 64, 16>(p, s);
 #ifdef SDMI_ATTN_PARTS
                     if (g_attn_occ == 10) return launch_attn_d<40, 64, 10>(p, s);
                     if (g_attn_occ == 11) return launch_attn_d<40, 64, 11>(p, s);

@@ -400,22 +400,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
             } else {
                 constexpr bool PIPEW = TN <= 5 && !LNF;             // (LayerNorm-folded layers never carry a residual: no ring registers)
                 const bool colb = p.bias && !(flags & EP_BIAS_ROW);
-                // (the row-sum variant needs the 20 registers of the hoisted bias; the LayerNorm consumer has no residual ring, so it can
-                // afford both its per-column vectors — loaded per (row pair, column tile) inside the store loop they made the folded
-                // q|k projection 2x slower than LayerNorm + the plain GEMM: GPU run 2 of round 3)
-                constexpr bool HOISTB = (PIPEW && !LNS) || (LNF && TN <= 5);
+                // (the row-sum variant needs the 20 registers of the hoisted bias.  The LayerNorm consumer keeps its per-column vectors as
+                // per-use loads: hoisting all of them — 56 registers with the row statistics — spills the 256x320 instantiation, GPU run 3
+                // of round 3; and per-use loads behind stores wait on vmcnt for the STORES too, which is why the folded projections run
+                // ~2x slower than LayerNorm + plain GEMM.  The option stays experimental: what it could save is ~5 ms per C1 job.)
+                constexpr bool HOISTB = PIPEW && !LNS;
                 f4 bcw[HOISTB ? TN : 1];
                 if constexpr (HOISTB) {
                     if (colb) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) bcw[j] = *reinterpret_cast<const f4*>(p.bias + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
                     }
-                }
-                constexpr bool HOISTS = LNF && TN <= 5;
-                [[maybe_unused]] f4 svw[HOISTS ? TN : 1];
-                if constexpr (HOISTS) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) svw[j] = *reinterpret_cast<const f4*>(p.ln_s + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
                 }
                 // (row-sum variant on the 5-column-tile wave tiles: a one-deep ring — the pair a+1 residual is requested once pair a's
                 // accumulators are dead, or the 256x320 instantiation spills; the other variants prefetch one pair ahead)
@@ -452,9 +447,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                         for (int r = 0; r < 4; ++r) { vx[r] *= p.alpha; vy[r] *= p.alpha; }
                         if constexpr (LNF) {
                             const f2e sx = lst[2 * a], sy = lst[2 * a + 1];
-                            f4 sv;
-                            if constexpr (HOISTS) sv = svw[j];
-                            else sv = *reinterpret_cast<const f4*>(p.ln_s + n);
+                            const f4 sv = *reinterpret_cast<const f4*>(p.ln_s + n);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { vx[r] = sx[1] * (vx[r] - sx[0] * sv[r]); vy[r] = sy[1] * (vy[r] - sy[0] * sv[r]); }
                         }
