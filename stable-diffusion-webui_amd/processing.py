@@ -310,6 +310,8 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
         image = (self.init_images.to(self.sd_model.device, dtype=torch.float32) * 2.0 - 1.0).contiguous()
         moments = self.sd_model.encode_first_stage(image)
         self.init_latent_all = self.sd_model.get_first_stage_encoding(moments)
+        if getattr(self, "_latent_mask_pil", None) is not None:
+            self._latent_mask_from_pil()
         if self.latent_mask is not None and self.inpainting_fill in (2, 3):
             dev = self.init_latent_all.device
             keep = self.latent_mask.to(dev, torch.float32).expand_as(self.init_latent_all).contiguous()
@@ -395,17 +397,23 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
         else:
             raise RuntimeError(f"bad number of images passed: {len(imgs)}; expecting {self.batch_size * self.n_iter} or less")
         self.init_images = torch.from_numpy(batch)
+        self._latent_mask_pil = None
         if image_mask is not None:
-            h, w = self.height // opt_f, self.width // opt_f
-            latmask = latent_mask.convert('RGB').resize((w, h))
-            latmask = np.moveaxis(np.array(latmask, dtype=np.float32), 2, 0)[0] / 255
-            if self.mask_round:
-                latmask = np.around(latmask)
-            self.latent_mask = torch.from_numpy(1.0 - np.tile(latmask[None, None], (batch.shape[0], opt_C, 1, 1))).float()    # 1 = keep
+            self._latent_mask_pil = latent_mask                 # resized to the latent grid once the init latent exists (init)
             cond = np.array(image_mask.convert("L")).astype(np.float32) / 255.0
             self.image_mask = torch.from_numpy(cond[None, None])
         else:
             self.latent_mask = self.image_mask = None
+
+    def _latent_mask_from_pil(self):
+        """modules/processing.py:1733-1742: the mask image resized (PIL default filter) to the init latent's grid, red channel / 255,
+        rounded when mask_round, tiled over the latent channels; stored as 1 = keep (the reference's self.mask = 1 - latmask)."""
+        n, c, h, w = self.init_latent_all.shape
+        latmask = self._latent_mask_pil.convert('RGB').resize((w, h))
+        latmask = np.moveaxis(np.array(latmask, dtype=np.float32), 2, 0)[0] / 255
+        if self.mask_round:
+            latmask = np.around(latmask)
+        self.latent_mask = torch.from_numpy(1.0 - np.tile(latmask[None, None], (n, c, 1, 1))).float()
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
         """modules/processing.py:1759-1789"""

@@ -173,6 +173,36 @@ def test_conv_gemm_split_k_is_exact_and_deterministic(dev, cfg, split):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("cfg,split", [(0, 3), (5, 4), (8, 2), (8, 8), (3, 6), (4, 2), (9, 4)])
+def test_split_k_reduced_inside_the_launch_equals_the_reduce_kernel(dev, cfg, split):
+    """GemmP::splitk_cnt (knob splitk_inkernel): each tile's last-arriving K slice sums the slabs itself, in slice order, and runs the
+    ordinary epilogue — no second launch.  Same slabs, same summation order, same epilogue arithmetic as splitk_reduce_kernel: the bits
+    must be equal, on every split-capable tile configuration, with bias + per-image row bias + residual, a ragged M, repeated launches
+    (the counters must come back to zero) and a batch of GEMMs in one launch."""
+    ops, lib = sub("ops"), sub("_lib")
+    for B, H, W in ((2, 8, 8), (3, 7, 9)):
+        cin, cout = 1280, 1280
+        x, w = seeded((B, H, W, cin), 11), seeded((cout, cin, 3, 3), 12, scale=(cin * 9) ** -0.5)
+        b, rb, res = seeded((cout,), 13, 0.1), seeded((B, cout), 14), seeded((B, H, W, cout), 15)
+        wp = ops.pack_conv_weight(w.half().to(dev))
+        args = dict(bias=b.to(dev), rowbias=rb.to(dev).contiguous(), resid=res.half().to(dev))
+        outs = {}
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
+        try:
+            for mode in (0, 1, 1, 0, 1):
+                lib.check(lib.lib.sdmi_debug_set(b"splitk_inkernel", mode))
+                out = ops.conv_gemm(x.half().to(dev), wp, **args)
+                torch.cuda.synchronize()
+                outs.setdefault(mode, []).append(out)
+        finally:
+            lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
+            lib.check(lib.lib.sdmi_debug_set(b"splitk_inkernel", -1))
+        ref = _conv_ref(h(x), h(w), b) + rb[:, None, None, :] + h(res)
+        assert rel_l2(outs[1][0].float().cpu(), ref) < 6e-4, (cfg, split)
+        for o in outs[0] + outs[1]:
+            assert torch.equal(o, outs[0][0]), (cfg, split, B, H, W)
+
+
 PHASE_CASES = [
     # (cfg, B, H, W, c0, c1, cout, taps, stride, up, split)   cfg 5 = 256x320, 4 = 256x256, 8 = 128x320
     (5, 2, 16, 16, 64, 0, 320, 1, 1, False, 0),        # K = 64: a single K tile (prologue only)
