@@ -1657,7 +1657,7 @@ int engine_hypernet_layernorm(sdmi_engine* e, int dim, int which, const void* g,
     SDMI_CHECK_HIP(hipSetDevice(e->device));
     HnModule* m = hn_module(e, dim, which);
     SDMI_REQUIRE(m != nullptr, "sdmi_unet_hypernet_begin first");
-    SDMI_REQUIRE(g && b && n % 64 == 0 && n <= 2048, "hypernetwork LayerNorm: width must be a multiple of 64 and <= 2048");
+    SDMI_REQUIRE(g && b && n % 64 == 0 && n <= 3072, "hypernetwork LayerNorm: width must be a multiple of 64 and <= 3072");
     std::map<std::string, RawTensor> tmp;
     const int64_t sh[1] = {n};
     TRY(load_raw(tmp, "n.weight", g, dtype, 1, sh, on_device));

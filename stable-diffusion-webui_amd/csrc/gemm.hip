@@ -1480,7 +1480,9 @@ int g_gemm_dbgflags = 0;
 
 template <int BM, int BN>
 static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
-    if (g_gemm_dbg && !(p.flags & EP_GEGLU)) {            // tuning: instrumented instantiation
+    // tuning: instrumented instantiation — never for a launch that promised GroupNorm / LayerNorm partial sums to its consumer (the
+    // instrumented kernel has no such epilogue: the consumer would normalise with sums that were never written)
+    if (g_gemm_dbg && !(p.flags & EP_GEGLU) && p.stats_nchunk == 0 && p.lnp_np == 0 && !(p.flags & EP_LNFOLD)) {
         GemmP q = p;
         q.dbg = (long long*)g_gemm_dbg;
         constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;
@@ -1656,6 +1658,7 @@ int gemm_set_override(const char* spec) {
         ShapeChoice sc{};
         int n = 0;
         if (sscanf(c, "%d,%d,%d,%d,%d:%d:%d%n", &sc.k.M, &sc.k.N, &sc.k.K, &sc.k.taps, &sc.k.kind, &sc.cfg, &sc.split, &n) != 7) return 1;
+        if (sc.split > 8) sc.split = 8;                      // gemm_splitk_ws_bytes sizes the slab workspace for 8 slices
         g_gemm_override.push_back(sc);
         c += n;
         if (*c == ';') ++c;
@@ -1674,7 +1677,7 @@ static const ShapeChoice* find_shape(const GemmP& p) {
 static int pick_cfg(const GemmP& p, int batch, int* split_out, bool allow_split) {
     *split_out = 1;
     if (g_force_gemm_cfg >= 0 && cfg_valid(g_force_gemm_cfg, p)) {
-        if (allow_split && g_force_gemm_split > 1 && p.K / 64 / g_force_gemm_split >= 4) *split_out = g_force_gemm_split;
+        if (allow_split && g_force_gemm_split > 1 && p.K / 64 / g_force_gemm_split >= 4) *split_out = std::min(g_force_gemm_split, 8);   // workspace: 8 slices
         return g_force_gemm_cfg;
     }
     if (g_force_gemm_split == 1) allow_split = false;

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
 
 // Single-launch GroupNorm(+SiLU) for the small levels (8x8 / 16x16 / 32x32 latents: 2.6 - 40 MB tensors that the two-pass pair above
 // spends ~20 us on whatever their size — two dependent launches of 32 workgroups each, one pixel loop per thread): one workgroup per
-// (image, group) holds the group's HW x cpg values in registers (<= NVT 16-byte vectors per thread), so the tensor is read ONCE;
+// (image, group) holds the group's HW x cpg values in registers (<= NVT 16-byte vectors per thread, NVT = 4 or 12), so the tensor is read ONCE;
 // mean first, then the centred sum of squares (two-pass in registers), fixed reduction order (lane partials -> wave shuffle tree ->
 // LDS -> every thread adds the 4 wave sums in order): deterministic.  Needs cpg % 8 == 0 (C = 256, 512, 1280, 2560 at 32 groups).
 template <int NVT>
@@ -269,14 +269,15 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     {
         const int cpg = C / groups;
         const long nv = (long)HW * (cpg / 8);
-        if (pre_nchunk <= 0 && g_gn_small && cpg % 8 == 0 && nv <= 24 * 256) {
+        // (<= 12 vectors per thread: the 24-vector instantiation needs all 256 VGPRs — one workgroup per SIMD — and ran the 32x32-latent
+        // C = 1280 norm at 77 us against 33 us for the two-pass pair: GPU run 2 of round 3)
+        if (pre_nchunk <= 0 && g_gn_small && cpg % 8 == 0 && nv <= 12 * 256) {
             snprintf(pname, sizeof pname, "groupnorm_silu_fused B%d HW%d C%d", B, HW, C);
             ProfScope ps(pname, 0.0, 2.0 * B * (double)HW * C * 2.0, s);                            // read once + write once
             const dim3 grid(groups, B);
 #define SDMI_GNS(NVT) hipLaunchKernelGGL((gn_fused_small_kernel<NVT>), grid, dim3(256), 0, s, x0, x1, c0, c1, HW, groups, gamma, beta, out, eps, silu ? 1 : 0)
             if (nv <= 4 * 256) SDMI_GNS(4);
-            else if (nv <= 12 * 256) SDMI_GNS(12);
-            else SDMI_GNS(24);
+            else SDMI_GNS(12);
 #undef SDMI_GNS
             SDMI_CHECK_HIP(hipGetLastError());
             return 0;
@@ -494,7 +495,7 @@ int launch_ln_fold_weights(const half_t* w, const float* gamma, const float* bet
 
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
                      float eps, hipStream_t s) {
-    SDMI_REQUIRE(C % 8 == 0 && C <= 2048, "LayerNorm: C % 8 == 0 and C <= 2048");
+    SDMI_REQUIRE(C % 8 == 0 && C <= 3072, "LayerNorm: C % 8 == 0 and C <= 3072");
     char pname[48];
     snprintf(pname, sizeof pname, "layernorm rows%ld C%d", (long)rows, C);
     ProfScope ps(pname, 0.0, 2.0 * (double)rows * C * 2.0, s);
@@ -505,7 +506,9 @@ int launch_layernorm(const half_t* x, const float* gamma, const float* beta, hal
     if (K == 1) SDMI_LN(1, 4);
     else if (K == 2) SDMI_LN(2, 2);
     else if (K == 3) SDMI_LN(3, 1);
-    else SDMI_LN(4, 1);
+    else if (K == 4) SDMI_LN(4, 1);
+    else if (K == 5) SDMI_LN(5, 1);                          // C up to 2560: the hidden layer of a [1, 2, 1] hypernetwork on the 1280-wide levels
+    else SDMI_LN(6, 1);
 #undef SDMI_LN
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;

@@ -424,6 +424,11 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             self.mask = self.latent_mask[lo:lo + self.batch_size].to(dev, torch.float32).expand_as(self.init_latent).contiguous()
             self.nmask = (1.0 - self.mask).contiguous()
         x = self.rng.next()
+        if tuple(x.shape) != tuple(self.init_latent.shape):
+            # the reference draws noise at (4, height // 8, width // 8) and adds it to the encoded image: a VAE with another downscale
+            # factor, or init tensors of another size than width x height, is a shape error there (torch broadcast) and must be one here
+            raise ValueError(f"img2img: init latent {tuple(self.init_latent.shape)} does not match the noise shape {tuple(x.shape)} "
+                             f"of a {self.width}x{self.height} job (init_images must encode to (4, height // {opt_f}, width // {opt_f}))")
         if self.initial_noise_multiplier != 1.0:                                # :1762-1764
             x = ops.lincomb(x, [x], [float(self.initial_noise_multiplier)])
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)

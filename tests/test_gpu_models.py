@@ -1171,8 +1171,9 @@ def test_img2img_pil_front_end_fill_only_masked_and_overlay(dev, tiny):
     the unmasked part of every output IS the original image; "only masked" returns the full-size picture; an all-black mask turns the
     job into plain img2img."""
     from PIL import Image
-    processing = sub("processing")
-    model = tiny["model"]
+    processing, schema, sd_models = sub("processing"), sub("schema"), sub("sd_models")
+    ucfg, vcfg = schema.tiny_unet(), schema.tiny_vae(ch_mult=(1, 1, 2, 2))       # the PIL front-end works at width x height: needs the x8 VAE
+    model = sd_models.SdModel(schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16), ucfg, vcfg, device=0)
     g = np.random.RandomState(12)
     W = H = 128
     base = Image.fromarray(g.randint(0, 256, size=(H, W, 3)).astype(np.uint8))
@@ -1224,3 +1225,8 @@ def test_img2img_pil_front_end_fill_only_masked_and_overlay(dev, tiny):
     r7 = processing.process_images(p7)
     assert p7.latent_mask is None and p7.overlay_images == [] or p7.latent_mask is None
     assert r7.images[0].shape == (H, W, 3)
+    # a VAE of another downscale factor cannot meet the (4, height // 8, width // 8) noise: a loud error, never an out-of-bounds read
+    with pytest.raises(ValueError, match="does not match the noise shape"):
+        processing.process_images(processing.StableDiffusionProcessingImg2Img(
+            sd_model=tiny["model"], c=cond, uc=uncond, seed=77, batch_size=2, steps=4, cfg_scale=4.0, width=W, height=H, sampler_name="Euler a",
+            denoising_strength=0.6, init_images=[base]))

@@ -547,7 +547,7 @@ def test_groupnorm_silu_vs_torch(dev, c0, c1, hw, silu):
     assert rel_l2(got.float().cpu(), ref) < 5e-4
 
 
-@pytest.mark.parametrize("c", [64, 320, 640, 1280])
+@pytest.mark.parametrize("c", [64, 320, 640, 1280, 1920, 2560, 3072])     # 2560: hidden width of a [1, 2, 1] hypernetwork on the 1280-wide levels
 def test_layernorm_vs_torch(dev, c):
     ops = sub("ops")
     x = seeded((3, 50, c), 1) * 2 + 0.5
