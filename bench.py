@@ -65,6 +65,11 @@ def sub(name):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--pmc-traffic", action="store_true",
+                    help="take the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of one job of this workload before the roofline block, so "
+                         "that roofline.traffic is measured in this run (adds ~2-3 minutes; rank 0, N = 1)")
+    ap.add_argument("--verify-shards", action="store_true",
+                    help="N > 1: after the timed region, replay every rank's slice on rank 0 and compare with the gathered images (config.shard_check)")
     ap.add_argument("--steps", type=int, default=3, help="timed jobs (one job = the global batch through the whole path)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c1", choices=sorted(CONFIGS))
@@ -77,7 +82,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0)
-    ap.add_argument("--cpu-baseline-budget", type=float, default=75.0, help="seconds of CPU timing the baseline may spend (it adapts its repetitions)")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=110.0, help="seconds of CPU timing the baseline may spend (it adapts its repetitions)")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0, help="hard wall limit of the baseline child process")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline alone and print its JSON")
     args = ap.parse_args()
@@ -130,7 +135,7 @@ def model_configs(args):
     return schema.sd15_unet(), schema.sd15_vae()
 
 
-def make_job(args, model, rank, world, local_only=False):
+def make_job(args, model, rank, world, local_only=False, replay=None):
     """The GLOBAL job (batch per GPU x world images) as one processing object; every rank builds the same one and
     process_images_sharded takes its slice."""
     import torch
@@ -166,6 +171,8 @@ def make_job(args, model, rank, world, local_only=False):
             p = processing.StableDiffusionProcessingTxt2Img(c=c_dev, uc=uc_dev, **kw)
         if y is not None:
             p.y, p.uy = y, uy
+        if replay is not None:                                 # one rank's slice of the SAME global job, replayed in this process
+            return par.process_images_sharded(p, world=world, rank=replay)
         return par.process_images_sharded(p, world=1, rank=0) if local_only else par.process_images_sharded(p)
     return run_once, (lo, hi)
 
@@ -225,20 +232,78 @@ def dropin_path(args, model, jobs=3):
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch of the gemm_mfma family from rocprofv3 PMC passes of this same workload (tools/gpu/profile.sh ->
-    tools/summarize_profiles.py) and where they were taken: on this box in this session (gpurun_out/pmc_traffic.json) or the committed
-    passes of an earlier box (profiles/r02_pmc_traffic.json: same code path and workload, another GPU).  (None, None) when absent."""
-    for path, src in ((os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "PMC passes of this workload on this box (gpurun_out/pmc_traffic.json)"),
-                      (os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"),
-                       "committed PMC passes of this workload from another run / box (profiles/r02_pmc_traffic.json) - not measured in this run")):
-        if os.path.exists(path):
-            try:
-                d = json.load(open(path))
-                if d.get("workload") == f"{args.config}:{args.sampler_steps}":
-                    return d.get("gemm_mfma_bytes_per_launch"), src
-            except Exception:
-                pass
+    """HBM bytes per launch of the gemm_mfma family from rocprofv3 PMC passes of this same workload ON THIS BOX: either taken by this very
+    run (--pmc-traffic: measure_pmc_traffic below) or by tools/gpu/profile.sh earlier in the same box session (gpurun_out/ is scratch and
+    never travels, so a file there was written here).  (None, None) otherwise — a figure from another box is not reported."""
+    path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
+    if os.path.exists(path):
+        try:
+            d = json.load(open(path))
+            if d.get("workload") == f"{args.config}:{args.sampler_steps}":
+                return d.get("gemm_mfma_bytes_per_launch"), d.get("source", "PMC passes of this workload on this box (gpurun_out/pmc_traffic.json)")
+        except Exception:
+            pass
     return None, None
+
+
+def measure_pmc_traffic(args):
+    """--pmc-traffic: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE — they do not fit one pass; kernel trace only, as the guide's
+    HBM section prescribes) over ONE job of this workload in child processes, summed over the gemm_mfma launches: bytes per launch =
+    (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches (gfx950 tallies 128-byte read requests at 64 B: FETCH_SIZE is doubled).  Writes
+    gpurun_out/pmc_traffic.json, which pmc_traffic() then reports.  A flag the driver's command does not need: without it `traffic` is
+    null unless tools/gpu/profile.sh ran on this box."""
+    import collections
+    import glob
+    import shutil
+    import sqlite3
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    passthrough = [a for a in sys.argv[1:] if a not in ("--pmc-traffic", "--verify-shards")]
+    drop_with_value = ("--steps", "--warmup", "--gpus")
+    child = []
+    skip = False
+    for a in passthrough:
+        if skip:
+            skip = False
+            continue
+        if a in drop_with_value:
+            skip = True
+            continue
+        if any(a.startswith(k + "=") for k in drop_with_value):
+            continue
+        child.append(a)
+    child += ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    for counter, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        d = os.path.join(out_dir, f"prof_pmc_{tag}")
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + child
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+        dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
+        if r.returncode != 0 or not dbs:
+            print(f"bench.py: PMC pass {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-400:]}", file=sys.stderr)
+            return None
+        acc = collections.defaultdict(lambda: [0, 0.0])
+        con = sqlite3.connect(dbs[0])
+        for name, val in con.execute("select kernel_name, value from counters_collection where counter_name=?", (counter,)):
+            a = acc[name]
+            a[0] += 1; a[1] += val
+        sums[tag] = acc
+    calls = kb = 0.0
+    for name, (c, fv) in sums["fetch"].items():
+        if "gemm_mfma" in name:
+            wc, wv = sums["write"].get(name, [1, 0.0])
+            calls += c
+            kb += 2.0 * fv + wv * c / max(wc, 1)
+    if not calls:
+        return None
+    res = {"workload": f"{args.config}:{args.sampler_steps}", "gemm_mfma_bytes_per_launch": round(kb * 1024 / calls), "gemm_mfma_launches": int(calls),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one job of this workload, taken by this bench.py run (--pmc-traffic)",
+           "note": "2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, per launch over the gemm_mfma family"}
+    json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+    return res
 
 
 def roofline_block(args, run_once):
@@ -370,13 +435,33 @@ def cpu_baseline(args, sd=None):
     if args.img2img:
         evals = 16
     per_image = evals * t_pair + t_dec
+    # BASELINE.md section 3's own protocol when the budget has room for it: the CFG step at the workload's batch (one UNet forward of
+    # 2 x batch rows), measured twice, instead of `batch` single-image pairs — large-batch GEMMs use the host's cores better.
+    step_note = ""
+    nb = args.batch
+    if nb > 1 and args.model != "tiny" and time.time() + 2.2 * nb * t_pair < deadline:
+        gb = torch.Generator().manual_seed(2)
+        xb = torch.randn(2 * nb, 4, hw, hw, generator=gb)
+        cb = torch.randn(2 * nb, 77, ucfg.context_dim, generator=gb)
+        yb = torch.randn(2 * nb, ucfg.adm_in_channels, generator=gb) if ucfg.adm_in_channels else None
+        tb = torch.full((2 * nb,), 500.0)
+        with torch.no_grad():
+            ts = []
+            for _ in range(2):
+                t0 = time.time(); om.apply_model(xb, tb, cb, yb); ts.append(time.time() - t0)
+        t_step = min(ts)
+        out["cfg_step_at_batch"] = {"seconds": round(t_step, 3), "rows": 2 * nb, "runs": 2,
+                                    "per_image_pair_equivalent_s": round(t_step / nb, 3)}
+        if t_step / nb < t_pair:
+            per_image = evals * (t_step / nb) + t_dec
+            step_note = f"; UNet cost taken from 2 measured CFG steps at batch {nb} ({2 * nb} rows, {t_step:.2f}s best) = {t_step / nb:.2f}s per image-evaluation"
     if args.hires:
         per_image = None
     out.update({"value": round(1.0 / per_image, 6) if per_image else None, "unit": "images/s", "cores": threads, "kind": "port",
                 "sample": f"1 CFG pair of UNet forwards (batch 2) = {t_pair:.2f}s + 1 VAE decode = {t_dec:.2f}s at "
                           f"{args.size}x{args.size} ({'median of 3 after 1 warm-up' if n_pair > 1 else 'one cold run'}), extrapolated to "
                           f"{evals} evaluations + decode per image; fp32 torch CPU, {threads} threads of {host} usable "
-                          f"({os.cpu_count()} host) hardware threads" + ("; " + "; ".join(sorted(set(notes))) if notes else "")})
+                          f"({os.cpu_count()} host) hardware threads" + step_note + ("; " + "; ".join(sorted(set(notes))) if notes else "")})
     return out
 
 
@@ -429,7 +514,8 @@ def main():
     t_bcast = 0.0
     if world > 1:
         torch.cuda.synchronize(); par.barrier(); t0 = time.time()
-        sd = par.broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank))
+        import torch.distributed as dist
+        sd = par.broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
         torch.cuda.synchronize(); t_bcast = time.time() - t0
     model = sd_models.SdModel(sd, ucfg, vcfg, device=local_rank, vae_decoder_only=not (args.img2img))
     del sd
@@ -444,6 +530,26 @@ def main():
     torch.cuda.synchronize(); par.barrier()
     elapsed = par.max_over_ranks(time.time() - t0, device=torch.device("cuda", local_rank))
 
+    shard_check = None
+    if args.verify_shards and world > 1:
+        # the gathered images of one more sharded job against rank-local replays of every rank's slice on rank 0's GPU: the images are
+        # functions of (weights, cond row, seed + global index) only, so they must be bit-identical (same per-call batch size)
+        whole = run_once()
+        if rank == 0:
+            import numpy as np
+            bad = []
+            for r in range(world):
+                res_r = make_job(args, model, 0, world, replay=r)[0]()
+                lo_r, hi_r = res_r.shard
+                if len(res_r.images) != hi_r - lo_r or not all(np.array_equal(a, b) for a, b in zip(res_r.images, whole.images[lo_r:hi_r])):
+                    bad.append(r)
+            shard_check = "ok" if not bad and len(whole.images) == args.batch * world else f"MISMATCH on the slices of ranks {bad}"
+        par.barrier()
+    if args.pmc_traffic and rank == 0 and world == 1 and not args.no_roofline:
+        try:
+            measure_pmc_traffic(args)
+        except Exception as ex:                                # never lose the bench line to the profiler
+            print(f"bench.py: --pmc-traffic failed: {type(ex).__name__}: {ex}", file=sys.stderr)
     roof, kernels = (None, None)
     if rank == 0 and not args.no_roofline:
         if world > 1:                                  # profile this rank's slice alone (no collective inside the profiled pass)
@@ -480,6 +586,7 @@ def main():
                    "sharding": "process_images_sharded: contiguous image ranges, seeds 1000 + global index, uint8 gather to rank 0 per job",
                    "weights": "synthetic N(0,1/fan_in) in the checkpoint's state-dict schema (seed 0x5D15)",
                    "weights_broadcast_ms": round(t_bcast * 1e3, 1), "weights_generate_s": round(t_gen, 1),
+                   "shard_check": shard_check,
                    "algorithmic_tflop_per_image": tflop_per_image,
                    "dropin_images_per_s": dropin,
                    "dropin_path": "torch stand-in of the reference's CFGDenoiser + Euler-a loop calling Mi355xUnet.forward per step + engine VAE decode (bench.py dropin_path)",

@@ -864,6 +864,7 @@ int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e
 // default 15 since round 2: same-box A/Bs on the C1 job — 0 -> 5: self-attention 72.4 -> 69.5 ms per job (profiles/r02_knob_sweep.md);
 // 5 -> 15: 68.2 -> 66.6 and 70.0 -> 68.7 ms on two boxes (profiles/r02_attention_experiments.md)
 int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 15; }();
+int g_attn_lds_pad = 0;      // tuning only: extra dynamic LDS per workgroup (bytes) = an occupancy limiter (32 KB + pad per workgroup of 160 KB)
 int g_attn_pp_min_m = [] { const char* e = getenv("SDMI_ATTN_PP_MIN_M"); return e ? atoi(e) : 256; }();   // shortest key sequence the 8-wave kernel takes
 
 template <int D, int KVT, int VAR = 0>
@@ -871,13 +872,14 @@ static int launch_attn_d(const AttnP& p, hipStream_t s) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     constexpr int SMEM = 2 * (KVT * (DK * 2 + 16) + DV * (KVT * 2 + 16));
     auto kern = attn_mfma_kernel<D, KVT, VAR>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
+    static int attr_set = -1;
+    const int smem = SMEM + (g_attn_lds_pad > 0 ? g_attn_lds_pad : 0);
+    if (attr_set < smem) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = smem;
     }
     dim3 grid(cdiv(p.N, 128), p.B * p.H);
-    hipLaunchKernelGGL(kern, grid, dim3(256), SMEM, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }

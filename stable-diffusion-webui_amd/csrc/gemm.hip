@@ -1727,7 +1727,7 @@ static int* splitk_counters() {                              // per device, zero
 }
 
 size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch) {
-    if (K < 64 * 24 || N % 64) return 0;                    // split needs >= 12 BK-steps per slice
+    if (K < 64 * 16 || N % 64) return 0;                    // the score model splits at >= 12 BK-steps per slice; tuned shapes (gemm_tuned_shapes.inc) may go down to 8
     if ((long)cdiv(M, 128) * cdiv(N, 128) * batch >= 512) return 0;   // chip already full with ordinary tiles
     return (size_t)8 * M * N * batch * sizeof(float);
 }

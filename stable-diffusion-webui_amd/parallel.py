@@ -27,8 +27,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Join the process group the launcher (torch.distributed.run) described in the environment."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:                                   # SDMI_DIST_BACKEND=gloo: several ranks on ONE GPU (the single-GPU test of the N > 1 bench path)
+            backend = os.environ.get("SDMI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

@@ -41,6 +41,14 @@ class InterruptedException(BaseException):
     pass
 
 
+
+def _same_shape(a, b, what_a, what_b):
+    """The element-wise kernels take one length for all their operands: a torch broadcast error in the reference is a ValueError here,
+    never a read past the shorter tensor."""
+    if tuple(a.shape) != tuple(b.shape):
+        raise ValueError(f"{what_a} {tuple(a.shape)} and {what_b} {tuple(b.shape)} differ in shape")
+
+
 def setup_img2img_steps(p, steps=None):
     """modules/sd_samplers_common.py:22-31"""
     if shared.opts.img2img_fix_steps or steps is not None:
@@ -390,7 +398,11 @@ class CFGDenoiser:
                 raise AssertionError("AND is not supported for InstructPix2Pix checkpoint (unless using Image CFG scale = 1.0)")
         split_calls = tensor.shape[1] != uncond.shape[1] and not skip_uncond      # :253-268: one UNet call per context length
         if is_edit_model and (split_calls or skip_uncond):
-            raise NotImplementedError("InstructPix2Pix with skip-uncond or cond / uncond of different token counts")
+            # not a gap: the reference cannot run these either.  With skip-uncond it drops the last group of x_in / sigma_in but still
+            # concatenates three groups of text and image conditioning (:233-235, :244-245: a batch-size mismatch inside apply_model);
+            # with cond / uncond of different token counts it calls torch.cat([tensor[a:b]], uncond) (:265: a TypeError).
+            raise RuntimeError("InstructPix2Pix checkpoints cannot be sampled with skip-early-cond, or with cond / uncond of different "
+                               "token counts without pad_cond_uncond (modules/sd_samplers_cfg_denoiser.py:233-245, 265 fail the same way)")
 
         rows = n_cond + (0 if skip_uncond else b) + (b if is_edit_model else 0)
         if (self._x_in is None or self._x_in.shape[0] < max(rows, 2 * b) or self._x_in.shape[1] != cin
@@ -418,12 +430,11 @@ class CFGDenoiser:
             c_out_t = None
             t_model = sig
             if vpred:                                     # eps = sqrt(a_t) * v + sqrt(1 - a_t) * x_t  (sd_samplers_timesteps.py:38-39)
-                if self.need_last_noise_uncond:
-                    raise NotImplementedError("DDIM CFG++ with a v-prediction model is not implemented")
                 ac = sd_model.alphas_cumprod.float().cpu()
                 a_t = ac[int(sig)]
-                c_out_t = torch.full((b,), float(torch.sqrt(a_t)), dtype=torch.float32, device=x.device)
-                c_skip_t = torch.full((b,), float(torch.sqrt(1 - a_t)), dtype=torch.float32, device=x.device)
+                v_c_out, v_c_skip = float(torch.sqrt(a_t)), float(torch.sqrt(1 - a_t))
+                c_out_t = torch.full((b,), v_c_out, dtype=torch.float32, device=x.device)
+                c_skip_t = torch.full((b,), v_c_skip, dtype=torch.float32, device=x.device)
         # x_in rows: every image once per prompt, then (unless skipped) every image once more for uncond (:203-205)
         x_in, eps = self._x_in[:rows], self._eps[:rows]
 
@@ -497,6 +508,12 @@ class CFGDenoiser:
                 self.last_noise_uncond = torch.stack([(eps[first[i]] if skip_uncond else eps[n_cond + i]) for i in range(b)])
         if self.need_last_noise_uncond and pair is eps:
             self.last_noise_uncond = eps[b:2 * b].clone()
+        if self.need_last_noise_uncond and self.mode != 0 and vpred:
+            # DDIM CFG++ on a v-prediction checkpoint: the reference's inner model (CompVisTimestepsVDenoiser.forward, :41-44) has already
+            # turned every row into eps when CFGDenoiser keeps the uncond rows (:281-282); here the conversion is fused into the combine, so
+            # the kept rows are converted on their own: eps_u = sqrt(a_t) * v_u + sqrt(1 - a_t) * x_in
+            lnu = self.last_noise_uncond.contiguous()
+            self.last_noise_uncond = _lc(lnu, [lnu, x.contiguous()], [v_c_out, v_c_skip])
         den = torch.empty_like(x)
         use_mask = (not self.mask_before_denoising) and self.mask is not None
         if c_skip_t is not None:
@@ -1593,6 +1610,7 @@ class KDiffusionSampler(Sampler):
         steps, t_enc = setup_img2img_steps(p, steps)
         sigmas = self.get_sigmas(p, steps)
         sigma_sched = sigmas[steps - t_enc - 1:]
+        _same_shape(x, noise, "sample_img2img: init latent", "noise")
         xi = torch.empty_like(x)
         check(lib.sdmi_axpby(ptr(xi), ptr(x.contiguous()), 1.0, ptr(noise.contiguous()), float(sigma_sched[0]), x.numel(),
                              stream_ptr()), "x + noise*sigma")
@@ -1721,6 +1739,7 @@ class CompVisSampler(Sampler):
         ac = self.sd_model.alphas_cumprod.float().cpu()
         sqrt_alpha_cumprod = torch.sqrt(ac[timesteps[t_enc]])
         sqrt_one_minus_alpha_cumprod = torch.sqrt(1 - ac[timesteps[t_enc]])
+        _same_shape(x, noise, "sample_img2img: init latent", "noise")
         xi = torch.empty_like(x)
         check(lib.sdmi_axpby(ptr(xi), ptr(x.contiguous()), float(sqrt_alpha_cumprod), ptr(noise.contiguous()),
                              float(sqrt_one_minus_alpha_cumprod), x.numel(), stream_ptr()), "ddim img2img noise")

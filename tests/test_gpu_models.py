@@ -546,7 +546,8 @@ def test_clip_l_full_size_vs_oracle(dev):
     assert rel_l2(got.cpu(), ref) < 5e-3
 
 
-@pytest.mark.parametrize("sampler,name,steps", [("euler_a", "Euler a", 4), ("dpmpp_2m", "DPM++ 2M", 5), ("ddim", "DDIM", 5)])
+@pytest.mark.parametrize("sampler,name,steps", [("euler_a", "Euler a", 4), ("dpmpp_2m", "DPM++ 2M", 5), ("ddim", "DDIM", 5),
+                                                ("ddim_cfgpp", "DDIM CFG++", 5)])
 def test_v_prediction_model_vs_oracle(dev, sampler, name, steps):
     """parameterization == "v" (SD 2.x 768-v): CompVisVDenoiser scalings in sigma space, v -> eps conversion in timestep
     space (modules/sd_samplers_timesteps.py:33-45), fused into sdmi_cfg_combine_affine; SD2-style UNet (linear proj_in/out)."""

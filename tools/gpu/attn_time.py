@@ -20,11 +20,13 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "attn_time.json"))
     ap.add_argument("--variants", default="15,20,21")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--lds-pads", default="", help="occupancy probe: comma-separated extra LDS bytes per workgroup for variant 15 (e.g. 0,24000,56000,100000 = 4,2..3,1 workgroups per CU)")
     args = ap.parse_args()
     lib = importlib.import_module(f"{PKG}._lib")
     ops = importlib.import_module(f"{PKG}.ops")
     lib.require_device()
     variants = [int(v) for v in args.variants.split(",")]
+    pads = [int(v) for v in args.lds_pads.split(",")] if args.lds_pads else []
     shapes = [("c1 level 0", 16, 8, 4096, 40), ("c4a hires level 0", 2, 8, 16384, 40), ("c1 level 1", 16, 8, 1024, 80),
               ("c3 sdxl level 1", 8, 10, 4096, 64), ("c3 sdxl level 2", 8, 20, 1024, 64)]
     out = {}
@@ -47,7 +49,22 @@ def main():
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / 10 * 1e3)
         lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
-        out[name] = {"B": b, "H": h, "N": n, "D": d,
+        pad_times = {pd: [] for pd in pads}
+        for rep in range(args.reps if pads else 0):
+            for pd in pads:
+                lib.check(lib.lib.sdmi_debug_set(b"attn_lds_pad", pd))
+                ops.attention_vt(q, k, vt, h, n)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    ops.attention_vt(q, k, vt, h, n)
+                e1.record()
+                torch.cuda.synchronize()
+                pad_times[pd].append(e0.elapsed_time(e1) / 10 * 1e3)
+        lib.check(lib.lib.sdmi_debug_set(b"attn_lds_pad", 0))
+        out[name] = {**{f"occ15_ldspad{pd}": {"us_min": round(min(t), 1), "workgroups_per_cu_by_lds": min(160 * 1024 // (32768 + pd), 8)} for pd, t in pad_times.items()},
+                     "B": b, "H": h, "N": n, "D": d,
                      **{f"occ{v}": {"us_min": round(min(t), 1), "us_median": round(statistics.median(t), 1), "tflops_at_min": round(flops / min(t) / 1e6, 1)}
                         for v, t in times.items()}}
         print(name, out[name], flush=True)

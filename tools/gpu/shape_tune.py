@@ -23,8 +23,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PKG = "stable-diffusion-webui_amd"
-CFG_BN = {0: 128, 2: 64, 3: 128, 4: 256, 5: 320, 7: 64, 8: 320, 9: 160}
-CFG_NAME = {0: "128x128", 2: "64x64", 3: "128x128k32", 4: "256x256", 5: "256x320", 7: "128x64", 8: "128x320", 9: "128x160"}
+CFG_BN = {0: 128, 2: 64, 3: 128, 4: 256, 5: 320, 6: 128, 7: 64, 8: 320, 9: 160}
+CFG_NAME = {0: "128x128", 2: "64x64", 3: "128x128k32", 4: "256x256", 5: "256x320", 6: "256x128", 7: "128x64", 8: "128x320", 9: "128x160"}
 
 
 def sub(name):
@@ -50,10 +50,10 @@ def candidates(key):
     for cfg, bn in CFG_BN.items():
         if N % bn:
             continue
-        if kind == 1 and cfg in (5, 8, 9):
+        if kind == 1 and cfg in (5, 6, 8, 9):
             continue
         splits = [1]
-        if kind == 0 and K >= 64 * 24 and ((M + 127) // 128) * ((N + 127) // 128) < 512:      # a split-K workspace exists for these
+        if kind == 0 and K >= 64 * 16 and ((M + 127) // 128) * ((N + 127) // 128) < 512:      # a split-K workspace exists for these
             splits += [s for s in (2, 3, 4, 6, 8) if K // 64 // s >= 4]
         out += [(cfg, s) for s in splits]
     return out
@@ -65,20 +65,32 @@ def main():
     ap.add_argument("--emit", action="store_true")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--sampler-steps", type=int, default=20)
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"])
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--hires", action="store_true", help="txt2img + hires-fix x2 (the c4a job) instead of plain txt2img")
+    ap.add_argument("--tag", default="r03_shape_tuning")
     args = ap.parse_args()
     lib = sub("_lib")
     lib.require_device()
     schema, sd_models, processing = sub("schema"), sub("sd_models"), sub("processing")
-    ucfg, vcfg = schema.sd15_unet(), schema.sd15_vae()
+    ucfg, vcfg = (schema.sdxl_unet(), schema.sdxl_vae()) if args.model == "sdxl" else (schema.sd15_unet(), schema.sd15_vae())
     sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16)
     model = sd_models.SdModel(sd, ucfg, vcfg, device=0, vae_decoder_only=True)
     del sd
     g = torch.Generator().manual_seed(50_000)
-    c, uc = torch.randn(8, 77, 768, generator=g).cuda(), torch.randn(8, 77, 768, generator=g).cuda()
+    B = args.batch
+    c, uc = torch.randn(B, 77, ucfg.context_dim, generator=g).cuda(), torch.randn(B, 77, ucfg.context_dim, generator=g).cuda()
+    y = uy = None
+    if ucfg.adm_in_channels:
+        y, uy = torch.randn(B, ucfg.adm_in_channels, generator=g).cuda(), torch.randn(B, ucfg.adm_in_channels, generator=g).cuda()
 
     def job():
-        p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=c, uc=uc, seed=1000, batch_size=8, n_iter=1, steps=args.sampler_steps,
-                                                        cfg_scale=7.0, width=512, height=512, sampler_name="Euler a", keep_latents=False)
+        kw = dict(enable_hr=True, hr_scale=2.0, hr_upscaler="Latent", denoising_strength=0.75) if args.hires else {}
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=c, uc=uc, seed=1000, batch_size=B, n_iter=1, steps=args.sampler_steps,
+                                                        cfg_scale=7.0, width=args.size, height=args.size, sampler_name="Euler a", keep_latents=False, **kw)
+        if y is not None:
+            p.y, p.uy = y, uy
         return processing.process_images(p)
 
     def set_override(table):
@@ -123,7 +135,7 @@ def main():
                 results[k][choice] = (per[k][0], per[k][2])
     # split-K launches are followed by a reduce kernel that the per-shape time does not include: charge 12 us per launch
     best = {}
-    report = ["# In-engine per-shape GEMM tuning on the C1 job (tools/gpu/shape_tune.py)\n",
+    report = [f"# In-engine per-shape GEMM tuning (tools/gpu/shape_tune.py): {args.model} {args.size}x{args.size} batch {args.batch}{' + hires x2' if args.hires else ''}, {args.sampler_steps} steps\n",
               "ms = time of all launches of the shape in one profiled job (HIP events); split-K candidates are charged 12 us per launch for the reduce kernel.\n",
               "| shape (M, N, K, taps, kind) | launches | default | ms | best | ms | gain ms | all candidates (cfg/split: ms) |", "|---|---:|---|---:|---|---:|---:|---|"]
     total_gain = 0.0
@@ -159,12 +171,12 @@ def main():
     report.append(f"\nWhole-job A/B (min of {args.reps} interleaved rounds of 2 jobs): default {d:.2f} ms, tuned {t:.2f} ms ({(d - t) / d * 100:+.2f} %).")
     print(report[-1], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    open(os.path.join(ROOT, "gpurun_out", "r02_shape_tuning.md"), "w").write("\n".join(report) + "\n")
-    inc = ["// generated by tools/gpu/shape_tune.py --emit (measured inside the C1 job on an MI355X; profiles/r02_shape_tuning.md)"]
+    open(os.path.join(ROOT, "gpurun_out", f"{args.tag}.md"), "w").write("\n".join(report) + "\n")
+    inc = ["// generated by tools/gpu/shape_tune.py --emit (measured inside the C1 job on an MI355X; profiles/r03_shape_tuning.md)"]
     for k, (cfg, split) in best.items():
         inc.append(f"    {{{{{k[0]}, {k[1]}, {k[2]}, {k[3]}, {k[4]}}}, {cfg}, {split}}},")
-    open(os.path.join(ROOT, "gpurun_out", "gemm_tuned_shapes.inc"), "w").write("\n".join(inc) + "\n")
-    json.dump({"times": times, "best": {str(k): v for k, v in best.items()}}, open(os.path.join(ROOT, "gpurun_out", "r02_shape_tuning.json"), "w"), indent=1)
+    open(os.path.join(ROOT, "gpurun_out", f"gemm_tuned_shapes_{args.tag}.inc"), "w").write("\n".join(inc) + "\n")
+    json.dump({"times": times, "best": {str(k): v for k, v in best.items()}}, open(os.path.join(ROOT, "gpurun_out", f"{args.tag}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
