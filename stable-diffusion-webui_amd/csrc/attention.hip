@@ -62,9 +62,15 @@ __device__ __forceinline__ float tree_max(const f16v (&sc)[NKB]) {
 //      Same products in the same order per accumulator: bit-identical to 0 and 5 (tests/test_gpu_ops.py).
 //  10..14, 18  (-DSDMI_ATTN_PARTS builds only, tools/gpu/attn_parts.py) 5 with one component removed / 15 with section timers
 template <int D, int KVT, int VAR = 0>
-__global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (VAR == 5 || VAR >= 10) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
+__global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 17 || VAR == 18) ? 3 : (VAR == 5 || VAR >= 10) ? 4 : D <= 80 ? 2 : 1)) void attn_mfma_kernel(AttnP p) {
     constexpr bool LAZY_RESCALE = VAR >= 5;
-    constexpr bool PREF = VAR == 15 || VAR == 16 || VAR == 18;
+    constexpr bool PREF = VAR == 15 || VAR == 16 || VAR == 17 || VAR == 18;
+    // 17 = 15 with the softmax scale and shift folded into the S^T MFMA (head sizes with a spare contraction column: d = 40 -> 48), as in
+    // attn_pp_kernel's FOLD form: Q is multiplied by scale * log2(e) when its fragments are loaded, K's padding column holds 1.0 and Q's
+    // padding element -shift, so the accumulators ARE s * c - shift and exp2 applies to them directly: the 16 v_pk_fma_f32 per tile and
+    // the per-tile alpha bookkeeping disappear (20 of the 92 VALU instructions of a tile).  shift is an fp16 number >= every score seen
+    // so far (P <= 1); it is raised — scores re-based, O rescaled, Q's padding element rewritten — only when a tile's maximum exceeds it.
+    constexpr bool FOLD = VAR == 17 && ((D + 15) / 16 * 16) > D;
     constexpr bool TREEMAX = VAR == 16;      // 16 = 15 with the tile maximum taken as a v_max3 tree (serial depth 4 instead of 16)
     constexpr bool TIMING = VAR == 18;       // s_memtime stamps around the sections of an iteration (AttnP::dbg)
     long long tm[6] = {0, 0, 0, 0, 0, 0};
@@ -126,9 +132,16 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (
             const int d = dc * 16 + half * 8;
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (qok && d < D) v = *reinterpret_cast<const h8*>(qptr + d);
+            if constexpr (FOLD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * p.scale_log2);
+            }
             qf[dc] = v;
         }
     }
+    // FOLD: element (D & 7) of the fragment that covers column D carries -shift (lanes of the half-wave that holds that column)
+    constexpr int F_DC = D / 16, F_HALF = (D >> 3) & 1, F_E = D & 7;
+    float shift = 0.f;
 
     const half_t* kbase = p.k + (long)b * p.M * p.ldk + h * D;
     const half_t* vbase = p.vt + ((long)b * p.H + h) * D * (long)p.vt_ld;
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (
         for (int it = 0; it < K_IT; ++it) {
             const int idx = it * 256 + tid;
             const int row = idx / KCPR, c = idx - row * KCPR;
-            if (KCH % 256 == 0 || it + 1 < K_IT || idx < KCH) *reinterpret_cast<u4v*>(Ks + row * KSTR + c * 16) = kr[it];
+            if ((KCH % 256 == 0 || it + 1 < K_IT || idx < KCH) && !(FOLD && c * 8 >= D)) *reinterpret_cast<u4v*>(Ks + row * KSTR + c * 16) = kr[it];
         }
 #pragma unroll
         for (int it = 0; it < V_IT; ++it) {
@@ -196,6 +209,14 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (
     const int nfull = p.M / KVT;
     load_tile(0);
     write_tile(0);
+    if constexpr (FOLD) {
+        // K columns D..DK-1 of both buffers: column D = 1.0, the rest 0 — written once (write_tile skips these chunks)
+        static_assert(!FOLD || (D % 8 == 0 && DK - D == 8), "one padding chunk per K row");
+        for (int i = tid; i < 2 * KVT; i += 256) {
+            const int buf = i / KVT, row = i - buf * KVT;
+            *reinterpret_cast<uint4*>(smem + buf * TILE_BYTES + row * KSTR + (D / 8) * 16) = make_uint4(0x00003C00u, 0u, 0u, 0u);
+        }
+    }
     if (SUMROW) {
         // V^T rows D..DV-1 of both buffers: row D = 1.0 (fp16 0x3C00), the rest 0 — written once, never overwritten
         constexpr int PADCH = (DV - D) * VCPR;
@@ -269,6 +290,52 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (
                 for (int r = 0; r < 16; ++r)
                     if (32 * kb + 16 * (r >> 3) + (r & 7) >= lim) sc[kb][r] = -INFINITY;
         }
+        h8 pb[NKB][2];
+        long long tc = 0;
+        if constexpr (FOLD) {
+            // the accumulators are s * c - shift already
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+            float mlo = mx, mhi = mx;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mlo), "+v"(mhi));
+            mx = fmaxf(mlo, mhi);
+            const bool up = t == 0 || mx > 0.f;                // per query; the first tile always sets the shift (it may be negative)
+            if (__builtin_amdgcn_ballot_w64(up) != 0) {
+                asm volatile("");                                 // a real (wave-uniform) branch: rare after the first few tiles
+                // new shift = the smallest fp16 number >= shift + mx (both halves of the wave compute the same value for a query)
+                const float want = fmaxf(shift + mx, -60000.f);
+                half_t hs = (half_t)want;
+                float f = (float)hs;
+                if (f < want) {
+                    unsigned short bits = __builtin_bit_cast(unsigned short, hs);
+                    bits = (f >= 0.f) ? (unsigned short)(bits + 1) : (unsigned short)(bits - 1);
+                    hs = __builtin_bit_cast(half_t, bits);
+                    f = (float)hs;
+                }
+                const float delta = up ? f - shift : 0.f;         // exact: both are fp16 numbers
+                if (up) shift = f;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                if (half == F_HALF) qf[F_DC][F_E] = (half_t)(-shift);
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    pb[kb][r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(sc[kb][r]);
+                    pb[kb][r >> 3][(r & 7) + 1] = (half_t)__builtin_amdgcn_exp2f(sc[kb][r + 1]);
+                }
+        } else {
         float mx = -INFINITY;
         if constexpr (NO_MAX) { mx = sc[0][0] * p.scale_log2; }
         else {
@@ -290,14 +357,12 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;      // scale > 0: max commutes with the scaling
         }
         const float m_new = fmaxf(m_run, mx);
-        long long tc = 0;
         if constexpr (TIMING) { asm volatile("" :: "v"(m_new)); tc = stamp(); }
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         const bool max_moved = !LAZY_RESCALE || __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;   // wave-uniform
         m_run = m_new;
         const f2v mneg = {-m_new, -m_new};
         f2v rs = {0.f, 0.f};
-        h8 pb[NKB][2];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -317,6 +382,7 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 18) ? 3 : (
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
+        }   // !FOLD
 
         // ---- O^T += V^T P^T ---------------------------------------------------------------------------------
         if constexpr (PREF) {
@@ -927,6 +993,7 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
                     if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
                     if (g_attn_occ == 15) return launch_attn_d<40, 64, 15>(p, s);
                     if (g_attn_occ == 16) return launch_attn_d<40, 64, 16>(p, s);
+                    if (g_attn_occ == 17) return launch_attn_d<40, 64, 17>(p, s);
 #ifdef SDMI_ATTN_PARTS
                     if (g_attn_occ == 10) return launch_attn_d<40, 64, 10>(p, s);
                     if (g_attn_occ == 11) return launch_attn_d<40, 64, 11>(p, s);

@@ -490,7 +490,6 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "conv_korder") g_conv_korder = value;
     else if (n == "gn_fuse") g_gn_fuse = value;
     else if (n == "gn_small") g_gn_small = value;
-    else if (n == "splitk_inkernel") g_splitk_inkernel = value < 0 ? g_splitk_inkernel_default : value;
     else if (n == "ep_wide") g_ep_wide = value;
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "attn_occ") g_attn_occ = value;

@@ -70,8 +70,6 @@ struct GemmP {
     float* splitk_ws;
     int splitk;
     int splitk_steps;     // BK-steps per slice
-    int* splitk_cnt;      // non-null: per-tile arrival counters (zero before and after every launch) — the last-arriving slice of a tile sums
-                          // the slabs itself, in slice order, and runs the epilogue: no second launch (launch_gemm, g_splitk_inkernel)
     long long* dbg;       // tuning only: per-wave section timers of the ping-pong kernel (sdmi_debug_set gemm_dbg_lo/hi)
     // GroupNorm statistics of the OUTPUT tensor from this launch's epilogue (drops the consumer's statistics pass): per
     // (image, row chunk = this tile's BM rows, group) the sum and sum of squares of the fp16-rounded outputs, written to
@@ -140,8 +138,6 @@ extern int g_tile_order;            // -1 heuristic (default), 0 / 1 force
 extern int g_vt_mode;               // 1 (default): V^T through EP_TRANSPOSE on token-major tiles; 0: weights-as-rows GEMM (round 1)
 extern int g_gemm_pipe;             // 0 = two-stage kernels only, 3 = ping-pong 256-row tiles, 4 = also 128x320 (default)
 extern int g_gemm_pipe_default;     // value restored by sdmi_debug_set("gemm_pipe", -1)
-extern int g_splitk_inkernel_default;
-extern int g_splitk_inkernel;       // 1: split-K slabs summed inside the GEMM launch by each tile's last-arriving slice; 0: splitk_reduce_kernel
 extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = force k slices where allowed
 extern int g_attn_kvt;
 extern int g_attn_occ;

@@ -204,48 +204,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 *reinterpret_cast<f4*>(slab + (long)m * p.N + n) = acc[i][j];
             }
         }
-        if (p.splitk_cnt == nullptr) return;                 // the slabs are summed by splitk_reduce_kernel (second launch)
-        // ---- ordered in-launch reduction (GemmP::splitk_cnt): the slice that arrives LAST at this tile's counter sums all slabs
-        // of the tile in slice order — the order, and so the bits, of splitk_reduce_kernel — into its accumulators and runs the
-        // ordinary epilogue below.  Publication as /opt/skills/guides/cdna_hip_programming.md prescribes it for a split-K seam:
-        // plain slab stores, every wave drains vmcnt, workgroup barrier, ONE lane releases at agent scope (buffer_wbl2), drains
-        // again (the compiler may drop the wait behind the fence), then the relaxed agent-scope ticket; the last arriver acquires
-        // at agent scope (its CU's L1 dropped) before anyone in the workgroup reads the other slices' slabs.  The counter is reset
-        // by the last arriver: launches on one stream never overlap, so the next split-K launch finds zeros.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        volatile int* flag = reinterpret_cast<volatile int*>(smem);
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            constexpr int BM_ = WR_ * WTM;
-            const int tiles_n = p.N / BN_;
-            const int tile = (m0 / BM_) * tiles_n + n0 / BN_ + (int)z * ((p.M + BM_ - 1) / BM_) * tiles_n;
-            int* c = p.splitk_cnt + tile;
-            const int ticket = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = ticket == p.splitk - 1 ? 1 : 0;
-            if (last) {
-                __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            *flag = last;
-        }
-        __syncthreads();
-        if (*flag == 0) return;
-        const long slice = (long)gridDim.z * p.M * p.N;
-        const float* base = p.splitk_ws + z * (long)p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = min(m0 + wr * WTM + i * 16 + (lane & 15), p.M - 1);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
-                f4 v = {0.f, 0.f, 0.f, 0.f};
-                for (int sl = 0; sl < p.splitk; ++sl) v += *reinterpret_cast<const f4*>(base + sl * slice + (long)m * p.N + n);
-                acc[i][j] = v;
-            }
-        }
-        __syncthreads();                                     // (the flag word is operand-tile memory the STATS / LNS epilogues reuse)
+        // the slabs are summed by splitk_reduce_kernel, a second launch.  (Round 3 built the alternative — each tile's last-arriving slice
+        // sums the slabs itself behind an agent-scope release / acquire pair and a ticket counter, same bits — and measured it on the C1 job:
+        // 458.1 ms against 424.8 ms, profiles/r03_knob_sweep_run5.json; every split launch paid the vmcnt(0) drain + two workgroup barriers
+        // + the L2 write-back of the fence, more than the 13 us reduce launches it saved.  Removed again: it also cost the production
+        // 256x320 instantiation 6 SGPR spills.)
+        return;
     }
     if constexpr (STATS && !GEGLU) {
         // ---- GroupNorm-statistics variant (GemmP::stats_out; launch_gemm admits only fp16 row-major outputs with a column bias,
@@ -1707,25 +1671,6 @@ static int pick_cfg(const GemmP& p, int batch, int* split_out, bool allow_split)
     return best >= 0 ? best : CFG_64x64;
 }
 
-// 1 (default after GPU validation: see DESIGN.md): split-K slabs are summed inside the GEMM launch by the last-arriving slice of each
-// tile (ordered: same bits as the reduce kernel); 0: second launch of splitk_reduce_kernel
-int g_splitk_inkernel_default = [] { const char* e = getenv("SDMI_SPLITK_INKERNEL"); return e ? atoi(e) : 0; }();
-int g_splitk_inkernel = g_splitk_inkernel_default;
-static constexpr int kSplitkCounters = 16384;
-static int* splitk_counters() {                              // per device, zeroed once; every launch leaves them zero again
-    static std::map<int, int*> ctr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    auto it = ctr.find(dev);
-    if (it == ctr.end()) {
-        void* q = nullptr;
-        if (hipMalloc(&q, kSplitkCounters * sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemset(q, 0, kSplitkCounters * sizeof(int)) != hipSuccess) return nullptr;
-        it = ctr.emplace(dev, (int*)q).first;
-    }
-    return it->second;
-}
-
 size_t gemm_splitk_ws_bytes(int M, int N, int K, int batch) {
     if (K < 64 * 16 || N % 64) return 0;                    // the score model splits at >= 12 BK-steps per slice; tuned shapes (gemm_tuned_shapes.inc) may go down to 8
     if ((long)cdiv(M, 128) * cdiv(N, 128) * batch >= 512) return 0;   // chip already full with ordinary tiles
@@ -1793,16 +1738,6 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     } else {
         p.splitk = 0;
     }
-    p.splitk_cnt = nullptr;
-    bool reduce_in_launch = false;
-    if (split > 1 && g_splitk_inkernel && use_glds) {
-        const long ntile = (long)cdiv(p.M, kCfgBM[cfg]) * (p.N / kCfgBN[cfg]) * batch;
-        if (ntile <= kSplitkCounters) {
-            p.splitk_cnt = splitk_counters();
-            SDMI_REQUIRE(p.splitk_cnt != nullptr, "split-K counter allocation failed");
-            reduce_in_launch = true;
-        }
-    }
     {
         // Which operand should an XCD-local run of consecutive tiles share?  One XCD (its own 4 MB L2) executes tiles/8 consecutive
         // logical tiles.  N first: the run covers ~run/tiles_n row panels of A and min(run, tiles_n) weight panels; M first the
@@ -1838,7 +1773,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     }
     std::string pname;
     if (prof_enabled()) {
-        pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) + (reduce_in_launch ? "i" : "") : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
+        pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
                 ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 ((p.flags & EP_LNFOLD) ? " ln" : "") + (batch > 1 ? " x" + std::to_string(batch) : "");
     }
@@ -1854,7 +1789,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
             SDMI_CHECK_HIP(hipGetLastError());
             return 0;
         }
-    } reduce{p, batch, s, split > 1 && !reduce_in_launch};
+    } reduce{p, batch, s, split > 1};
 #define SDMI_CASE(ID, BM, BN, WR, WC, BK)                                                                       \
     case ID:                                                                                                    \
         if (use_glds ? launch_cfg<BM, BN, WR, WC, BK, true>(p, batch, s) : launch_cfg<BM, BN, WR, WC, BK, false>(p, batch, s)) \

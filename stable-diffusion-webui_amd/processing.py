@@ -310,6 +310,8 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
         image = (self.init_images.to(self.sd_model.device, dtype=torch.float32) * 2.0 - 1.0).contiguous()
         moments = self.sd_model.encode_first_stage(image)
         self.init_latent_all = self.sd_model.get_first_stage_encoding(moments)
+        if self.resize_mode == 3:                                                          # :1733-1734 "Just resize (latent upscale)"
+            self.init_latent_all = ops.latent_resize(self.init_latent_all.contiguous(), (self.height // opt_f, self.width // opt_f), "bilinear")
         if getattr(self, "_latent_mask_pil", None) is not None:
             self._latent_mask_from_pil()
         if self.latent_mask is not None and self.inpainting_fill in (2, 3):

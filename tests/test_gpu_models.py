@@ -1226,6 +1226,14 @@ def test_img2img_pil_front_end_fill_only_masked_and_overlay(dev, tiny):
     r7 = processing.process_images(p7)
     assert p7.latent_mask is None and p7.overlay_images == [] or p7.latent_mask is None
     assert r7.images[0].shape == (H, W, 3)
+    # resize_mode 3 ("latent upscale"): a 64x64 init image is encoded as it is and its 8x8 latent resized (bilinear) to the job's 16x16
+    small = Image.fromarray(g.randint(0, 256, size=(64, 64, 3)).astype(np.uint8))
+    p8 = job(init_images=[small], resize_mode=3)
+    r8 = processing.process_images(p8)
+    assert r8.images[0].shape == (H, W, 3) and tuple(p8.init_latent_all.shape) == (2, 4, H // 8, W // 8)
+    lat = sub("ops").latent_resize(model.get_first_stage_encoding(model.encode_first_stage(
+        (torch.from_numpy(np.moveaxis(np.array(small).astype(np.float32) / 255.0, 2, 0))[None].to(dev) * 2 - 1).contiguous())), (H // 8, W // 8), "bilinear")
+    assert rel_l2(p8.init_latent_all[0].cpu(), lat[0].cpu()) < 2e-3      # batch 2 vs batch 1 encode: other tile configuration, fp16 rounding apart
     # a VAE of another downscale factor cannot meet the (4, height // 8, width // 8) noise: a loud error, never an out-of-bounds read
     with pytest.raises(ValueError, match="does not match the noise shape"):
         processing.process_images(processing.StableDiffusionProcessingImg2Img(

@@ -173,36 +173,6 @@ def test_conv_gemm_split_k_is_exact_and_deterministic(dev, cfg, split):
     assert torch.equal(got, again)
 
 
-@pytest.mark.parametrize("cfg,split", [(0, 3), (5, 4), (8, 2), (8, 8), (3, 6), (4, 2), (9, 4)])
-def test_split_k_reduced_inside_the_launch_equals_the_reduce_kernel(dev, cfg, split):
-    """GemmP::splitk_cnt (knob splitk_inkernel): each tile's last-arriving K slice sums the slabs itself, in slice order, and runs the
-    ordinary epilogue — no second launch.  Same slabs, same summation order, same epilogue arithmetic as splitk_reduce_kernel: the bits
-    must be equal, on every split-capable tile configuration, with bias + per-image row bias + residual, a ragged M, repeated launches
-    (the counters must come back to zero) and a batch of GEMMs in one launch."""
-    ops, lib = sub("ops"), sub("_lib")
-    for B, H, W in ((2, 8, 8), (3, 7, 9)):
-        cin, cout = 1280, 1280
-        x, w = seeded((B, H, W, cin), 11), seeded((cout, cin, 3, 3), 12, scale=(cin * 9) ** -0.5)
-        b, rb, res = seeded((cout,), 13, 0.1), seeded((B, cout), 14), seeded((B, H, W, cout), 15)
-        wp = ops.pack_conv_weight(w.half().to(dev))
-        args = dict(bias=b.to(dev), rowbias=rb.to(dev).contiguous(), resid=res.half().to(dev))
-        outs = {}
-        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
-        try:
-            for mode in (0, 1, 1, 0, 1):
-                lib.check(lib.lib.sdmi_debug_set(b"splitk_inkernel", mode))
-                out = ops.conv_gemm(x.half().to(dev), wp, **args)
-                torch.cuda.synchronize()
-                outs.setdefault(mode, []).append(out)
-        finally:
-            lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
-            lib.check(lib.lib.sdmi_debug_set(b"splitk_inkernel", -1))
-        ref = _conv_ref(h(x), h(w), b) + rb[:, None, None, :] + h(res)
-        assert rel_l2(outs[1][0].float().cpu(), ref) < 6e-4, (cfg, split)
-        for o in outs[0] + outs[1]:
-            assert torch.equal(o, outs[0][0]), (cfg, split, B, H, W)
-
-
 PHASE_CASES = [
     # (cfg, B, H, W, c0, c1, cout, taps, stride, up, split)   cfg 5 = 256x320, 4 = 256x256, 8 = 128x320
     (5, 2, 16, 16, 64, 0, 320, 1, 1, False, 0),        # K = 64: a single K tile (prologue only)
@@ -473,9 +443,9 @@ def test_attention_softmax_is_shift_invariant_and_handles_spikes(dev):
     assert float((got[0, 5].float().cpu() - ref[0, 5]).abs().max()) < 2e-2
 
 
-@pytest.mark.parametrize("variant", [20, 21, 30, 31])
+@pytest.mark.parametrize("variant", [17, 20, 21, 30, 31])
 def test_attention_role_offset_kernel(dev, variant):
-    """The 8-wave role-offset kernel (attn_occ 20; 21 = with the softmax shift folded into the S^T MFMA: Q pre-multiplied by
+    """(17 = the production 4-wave kernel with the softmax shift folded into the S^T MFMA like 21.)  The 8-wave role-offset kernel (attn_occ 20; 21 = with the softmax shift folded into the S^T MFMA: Q pre-multiplied by
     scale * log2 e, K's padding column at 1.0, Q's padding element at -shift): level-0 / hires shapes, ragged query and key counts, 1 to
     9 KV tiles, d = 64 (SDXL; no padding column, so 21 runs the unfolded arithmetic there); 30 / 31 = the same two forms with THREE wave
     groups (12 waves, 384 queries per workgroup, the VALU work of a tile split over two sections) — against fp32; the unfolded form runs
@@ -494,7 +464,7 @@ def test_attention_role_offset_kernel(dev, variant):
         return out
 
     for d, heads, n, m in ((40, 8, 512, 512), (40, 2, 256, 256), (40, 1, 300, 333), (40, 2, 1024, 576), (40, 1, 256, 290), (40, 8, 4096, 4096),
-                           (40, 2, 384, 256), (40, 1, 768, 320), (40, 1, 700, 449), (64, 2, 512, 512), (64, 1, 260, 400)):
+                           (40, 2, 384, 256), (40, 1, 768, 320), (40, 1, 700, 449), (40, 2, 200, 77), (40, 1, 130, 64), (64, 2, 512, 512), (64, 1, 260, 400)):
         b = 1 if n >= 4096 else 2
         q, k, v = seeded((b, n, heads * d), 61), seeded((b, m, heads * d), 62), seeded((b, m, heads * d), 63)
         got = run(q, k, v, heads, variant)

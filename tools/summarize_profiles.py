@@ -38,9 +38,38 @@ def first_db(d):
     raise FileNotFoundError(d)
 
 
+def config_stats(rnd, configs):
+    """profiles/<round>_kernel_stats_<config>.md from gpurun_out/prof_stats_<config> (rocprofv3 --kernel-trace --stats of
+    `bench.py --config <config> --steps 1 --warmup 0`), plus the PMC traffic of the same workload when bench.py --pmc-traffic left it."""
+    what = {"c2": "SD1.5 512x512, 50-step DPM++ 2M Karras, batch 8", "c3": "SDXL-base 1024x1024, 30-step Euler a, batch 4",
+            "c4a": "SD1.5 txt2img 512x512 + hires-fix x2 (20 + 20 evaluations), batch 8", "c4b": "SD1.5 img2img 512x512, denoise 0.75, batch 8"}
+    for c in configs:
+        d = os.path.join(G, f"prof_stats_{c}")
+        if not os.path.isdir(d):
+            continue
+        con = sqlite3.connect(first_db(d))
+        rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+        tot = sum(r[2] for r in rows)
+        with open(os.path.join(P, f"{rnd}_kernel_stats_{c}.md"), "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats — `python bench.py --config {c} --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-dropin` ({rnd})\n\n")
+            f.write(f"One job of {what.get(c, c)} plus the one-time weight packing.  Durations in microseconds.\n\n")
+            pt = os.path.join(G, f"pmc_traffic_{c}.json")
+            if os.path.exists(pt):
+                t = json.load(open(pt))
+                f.write(f"HBM traffic of the implicit-GEMM family on this workload (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes taken by "
+                        f"`bench.py --config {c} --pmc-traffic` on the same box; 2 x FETCH_SIZE + WRITE_SIZE): **{t['gemm_mfma_bytes_per_launch'] / 1e6:.1f} MB per launch** "
+                        f"over {t['gemm_mfma_launches']} launches.\n\n")
+            f.write(f"Total kernel time: {tot / 1e3:.1f} ms\n\n| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n")
+            for n, cnt, tt, a, pc in rows[:30]:
+                f.write(f"| `{short(n)}` | {cnt} | {tt:.0f} | {a:.1f} | {pc:.2f} |\n")
+    print("wrote config stats", configs)
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     os.makedirs(P, exist_ok=True)
+    if "--configs" in sys.argv:
+        return config_stats(rnd, sys.argv[sys.argv.index("--configs") + 1:])
     con = sqlite3.connect(first_db(os.path.join(G, "prof_stats")))
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     tot = sum(r[2] for r in rows)
