@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0)
-    ap.add_argument("--cpu-baseline-budget", type=float, default=110.0, help="seconds of CPU timing the baseline may spend (it adapts its repetitions)")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=140.0, help="seconds of CPU timing the baseline may spend (it adapts its repetitions)")
     ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0, help="hard wall limit of the baseline child process")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline alone and print its JSON")
     args = ap.parse_args()
@@ -246,6 +246,25 @@ def pmc_traffic(args):
     return None, None
 
 
+def pmc_child_args(argv):
+    """The command line of the one-job child a PMC pass profiles: this run's workload flags, without the flags that shape the timed
+    region or start further children."""
+    drop_with_value = ("--steps", "--warmup", "--gpus", "--cpu-baseline-budget", "--cpu-baseline-timeout")
+    drop_flags = ("--pmc-traffic", "--verify-shards", "--no-cpu-baseline", "--no-roofline", "--no-dropin")
+    child, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in drop_with_value:
+            skip = True
+            continue
+        if a in drop_flags or any(a.startswith(k + "=") for k in drop_with_value):
+            continue
+        child.append(a)
+    return child + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin"]
+
+
 def measure_pmc_traffic(args):
     """--pmc-traffic: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE — they do not fit one pass; kernel trace only, as the guide's
     HBM section prescribes) over ONE job of this workload in child processes, summed over the gemm_mfma launches: bytes per launch =
@@ -258,21 +277,7 @@ def measure_pmc_traffic(args):
     import sqlite3
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    passthrough = [a for a in sys.argv[1:] if a not in ("--pmc-traffic", "--verify-shards")]
-    drop_with_value = ("--steps", "--warmup", "--gpus")
-    child = []
-    skip = False
-    for a in passthrough:
-        if skip:
-            skip = False
-            continue
-        if a in drop_with_value:
-            skip = True
-            continue
-        if any(a.startswith(k + "=") for k in drop_with_value):
-            continue
-        child.append(a)
-    child += ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin"]
+    child = pmc_child_args(sys.argv[1:])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
     env["TMPDIR"] = "/tmp"
     sums = {}

@@ -17,13 +17,22 @@ named functions exec'd from its text):
   * timestep embedding, SpatialTransformer forward        <- modules/sd_hijack_unet.py:56-102
   * VAE decoder / encoder                                 <- modules/models/sd3/sd3_impls.py VAEDecoder / VAEEncoder
   * CLIP text transformer                                 <- modules/models/sd3/other_impls.py (+ the installed transformers CLIPTextModel)
-  * DDIM, DDIM CFG++, PLMS, UniPC, Restart, LCM, Euler    <- modules/sd_samplers_timesteps_impl.py, modules/models/diffusion/uni_pc/uni_pc.py,
-                                                             modules/sd_samplers_extra.py, modules/sd_samplers_lcm.py, sd3_impls.py:145-163
+  * DDIM, DDIM CFG++, PLMS, UniPC (bh1 / bh2 / vary_coeff  <- modules/sd_samplers_timesteps_impl.py, modules/models/diffusion/uni_pc/uni_pc.py,
+    at batch 1: the reference breaks beyond), Restart,        modules/sd_samplers_extra.py, modules/sd_samplers_lcm.py, sd3_impls.py:145-163
+    LCM, Euler
   * every in-repo scheduler                               <- modules/sd_schedulers.py
   * CFGDenoiser.forward (20 scenarios), apply_refiner     <- modules/sd_samplers_cfg_denoiser.py, modules/sd_samplers_common.py:158-202
   * conditioning containers / per-step reconstruction     <- modules/prompt_parser.py:136-349
   * image conditioning, resize_image + Upscaler loop      <- modules/processing.py:100-133, 321-374; modules/images.py:252-291, modules/upscaler.py
   * LoRA layer naming, every LyCORIS module's calc_updown  <- extensions-builtin/Lora/networks.py:56-120, network*.py, lyco_helpers.py
+    incl. the dense bias entry (ex_bias)
+  * hypernetwork modules and their chained application     <- modules/hypernetworks/hypernetwork.py:25-113, 358-379
+  * alpha-schedule overrides (zero terminal SNR, fp16)     <- modules/sd_models.py:553-589
+The img2img / inpainting front-end (masking.py of the PACKAGE, not part of this oracle) is pinned the same way by
+tests/golden/img2img_frontend.npz <- modules/masking.py, modules/images.py:252-291, modules/processing.py:70-98; its Gaussian mask blur is
+unpinned (the reference calls cv2.GaussianBlur; cv2 is not installed).
+Full-size outputs of this oracle at the benchmarked shapes are committed as tests/golden/fullsize_*.npz (make_fullsize_golden.py) so that
+the GPU parity tests at those shapes cost no oracle time on the GPU box.
   * structural checksums                                   <- parameter counts in SURVEY.md section 8(c)
 PARITY UNPINNED: the remainder of the UNet forward (ResBlock, GEGLU feed-forward, block wiring) and the k-diffusion samplers other
 than Euler, with get_sigmas_karras / _exponential / _polyexponential — the reference's tests hold no numeric vector for them and

@@ -952,3 +952,18 @@ def test_mask_blur_kernel_is_the_one_cv2_would_build():
     out = masking.blur_mask(Image.fromarray(m), 4, 4)
     assert out.size == (56, 40) and np.array(out).max() <= 255 and 0 < np.array(out).mean() < 255
     assert masking.blur_mask(Image.fromarray(m), 0, 0).tobytes() == Image.fromarray(m).tobytes()
+
+
+def test_bench_pmc_child_command_line(monkeypatch):
+    """bench.py --pmc-traffic profiles ONE job of the same workload in child processes: the child's flags keep the workload selection and
+    drop everything that shapes the timed region or would start children of its own; without measured passes on the box `traffic` is null
+    (a figure from another box is never reported)."""
+    monkeypatch.syspath_prepend(ROOT)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    bench = importlib.import_module("bench")
+    got = bench.pmc_child_args(["--config", "c3", "--steps", "5", "--warmup=2", "--pmc-traffic", "--gpus", "1", "--verify-shards", "--no-cpu-baseline"])
+    assert got == ["--config", "c3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin"]
+    args = bench.parse()
+    path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
+    if not os.path.exists(path):
+        assert bench.pmc_traffic(args) == (None, None)

@@ -1126,6 +1126,38 @@ def test_hypernetworks_in_engine_vs_oracle(dev, tiny):
     assert torch.equal(fwd(), base)
 
 
+def test_hypernetwork_with_layernorm_at_sd15_widths(dev):
+    """The widths a real SD1.5 hypernetwork carries (320 / 768 / 1280; 640 has the same code path as 320) with the default [1, 2, 1]
+    structure AND LayerNorm: the hidden layer of the 1280-wide modules is 2560 wide — LayerNorm rows the engine used to reject — on a
+    two-level UNet with those channel counts (320 -> 1280, text context 768) against the oracle's HypernetworkModule chain."""
+    from oracle import hypernetwork as ohn, pipeline as opipe, unet as ou
+    schema, hn_mod = sub("schema"), sub("hypernetwork")
+    kw = dict(model_channels=320, channel_mult=(1, 4), context_dim=768)
+    ucfg = schema.tiny_unet(**kw)
+    sd = schema.synthetic_state_dict(ucfg, None, dtype=torch.float16, seed=0x4A11)
+    model = sub("sd_models").SdModel(sd, ucfg, None, device=0, load_vae=False)
+    om = opipe.OracleModel(sd, ou.tiny_config(**kw), None)
+    eng = model.engine
+    x, t, ctx = seeded((2, 4, 8, 8), 81).to(dev), torch.tensor([700.0, 90.0], device=dev), seeded((2, 77, 768), 82).to(dev)
+
+    def fwd():
+        eng.set_context(ctx)
+        return eng.unet_forward(x, t, None, None).float().cpu()
+    base = fwd()
+    hn = _hn_state([320, 768, 1280], [1, 2, 1], "relu", True, False, None, 7300, "hn_sd15_widths")
+    try:
+        hn_mod.load_hypernetworks(model, [hn], [0.3])
+        got = fwd()
+        ou.LOADED_HYPERNETWORKS[:] = [ohn.Hypernetwork(hn, 0.3)]
+        with torch.no_grad():
+            ref = om.unet(x.cpu(), t.cpu(), ctx.cpu().half().float())
+        assert rel_l2(got, ref) < 8e-3 and rel_l2(got, base) > 2e-2, (rel_l2(got, ref), rel_l2(got, base))
+    finally:
+        ou.LOADED_HYPERNETWORKS[:] = []
+        hn_mod.load_hypernetworks(model, [], [])
+    assert torch.equal(fwd(), base)
+
+
 def test_sharded_job_replayed_rank_by_rank_equals_the_single_process_job(dev, tiny):
     """SURVEY.md section 8e on ONE GPU with the REAL engine: parallel.process_images_sharded(p, world=2, rank=r) for r = 0, 1 run one
     after the other in this process — what rank r of a 2-GPU job computes — and concatenated must be BIT-identical to the single-process

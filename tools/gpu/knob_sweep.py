@@ -84,9 +84,16 @@ def main():
                 vals[k] = int(v)
         for k, v in vals.items():
             if k in ENGINE_OPTS:
-                model.engine.set_option(k, v)
+                try:
+                    model.engine.set_option(k, v)
+                except Exception:
+                    if v != DEFAULTS.get(k):
+                        raise
             else:
-                lib.check(lib.lib.sdmi_debug_set(k.encode(), int(v)), k)
+                rc = lib.lib.sdmi_debug_set(k.encode(), int(v))
+                if rc and v == DEFAULTS.get(k):               # an older library (two-builds A/B through SDMI_LIB) does not know this knob
+                    continue
+                lib.check(rc, k)
 
     times = {s: [] for s in args.settings}
     first_img = {}
