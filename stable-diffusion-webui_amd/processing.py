@@ -301,6 +301,7 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
         """modules/processing.py:1602-1757 from the point where the image tensor exists: image*2-1 -> VAE encode -> latent
         (posterior mean, deterministic), the "masked content" fills 2 / 3 over the latent mask (:1747-1753) and the image
         conditioning of inpainting / edit checkpoints (:1755)."""
+        self.extra_generation_params["Denoising strength"] = self.denoising_strength       # :1603
         if getattr(self.sd_model, "cond_stage_key", "txt") != "edit":
             self.image_cfg_scale = None                                                    # :1605
         if self.initial_noise_multiplier is None:
@@ -319,8 +320,10 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             keep = self.latent_mask.to(dev, torch.float32).expand_as(self.init_latent_all).contiguous()
             if self.inpainting_fill == 2:         # init * mask + create_random_tensors(shape, all_seeds[:N]) * nmask
                 fill = ImageRNG(tuple(self.init_latent_all.shape[1:]), all_seeds[0:self.init_latent_all.shape[0]], device=dev).next()
+                self.extra_generation_params["Masked content"] = 'latent noise'
             else:                                 # init * mask
                 fill = torch.zeros_like(self.init_latent_all)
+                self.extra_generation_params["Masked content"] = 'latent nothing'
             self.init_latent_all = ops.mask_blend(fill.contiguous(), self.init_latent_all, keep, (1.0 - keep).contiguous())
         elif self.inpainting_fill not in (0, 1, 2, 3):
             raise ValueError(f"inpainting_fill {self.inpainting_fill!r}")
@@ -394,7 +397,13 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             batch = np.expand_dims(imgs[0], axis=0).repeat(self.batch_size * self.n_iter, axis=0)
             if self.overlay_images is not None:
                 self.overlay_images = self.overlay_images * (self.batch_size * self.n_iter)
-        elif len(imgs) <= self.batch_size * self.n_iter:
+        elif len(imgs) <= self.batch_size:                    # :1718-1720: fewer images than the batch size shrink the batch; every
+            self.batch_size = len(imgs)                       # iteration then starts from the same images
+            batch = np.array(imgs).repeat(1, axis=0)
+            batch = np.concatenate([batch] * self.n_iter, axis=0)
+            if self.overlay_images is not None:
+                self.overlay_images = self.overlay_images * self.n_iter
+        elif len(imgs) == self.batch_size * self.n_iter:      # (extension: one init image per image of the whole job)
             batch = np.array(imgs)
         else:
             raise RuntimeError(f"bad number of images passed: {len(imgs)}; expecting {self.batch_size * self.n_iter} or less")

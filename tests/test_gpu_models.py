@@ -1266,6 +1266,16 @@ def test_img2img_pil_front_end_fill_only_masked_and_overlay(dev, tiny):
     lat = sub("ops").latent_resize(model.get_first_stage_encoding(model.encode_first_stage(
         (torch.from_numpy(np.moveaxis(np.array(small).astype(np.float32) / 255.0, 2, 0))[None].to(dev) * 2 - 1).contiguous())), (H // 8, W // 8), "bilinear")
     assert rel_l2(p8.init_latent_all[0].cpu(), lat[0].cpu()) < 2e-3      # batch 2 vs batch 1 encode: other tile configuration, fp16 rounding apart
+    # one init image per image of the batch; fewer images than the batch size shrink the batch (:1718-1720)
+    other = Image.fromarray(g.randint(0, 256, size=(H, W, 3)).astype(np.uint8))
+    p9 = job(init_images=[base, other])
+    r9 = processing.process_images(p9)
+    assert len(r9.images) == 2 and not np.array_equal(r9.images[0], r9.images[1]) and p9.extra_generation_params["Denoising strength"] == 0.6
+    p10 = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=tiny["cond"][:3], uc=tiny["uncond"][:3], seed=77, batch_size=3, steps=4, cfg_scale=4.0,
+                                                      width=W, height=H, sampler_name="Euler a", denoising_strength=0.6, init_images=[base, other])
+    r10 = processing.process_images(p10)
+    assert p10.batch_size == 2 and len(r10.images) == 2
+    assert all(np.array_equal(a, b) for a, b in zip(r10.images, r9.images))      # same seeds, same conds rows, same images
     # a VAE of another downscale factor cannot meet the (4, height // 8, width // 8) noise: a loud error, never an out-of-bounds read
     with pytest.raises(ValueError, match="does not match the noise shape"):
         processing.process_images(processing.StableDiffusionProcessingImg2Img(
