@@ -82,8 +82,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0)
-    ap.add_argument("--cpu-baseline-budget", type=float, default=140.0, help="seconds of CPU timing the baseline may spend (it adapts its repetitions)")
-    ap.add_argument("--cpu-baseline-timeout", type=float, default=240.0, help="hard wall limit of the baseline child process")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=185.0, help="seconds of CPU timing the baseline may spend (it adapts its repetitions)")
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=330.0, help="hard wall limit of the baseline child process")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline alone and print its JSON")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -372,6 +372,7 @@ def cpu_baseline(args, sd=None):
     is slow is measured by that run alone).  C0 (256x256, 5-step Euler a, batch 1) is timed IN FULL when the budget allows;
     the workload itself is a bounded sample — ONE CFG pair of UNet forwards (batch 2 = one image's cond + uncond) + ONE VAE decode
     at the workload's size — extrapolated to evaluations x pair + decode per image."""
+    t_enter = time.time()
     import torch
     from oracle import pipeline as opipe, unet as ou, vae as ov
     schema = sub("schema")
@@ -444,7 +445,7 @@ def cpu_baseline(args, sd=None):
     # 2 x batch rows), measured twice, instead of `batch` single-image pairs — large-batch GEMMs use the host's cores better.
     step_note = ""
     nb = args.batch
-    if nb > 1 and args.model != "tiny" and time.time() + 2.2 * nb * t_pair < deadline:
+    if nb > 1 and args.model != "tiny" and time.time() + 2.2 * nb * t_pair < deadline and (time.time() - t_enter) + 2.4 * nb * t_pair < 0.85 * args.cpu_baseline_timeout:
         gb = torch.Generator().manual_seed(2)
         xb = torch.randn(2 * nb, 4, hw, hw, generator=gb)
         cb = torch.randn(2 * nb, 77, ucfg.context_dim, generator=gb)
