@@ -975,6 +975,18 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
     const bool aligned = (p.ldq % 8 == 0) && (p.ldk % 8 == 0) && (p.vt_ld % 8 == 0) && (p.ldo % 4 == 0) && (p.D % 8 == 0);
     const bool kvt128 = g_attn_kvt == 128;       // measured: 64-key tiles win for every head size (profiles/)
     if (!force_generic && aligned) {
+        // knob attn_kvt = 96: the text context (77 keys; M in (64, 96]) as ONE 96-key tile — three 32-key blocks — instead of a 64-key tile
+        // plus a 13-key one padded to 64: 21 instead of 28 MFMAs and 96 instead of 128 score columns per query block, no second staging /
+        // barrier round
+        if (g_attn_kvt == 96 && p.M > 64 && p.M <= 96 && !p.causal) {
+            switch (p.D) {
+                case 40: return launch_attn_d<40, 96, 0>(p, s);          // (the fragment-prefetch form 15 spills with three key blocks)
+                case 64: return launch_attn_d<64, 96>(p, s);
+                case 80: return launch_attn_d<80, 96>(p, s);
+                case 160: return launch_attn_d<160, 96>(p, s);
+                default: break;
+            }
+        }
         switch (p.D) {
             // KV tile: 128 keys where the register budget allows it (small heads: the per-tile barrier / staging
             // overhead is amortised over twice the MFMA work), 64 otherwise or when the key sequence is short

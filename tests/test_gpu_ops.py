@@ -443,6 +443,24 @@ def test_attention_softmax_is_shift_invariant_and_handles_spikes(dev):
     assert float((got[0, 5].float().cpu() - ref[0, 5]).abs().max()) < 2e-2
 
 
+def test_attention_text_context_as_one_96_key_tile(dev):
+    """Knob attn_kvt = 96: key sequences of 65..96 tokens (the 77-token text context) run as ONE tile of three 32-key blocks instead of a
+    64-key tile plus a ragged one — every head size the UNets use, ragged query counts, 65 / 77 / 96 keys; same arithmetic per score, so the
+    result agrees with the two-tile form to fp16 rounding of P and with fp32 to the attention tolerance."""
+    ops, lib = sub("ops"), sub("_lib")
+    for d, heads, n, m in ((40, 8, 512, 77), (40, 2, 200, 77), (40, 1, 130, 65), (40, 1, 128, 96), (80, 8, 256, 77), (160, 8, 64, 77), (64, 10, 300, 77), (64, 20, 128, 96)):
+        q, k, v = seeded((2, n, heads * d), 91), seeded((2, m, heads * d), 92), seeded((2, m, heads * d), 93)
+        base = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
+        lib.check(lib.lib.sdmi_debug_set(b"attn_kvt", 96))
+        try:
+            got = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
+            torch.cuda.synchronize()
+        finally:
+            lib.check(lib.lib.sdmi_debug_set(b"attn_kvt", 0))
+        assert rel_l2(got.float().cpu(), _attn_ref(h(q), h(k), h(v), heads)) < 5e-4, (d, heads, n, m)
+        assert rel_l2(got.float().cpu(), base.float().cpu()) < 5e-4, (d, heads, n, m)
+
+
 @pytest.mark.parametrize("variant", [17, 20, 21, 30, 31])
 def test_attention_role_offset_kernel(dev, variant):
     """(17 = the production 4-wave kernel with the softmax shift folded into the S^T MFMA like 21.)  The 8-wave role-offset kernel (attn_occ 20; 21 = with the softmax shift folded into the S^T MFMA: Q pre-multiplied by
