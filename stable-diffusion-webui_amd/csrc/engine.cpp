@@ -51,6 +51,10 @@ struct Run {
     Run(sdmi_engine* e_, hipStream_t s_, bool dry_, Arena* ar_ = nullptr, int b0_ = 0, int Btot_ = 0)
         : e(e_), s(s_), dry(dry_), ar(ar_ ? ar_ : &e_->arena), b0(b0_), Btot(Btot_) {}
     half_t* H(size_t n) { return (half_t*)ar->take(n * sizeof(half_t)); }
+    // option "arena_reuse": a block's temporaries are released when the block returns — the next block's launches (same stream, so
+    // ordered behind every reader) write over them while their lines are still in the 256 MB Infinity Cache, instead of every
+    // activation of a forward (~10 GB) being written back to HBM once.  Not while block outputs are tapped or LayerNorm partials live.
+    bool reuse() const { return e->arena_reuse && !e->trace && !e->ln_fold; }
     float* F(size_t n) { return (float*)ar->take(n * sizeof(float)); }
     void tap(const std::string& name, const half_t* p, int B, int H, int W, int C) {
         if (!dry && e->trace) e->taps.push_back({name, p, B, H, W, C});
@@ -362,6 +366,7 @@ struct ConvArgs {
     const int* gate = nullptr;
     int stats_C = 0;              // > 0: the output feeds a GroupNorm(32) over stats_C channels: emit its partial sums from the epilogue
     bool no_split = false;        // never take a split-K workspace from the arena (callers outside a sized forward pass)
+    float* stats_ws_pre = nullptr;    // arena_reuse: room for the GroupNorm partial sums taken by the caller (it must outlive the caller's rewind)
 };
 
 static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
@@ -373,7 +378,7 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     }
     // room for the GroupNorm partial sums of the output ([B][<= 64 chunks][32 groups][2]); allocated in the dry pass too
     float* stats_ws = nullptr;
-    if (a.stats_C > 0 && W.n_pad == a.stats_C && a.stats_C % 32 == 0) stats_ws = r.F((size_t)a.B * 64 * 32 * 2);
+    if (a.stats_C > 0 && W.n_pad == a.stats_C && a.stats_C % 32 == 0) stats_ws = a.stats_ws_pre ? a.stats_ws_pre : r.F((size_t)a.B * 64 * 32 * 2);
     r.st_tensor = nullptr; r.st_nchunk = 0;
     // room for the LayerNorm row partials of the output ([M][N / 64 tiles at most][2]); allocated in the dry pass too
     float* lnp_ws = nullptr;
@@ -515,6 +520,12 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
                    float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f) {
     const int HW = H * Wd;
     const size_t M = (size_t)B * HW;
+    // arena_reuse: what outlives the block — its output and the GroupNorm partial sums the last conv leaves for the next norm — is taken
+    // first, everything after the mark is released on return
+    const bool reuse = r.reuse();
+    half_t* o_pre = reuse ? r.H(M * w.cout) : nullptr;
+    float* st_pre = (reuse && ss == 1.f && w.cout % 32 == 0) ? r.F((size_t)B * 64 * 32 * 2) : nullptr;
+    const size_t mk = r.ar->mark();
     half_t* t1 = r.H(M * w.cin);
     TRY(run_gn(r, w.n1, x0, x1, c0, c1, B, HW, eps * ss * ss, true, t1));
     half_t* h1 = r.H(M * w.cout);
@@ -540,15 +551,17 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
     } else {
         SDMI_REQUIRE(x1 == nullptr, "identity skip with a concatenated input");
     }
-    half_t* o = r.H(M * w.cout);
+    half_t* o = reuse ? o_pre : r.H(M * w.cout);
     {
         ConvArgs c;
         c.a0 = t2; c.c0 = w.cout; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
         c.resid = resid; c.ldr = w.cout; c.out = o; c.ldo = w.cout;
         c.alpha = ss; c.bias_scale = ss;
         c.stats_C = ss == 1.f ? w.cout : 0;                   // the block output usually feeds the next GroupNorm (ignored if not)
+        c.stats_ws_pre = st_pre;
         TRY(run_conv(r, w.c2, c));
     }
+    if (reuse) r.ar->rewind(mk);
     *out = o;
     return 0;
 }
@@ -664,14 +677,22 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     const int C = st.ch, HW = H * Wd;
     const size_t M = (size_t)B * HW;
     const int Npad = rup(HW, 64);
+    // arena_reuse: the output, the token stream after proj_in and two ping-pong buffers for the transformer blocks' outputs are taken
+    // first; everything after the mark lives for one block (or for proj_in) only
+    const bool reuse = r.reuse();
+    half_t* o_pre = reuse ? r.H(M * C) : nullptr;
+    half_t* cur_pre = reuse ? r.H(M * C) : nullptr;
+    half_t* pp[2] = {reuse ? r.H(M * C) : nullptr, (reuse && st.blocks.size() > 1) ? r.H(M * C) : nullptr};
+    const size_t mk = r.ar->mark();
     half_t* n0 = r.H(M * C);
     TRY(run_gn(r, st.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
-    half_t* cur = r.H(M * C);
+    half_t* cur = reuse ? cur_pre : r.H(M * C);
     // with "ln_fold" the GEMMs that write a LayerNorm's input also leave its row sums (Run::lnp_want; a no-op otherwise)
     const bool fold_any = e->ln_fold && !hn_has_dim(e, C) && !e->force_generic && e->use_glds && g_vt_mode == 1 && HW == Npad && HW % 4 == 0;
     r.lnp_want = fold_any && e->ln_fold >= 2;
     TRY(run_linear(r, st.proj_in, n0, (int)M, nullptr, cur, C));
-    int bi = 0;
+    if (reuse) r.ar->rewind(mk);
+    int bi = 0, blk = 0;
     for (const TBlockW& b : st.blocks) {
         const std::string bname = name + ".transformer_blocks." + std::to_string(bi++);
         // --- self attention
@@ -769,13 +790,15 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             g = r.H(M * 4 * C);
             TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
         }
-        half_t* x3 = r.H(M * C);
+        half_t* x3 = reuse ? pp[blk & 1] : r.H(M * C);                          // (block k reads pp[(k - 1) & 1] — or proj_in's buffer — and writes pp[k & 1])
         r.lnp_want = fold && e->ln_fold >= 2;                                   // read by the next block's norm1 (SDXL: depth > 1); unused after the last
         TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
         r.tap(bname, x3, B, H, Wd, C);
         cur = x3;
+        ++blk;
+        if (reuse) r.ar->rewind(mk);
     }
-    half_t* o = r.H(M * C);
+    half_t* o = reuse ? o_pre : r.H(M * C);
     TRY(run_linear(r, st.proj_out, cur, (int)M, x, o, C));
     *out = o;
     (void)L;

@@ -148,6 +148,8 @@ public:
     size_t cap = 0, off = 0, high = 0;
     bool dry = false;
     void reset() { off = 0; }
+    size_t mark() const { return off; }
+    void rewind(size_t m) { off = m; }            // everything taken since mark() is dead: later launches of the same stream may overwrite it
     void* take(size_t bytes) {
         const size_t a = (off + 255) & ~size_t(255);
         off = a + bytes;
@@ -185,6 +187,7 @@ struct sdmi_engine {
     sdmi::Arena arena;
     // option "streams" (> 1): a UNet call's rows are cut into that many slices, each on its own HIP stream / arena (engine.cpp unet_forward)
     int n_streams = 1;
+    int arena_reuse = 0;                      // 1: the temporaries of a ResBlock / transformer block are released when the block returns (option "arena_reuse")
     std::vector<hipStream_t> aux_streams;
     std::vector<sdmi::Arena> aux_arenas;
     std::vector<hipEvent_t> ev_join;

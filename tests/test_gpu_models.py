@@ -1126,6 +1126,40 @@ def test_hypernetworks_in_engine_vs_oracle(dev, tiny):
     assert torch.equal(fwd(), base)
 
 
+def test_arena_reuse_gives_the_same_bits(dev, tiny):
+    """Engine option "arena_reuse": the temporaries of every ResBlock / transformer block are released when the block returns and the next
+    block's launches write over them (same stream: ordered behind every reader).  Only addresses change — UNet forward (tiny, and an
+    SDXL-shaped one with two transformer blocks per level: the ping-pong buffers), VAE decode and a whole sampled job must give the
+    bits of the bump-only arena, call after call."""
+    processing, schema = sub("processing"), sub("schema")
+    model = tiny["model"]
+    eng = model.engine
+    x, t, ctx = seeded((4, 4, 16, 16), 1).to(dev), torch.tensor([999.0, 500.25, 37.5, 1.0], device=dev), tiny["cond"].to(dev)
+    z = seeded((2, 4, 16, 16), 5).to(dev)
+
+    def run_all(e, xx, tt, cc, yy=None):
+        e.set_context(cc)
+        return e.unet_forward(xx, tt, None, yy).clone()
+    base_u, base_v = run_all(eng, x, t, ctx), model.decode_first_stage(z).clone()
+    job = lambda: processing.process_images(processing.StableDiffusionProcessingTxt2Img(
+        sd_model=model, c=tiny["cond"][:2], uc=tiny["uncond"][:2], seed=31, batch_size=2, steps=4, cfg_scale=5.0, width=128, height=128, sampler_name="Euler a"))
+    base_imgs = job().images
+    ucfg2 = schema.tiny_unet(transformer_depth=2)
+    sd2 = schema.synthetic_state_dict(ucfg2, None, dtype=torch.float16, seed=0x51)
+    m2 = sub("sd_models").SdModel(sd2, ucfg2, None, device=0, load_vae=False)
+    base_u2 = run_all(m2.engine, x, t, ctx)
+    try:
+        eng.set_option("arena_reuse", 1); m2.engine.set_option("arena_reuse", 1)
+        for _ in range(2):
+            assert torch.equal(run_all(eng, x, t, ctx), base_u)
+            assert torch.equal(model.decode_first_stage(z), base_v)
+            assert torch.equal(run_all(m2.engine, x, t, ctx), base_u2)
+        assert all(np.array_equal(a, b) for a, b in zip(job().images, base_imgs))
+    finally:
+        eng.set_option("arena_reuse", 0); m2.engine.set_option("arena_reuse", 0)
+    assert torch.equal(run_all(eng, x, t, ctx), base_u)
+
+
 def test_hypernetwork_with_layernorm_at_sd15_widths(dev):
     """The widths a real SD1.5 hypernetwork carries (320 / 768 / 1280; 640 has the same code path as 320) with the default [1, 2, 1]
     structure AND LayerNorm: the hidden layer of the 1280-wide modules is 2560 wide — LayerNorm rows the engine used to reject — on a
