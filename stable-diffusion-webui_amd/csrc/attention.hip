@@ -930,6 +930,7 @@ int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e
 // default 15 since round 2: same-box A/Bs on the C1 job — 0 -> 5: self-attention 72.4 -> 69.5 ms per job (profiles/r02_knob_sweep.md);
 // 5 -> 15: 68.2 -> 66.6 and 70.0 -> 68.7 ms on two boxes (profiles/r02_attention_experiments.md)
 int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 15; }();
+int g_attn_fold_min_m = [] { const char* e = getenv("SDMI_ATTN_FOLD_MIN_M"); return e ? atoi(e) : 8192; }();   // 0: never
 int g_attn_lds_pad = 0;      // tuning only: extra dynamic LDS per workgroup (bytes) = an occupancy limiter (32 KB + pad per workgroup of 160 KB)
 int g_attn_pp_min_m = [] { const char* e = getenv("SDMI_ATTN_PP_MIN_M"); return e ? atoi(e) : 256; }();   // shortest key sequence the 8-wave kernel takes
 
@@ -1003,6 +1004,11 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
                     return g_attn_occ == 31 ? launch_attn_pp<40, true, 3>(p, s) : launch_attn_pp<40, false, 3>(p, s);
                 if (!(kvt128 && p.M > 64)) {
                     if (g_attn_occ == 5) return launch_attn_d<40, 64, 5>(p, s);
+                    // long self-attention (the 128x128-latent hires pass: N = M = 16384) takes the folded-shift form 17 by default: -4.2 % on
+                    // the launch, -1.3 % on the c4a job in a same-box A/B, parity at those shapes re-measured with it
+                    // (profiles/r03_parity_fullsize.json); at N = 4096 (C1) the two forms are within 1 % and 15 keeps the measured numerics
+                    if (g_attn_occ == 15 && g_attn_fold_min_m > 0 && p.M >= g_attn_fold_min_m && p.N >= g_attn_fold_min_m && !p.causal)
+                        return launch_attn_d<40, 64, 17>(p, s);
                     if (g_attn_occ == 15) return launch_attn_d<40, 64, 15>(p, s);
                     if (g_attn_occ == 16) return launch_attn_d<40, 64, 16>(p, s);
                     if (g_attn_occ == 17) return launch_attn_d<40, 64, 17>(p, s);

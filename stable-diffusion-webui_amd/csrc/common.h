@@ -142,6 +142,7 @@ extern int g_force_gemm_split;      // 0 = heuristic, 1 = never split, k > 1 = f
 extern int g_attn_kvt;
 extern int g_attn_occ;
 extern int g_attn_lds_pad;
+extern int g_attn_fold_min_m;
 extern unsigned long long g_attn_dbg;   // device pointer (0 = off) for AttnP::dbg
 extern int g_gemm_dbgflags;
 extern unsigned long long g_gemm_dbg;   // device pointer (0 = off): 5 x int64 per wave of section cycle sums
