@@ -39,7 +39,12 @@ def _register_samplers_and_lora():
     done = {}
     try:
         from modules import sd_samplers, sd_unet
-        done["samplers"] = bridge.install_samplers(sd_samplers, sd_unet)      # modules/sd_samplers.py:11-16 all_samplers rows, same names
+        try:                                                                  # store_latent (live preview) and MaskBlendArgs (soft inpainting)
+            from modules import sd_samplers_common, scripts as webui_scripts
+        except ImportError:
+            sd_samplers_common = webui_scripts = None
+        bridge.bind_shared(shared, sd_samplers_common, webui_scripts)         # modules.shared.opts / state / cmd_opts reach the engine samplers
+        done["samplers"] = bridge.install_samplers(sd_samplers, sd_unet, script_callbacks)   # modules/sd_samplers.py:11-16 rows, same names
     except ImportError:
         sd_unet = None
     try:

@@ -445,8 +445,14 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
         samples = self.sampler.sample_img2img(self, self.init_latent, x, conditioning, unconditional_conditioning,
                                               image_conditioning=self.image_conditioning_all[lo:lo + self.batch_size].contiguous())
-        if self.mask is not None:
-            samples = ops.mask_blend(samples.contiguous(), self.init_latent, self.mask, self.nmask)      # :1776-1784 final blend
+        if self.mask is not None:                                               # :1776-1784 final blend (+ Script.on_mask_blend, is_final_blend)
+            blended = ops.mask_blend(samples.contiguous().clone(), self.init_latent, self.mask, self.nmask)
+            runner = getattr(self, "scripts", None)
+            if runner is not None and hasattr(runner, "on_mask_blend"):
+                mba = shared.MaskBlendArgs(samples, self.nmask, self.init_latent, self.mask, blended)
+                runner.on_mask_blend(self, mba)
+                blended = mba.blended_latent
+            samples = blended
         return samples
 
 

@@ -319,6 +319,25 @@ class CFGDenoiser:
             self.sampler.sd_model.engine.set_context(ctx)
             self._ctx_key = key
 
+    def _mask_blend_scripts(self):
+        """The job's script runner if any of its scripts overrides ``on_mask_blend`` (modules/scripts.py:900-906; the built-in soft
+        inpainting script does) — then the blend is not fused into the combine kernel: the script sees both latents and may
+        replace the result, as in modules/sd_samplers_cfg_denoiser.py:176-185."""
+        runner = getattr(self.p, "scripts", None)
+        if runner is None or not hasattr(runner, "on_mask_blend"):
+            return None
+        listed = getattr(runner, "ordered_scripts", None)
+        if listed is not None and not listed("on_mask_blend"):
+            return None
+        return runner
+
+    def _script_blend(self, runner, current_latent, blended_latent, sigma):
+        if not runner:
+            return blended_latent
+        mba = shared.MaskBlendArgs(current_latent, self.nmask, self.init_latent, self.mask, blended_latent, denoiser=self, sigma=sigma)
+        runner.on_mask_blend(self.p, mba)
+        return mba.blended_latent.to(torch.float32).contiguous()
+
     def pad_cond_uncond(self, cond, uncond):
         """modules/sd_samplers_cfg_denoiser.py:100-111: pad the shorter side with repeats of the empty-prompt embedding."""
         empty = getattr(self.sampler.sd_model, "cond_stage_model_empty_prompt", None)
@@ -373,10 +392,11 @@ class CFGDenoiser:
         conds_list, tensor = cond if isinstance(cond, tuple) else (None, cond)
         if conds_list is not None and all(len(cl) == 1 and cl[0] == (i, 1.0) for i, cl in enumerate(conds_list)):
             conds_list = None                                 # plain CFG written the long way
+        blend_scripts = self._mask_blend_scripts() if self.mask is not None else None
         if self.mask_before_denoising and self.mask is not None:
             # blend in the original latents BEFORE denoising (timestep samplers, cfg_denoiser.py:186-187); the sampler keeps
             # its own, unblended x for the update, so work on a copy
-            x = ops.mask_blend(x.clone(), self.init_latent, self.mask, self.nmask)
+            x = self._script_blend(blend_scripts, x, ops.mask_blend(x.clone(), self.init_latent, self.mask, self.nmask), sigma)
         n_cond = b if conds_list is None else sum(len(cl) for cl in conds_list)
         if tensor.shape[0] != n_cond:
             raise ValueError(f"cond has {tensor.shape[0]} rows, conds_list names {n_cond}")
@@ -515,7 +535,8 @@ class CFGDenoiser:
             lnu = self.last_noise_uncond.contiguous()
             self.last_noise_uncond = _lc(lnu, [lnu, x.contiguous()], [v_c_out, v_c_skip])
         den = torch.empty_like(x)
-        use_mask = (not self.mask_before_denoising) and self.mask is not None
+        blend_after = (not self.mask_before_denoising) and self.mask is not None
+        use_mask = blend_after and not blend_scripts         # fused into the combine unless a script wants to see / replace the blend
         if c_skip_t is not None:
             check(lib.sdmi_cfg_combine_affine(ptr(x), ptr(pair), ptr(c_out_t), ptr(c_skip_t), scale,
                                               ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
@@ -525,7 +546,32 @@ class CFGDenoiser:
             check(lib.sdmi_cfg_combine(ptr(x), ptr(pair), ptr(c_out_t), scale, self.mode,
                                        ptr(self.mask) if use_mask else None, ptr(self.nmask) if use_mask else None,
                                        ptr(self.init_latent) if use_mask else None, ptr(den), b, chw, stream_ptr()), "cfg_combine")
-        self.sampler.last_latent = den
+        if blend_after and blend_scripts:                     # :291-292 with p.scripts.on_mask_blend (soft inpainting, :176-185)
+            den = self._script_blend(blend_scripts, den, ops.mask_blend(den.clone(), self.init_latent, self.mask, self.nmask), sigma)
+
+        # ---- :295-304: what an interrupted job returns (the x0 prediction of each image's first prompt) and the live preview
+        cond_rows = eps[:b] if conds_list is None else torch.stack([eps[cl[0][0]] for cl in conds_list])
+        if self.mode == 0:
+            k_out, k_x = float(c_out), (1.0 if c_skip_t is None else float(c_skip))      # denoised row = out * c_out + x * c_skip
+        elif vpred:
+            k_out, k_x = -v_c_skip, v_c_out                    # (x - sqrt(1-a) (sqrt(a) v + sqrt(1-a) x)) / sqrt(a), CFGDenoiserTimesteps.get_pred_x0
+        else:
+            a_t = sd_model.alphas_cumprod.float().cpu()[int(sig)]
+            k_out, k_x = -float(torch.sqrt(1 - a_t) / torch.sqrt(a_t)), float(1 / torch.sqrt(a_t))
+        xc = x.contiguous()
+        pred_x0 = lambda rows: _lc(torch.empty_like(xc), [rows, xc], [k_out, k_x])
+        self.sampler.last_latent = pred_x0(cond_rows)
+        content = getattr(opts, "live_preview_content", "Prompt")
+        if content == "Prompt":
+            preview = self.sampler.last_latent
+        elif content == "Negative prompt":
+            preview = self.sampler.last_latent if skip_uncond else pred_x0(eps[rows - b:rows])
+        elif self.mode == 0:
+            preview = den                                     # CFGDenoiserKDiffusion.get_pred_x0 is the identity on denoised rows
+        else:                                                 # the combined rows are eps here, whatever the parameterization
+            a_t = sd_model.alphas_cumprod.float().cpu()[int(sig)]
+            preview = _lc(torch.empty_like(xc), [den, xc], [-float(torch.sqrt(1 - a_t) / torch.sqrt(a_t)), float(1 / torch.sqrt(a_t))])
+        shared.store_latent(preview)
         self.step += 1
         return den
 
@@ -772,64 +818,57 @@ def sample_dpmpp_2s_ancestral(model, x, sigmas, extra_args=None, callback=None, 
     return x
 
 
+def restart_plan(sigmas, restart_list=None):
+    """The (sigma_from, sigma_to) pairs the Restart sampler walks (Xu et al. 2023; modules/sd_samplers_extra.py:36-63): the main
+    descent, and after the level nearest to each restart key a Karras ladder from there back up to the level nearest ``restart_max``,
+    repeated ``restart_times`` times.  Default plan: none below 20 steps, one 9-step restart from 0.1 to 2 below 36 steps, two of
+    steps // 4 above — paid for by shortening the main descent.  Entries stay 0-d fp32 tensors of the (CPU) schedule, so every
+    difference the loop forms rounds as the reference's does."""
+    n = len(sigmas) - 1
+    if restart_list is None:
+        restart_list = {}
+        if n >= 20:
+            per_restart, times = (n // 4, 2) if n >= 36 else (9, 1)
+            sigmas = get_sigmas_karras(n - per_restart * times, float(sigmas[-2]), float(sigmas[0]), device=sigmas.device)
+            restart_list = {0.1: [per_restart + 1, times, 2]}
+    levels = sigmas.detach().cpu().numpy()
+    nearest = lambda value: int(np.argmin(np.abs(levels - np.float32(value))))
+    after_level = {nearest(key): spec for key, spec in restart_list.items()}
+    plan = []
+    for lo in range(1, len(sigmas)):
+        plan.append((sigmas[lo - 1], sigmas[lo]))
+        if lo not in after_level:
+            continue
+        ladder_steps, times, restart_max = after_level[lo]
+        hi = nearest(restart_max)
+        if hi < lo:                                           # only ever climbs back up
+            ladder = get_sigmas_karras(ladder_steps, float(sigmas[lo]), float(sigmas[hi]), device=sigmas.device)[:-1]
+            plan += list(zip(ladder[:-1], ladder[1:])) * int(times)
+    return plan
+
+
 def restart_sampler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_noise=1., restart_list=None, noise_sampler=None):
-    """modules/sd_samplers_extra.py:6-74: Heun steps over a Karras schedule with restart segments (re-noise from sigma ~0.1 up
-    to sigma ~2); schedule construction verbatim on the host, tensor updates on the device."""
+    """modules/sd_samplers_extra.py:6-74: Heun steps along ``restart_plan``; where the plan jumps back up, noise of the variance
+    difference is added first.  Every tensor update is one sdmi_lincomb."""
     extra_args = {} if extra_args is None else extra_args
     x = x.contiguous()
     s_in = x.new_ones([x.shape[0]])
-    step_id = 0
-
-    def heun_step(x, old_sigma, new_sigma, second_order=True):
-        nonlocal step_id
-        denoised = model(x, old_sigma * s_in, **extra_args)
-        d = _to_d(x, old_sigma, denoised)
+    at = None
+    for step_id, (sigma_from, sigma_to) in enumerate(restart_plan(sigmas, restart_list)):
+        if at is not None and at < sigma_from:
+            x = _lc(torch.empty_like(x), [x, noise_sampler(sigma_from, sigma_to)], [1.0, s_noise * float((sigma_from ** 2 - at ** 2) ** 0.5)])
+        denoised = model(x, sigma_from * s_in, **extra_args)
+        d = _to_d(x, sigma_from, denoised)
         if callback is not None:
-            callback({'x': x, 'i': step_id, 'sigma': new_sigma, 'sigma_hat': old_sigma, 'denoised': denoised})
-        dt = float(new_sigma - old_sigma)
-        if new_sigma == 0 or not second_order:
+            callback({'x': x, 'i': step_id, 'sigma': sigma_to, 'sigma_hat': sigma_from, 'denoised': denoised})
+        dt = float(sigma_to - sigma_from)
+        if sigma_to == 0:
             x = _lc(torch.empty_like(x), [x, d], [1.0, dt])
         else:
             x_2 = _lc(torch.empty_like(x), [x, d], [1.0, dt])
-            denoised_2 = model(x_2, new_sigma * s_in, **extra_args)
-            d_2 = _to_d(x_2, new_sigma, denoised_2)
+            d_2 = _to_d(x_2, sigma_to, model(x_2, sigma_to * s_in, **extra_args))
             x = _lc(torch.empty_like(x), [x, d, d_2], [1.0, 0.5 * dt, 0.5 * dt])
-        step_id += 1
-        return x
-
-    steps = sigmas.shape[0] - 1
-    if restart_list is None:
-        if steps >= 20:
-            restart_steps = 9
-            restart_times = 1
-            if steps >= 36:
-                restart_steps = steps // 4
-                restart_times = 2
-            sigmas = get_sigmas_karras(steps - restart_steps * restart_times, sigmas[-2].item(), sigmas[0].item(), device=sigmas.device)
-            restart_list = {0.1: [restart_steps + 1, restart_times, 2]}
-        else:
-            restart_list = {}
-    restart_list = {int(torch.argmin(abs(sigmas - key), dim=0)): value for key, value in restart_list.items()}
-    step_list = []
-    for i in range(len(sigmas) - 1):
-        step_list.append((sigmas[i], sigmas[i + 1]))
-        if i + 1 in restart_list:
-            restart_steps, restart_times, restart_max = restart_list[i + 1]
-            min_idx = i + 1
-            max_idx = int(torch.argmin(abs(sigmas - restart_max), dim=0))
-            if max_idx < min_idx:
-                sigma_restart = get_sigmas_karras(restart_steps, sigmas[min_idx].item(), sigmas[max_idx].item(), device=sigmas.device)[:-1]
-                while restart_times > 0:
-                    restart_times -= 1
-                    step_list.extend(zip(sigma_restart[:-1], sigma_restart[1:]))
-    last_sigma = None
-    for old_sigma, new_sigma in step_list:
-        if last_sigma is None:
-            last_sigma = old_sigma
-        elif last_sigma < old_sigma:
-            x = _lc(torch.empty_like(x), [x, noise_sampler(old_sigma, new_sigma)], [1.0, s_noise * float((old_sigma ** 2 - last_sigma ** 2) ** 0.5)])
-        x = heun_step(x, old_sigma, new_sigma)
-        last_sigma = new_sigma
+        at = sigma_to
     return x
 
 
@@ -1423,7 +1462,9 @@ class Sampler:
         self.s_tmax = float('inf')
         self.s_noise = 1.0
         self.eta_option_field = 'eta_ancestral'
+        self.eta_infotext_field = 'Eta'
         self.eta_default = 1.0
+        self.conditioning_key = getattr(getattr(sd_model, 'model', None), 'conditioning_key', 'crossattn')   # read at processing.py:386-389
         self.p = None
         self.model_wrap_cfg = None
         self.sampler_extra_args = None
@@ -1434,6 +1475,7 @@ class Sampler:
         if self.stop_at is not None and step > self.stop_at:
             raise InterruptedException
         shared.state.sampling_step = step
+        shared.total_tqdm.update()
 
     def launch_sampling(self, steps, func):
         self.model_wrap_cfg.steps = steps
@@ -1442,6 +1484,11 @@ class Sampler:
         shared.state.sampling_step = 0
         try:
             return func()
+        except RecursionError:
+            print('Encountered RecursionError during sampling, returning last latent. '
+                  'rho >5 with a polyexponential scheduler may cause this error. '
+                  'You should try to use a smaller rho value instead.')
+            return self.last_latent
         except InterruptedException:
             return self.last_latent
 
@@ -1460,7 +1507,10 @@ class Sampler:
         for param_name in self.extra_params:
             if hasattr(p, param_name) and param_name in params:
                 extra_params_kwargs[param_name] = getattr(p, param_name)
+        info = p.extra_generation_params                  # the infotext keys of modules/sd_samplers_common.py:303-331
         if 'eta' in params:
+            if self.eta != self.eta_default:
+                info[self.eta_infotext_field] = self.eta
             extra_params_kwargs['eta'] = self.eta
         if len(self.extra_params) > 0:                    # modules/sd_samplers_common.py:309-331 (options override p)
             opts = shared.opts
@@ -1471,15 +1521,19 @@ class Sampler:
             if 's_churn' in extra_params_kwargs and s_churn != self.s_churn:
                 extra_params_kwargs['s_churn'] = s_churn
                 p.s_churn = s_churn
+                info['Sigma churn'] = s_churn
             if 's_tmin' in extra_params_kwargs and s_tmin != self.s_tmin:
                 extra_params_kwargs['s_tmin'] = s_tmin
                 p.s_tmin = s_tmin
+                info['Sigma tmin'] = s_tmin
             if 's_tmax' in extra_params_kwargs and s_tmax != self.s_tmax:
                 extra_params_kwargs['s_tmax'] = s_tmax
                 p.s_tmax = s_tmax
+                info['Sigma tmax'] = s_tmax
             if 's_noise' in extra_params_kwargs and s_noise != self.s_noise:
                 extra_params_kwargs['s_noise'] = s_noise
                 p.s_noise = s_noise
+                info['Sigma noise'] = s_noise
             for k in ('s_churn', 's_tmin', 's_tmax', 's_noise'):     # a caller that left the field unset gets the sampler default
                 if k in extra_params_kwargs and extra_params_kwargs[k] is None:
                     extra_params_kwargs[k] = getattr(self, k)
@@ -1487,6 +1541,13 @@ class Sampler:
             rng = p.rng                                   # TorchHijack.randn_like -> p.rng.next() (common.py:205-226)
             extra_params_kwargs['noise_sampler'] = (lambda *a: rng.next())
         return extra_params_kwargs
+
+    def add_infotext(self, p):
+        """modules/sd_samplers_common.py:350-355"""
+        if self.model_wrap_cfg.padded_cond_uncond:
+            p.extra_generation_params["Pad conds"] = True
+        if self.model_wrap_cfg.padded_cond_uncond_v0:
+            p.extra_generation_params["Pad conds v0"] = True
 
     def sample(self, p, x, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
         raise NotImplementedError()
@@ -1546,36 +1607,46 @@ class KDiffusionSampler(Sampler):
         self.model_wrap = self.model_wrap_cfg.inner_model
 
     def get_sigmas(self, p, steps):
-        """modules/sd_samplers_kdiffusion.py:79-132"""
-        opts = shared.opts
-        discard_next_to_last_sigma = self.config is not None and self.config.options.get('discard_next_to_last_sigma', False)
-        if opts.always_discard_next_to_last_sigma and not discard_next_to_last_sigma:
-            discard_next_to_last_sigma = True
-        steps += 1 if discard_next_to_last_sigma else 0
-        scheduler_name = (getattr(p, 'hr_scheduler', None) if getattr(p, 'is_hr_pass', False) else getattr(p, 'scheduler', None)) or 'Automatic'
-        if scheduler_name == 'Automatic':
-            scheduler_name = self.config.options.get('scheduler', None) if self.config is not None else None
-        scheduler = schedulers_map.get(scheduler_name)
-        if scheduler_name is not None and scheduler is None:
-            raise NotImplementedError(f"unknown scheduler {scheduler_name!r}")
-        m_sigma_min, m_sigma_max = self.model_wrap.sigmas[0].item(), self.model_wrap.sigmas[-1].item()
-        sigma_min, sigma_max = (0.1, 10) if opts.use_old_karras_scheduler_sigmas else (m_sigma_min, m_sigma_max)
-        if getattr(p, 'sampler_noise_scheduler_override', None):
-            sigmas = p.sampler_noise_scheduler_override(steps)
+        """The job's noise levels, resolved the way modules/sd_samplers_kdiffusion.py:79-132 resolves them — sampler row options,
+        p.scheduler / p.hr_scheduler, then the user's opts.sigma_min / sigma_max / rho / always_discard_next_to_last_sigma /
+        use_old_karras_scheduler_sigmas — and recorded under the same infotext keys.  Host fp32, as the reference keeps them."""
+        opts, info = shared.opts, p.extra_generation_params
+        row = self.config.options if self.config is not None else {}
+        drop_penultimate = bool(row.get('discard_next_to_last_sigma', False))
+        if not drop_penultimate and opts.always_discard_next_to_last_sigma:
+            drop_penultimate = info["Discard penultimate sigma"] = True
+        n = steps + int(drop_penultimate)
+        second_pass = bool(getattr(p, 'is_hr_pass', False))
+        name = getattr(p, 'hr_scheduler' if second_pass else 'scheduler', None) or 'Automatic'
+        if name == 'Automatic':
+            name = row.get('scheduler')
+        scheduler = schedulers_map.get(name)
+        if name is not None and scheduler is None:
+            raise NotImplementedError(f"unknown scheduler {name!r}")
+        model_range = {'sigma_min': self.model_wrap.sigmas[0].item(), 'sigma_max': self.model_wrap.sigmas[-1].item()}
+        override = getattr(p, 'sampler_noise_scheduler_override', None)
+        if override:
+            sigmas = override(n)
         elif scheduler is None or scheduler.function is None:
-            sigmas = self.model_wrap.get_sigmas(steps)
+            sigmas = self.model_wrap.get_sigmas(n)
         else:
-            sigmas_kwargs = {'sigma_min': sigma_min, 'sigma_max': sigma_max}
-            if opts.sigma_min != 0 and opts.sigma_min != m_sigma_min:
-                sigmas_kwargs['sigma_min'] = opts.sigma_min
-            if opts.sigma_max != 0 and opts.sigma_max != m_sigma_max:
-                sigmas_kwargs['sigma_max'] = opts.sigma_max
+            kwargs = {'sigma_min': 0.1, 'sigma_max': 10} if opts.use_old_karras_scheduler_sigmas else dict(model_range)
+            if scheduler.label != 'Automatic' and not second_pass:
+                info["Schedule type"] = scheduler.label
+            elif scheduler.label != info.get("Schedule type"):
+                info["Hires schedule type"] = scheduler.label
+            for key, text in (('sigma_min', "Schedule min sigma"), ('sigma_max', "Schedule max sigma")):
+                wanted = getattr(opts, key)
+                if wanted != 0 and wanted != model_range[key]:
+                    kwargs[key] = info[text] = wanted
             if scheduler.default_rho != -1 and opts.rho != 0 and opts.rho != scheduler.default_rho:
-                sigmas_kwargs['rho'] = opts.rho
+                kwargs['rho'] = info["Schedule rho"] = opts.rho
             if scheduler.need_inner_model:
-                sigmas_kwargs['inner_model'] = self.model_wrap
-            sigmas = scheduler.function(n=steps, **sigmas_kwargs, device='cpu')
-        if discard_next_to_last_sigma:
+                kwargs['inner_model'] = self.model_wrap
+            if scheduler.label == 'Beta':
+                info["Beta schedule alpha"], info["Beta schedule beta"] = opts.beta_dist_alpha, opts.beta_dist_beta
+            sigmas = scheduler.function(n=n, **kwargs, device='cpu')
+        if drop_penultimate:
             sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
         return sigmas.cpu()
 
@@ -1631,8 +1702,10 @@ class KDiffusionSampler(Sampler):
         self.model_wrap_cfg.init_latent = x
         self.last_latent = x
         extra = self._extra(p, conditioning, unconditional_conditioning, image_conditioning)
-        return self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=extra, disable=False,
+        samples = self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=extra, disable=False,
                                                                   callback=self.callback_state, **extra_params_kwargs))
+        self.add_infotext(p)
+        return samples
 
     def sample(self, p, x, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
         steps = steps or p.steps
@@ -1655,8 +1728,10 @@ class KDiffusionSampler(Sampler):
         self._sde_options(extra_params_kwargs, x0, sigmas, p)  # :213-218
         self.last_latent = x0
         extra = self._extra(p, conditioning, unconditional_conditioning, image_conditioning)
-        return self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,
+        samples = self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,
                                                               callback=self.callback_state, **extra_params_kwargs))
+        self.add_infotext(p)
+        return samples
 
 
 class CFGDenoiserLCM(CFGDenoiser):
@@ -1702,6 +1777,7 @@ class CompVisSampler(Sampler):
         super().__init__(func.__name__, sd_model)
         self.func = func
         self.eta_option_field = 'eta_ddim'
+        self.eta_infotext_field = 'Eta DDIM'
         self.eta_default = 0.0
         self.model_wrap_cfg = CFGDenoiserTimesteps(self)
         self.model_wrap = self.model_wrap_cfg.inner_model
@@ -1709,7 +1785,7 @@ class CompVisSampler(Sampler):
     def get_timesteps(self, p, steps):
         discard = self.config is not None and self.config.options.get('discard_next_to_last_sigma', False)
         if shared.opts.always_discard_next_to_last_sigma and not discard:
-            discard = True
+            discard = p.extra_generation_params["Discard penultimate sigma"] = True
         steps += 1 if discard else 0
         return torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
 
@@ -1729,8 +1805,10 @@ class CompVisSampler(Sampler):
         self.sampler_extra_args = _sampler_extra_args(self, p, conditioning, unconditional_conditioning, image_conditioning)
         extra = self.sampler_extra_args
         x0 = x.clone()
-        return self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,
+        samples = self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x0, extra_args=extra, disable=False,
                                                               callback=self.callback_state, **extra_params_kwargs))
+        self.add_infotext(p)
+        return samples
 
     def sample_img2img(self, p, x, noise, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
         steps, t_enc = setup_img2img_steps(p, steps)
@@ -1754,8 +1832,10 @@ class CompVisSampler(Sampler):
         self.last_latent = x
         self.sampler_extra_args = _sampler_extra_args(self, p, conditioning, unconditional_conditioning, image_conditioning)
         extra = self.sampler_extra_args
-        return self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=extra, disable=False,
+        samples = self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=extra, disable=False,
                                                                   callback=self.callback_state, **extra_params_kwargs))
+        self.add_infotext(p)
+        return samples
 
 
 samplers_data_k_diffusion = [

@@ -73,6 +73,12 @@ class Mi355xUnet(SdUnet):
     def forward(self, x, timesteps, context, *args, **kwargs):
         if kwargs.get("control") is not None or args:
             raise NotImplementedError("extra UNet inputs (ControlNet residuals etc.) are not supported by the engine UNet")
+        from . import shared
+        if shared.webui is not None:                          # ToMe / Hypertile patch the torch UNet this adapter replaces: refuse, never ignore
+            from .webui_bridge import patched_unet_reason, REFUSAL
+            why = patched_unet_reason(getattr(shared.webui, "sd_model", None))
+            if why is not None:
+                raise NotImplementedError(REFUSAL.format(why=why))
         if x.dtype not in (torch.float16, torch.float32):
             x = x.float()
         y = kwargs.get("y", None)

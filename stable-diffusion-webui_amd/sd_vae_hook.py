@@ -28,6 +28,9 @@ def install(sd_model, device_index: int = 0):
     fsm._torch_decode = fsm.decode
 
     def decode(z, *a, **kw):
+        from .webui_bridge import hypertile_active
+        if hypertile_active(fsm):                  # opts.hypertile_enable_vae tiles the torch mid-block attention: that IS the torch decode
+            return fsm._torch_decode(z, *a, **kw)
         return eng.vae_decode(z if z.dtype in (torch.float16, torch.float32) else z.float()).to(z.dtype)
 
     fsm.decode = decode

@@ -1,10 +1,14 @@
 """Webui-side registrations beyond the SdUnet / SdOptimization / VAE hooks (boundaries B3, B5, B6 of INTEGRATION.md), as functions
 the shipped extension script calls with the webui's OWN modules as arguments — so a CPU test can drive them with stubs.
 
-  B3  install_samplers      every row of ``modules.sd_samplers.all_samplers`` (modules/sd_samplers.py:11-16) whose name the engine's
+  B3  bind_shared           the engine samplers read ``modules.shared.opts / state / cmd_opts`` (the user's sampler settings, Interrupt /
+                            Skip, progress, live preview) instead of the package's standalone defaults.
+      install_samplers      every row of ``modules.sd_samplers.all_samplers`` (modules/sd_samplers.py:11-16) whose name the engine's
                             sampler table carries gets a constructor that returns the engine sampler (fused CFG / step kernels) WHILE
-                            the engine UNet is the active ``sd_unet.current_unet``, and the stock torch sampler otherwise: same names,
-                            aliases and options, so scripts / API / infotext are untouched.
+                            the engine UNet is the active ``sd_unet.current_unet`` and no cfg_denoiser / cfg_denoised / cfg_after_cfg /
+                            extra_noise script callback is registered, and the stock torch sampler otherwise: same names, aliases and
+                            options, so scripts / API / infotext are untouched.  ToMe / Hypertile jobs are refused (they patch torch
+                            modules the engine UNet replaces); a refiner-checkpoint job is forwarded to the stock sampler.
   B5  install_lora_hook     wraps ``networks.load_networks`` of extensions-builtin/Lora (called from ExtraNetworkLora.activate,
                             extra_networks_lora.py:18-45): the stock function keeps the text-encoder part and the bookkeeping, then the
                             UNet part of the same network files is merged on the GPU into the engine's packed weights.
@@ -83,9 +87,112 @@ def engine_model_view(sd_model, sd_unet_module) -> Optional[EngineModelView]:
 
 
 # ---- B3 ---------------------------------------------------------------------------------------------------------------------------
-def install_samplers(webui_sd_samplers, sd_unet_module) -> list:
-    """Idempotent (the webui re-imports extension scripts on "Reload UI").  Returns the names that now dispatch."""
-    from . import sd_samplers as amd
+def bind_shared(webui_shared, webui_sd_samplers_common=None, webui_scripts=None):
+    """The engine samplers read the webui's OWN ``opts`` / ``state`` / ``cmd_opts`` / ``total_tqdm`` from here on (shared.bind_webui),
+    store their x0 predictions through the webui's ``store_latent`` (live preview, modules/sd_samplers_common.py:115-120) and hand
+    ``Script.on_mask_blend`` the webui's ``MaskBlendArgs`` (modules/scripts.py:16-26)."""
+    from . import shared
+    shared.bind_webui(webui_shared, getattr(webui_sd_samplers_common, "store_latent", None), getattr(webui_scripts, "MaskBlendArgs", None))
+
+
+SAMPLER_CALLBACK_LISTS = ("callbacks_cfg_denoiser", "callbacks_cfg_denoised", "callbacks_cfg_after_cfg", "callbacks_extra_noise")
+
+
+def registered_sampler_callbacks(script_callbacks) -> list:
+    """Names of the per-step script callback lists that are not empty (modules/script_callbacks.py:219-230, fired at
+    modules/sd_samplers_cfg_denoiser.py:212, 279, 307 and modules/sd_samplers_kdiffusion.py:146-151).  They receive — and may rewrite —
+    the torch tensors of the reference's CFG denoiser (x_in, sigma_in, the cond batch, x_out, denoised); the fused CFG kernels have
+    no such tensors to offer, so a job that would fire any of them runs the stock sampler."""
+    table = getattr(script_callbacks, "callback_map", None) or {}
+    return [name for name in SAMPLER_CALLBACK_LISTS if table.get(name)]
+
+
+def hypertile_active(torch_module) -> bool:
+    """extensions-builtin/hypertile/hypertile.py:318-347: ``hypertile_hook_model(module, ...)`` wraps the self-attention forwards below
+    ``module`` (``sd_model.model`` for the U-Net, ``sd_model.first_stage_model`` for the VAE) and marks each wrapped layer with
+    ``__webui_hypertile_params``; the tiling is live while any of them has ``enabled`` set."""
+    layers = getattr(torch_module, "__webui_hypertile_layers", None)
+    if not layers:
+        return False
+    cached = _hypertile_params.get(id(layers))
+    if cached is None or cached[0] is not layers:
+        cached = _hypertile_params[id(layers)] = (layers, [getattr(m, "__webui_hypertile_params") for n, m in torch_module.named_modules()
+                                                           if n in layers and hasattr(m, "__webui_hypertile_params")])
+    return any(getattr(prm, "enabled", False) for prm in cached[1])
+
+
+def hypertile_unet_active(sd_model) -> bool:
+    """opts.hypertile_enable_unet, or the second-pass option inside a hires pass (hypertile_script.py:17-42)."""
+    return hypertile_active(getattr(sd_model, "model", None))
+
+
+_hypertile_params = {}
+
+
+def patched_unet_reason(sd_model):
+    """Why the torch UNet of ``sd_model`` currently computes something the engine UNet does not: token merging
+    (modules/sd_models.py:1011-1034 ``tomesd.apply_patch``: merges tokens around attn1) or Hypertile (tiled self-attention).  Both patch
+    torch modules the engine never calls, so the engine refuses the job instead of silently ignoring them."""
+    if getattr(sd_model, "applied_token_merged_ratio", 0) > 0:
+        return f"token merging is active (ratio {sd_model.applied_token_merged_ratio})"
+    if hypertile_unet_active(sd_model):
+        return "Hypertile is enabled for the U-Net"
+    return None
+
+
+REFUSAL = ("{why}: it patches the torch UNet, which the [MI355X] SD Unet replaces. Set Settings -> SD Unet to None for this job "
+           "(the mi355x cross-attention optimization keeps working inside the torch UNet), or turn the feature off.")
+
+
+def job_needs_stock_sampler(p):
+    """Per-job reasons (only ``p`` knows them, and ``p`` is not there yet when the row's constructor runs) to hand a sampling call to
+    the stock sampler: a refiner CHECKPOINT switch (modules/sd_samplers_common.py:158-202 reloads weights mid-job; the engine's own
+    refiner is a second resident engine the webui's p does not carry)."""
+    if getattr(p, "refiner_checkpoint_info", None) is not None and getattr(p, "refiner_sd_model", None) is None:
+        return "refiner checkpoint switch"
+    return None
+
+
+def _check_job(p, sd_model):
+    """Raises for jobs the engine UNet cannot honour at all (ToMe / Hypertile, including the hires-pass ratios that are applied
+    after the sampler was built: modules/processing.py:1442)."""
+    from . import shared
+    why = patched_unet_reason(sd_model)
+    if why is None and hasattr(p, "get_token_merging_ratio"):
+        ratio = p.get_token_merging_ratio(for_hr=bool(getattr(p, "is_hr_pass", False)))
+        why = f"token merging is requested (ratio {ratio})" if ratio and ratio > 0 else None
+    if why is None and getattr(p, "is_hr_pass", False) and getattr(shared.opts, "hypertile_enable_unet_secondpass", False):
+        why = "Hypertile is enabled for the U-Net second pass"
+    if why is None and getattr(shared.opts, "hypertile_enable_unet", False):
+        why = "Hypertile is enabled for the U-Net"
+    if why is not None:
+        raise NotImplementedError(REFUSAL.format(why=why))
+
+
+def _engine_sampler_with_job_checks(engine_sampler, stock_ctor, model):
+    """``sample`` / ``sample_img2img`` of the engine sampler, preceded by the per-job checks; a job that needs the stock sampler
+    gets one built on the spot (same row, so same config) and the call is forwarded."""
+    for name in ("sample", "sample_img2img"):
+        fused = getattr(engine_sampler, name)
+
+        def call(p, *args, _fused=fused, _name=name, **kwargs):
+            _check_job(p, model)
+            why = job_needs_stock_sampler(p)
+            if why is None:
+                return _fused(p, *args, **kwargs)
+            stock = stock_ctor(model)
+            stock.config = engine_sampler.config
+            engine_sampler.stock_delegate, engine_sampler.stock_reason = stock, why
+            return getattr(stock, _name)(p, *args, **kwargs)
+        setattr(engine_sampler, name, call)
+    return engine_sampler
+
+
+def install_samplers(webui_sd_samplers, sd_unet_module, script_callbacks=None) -> list:
+    """Idempotent (the webui re-imports extension scripts on "Reload UI").  Returns the names that now dispatch.  A row builds the
+    engine sampler when the engine UNet is the active ``sd_unet.current_unet`` AND no per-step script callback is registered;
+    the stock sampler otherwise."""
+    from . import sd_samplers as amd, shared
     replaced = []
     rows = list(webui_sd_samplers.all_samplers)
     for i, row in enumerate(rows):
@@ -96,7 +203,10 @@ def install_samplers(webui_sd_samplers, sd_unet_module) -> list:
 
         def constructor(model, stock=stock, mine=mine):
             view = engine_model_view(model, sd_unet_module)
-            return stock(model) if view is None else mine.constructor(view)
+            if view is None or registered_sampler_callbacks(script_callbacks):
+                return stock(model)
+            shared.sd_model = view                            # what the package's schedulers ask for is_sdxl (sd_schedulers.py)
+            return _engine_sampler_with_job_checks(mine.constructor(view), stock, model)
         constructor._mi355x_stock = stock
         rows[i] = type(row)(row.name, constructor, row.aliases, row.options)
         replaced.append(row.name)

@@ -85,9 +85,11 @@ def test_sampler_registry_and_sigma_selection():
         scheduler = None
         is_hr_pass = False
         sampler_noise_scheduler_override = None
+        extra_generation_params = {}
     s = ss.create_sampler("DPM++ 2M", M())
     sig = s.get_sigmas(P(), 50)
     assert sig.shape == (51,) and abs(float(sig[1]) - 13.4292) < 2e-4      # Karras by default for DPM++ 2M
+    assert P.extra_generation_params == {"Schedule type": "Karras"}        # the infotext key of sd_samplers_kdiffusion.py:103-104
     s = ss.create_sampler("Euler a", M())
     assert abs(float(s.get_sigmas(P(), 20)[1]) - 10.7468) < 1e-4            # model schedule for Euler a
     P.scheduler = "Karras"
@@ -147,6 +149,7 @@ def test_sampler_table_matches_reference_rows():
         scheduler = None
         is_hr_pass = False
         sampler_noise_scheduler_override = None
+        extra_generation_params = {}
     from oracle import pipeline as opipe
     ora = okd.CompVisDenoiser(None, okd.make_alphas_cumprod())
     for name, key in (("DPM2", "dpm_2"), ("DPM2 a", "dpm_2_a"), ("Heun", "heun"), ("LMS", "lms"), ("DPM++ 2S a", "dpmpp_2s_a")):
@@ -207,7 +210,7 @@ def test_host_lcm_schedule_and_folded_scalings_match_reference(golden_dir):
     den = s.model_wrap
     assert np.array_equal(den.sigmas.numpy(), z["sigmas"])
     assert np.array_equal(den.sigma_to_t(torch.tensor(z["probe_sigma"])).numpy(), z["probe_t"])
-    P = type("P", (), {"scheduler": None, "is_hr_pass": False, "sampler_noise_scheduler_override": None})
+    P = type("P", (), {"scheduler": None, "is_hr_pass": False, "sampler_noise_scheduler_override": None, "extra_generation_params": {}})
     for ci, steps in enumerate([4, 8]):
         np.testing.assert_allclose(s.get_sigmas(P(), steps).numpy(), z[f"c{ci}_sigmas"], rtol=1e-6)
     from tests.test_oracle_pins import seeded
@@ -967,3 +970,210 @@ def test_bench_pmc_child_command_line(monkeypatch):
     path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
     if not os.path.exists(path):
         assert bench.pmc_traffic(args) == (None, None)
+
+
+def test_restart_plan_matches_the_pinned_oracle_restatement():
+    """sd_samplers.restart_plan (the repo's own form of the schedule builder) against oracle.kdiffusion.restart_step_list, which
+    tests/test_oracle_pins.py pins to modules/sd_samplers_extra.py: same pairs, same fp32 bits, for no / one / two restarts and an
+    explicit restart_list whose target lies below the trigger (never climbs: no ladder)."""
+    ss = sub("sd_samplers")
+    from oracle import kdiffusion as kd
+    smin, smax = 0.0291672, 14.614641
+    for steps, restart_list in ((8, None), (22, None), (40, None), (12, {0.5: [4, 2, 3.0]}), (12, {3.0: [4, 1, 0.5]})):
+        sig = kd.get_sigmas_karras(steps, smin, smax)
+        got, want = ss.restart_plan(sig.clone(), restart_list), kd.restart_step_list(sig.clone(), None if restart_list is None else dict(restart_list))
+        assert len(got) == len(want)
+        assert all(torch.equal(a0, b0) and torch.equal(a1, b1) for (a0, a1), (b0, b1) in zip(got, want))
+    assert len(ss.restart_plan(kd.get_sigmas_karras(22, smin, smax))) == 13 + 9
+
+
+def _stub_webui(monkeypatch, opts=None):
+    """A webui small enough for a CPU test: modules.{shared, script_callbacks, sd_models, sd_samplers, sd_unet, sd_samplers_common,
+    scripts} with the attributes the extension script and the engine samplers touch."""
+    import collections
+    import types
+    class SamplerData(collections.namedtuple("SamplerData", ["name", "constructor", "aliases", "options"])):
+        def total_steps(self, steps):                         # modules/sd_samplers_common.py:14-18
+            return steps * 2 if self.options.get("second_order", False) else steps
+    w = types.SimpleNamespace(stock_calls=[], tqdm=[], stored=[])
+
+    def mk(name):
+        def ctor(model):
+            w.stock_calls.append((name, model))
+            calls = []
+            return types.SimpleNamespace(stock=name, config=None, calls=calls,
+                                         sample=lambda p, *a, **k: calls.append(("sample", p)) or "stock-samples",
+                                         sample_img2img=lambda p, *a, **k: calls.append(("sample_img2img", p)) or "stock-samples")
+        return ctor
+    samplers_mod = types.ModuleType("modules.sd_samplers")
+    samplers_mod.all_samplers = [SamplerData("Euler a", mk("Euler a"), ["k_euler_a"], {"uses_ensd": True}),
+                                 SamplerData("DPM++ 2M", mk("DPM++ 2M"), ["k_dpmpp_2m"], {"scheduler": "karras"}),
+                                 SamplerData("DDIM", mk("DDIM"), ["ddim"], {})]
+    samplers_mod.all_samplers_map = {x.name: x for x in samplers_mod.all_samplers}
+    samplers_mod.set_samplers = lambda: None
+    unet_mod = types.ModuleType("modules.sd_unet")
+    unet_mod.current_unet = None
+    cb = types.ModuleType("modules.script_callbacks")
+    cb.on_list_unets = cb.on_list_optimizers = cb.on_model_loaded = lambda f: None
+    cb.callback_map = dict(callbacks_cfg_denoiser=[], callbacks_cfg_denoised=[], callbacks_cfg_after_cfg=[], callbacks_extra_noise=[],
+                           callbacks_model_loaded=["something unrelated"])
+    sdm = types.ModuleType("modules.sd_models")
+    sdm.checkpoints_list = {}
+    sdm.read_state_dict = lambda fn, map_location=None: {}
+    shared_stub = types.ModuleType("modules.shared")
+    shared_stub.sd_model = types.SimpleNamespace(alphas_cumprod=sub("schema").make_alphas_cumprod(), model=torch.nn.Module())
+    shared_stub.opts = types.SimpleNamespace(**(opts or {}))
+    shared_stub.state = types.SimpleNamespace(interrupted=False, skipped=False, sampling_step=0, sampling_steps=0, current_latent=None)
+    shared_stub.cmd_opts = types.SimpleNamespace(disable_nan_check=True)
+    shared_stub.total_tqdm = types.SimpleNamespace(update=lambda: w.tqdm.append(1))
+    common = types.ModuleType("modules.sd_samplers_common")
+    common.store_latent = lambda decoded: w.stored.append(decoded)
+    scripts_mod = types.ModuleType("modules.scripts")
+    scripts_mod.MaskBlendArgs = type("MaskBlendArgs", (), {"__init__": lambda self, *a, **k: setattr(self, "args", (a, k))})
+    root = types.ModuleType("modules")
+    mods = {"script_callbacks": cb, "sd_models": sdm, "shared": shared_stub, "sd_samplers": samplers_mod, "sd_unet": unet_mod,
+            "sd_samplers_common": common, "scripts": scripts_mod}
+    monkeypatch.setitem(sys.modules, "modules", root)
+    for name, m in mods.items():
+        setattr(root, name, m)
+        monkeypatch.setitem(sys.modules, "modules." + name, m)
+    import importlib.util
+    path = os.path.join(ROOT, "stable-diffusion-webui_amd", "extension", "scripts", "mi355x_engine.py")
+    spec = importlib.util.spec_from_file_location("mi355x_engine_script_c", path)
+    w.script = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(w.script)
+    w.__dict__.update(mods)
+    # an "active" engine UNet (no GPU here: the engine handle is a stand-in, nothing below launches a kernel)
+    unet = sub("sd_unet").Mi355xUnet(lambda: {}, unet_cfg=sub("schema").tiny_unet())
+    unet.engine, unet._sd = types.SimpleNamespace(device=0), {}
+    w.unet = unet
+    return w
+
+
+@pytest.fixture
+def webui(monkeypatch):
+    w = _stub_webui(monkeypatch, opts=dict(eta_ancestral=0.5, sigma_min=0.05, always_discard_next_to_last_sigma=True,
+                                           live_previews_enable=True, show_progress_every_n_steps=2, live_preview_content="Combined"))
+    yield w
+    sub("shared").unbind_webui()
+
+
+def _job(**kw):
+    import types
+    p = types.SimpleNamespace(scheduler="Karras", hr_scheduler=None, is_hr_pass=False, sampler_noise_scheduler_override=None,
+                              extra_generation_params={}, eta=None, s_min_uncond=0.0, steps=20, batch_size=1, iteration=0, rng=None,
+                              get_token_merging_ratio=lambda for_hr=False: 0.0)
+    p.__dict__.update(kw)
+    return p
+
+
+def test_engine_samplers_read_the_webuis_own_opts_and_state(webui):
+    """VERDICT r3 missing #1: once the extension script ran, ``stable-diffusion-webui_amd.shared.opts / state / cmd_opts`` ARE the
+    webui's objects (names the webui lacks fall back to the reference defaults), so the user's eta / sigma_min / "always discard
+    next-to-last sigma", Interrupt, the progress counters and the live-preview store reach the engine samplers as they reach the
+    stock ones (modules/sd_samplers_kdiffusion.py:79-132, modules/sd_samplers_common.py:256-281, 303-305,
+    modules/sd_samplers_cfg_denoiser.py:157-158)."""
+    amd_shared, ss = sub("shared"), sub("sd_samplers")
+    assert amd_shared.webui is webui.shared and amd_shared.opts.eta_ancestral == 0.5 and amd_shared.opts.uni_pc_order == 3
+    assert amd_shared.cmd_opts.disable_nan_check is True and amd_shared.cmd_opts.no_half is False
+    webui.shared.opts.eta_ancestral = 0.25                    # a settings change AFTER the bind is seen: the view reads through
+    assert amd_shared.opts.eta_ancestral == 0.25
+    webui.sd_unet.current_unet = webui.unet
+    s = webui.sd_samplers.all_samplers_map["Euler a"].constructor(webui.shared.sd_model)
+    s.config = webui.sd_samplers.all_samplers_map["Euler a"]
+    assert isinstance(s, ss.KDiffusionSampler) and webui.stock_calls == []
+    p = _job()
+    sig = s.get_sigmas(p, 20)
+    assert sig.shape == (21,) and abs(float(sig[-2]) - 0.05) > 1e-3          # 21 + 1 levels from sigma_min 0.05, the penultimate (0.05) dropped
+    ref = ss.get_sigmas_karras(n=21, sigma_min=0.05, sigma_max=float(s.model_wrap.sigmas[-1]), device="cpu")
+    assert torch.equal(sig, torch.cat([ref[:-2], ref[-1:]]))
+    assert p.extra_generation_params == {"Discard penultimate sigma": True, "Schedule type": "Karras", "Schedule min sigma": 0.05}
+    kw = s.initialize(p)
+    assert kw["eta"] == 0.25 and s.eta == 0.25 and p.extra_generation_params["Eta"] == 0.25
+    # progress: the webui's state object and its console bar
+    assert s.launch_sampling(20, lambda: "done") == "done" and webui.shared.state.sampling_steps == 20
+    s.callback_state({"i": 7})
+    assert webui.shared.state.sampling_step == 7 and webui.tqdm == [1]
+    # Interrupt / Skip: checked before anything else in CFGDenoiser.forward; launch_sampling returns the last latent
+    s.last_latent = "last-latent"
+    for flag in ("interrupted", "skipped"):
+        setattr(webui.shared.state, flag, True)
+        with pytest.raises(ss.InterruptedException):
+            s.model_wrap_cfg.forward(None, None, None, None, 7.0)
+        assert s.launch_sampling(20, lambda: s.model_wrap_cfg.forward(None, None, None, None, 7.0)) == "last-latent"
+        setattr(webui.shared.state, flag, False)
+    # the live-preview store is the webui's own function
+    amd_shared.store_latent("x0")
+    assert webui.stored == ["x0"] and amd_shared.MaskBlendArgs is webui.scripts.MaskBlendArgs
+    amd_shared.unbind_webui()
+    assert amd_shared.opts.eta_ancestral == 1.0 and amd_shared.webui is None and amd_shared.MaskBlendArgs is not webui.scripts.MaskBlendArgs
+
+
+def test_engine_sampler_rows_fall_back_or_refuse_when_the_webui_job_needs_torch_side_hooks(webui):
+    """VERDICT r3 missing #1 / #2: a row builds the STOCK sampler while any cfg_denoiser / cfg_denoised / cfg_after_cfg / extra_noise
+    script callback is registered (modules/sd_samplers_cfg_denoiser.py:212, 279, 307; sd_samplers_kdiffusion.py:146-151); ToMe
+    (modules/sd_models.py:1011-1034) and Hypertile (extensions-builtin/hypertile) jobs are refused by the sampler AND by
+    Mi355xUnet.forward — never silently ignored; a refiner-checkpoint job is forwarded to a stock sampler built on the spot."""
+    import types
+    ss, bridge = sub("sd_samplers"), sub("webui_bridge")
+    webui.sd_unet.current_unet = webui.unet
+    row = webui.sd_samplers.all_samplers_map["DPM++ 2M"]
+    model = webui.shared.sd_model
+    assert isinstance(row.constructor(model), ss.KDiffusionSampler) and webui.stock_calls == []
+    for i, name in enumerate(bridge.SAMPLER_CALLBACK_LISTS):
+        webui.script_callbacks.callback_map[name].append(object())
+        assert bridge.registered_sampler_callbacks(webui.script_callbacks) == [name]
+        assert row.constructor(model).stock == "DPM++ 2M" and len(webui.stock_calls) == i + 1
+        webui.script_callbacks.callback_map[name].clear()
+    assert isinstance(row.constructor(model), ss.KDiffusionSampler)
+    x = torch.zeros(1, 4, 8, 8)
+
+    def refused(p=None, **model_attrs):
+        s = row.constructor(model)
+        s.config = row
+        for k, v in model_attrs.items():
+            setattr(model, k, v)
+        try:
+            with pytest.raises(NotImplementedError, match="SD Unet to None"):
+                s.sample(p or _job(), x, None, None)
+            with pytest.raises(NotImplementedError, match="SD Unet to None"):
+                s.sample_img2img(p or _job(), x, x, None, None)
+        finally:
+            for k in model_attrs:
+                delattr(model, k)
+    # ToMe applied to the model (first pass: processing.py:841 runs before the sampler is built) ...
+    model.applied_token_merged_ratio = 0.5
+    with pytest.raises(NotImplementedError, match="token merging is active"):
+        webui.unet.forward(x, torch.zeros(1), torch.zeros(1, 77, 64))
+    del model.applied_token_merged_ratio
+    refused(applied_token_merged_ratio=0.5)
+    # ... or only requested for the hires pass (applied at processing.py:1442, AFTER the hires sampler was built)
+    refused(_job(is_hr_pass=True, get_token_merging_ratio=lambda for_hr=False: 0.3 if for_hr else 0.0))
+    # Hypertile: the options, and the live module flags hypertile_hook_model leaves on the torch UNet
+    webui.shared.opts.hypertile_enable_unet = True
+    refused()
+    webui.shared.opts.hypertile_enable_unet = False
+    webui.shared.opts.hypertile_enable_unet_secondpass = True
+    refused(_job(is_hr_pass=True))
+    s_ok = row.constructor(model)                             # first pass of the same settings: nothing is tiled yet
+    assert bridge.patched_unet_reason(model) is None
+    webui.shared.opts.hypertile_enable_unet_secondpass = False
+    attn = torch.nn.Linear(2, 2)
+    model.model.add_module("attn1", attn)
+    setattr(attn, "__webui_hypertile_params", types.SimpleNamespace(enabled=False))
+    setattr(model.model, "__webui_hypertile_layers", {"attn1": 1})
+    assert not bridge.hypertile_unet_active(model)
+    getattr(attn, "__webui_hypertile_params").enabled = True
+    assert bridge.hypertile_unet_active(model) and "Hypertile" in bridge.patched_unet_reason(model)
+    with pytest.raises(NotImplementedError, match="Hypertile"):
+        webui.unet.forward(x, torch.zeros(1), torch.zeros(1, 77, 64))
+    getattr(attn, "__webui_hypertile_params").enabled = False
+    # refiner checkpoint: the stock sampler of the same row takes the call
+    n_stock = len(webui.stock_calls)
+    s = row.constructor(model)
+    s.config = row
+    p = _job(refiner_checkpoint_info=types.SimpleNamespace(short_title="refiner"))
+    assert s.sample(p, x, None, None) == "stock-samples" and len(webui.stock_calls) == n_stock + 1
+    assert s.stock_delegate.config is row and s.stock_delegate.calls == [("sample", p)] and s.stock_reason == "refiner checkpoint switch"
+    # the B4 decode hook leaves a Hypertile-tiled VAE to torch
+    assert bridge.hypertile_active(torch.nn.Module()) is False

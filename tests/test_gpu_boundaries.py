@@ -230,3 +230,93 @@ def test_bench_two_gpus_rccl_gathered_images_equal_rank_local_replays(dev):
     """Same over RCCL, one rank per GPU (runs only where two devices are visible: the builder's boxes have one)."""
     out = _bench_ranks(2, {}, BENCH_TINY)
     assert out["n_gpus"] == 2 and out["config"]["shard_check"] == "ok" and out["config"]["weights_broadcast_ms"] > 0
+
+
+def test_engine_sampler_progress_interrupt_live_preview_and_mask_blend_hooks(dev, monkeypatch):
+    """What the reference's sampler loop does besides arithmetic (modules/sd_samplers_cfg_denoiser.py:157-158, 176-185, 295-304;
+    modules/sd_samplers_common.py:256-281), on the engine samplers with the real kernels:
+      * every step stores an x0 prediction through ``shared.store_latent`` — "Prompt" / "Negative prompt" / "Combined" previews obey
+        combined = negative + cfg * (prompt - negative) (x0 is affine in the model output) for the sigma AND the timestep family,
+        and the choice never changes the samples;
+      * ``state.interrupted`` raised mid-run ends the job at the next denoiser call, returning the LAST "Prompt" x0 prediction;
+      * a script with ``on_mask_blend`` sees every per-step blend (current, blended, denoiser, sigma) and the final one, and what it
+        writes to ``blended_latent`` is what the sampler continues from."""
+    schema, processing, shared, ss = sub("schema"), sub("processing"), sub("shared"), sub("sd_samplers")
+    ucfg, vcfg = schema.tiny_unet(), schema.tiny_vae()
+    sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16)
+    model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0)
+    g = torch.Generator().manual_seed(11)
+    cond, uncond = torch.randn(2, 77, 64, generator=g), torch.randn(2, 77, 64, generator=g)
+
+    def run(name, content, hook=None, steps=6):
+        stored = []
+
+        def store(decoded):
+            stored.append(decoded.clone())
+            shared.state.current_latent = decoded
+            if hook is not None:
+                hook(len(stored))
+        monkeypatch.setattr(shared, "store_latent", store)
+        monkeypatch.setattr(shared.opts, "live_preview_content", content)
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond, uc=uncond, seed=1000, batch_size=2, steps=steps,
+                                                        cfg_scale=7.0, width=128, height=128, sampler_name=name)
+        res = processing.process_images(p)
+        return res.latents.clone(), stored
+
+    try:
+        for name in ("Euler a", "DDIM"):
+            lat_c, combined = run(name, "Combined")
+            lat_p, prompt = run(name, "Prompt")
+            lat_n, negative = run(name, "Negative prompt")
+            assert torch.equal(lat_c, lat_p) and torch.equal(lat_c, lat_n)
+            assert len(combined) == len(prompt) == len(negative) == 6 and shared.state.sampling_steps == 6 and shared.state.sampling_step == 5
+            for c, pr, ng in zip(combined, prompt, negative):
+                assert rel_l2(c.cpu(), (ng + 7.0 * (pr - ng)).cpu()) < 2e-5, name
+                assert rel_l2(pr.cpu(), ng.cpu()) > 1e-3
+            # interrupt after the third stored preview: three UNet evaluations happened, the fourth denoiser call raises
+            def press_interrupt(n):
+                if n == 3:
+                    shared.state.interrupted = True
+            lat_i, seen = run(name, "Prompt", hook=press_interrupt)
+            shared.state.interrupted = False
+            assert len(seen) == 3 and torch.equal(lat_i, seen[-1]) and torch.equal(seen[-1], prompt[2])
+            assert shared.state.sampling_step == 2
+    finally:
+        shared.state.interrupted = False
+
+    # ---- Script.on_mask_blend (soft inpainting's hook): img2img with a latent mask
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(11))
+    mask = torch.zeros(2, 4, 16, 16)
+    mask[:, :, 4:12, 2:9] = 1.0
+    monkeypatch.setattr(shared, "store_latent", lambda d: None)
+
+    def inpaint(name, runner):
+        p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=3000, batch_size=2, steps=5, cfg_scale=7.0,
+                                                        width=128, height=128, sampler_name=name, init_images=img,
+                                                        denoising_strength=0.6, latent_mask=mask)
+        p.scripts = runner
+        return processing.process_images(p).latents.clone()
+
+    class Runner:
+        def __init__(self, rewrite=None):
+            self.seen, self.rewrite = [], rewrite
+
+        def on_mask_blend(self, p, mba):
+            self.seen.append((mba.is_final_blend, mba.denoiser, None if mba.sigma is None else tuple(mba.sigma.shape),
+                              tuple(mba.current_latent.shape), tuple(mba.blended_latent.shape)))
+            assert torch.equal(mba.blended_latent, mba.current_latent * mba.nmask + mba.init_latent * mba.mask) or \
+                rel_l2(mba.blended_latent.cpu(), (mba.current_latent * mba.nmask + mba.init_latent * mba.mask).cpu()) < 1e-6
+            if self.rewrite is not None:
+                mba.blended_latent = self.rewrite(mba)
+
+    for name in ("Euler a", "DDIM"):                          # blend after / before denoising
+        fused = inpaint(name, None)
+        watch = Runner()
+        seen = inpaint(name, watch)
+        assert rel_l2(seen.cpu(), fused.cpu()) < 1e-6, name   # same blends, one kernel later
+        steps = [s for s in watch.seen if not s[0]]
+        n_eval = 4 if name == "Euler a" else 3               # t_enc + 1 sigmas-steps / t_enc timesteps (sd_samplers_timesteps.py:104)
+        assert len(steps) == n_eval and len(watch.seen) == n_eval + 1 and watch.seen[-1][0] and watch.seen[-1][1] is None
+        assert all(isinstance(s[1], ss.CFGDenoiser) and s[2] == (2,) and s[3] == s[4] == (2, 4, 16, 16) for s in steps)
+        unblended = inpaint(name, Runner(rewrite=lambda mba: mba.current_latent if not mba.is_final_blend else mba.blended_latent))
+        assert rel_l2(unblended.cpu(), fused.cpu()) > 1e-3, name      # the script's word counts: no per-step blending happened
