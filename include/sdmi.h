@@ -53,6 +53,16 @@ int sdmi_attention(const void* q, const void* k, const void* v, void* out,
                    int ldq, int ldk, int ldv, int ldo, float scale,
                    void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Single-head attention over a wide head: the VAE mid-block AttnBlock (d = C = 512, N = M = h*w) that every in-tree optimizer
+ * also replaces — modules/sd_hijack_optimizations.py:554-610 (cross_attention_attnblock_forward), :613-634 (xformers), :637-655
+ * (sdp), :658-676 (sub-quadratic).  Scores are materialised in fp32 one image at a time (GEMM, row softmax, GEMM: the engine's own
+ * VAE attention).  q / k / v / out [B, N|M, ld*] fp16, D a multiple of 64, row strides multiples of 8 elements. */
+int64_t sdmi_attention_wide_workspace_bytes(int B, int N, int M, int D);
+int sdmi_attention_wide(const void* q, const void* k, const void* v, void* out,
+                        int B, int N, int M, int D,
+                        int ldq, int ldk, int ldv, int ldo, float scale,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Same, with V already transposed by the producer: vt [B, H*D, Mpad] (row = h*D+d, Mpad = vt_ld >= M rounded up to 64,
  * padding columns must be finite).  This is what the engine's UNet uses (its V projection writes V^T directly). */
 int sdmi_attention_vt(const void* q, const void* k, const void* vt, void* out,

@@ -80,6 +80,8 @@ _SIGS = {
     "sdmi_device_ok": (C.c_int, []),
     "sdmi_attention_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "sdmi_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i64, _vp]),
+    "sdmi_attention_wide_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "sdmi_attention_wide": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i64, _vp]),
     "sdmi_attention_vt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sdmi_conv_gemm": (_i, [C.POINTER(ConvDesc), _vp]),
     "sdmi_conv_splitk_workspace_bytes": (_i64, [_i, _i, _i, _i]),

@@ -28,9 +28,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     d = c // heads
     q, k, v = [t if t.stride(-1) == 1 and t.stride(0) == t.shape[1] * t.stride(1) else t.contiguous() for t in (q, k, v)]
     out = torch.empty((b, n, c), dtype=torch.float16, device=q.device)
+    scale = d ** -0.5 if scale is None else scale
+    if heads == 1 and d > 160 and d % 64 == 0:           # the VAE AttnBlock (d = 512): materialised scores, one image at a time
+        ws_bytes = lib.sdmi_attention_wide_workspace_bytes(b, n, m, d)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        check(lib.sdmi_attention_wide(ptr(q), ptr(k), ptr(v), ptr(out), b, n, m, d, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                                      float(scale), ptr(ws), ws_bytes, stream_ptr()), "sdmi_attention_wide")
+        return out
     ws_bytes = lib.sdmi_attention_workspace_bytes(b, heads, m, d)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-    scale = d ** -0.5 if scale is None else scale
     check(lib.sdmi_attention(ptr(q), ptr(k), ptr(v), ptr(out), b, heads, n, m, d, q.stride(1), k.stride(1), v.stride(1),
                              out.stride(1), float(scale), ptr(ws), ws_bytes, stream_ptr()), "sdmi_attention")
     return out

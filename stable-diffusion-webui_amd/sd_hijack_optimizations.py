@@ -41,17 +41,31 @@ def mi355x_attention_forward(self, x, context=None, mask=None, **kwargs):
     h = self.heads
     q_in = self.to_q(x)
     context = x if context is None else context
-    try:
+    try:                                        # standalone (no webui on the path) there are no hypernetworks to apply ...
         from modules import shared as _shared
         from modules.hypernetworks import hypernetwork as _hn
-        context_k, context_v = _hn.apply_hypernetworks(_shared.loaded_hypernetworks, context)
-    except Exception:
+    except ImportError:
         context_k, context_v = context, context
+    else:                                       # ... inside the webui their errors are the user's to see, as with every in-tree optimizer (:227)
+        context_k, context_v = _hn.apply_hypernetworks(_shared.loaded_hypernetworks, context)
     k_in = self.to_k(context_k)
     v_in = self.to_v(context_v)
     dtype = q_in.dtype
     out = ops.attention(q_in.half(), k_in.half(), v_in.half(), heads=h, scale=getattr(self, "scale", None))
     return self.to_out(out.to(dtype))
+
+
+def mi355x_attnblock_forward(self, x):
+    """Drop-in for ldm.modules.diffusionmodules.model.AttnBlock.forward(self, x) — the single-head VAE mid-block attention
+    (N = h*w tokens, d = C = 512) that every in-tree optimizer replaces too (modules/sd_hijack_optimizations.py:554-610, 613-676):
+    norm / q / k / v / proj_out stay torch modules, softmax(q k^T * C^-0.5) v runs in sdmi_attention_wide."""
+    h_ = self.norm(x)
+    q, k, v = self.q(h_), self.k(h_), self.v(h_)
+    b, c, h, w = q.shape
+    tokens = lambda t: t.reshape(b, c, h * w).transpose(1, 2).half().contiguous()
+    out = ops.attention(tokens(q), tokens(k), tokens(v), heads=1, scale=int(c) ** (-0.5))
+    out = out.to(q.dtype).transpose(1, 2).reshape(b, c, h, w)
+    return x + self.proj_out(out)
 
 
 class SdOptimizationMi355x(SdOptimization):
@@ -66,9 +80,13 @@ class SdOptimizationMi355x(SdOptimization):
 
     def apply(self):
         import ldm.modules.attention
+        import ldm.modules.diffusionmodules.model
         ldm.modules.attention.CrossAttention.forward = mi355x_attention_forward
+        ldm.modules.diffusionmodules.model.AttnBlock.forward = mi355x_attnblock_forward      # as :62-63, 76-77 ... of the in-tree rows
         try:
             import sgm.modules.attention
+            import sgm.modules.diffusionmodules.model
             sgm.modules.attention.CrossAttention.forward = mi355x_attention_forward
-        except Exception:
+            sgm.modules.diffusionmodules.model.AttnBlock.forward = mi355x_attnblock_forward
+        except ImportError:
             pass

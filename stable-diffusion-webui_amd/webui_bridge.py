@@ -224,32 +224,58 @@ def install_lora_hook(webui_networks, webui_sd_models, webui_shared, sd_unet_mod
     from . import networks as amd_networks
     stock = getattr(webui_networks.load_networks, "_mi355x_stock", webui_networks.load_networks)
 
+    files = {}                                                # filename -> (mtime, parsed state dict): a job re-activates the same files
+
+    def on_disk(name):
+        """The stock resolution rule (extensions-builtin/Lora/networks.py:303): names that collide with an alias are looked up by
+        file name only, everything else through the alias table."""
+        forbidden = getattr(webui_networks, "forbidden_network_aliases", {})
+        table = webui_networks.available_networks if name.lower() in forbidden else webui_networks.available_network_aliases
+        return table.get(name, None)
+
+    def read(filename):
+        import os
+        try:
+            mtime = os.path.getmtime(filename)
+        except OSError:
+            mtime = None
+        hit = files.get(filename)
+        if hit is None or hit[0] != mtime:
+            hit = files[filename] = (mtime, webui_sd_models.read_state_dict(filename))
+        return hit[1]
+
     def load_networks(names, te_multipliers=None, unet_multipliers=None, dyn_dims=None):
         stock(names, te_multipliers, unet_multipliers, dyn_dims)          # text encoder + loaded_networks bookkeeping as before
         view = engine_model_view(webui_shared.sd_model, sd_unet_module)
         if view is None:
             return
-        sds = []
-        for n in names:
-            on_disk = webui_networks.available_network_aliases.get(n) or webui_networks.available_networks.get(n)
-            if on_disk is None:                               # the stock loader already reported it
-                continue
-            sds.append((n, webui_sd_models.read_state_dict(on_disk.filename)))
+        found = [(n, on_disk(n)) for n in names]
+        found = [(n, d) for n, d in found if d is not None]   # the stock loader already reported the missing ones
         idx = {n: i for i, n in enumerate(names)}
-        pick = lambda xs: None if not xs else [xs[idx[n]] for n, _ in sds]
-        amd_networks.load_networks(view, [n for n, _ in sds], [sd for _, sd in sds], pick(te_multipliers), pick(unet_multipliers), pick(dyn_dims))
+        pick = lambda xs: None if not xs else [xs[idx[n]] for n, _ in found]
+        te, un, dyn = pick(te_multipliers), pick(unet_multipliers), pick(dyn_dims)
+        wanted = tuple((n, d.filename, None if te is None else te[i], None if un is None else un[i], None if dyn is None else dyn[i])
+                       for i, (n, d) in enumerate(found))
+        if getattr(view, "_networks_request", None) == (wanted, getattr(view.engine, "weights_version", 0)) and \
+                all(files.get(d.filename, (None,))[0] == _mtime(d.filename) for _, d in found):
+            return                                            # same files, same multipliers, weights untouched since: nothing to merge
+        for gone in set(files) - {d.filename for _, d in found}:
+            del files[gone]
+        amd_networks.load_networks(view, [n for n, _ in found], [read(d.filename) for _, d in found], te, un, dyn)
+        view._networks_request = (wanted, getattr(view.engine, "weights_version", 0))
     load_networks._mi355x_stock = stock
     webui_networks.load_networks = load_networks
     return load_networks
 
 
 # ---- B6 ---------------------------------------------------------------------------------------------------------------------------
-def install_clip_hook(sd_model, device_index: int = 0):
+def install_clip_hook(sd_model, device_index: int = 0, lora_networks=None):
     """SD 1.x checkpoints (FrozenCLIPEmbedderWithCustomWords over transformers' CLIPTextModel): the CLIP-L tower is packed into an engine
     and ``encode_with_transformers`` of THIS model's embedder is rebound to it.  Token embeddings still come from the webui's
     (textual-inversion patched) embedding layer and enter as ``inputs_embeds``.  Returns the encoder, or None when the checkpoint's text
     encoder is not that class (SD 2.x / SDXL keep the torch towers: their hooks live in sd_hijack_clip.Mi355xClipTextEncoder and are
-    bound the same way once the webui exposes the wrapped towers)."""
+    bound the same way once the webui exposes the wrapped towers).  Prompts with a text-encoder LoRA active are encoded by the torch
+    tower (``text_encoder_networks_active``): the engine tower is packed from the checkpoint weights and never sees those deltas."""
     from . import schema
     from .engine import Engine
     from .sd_hijack_clip import Mi355xClipTextEncoder
@@ -268,10 +294,44 @@ def install_clip_hook(sd_model, device_index: int = 0):
     csm._torch_encode_with_transformers = csm.encode_with_transformers
 
     def encode_with_transformers(tokens):
+        if text_encoder_networks_active(csm, lora_networks):
+            # The Lora extension applies text-encoder deltas lazily, inside the patched torch Linear / MultiheadAttention forwards
+            # (extensions-builtin/Lora/networks.py:411-480, 578-605) — forwards the packed tower never runs.  While a loaded network
+            # touches this text encoder with a non-zero multiplier, the prompt goes through the torch tower, deltas included.
+            return csm._torch_encode_with_transformers(tokens)
         emb = text_model.embeddings.token_embedding(tokens)   # EmbeddingsWithFixes: textual-inversion vectors spliced in
         return enc.encode_with_transformers(tokens, inputs_embeds=emb)
     csm.encode_with_transformers = encode_with_transformers
     return enc
+
+
+def text_encoder_networks_active(cond_stage_model, lora_networks=None) -> bool:
+    """True while ``networks.loaded_networks`` of the built-in Lora extension holds a network with ``te_multiplier != 0`` and at least
+    one module whose ``sd_module`` lives under ``cond_stage_model`` (extensions-builtin/Lora/networks.py:122-147 maps ``lora_te_*`` keys
+    to the text encoder's Linear layers)."""
+    import sys
+    lora_networks = lora_networks if lora_networks is not None else sys.modules.get("networks")
+    loaded = getattr(lora_networks, "loaded_networks", None)
+    if not loaded:
+        return False
+    mine = None
+    for net in loaded:
+        if not getattr(net, "te_multiplier", 0):
+            continue
+        for module in getattr(net, "modules", {}).values():
+            if mine is None:
+                mine = {id(m) for m in cond_stage_model.modules()} if hasattr(cond_stage_model, "modules") else set()
+            if id(getattr(module, "sd_module", None)) in mine:
+                return True
+    return False
+
+
+def _mtime(filename):
+    import os
+    try:
+        return os.path.getmtime(filename)
+    except OSError:
+        return None
 
 
 def uninstall_clip_hook(sd_model):

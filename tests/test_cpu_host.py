@@ -854,17 +854,43 @@ def test_extension_script_registers_samplers_lora_and_clip_hooks_against_stubbed
     lora.load_networks(["myLora"], [0.5], [0.8], [None])
     assert lora_calls == [(("myLora",), [0.5], [0.8], [None])] and reads == ["/models/Lora/myLora.safetensors"]
     assert merged == [(fake_engine, ["myLora"], [0.5], [0.8], [None])]
+    # the same request again (ExtraNetworkLora.activate runs per job): stock bookkeeping, no re-read, no re-merge; new multipliers merge
+    # again from the cached file; a name that collides with an alias resolves by file name only (networks.py:303)
+    lora.load_networks(["myLora"], [0.5], [0.8], [None])
+    assert len(lora_calls) == 2 and len(reads) == 1 and len(merged) == 1
+    lora.load_networks(["myLora"], [0.5], [0.3], [None])
+    assert len(reads) == 1 and merged[-1] == (fake_engine, ["myLora"], [0.5], [0.3], [None])
+    lora.forbidden_network_aliases = {"mylora": 1}
+    lora.load_networks(["myLora"], [0.5], [0.3], [None])
+    assert len(merged) == 3 and merged[-1][1] == []           # not in available_networks under that name: nothing of it is merged
+    del lora.forbidden_network_aliases
     unet_mod.current_unet = None
+    n_calls = len(lora_calls)
     lora.load_networks(["myLora"], [1.0], [1.0], [None])
-    assert len(lora_calls) == 2 and len(merged) == 1          # torch UNet active: the stock path only
+    assert len(lora_calls) == n_calls + 1 and len(merged) == 3          # torch UNet active: the stock path only
     # "Reload UI": a second import wraps the ORIGINAL constructors / loader again, not the wrappers
     mod2 = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod2)
     assert samplers_mod.all_samplers[0].constructor("m2").stock == "Euler a"
+    n_calls = len(lora_calls)
     lora.load_networks(["myLora"])
-    assert len(lora_calls) == 3
+    assert len(lora_calls) == n_calls + 1
     # B6: a model without the transformers CLIP wrapper is left alone
-    assert sub("webui_bridge").install_clip_hook(types.SimpleNamespace(cond_stage_model=None)) is None
+    bridge = sub("webui_bridge")
+    assert bridge.install_clip_hook(types.SimpleNamespace(cond_stage_model=None)) is None
+    # B6 + Lora: a loaded network that touches the text encoder with a non-zero multiplier sends prompts through the torch tower
+    # (the packed tower never runs the patched Linear forwards that apply those deltas)
+    csm = torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.Linear(2, 2))
+    te_mod, unet_mod_ = types.SimpleNamespace(sd_module=csm[1]), types.SimpleNamespace(sd_module=torch.nn.Linear(2, 2))
+    net = types.SimpleNamespace(te_multiplier=0.7, modules={"lora_te_x": te_mod, "lora_unet_y": unet_mod_})
+    lora.loaded_networks = []
+    assert not bridge.text_encoder_networks_active(csm, lora)
+    lora.loaded_networks = [types.SimpleNamespace(te_multiplier=1.0, modules={"lora_unet_y": unet_mod_})]
+    assert not bridge.text_encoder_networks_active(csm, lora)           # UNet-only network
+    lora.loaded_networks.append(net)
+    assert bridge.text_encoder_networks_active(csm, lora) and bridge.text_encoder_networks_active(csm)      # (resolved from sys.modules)
+    net.te_multiplier = 0
+    assert not bridge.text_encoder_networks_active(csm, lora)
 
 
 def test_hypernetwork_file_is_loaded_without_unpickling_arbitrary_objects(tmp_path):

@@ -379,7 +379,7 @@ def test_c1_euler_a_20_steps_512_final_latent_vs_oracle(dev, sd15, golden_dir):
 
     class P:
         steps, cfg_scale, eta, scheduler, is_hr_pass = 20, 7.0, None, None, False
-        sampler_noise_scheduler_override = None
+        sampler_noise_scheduler_override, extra_generation_params = None, {}
         rng = sub("rng").ImageRNG((4, 64, 64), [1000], device=dev)
     p = P()
     got = sampler.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev)).cpu()

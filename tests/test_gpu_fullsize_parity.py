@@ -195,7 +195,7 @@ def test_c2_dpmpp_2m_karras_50_steps_final_latent(dev, golden_dir):
 
     class P:
         steps, cfg_scale, eta, scheduler, is_hr_pass = s["steps"], s["cfg"], None, None, False      # Automatic = the sampler's own: karras
-        sampler_noise_scheduler_override = None
+        sampler_noise_scheduler_override, extra_generation_params = None, {}
         rng = sub("rng").ImageRNG((4, 64, 64), [s["seed"]], device=dev)
     p = P()
     got = sampler.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev)).cpu()

@@ -984,7 +984,7 @@ def test_c0_shape_sd15_256px_b1_euler_a_5_steps(dev):
 
     class P:
         steps, cfg_scale, eta, scheduler, is_hr_pass = 5, 7.0, None, None, False
-        sampler_noise_scheduler_override = None
+        sampler_noise_scheduler_override, extra_generation_params = None, {}
         rng = sub("rng").ImageRNG((4, 32, 32), [1000], device=dev)
     p = P()
     got = sampler.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev))
