@@ -530,11 +530,13 @@ def main():
     for _ in range(args.warmup):
         run_once()
     torch.cuda.synchronize(); par.barrier()
+    coll0 = par.COLLECTIVES["job"]
     t0 = time.time()
     for _ in range(args.steps):
         run_once()
     torch.cuda.synchronize(); par.barrier()
     elapsed = par.max_over_ranks(time.time() - t0, device=torch.device("cuda", local_rank))
+    collectives_per_job = (par.COLLECTIVES["job"] - coll0) / max(args.steps, 1)      # data-path collectives inside the timed region
 
     shard_check = None
     if args.verify_shards and world > 1:
@@ -589,9 +591,10 @@ def main():
                                f"{args.sampler_steps}-step {args.sampler}{' Karras' if args.scheduler == 'karras' else ''}, batch {args.batch} per GPU, cfg 7.0, "
                                f"fp16 weights/activations, fp32 accumulate + fp32 sampler state, Philox (NV) noise, VAE decode to uint8 included",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "sharding": "process_images_sharded: contiguous image ranges, seeds 1000 + global index, uint8 gather to rank 0 per job",
+                   "sharding": "process_images_sharded: contiguous image ranges, seeds 1000 + global index, one uint8 gather to rank 0 per job straight from the device buffer",
                    "weights": "synthetic N(0,1/fan_in) in the checkpoint's state-dict schema (seed 0x5D15)",
                    "weights_broadcast_ms": round(t_bcast * 1e3, 1), "weights_generate_s": round(t_gen, 1),
+                   "weights_collectives": par.COLLECTIVES["weights"], "collectives_per_job": collectives_per_job,
                    "shard_check": shard_check,
                    "algorithmic_tflop_per_image": tflop_per_image,
                    "dropin_images_per_s": dropin,

@@ -50,26 +50,35 @@ def _pad_to(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+COLLECTIVES = {"weights": 0, "job": 0}                       # calls issued by this process (bench.py prints them per job)
+
+
+def blob_algorithm(backend: str, nbytes: int, requested: str = "scatter_allgather") -> str:
+    """Which collective carries a weight blob — decided UP FRONT from the backend and the size, identically on every rank (never by
+    catching an exception on some ranks, which would leave the others inside a different collective): scatter + all-gather where the
+    backend has ``scatter`` (nccl = RCCL, gloo), a plain broadcast elsewhere, for small blobs, or on request."""
+    if requested == "broadcast" or nbytes < (1 << 20) or backend not in ("nccl", "gloo"):
+        return "broadcast"
+    return "scatter_allgather"
+
+
 def broadcast_blob(blob: torch.Tensor, src: int = 0, algo: str = "scatter_allgather") -> torch.Tensor:
     """Broadcast a flat uint8 tensor (same length on every rank; contents valid on ``src``)."""
     world = dist.get_world_size()
     if world == 1:
         return blob
     n = blob.numel()
-    if algo == "broadcast" or n < (1 << 20):
+    if blob_algorithm(dist.get_backend(), n, algo) == "broadcast":
         dist.broadcast(blob, src=src)
+        COLLECTIVES["weights"] += 1
         return blob
     assert n % world == 0, "pad the blob to a multiple of the world size"
     shard = n // world
     views = list(blob.view(world, shard).unbind(0))
     mine = torch.empty(shard, dtype=blob.dtype, device=blob.device)
-    try:
-        dist.scatter(mine, scatter_list=[v.contiguous() for v in views] if dist.get_rank() == src else None, src=src)
-        dist.all_gather(views, mine)      # each rank pulls the other W-1 shards from their owners (all links busy)
-    except (RuntimeError, NotImplementedError, ValueError) as e:      # a backend without scatter: correctness first
-        if dist.get_rank() == src:
-            print(f"[parallel] scatter + all-gather unavailable ({type(e).__name__}: {e}); falling back to broadcast", flush=True)
-        dist.broadcast(blob, src=src)
+    dist.scatter(mine, scatter_list=[v.contiguous() for v in views] if dist.get_rank() == src else None, src=src)
+    dist.all_gather(views, mine)          # each rank pulls the other W-1 shards from their owners (all links busy)
+    COLLECTIVES["weights"] += 2
     return blob
 
 
@@ -120,6 +129,7 @@ def gather_to_rank0(t: torch.Tensor, counts: List[int]) -> Optional[torch.Tensor
     else:
         bufs = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad)
+    COLLECTIVES["job"] += 1
     if rank != 0:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)])
@@ -200,6 +210,8 @@ def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Op
         rank = dist.get_rank() if dist.is_initialized() else 0
     q, lo, hi, all_seeds = shard_job(p, world, rank)
     n_total = p.batch_size * p.n_iter
+    if not explicit and world > 1 and gather and rank != 0 and dist.get_backend() == "nccl":
+        q.images_to_host = False                              # these images leave the GPU through the gather only
     if hi > lo:
         if q.n_iter * q.batch_size != hi - lo:                # ragged tail: full batches first, then the remainder as its own job
             full = (hi - lo) // q.batch_size * q.batch_size
@@ -212,6 +224,8 @@ def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Op
                 res.images = list(res.images) + list(extra.images)
                 if res.latents is not None and extra.latents is not None:
                     res.latents = torch.cat([res.latents, extra.latents])
+                both = res.images_device is not None and extra.images_device is not None
+                res.images_device = torch.cat([res.images_device, extra.images_device]) if both else None
                 for f in ("all_seeds", "all_subseeds"):
                     if isinstance(getattr(res, f, None), list) and isinstance(getattr(extra, f, None), list):
                         setattr(res, f, getattr(res, f) + getattr(extra, f))
@@ -223,16 +237,24 @@ def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Op
     if explicit or world == 1 or not gather:
         return res
     counts = [shard_range(n_total, world, r)[1] - shard_range(n_total, world, r)[0] for r in range(world)]
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    # the size of the job's FINAL images (a hires job's are not p.height x p.width) comes from rank 0, which owns at least as many
-    # images as any other rank: a rank with no images still has to offer a buffer of the right shape to the gather
-    hw = torch.tensor(list(res.images[0].shape[:2]) if res.images else [0, 0], dtype=torch.int64, device=dev)
-    dist.broadcast(hw, src=0)
-    if res.images:
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    dev_images = getattr(res, "images_device", None)          # what sdmi_image_to_u8 wrote, still on the GPU (process_images keeps it)
+    if on_gpu and dev_images is not None and dev_images.shape[0] == hi - lo:
+        mine = dev_images                                     # RCCL gathers straight from that buffer: no host bounce on the way out
+    elif res.images:
         mine = torch.from_numpy(np.stack(res.images)).to(dev)
     else:
-        mine = torch.zeros((0, int(hw[0]), int(hw[1]), 3), dtype=torch.uint8, device=dev)
+        # a rank WITHOUT images (fewer images than ranks) does not know the size of the job's final images (a hires job's are not
+        # p.height x p.width): rank 0, which owns at least as many images as any other rank, tells it.  ``counts`` is the same list on
+        # every rank, so all of them take this branch or none does; a job with an image on every rank needs no such exchange.
+        mine = None
+    if min(counts) == 0:
+        hw = torch.tensor(list(res.images[0].shape[:2]) if res.images else [0, 0], dtype=torch.int64, device=dev)
+        dist.broadcast(hw, src=0)
+        COLLECTIVES["job"] += 1
+        if mine is None:
+            mine = torch.zeros((0, int(hw[0]), int(hw[1]), 3), dtype=torch.uint8, device=dev)
     allv = gather_to_rank0(mine, counts)
     if dist.get_rank() == 0:
         res.images = list(allv.cpu().numpy())

@@ -459,8 +459,10 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
 class Processed:
     """modules/processing.py:516-613 (fields the callers on this path read)."""
 
-    def __init__(self, p, images_list, seed=-1, all_seeds=None, latents=None):
+    def __init__(self, p, images_list, seed=-1, all_seeds=None, latents=None, images_device=None):
         self.images = images_list
+        self.images_device = images_device                   # [n, H, W, 3] uint8 on the GPU: the same images before the host copy (None
+                                                             # when a host-side overlay was composited over them) — parallel.py gathers from it
         self.seed = seed
         self.all_seeds = all_seeds or [seed]
         self.width, self.height = p.width, p.height
@@ -518,7 +520,7 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
             m.engine.set_option("tiling", 1 if p.tiling else 0)      # of the UNet and the VAE wraps around (sd_hijack.py:311-318)
     sd_models.apply_alpha_schedule_override(p.sd_model, p)           # :930
     p.init(None, p.all_seeds, None)
-    images, latents = [], []
+    images, latents, device_u8 = [], [], []
     dev = p.sd_model.device
     for n in range(p.n_iter):
         p.iteration = n
@@ -542,8 +544,11 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
         decode_model = p.sampler.sd_model if getattr(p, "sampler", None) is not None else p.sd_model
         x_samples = decode_latent_batch(decode_model, samples, check_for_nans=True)             # :1002 (hires: decoded inside sample_hr_pass, :1459)
         u8 = ops.image_to_u8(x_samples)                                                           # :1004-1005, 1034-1035
-        batch_u8 = list(u8.cpu().numpy())
+        device_u8.append(u8)
         overlays = getattr(p, "overlay_images", None)
+        if not overlays and not getattr(p, "images_to_host", True):   # a non-zero rank of a sharded job: rank 0 gets them over RCCL
+            continue
+        batch_u8 = list(u8.cpu().numpy())
         if overlays:                                                 # :1063-1068, 1086: paste the generated crop back, composite the unmasked original over it
             from PIL import Image
             from . import masking
@@ -555,4 +560,6 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
             latents.append(samples)
     p.close()
     shared.sd_model = p.sd_model                                     # :941 reload_model_weights(): back from a refiner
-    return Processed(p, images, seed, p.all_seeds, torch.cat(latents) if latents else None)
+    same_size = len({tuple(t.shape[1:]) for t in device_u8}) == 1 and not getattr(p, "overlay_images", None)
+    return Processed(p, images, seed, p.all_seeds, torch.cat(latents) if latents else None,
+                     images_device=(device_u8[0] if len(device_u8) == 1 else torch.cat(device_u8)) if same_size else None)

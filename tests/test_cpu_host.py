@@ -508,15 +508,19 @@ SHARD_WORKER = textwrap.dedent("""
         c = torch.arange(n, dtype=torch.float32)[:, None, None].repeat(1, 3, 2)
         return processing.StableDiffusionProcessingTxt2Img(sd_model=None, c=c, uc=c * 2 + 1, seed=4242, batch_size=bs, n_iter=n_iter,
                                                            steps=2, width=8, height=8, sampler_name="Euler a", enable_hr=hr)
-    # hires job with fewer images than ranks: the empty rank's gather buffer must have the FINAL image size
+    # hires job with fewer images than ranks: the empty rank's gather buffer must have the FINAL image size — the one case that costs
+    # a second collective (the size from rank 0); a job with an image on every rank is ONE gather and nothing else
     res = par.process_images_sharded(job(1, 1, hr=True), runner=fake_runner)
+    assert par.COLLECTIVES["job"] == 2
     if rank == 0:
         assert len(res.images) == 1 and res.images[0].shape == (16, 16, 3)
     for bs, n_iter in ((2, 2), (2, 3), (1, 1), (4, 1)):
         calls.clear()
         whole = fake_runner(job(bs, n_iter))
         calls.clear()
+        before = par.COLLECTIVES["job"]
         res = par.process_images_sharded(job(bs, n_iter), runner=fake_runner)
+        assert par.COLLECTIVES["job"] - before == (1 if bs * n_iter >= world else 2), (bs, n_iter)
         lo, hi = par.shard_range(bs * n_iter, world, rank)
         assert sum(calls) == hi - lo and all(c <= bs for c in calls), (calls, lo, hi)
         if rank == 0:
@@ -558,6 +562,17 @@ def _run_world2(script):
         if "AssertionError" in last:                          # a real mismatch, not a rendezvous problem
             break
     raise AssertionError(last)
+
+
+def test_weight_blob_collective_is_chosen_up_front_from_the_backend():
+    """broadcast_blob must not pick its fallback by catching an exception on some ranks.  The choice is a pure function of
+    (backend, size, request), evaluated identically on every rank."""
+    par = sub("parallel")
+    assert par.blob_algorithm("nccl", 2 << 30) == "scatter_allgather" and par.blob_algorithm("gloo", 2 << 20) == "scatter_allgather"
+    assert par.blob_algorithm("mpi", 2 << 30) == "broadcast" and par.blob_algorithm("ucc", 2 << 30) == "broadcast"
+    assert par.blob_algorithm("nccl", 1000) == "broadcast" and par.blob_algorithm("nccl", 2 << 30, "broadcast") == "broadcast"
+    import inspect
+    assert "except" not in inspect.getsource(par.broadcast_blob)
 
 
 def test_process_images_sharded_world_size_2_gloo(tmp_path):
