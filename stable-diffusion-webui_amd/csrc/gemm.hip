@@ -1257,6 +1257,289 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Row-shared ping-pong kernel for the stride-1 3x3 convolutions (GemmP::korder == 2, "dx" K order; round 4).
+//
+// The three taps of one kernel row (dy; dx = 0, 1, 2) read the SAME input rows shifted by one pixel.  When a tile consists of whole
+// image rows (BM % W == 0: 4 rows of 64, 4 of 32, 8 of 16 ...) the shifted pixel of every GEMM row but the image-border ones is
+// another row of the same LDS tile, so the activation tile is staged ONCE per (dy, 64-channel block) — at dx = 1, i.e. unshifted —
+// and the dx = 0 / 2 K tiles read their MFMA fragments one LDS row up / down.  Every image row of the tile sits between two zeroed
+// GUARD rows in LDS (pixel row r of the tile lives in LDS row r + r / W + 1; the guards are written once, the staging never touches
+// them), so the lanes that read across the left / right image border (lane 0 of an x = 0 fragment, lane 15 of an x = W - 16
+// fragment) get their zero padding from the same ds_read, without a select.  The XOR swizzle is a function of the PIXEL row, so the
+// shifted reads stay conflict-free (16 consecutive rows whatever the offset) and the staging side is the tap-major kernel's.
+// K order: dy outer, channel block, dx inner; weights stay [N][tap][Cin].  Against the tap-major kernel above this removes two
+// thirds of the activation global_load_lds traffic (72 -> 50.7 KB per K tile on the 256x320 tile), two thirds of the A issue
+// slots, and the gather rebuild runs 3 times per source instead of 9; the weight pipeline (B of tile T+2 refilled in L(1) / L(2) of
+// tile T) is unchanged.  The fp32 summation order differs from the tap-major order: results agree to accumulation rounding, not
+// bitwise (tests/test_gpu_ops.py).
+//
+// Schedule per group g of 3 K tiles (s = 0, 1, 2 = dx), loads per thread in brackets, A buffer g & 1, B buffer T & 1:
+//     s = 0 : L(0) A units 0, 1 of group g+1 [2] | L(1) B half 0 of T+2 [NB0] | L(2) B half 1 of T+2 [NB1] | L(3) A units 2, 3 of g+1 [2]
+//                                                                                                       | L(last) wait <= BU + 4
+//     s = 1 : L(1), L(2) B of T+2                                                                       | L(last) wait <= BU + 2
+//     s = 2 : L(1), L(2) B of T+2                                                                       | L(last) wait <= BU
+// (PH = 2 tiles: one A unit per slot, B in L(1); waits BU + 2 / BU + 1 / BU.)  The wait of tile T leaves only loads younger than B of
+// tile T+1 outstanding (in issue order the second A pair follows B of tile 3g+2, so the s = 1 wait may leave it in flight); the s = 2
+// wait covers all of group g+1's activations, issued two K tiles earlier: the buffer they land in was read last by group g-1.  RAW / WAR as in
+// the tap-major kernel: counted wait, then the barrier that closes the L section; a buffer is refilled only after the L section
+// that read it last was closed by lgkmcnt(0) + barrier on both wave groups.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool STATS = false>
+__global__ __launch_bounds__(512) void gemm_mfma_pingpong_dx_kernel(GemmP p) {
+    if (p.gate && *p.gate == 0) return;
+    constexpr int WC = 4, ROWB = 128;
+    constexpr int WTM = BM / 2, WTN = BN / WC, TM = WTM / 16, TN = WTN / 16;
+    constexpr int RP = 32, TMP = 2;
+    constexpr int PH = WTM / RP;
+    static_assert(PH == 4 || PH == 2, "BM must be 256 or 128");
+    constexpr int BU = BN / 64, NB0 = BU / 2, NB1 = BU - NB0;
+    constexpr int NA = PH == 4 ? 4 : 2;                      // activation loads per thread and group
+    constexpr int A_ROWS = BM + BM / 16 + 1;                 // pixel rows + one guard row per image row (W >= 16) + the leading guard
+    constexpr int A_BYTES = A_ROWS * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    static_assert(BN % 64 == 0 && WTN % 16 == 0 && BU + NA < 64 && TM <= 8, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+
+    const int tiles_n = p.N / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, sub = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sub;
+    }
+    int tile_m, tile_n;
+    if (p.tile_order) {
+        const int tiles_m = (p.M + BM - 1) / BM;
+        tile_n = bid / tiles_m; tile_m = bid - tile_n * tiles_m;
+    } else {
+        tile_m = bid / tiles_n; tile_n = bid - tile_m * tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const long z = blockIdx.z;
+    const half_t* a0 = p.a0 + z * p.a_bs;
+    const half_t* a1 = p.a1 ? p.a1 + z * p.a_bs : nullptr;
+    const half_t* wbase = p.w + z * p.w_bs;
+
+    // staging roles: as in gemm_mfma_pingpong_kernel
+    const int ch = tid & 7;
+    const int a_rin = (wave & 3) * 8 + (lane >> 3);
+    const int b_row = tid >> 3;
+    const int src_chunk = (ch ^ (lane >> 3)) * 8;
+    int* rinfo = reinterpret_cast<int*>(smem + 2 * STAGE) + tid;        // [q * 512]
+    const half_t* rptr[PH];
+#pragma unroll
+    for (int q = 0; q < PH; ++q) {
+        const int m = m0 + wr * WTM + q * RP + a_rin;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / p.rows_per_batch;
+        const int rem = mm - b * p.rows_per_batch;
+        const int yo = rem / p.Wo;
+        const int xo = rem - yo * p.Wo;
+        rinfo[q * 512] = (b << 24) | (((ok ? yo - 1 : -2048) & 0xfff) << 12) | (xo & 0xfff);     // window origin row, the pixel's own column
+        rptr[q] = p.zero;
+    }
+    {   // guard rows of both activation buffers: LDS rows k * (W + 1), k = 0 .. BM / W
+        const int ngr = BM / p.Wo + 1, k = tid >> 3;
+        if (k < 2 * ngr) {
+            const int sb = k >= ngr ? 1 : 0, kk = k - sb * ngr;
+            *reinterpret_cast<uint4*>(smem + sb * STAGE + kk * (p.Wo + 1) * ROWB + (tid & 7) * 16) = uint4{0u, 0u, 0u, 0u};
+        }
+    }
+    const int img_pix = p.Hi * p.Wi;
+    const int chunk8 = ((tid & 7) ^ (lane >> 3)) * 8;
+    // LDS row of the first of the 8 pixel rows this wave stages in unit q (8 aligned rows never straddle an image row), and the
+    // guard rows in front of each of the wave's TM fragment tiles, 8 bits per tile
+    int a_lds[PH];
+    unsigned long long gpack = 0;
+#pragma unroll
+    for (int q = 0; q < PH; ++q) {
+        const int r0 = wr * WTM + q * RP + (wave & 3) * 8;
+        a_lds[q] = (r0 + r0 / p.Wo + 1) * ROWB;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) gpack |= (unsigned long long)((wr * WTM + i * 16) / p.Wo + 1) << (8 * i);
+    const int b_lds = A_BYTES + wave * 8 * ROWB;
+    const half_t* b_src = wbase + (long)(n0 + b_row) * p.ldw + src_chunk;
+    const long b_piece = 64L * p.ldw;
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    int nk = p.K / 64;
+    int k_first = 0;
+    if (p.splitk > 1) {
+        k_first = blockIdx.y * p.splitk_steps;               // a multiple of 3 (launch_gemm)
+        nk = min(nk - k_first, p.splitk_steps);
+    }
+    const int ng = nk / 3;
+    // K position of the weight tile T+2 (dy2, cb2, dx2) and of the NEXT group's activations (dyA, cbA)
+    int dy2, cb2, dx2 = 0, dyA, cbA;
+    {
+        const int cpb = p.cin >> 6, g0 = k_first / 3;
+        dy2 = g0 / cpb;
+        cb2 = (g0 - dy2 * cpb) << 6;
+        dyA = dy2; cbA = cb2;
+    }
+    auto advance_b = [&]() {
+        if (++dx2 == 3) { dx2 = 0; cb2 += 64; if (cb2 >= p.cin) { cb2 = 0; ++dy2; } }
+    };
+    auto advance_a = [&]() {
+        cbA += 64;
+        if (cbA >= p.cin) { cbA = 0; ++dyA; }
+    };
+    // A units [q0, q0+nq) of group (dy, cbase) into A buffer sb (the tap-major kernel's gather at dx = 1: the pixel's own column)
+    auto issue_a = [&](int q0, int nq, int dy, int cbase, int sb, bool force) {
+        char* base = smem + sb * STAGE;
+        const bool first = cbase < p.c0;
+        const int seg0 = first ? 0 : p.c0;
+        if (force || cbase == seg0) {                        // block-uniform: the group opens a new (dy, source) segment
+            const half_t* src = first ? a0 : a1;
+            const int lda = first ? p.lda0 : p.lda1;
+#pragma unroll
+            for (int q = q0; q < q0 + nq; ++q) {
+                const int ri = rinfo[q * 512];
+                const int yr = ((ri << 8) >> 20) + dy, xr = ri & 0xfff;
+                const bool ok = (unsigned)yr < (unsigned)p.Hi;            // rows past M carry yb = -2048
+                const int pix = (ri >> 24) * img_pix + yr * p.Wi + xr;
+                rptr[q] = (ok ? src + (long)pix * lda : p.zero) + chunk8;
+            }
+        }
+        const int coff = cbase - seg0;
+#pragma unroll
+        for (int q = q0; q < q0 + nq; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(rptr[q] + coff), (lptr_t)(base + a_lds[q]), 16, 0, 0);
+    };
+    auto issue_b = [&](int i0, int n, int sb) {              // B pieces [i0, i0+n) of the K tile at (dy2, cb2, dx2)
+        char* base = smem + sb * STAGE + b_lds;
+        const half_t* bt = b_src + (long)(dy2 * 3 + dx2) * p.cin + cb2;
+#pragma unroll
+        for (int i = i0; i < i0 + n; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(bt + i * b_piece), (lptr_t)(base + i * 64 * ROWB), 16, 0, 0);
+    };
+
+    const int lr = lane & 15, lk = lane >> 4;
+    const int sw0 = (lk ^ (lr & 7)) << 4, sw1 = ((4 + lk) ^ (lr & 7)) << 4;
+    const int b_rd = A_BYTES + (wc * WTN + lr) * ROWB;
+    h8 bf[2][TN], af[2][TMP];
+    auto read_b = [&](const char* sbuf) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf[0][j] = *reinterpret_cast<const h8*>(sbuf + b_rd + j * 16 * ROWB + sw0);
+            bf[1][j] = *reinterpret_cast<const h8*>(sbuf + b_rd + j * 16 * ROWB + sw1);
+        }
+    };
+
+    // ---- prologue: weights of tiles 0 and 1, activations of group 0 ---------------------------------------------------
+    issue_b(0, NB0, 0);
+    issue_b(NB0, NB1, 0);
+    issue_a(0, PH / 2, dyA, cbA, 0, true);
+    issue_a(PH / 2, PH / 2, dyA, cbA, 0, true);
+    advance_b();
+    advance_a();
+    if (nk > 1) {
+        issue_b(0, NB0, 1);
+        issue_b(NB0, NB1, 1);
+        wait_vmcnt<BU>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    advance_b();                                             // (dy2, cb2, dx2) = tile 2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the guard rows are written
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) {                                           // group 1 runs one barrier behind group 0 from here on
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // dx (the tile's kernel column) and `more` (another group follows this one) are wave-uniform RUNTIME values: the three tiles of a
+    // group differ in a few scalar branches only.  (Unrolled by 3 with dx a compile-time constant the loop body triples and the
+    // register allocator spills ~200 VGPRs on the 256x320 tile.)
+    int dx = 0, ga = 0;
+    bool more = ng > 1;
+#pragma nounroll
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("" : "+s"(dx));                         // opaque: no unroll-by-3 / jump threading through the dx cycle (28 loop clones, spills)
+        const int cur = t & 1;
+        const char* sbufB = smem + cur * STAGE;
+        const bool last_tile = t + 1 == nk;
+        const bool issue_bt = dx == 0 || more;               // the weight tile t + 2 exists
+        const bool issue_at = dx == 0 && more;               // this tile carries the next group's activation loads
+        // lane part of the fragment addresses: pixel row (lr + dx - 1) of a 16-row tile, swizzled by the pixel row
+        const int rs = lr + dx - 1;
+        const int ao0 = (wr * WTM + rs) * ROWB + ((lk ^ (rs & 7)) << 4) + ga * STAGE;
+        const int ao1 = (wr * WTM + rs) * ROWB + (((4 + lk) ^ (rs & 7)) << 4) + ga * STAGE;
+#pragma unroll
+        for (int ph = 0; ph < PH; ++ph) {
+            // ================= L section =================
+            if (ph == 0) read_b(sbufB);
+#pragma unroll
+            for (int i = 0; i < TMP; ++i) {
+                const int ti = ph * TMP + i;
+                const int gu = (int)((gpack >> (8 * ti)) & 0xffu) * ROWB;       // wave-uniform: the guard rows in front of this tile
+                af[0][i] = *reinterpret_cast<const h8*>(smem + (gu + ao0) + ti * 16 * ROWB);
+                af[1][i] = *reinterpret_cast<const h8*>(smem + (gu + ao1) + ti * 16 * ROWB);
+            }
+            if (PH == 4) {
+                if (ph == 0) { if (issue_at) issue_a(0, 2, dyA, cbA, ga ^ 1, false); }
+                else if (ph == 1) { if (issue_bt) issue_b(0, NB0, cur); }
+                else if (ph == 2) { if (issue_bt) issue_b(NB0, NB1, cur); }
+                else { if (issue_at) issue_a(2, 2, dyA, cbA, ga ^ 1, false); }
+            } else {
+                if (ph == 0) { if (issue_at) issue_a(0, 1, dyA, cbA, ga ^ 1, false); }
+                else {
+                    if (issue_bt) issue_b(0, BU, cur);
+                    if (issue_at) issue_a(1, 1, dyA, cbA, ga ^ 1, false);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ph == PH - 1) {                              // the weight tile t + 1 has landed; what may still fly is younger (header)
+                if (issue_at) wait_vmcnt<BU + NA>();
+                else if (dx == 1 && more) wait_vmcnt<BU + NA / 2>();
+                else if (issue_bt) wait_vmcnt<BU>();
+                else wait_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= M section =================
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TMP; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[ph * TMP + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j], af[ks][i], acc[ph * TMP + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ph == PH - 1 && wr == 1 && last_tile)) {   // group 1's very last barrier would have no partner
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        advance_b();
+        if (++dx == 3) {
+            dx = 0;
+            advance_a();
+            ga ^= 1;
+            more = t + 4 < nk;                               // the group that starts at tile t + 1 has a successor
+        }
+    }
+    gemm_epilogue<TM, TN, WTM, WTN, false, false, 2, BN, STATS, 0>(p, acc, m0, n0, wr, wc, lane, z, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Generic kernel: one thread per output element, same addressing rules, no shape restrictions beyond Cin % 8 == 0.
 // Used for shapes the MFMA kernel does not cover and as the independent HIP cross-check in the parity tests.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1439,11 +1722,27 @@ static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
+template <int BM, int BN>
+static int launch_pingpong_dx(const GemmP& p, int batch, hipStream_t s) {
+    constexpr int SMEM = 2 * (BM + BM / 16 + 1 + BN) * 128 + 8192;  // tile buffers (activations with guard rows) + packed gather words
+    const bool stats = p.stats_nchunk > 0;
+    auto kern = stats ? gemm_mfma_pingpong_dx_kernel<BM, BN, true> : gemm_mfma_pingpong_dx_kernel<BM, BN, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[stats]) {
+        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set[stats] = true;
+    }
+    const int tiles = cdiv(p.M, BM) * (p.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(512), SMEM, s, p);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 unsigned long long g_gemm_dbg = 0;
 int g_gemm_dbgflags = 0;
 
 template <int BM, int BN>
 static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
+    if (p.korder == 2) return launch_pingpong_dx<BM, BN>(p, batch, s);     // row-shared 3x3 walk (launch_gemm admitted the shape)
     // tuning: instrumented instantiation — never for a launch that promised GroupNorm / LayerNorm partial sums to its consumer (the
     // instrumented kernel has no such epilogue: the consumer would normalise with sums that were never written)
     if (g_gemm_dbg && !(p.flags & EP_GEGLU) && p.stats_nchunk == 0 && p.lnp_np == 0 && !(p.flags & EP_LNFOLD)) {
@@ -1686,7 +1985,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     p.flags |= g_gemm_dbgflags;
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     if (p.bias_scale == 0.f) p.bias_scale = 1.f;
-    p.korder = (p.taps == 9 && g_conv_korder && !p.up && !(p.flags & EP_WRAP)) ? 1 : 0;     // (the ping-pong kernel's KORD form has no upsample / wrap addressing)
+    p.korder = (p.taps == 9 && g_conv_korder == 1 && !p.up && !(p.flags & EP_WRAP)) ? 1 : 0;     // (the ping-pong kernel's KORD form has no upsample / wrap addressing)
     p.zero = zero_page();
     SDMI_REQUIRE(p.zero != nullptr, "zero page allocation failed");
     SDMI_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
@@ -1730,9 +2029,16 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
                        ((p.taps == 1 && p.stride == 1 && !p.up && p.Ho == p.Hi && p.Wo == p.Wi) ||
                         (p.M / p.rows_per_batch < 128 && (p.up ? 2 : 1) * p.Hi < 2040 && (p.up ? 2 : 1) * p.Wi < 2040 &&
                          p.stride * p.Ho < 2040 && p.stride * p.Wo < 2040));
+    // Row-shared 3x3 walk (g_conv_korder == 2, gemm_mfma_pingpong_dx_kernel): stride-1 "same" convs on the ping-pong tiles whose BM rows
+    // are whole image rows (then the dx = 0 / 2 taps are LDS-row shifts of the staged dx = 1 tile).  Everything else keeps the tap-major walk.
+    const bool dxwalk = g_conv_korder == 2 && phase && p.taps == 9 && p.stride == 1 && p.pad == 1 && !p.up &&
+                        !(p.flags & (EP_WRAP | EP_GEGLU | EP_TRANSPOSE | EP_LNFOLD)) && p.Ho == p.Hi && p.Wo == p.Wi && p.Wo % 16 == 0 &&
+                        kCfgBM[cfg] % p.Wo == 0 && p.Wi < 2040 && p.Hi < 2040 && !p.lnp_out && !(g_gemm_dbg && p.stats_nchunk == 0);
+    if (dxwalk) p.korder = 2;
     if (split > 1) {
         const int nk = p.K / (cfg == CFG_128x128_K32 ? 32 : 64);
         p.splitk_steps = cdiv(nk, split);
+        if (dxwalk) p.splitk_steps = cdiv(p.splitk_steps, 3) * 3;       // a slice is a whole number of (dy, channel block) groups
         p.splitk = cdiv(nk, p.splitk_steps);
         if (p.splitk <= 1) { p.splitk = 0; split = 1; }
     } else {
@@ -1774,7 +2080,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     std::string pname;
     if (prof_enabled()) {
         pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
-                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
+                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + (p.korder == 2 ? "_dx" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 ((p.flags & EP_LNFOLD) ? " ln" : "") + (batch > 1 ? " x" + std::to_string(batch) : "");
     }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);

@@ -137,6 +137,22 @@ def main():
             for g_, a in sorted(groups.items(), key=lambda t: -t[1][0]):
                 print(f"    {g_:24s} {a[0]:8.2f} ms  n={a[2]:5d}  {a[1] / a[0] / 1e9 if a[0] else 0:8.1f} TFLOP/s")
             out[s]["kernels"] = sorted(kernels, key=lambda k: -k["ms"])[:40]
+            out[s]["conv3x3"] = sorted((k for k in kernels if classify(k["name"]) == "conv3x3"), key=lambda k: -k["ms"])
+    if args.profile and len(args.settings) > 1:              # per-shape 3x3 conv times, first setting against the others
+        import re
+        shape = lambda n: re.search(r"M\d+ N\d+ K\d+", n).group(0)
+        base_k = {}
+        for k in out[base]["conv3x3"]:
+            base_k[shape(k["name"])] = base_k.get(shape(k["name"]), 0.0) + k["ms"]
+        for s in args.settings[1:]:
+            print(f"--- 3x3 convs per shape: {base} -> {s}")
+            cur = {}
+            for k in out[s]["conv3x3"]:
+                e = cur.setdefault(shape(k["name"]), [0.0, k["name"].split(" ")[0], k["launches"]])
+                e[0] += k["ms"]
+            for sh, (ms, nm, n) in sorted(cur.items(), key=lambda t: -t[1][0]):
+                b = base_k.get(sh, 0.0)
+                print(f"    {sh:28s} n={n:4d} {b:8.2f} -> {ms:8.2f} ms  ({(ms / b - 1) * 100 if b else 0:+6.1f} %)  {nm}")
     apply("base")
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
