@@ -133,7 +133,8 @@ extern int g_force_gemm_cfg;
 extern int g_shortk_gemm_cfg;
 extern int g_shortk_max_k;          // the launches g_shortk_gemm_cfg applies to: taps == 1 and K <= this (default 448)
 extern int g_geglu_gemm_cfg;        // tile config forced on the GEGLU (ff.net.0.proj) launches, -1 = heuristic
-extern int g_conv_korder;           // 0 (default) tap-major, 1 channel-block-major (less HBM traffic, ~2.5 % slower convs)
+extern int g_conv_korder;           // 2 (default) row-shared walk where admitted, 0 tap-major, 1 channel-block-major (gemm.hip)
+extern int g_conv_korder_default;   // value restored by sdmi_debug_set("conv_korder", -1)
 extern int g_tile_order;            // -1 heuristic (default), 0 / 1 force
 extern int g_vt_mode;               // 1 (default): V^T through EP_TRANSPOSE on token-major tiles; 0: weights-as-rows GEMM (round 1)
 extern int g_gemm_pipe;             // 0 = two-stage kernels only, 3 = ping-pong 256-row tiles, 4 = also 128x320 (default)

@@ -1086,6 +1086,9 @@ int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, 
     // the other, and a launch that leaves CUs idle (tail wave, small-M levels) no longer idles them.  Same arithmetic per row; the tile
     // configuration follows the slice's M, so the bits are those of a call with Bn / n rows.  Not while block outputs are tapped.
     const int ns = (e->n_streams > 1 && !e->trace && Bn % e->n_streams == 0) ? e->n_streams : 1;
+    // (ln_fold rebuilds its folded weight copies lazily on the stream of the slice that meets them first; the other slices would read
+    // them with no event dependency on that stream — the two experimental options are mutually exclusive)
+    SDMI_REQUIRE(!(ns > 1 && e->ln_fold), "engine options ln_fold and streams > 1 cannot be combined");
     if (ns == 1) return unet_forward_slice(e, e->arena, x, t, y, out, io_dtype, Bn, 0, Bn, h, w, L, s);
     const sdmi_unet_config& c = e->unet.cfg;
     while ((int)e->aux_streams.size() < ns - 1) {

@@ -661,7 +661,10 @@ __device__ __forceinline__ int swz(int r) {
     else return (0x78 >> (((r >> 2) & 3) * 2)) & 3;
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
@@ -830,6 +833,33 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         }
     };
 
+    if constexpr (NS > 2) {
+        // ---- ring of NS stages (round 4): NS - 1 K steps of LDS-direct loads in flight, counted vmcnt, one barrier per K step -----
+        // The two-stage loop below waits for step k+1's loads at the end of step k: a workgroup's K loop is a chain of nk load
+        // latencies (M4096 N1280 K1280 on 128x64 tiles: 20 steps x 1.6 us, MFMA pipe 23 % busy, profiles/r03_shape_tuning.md).  Here
+        // the loads of step k + NS - 1 are issued at step k (into the slot step k - 1 just released), so a step waits for data issued
+        // NS - 1 steps earlier.  Every thread issues LPS loads per stage and vmcnt retires in order, so "at most rem * LPS outstanding"
+        // means stage k has landed.  Same accumulation order as the two-stage kernel: identical bits.
+        static_assert(GLDS && NS <= 4, "the ring form exists for the LDS-direct path only");
+        constexpr int LPS = A_IT + B_IT;
+        static_assert((NS - 2) * LPS < 64, "vmcnt is 6 bits");
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) stage_issue(s);
+        int slot = 0, fill = NS - 1;                         // slot of step kt; slot the next refill goes to
+        for (int kt = 0; kt < nk; ++kt) {
+            const int rem = min(nk - 1 - kt, NS - 2);        // stages issued beyond step kt: they may stay in flight
+            if (rem >= 2) wait_vmcnt<2 * LPS>();
+            else if (rem == 1) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
+            __syncthreads();                                 // stage kt visible to all; everyone is done with step kt - 1's slot
+            if (kt + NS - 1 < nk) stage_issue(fill);
+            compute(slot);
+            if (++slot == NS) slot = 0;
+            if (++fill == NS) fill = 0;
+        }
+        __syncthreads();
+    } else {
     // ---- main loop: double-buffered, one barrier per K step ------------------------------------------------
     stage_issue(0);
     stage_commit(0);
@@ -844,12 +874,10 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    }
 
     gemm_epilogue<TM, TN, WTM, WTN, GEGLU, TR, WR, BN, STATS, LNM>(p, acc, m0, n0, wr, wc, lane, z, smem);
 }
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Ping-pong kernel for the 256-row tiles: BK = 64, 8 waves as 2 (M) x 4 (N).  Every SIMD holds one wave of each
@@ -1507,6 +1535,9 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_dx_kernel(GemmP p) {
                 else if (issue_bt) wait_vmcnt<BU>();
                 else wait_vmcnt<0>();
             }
+            // (Tried, round 4: passing this barrier of phases >= 1 — which read activations only, a buffer not rewritten before the group
+            // after next — BEFORE the fragment reads returned, the 8-phase template's order: 434.5 vs 434.2 ms on the C1 job, no gain, and
+            // the flag cost the 256x320 instantiation 6 SGPR spills.  Removed.)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1692,11 +1723,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
-    constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+    constexpr int SMEM = NS * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM, NS>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1803,6 +1834,17 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
     return launch_cfg2<BM, BN, WR, WC, BK, GLDS, false>(p, batch, s);
 }
 
+// ring-buffered instantiations (NS stages): plain / GEGLU / transposed / GroupNorm-statistics epilogues, tap-major K walk
+template <int BM, int BN, int WR, int WC, int NS>
+static int launch_ring(const GemmP& p, int batch, hipStream_t s) {
+    if constexpr ((BN / WC) % 64 == 0) {
+        if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, 64, true, true, false, false, false, 0, NS>(p, batch, s);
+    }
+    if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, 64, true, false, true, false, false, 0, NS>(p, batch, s);
+    if (p.stats_nchunk > 0) return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, true, 0, NS>(p, batch, s);
+    return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, false, 0, NS>(p, batch, s);
+}
+
 bool gemm_mfma_supported(const GemmP& p) {
     if (p.N % 64 || p.cin % 64 || p.K % 64) return false;
     if (p.c1 > 0 && (p.c0 % 64)) return false;
@@ -1825,15 +1867,22 @@ enum GemmCfg {
     CFG_128x320 = 8,      // 8 waves, BK 64, 112 KB     (mid levels: twice the tiles of 256x320 at 91 flop/B)
     CFG_128x160 = 9,      // 4 waves, BK 64, 72 KB      (2 blocks/CU; the HBM-bound short-K 1x1 layers with N = 320 / 640 / 1280:
                           //                             one block's epilogue / prologue overlaps the other's K loop)
-    CFG_COUNT = 10
+    // ring-buffered forms of the 4-wave tiles (round 4; gemm_mfma_kernel NS > 2): the short-K / small-M 1x1 layers, whose two-stage K
+    // loop is a chain of load latencies.  Never picked by the score model: per shape through gemm_tuned_shapes.inc / gemm_override.
+    CFG_128x160_R4 = 10,  // 4 stages, 144 KB (1 block/CU)
+    CFG_128x128_R4 = 11,  // 4 stages, 128 KB (1 block/CU)
+    CFG_128x64_R3 = 12,   // 3 stages, 72 KB  (2 blocks/CU)
+    CFG_128x160_R3 = 13,  // 3 stages, 108 KB (1 block/CU)
+    CFG_COUNT = 14
 };
-static const int kCfgBM[CFG_COUNT] = {128, 256, 64, 128, 256, 256, 256, 128, 128, 128};
-static const int kCfgBN[CFG_COUNT] = {128, 64, 64, 128, 256, 320, 128, 64, 320, 160};
+static const int kCfgBM[CFG_COUNT] = {128, 256, 64, 128, 256, 256, 256, 128, 128, 128, 128, 128, 128, 128};
+static const int kCfgBN[CFG_COUNT] = {128, 64, 64, 128, 256, 320, 128, 64, 320, 160, 160, 128, 64, 160};
 static const char* kCfgName[CFG_COUNT] = {"gemm_mfma_128x128", "gemm_mfma_256x64", "gemm_mfma_64x64", "gemm_mfma_128x128k32",
                                           "gemm_mfma_256x256", "gemm_mfma_256x320", "gemm_mfma_256x128", "gemm_mfma_128x64",
-                                          "gemm_mfma_128x320", "gemm_mfma_128x160"};
+                                          "gemm_mfma_128x320", "gemm_mfma_128x160", "gemm_mfma_128x160r4", "gemm_mfma_128x128r4",
+                                          "gemm_mfma_128x64r3", "gemm_mfma_128x160r3"};
 // relative MFMA efficiency of each tile once the chip is full (measured, profiles/): used only to rank candidates
-static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f, 0.60f, 0.64f, 0.95f, 0.70f};
+static const float kCfgEff[CFG_COUNT] = {0.66f, 0.55f, 0.45f, 0.62f, 1.0f, 1.0f, 0.60f, 0.64f, 0.95f, 0.70f, 0.70f, 0.66f, 0.64f, 0.70f};
 
 int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
 
@@ -1844,11 +1893,15 @@ int g_force_gemm_split = 0;
 int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e ? atoi(e) : -1; }();
 int g_shortk_max_k = [] { const char* e = getenv("SDMI_SHORTK_MAXK"); return e ? atoi(e) : 448; }();
 int g_geglu_gemm_cfg = [] { const char* e = getenv("SDMI_GEGLU_CFG"); return e ? atoi(e) : -1; }();
-// 0 (default): tap-major K walk; 1: channel-block-major (-31 % HBM traffic on the 3x3 convs, PMC profiles/r02_pmc_traffic.md).  Same-box,
-// two-build A/B on the C1 job (profiles/r02_conv_korder.md): tap-major 161.4 ms of 3x3 convs per job, channel-block-major 165.5 ms with
-// the per-source pointer + tap-mask addressing, 188.3 ms with the per-tile address rebuild it shipped with first — the traffic it saves
-// is L2-hit traffic that was not the bound, and its one cold tile per channel block stalls the 1.5-tile prefetch window.
-int g_conv_korder = [] { const char* e = getenv("SDMI_CONV_KORDER"); return e ? atoi(e) : 0; }();
+// K walk of the 3x3 convolutions.  2 (default since round 4): row-shared walk (gemm_mfma_pingpong_dx_kernel: dy outer, channel block,
+// dx inner; the activation tile staged once per three K tiles) wherever launch_gemm admits it — stride 1, ping-pong tile made of whole
+// image rows, W % 16 == 0 — and tap-major elsewhere; same-box A/B on the C1 job 407.9 -> 405.1 ms, 3x3 class 150.1 -> 147.7 ms, every
+// admitted shape faster or equal (profiles/r04_knob_dx.json).  0: tap-major everywhere (rounds 1-3).  1: channel-block-major
+// (-31 % HBM traffic on the 3x3 convs, PMC profiles/r02_pmc_traffic.md, but slower: same-box two-build A/B profiles/r02_conv_korder.md —
+// tap-major 161.4 ms of 3x3 convs per job, channel-block-major 165.5 ms with the per-source pointer + tap-mask addressing, 188.3 ms
+// with the per-tile address rebuild it shipped with first).
+int g_conv_korder_default = [] { const char* e = getenv("SDMI_CONV_KORDER"); return e ? atoi(e) : 2; }();
+int g_conv_korder = g_conv_korder_default;
 int g_ep_wide = [] { const char* e = getenv("SDMI_EP_WIDE"); return e ? atoi(e) : 1; }();
 int g_gn_fuse = [] { const char* e = getenv("SDMI_GN_FUSE"); return e ? atoi(e) : 1; }();
 int g_tile_order = [] { const char* e = getenv("SDMI_TILE_ORDER"); return e ? atoi(e) : -1; }();
@@ -1866,12 +1919,13 @@ static bool cfg_valid(int cfg, const GemmP& p) {
     if (cfg == CFG_256x64) return false;                               // measured never best: not instantiated
     // 256x128: not in pick_cfg's candidate list (the two-stage form was never best in round 1); instantiated for the ping-pong kernel
     // so that the shape tuner / gemm_cfg=6 can try it on the N = 128 VAE convs (now 128x128 two-stage at ~750 TFLOP/s)
-    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_256x128)) return false;   // wave tile not a multiple of 64
+    if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_256x128 || cfg == CFG_128x160_R4 || cfg == CFG_128x160_R3)) return false;   // wave tile not a multiple of 64
+    if (cfg >= CFG_128x160_R4 && (p.korder || (p.flags & EP_LNFOLD) || p.lnp_out)) return false;     // ring forms: tap-major, no LayerNorm epilogues
     return true;
 }
 
 // workgroups of each config that fit on one CU (LDS-limited)
-static const int kCfgOcc[CFG_COUNT] = {2, 2, 4, 3, 1, 1, 1, 3, 1, 2};
+static const int kCfgOcc[CFG_COUNT] = {2, 2, 4, 3, 1, 1, 1, 3, 1, 2, 1, 1, 2, 1};
 
 // Expected relative throughput of (cfg, split): tile efficiency x chip fill / split-K overhead.  Fitted to the sweeps in
 // profiles/ (tools/bench_kernels.py): the first workgroup per CU brings ~80 % of a config's rate, co-resident ones the
@@ -2123,6 +2177,11 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_CASE(CFG_128x64, 128, 64, 4, 1, 64)
         SDMI_CASE(CFG_128x320, 128, 320, 2, 4, 64)
         SDMI_CASE(CFG_128x160, 128, 160, 2, 2, 64)
+        // ring forms need the LDS-direct path; without it they run as their two-stage twins
+        case CFG_128x160_R4: if (use_glds ? launch_ring<128, 160, 2, 2, 4>(p, batch, s) : launch_cfg<128, 160, 2, 2, 64, false>(p, batch, s)) return 1; return reduce.run();
+        case CFG_128x160_R3: if (use_glds ? launch_ring<128, 160, 2, 2, 3>(p, batch, s) : launch_cfg<128, 160, 2, 2, 64, false>(p, batch, s)) return 1; return reduce.run();
+        case CFG_128x128_R4: if (use_glds ? launch_ring<128, 128, 2, 2, 4>(p, batch, s) : launch_cfg<128, 128, 2, 2, 64, false>(p, batch, s)) return 1; return reduce.run();
+        case CFG_128x64_R3: if (use_glds ? launch_ring<128, 64, 4, 1, 3>(p, batch, s) : launch_cfg<128, 64, 4, 1, 64, false>(p, batch, s)) return 1; return reduce.run();
     }
 #undef SDMI_CASE
     set_error("bad gemm config");

@@ -413,8 +413,9 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             self._latent_mask_pil = latent_mask                 # resized to the latent grid once the init latent exists (init)
             cond = np.array(image_mask.convert("L")).astype(np.float32) / 255.0
             self.image_mask = torch.from_numpy(cond[None, None])
-        else:
+        elif self.mask_image is not None:                      # a mask was given but is blank after the inversion / blur: plain img2img
             self.latent_mask = self.image_mask = None
+        # (no PIL mask at all: tensor latent_mask / image_mask a caller set on the object stay as they are)
 
     def _latent_mask_from_pil(self):
         """modules/processing.py:1733-1742: the mask image resized (PIL default filter) to the init latent's grid, red channel / 255,

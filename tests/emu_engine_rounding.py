@@ -138,6 +138,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--save", default="", help="write the emulated outputs (fp16 stream / all-fp32 non-operand tensors) to this .npz: "
+                                               "tests/golden/emu_engine_c1.npz is read by tests/test_gpu_c1_parity.py")
     args = ap.parse_args()
     schema = importlib.import_module("stable-diffusion-webui_amd.schema")
     from helpers import seeded, usable_cpus
@@ -152,6 +154,7 @@ def main():
     x = seeded((B, 4, hw, hw), 101)[:args.rows]               # the inputs of tests/test_gpu_c1_parity.py::test_c1_unet_cfg_forward_16_rows_vs_oracle
     t = torch.linspace(999.0, 1.0, B)[:args.rows]
     ctx = seeded((B, 77, cdim), 102).half().float()[:args.rows]
+    saved = []
     with torch.no_grad():
         t0 = time.time()
         ref = net(x, t, ctx)
@@ -162,6 +165,13 @@ def main():
                          ("... + fp32 conv1 output (every tensor that is not a matrix-core operand in fp32)", dict(stream_fp32=True, skip_fp32=True, h1_fp32=True))):
             got = Emu(net, **kw)(x, t, ctx)
             print(f"{name}: rel-L2 {rel_l2(got, ref):.3e}   per row {[f'{rel_l2(got[i], ref[i]):.2e}' for i in range(args.rows)]}", flush=True)
+            saved.append((got, rel_l2(got, ref)))
+    if args.save:
+        import numpy as np
+        np.savez_compressed(args.save, rows=args.rows, fp16_stream=saved[0][0].numpy(), fp32_stream=saved[1][0].numpy(),
+                            fp32_stream_skip=saved[2][0].numpy(), fp32_all_non_operand=saved[3][0].numpy(),
+                            rel_l2_vs_fp32_oracle=np.array([e for _, e in saved]))
+        print("wrote", args.save)
 
 
 if __name__ == "__main__":

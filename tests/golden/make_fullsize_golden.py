@@ -4,6 +4,7 @@ GPU test session can afford to recompute: each leg is minutes of host CPU, so th
 and tests/test_gpu_fullsize_parity.py compares the HIP engine with the committed outputs (inputs are re-derived from the seeds).
 
     python tests/golden/make_fullsize_golden.py [leg ...]        # legs: c4_unet128 c3_sdxl128 vae1024 vae1024_xl enc512 c2_dpmpp2m
+                                                                 #       c4a_hires c4b_img2img c3_sdxl_e2e   (round 4: compositions)
 
   c4_unet128   SD1.5 UNet, one CFG pair (2 rows), 128x128 latent (the hires pass of c4a: modules/processing.py:1364-1464;
                level-0 self-attention N = M = 16384, d = 40)
@@ -16,6 +17,14 @@ and tests/test_gpu_fullsize_parity.py compares the HIP engine with the committed
   enc512       SD1.5 first stage ENCODE of a 512x512 image -> posterior moments [1, 8, 64, 64] (modules/sd_samplers_common.py:87-112)
   c2_dpmpp2m   the c2 job at batch 1: 50-step DPM++ 2M on the Karras schedule, cfg 7, 512x512, Philox seed 2000 — final latent
                (modules/sd_samplers_kdiffusion.py:12,18,116-127)
+
+  c4a_hires    the c4a job composed end to end at batch 2: txt2img 512x512, 2 Euler-a steps -> bilinear latent upscale to 128x128
+               (modules/processing.py:1364-1398) -> second pass (sample_img2img with steps given, 2 evaluations, :1429-1454) ->
+               first-stage decode at 1024x1024 of image 0 (sub-sampled)
+  c4b_img2img  the c4b job at batch 2: first-stage encode of two 512x512 images (modules/processing.py:1745-1760) -> Euler-a img2img,
+               steps 4, denoising 0.5 (t_enc = 2: 3 evaluations, modules/sd_samplers_kdiffusion.py:134-178) -> decode at 512x512
+  c3_sdxl_e2e  SDXL-base, batch 1, 3 Euler-a steps with CFG 5 at a 128x128 latent (vector conditioning y / uy through the CFG
+               denoiser): final latent
 
 Attention products above 4096 query rows are evaluated in row blocks (oracle.unet.QUERY_CHUNK: softmax rows are independent, the
 result is the unchunked product's) — the memory bound modules/sub_quadratic_attention.py puts on the reference's own product.
@@ -41,6 +50,9 @@ SPEC = {
     "vae1024_xl": dict(z=((1, 4, 128, 128), 423), z_scale=0.13025 * 4.5, weight_gain=2.0e5),
     "enc512": dict(x=((1, 3, 512, 512), 431)),
     "c2_dpmpp2m": dict(prompt_seed=50_002, seed=2000, steps=50, cfg=7.0),
+    "c4a_hires": dict(prompt_seed=50_004, seeds=[4000, 4001], steps=2, cfg=7.0, denoising_strength=0.75),
+    "c4b_img2img": dict(prompt_seed=50_005, seeds=[4100, 4101], steps=4, cfg=7.0, denoising_strength=0.5, image_seed=441),
+    "c3_sdxl_e2e": dict(prompt_seed=50_003, seeds=[4200], steps=3, cfg=5.0),
 }
 
 
@@ -135,6 +147,51 @@ def main(legs):
         ref = opipe.sample(om, cond, uncond, [s["seed"]], s["steps"], "dpmpp_2m", s["cfg"], (64, 64), scheduler="karras")
         print(f"[c2_dpmpp2m] {time.time() - t0:.0f}s", flush=True)
         save("c2_dpmpp2m", final_latent=ref.numpy())
+    if "c4a_hires" in legs or "c4b_img2img" in legs:
+        sd = schema.synthetic_state_dict(schema.sd15_unet(), schema.sd15_vae(), dtype=torch.float16)
+        om = opipe.OracleModel(sd, ou.sd15_config(), ov.sd15_vae_config())
+        del sd
+        if "c4a_hires" in legs:
+            s = SPEC["c4a_hires"]
+            g = torch.Generator().manual_seed(s["prompt_seed"])
+            cond, uncond = torch.randn(2, 77, 768, generator=g), torch.randn(2, 77, 768, generator=g)
+            t0 = time.time()
+            lat = opipe.txt2img_hires(om, cond.half().float(), uncond.half().float(), s["seeds"], s["steps"], "euler_a", s["cfg"], (64, 64),
+                                      hr_scale=2.0, denoising_strength=s["denoising_strength"])
+            print(f"[c4a_hires] sampling {time.time() - t0:.0f}s", flush=True)
+            with torch.no_grad():
+                img = om.vae.decode_first_stage(lat[:1])
+            print(f"[c4a_hires] {time.time() - t0:.0f}s", flush=True)
+            save("c4a_hires", final_latent=lat.numpy(), image0_sub4=img[:, :, ::4, ::4].numpy(), image0_window=img[:, :, 448:576, 448:576].numpy())
+        if "c4b_img2img" in legs:
+            s = SPEC["c4b_img2img"]
+            g = torch.Generator().manual_seed(s["prompt_seed"])
+            cond, uncond = torch.randn(2, 77, 768, generator=g), torch.randn(2, 77, 768, generator=g)
+            image = torch.rand((2, 3, 512, 512), generator=torch.Generator().manual_seed(s["image_seed"]))
+            t0 = time.time()
+            with torch.no_grad():
+                init = om.vae.encode_first_stage_mean(image.half().float() * 2 - 1)
+            lat = opipe.sample(om, cond.half().float(), uncond.half().float(), s["seeds"], s["steps"], "euler_a", s["cfg"], (64, 64),
+                               init_latent=init, denoising_strength=s["denoising_strength"], img2img_steps_given=False)
+            with torch.no_grad():
+                img = opipe.decode(om, lat)
+            print(f"[c4b_img2img] {time.time() - t0:.0f}s", flush=True)
+            save("c4b_img2img", init_latent=init.numpy(), final_latent=lat.numpy(), images_sub2=img[:, :, ::2, ::2].numpy())
+        del om
+    if "c3_sdxl_e2e" in legs:
+        s = SPEC["c3_sdxl_e2e"]
+        sd = schema.synthetic_state_dict(schema.sdxl_unet(), None, dtype=torch.float16)
+        om = opipe.OracleModel(sd, ou.sdxl_base_config(), None)
+        del sd
+        g = torch.Generator().manual_seed(s["prompt_seed"])
+        cond, uncond = torch.randn(1, 77, 2048, generator=g), torch.randn(1, 77, 2048, generator=g)
+        y, uy = torch.randn(1, 2816, generator=g), torch.randn(1, 2816, generator=g)
+        t0 = time.time()
+        lat = opipe.sample(om, cond.half().float(), uncond.half().float(), s["seeds"], s["steps"], "euler_a", s["cfg"], (128, 128),
+                           y=y.half().float(), uy=uy.half().float())
+        print(f"[c3_sdxl_e2e] {time.time() - t0:.0f}s", flush=True)
+        save("c3_sdxl_e2e", final_latent=lat.numpy())
+        del om
     return done
 
 

@@ -661,11 +661,14 @@ def test_kernels_compile_without_scratch_or_spills():
             # ... and in the GroupNorm-statistics instantiations of the ping-pong GEMM (last template flag), where a handful of
             # kernel-argument SGPRs are parked in VGPR lanes BEFORE the K loop and read back after it — checked below)
             stats_pp = re.search(r"gemm_mfma_pingpong_kernelILi\d+ELi\d+E(Lb[01]E){4}Lb1ELi0EEEv", kname) is not None
+            # ... the same epilogue on the row-shared 3x3 walk (gemm_mfma_pingpong_dx_kernel<BM, BN, STATS = true>)
+            stats_dx = re.search(r"gemm_mfma_pingpong_dx_kernelILi\d+ELi\d+ELb1EEEv", kname) is not None
             # ... and in the LayerNorm consumer / producer forms (last template argument 1 / 2), same rule: parked before the K loop
             ln_pp = re.search(r"gemm_mfma_pingpong_kernelILi\d+ELi\d+E(Lb[01]E){5}Li[12]EEEv", kname) is not None
             assert field("vgpr_spill_count") == 0, f"{kname} spills registers"
-            assert field("sgpr_spill_count") == 0 or "generic" in kname or (stats_pp and field("sgpr_spill_count") <= 8) or (ln_pp and field("sgpr_spill_count") <= 24), f"{kname} spills registers"
-            if (stats_pp or ln_pp) and field("sgpr_spill_count"):
+            assert field("sgpr_spill_count") == 0 or "generic" in kname or (stats_pp and field("sgpr_spill_count") <= 8) or (ln_pp and field("sgpr_spill_count") <= 24) or \
+                (stats_dx and field("sgpr_spill_count") <= 12), f"{kname} spills registers"
+            if (stats_pp or ln_pp or stats_dx) and field("sgpr_spill_count"):
                 body = re.search(r"^%s:[^\n]*\n(.*?)\.Lfunc_end" % re.escape(kname), text, re.S | re.M).group(1)
                 loop = body[body.index("s_setprio 1"):body.rindex("s_setprio 0")]
                 assert "v_readlane" not in loop and "v_writelane" not in loop, f"{kname}: SGPR spill traffic inside the K loop"

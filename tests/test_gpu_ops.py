@@ -218,13 +218,14 @@ def test_pingpong_gemm_is_bit_identical_to_two_stage_kernel(dev, case):
     outs = {}
     try:
         lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
+        lib.check(lib.lib.sdmi_debug_set(b"conv_korder", 0))          # tap-major on both sides (the default row-shared walk sums in another order)
         pp = 4 if cfg == 8 else 3                          # 4 also routes the 128x320 tile to the ping-pong kernel
         for pipe in (0, pp, pp, pp):
             lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", pipe))
             outs.setdefault(3 if pipe else 0, []).append(ops.conv_gemm(x0.half().to(dev), wp, **args))
     finally:
         lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
-        lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1))
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1)); lib.check(lib.lib.sdmi_debug_set(b"conv_korder", -1))
     torch.cuda.synchronize()
     assert rel_l2(outs[0][0].float().cpu(), ref) < 6e-4, case
     for o in outs[3]:
@@ -256,10 +257,63 @@ def test_channel_block_major_k_order_pingpong_equals_two_stage(dev, case):
             outs.append(ops.conv_gemm(x0.half().to(dev), wp, **args))
     finally:
         lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
-        lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1)); lib.check(lib.lib.sdmi_debug_set(b"conv_korder", 0))
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_pipe", -1)); lib.check(lib.lib.sdmi_debug_set(b"conv_korder", -1))
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]), case
     assert rel_l2(outs[1].float().cpu(), ref) < 6e-4, case
+
+
+DX_CASES = [
+    # (cfg, B, H, W, c0, c1, cout, split, resid)      row-shared walk (conv_korder 2, the default): stride-1 3x3, tile = whole image rows
+    (5, 2, 64, 64, 128, 0, 320, 0, True),              # 256x320: 4 rows of 64 per tile (level 0), 6 K tiles = 2 groups
+    (5, 2, 64, 64, 64, 0, 320, 0, False),              # one 64-channel block per kernel row: 3 groups, the shortest loop
+    (5, 1, 32, 32, 192, 128, 320, 0, True),            # two sources, source switch between groups, 8 rows of 32 per tile
+    (5, 1, 24, 16, 320, 0, 320, 0, True),              # W = 16: 16 image rows per tile (a guard row between every fragment), ragged M = 384
+    (5, 2, 16, 16, 1280, 0, 1280, 4, True),            # split-K: slices of whole (dy, channel block) groups
+    (4, 2, 64, 64, 128, 0, 256, 0, False),             # 256x256 (VAE widths)
+    (4, 1, 16, 256, 128, 0, 256, 0, True),             # W = 256 = BM: one image row per tile, the halves of a row belong to different wave groups
+    (8, 2, 32, 32, 192, 0, 320, 0, True),              # 128x320 (two phases): 4 rows of 32 per tile (level 1)
+    (8, 1, 48, 64, 128, 64, 640, 0, False),            # 128x320: 2 rows of 64, two sources, two column tiles
+    (8, 2, 16, 16, 640, 0, 1280, 2, True),             # 128x320 split-K
+]
+
+
+@pytest.mark.parametrize("case", DX_CASES)
+def test_row_shared_3x3_walk_vs_torch_and_tap_major(dev, case):
+    """conv_korder = 2 (default since round 4, gemm_mfma_pingpong_dx_kernel): the activation tile of a (dy, channel block) group is staged
+    once and the dx = 0 / 2 K tiles read it one LDS row up / down, zero padding coming from guard rows between the image rows.  The fp32
+    summation order differs from the tap-major walk, so the two agree to accumulation rounding (a few fp16 ulps on a few outputs), not
+    bitwise; each equals torch within the conv tolerance; the walk is deterministic; and shapes it cannot take (checked in
+    tools/micro/conv_check.cpp: W = 8, stride 2, upsample) keep the tap-major bits."""
+    ops, lib = sub("ops"), sub("_lib")
+    cfg, B, H, W, c0, c1, cout, split, with_res = case
+    x0 = seeded((B, H, W, c0), 1)
+    x1 = seeded((B, H, W, c1), 2) if c1 else None
+    w = seeded((cout, c0 + c1, 3, 3), 3, scale=((c0 + c1) * 9) ** -0.5)
+    b = seeded((cout,), 4, 0.1)
+    xin = torch.cat([x0, x1], dim=3) if c1 else x0
+    ref = _conv_ref(h(xin), h(w), b)
+    res = seeded(tuple(ref.shape), 5) if with_res else None
+    if with_res:
+        ref = ref + h(res)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    args = dict(a1=None if x1 is None else x1.half().to(dev), bias=ops.pack_bias(b.to(dev), wp.shape[0]),
+                resid=None if res is None else res.half().to(dev), taps=9)
+    outs = {}
+    try:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", cfg)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split))
+        for korder in (0, 2, 2):
+            lib.check(lib.lib.sdmi_debug_set(b"conv_korder", korder))
+            outs.setdefault(korder, []).append(ops.conv_gemm(x0.half().to(dev), wp, **args))
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
+        lib.check(lib.lib.sdmi_debug_set(b"conv_korder", -1))
+    torch.cuda.synchronize()
+    tap, dx, dx2 = outs[0][0], outs[2][0], outs[2][1]
+    assert torch.equal(dx, dx2), case
+    assert rel_l2(tap.float().cpu(), ref) < 6e-4 and rel_l2(dx.float().cpu(), ref) < 6e-4, case
+    assert rel_l2(dx.float().cpu(), tap.float().cpu()) < 1e-4, case               # measured ~2e-5 (tools/micro/conv_check.cpp)
+    assert not torch.equal(dx, tap) or c0 + c1 == 64, case                        # the walk really differs (one block per row: same order)
 
 
 @pytest.mark.parametrize("rows,cin,cout,cfg", [(4096, 320, 320, -1), (1024, 640, 640, -1), (256, 1280, 1280, -1), (1024, 320, 320, 9),
