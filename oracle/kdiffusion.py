@@ -243,6 +243,7 @@ class CFGDenoiser:
         self.empty_prompt = None                             # shared.sd_model.cond_stage_model_empty_prompt
         self.padded_cond_uncond = self.padded_cond_uncond_v0 = False
         self.skipped_uncond = False
+        self.adm = False                                     # shared.sd_model.model.conditioning_key == "crossattn-adm" (unCLIP, :192-194)
         self.refiner = None                                  # dict(inner_model=, cond=, uncond=, switch_at=[, extra=the sampler's dict])
         self.on_refiner = False
 
@@ -306,7 +307,8 @@ class CFGDenoiser:
         sigma_in = torch.cat([rep(sigma)] + [sigma] * len(tail))
         image_cond_in = None
         if image_cond is not None:
-            image_cond_in = torch.cat([rep(image_cond), image_cond] + ([torch.zeros_like(self.init_latent)] if is_edit else []))
+            image_uncond = torch.zeros_like(image_cond) if self.adm else image_cond      # unCLIP: c_adm of the uncond rows is zero
+            image_cond_in = torch.cat([rep(image_cond), image_uncond] + ([torch.zeros_like(self.init_latent)] if is_edit else []))
         skip_uncond = False                                                               # :218-230
         if self.skip_early_cond != 0. and self.step / self.total_steps <= self.skip_early_cond:
             skip_uncond = True

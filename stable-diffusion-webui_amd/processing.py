@@ -100,7 +100,46 @@ class StableDiffusionProcessing:
             latent = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(image))
             ones = torch.ones((b, 1, *latent.shape[2:]), dtype=torch.float32, device=x.device)
             return torch.cat([ones, latent], dim=1).contiguous()
+        if self._conditioning_key() == "crossattn-adm":      # unCLIP (:113-115): no image to embed in txt2img -> a zero c_adm
+            na = getattr(self.sd_model, "noise_augmentor", None)
+            dim = 2 * na.time_embed.dim if na is not None else self.sd_model.unet_cfg.adm_in_channels
+            return x.new_zeros(b, dim)
         return x.new_zeros(b, 5, 1, 1)
+
+    def depth2img_image_conditioning(self, source_image, latent_hw):
+        """:304-320.  The MiDaS depth model and its input transform (ldm.data.util.AddMiDaS) belong to the host application (they are
+        part of the depth2img checkpoint / the ldm package, torch modules that run once per job); the depth map is resized to the latent
+        grid (bicubic) and normalised to [-1, 1] over the whole batch, and travels to the UNet as the fifth input channel (c_concat).
+        ``latent_hw``: the reference encodes the image a second time only to read this shape off the result."""
+        depth_model = getattr(self.sd_model, "depth_model", None)
+        if depth_model is None:
+            raise NotImplementedError("depth2img checkpoints need sd_model.depth_model (the checkpoint's MiDaS module)")
+        try:
+            from ldm.data.util import AddMiDaS
+        except ImportError as e:
+            raise NotImplementedError("depth2img conditioning needs ldm.data.util.AddMiDaS (present in a webui install)") from e
+        from einops import rearrange, repeat
+        transformer = AddMiDaS(model_type="dpt_hybrid")
+        transformed = transformer({"jpg": rearrange(source_image[0], "c h w -> h w c")})
+        midas_in = torch.from_numpy(transformed["midas_in"][None, ...]).to(device=source_image.device)
+        midas_in = repeat(midas_in, "1 ... -> n ...", n=self.batch_size)
+        conditioning = torch.nn.functional.interpolate(depth_model(midas_in), size=tuple(latent_hw), mode="bicubic", align_corners=False)
+        (depth_min, depth_max) = torch.aminmax(conditioning)
+        return (2. * (conditioning - depth_min) / (depth_max - depth_min) - 1.).float().contiguous()
+
+    def unclip_image_conditioning(self, source_image):
+        """:327-333: c_adm = CLIP image embedding of the source image (+ the noise-level embedding at level 0) — the host's
+        embedder / noise augmentor modules; the CFG denoiser hands it to the UNet's vector input, zeros on the uncond rows."""
+        embedder = getattr(self.sd_model, "embedder", None)
+        if embedder is None:
+            raise NotImplementedError("unCLIP checkpoints need sd_model.embedder (the checkpoint's CLIP image embedder)")
+        c_adm = embedder(source_image)
+        na = getattr(self.sd_model, "noise_augmentor", None)
+        if na is not None:
+            noise_level = torch.zeros((c_adm.shape[0],), dtype=torch.long, device=c_adm.device)
+            c_adm, noise_level_emb = na(c_adm, noise_level=noise_level)
+            c_adm = torch.cat((c_adm, noise_level_emb), 1)
+        return c_adm.float().contiguous()
 
     def inpainting_image_conditioning(self, source_image, latent_image, image_mask=None, round_image_mask=True):
         """:332-374.  ``source_image`` [B,3,H,W] in [-1,1] on the device; ``image_mask`` a float tensor [1,1,H,W] in [0,1]
@@ -130,11 +169,17 @@ class StableDiffusionProcessing:
         return mean.contiguous()
 
     def img2img_image_conditioning(self, source_image, latent_image, image_mask=None, round_image_mask=True):
-        """:376-393 (depth2img and unCLIP checkpoints are not on the path)."""
+        """:376-398, in the reference's order: depth2img, edit, inpainting, unCLIP, SDXL inpainting, dummy."""
+        if getattr(self.sd_model, "is_depth2img", False):       # the reference asks isinstance(sd_model, LatentDepth2ImageDiffusion)
+            return self.depth2img_image_conditioning(source_image, latent_image.shape[2:])
         if getattr(self.sd_model, "cond_stage_key", "txt") == "edit":
             return self.edit_image_conditioning(source_image)
-        if self._conditioning_key() in {'hybrid', 'concat'} or getattr(self.sd_model, "is_sdxl_inpaint", False):
+        if self._conditioning_key() in {'hybrid', 'concat'}:
             return self.inpainting_image_conditioning(source_image, latent_image, image_mask=image_mask, round_image_mask=round_image_mask)
+        if self._conditioning_key() == "crossattn-adm":
+            return self.unclip_image_conditioning(source_image)
+        if getattr(self.sd_model, "is_sdxl_inpaint", False):
+            return self.inpainting_image_conditioning(source_image, latent_image, image_mask=image_mask)
         return latent_image.new_zeros(latent_image.shape[0], 5, 1, 1)
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):

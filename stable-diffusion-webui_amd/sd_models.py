@@ -96,15 +96,23 @@ def guess_unet_config(sd: dict) -> schema.UNetConfig:
 class SdModel:
     def __init__(self, state_dict: dict, unet_cfg: Optional[schema.UNetConfig] = None,
                  vae_cfg: Optional[schema.VAEConfig] = None, device: int = 0, load_vae: bool = True,
-                 vae_decoder_only: bool = False, parameterization: str = "eps", cond_stage_key: Optional[str] = None):
+                 vae_decoder_only: bool = False, parameterization: str = "eps", cond_stage_key: Optional[str] = None,
+                 conditioning_key: Optional[str] = None, embedder=None, noise_augmentor=None, depth_model=None):
         self.unet_cfg = unet_cfg or guess_unet_config(state_dict)
-        self.is_sdxl = self.unet_cfg.adm_in_channels is not None
+        # unCLIP checkpoints (SD 2.1-unclip: conditioning_key "crossattn-adm", configs/v2-1-stable-unclip-*.yaml) carry the same
+        # label_emb vector input as SDXL but are not SDXL: the vector is the CLIP image embedding + its noise-level embedding
+        self.is_sdxl = self.unet_cfg.adm_in_channels is not None and conditioning_key != "crossattn-adm"
         # what the reference reads from the checkpoint's yaml (modules/sd_models_config.py:72-115): 9 input channels = inpainting
         # ("hybrid": c_concat = mask + masked-image latent), 8 = InstructPix2Pix (also "hybrid", cond_stage_key "edit")
         cin = self.unet_cfg.in_channels
         self.cond_stage_key = cond_stage_key or ("edit" if cin == 8 else "txt")
         self.is_sdxl_inpaint = self.is_sdxl and cin == 9
-        self.model = types.SimpleNamespace(conditioning_key="hybrid" if cin in (8, 9) and not self.is_sdxl else "crossattn")
+        # 5 input channels = depth2img (LatentDepth2ImageDiffusion: "hybrid", c_concat = the MiDaS depth map at latent size)
+        self.is_depth2img = cin == 5 and not self.is_sdxl
+        self.model = types.SimpleNamespace(conditioning_key=conditioning_key or ("hybrid" if cin in (5, 8, 9) and not self.is_sdxl else "crossattn"))
+        # torch modules of the host application that build the image conditioning of those two families (modules/processing.py:304-340);
+        # they run once per job, outside the sampling loop, exactly as in the reference
+        self.embedder, self.noise_augmentor, self.depth_model = embedder, noise_augmentor, depth_model
         shared.sd_model = self                            # the reference's global (modules/shared.py); schedulers read is_sdxl
         self.vae_cfg = vae_cfg or (schema.sdxl_vae() if self.is_sdxl else schema.sd15_vae())
         assert parameterization in ("eps", "v")

@@ -383,6 +383,12 @@ class CFGDenoiser:
         b, c, h, w = x.shape
         chw = c * h * w
         cin = eng.unet_cfg.in_channels
+        adm_cond = None
+        if getattr(getattr(sd_model, "model", None), "conditioning_key", None) == "crossattn-adm":
+            # unCLIP (:192-194): image_cond is c_adm [B, adm] — the UNet's vector input on the cond rows, zeros on the uncond rows
+            if image_cond is None or image_cond.dim() != 2 or image_cond.shape[0] != b:
+                raise ValueError(f"this checkpoint needs image_cond = c_adm of shape ({b}, adm) (unCLIP conditioning)")
+            adm_cond, image_cond = image_cond.to(x.device, torch.float32), None
         if cin > c:                                           # conditioning_key hybrid / concat: UNet input = cat([x, c_concat], 1)
             if image_cond is None or tuple(image_cond.shape) != (b, cin - c, h, w):
                 raise ValueError(f"this checkpoint needs image_cond of shape {(b, cin - c, h, w)} (inpainting / edit conditioning)")
@@ -392,6 +398,9 @@ class CFGDenoiser:
         conds_list, tensor = cond if isinstance(cond, tuple) else (None, cond)
         if conds_list is not None and all(len(cl) == 1 and cl[0] == (i, 1.0) for i, cl in enumerate(conds_list)):
             conds_list = None                                 # plain CFG written the long way
+        if adm_cond is not None:                              # one c_adm row per cond row (repeat_interleave by the prompts of an image)
+            y = adm_cond if conds_list is None else torch.cat([adm_cond[i:i + 1].expand(len(cl), -1) for i, cl in enumerate(conds_list)])
+            uy = torch.zeros_like(adm_cond)
         blend_scripts = self._mask_blend_scripts() if self.mask is not None else None
         if self.mask_before_denoising and self.mask is not None:
             # blend in the original latents BEFORE denoising (timestep samplers, cfg_denoiser.py:186-187); the sampler keeps

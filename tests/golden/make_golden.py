@@ -582,6 +582,10 @@ CFG_SCENARIOS = [
     ("no_batch", dict(opts=dict(batch_cond_uncond=False))),
     ("edit", dict(edit=True, image_cfg_scale=1.5)),
     ("edit_scale_1", dict(edit=True, image_cfg_scale=1.0, conds_list=[[(0, 1.0), (1, 0.6)], [(2, 0.8)]])),
+    # unCLIP checkpoints (conditioning_key "crossattn-adm", :192-194): image_cond is the CLIP image embedding [B, adm], handed to the
+    # UNet as c_adm; the uncond rows get zeros
+    ("unclip", dict(adm=True)),
+    ("unclip_and_ngms", dict(adm=True, conds_list=[[(0, 1.0), (1, 0.6)], [(2, 0.8)]], s_min_uncond=5.0, sigma=2.0, step=1)),
 ]
 
 
@@ -594,7 +598,8 @@ def cfg_scenario_inputs(k, sc):
         x=seeded((b, c, hw, hw), 5000 + 10 * k), conds_list=conds_list,
         cond=seeded((n_cond, sc.get("t_cond", 8), dim), 5001 + 10 * k, 0.5),
         uncond=seeded((b, sc.get("t_uncond", 8), dim), 5002 + 10 * k, 0.5),
-        image_cond=seeded((b, 4 if sc.get("edit") else 5, hw, hw), 5003 + 10 * k), init_latent=seeded((b, c, hw, hw), 5004 + 10 * k),
+        image_cond=seeded((b, 12), 5003 + 10 * k) if sc.get("adm") else seeded((b, 4 if sc.get("edit") else 5, hw, hw), 5003 + 10 * k),
+        init_latent=seeded((b, c, hw, hw), 5004 + 10 * k),
         mask=(seeded((b, 1, hw, hw), 5005 + 10 * k) > 0).float(), empty=seeded((1, 8, dim), 4999, 0.5),
         sigma=torch.full((b,), float(sc.get("sigma", 3.0))))
 
@@ -603,6 +608,8 @@ def cfg_inner_model(x_in, sigma_in, c_crossattn, c_concat):
     """Analytic stand-in for the wrapped UNet: depends on every input, and on the token COUNT of the context."""
     ctx = c_crossattn.sum(dim=(1, 2))[:, None, None, None]
     # (the reference leaves c_concat at full length when it drops the uncond rows, :212-214 — only the matching rows are read)
+    if c_concat.dim() == 2:                               # unCLIP: c_adm [rows, adm] — a per-row vector, as the UNet's y
+        return torch.tanh(0.5 * x_in + 0.2 * ctx + 0.1 * sigma_in[:, None, None, None]) + 0.05 * c_concat[:x_in.shape[0]].sum(1)[:, None, None, None] * x_in
     return torch.tanh(0.5 * x_in + 0.2 * ctx + 0.1 * sigma_in[:, None, None, None]) + 0.05 * c_concat[:x_in.shape[0], :4] * x_in
 
 
@@ -642,14 +649,15 @@ def gen_cfg_denoiser():
         shared.opts = types.SimpleNamespace(**base)
         inp = cfg_scenario_inputs(k, sc)
         shared.sd_model = types.SimpleNamespace(cond_stage_key="edit" if sc.get("edit") else "txt",
-                                                model=types.SimpleNamespace(conditioning_key="hybrid"),
+                                                model=types.SimpleNamespace(conditioning_key="crossattn-adm" if sc.get("adm") else "hybrid"),
                                                 cond_stage_model_empty_prompt=inp["empty"])
         ref = load_by_path("ref_cfg_denoiser", "modules/sd_samplers_cfg_denoiser.py")       # re-imported: binds this opts object
 
         class D(ref.CFGDenoiser):
             @property
             def inner_model(self):
-                return lambda x_in, sigma_in, cond: cfg_inner_model(x_in, sigma_in, cond["c_crossattn"][0], cond["c_concat"][0])
+                return lambda x_in, sigma_in, cond: cfg_inner_model(x_in, sigma_in, cond["c_crossattn"][0],
+                                                                    cond["c_adm"] if "c_adm" in cond else cond["c_concat"][0])
 
         d = D(types.SimpleNamespace(last_latent=None, sampler_extra_args={}))
         d.p = types.SimpleNamespace(extra_generation_params={}, scripts=None)

@@ -727,6 +727,106 @@ def test_instruct_pix2pix_checkpoint_vs_oracle(dev):
     assert rel_l2(outs[1.5], outs[1.0]) > 3e-2
 
 
+def test_depth2img_checkpoint_conditioning_vs_oracle(dev, monkeypatch):
+    """5-channel depth2img checkpoints (LatentDepth2ImageDiffusion, conditioning_key "hybrid"): the host's MiDaS module and its
+    ldm.data.util.AddMiDaS input transform (both stubbed here: they are the webui's torch code, run once per job) give a depth map that
+    processing.depth2img_image_conditioning resizes to the latent grid (bicubic) and normalises to [-1, 1] over the batch
+    (modules/processing.py:304-320); it is the fifth input channel of every UNet row."""
+    import sys
+    import types
+    from oracle import pipeline as opipe
+    processing = sub("processing")
+    wd = torch.tensor([0.5, -0.3, 0.8])
+
+    class AddMiDaS:                                           # stand-in for ldm.data.util.AddMiDaS("dpt_hybrid"): [-1, 1] HWC -> CHW numpy
+        def __init__(self, model_type):
+            assert model_type == "dpt_hybrid"
+
+        def __call__(self, sample):
+            x = ((sample["jpg"] + 1.0) * .5).detach().cpu().numpy()
+            sample["midas_in"] = np.ascontiguousarray(x.transpose(2, 0, 1)).astype(np.float32)
+            return sample
+
+    ldm, data, util = types.ModuleType("ldm"), types.ModuleType("ldm.data"), types.ModuleType("ldm.data.util")
+    util.AddMiDaS, data.util, ldm.data = AddMiDaS, util, data
+    for k, m in (("ldm", ldm), ("ldm.data", data), ("ldm.data.util", util)):
+        monkeypatch.setitem(sys.modules, k, m)
+    depth_model = lambda t: torch.tanh((t * wd.to(t.device)[None, :, None, None]).sum(1, keepdim=True) * 3.0 + torch.linspace(-1, 1, t.shape[-1], device=t.device))
+    model, om, cond, uncond = _concat_model(5, depth_model=depth_model)
+    assert model.is_depth2img and model.model.conditioning_key == "hybrid"
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(23)).half().float()
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=930, batch_size=2, steps=5, cfg_scale=6.0,
+                                                    width=128, height=128, sampler_name="Euler a", init_images=img, denoising_strength=0.8)
+    res = processing.process_images(p)
+    # the reference's arithmetic on the CPU: the FIRST image's MiDaS input repeated over the batch (:307-309), bicubic, aminmax
+    src = img * 2 - 1
+    midas_in = ((src[0].permute(1, 2, 0) + 1.0) * .5).permute(2, 0, 1)[None].repeat(2, 1, 1, 1)
+    d = torch.nn.functional.interpolate(depth_model(midas_in), size=(16, 16), mode="bicubic", align_corners=False)
+    lo, hi = torch.aminmax(d)
+    ic = 2. * (d - lo) / (hi - lo) - 1.
+    assert tuple(p.image_conditioning_all.shape) == (2, 1, 16, 16) and rel_l2(p.image_conditioning_all.cpu(), ic) < 1e-5
+    init = om.vae.encode_first_stage_mean(src)
+    lat = opipe.sample(om, cond, uncond, [930, 931], 5, "euler_a", 6.0, (16, 16), init_latent=init, denoising_strength=0.8,
+                       img2img_steps_given=False, image_cond=ic)
+    assert rel_l2(res.latents.cpu(), lat) < 1.5e-2
+    flat = opipe.sample(om, cond, uncond, [930, 931], 5, "euler_a", 6.0, (16, 16), init_latent=init, denoising_strength=0.8,
+                        img2img_steps_given=False, image_cond=torch.zeros_like(ic))
+    assert rel_l2(flat, lat) > 1e-2                           # the depth channel matters
+    model.depth_model = None
+    with pytest.raises(NotImplementedError):
+        processing.process_images(processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=930, batch_size=2, steps=2,
+                                                                              width=128, height=128, sampler_name="Euler a", init_images=img))
+    model.engine.close()
+
+
+@pytest.mark.parametrize("and_prompts", [False, True])
+def test_unclip_checkpoint_conditioning_vs_oracle(dev, and_prompts):
+    """unCLIP checkpoints (SD 2.1-unclip, conditioning_key "crossattn-adm"): c_adm = the host's CLIP image embedder + noise augmentor at level 0
+    (modules/processing.py:327-333; stubs here) goes to the UNet's vector input on the cond rows and zeros on the uncond rows
+    (modules/sd_samplers_cfg_denoiser.py:192-194; the oracle CFG denoiser is pinned on it, tests/golden/cfg_denoiser.npz "unclip*"); txt2img
+    feeds a zero vector of 2 x time_embed.dim (:113-115).  With AND prompts the vector is repeated per sub-prompt."""
+    import types
+    from oracle import pipeline as opipe, unet as ou, vae as ov
+    schema, processing = sub("schema"), sub("processing")
+    ucfg, vcfg = schema.tiny_unet(adm_in_channels=24), schema.tiny_vae()
+    sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16, seed=0x2B7)
+    we = torch.randn(3, 12, generator=torch.Generator().manual_seed(31))
+    embedder = lambda im: torch.tanh(im.mean(dim=(2, 3)) @ we.to(im.device) * 4.0)
+    augment = types.SimpleNamespace(time_embed=types.SimpleNamespace(dim=12))
+    noise_augmentor = lambda c, noise_level: (c * 0.9 + 0.01 * noise_level[:, None], torch.sin(3.0 * c))
+    noise_augmentor_obj = type("NA", (), {"time_embed": augment.time_embed, "__call__": staticmethod(noise_augmentor)})()
+    model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0, conditioning_key="crossattn-adm", embedder=embedder, noise_augmentor=noise_augmentor_obj)
+    assert not model.is_sdxl and model.model.conditioning_key == "crossattn-adm"
+    om = opipe.OracleModel(sd, ou.tiny_config(adm_in_channels=24), ov.tiny_vae_config())
+    g = torch.Generator().manual_seed(14)
+    cond, uncond = torch.randn(3 if and_prompts else 2, 77, 64, generator=g), torch.randn(2, 77, 64, generator=g)
+    conds_list = [[(0, 1.0), (1, 0.7)], [(2, 1.0)]] if and_prompts else None
+    c_arg = (conds_list, cond) if and_prompts else cond
+    img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(24)).half().float()
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=c_arg, uc=uncond, seed=940, batch_size=2, steps=5, cfg_scale=6.0,
+                                                    width=128, height=128, sampler_name="Euler a", init_images=img, denoising_strength=0.8)
+    res = processing.process_images(p)
+    e = embedder(img * 2 - 1)
+    c_adm = torch.cat([e * 0.9, torch.sin(3.0 * e)], 1)
+    assert tuple(p.image_conditioning_all.shape) == (2, 24) and rel_l2(p.image_conditioning_all.cpu(), c_adm) < 1e-5
+    init = om.vae.encode_first_stage_mean(img * 2 - 1)
+    y = c_adm if not and_prompts else torch.stack([c_adm[0], c_adm[0], c_adm[1]])
+    lat = opipe.sample(om, c_arg, uncond, [940, 941], 5, "euler_a", 6.0, (16, 16), init_latent=init, denoising_strength=0.8,
+                       img2img_steps_given=False, y=y, uy=torch.zeros_like(c_adm))
+    assert rel_l2(res.latents.cpu(), lat) < 1.5e-2
+    same_uy = opipe.sample(om, c_arg, uncond, [940, 941], 5, "euler_a", 6.0, (16, 16), init_latent=init, denoising_strength=0.8,
+                           img2img_steps_given=False, y=y, uy=c_adm)
+    assert rel_l2(same_uy, lat) > 1e-2                        # zeros on the uncond rows, not the embedding
+    if not and_prompts:                                       # txt2img: zero c_adm of 2 x time_embed.dim
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond, uc=uncond, seed=950, batch_size=2, steps=4, cfg_scale=6.0,
+                                                        width=128, height=128, sampler_name="Euler a")
+        res = processing.process_images(p)
+        z = torch.zeros(2, 24)
+        lat = opipe.sample(om, cond, uncond, [950, 951], 4, "euler_a", 6.0, (16, 16), y=z, uy=z)
+        assert rel_l2(res.latents.cpu(), lat) < 1e-2
+    model.engine.close()
+
+
 def test_img2img_masked_content_fills_and_noise_multiplier(dev, tiny):
     """inpainting_fill 2 / 3 ("latent noise" / "latent nothing", processing.py:1747-1753) rewrite the masked part of the init
     latent before sampling; initial_noise_multiplier scales the img2img noise (:1762-1764)."""

@@ -236,13 +236,14 @@ def _golden_module():
 
 
 def test_cfg_denoiser_matches_reference(golden_dir):
-    """oracle CFGDenoiser == the reference class (modules/sd_samplers_cfg_denoiser.py:35-311) executed by make_golden over twenty
+    """oracle CFGDenoiser == the reference class (modules/sd_samplers_cfg_denoiser.py:35-311) executed by make_golden over twenty-two
     scenarios: plain CFG, AND composition, NGMS / skip-early skip-uncond (odd, even, all steps, sigma above the threshold, with
     AND), mask before / after, cond and uncond of different token counts (two calls, pad_cond_uncond, pad_cond_uncond_v0, both
-    directions), CFG++ bookkeeping, unbatched cond / uncond, InstructPix2Pix three-way CFG and its scale-1 fallback."""
+    directions), CFG++ bookkeeping, unbatched cond / uncond, InstructPix2Pix three-way CFG and its scale-1 fallback, unCLIP's c_adm rows
+    (zeros for uncond; with AND + NGMS)."""
     mg = _golden_module()
     z = np.load(os.path.join(golden_dir, "cfg_denoiser.npz"))
-    assert len(mg.CFG_SCENARIOS) == 20
+    assert len(mg.CFG_SCENARIOS) == 22
     for k, (name, sc) in enumerate(mg.CFG_SCENARIOS):
         inp = mg.cfg_scenario_inputs(k, sc)
         d = kd.CFGDenoiser(lambda xi, si, c, ic: mg.cfg_inner_model(xi, si, c, ic))
@@ -251,6 +252,7 @@ def test_cfg_denoiser_matches_reference(golden_dir):
                 setattr(d, key, val)
         d.empty_prompt, d.step, d.total_steps = inp["empty"], sc.get("step", 0), sc.get("total_steps", 20)
         d.image_cfg_scale, d.is_edit_cond_stage = sc.get("image_cfg_scale"), bool(sc.get("edit"))
+        d.adm = bool(sc.get("adm"))
         d.cond_scale_miltiplier = sc.get("cond_scale_miltiplier", 1.0)
         d.need_last_noise_uncond = sc.get("need_last_noise_uncond", False)
         d.mask_before_denoising = sc.get("mask_before", False)
