@@ -531,6 +531,7 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "vt_mode") g_vt_mode = value;
     else if (n == "tile_order") g_tile_order = value;
     else if (n == "conv_korder") g_conv_korder = value < 0 ? g_conv_korder_default : value;
+    else if (n == "small_linear_lds") g_small_linear_lds = value;
     else if (n == "gn_fuse") g_gn_fuse = value;
     else if (n == "gn_small") g_gn_small = value;
     else if (n == "ep_wide") g_ep_wide = value;

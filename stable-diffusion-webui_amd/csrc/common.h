@@ -123,6 +123,7 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
 int launch_gemm(const GemmP& p, int batch, bool force_generic, bool use_glds, hipStream_t s, int* stats_nchunk_out = nullptr,
                 int* lnp_np_out = nullptr);      // lnp_np_out: partial pairs per row written to p.lnp_out, 0 when not produced
 extern int g_ep_wide;               // 1 (default): 16-byte epilogue accesses where the alignment allows; 0: always 8-byte
+extern int g_small_linear_lds;      // 1 (default): small_linear stages the activation block in LDS (elementwise.hip); 0: wave-per-column form
 extern int g_gn_small;              // 1 (default): single-launch register-resident GroupNorm for the small levels (norm.hip gn_fused_small_kernel)
 extern int g_gn_fuse;               // 1 (default): GroupNorm statistics from the producing GEMM's epilogue where possible; 0: always a stats pass
 // debug / tuning knobs (sdmi_debug_set): forced GEMM tile config (-1 = heuristic), attention KV tile (0 = heuristic)

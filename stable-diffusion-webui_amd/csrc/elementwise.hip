@@ -6,7 +6,9 @@
 //     (/root/reference/modules/sd_hijack_unet.py:58-78), small-M linear layers (time embedding MLP), row softmax (VAE
 //     mid attention), weight repacking, final uint8 conversion (/root/reference/modules/processing.py:1004-1005,1034-1035).
 #include "common.h"
+#include "prof.h"
 #include <algorithm>
+#include <cstdio>
 
 // The sampler / RNG arithmetic mirrors separately-rounded torch / numpy ops: never contract a*b+c into an fma here.
 #pragma clang fp contract(off)
@@ -768,6 +770,81 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* a, const
         }
     }
 }
+// Round 4: the same product with the activations staged ONCE per workgroup in LDS (fp32 [B][K], silu applied while staging) and four
+// output columns per wave and pass, so an activation value read from LDS feeds four fmas.  The wave-per-column kernel above re-reads
+// the B x K activation block from L1 / L2 for every column — 80 KB per 2.5 KB weight row on the fused ResBlock embedding projection
+// (16 x 1280 -> 17920: 1.4 GB of cache reads per launch, ~150 us for 46 MB of weights).  Per output the lane -> k assignment, the fma
+// order and the shuffle tree are the kernel above's: identical bits (tests/test_gpu_ops.py).
+template <int BMAX, int CW>
+__global__ __launch_bounds__(256) void small_linear_lds_kernel(const float* a, const half_t* w, const float* bias, const float* add,
+                                                              float* out, int B, int N, int K, int lda, int ldo, int silu_in,
+                                                              int silu_out) {
+    extern __shared__ __attribute__((aligned(16))) float sa[];            // [BMAX][K]; rows >= B are zero (computed, never stored)
+    for (int idx = threadIdx.x * 4; idx < BMAX * K; idx += 256 * 4) {       // K % 8 == 0: a quad never straddles rows
+        const int b = idx / K, k = idx - b * K;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < B) {
+            v = *reinterpret_cast<const f4*>(a + (long)b * lda + k);
+            if (silu_in) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+            }
+        }
+        *reinterpret_cast<f4*>(sa + idx) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int n0 = wave * CW; n0 < N; n0 += nwaves * CW) {
+        float acc[BMAX][CW];
+#pragma unroll
+        for (int i = 0; i < BMAX; ++i)
+#pragma unroll
+            for (int c = 0; c < CW; ++c) acc[i][c] = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            float wf[CW][8];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const h8 wv = *reinterpret_cast<const h8*>(w + (long)min(n0 + c, N - 1) * K + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wf[c][e] = (float)wv[e];
+            }
+#pragma unroll
+            for (int i = 0; i < BMAX; ++i) {
+                const f4 a0 = *reinterpret_cast<const f4*>(sa + i * K + k), a1 = *reinterpret_cast<const f4*>(sa + i * K + k + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float av = e < 4 ? a0[e] : a1[e - 4];
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) acc[i][c] = fmaf(av, wf[c][e], acc[i][c]);
+                }
+            }
+        }
+        // the xor butterfly leaves the full sum in EVERY lane (both partners add the same two values at each level), so lane
+        // i * CW + c keeps output (i, c) and the BMAX * CW results leave in one guarded store per lane
+        float mine = 0.f;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                         // (the 64 lane masks below are loop-invariant: hoisted they spill 72 SGPRs)
+#pragma unroll
+        for (int i = 0; i < BMAX; ++i) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                float v = acc[i][c];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                mine = ln == i * CW + c ? v : mine;
+            }
+        }
+        const int oi = lane / CW, n = n0 + lane % CW;
+        if (lane < BMAX * CW && oi < B && n < N) {
+            float v = mine + (bias ? bias[n] : 0.f);
+            if (silu_out) v = v / (1.0f + expf(-v));
+            if (add) v += add[(long)oi * ldo + n];
+            out[(long)oi * ldo + n] = v;
+        }
+    }
+}
+int g_small_linear_lds = [] { const char* e = getenv("SDMI_SMALL_LINEAR_LDS"); return e ? atoi(e) : 1; }();
+
 // y = silu(x) elementwise fp32 (same expression as small_linear's silu_in, so hoisting it out changes no bits)
 __global__ __launch_bounds__(256) void silu_f32_kernel(const float* x, float* y, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -822,6 +899,23 @@ int launch_axpy_f16(half_t* y, const half_t* x, const half_t* h, float a, int64_
 int launch_small_linear(const float* a, const half_t* w, const float* bias, const float* add, float* out, int B, int N, int K,
                         int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s) {
     SDMI_REQUIRE(K % 8 == 0 && lda % 4 == 0, "small_linear: K % 8 == 0, lda % 4 == 0");
+    char pname[64];
+    if (prof_enabled()) snprintf(pname, sizeof pname, "small_linear B%d N%d K%d", B, N, K);
+    ProfScope ps(pname, 2.0 * B * (double)N * K, (double)N * K * 2.0 + ((double)B * K + (double)B * N) * 4.0, s);     // weights once + in / out
+    const int rows = B <= 4 ? 4 : 16;
+    const size_t lds = (size_t)rows * K * sizeof(float);
+    if (g_small_linear_lds && B <= 16 && lds <= 96 * 1024 && N >= 256) {         // activations fit LDS: staged once per workgroup
+        auto kern = rows == 4 ? small_linear_lds_kernel<4, 4> : small_linear_lds_kernel<16, 4>;
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[rows == 4]) {
+            SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_set[rows == 4] = true;
+        }
+        const int blocks = std::min(cdiv(N, 16), 256);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a, w, bias, add, out, B, N, K, lda, ldo, silu_in ? 1 : 0, silu_out ? 1 : 0);
+        SDMI_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(small_linear_kernel<16>, dim3(cdiv(N, 4)), dim3(256), 0, s, a, w, bias, add, out, B, N, K, lda, ldo,
                        silu_in ? 1 : 0, silu_out ? 1 : 0);
     SDMI_CHECK_HIP(hipGetLastError());

@@ -454,3 +454,21 @@ def test_c3_sdxl_base_full_size_unet_forward_vs_oracle(dev):
                                     "reference_fp16_emulation_vs_fp32_oracle": e_emu})
     print(f"[c3 sdxl unet] engine {e:.3e}; reference fp16 emulation {e_emu:.3e}")
     assert e < 3e-3 and e < 1.1 * e_emu
+
+
+def test_c1_small_linear_lds_staged_form_gives_the_same_bits(dev, sd15):
+    """The timestep-embedding MLP and the fused ResBlock embedding projection (16 x 1280 -> 17920) run on small_linear: round 4 stages the
+    activation block in LDS once per workgroup and computes four output columns per wave and pass (csrc/elementwise.hip
+    small_linear_lds_kernel; the wave-per-column form re-read 80 KB of activations per 2.5 KB weight row).  Per output the lane -> k
+    assignment, fma order and shuffle tree are unchanged: the whole forward must come out bit for bit the same, at 16 rows and at 2."""
+    lib = sub("_lib")
+    eng = sd15["model"].engine
+    x, t, ctx = seeded((16, 4, 64, 64), 101), torch.linspace(999.0, 1.0, 16), seeded((16, 77, 768), 102)
+    outs = {}
+    try:
+        for mode in (0, 1):
+            lib.check(lib.lib.sdmi_debug_set(b"small_linear_lds", mode))
+            outs[mode] = [eng.unet_forward(x[:n].to(dev), t[:n].to(dev), ctx[:n].to(dev)).cpu() for n in (16, 2)]
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"small_linear_lds", 1))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -801,9 +801,14 @@ def test_unclip_checkpoint_conditioning_vs_oracle(dev, and_prompts):
     g = torch.Generator().manual_seed(14)
     cond, uncond = torch.randn(3 if and_prompts else 2, 77, 64, generator=g), torch.randn(2, 77, 64, generator=g)
     conds_list = [[(0, 1.0), (1, 0.7)], [(2, 1.0)]] if and_prompts else None
-    c_arg = (conds_list, cond) if and_prompts else cond
+    c_arg = (conds_list, cond) if and_prompts else cond       # what the oracle's CFG denoiser takes
+    c_job = cond
+    if and_prompts:                                           # ... and the reference's container for the same thing (prompt_parser.py)
+        hp = sub("prompt_parser")
+        one = lambda i, w: hp.ComposableScheduledPromptConditioning([hp.ScheduledPromptConditioning(99, cond[i])], w)
+        c_job = hp.MulticondLearnedConditioning((2,), [[one(0, 1.0), one(1, 0.7)], [one(2, 1.0)]])
     img = torch.rand((2, 3, 32, 32), generator=torch.Generator().manual_seed(24)).half().float()
-    p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=c_arg, uc=uncond, seed=940, batch_size=2, steps=5, cfg_scale=6.0,
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=c_job, uc=uncond, seed=940, batch_size=2, steps=5, cfg_scale=6.0,
                                                     width=128, height=128, sampler_name="Euler a", init_images=img, denoising_strength=0.8)
     res = processing.process_images(p)
     e = embedder(img * 2 - 1)

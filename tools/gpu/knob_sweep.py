@@ -21,10 +21,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PKG = "stable-diffusion-webui_amd"
-KNOBS = ("tile_order", "conv_korder", "gemm_cfg", "gemm_shortk_cfg", "gemm_shortk_maxk", "gemm_geglu_cfg", "vt_mode", "attn_kvt", "attn_occ", "gemm_split", "gemm_pipe", "gn_fuse", "gn_small", "ep_wide", "gemm_dbgflags",
+KNOBS = ("tile_order", "conv_korder", "small_linear_lds", "gemm_cfg", "gemm_shortk_cfg", "gemm_shortk_maxk", "gemm_geglu_cfg", "vt_mode", "attn_kvt", "attn_occ", "gemm_split", "gemm_pipe", "gn_fuse", "gn_small", "ep_wide", "gemm_dbgflags",
          )
 ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse")
-DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "tile_order": -1, "conv_korder": -1,
+DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1,
             "gemm_split": 0, "gemm_pipe": -1, "gn_fuse": 1, "gn_small": 1, "ep_wide": 1, "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0}
 
 
@@ -44,7 +44,7 @@ def classify(name):
         if re.search(r" x\d+$", name):
             return "1x1_batched"
         return "1x1"
-    for p in ("attention_mfma_self", "attention_mfma_cross", "groupnorm", "layernorm", "splitk"):
+    for p in ("attention_mfma_self", "attention_mfma_cross", "groupnorm", "layernorm", "splitk", "small_linear"):
         if name.startswith(p):
             return p
     return "other"
@@ -138,6 +138,9 @@ def main():
                 print(f"    {g_:24s} {a[0]:8.2f} ms  n={a[2]:5d}  {a[1] / a[0] / 1e9 if a[0] else 0:8.1f} TFLOP/s")
             out[s]["kernels"] = sorted(kernels, key=lambda k: -k["ms"])[:40]
             out[s]["conv3x3"] = sorted((k for k in kernels if classify(k["name"]) == "conv3x3"), key=lambda k: -k["ms"])
+            for k in kernels:
+                if k["name"].startswith("small_linear"):
+                    print(f"    {k['name']:40s} n={k['launches']:4d} {k['ms'] / k['launches'] * 1e3:8.1f} us / launch")
     if args.profile and len(args.settings) > 1:              # per-shape 3x3 conv times, first setting against the others
         import re
         shape = lambda n: re.search(r"M\d+ N\d+ K\d+", n).group(0)
