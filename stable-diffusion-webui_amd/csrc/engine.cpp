@@ -940,10 +940,16 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     float* emb_act = r.F((size_t)Bn * ted);              // silu(emb), computed once instead of once per output column
     float* yf = c.adm_in_channels > 0 ? r.F((size_t)Bn * c.adm_in_channels) : nullptr;
     float* l1 = c.adm_in_channels > 0 ? r.F((size_t)Bn * ted) : nullptr;
+    // Option "uniform_t" (the samplers set it: every row of a CFG batch sits at the same timestep, sd_samplers.py builds the vector with
+    // torch.full): the embedding MLP and the 20160-wide ResBlock projection run for ONE row and every image reads that row (row stride 0 of
+    // the GEMM epilogues' per-image bias).  Same arithmetic per row: identical bits.  Not with a vector conditioning (label_emb(y) differs
+    // per row).  The arena slots keep their Bn-row sizes, so the layout does not depend on the option.
+    const int Be = (r.e->uniform_t && c.adm_in_channels == 0) ? 1 : Bn;
+    const int emb_ld = Be == 1 ? 0 : u.emb_cols;
     if (!r.dry) {
-        TRY(launch_timestep_embedding(t, io_dtype, sinus, Bn, mc, r.s));
-        TRY(launch_small_linear(sinus, u.te0.w, u.te0.b, nullptr, e1, Bn, ted, mc, mc, ted, false, true, r.s));
-        TRY(launch_small_linear(e1, u.te2.w, u.te2.b, nullptr, emb, Bn, ted, ted, ted, ted, false, false, r.s));
+        TRY(launch_timestep_embedding(t, io_dtype, sinus, Be, mc, r.s));
+        TRY(launch_small_linear(sinus, u.te0.w, u.te0.b, nullptr, e1, Be, ted, mc, mc, ted, false, true, r.s));
+        TRY(launch_small_linear(e1, u.te2.w, u.te2.b, nullptr, emb, Be, ted, ted, ted, ted, false, false, r.s));
         if (c.adm_in_channels > 0) {
             SDMI_REQUIRE(y != nullptr, "this UNet needs the vector conditioning y");
             TRY(launch_convert_to_f32(y, io_dtype, yf, (int64_t)Bn * c.adm_in_channels, r.s));
@@ -952,8 +958,8 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
             TRY(launch_small_linear(l1, u.le2.w, u.le2.b, emb, emb, Bn, ted, ted, ted, ted, false, false, r.s));
         }
         // every ResBlock's emb_layers (SiLU -> Linear) in one launch
-        TRY(launch_silu_f32(emb, emb_act, (int64_t)Bn * ted, r.s));
-        TRY(launch_small_linear(emb_act, u.emb_all.w, u.emb_all.b, nullptr, embs, Bn, u.emb_cols, ted, ted, u.emb_cols,
+        TRY(launch_silu_f32(emb, emb_act, (int64_t)Be * ted, r.s));
+        TRY(launch_small_linear(emb_act, u.emb_all.w, u.emb_all.b, nullptr, embs, Be, u.emb_cols, ted, ted, u.emb_cols,
                                 false, false, r.s));
     }
     // ---- input: NCHW -> NHWC fp16, channels zero-padded to the packed conv_in width ----------------------------
@@ -983,9 +989,9 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                     if (skip && first) {
                         SDMI_REQUIRE(Lr.c0 == cur.C && Lr.c1 == skip->C, "skip concat channel mismatch");
                         SDMI_REQUIRE(cur.H == skip->H && cur.W == skip->W, "skip connection spatial mismatch");
-                        TRY(run_res(r, Lr.res, cur.p, skip->p, cur.C, skip->C, Bn, cur.H, cur.W, 1e-5f, embs, u.emb_cols, &o));
+                        TRY(run_res(r, Lr.res, cur.p, skip->p, cur.C, skip->C, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o));
                     } else {
-                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bn, cur.H, cur.W, 1e-5f, embs, u.emb_cols, &o));
+                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o));
                     }
                     cur = Act{o, Lr.res.cout, cur.H, cur.W};
                     break;

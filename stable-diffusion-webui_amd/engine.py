@@ -53,6 +53,7 @@ class Engine:
         self.unet_cfg: Optional[UNetConfig] = None
         self.vae_cfg: Optional[VAEConfig] = None
         self._ctx_key = None
+        self._uniform_t = False                               # mirror of the engine option (unet_forward)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -175,8 +176,13 @@ class Engine:
         self._ctx_shape = (bn, l)
 
     def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
-                     y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections."""
+                     y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, uniform_t: bool = False) -> torch.Tensor:
+        """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections.  ``uniform_t``: the
+        caller guarantees that all rows share one timestep (the samplers' CFG batch): the timestep-embedding path then runs for one row
+        (engine option "uniform_t"; same bits)."""
+        if uniform_t != self._uniform_t:
+            self.set_option("uniform_t", 1 if uniform_t else 0)
+            self._uniform_t = uniform_t
         x = x.contiguous()
         dt = x.dtype
         timesteps = timesteps.to(dt).contiguous()

@@ -491,14 +491,14 @@ class CFGDenoiser:
                 raise ValueError(f"vector conditioning has {y.shape[0]} rows for {n_cond} cond rows (dict conds carry one per sub-prompt)")
             yy = (y if skip_uncond else torch.cat([y, uy, uy] if is_edit_model else [y, uy])).float().contiguous()
         if split_calls:
-            eng.unet_forward(x_in[:n_cond], ts[:n_cond], tensor.float().contiguous(), None if yy is None else yy[:n_cond], out=eps[:n_cond])
-            eng.unet_forward(x_in[n_cond:], ts[n_cond:], uncond.float().contiguous(), None if yy is None else yy[n_cond:], out=eps[n_cond:])
+            eng.unet_forward(x_in[:n_cond], ts[:n_cond], tensor.float().contiguous(), None if yy is None else yy[:n_cond], out=eps[:n_cond], uniform_t=True)
+            eng.unet_forward(x_in[n_cond:], ts[n_cond:], uncond.float().contiguous(), None if yy is None else yy[n_cond:], out=eps[n_cond:], uniform_t=True)
             self._ctx_key = None
         else:
             self._ensure_context([tensor] if skip_uncond else [tensor, uncond, uncond] if is_edit_model else [tensor, uncond],
                                  [src_tensor] if skip_uncond else [src_tensor, src_uncond, src_uncond] if is_edit_model else [src_tensor, src_uncond],
                                  (self.padded_cond_uncond, self.padded_cond_uncond_v0))
-            eng.unet_forward(x_in, ts, None, yy, out=eps)
+            eng.unet_forward(x_in, ts, None, yy, out=eps, uniform_t=True)      # ts = torch.full(...): one timestep for every row
 
         # ---- combine (:73-82, :270-290).  The fused kernel takes eps = [cond(B) | uncond(B)]; the general cases are reduced to it
         # by first forming, per image, E = (1 - s*sum(w)) * eps_u + sum_j s*w_j * eps_cj (the same affine map commutes with the

@@ -472,3 +472,18 @@ def test_c1_small_linear_lds_staged_form_gives_the_same_bits(dev, sd15):
     finally:
         lib.check(lib.lib.sdmi_debug_set(b"small_linear_lds", 1))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_c1_uniform_timestep_option_gives_the_same_bits(dev, sd15):
+    """Engine option "uniform_t" (set by the samplers, whose CFG batch sits at one timestep): the timestep-embedding MLP and the ResBlock
+    embedding projection run for one row and every image reads it through a zero row stride.  Same arithmetic per row => same bits as the
+    per-row path on a batch whose rows do share the timestep; and the flag is dropped again by a call without it."""
+    eng = sd15["model"].engine
+    x, ctx = seeded((16, 4, 64, 64), 101), seeded((16, 77, 768), 102)
+    t = torch.full((16,), 481.0)
+    per_row = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
+    shared_row = eng.unet_forward(x.to(dev), t.to(dev), None, uniform_t=True).cpu()
+    assert torch.equal(per_row, shared_row)
+    t2 = torch.linspace(999.0, 1.0, 16)                       # rows at different timesteps, flag off again: the per-row path
+    a = eng.unet_forward(x.to(dev), t2.to(dev), None).cpu()
+    assert not torch.equal(a, per_row) and rel_l2(a[7], per_row[7]) > 1e-3
