@@ -588,6 +588,7 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     else if (n == "trace") { e->trace = value != 0; e->taps.clear(); }
     else if (n == "tiling") e->tiling = value != 0;
     else if (n == "uniform_t") e->uniform_t = value != 0;
+    else if (n == "cfg_pairs") e->cfg_pairs = value != 0;
     else if (n == "ln_fold") e->ln_fold = value;
     else if (n == "arena_reuse") e->arena_reuse = value;
     else if (n == "streams") { if (value < 1 || value > 8) { sdmi::set_error("streams must be 1..8"); return 1; } e->n_streams = value; }

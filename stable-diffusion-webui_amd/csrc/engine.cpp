@@ -517,7 +517,7 @@ static int run_vt_ln(Run& r, const ConvW& Wv, const NormW& n, const half_t* x, c
 // scale-invariant once eps is multiplied by ss^2, the block-internal tensors stay at true scale, and the two layers that write the
 // stream scale their accumulator (alpha) and / or bias (bias_scale).
 static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, int c0, int c1, int B, int H, int Wd,
-                   float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f) {
+                   float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f, half_t* out_buf = nullptr) {
     const int HW = H * Wd;
     const size_t M = (size_t)B * HW;
     // arena_reuse: what outlives the block — its output and the GroupNorm partial sums the last conv leaves for the next norm — is taken
@@ -551,7 +551,7 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
     } else {
         SDMI_REQUIRE(x1 == nullptr, "identity skip with a concatenated input");
     }
-    half_t* o = reuse ? o_pre : r.H(M * w.cout);
+    half_t* o = out_buf ? out_buf : (reuse ? o_pre : r.H(M * w.cout));       // (out_buf: the caller's, larger buffer — unet_run's shared CFG prefix)
     {
         ConvArgs c;
         c.a0 = t2; c.c0 = w.cout; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
@@ -671,11 +671,16 @@ static int run_hn(Run& r, int dim, int which, const half_t* x, size_t rows, Allo
     return 0;
 }
 
+// Bh > 0 (unet_run's shared CFG prefix, engine option "cfg_pairs"): rows [Bh, B) of x repeat rows [0, Bh) and differ from them only in
+// their text context, so everything in front of the first cross-attention — GroupNorm, proj_in, and norm1 / q, k, v / self-attention /
+// out-projection of the first block — is computed for Bh rows and copied to the other half; x itself holds all B rows (proj_out's residual).
 static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, int L, half_t** out,
-                  const std::string& name = std::string()) {
+                  const std::string& name = std::string(), int Bh = 0) {
     sdmi_engine* e = r.e;
     const int C = st.ch, HW = H * Wd;
     const size_t M = (size_t)B * HW;
+    int B1 = Bh > 0 ? Bh : B;                            // rows of the part in front of the first cross-attention
+    size_t M1 = (size_t)B1 * HW;
     const int Npad = rup(HW, 64);
     // arena_reuse: the output, the token stream after proj_in and two ping-pong buffers for the transformer blocks' outputs are taken
     // first; everything after the mark lives for one block (or for proj_in) only
@@ -685,12 +690,12 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     half_t* pp[2] = {reuse ? r.H(M * C) : nullptr, (reuse && st.blocks.size() > 1) ? r.H(M * C) : nullptr};
     const size_t mk = r.ar->mark();
     half_t* n0 = r.H(M * C);
-    TRY(run_gn(r, st.norm, x, nullptr, C, 0, B, HW, 1e-6f, false, n0));
+    TRY(run_gn(r, st.norm, x, nullptr, C, 0, B1, HW, 1e-6f, false, n0));
     half_t* cur = reuse ? cur_pre : r.H(M * C);
     // with "ln_fold" the GEMMs that write a LayerNorm's input also leave its row sums (Run::lnp_want; a no-op otherwise)
     const bool fold_any = e->ln_fold && !hn_has_dim(e, C) && !e->force_generic && e->use_glds && g_vt_mode == 1 && HW == Npad && HW % 4 == 0;
     r.lnp_want = fold_any && e->ln_fold >= 2;
-    TRY(run_linear(r, st.proj_in, n0, (int)M, nullptr, cur, C));
+    TRY(run_linear(r, st.proj_in, n0, (int)M1, nullptr, cur, C));
     if (reuse) r.ar->rewind(mk);
     int bi = 0, blk = 0;
     for (const TBlockW& b : st.blocks) {
@@ -712,15 +717,15 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
         }
         half_t* n1 = fold ? nullptr : r.H(M * C);
-        if (!fold) TRY(run_ln(r, b.ln1, cur, M, n1));
+        if (!fold) TRY(run_ln(r, b.ln1, cur, M1, n1));
         if (fold) {
         } else if (!hn_has_dim(e, C)) {
             half_t* qk = r.H(M * 2 * C);
-            TRY(run_linear(r, b.qk1, n1, (int)M, nullptr, qk, 2 * C));
+            TRY(run_linear(r, b.qk1, n1, (int)M1, nullptr, qk, 2 * C));
             half_t* vt = r.H((size_t)B * C * Npad);
-            TRY(run_vt(r, b.v1, n1, C, B, HW, Npad, vt, false));
+            TRY(run_vt(r, b.v1, n1, C, B1, HW, Npad, vt, false));
             a1 = r.H(M * C);
-            TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
+            TRY(run_attn(r, qk, qk + C, vt, a1, B1, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
         } else {
             // hypernetworks loaded for this width: K and V are projected from their own transformed copies of the context (= n1),
             // so the stacked q|k GEMM splits into its two halves (views into the same packed weight)
@@ -743,7 +748,11 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         }
         half_t* x1 = r.H(M * C);
         r.lnp_want = fold && e->ln_fold >= 2;
-        TRY(run_linear(r, b.o1, a1, (int)M, cur, x1, C));
+        TRY(run_linear(r, b.o1, a1, (int)M1, cur, x1, C));
+        if (B1 != B) {                                       // end of the shared prefix: the other half of the batch continues from a copy
+            if (!r.dry) SDMI_CHECK_HIP(hipMemcpyAsync(x1 + M1 * C, x1, M1 * C * sizeof(half_t), hipMemcpyDeviceToDevice, r.s));
+            B1 = B; M1 = M;
+        }
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
         half_t* q2 = nullptr;
@@ -969,14 +978,41 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
 
     std::vector<Act> hs;
     Act cur{nullptr, 0, h, w};
+    // Option "cfg_pairs" (set per call by the CFG denoiser for its plain [cond | uncond] batch): rows [Bn / 2, Bn) carry the same latent
+    // and timestep as rows [0, Bn / 2) — only the text context differs — so every layer in front of the first cross-attention gives the
+    // same result for both halves: conv_in, the first ResBlock, and GroupNorm / proj_in / norm1 / self-attention of the first transformer
+    // block (SD1.x / 2.x: the largest self-attention launch of the forward) run for Bn / 2 rows and are copied (three 21 MB device copies
+    // at the C1 batch against ~0.48 ms of kernels).  Same function; the fp32 summation order of those layers follows the halved M.
+    // Not with a vector conditioning (label_emb(y) differs per row), taps, LayerNorm fold, hypernetworks, arena reuse or batch slices.
+    const bool pairs = e->cfg_pairs && c.adm_in_channels == 0 && Bn % 2 == 0 && Bn >= 2 && !e->trace && !e->ln_fold && !r.reuse() &&
+                       e->hypernets.empty() && (r.Btot == 0 || r.Btot == Bn);
+    const int Bh = Bn / 2;
+    bool shared = pairs;                                     // cur.p: rows [0, Bh) computed, buffer sized for Bn rows
+    auto dup = [&](const Act& a) -> int {                    // copy the computed half of a full-size activation to the other half
+        const size_t n = (size_t)Bh * a.H * a.W * a.C;
+        if (!r.dry) SDMI_CHECK_HIP(hipMemcpyAsync((half_t*)a.p + n, a.p, n * sizeof(half_t), hipMemcpyDeviceToDevice, r.s));
+        return 0;
+    };
     auto run_block = [&](const std::vector<UNetLayer>& blk, const Act* skip, const std::string& bname) -> int {
         bool first = true;
         int li = 0;
         for (const UNetLayer& Lr : blk) {
             const std::string lname = bname + "." + std::to_string(li++);
+            if (shared && (Lr.kind == UNetLayer::DOWN || Lr.kind == UNetLayer::UP || (Lr.kind == UNetLayer::RES && skip && first))) {
+                TRY(dup(cur));                               // (no transformer before the first resolution change: give up the sharing here)
+                shared = false;
+            }
             switch (Lr.kind) {
                 case UNetLayer::CONV_IN: {
                     half_t* o = r.H((size_t)Bn * cur.H * cur.W * Lr.conv.n_pad);
+                    if (shared) {
+                        ConvArgs a;
+                        a.a0 = xin; a.c0 = Lr.conv.cin_pad; a.B = Bh; a.Hi = cur.H; a.Wi = cur.W; a.Ho = cur.H; a.Wo = cur.W;
+                        a.pad = 1; a.out = o; a.ldo = Lr.conv.n_pad;
+                        TRY(run_conv(r, Lr.conv, a));
+                        cur = Act{o, Lr.conv.cout, cur.H, cur.W};
+                        break;
+                    }
                     ConvArgs a;
                     a.a0 = xin; a.c0 = Lr.conv.cin_pad; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = cur.H; a.Wo = cur.W;
                     a.pad = 1; a.out = o; a.ldo = Lr.conv.n_pad;
@@ -990,6 +1026,9 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                         SDMI_REQUIRE(Lr.c0 == cur.C && Lr.c1 == skip->C, "skip concat channel mismatch");
                         SDMI_REQUIRE(cur.H == skip->H && cur.W == skip->W, "skip connection spatial mismatch");
                         TRY(run_res(r, Lr.res, cur.p, skip->p, cur.C, skip->C, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o));
+                    } else if (shared) {
+                        half_t* full = r.H((size_t)Bn * cur.H * cur.W * Lr.res.cout);
+                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bh, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, full));
                     } else {
                         TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o));
                     }
@@ -998,7 +1037,9 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                 }
                 case UNetLayer::ST: {
                     half_t* o = nullptr;
-                    TRY(run_st(r, Lr.st, cur.p, Bn, cur.H, cur.W, L, &o, lname));
+                    if (shared) TRY(dup(cur));               // proj_out adds the block's input to all Bn rows
+                    TRY(run_st(r, Lr.st, cur.p, Bn, cur.H, cur.W, L, &o, lname, shared ? Bh : 0));
+                    shared = false;
                     cur.p = o;
                     break;
                 }
@@ -1032,8 +1073,10 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     int bidx = 0;
     for (auto& blk : u.input) {
         TRY(run_block(blk, nullptr, "input_blocks." + std::to_string(bidx++)));
+        if (shared) TRY(dup(cur));                           // the skip connection is read for all Bn rows (the next block goes on with Bh)
         hs.push_back(cur);
     }
+    shared = false;                                          // (a UNet without a transformer on the way down: every hs entry is complete)
     TRY(run_block(u.middle, nullptr, "middle_block"));
     bidx = 0;
     for (auto& blk : u.output) {

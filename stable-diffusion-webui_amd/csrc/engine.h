@@ -202,6 +202,7 @@ struct sdmi_engine {
     // ff.net.0): only the per-row (mean, rstd) are computed, the normalised tensors never reach HBM.  Off by default until measured.
     int ln_fold = 0;                          // 1: row statistics from ln_rowstats_kernel; 2: also per-tile partial sums from the producing GEMMs' epilogues
     long weights_epoch = 0;                   // bumped by every in-place weight / vector update: folded copies older than this are stale
+    bool cfg_pairs = false;                   // rows [Bn/2, Bn) repeat the latent and timestep of rows [0, Bn/2): the layers in front of the first cross-attention run once (option "cfg_pairs")
     bool uniform_t = false;                   // every row of the call sits at the same timestep: the embedding path runs for one row (option "uniform_t")
     bool tiling = false;                      // p.tiling: every padded 3x3 conv wraps around (modules/sd_hijack.py:311-318)
     // activation taps (parity error budget): with `trace` on, every block output of the last forward is recorded by name

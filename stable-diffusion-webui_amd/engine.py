@@ -11,6 +11,10 @@ import torch
 from . import _lib
 from ._lib import lib, check, ptr, stream_ptr, dtype_code
 from .schema import UNET_PREFIX, VAE_PREFIX, UNetConfig, VAEConfig, unet_schema, vae_schema
+import os
+
+# SDMI_CFG_PAIRS=0 keeps the CFG denoiser's [cond | uncond] batch on the per-row path everywhere (same-box A/B, tools/gpu/knob_sweep.py)
+CFG_PAIRS = os.environ.get("SDMI_CFG_PAIRS", "1") != "0"
 
 
 def _unet_cfg_c(cfg: UNetConfig) -> _lib.UNetConfigC:
@@ -53,7 +57,8 @@ class Engine:
         self.unet_cfg: Optional[UNetConfig] = None
         self.vae_cfg: Optional[VAEConfig] = None
         self._ctx_key = None
-        self._uniform_t = False                               # mirror of the engine option (unet_forward)
+        self._uniform_t = False                               # mirrors of the engine options (unet_forward)
+        self._cfg_pairs = False
 
     def close(self):
         if getattr(self, "handle", None):
@@ -176,13 +181,20 @@ class Engine:
         self._ctx_shape = (bn, l)
 
     def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
-                     y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, uniform_t: bool = False) -> torch.Tensor:
+                     y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, uniform_t: bool = False,
+                     cfg_pairs: bool = False) -> torch.Tensor:
         """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections.  ``uniform_t``: the
         caller guarantees that all rows share one timestep (the samplers' CFG batch): the timestep-embedding path then runs for one row
         (engine option "uniform_t"; same bits)."""
         if uniform_t != self._uniform_t:
             self.set_option("uniform_t", 1 if uniform_t else 0)
             self._uniform_t = uniform_t
+        # ``cfg_pairs``: the caller guarantees rows [Bn/2, Bn) repeat the latent AND the timestep of rows [0, Bn/2) (the CFG denoiser's
+        # [cond | uncond] batch): the layers in front of the first cross-attention then run for one half (engine option "cfg_pairs")
+        cfg_pairs = bool(cfg_pairs and CFG_PAIRS)
+        if cfg_pairs != self._cfg_pairs:
+            self.set_option("cfg_pairs", 1 if cfg_pairs else 0)
+            self._cfg_pairs = cfg_pairs
         x = x.contiguous()
         dt = x.dtype
         timesteps = timesteps.to(dt).contiguous()

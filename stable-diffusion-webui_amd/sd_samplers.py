@@ -498,7 +498,9 @@ class CFGDenoiser:
             self._ensure_context([tensor] if skip_uncond else [tensor, uncond, uncond] if is_edit_model else [tensor, uncond],
                                  [src_tensor] if skip_uncond else [src_tensor, src_uncond, src_uncond] if is_edit_model else [src_tensor, src_uncond],
                                  (self.padded_cond_uncond, self.padded_cond_uncond_v0))
-            eng.unet_forward(x_in, ts, None, yy, out=eps, uniform_t=True)      # ts = torch.full(...): one timestep for every row
+            # ts = torch.full(...): one timestep for every row; plain CFG: x_in = [x | x] (prepare above) with one image conditioning
+            pairs = conds_list is None and not skip_uncond and not is_edit_model and rows == 2 * b
+            eng.unet_forward(x_in, ts, None, yy, out=eps, uniform_t=True, cfg_pairs=pairs)
 
         # ---- combine (:73-82, :270-290).  The fused kernel takes eps = [cond(B) | uncond(B)]; the general cases are reduced to it
         # by first forming, per image, E = (1 - s*sum(w)) * eps_u + sum_j s*w_j * eps_cj (the same affine map commutes with the

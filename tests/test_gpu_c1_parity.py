@@ -487,3 +487,30 @@ def test_c1_uniform_timestep_option_gives_the_same_bits(dev, sd15):
     t2 = torch.linspace(999.0, 1.0, 16)                       # rows at different timesteps, flag off again: the per-row path
     a = eng.unet_forward(x.to(dev), t2.to(dev), None).cpu()
     assert not torch.equal(a, per_row) and rel_l2(a[7], per_row[7]) > 1e-3
+
+
+def test_c1_cfg_pairs_shared_prefix_vs_per_row_forward_and_oracle(dev, sd15):
+    """Engine option "cfg_pairs" (set by the CFG denoiser for its [cond | uncond] batch: both halves carry the same latent and timestep):
+    conv_in, the first ResBlock and GroupNorm / proj_in / norm1 / self-attention of the first transformer block run for 8 of the 16 rows and
+    are copied.  Same function as the per-row forward (those layers are realised at half the GEMM M: agreement to fp16 rounding, not
+    bitwise), still inside the forward tolerance against the fp32 oracle, deterministic, and — with equal contexts in both halves — the
+    two halves come out bit for bit the same (the copy lands where the second half is read)."""
+    eng, net = sd15["model"].engine, sd15["unet"]
+    x8, ctx = seeded((8, 4, 64, 64), 101), seeded((16, 77, 768), 102)
+    x, t = torch.cat([x8, x8]), torch.full((16,), 481.0)
+    per_row = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
+    shared = eng.unet_forward(x.to(dev), t.to(dev), None, uniform_t=True, cfg_pairs=True).cpu()
+    again = eng.unet_forward(x.to(dev), t.to(dev), None, uniform_t=True, cfg_pairs=True).cpu()
+    assert torch.equal(shared, again) and not torch.equal(shared, per_row)
+    e_pair = rel_l2(shared, per_row)
+    with torch.no_grad():
+        ref = net(x[[0, 8]], t[[0, 8]], ctx.half().float()[[0, 8]])
+    e_shared, e_rows = rel_l2(shared[[0, 8]], ref), rel_l2(per_row[[0, 8]], ref)
+    ctx_same = torch.cat([ctx[:8], ctx[:8]])
+    twin = eng.unet_forward(x.to(dev), t.to(dev), ctx_same.to(dev), uniform_t=True, cfg_pairs=True).cpu()
+    report("unet_c1_cfg_pairs", {"shared_prefix_vs_per_row_rel_l2": e_pair, "shared_prefix_vs_fp32_oracle_rows_0_8": e_shared,
+                                 "per_row_vs_fp32_oracle_rows_0_8": e_rows})
+    print(f"[c1 cfg_pairs] shared vs per-row {e_pair:.3e}; vs oracle {e_shared:.3e} (per-row path {e_rows:.3e})")
+    assert torch.equal(twin[:8], twin[8:])
+    assert e_pair < 2.5e-3 and e_shared < 2e-3
+    eng.unet_forward(x.to(dev), t.to(dev), None)              # (leaves both per-call options off for the tests that follow)

@@ -24,7 +24,7 @@ PKG = "stable-diffusion-webui_amd"
 KNOBS = ("tile_order", "conv_korder", "small_linear_lds", "gemm_cfg", "gemm_shortk_cfg", "gemm_shortk_maxk", "gemm_geglu_cfg", "vt_mode", "attn_kvt", "attn_occ", "gemm_split", "gemm_pipe", "gn_fuse", "gn_small", "ep_wide", "gemm_dbgflags",
          )
 ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse")
-DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1,
+DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1, "cfg_pairs": 1,
             "gemm_split": 0, "gemm_pipe": -1, "gn_fuse": 1, "gn_small": 1, "ep_wide": 1, "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0}
 
 
@@ -83,6 +83,9 @@ def main():
                 k, v = kv.split("=")
                 vals[k] = int(v)
         for k, v in vals.items():
+            if k == "cfg_pairs":                               # read by Engine.unet_forward per call (the CFG denoiser asks for it)
+                sub("engine").CFG_PAIRS = bool(v)
+                continue
             if k in ENGINE_OPTS:
                 try:
                     model.engine.set_option(k, v)
