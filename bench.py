@@ -571,6 +571,25 @@ def main():
             dropin = round(dropin_path(args, model, jobs=min(3, max(1, args.steps))), 4)
         except Exception as ex:                                # the drop-in stand-in must never cost the bench line
             dropin = f"failed: {type(ex).__name__}: {ex}"
+    per_row = None
+    if rank == 0 and world == 1 and not args.no_dropin:
+        # transparency leg: the same job with the CFG denoiser's common-subexpression options off — every UNet row computed on its own, as the
+        # reference does (engine.CFG_PAIRS: the layers in front of the first cross-attention run for both halves of the [cond | uncond] batch)
+        eng_mod = importlib.import_module(PKG + ".engine")
+        prev_pairs = eng_mod.CFG_PAIRS
+        try:
+            eng_mod.CFG_PAIRS = False
+            run_once()
+            torch.cuda.synchronize(); t1 = time.time()
+            n_jobs = min(3, max(1, args.steps))
+            for _ in range(n_jobs):
+                run_once()
+            torch.cuda.synchronize()
+            per_row = round(args.batch * n_jobs / (time.time() - t1), 4)
+        except Exception as ex:
+            per_row = f"failed: {type(ex).__name__}: {ex}"
+        finally:
+            eng_mod.CFG_PAIRS = prev_pairs
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_isolated(args)
@@ -597,6 +616,10 @@ def main():
                    "weights_collectives": par.COLLECTIVES["weights"], "collectives_per_job": collectives_per_job,
                    "shard_check": shard_check,
                    "algorithmic_tflop_per_image": tflop_per_image,
+                   "cfg_pairs": "on (samplers' default): both halves of the CFG batch share latent and timestep, so conv_in, the first ResBlock and "
+                                "GroupNorm / proj_in / norm1 / self-attention of the first transformer block are computed once per image and copied; every "
+                                "row's output is produced (DESIGN.md 9.1)",
+                   "images_per_s_every_row_computed": per_row,
                    "dropin_images_per_s": dropin,
                    "dropin_path": "torch stand-in of the reference's CFGDenoiser + Euler-a loop calling Mi355xUnet.forward per step + engine VAE decode (bench.py dropin_path)",
                    "whole_job_mfma_frac": round(value / world * tflop_per_image / MFMA_PEAK_TFLOPS, 4) if tflop_per_image else None},
