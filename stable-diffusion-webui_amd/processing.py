@@ -118,14 +118,13 @@ class StableDiffusionProcessing:
             from ldm.data.util import AddMiDaS
         except ImportError as e:
             raise NotImplementedError("depth2img conditioning needs ldm.data.util.AddMiDaS (present in a webui install)") from e
-        from einops import rearrange, repeat
-        transformer = AddMiDaS(model_type="dpt_hybrid")
-        transformed = transformer({"jpg": rearrange(source_image[0], "c h w -> h w c")})
-        midas_in = torch.from_numpy(transformed["midas_in"][None, ...]).to(device=source_image.device)
-        midas_in = repeat(midas_in, "1 ... -> n ...", n=self.batch_size)
-        conditioning = torch.nn.functional.interpolate(depth_model(midas_in), size=tuple(latent_hw), mode="bicubic", align_corners=False)
-        (depth_min, depth_max) = torch.aminmax(conditioning)
-        return (2. * (conditioning - depth_min) / (depth_max - depth_min) - 1.).float().contiguous()
+        # the FIRST image's MiDaS input stands for the whole batch, as in the reference (:307-309)
+        sample = AddMiDaS(model_type="dpt_hybrid")({"jpg": source_image[0].permute(1, 2, 0)})       # HWC in [-1, 1] -> the network's CHW input
+        midas_in = torch.from_numpy(sample["midas_in"]).to(device=source_image.device)
+        depth = depth_model(midas_in.unsqueeze(0).repeat(self.batch_size, 1, 1, 1))
+        depth = torch.nn.functional.interpolate(depth, size=tuple(latent_hw), mode="bicubic", align_corners=False)
+        lo, hi = torch.aminmax(depth)
+        return (2. * (depth - lo) / (hi - lo) - 1.).float().contiguous()
 
     def unclip_image_conditioning(self, source_image):
         """:327-333: c_adm = CLIP image embedding of the source image (+ the noise-level embedding at level 0) — the host's

@@ -103,6 +103,20 @@ int main(int argc, char** argv) {
             printf("    %-10s %8.1f us %8.1f TFLOP/s  rel-L2 vs generic %.2e%s\n", cname[c], ms * 1000.f, flop / ms * 1e-9, rel,
                    ok ? "" : (nan ? "  <-- NaN / unwritten" : "  <-- MISMATCH"));
         }
+        // the register-staged form of the two-stage tiles (global_load_dwordx4 -> VGPR -> ds_write_b128 instead of LDS-direct loads): is the
+        // LDS-DMA path what bounds these shapes?  (force_generic = 2; timing only, the bits are the LDS-direct kernel's: tests/test_gpu_ops.py)
+        if (argc > 2) {
+            for (int c = 0; c < ncfg; ++c) {
+                if (cfgs[c] == 12 || cfgs[c] == 11 || cfgs[c] == 13 || cfgs[c] == 10 || cfgs[c] == 8) continue;      // ring / ping-pong: LDS-direct only
+                SDMI_OK(sdmi_debug_set("gemm_cfg", cfgs[c]));
+                d.out = o; d.force_generic = 2;
+                if (sdmi_conv_gemm(&d, nullptr) != 0) continue;
+                HIP_OK(hipDeviceSynchronize());
+                float ms = 0.f;
+                SDMI_OK(sdmi_bench_conv_gemm(&d, iters, &ms, nullptr));
+                printf("    %-10s %8.1f us %8.1f TFLOP/s  (register-staged)\n", cname[c], ms * 1000.f, flop / ms * 1e-9);
+            }
+        }
         // ring tiles against their two-stage twins: same bits
         const int twins[][2] = {{1, 2}, {3, 4}, {5, 6}, {5, 7}};
         for (auto& t : twins) {
