@@ -702,6 +702,28 @@ def test_pingpong_gemm_isa_keeps_counted_waits(tmp_path):
         assert "scratch_" not in loop, "register spill inside the K loop (scratch traffic would disturb the vmcnt accounting)"
 
 
+def test_row_shared_conv_kernel_isa_is_one_loop_with_counted_waits():
+    """gemm_mfma_pingpong_dx_kernel (the default 3x3 walk): its K loop must stay ONE copy of four (two) phases whose only waits are the
+    counted ones of the header — BU, BU + 2, BU + 4 (PH = 2: BU, BU + 1, BU + 2) and the tail's 0.  Two round-4 variants compiled into
+    something else and lost 30-40 % without a single spill being reported: dx as a compile-time constant tripled the body (accumulators
+    renamed across it), a second group order behind a runtime flag made the compiler clone the loop.  Checked on the cross-compiled ISA:
+    MFMA count of the loop = one K tile, the counted waits present, no scratch, no lane spill traffic."""
+    import re
+    text = _gfx950_assembly("gemm")
+    for bm, bn, phases, st in [(256, 320, 4, 0), (256, 320, 4, 1), (256, 256, 4, 0), (128, 320, 2, 0), (128, 320, 2, 1)]:
+        m = re.search(r"^_ZN4sdmi28gemm_mfma_pingpong_dx_kernelILi%dELi%dELb%dEEEvNS_5GemmPE:[^\n]*\n(.*?)\.Lfunc_end" % (bm, bn, st), text, re.S | re.M)
+        assert m, f"row-shared kernel <{bm},{bn},{st}> not found in the assembly"
+        body = m.group(1)
+        loop = body[body.index("s_setprio 1"):body.rindex("s_setprio 0")]
+        bu, na = bn // 64, 4 if phases == 4 else 2
+        assert loop.count("s_setprio 1") == phases and loop.count("v_mfma_f32_16x16x32_f16") == phases * 4 * (bn // 64), (bm, bn, st)
+        for n in (bu, bu + na // 2, bu + na):
+            assert f"s_waitcnt vmcnt({n})" in loop, (bm, bn, st, n)
+        assert set(re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop)) <= {str(v) for v in (0, bu, bu + na // 2, bu + na)}, (bm, bn, st)
+        assert "scratch_" not in loop and "v_readlane" not in loop and "v_writelane" not in loop, (bm, bn, st)
+        assert body.count("v_mfma_f32_16x16x32_f16") == phases * 4 * (bn // 64), "the K loop was cloned / unrolled"
+
+
 def test_oracle_pipeline_batch_invariance():
     """Image i of a batch equals that image generated alone (per-image generators, modules/rng.py:108)."""
     schema = sub("schema")
