@@ -25,6 +25,9 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                   on the launch stream in a separate profiled pass of the same job; "traffic" = HBM bytes per launch of that family
                   from the rocprofv3 PMC passes of THIS workload when tools/gpu/profile.sh has produced them (else null)
   "cpu_baseline": the fp32 CPU oracle (restated reference path) timed on this host on a bounded sample.
+`config.images_per_s_every_row_computed` re-times a few jobs with the CFG denoiser's common-subexpression option off (`cfg_pairs`: the
+layers in front of the first cross-attention are the same function value for the cond and the uncond row of an image and are computed
+once — every row's output is still produced), `config.dropin_images_per_s` the same job through the B1 / B4 boundaries.
 """
 import argparse
 import ctypes
