@@ -23,7 +23,9 @@ N(0,1) conditioning; the text encoder is outside the path).  Weights are generat
 Prints ONE JSON line on rank 0 with the contract fields plus
   "roofline":     the implicit-GEMM MFMA kernel family's achieved TFLOP/s vs the 2.5 PFLOP/s dense fp16 peak — per-launch HIP events
                   on the launch stream in a separate profiled pass of the same job; "traffic" = HBM bytes per launch of that family
-                  from the rocprofv3 PMC passes of THIS workload when tools/gpu/profile.sh has produced them (else null)
+                  from two rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE; kernel trace only) of one job of THIS workload, taken by
+                  this run in child processes on the headline workload wherever rocprofv3 exists (--pmc-traffic / --no-pmc-traffic;
+                  null when the passes were skipped or failed — a figure from another box is never reported)
   "cpu_baseline": the fp32 CPU oracle (restated reference path) timed on this host on a bounded sample.
 `config.images_per_s_every_row_computed` re-times a few jobs with the CFG denoiser's common-subexpression option off (`cfg_pairs`: the
 layers in front of the first cross-attention are the same function value for the cond and the uncond row of an image and are computed
@@ -68,9 +70,12 @@ def sub(name):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--pmc-traffic", action="store_true",
+    ap.add_argument("--pmc-traffic", action="store_true", default=None,
                     help="take the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of one job of this workload before the roofline block, so "
-                         "that roofline.traffic is measured in this run (adds ~2-3 minutes; rank 0, N = 1)")
+                         "that roofline.traffic is measured in this run (two child processes of one job each, ~25 s per pass on the C1 job; "
+                         "rank 0, N = 1).  Default: on for the headline workload (c1) when rocprofv3 is on PATH, off for the other configs")
+    ap.add_argument("--no-pmc-traffic", dest="pmc_traffic", action="store_false", help="skip the PMC passes: roofline.traffic is null")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0, help="wall limit of one PMC pass (seconds); a pass that exceeds it leaves traffic null")
     ap.add_argument("--verify-shards", action="store_true",
                     help="N > 1: after the timed region, replay every rank's slice on rank 0 and compare with the gathered images (config.shard_check)")
     ap.add_argument("--steps", type=int, default=3, help="timed jobs (one job = the global batch through the whole path)")
@@ -252,8 +257,8 @@ def pmc_traffic(args):
 def pmc_child_args(argv):
     """The command line of the one-job child a PMC pass profiles: this run's workload flags, without the flags that shape the timed
     region or start further children."""
-    drop_with_value = ("--steps", "--warmup", "--gpus", "--cpu-baseline-budget", "--cpu-baseline-timeout")
-    drop_flags = ("--pmc-traffic", "--verify-shards", "--no-cpu-baseline", "--no-roofline", "--no-dropin")
+    drop_with_value = ("--steps", "--warmup", "--gpus", "--cpu-baseline-budget", "--cpu-baseline-timeout", "--pmc-timeout")
+    drop_flags = ("--pmc-traffic", "--no-pmc-traffic", "--verify-shards", "--no-cpu-baseline", "--no-roofline", "--no-dropin")
     child, skip = [], False
     for a in argv:
         if skip:
@@ -265,7 +270,7 @@ def pmc_child_args(argv):
         if a in drop_flags or any(a.startswith(k + "=") for k in drop_with_value):
             continue
         child.append(a)
-    return child + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin"]
+    return child + ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin", "--no-pmc-traffic"]
 
 
 def measure_pmc_traffic(args):
@@ -288,10 +293,20 @@ def measure_pmc_traffic(args):
         d = os.path.join(out_dir, f"prof_pmc_{tag}")
         shutil.rmtree(d, ignore_errors=True)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + child
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            _, err = proc.communicate(timeout=args.pmc_timeout)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, 9)                   # the profiler's own session: rocprofv3 and the python child it started
+            except Exception:
+                proc.kill()
+            proc.wait()
+            print(f"bench.py: PMC pass {counter} stopped at the {args.pmc_timeout:.0f} s wall limit", file=sys.stderr)
+            return None
         dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
-        if r.returncode != 0 or not dbs:
-            print(f"bench.py: PMC pass {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-400:]}", file=sys.stderr)
+        if proc.returncode != 0 or not dbs:
+            print(f"bench.py: PMC pass {counter} failed (rc {proc.returncode}): {err.decode(errors='replace')[-400:]}", file=sys.stderr)
             return None
         acc = collections.defaultdict(lambda: [0, 0.0])
         con = sqlite3.connect(dbs[0])
@@ -343,6 +358,13 @@ def roofline_block(args, run_once):
                              "tflops": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 2)},
         "traffic": pmc_traffic(args)[0], "traffic_source": pmc_traffic(args)[1],
     }
+    # the same family's ALGORITHMIC bytes per launch (activations read once + weights + output written once: launch_gemm's ProfScope
+    # figure), so that the measured traffic reads as a ratio: well above 1 = re-reads
+    alg_bytes = sum(k.get("bytes", 0) for k in fam)
+    if alg_bytes and launches:
+        block["traffic_algorithmic"] = round(alg_bytes / launches)
+        if block["traffic"]:
+            block["traffic_over_algorithmic"] = round(block["traffic"] / (alg_bytes / launches), 3)
     return block, kernels
 
 
@@ -556,6 +578,9 @@ def main():
                     bad.append(r)
             shard_check = "ok" if not bad and len(whole.images) == args.batch * world else f"MISMATCH on the slices of ranks {bad}"
         par.barrier()
+    if args.pmc_traffic is None:                           # default: measured for the headline workload wherever the profiler exists
+        import shutil
+        args.pmc_traffic = args.config == "c1" and args.named and shutil.which("rocprofv3") is not None
     if args.pmc_traffic and rank == 0 and world == 1 and not args.no_roofline:
         try:
             measure_pmc_traffic(args)

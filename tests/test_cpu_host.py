@@ -1030,9 +1030,15 @@ def test_bench_pmc_child_command_line(monkeypatch):
     monkeypatch.syspath_prepend(ROOT)
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     bench = importlib.import_module("bench")
-    got = bench.pmc_child_args(["--config", "c3", "--steps", "5", "--warmup=2", "--pmc-traffic", "--gpus", "1", "--verify-shards", "--no-cpu-baseline"])
-    assert got == ["--config", "c3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin"]
+    got = bench.pmc_child_args(["--config", "c3", "--steps", "5", "--warmup=2", "--pmc-traffic", "--gpus", "1", "--verify-shards", "--no-cpu-baseline",
+                                "--pmc-timeout", "60"])
+    assert got == ["--config", "c3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline", "--no-dropin", "--no-pmc-traffic"]
     args = bench.parse()
+    assert args.pmc_traffic is None                       # resolved in main(): on for the named c1 workload where rocprofv3 exists
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-pmc-traffic"])
+    assert bench.parse().pmc_traffic is False
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--pmc-traffic"])
+    assert bench.parse().pmc_traffic is True
     path = os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
     if not os.path.exists(path):
         assert bench.pmc_traffic(args) == (None, None)
