@@ -580,7 +580,10 @@ def main():
         par.barrier()
     if args.pmc_traffic is None:                           # default: measured for the headline workload wherever the profiler exists
         import shutil
-        args.pmc_traffic = args.config == "c1" and args.named and shutil.which("rocprofv3") is not None
+        # (not when this process is itself being profiled: the children would inherit the outer tool's environment)
+        profiled = any(k in os.environ for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")) or \
+            any(k.startswith(("ROCPROF_", "ROCPROFV3_")) for k in os.environ)
+        args.pmc_traffic = args.config == "c1" and args.named and not profiled and shutil.which("rocprofv3") is not None
     if args.pmc_traffic and rank == 0 and world == 1 and not args.no_roofline:
         try:
             measure_pmc_traffic(args)
