@@ -14,7 +14,9 @@ from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
-import torch
+
+# torch is imported where tensors are made (synthetic_state_dict, make_alphas_cumprod): the schemas themselves are plain Python, so the
+# torch-free kernel harness (tools/gpu/fwd_ab.py) can import this module without paying for `import torch` on a fresh GPU box
 
 UNET_PREFIX = "model.diffusion_model."
 VAE_PREFIX = "first_stage_model."
@@ -365,17 +367,20 @@ def vae_schema(cfg: VAEConfig) -> List[Entry]:
 
 def make_alphas_cumprod(linear_start=0.00085, linear_end=0.0120, n=1000) -> torch.Tensor:
     """ldm 'linear' schedule (configs/v1-inference.yaml:5-9; restated in-tree at ddpm_edit.py:133-154)."""
+    import torch
     betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n, dtype=torch.float64) ** 2
     return torch.tensor(np.cumprod(1.0 - betas.numpy(), axis=0), dtype=torch.float32)
 
 
 def synthetic_state_dict(unet_cfg: Optional[UNetConfig] = None, vae_cfg: Optional[VAEConfig] = None,
-                         seed: int = 0x5D15, dtype=torch.float16, device="cpu", clip_cfg: Optional["ClipConfig"] = None) -> dict:
+                         seed: int = 0x5D15, dtype=None, device="cpu", clip_cfg: Optional["ClipConfig"] = None) -> dict:
     """Seeded synthetic checkpoint in the reference's state-dict schema (no checkpoint exists offline).
 
     Values are generated in fp32 on ``device`` then cast to ``dtype`` (fp16 = what ``model.half()`` leaves in a
     loaded checkpoint, modules/sd_models.py:482-486); ``alphas_cumprod`` stays fp32 as in the reference.
     """
+    import torch
+    dtype = torch.float16 if dtype is None else dtype
     g = torch.Generator(device="cpu").manual_seed(seed)
     sd = {}
 

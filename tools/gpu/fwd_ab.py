@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Torch-free, same-process A/B of runtime knobs on the UNet forward of the headline workload (SD1.5, 64x64 latent, 16-row CFG batch).
+
+    python tools/gpu/fwd_ab.py base conv_korder=0 "gn_cat=1" ... [--reps 3] [--fwd 10] [--profile] [--model sd15|sdxl|tiny] [--hw 64]
+
+The C1 job is 20 such forwards + one VAE decode (the forwards are ~95 % of it), so a knob that moves the forward moves the job; what the
+whole-job sweep (tools/gpu/knob_sweep.py) adds is the sampler and the decode, at the price of `import torch` (1-2 minutes on a fresh
+GPU box — more than this whole script).  Nothing here imports torch: device memory comes from tools/gpu/hipmem.py (ctypes over
+libamdhip64), weights are seeded numpy values in the schema's shapes with the schema's variances (not the bench's torch-seeded
+values: outputs of this tool are compared with each other, never with the oracle).
+
+Per setting: ms per forward (min / median over `--reps` rounds of `--fwd` timed forwards after one warm-up, settings interleaved),
+and the output's relative L2 distance and exact-equality flag against the first setting.  `--profile` adds the HIP-event kernel-class
+table of one forward per setting.  Settings use knob_sweep.py's syntax; `cfg_pairs` / `uniform_t` are engine options here
+(default 1 / 1: what the samplers ask for).  (Does not import oracle/.)
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np  # noqa: E402
+
+import hipmem  # noqa: E402
+
+PKG = "stable-diffusion-webui_amd"
+ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse", "cfg_pairs", "uniform_t", "gn_cat", "ln_epi", "gn_proj_fold")
+DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15,
+            "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1, "gemm_split": 0, "gemm_pipe": -1, "gn_fuse": 1, "gn_small": 1, "ep_wide": 1,
+            "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0, "cfg_pairs": 1, "uniform_t": 1}
+
+
+def sub(name):
+    return importlib.import_module(f"{PKG}.{name}")
+
+
+def classify(name):
+    import re
+    if name.startswith("gemm_mfma"):
+        if "conv3x3" in name:
+            return "conv3x3"
+        if "geglu" in name:
+            return "1x1_geglu"
+        if "_tr" in name:
+            return "1x1_vt"
+        if re.search(r" x\d+$", name):
+            return "1x1_batched"
+        return "1x1"
+    for p in ("attention_mfma_self", "attention_mfma_cross", "groupnorm", "layernorm", "splitk", "small_linear"):
+        if name.startswith(p):
+            return p
+    return "other"
+
+
+_scaled = {}
+
+
+def synthetic_weight(pool, key, shape, kind):
+    """fp16 values in `shape` with the schema's variance for this kind of tensor (schema.synthetic_state_dict), cut at a key-dependent
+    offset from one seeded pool: generating (and converting) 860 M independent normals would cost more than the measurement.  The
+    fp16 pool is kept per distinct scale (a few dozen fan-ins), so a tensor is one slice copy."""
+    n = int(np.prod(shape))
+    if kind == "w":
+        mul, add = float(np.prod(shape[1:])) ** -0.5, 0.0
+    elif kind == "e":
+        mul, add = 0.5, 0.0
+    elif kind == "g":
+        mul, add = 0.02, 1.0
+    else:
+        mul, add = 0.02, 0.0
+    p16 = _scaled.get((mul, add))
+    if p16 is None:
+        tmp = _scaled.setdefault("tmp", np.empty_like(pool))       # (one scratch buffer: fresh 64 MB temporaries cost a page fault each)
+        np.multiply(pool, np.float32(mul), out=tmp)
+        if add:
+            tmp += np.float32(add)
+        p16 = _scaled[(mul, add)] = tmp.astype(np.float16)
+    if n >= p16.size:
+        return np.ascontiguousarray(np.resize(p16, n).reshape(shape))
+    off = hash_u32(key) % (p16.size - n)
+    return np.ascontiguousarray(p16[off:off + n].reshape(shape))
+
+
+def hash_u32(s):
+    h = 2166136261
+    for ch in s.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("settings", nargs="+")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--fwd", type=int, default=10)
+    ap.add_argument("--model", default="sd15", choices=("sd15", "sdxl", "tiny"))
+    ap.add_argument("--rows", type=int, default=16, help="UNet batch rows (the CFG batch: 2 x images)")
+    ap.add_argument("--hw", type=int, default=64, help="latent height = width")
+    ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fwd_ab.json"))
+    args = ap.parse_args()
+    t_start = time.time()
+    _lib = sub("_lib")
+    _lib.require_device()
+    lib = _lib.lib
+    schema = sub("schema")
+    engine_mod_cfg = {"sd15": schema.sd15_unet, "sdxl": schema.sdxl_unet, "tiny": schema.tiny_unet}[args.model]()
+    cfg = engine_mod_cfg
+    hipmem.set_device(0)
+
+    handle = lib.sdmi_engine_create(0)
+    if not handle:
+        raise SystemExit("sdmi_engine_create failed: " + _lib.last_error())
+    # the ctypes mirror of engine._unet_cfg_c (engine.py imports torch)
+    c = _lib.UNetConfigC()
+    c.in_channels, c.out_channels, c.model_channels = cfg.in_channels, cfg.out_channels, cfg.model_channels
+    c.num_levels = len(cfg.channel_mult)
+    ds = 1
+    for i, m in enumerate(cfg.channel_mult):
+        c.channel_mult[i] = m
+        c.attn_level[i] = 1 if ds in cfg.attention_resolutions else 0
+        c.transformer_depth[i] = cfg.depth_at(i)
+        ds *= 2
+    c.num_res_blocks, c.num_heads, c.num_head_channels = cfg.num_res_blocks, cfg.num_heads, cfg.num_head_channels
+    c.context_dim, c.adm_in_channels = cfg.context_dim, cfg.adm_in_channels or 0
+    _lib.check(lib.sdmi_unet_configure(handle, C.byref(c)), "unet_configure")
+    rng = np.random.default_rng(0x5D15)
+    pool = rng.standard_normal(1 << 22, dtype=np.float32)                 # (larger tensors tile it)
+    nparam = 0
+    for key, shape, kind in schema.unet_schema(cfg):
+        w = synthetic_weight(pool, key, tuple(shape), kind)
+        nparam += w.size
+        shp = (C.c_int64 * w.ndim)(*w.shape)
+        _lib.check(lib.sdmi_unet_load_tensor(handle, key.encode(), C.c_void_p(w.ctypes.data), _lib.F16, w.ndim, shp, 0), f"load_tensor({key})")
+    _lib.check(lib.sdmi_unet_finalize(handle), "unet_finalize")
+    t_loaded = time.time()
+
+    B, hw, L = args.rows, args.hw, 77
+    half = B // 2
+    lat = rng.standard_normal((half, cfg.in_channels, hw, hw), dtype=np.float32)
+    x = np.concatenate([lat, lat], 0).astype(np.float32)                      # the CFG denoiser's [cond | uncond] batch: same latent twice
+    t = np.full((B,), 601.0, dtype=np.float32)
+    ctx = rng.standard_normal((B, L, cfg.context_dim), dtype=np.float32)
+    y = rng.standard_normal((B, cfg.adm_in_channels), dtype=np.float32) if cfg.adm_in_channels else None
+    dx, dt, dctx = hipmem.DevBuf.from_numpy(x), hipmem.DevBuf.from_numpy(t), hipmem.DevBuf.from_numpy(ctx)
+    dy = hipmem.DevBuf.from_numpy(y) if y is not None else None
+    out_shape = (B, cfg.out_channels, hw, hw)
+    dout = hipmem.DevBuf(int(np.prod(out_shape)) * 4)
+    _lib.check(lib.sdmi_unet_set_context(handle, dctx.ptr, _lib.F32, B, L, None), "set_context")
+
+    def forward():
+        _lib.check(lib.sdmi_unet_forward(handle, dx.ptr, dt.ptr, None, dy.ptr if dy else None, dout.ptr, _lib.F32, B, hw, hw, L, None), "unet_forward")
+
+    def apply(setting):
+        vals = dict(DEFAULTS)
+        if setting != "base":
+            for kv in setting.split(","):
+                k, v = kv.split("=")
+                vals[k] = int(v)
+        for k, v in vals.items():
+            if k in ENGINE_OPTS:
+                rc = lib.sdmi_engine_set_option(handle, k.encode(), int(v))
+            else:
+                rc = lib.sdmi_debug_set(k.encode(), int(v))
+            if rc and v == DEFAULTS.get(k):                   # an older library (SDMI_LIB two-builds A/B) does not know this knob
+                continue
+            _lib.check(rc, k)
+        # cached K / V^T of the text context depend on nothing a knob changes, but a knob may change the arena: one untimed forward follows
+
+    e0, e1 = hipmem.Event(), hipmem.Event()
+    times = {s: [] for s in args.settings}
+    outs = {}
+    for rep in range(args.reps):
+        for s in args.settings:
+            apply(s)
+            forward()
+            hipmem.sync()
+            if s not in outs:
+                outs[s] = dout.to_numpy(np.float32, out_shape).copy()
+            e0.record()
+            for _ in range(args.fwd):
+                forward()
+            e1.record()
+            times[s].append(e1.ms_since(e0) / args.fwd)
+    base = args.settings[0]
+    res = {"model": args.model, "rows": B, "latent": hw, "params": nparam, "load_s": round(t_loaded - t_start, 1), "settings": {}}
+    for s in args.settings:
+        a, b = outs[s].astype(np.float64), outs[base].astype(np.float64)
+        rel = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+        finite = bool(np.isfinite(outs[s]).all())
+        r = {"ms_min": round(min(times[s]), 3), "ms_median": round(statistics.median(times[s]), 3), "all": [round(v, 3) for v in times[s]],
+             "rel_l2_vs_first": rel, "identical_to_first": bool(np.array_equal(outs[s], outs[base])), "finite": finite,
+             "out_rms": float(np.sqrt(np.mean(a * a)))}
+        res["settings"][s] = r
+        print(f"{s:48s} min {r['ms_min']:8.3f} ms  median {r['ms_median']:8.3f} ms  rel-L2 vs {base}: {rel:.3e}"
+              f"{'  (bit-identical)' if r['identical_to_first'] else ''}{'' if finite else '  NON-FINITE OUTPUT'}", flush=True)
+    if args.profile:
+        for s in args.settings:
+            apply(s)
+            forward()
+            hipmem.sync()
+            _lib.check(lib.sdmi_profile_begin(), "profile_begin")
+            forward()
+            hipmem.sync()
+            buf = C.create_string_buffer(1 << 21)
+            _lib.check(lib.sdmi_profile_end(buf, len(buf)), "profile_end")
+            kernels = json.loads(buf.value.decode())["kernels"]
+            groups = {}
+            for k in kernels:
+                g = groups.setdefault(classify(k["name"]), [0.0, 0.0, 0])
+                g[0] += k["ms"]; g[1] += k["flops"]; g[2] += k["launches"]
+            res["settings"][s]["profile_ms"] = {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}
+            res["settings"][s]["profile_launches"] = {k: v[2] for k, v in groups.items()}
+            print(f"--- {s}: {sum(v[0] for v in groups.values()):.2f} ms of kernels in {sum(v[2] for v in groups.values())} launches")
+            for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+                print(f"    {k:24s} {v[0]:8.3f} ms  {v[2]:4d} launches" + (f"  {v[1] / v[0] / 1e9:7.1f} TFLOP/s" if v[1] > 0 and v[0] > 0 else ""))
+    res["wall_s"] = round(time.time() - t_start, 1)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(f"load {res['load_s']} s, total {res['wall_s']} s -> {args.out}", flush=True)
+    lib.sdmi_engine_destroy(handle)
+
+
+if __name__ == "__main__":
+    main()
