@@ -176,22 +176,38 @@ def main():
 
     e0, e1 = hipmem.Event(), hipmem.Event()
     times = {s: [] for s in args.settings}
-    outs = {}
+    outs, failed = {}, {}
+    res = {"model": args.model, "rows": B, "latent": hw, "params": nparam, "load_s": round(t_loaded - t_start, 1), "settings": {}}
+
+    def save():
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump(res, f, indent=1)
+
     for rep in range(args.reps):
         for s in args.settings:
-            apply(s)
-            forward()
-            hipmem.sync()
-            if s not in outs:
-                outs[s] = dout.to_numpy(np.float32, out_shape).copy()
-            e0.record()
-            for _ in range(args.fwd):
+            if s in failed:
+                continue
+            try:                                              # a setting the library refuses is reported and skipped; the others still run
+                apply(s)
                 forward()
-            e1.record()
-            times[s].append(e1.ms_since(e0) / args.fwd)
-    base = args.settings[0]
-    res = {"model": args.model, "rows": B, "latent": hw, "params": nparam, "load_s": round(t_loaded - t_start, 1), "settings": {}}
+                hipmem.sync()
+                if s not in outs:
+                    outs[s] = dout.to_numpy(np.float32, out_shape).copy()
+                e0.record()
+                for _ in range(args.fwd):
+                    forward()
+                e1.record()
+                times[s].append(e1.ms_since(e0) / args.fwd)
+            except (_lib.SdmiError, RuntimeError) as ex:
+                failed[s] = str(ex)
+                res["settings"][s] = {"error": str(ex)}
+                print(f"{s:48s} FAILED: {ex}", flush=True)
+                save()
+    base = next((s for s in args.settings if s not in failed), None)
     for s in args.settings:
+        if s in failed:
+            continue
         a, b = outs[s].astype(np.float64), outs[base].astype(np.float64)
         rel = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
         finite = bool(np.isfinite(outs[s]).all())
@@ -201,8 +217,11 @@ def main():
         res["settings"][s] = r
         print(f"{s:48s} min {r['ms_min']:8.3f} ms  median {r['ms_median']:8.3f} ms  rel-L2 vs {base}: {rel:.3e}"
               f"{'  (bit-identical)' if r['identical_to_first'] else ''}{'' if finite else '  NON-FINITE OUTPUT'}", flush=True)
+    save()
     if args.profile:
         for s in args.settings:
+            if s in failed:
+                continue
             apply(s)
             forward()
             hipmem.sync()
@@ -218,13 +237,13 @@ def main():
                 g[0] += k["ms"]; g[1] += k["flops"]; g[2] += k["launches"]
             res["settings"][s]["profile_ms"] = {k: round(v[0], 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])}
             res["settings"][s]["profile_launches"] = {k: v[2] for k, v in groups.items()}
+            res["settings"][s]["kernels"] = sorted(kernels, key=lambda k: -k["ms"])          # per launch shape: name, launches, ms, flops, bytes
             print(f"--- {s}: {sum(v[0] for v in groups.values()):.2f} ms of kernels in {sum(v[2] for v in groups.values())} launches")
             for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0]):
                 print(f"    {k:24s} {v[0]:8.3f} ms  {v[2]:4d} launches" + (f"  {v[1] / v[0] / 1e9:7.1f} TFLOP/s" if v[1] > 0 and v[0] > 0 else ""))
+            save()
     res["wall_s"] = round(time.time() - t_start, 1)
-    os.makedirs(os.path.dirname(args.out), exist_ok=True)
-    with open(args.out, "w") as f:
-        json.dump(res, f, indent=1)
+    save()
     print(f"load {res['load_s']} s, total {res['wall_s']} s -> {args.out}", flush=True)
     lib.sdmi_engine_destroy(handle)
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _hip = None
-for _name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7"):
+for _name in ("libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):     # the soname libsdmi.so links: one runtime instance
     try:
         _hip = C.CDLL(_name, mode=getattr(os, "RTLD_GLOBAL", 0))
         break
