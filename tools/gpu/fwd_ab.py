@@ -31,10 +31,11 @@ import numpy as np  # noqa: E402
 import hipmem  # noqa: E402
 
 PKG = "stable-diffusion-webui_amd"
-ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse", "cfg_pairs", "uniform_t", "gn_cat", "ln_epi", "gn_proj_fold")
+ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse", "cfg_pairs", "uniform_t", "gn_cat")
 DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15,
             "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1, "gemm_split": 0, "gemm_pipe": -1, "gn_fuse": 1, "gn_small": 1, "ep_wide": 1,
-            "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0, "cfg_pairs": 1, "uniform_t": 1}
+            "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0, "cfg_pairs": 1, "uniform_t": 1, "gn_cat": 0}
+assert all(k in DEFAULTS for k in ENGINE_OPTS if k in ("gn_cat", "cfg_pairs", "uniform_t", "ln_fold", "streams", "arena_reuse"))     # every option a setting may switch is reset by the next one
 
 
 def sub(name):
@@ -199,23 +200,29 @@ def main():
                     forward()
                 e1.record()
                 times[s].append(e1.ms_since(e0) / args.fwd)
+                if rep == 0:                                  # (kept on disk as they come: a later setting may take the process down)
+                    res["settings"][s] = {"ms_first_round": round(times[s][0], 3), "finite": bool(np.isfinite(outs[s]).all())}
+                    save()
             except (_lib.SdmiError, RuntimeError) as ex:
                 failed[s] = str(ex)
                 res["settings"][s] = {"error": str(ex)}
                 print(f"{s:48s} FAILED: {ex}", flush=True)
                 save()
     base = next((s for s in args.settings if s not in failed), None)
+    prev = None
     for s in args.settings:
         if s in failed:
             continue
         a, b = outs[s].astype(np.float64), outs[base].astype(np.float64)
         rel = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+        rel_prev = None if prev is None else float(np.linalg.norm(a - outs[prev]) / max(np.linalg.norm(outs[prev].astype(np.float64)), 1e-30))
+        prev = s
         finite = bool(np.isfinite(outs[s]).all())
         r = {"ms_min": round(min(times[s]), 3), "ms_median": round(statistics.median(times[s]), 3), "all": [round(v, 3) for v in times[s]],
-             "rel_l2_vs_first": rel, "identical_to_first": bool(np.array_equal(outs[s], outs[base])), "finite": finite,
+             "rel_l2_vs_first": rel, "rel_l2_vs_previous_setting": rel_prev, "identical_to_first": bool(np.array_equal(outs[s], outs[base])), "finite": finite,
              "out_rms": float(np.sqrt(np.mean(a * a)))}
         res["settings"][s] = r
-        print(f"{s:48s} min {r['ms_min']:8.3f} ms  median {r['ms_median']:8.3f} ms  rel-L2 vs {base}: {rel:.3e}"
+        print(f"{s:48s} min {r['ms_min']:8.3f} ms  median {r['ms_median']:8.3f} ms  rel-L2 vs {base}: {rel:.3e}" + (f" vs previous: {rel_prev:.3e}" if rel_prev is not None else "") +
               f"{'  (bit-identical)' if r['identical_to_first'] else ''}{'' if finite else '  NON-FINITE OUTPUT'}", flush=True)
     save()
     if args.profile:
