@@ -410,11 +410,18 @@ class CFGDenoiser:
         if tensor.shape[0] != n_cond:
             raise ValueError(f"cond has {tensor.shape[0]} rows, conds_list names {n_cond}")
 
-        skip_uncond = False                                   # :218-230
+        skip_uncond = False                                   # :218-230, with the infotext keys the reference leaves at :222, :225-227
+        info = getattr(self.p, "extra_generation_params", None)
         if opts.skip_early_cond != 0. and self.step / self.total_steps <= opts.skip_early_cond:
             skip_uncond = True
+            if info is not None:
+                info["Skip Early CFG"] = opts.skip_early_cond
         elif (self.step % 2 or opts.s_min_uncond_all) and s_min_uncond > 0 and float(sigma[0]) < s_min_uncond and not is_edit_model:
             skip_uncond = True                                # NGMS; never for edit models (the reference's `and not is_edit_model`, :224)
+            if info is not None:
+                info["NGMS"] = s_min_uncond
+                if opts.s_min_uncond_all:
+                    info["NGMS all steps"] = opts.s_min_uncond_all
         self.padded_cond_uncond = False
         self.padded_cond_uncond_v0 = False
         src_tensor, src_uncond = tensor, uncond               # the selections before any padding temporaries (context-cache key)
