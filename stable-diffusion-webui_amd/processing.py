@@ -241,6 +241,22 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
                 if not any(x.name == self.hr_upscaler for x in shared.sd_upscalers):
                     raise Exception(f"could not find upscaler named {self.hr_upscaler}")                    # :1285-1286
             self.calculate_target_resolution()
+            # the infotext keys of :1223-1228, 1254, 1262-1265, 1278, 1301-1305 (the hires prompt entries belong to the text layer)
+            info = self.extra_generation_params
+            info["Denoising strength"] = self.denoising_strength                                            # :1254
+            if self.hr_resize_x == 0 and self.hr_resize_y == 0:
+                info["Hires upscale"] = self.hr_scale
+            else:
+                info["Hires resize"] = f"{self.hr_resize_x}x{self.hr_resize_y}"
+            if self.hr_sd_model is not None:
+                info["Hires checkpoint"] = getattr(self.hr_sd_model, "short_title", None) or getattr(self.hr_sd_model, "name", "hires checkpoint")
+            if self.hr_sampler_name is not None and self.hr_sampler_name != self.sampler_name:
+                info["Hires sampler"] = self.hr_sampler_name
+            info.setdefault("Hires schedule type", None)       # set by KDiffusionSampler.get_sigmas during the second pass
+            if self.hr_second_pass_steps:
+                info["Hires steps"] = self.hr_second_pass_steps
+            if self.hr_upscaler is not None:
+                info["Hires upscaler"] = self.hr_upscaler
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
         """modules/processing.py:1307-1362"""
@@ -486,6 +502,7 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessing):
             raise ValueError(f"img2img: init latent {tuple(self.init_latent.shape)} does not match the noise shape {tuple(x.shape)} "
                              f"of a {self.width}x{self.height} job (init_images must encode to (4, height // {opt_f}, width // {opt_f}))")
         if self.initial_noise_multiplier != 1.0:                                # :1762-1764
+            self.extra_generation_params["Noise multiplier"] = self.initial_noise_multiplier
             x = ops.lincomb(x, [x], [float(self.initial_noise_multiplier)])
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
         samples = self.sampler.sample_img2img(self, self.init_latent, x, conditioning, unconditional_conditioning,

@@ -182,6 +182,8 @@ def apply_refiner(cfg_denoiser, sigma=None):
     conds encoded by ITS text encoder, and the switch is a pointer swap on the sampler."""
     opts = shared.opts
     p = cfg_denoiser.p
+    if (opts.refiner_switch_by_sample_steps or sigma is None) and getattr(p, "extra_generation_params", None) is not None:
+        p.extra_generation_params["Refiner switch by sampling steps"] = True      # :159-161: noted whenever that rule is in force, refiner or not
     if getattr(p, "refiner_sd_model", None) is None:          # (the reference evaluates the progress first; without a refiner the
         return False                                          #  answer is False either way and the device read-back is saved)
     if opts.refiner_switch_by_sample_steps or sigma is None:
@@ -1730,6 +1732,7 @@ class KDiffusionSampler(Sampler):
         sigmas = self.get_sigmas(p, steps)
         x0 = torch.empty_like(x)
         if shared.opts.sgm_noise_multiplier:
+            p.extra_generation_params["SGM noise multiplier"] = True     # :196
             mult = float(torch.sqrt(1.0 + sigmas[0] ** 2.0))
         else:
             mult = float(sigmas[0])

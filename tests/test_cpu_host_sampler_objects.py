@@ -1,0 +1,220 @@
+"""The sampler OBJECTS of the product (KDiffusionSampler.sample / sample_img2img: boundary B3) on the CPU — the layer between a job and
+the sampler loops: schedule selection, the scaling of the initial noise, img2img's partial schedule and noising, which keyword
+arguments a loop receives, where per-step noise comes from, the infotext keys — against the same chain written with the oracle's pieces
+(oracle CFGDenoiser over CompVisDenoiser over an analytic UNet, oracle sampler loop, the same noise draws).  Device launches are
+replaced, for these tests only, by the elementwise contracts of include/sdmi.h (the shims of test_cpu_host_samplers.py / _cfg.py).
+"""
+import importlib
+import types
+
+import pytest
+import torch
+
+from oracle import kdiffusion as okd
+from tests.helpers import seeded
+from tests.test_cpu_host_cfg import C, StubEngine, TorchCfgKernels, unet
+from tests.test_cpu_host_samplers import _TorchStepKernels
+
+PKG = "stable-diffusion-webui_amd"
+SHAPE = (2, C, 8, 8)
+
+
+def sub(name):
+    return importlib.import_module(f"{PKG}.{name}")
+
+
+class AllKernels(TorchCfgKernels, _TorchStepKernels):
+    pass
+
+
+@pytest.fixture()
+def ss(monkeypatch):
+    mod = sub("sd_samplers")
+    monkeypatch.setattr(mod, "lib", AllKernels())
+    monkeypatch.setattr(mod, "ptr", lambda t: t)
+    monkeypatch.setattr(mod, "stream_ptr", lambda: None)
+    monkeypatch.setattr(mod, "_lc", lambda out, terms, coefs: out.copy_(sum(float(c) * t for c, t in zip(coefs, terms))))
+    monkeypatch.setattr(mod.ops, "mask_blend", lambda x, init, mask, nmask: x.copy_(x * nmask + init * mask))
+    for k, v in dict(skip_early_cond=0.0, s_min_uncond_all=False, pad_cond_uncond=False, pad_cond_uncond_v0=False, batch_cond_uncond=True,
+                     live_preview_content="Prompt", sgm_noise_multiplier=False, img2img_extra_noise=0.0, img2img_fix_steps=False,
+                     always_discard_next_to_last_sigma=False, sigma_min=0.0, sigma_max=0.0, rho=0.0, eta_ancestral=1.0, s_churn=0.0,
+                     s_tmin=0.0, s_tmax=0.0, s_noise=1.0, use_old_karras_scheduler_sigmas=False).items():
+        monkeypatch.setattr(mod.shared.opts, k, v, raising=False)
+    return mod
+
+
+class Rng:
+    """p.rng: the job's per-step noise (ImageRNG.next), here a seeded sequence both sides draw from."""
+
+    def __init__(self, seed0):
+        self.i, self.seed0 = 0, seed0
+
+    def next(self):
+        self.i += 1
+        return seeded(SHAPE, self.seed0 + self.i)
+
+
+def make(ss, name, **pkw):
+    eng = StubEngine(C)
+    sd_model = types.SimpleNamespace(engine=eng, alphas_cumprod=okd.make_alphas_cumprod(), parameterization="eps", cond_stage_key="txt",
+                                     model=types.SimpleNamespace(conditioning_key="crossattn"), device=torch.device("cpu"))
+    sampler = ss.create_sampler(name, sd_model)
+    base = dict(steps=7, cfg_scale=6.0, eta=None, s_min_uncond=0.0, extra_generation_params={}, rng=Rng(7000), scripts=None,
+                sampler_noise_scheduler_override=None, scheduler=None, is_hr_pass=False, denoising_strength=0.6, s_churn=0.0, s_tmin=0.0,
+                s_tmax=0.0, s_noise=1.0, all_seeds=[11, 12], iteration=0, batch_size=2, image_cfg_scale=None)
+    base.update(pkw)
+    return sampler, types.SimpleNamespace(**base), eng
+
+
+def oracle_chain():
+    den = okd.CompVisDenoiser(lambda xs, t, cond, ic=None: unet(xs, t, cond, ic), okd.make_alphas_cumprod())
+    cfg = okd.CFGDenoiser(den)
+    return den, cfg, (lambda x, sigma, **kw: cfg(x, sigma, kw["uncond"], kw["cond"], kw["cond_scale"], kw.get("s_min_uncond", 0.0)))
+
+
+COND, UNCOND = seeded((2, 8, 6), 7100, 0.5), seeded((2, 8, 6), 7101, 0.5)
+rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
+
+
+@pytest.mark.parametrize("sgm", [False, True])
+def test_euler_a_txt2img_through_the_sampler_object(ss, monkeypatch, sgm):
+    monkeypatch.setattr(ss.shared.opts, "sgm_noise_multiplier", sgm, raising=False)
+    sampler, p, eng = make(ss, "Euler a")
+    x = seeded(SHAPE, 7200)
+    got = sampler.sample(p, x.clone(), COND, UNCOND)
+    den, cfg, model = oracle_chain()
+    sig = den.get_sigmas(p.steps)                             # Euler a: the "Automatic" row = the model's own discrete schedule
+    assert torch.allclose(sampler.get_sigmas(p, p.steps), sig, rtol=1e-6, atol=0)
+    x0 = x * (torch.sqrt(1.0 + sig[0] ** 2.0) if sgm else sig[0])
+    rng = Rng(7000)
+    cfg.total_steps = p.steps
+    want = okd.sample_euler_ancestral(model, x0, sig, dict(cond=COND, uncond=UNCOND, cond_scale=p.cfg_scale), rng.next)
+    assert rel(got, want) < 5e-6
+    assert p.rng.i == rng.i == p.steps - 1                    # one draw per step with a next sigma > 0
+    assert ("SGM noise multiplier" in p.extra_generation_params) == sgm
+    assert len(eng.calls) == p.steps and all(c == (4, 8, True) for c in eng.calls)       # 2 B rows per call, the plain [cond | uncond] batch
+    assert sampler.model_wrap_cfg.step == p.steps and ss.shared.state.sampling_steps == p.steps
+
+
+def test_dpmpp_2m_karras_and_the_churn_options_through_the_sampler_object(ss, monkeypatch):
+    sampler, p, _ = make(ss, "DPM++ 2M", steps=9)
+    x = seeded(SHAPE, 7300)
+    got = sampler.sample(p, x.clone(), COND, UNCOND)
+    den, cfg, model = oracle_chain()
+    sig = okd.get_sigmas_karras(9, den.sigmas[0].item(), den.sigmas[-1].item())      # the row's scheduler: karras over the model's range
+    cfg.total_steps = 9
+    want = okd.sample_dpmpp_2m(model, x * sig[0], sig, dict(cond=COND, uncond=UNCOND, cond_scale=p.cfg_scale))
+    assert rel(got, want) < 5e-6
+    assert p.extra_generation_params.get("Schedule type") == "Karras"   # (:100-101 notes the resolved label, the row's own default included)
+    # Heun with churn taken from the OPTIONS (they override p, sd_samplers_common.py:309-331) and noted in the infotext
+    for k, v in dict(s_churn=3.0, s_tmin=0.1, s_tmax=9.0, s_noise=1.01).items():
+        monkeypatch.setattr(ss.shared.opts, k, v, raising=False)
+    sampler, p, _ = make(ss, "Heun", steps=5)
+    got = sampler.sample(p, x.clone(), COND, UNCOND)
+    den, cfg, model = oracle_chain()
+    sig = den.get_sigmas(5)
+    cfg.total_steps = 2 * 5                                  # second-order row: SamplerData.total_steps doubles the count (sd_samplers_common.py:14-19)
+    rng = Rng(7000)
+    want = okd.sample_heun(model, x * sig[0], sig, dict(cond=COND, uncond=UNCOND, cond_scale=p.cfg_scale), rng.next, s_churn=3.0, s_tmin=0.1,
+                           s_tmax=9.0, s_noise=1.01)
+    assert rel(got, want) < 5e-6 and p.rng.i == rng.i
+    info = p.extra_generation_params
+    assert (info["Sigma churn"], info["Sigma tmin"], info["Sigma tmax"], info["Sigma noise"]) == (3.0, 0.1, 9.0, 1.01)
+    assert sampler.model_wrap_cfg.total_steps == 10
+
+
+@pytest.mark.parametrize("extra_noise", [0.0, 0.2])
+def test_img2img_partial_schedule_and_noising_through_the_sampler_object(ss, monkeypatch, extra_noise):
+    monkeypatch.setattr(ss.shared.opts, "img2img_extra_noise", extra_noise, raising=False)
+    sampler, p, eng = make(ss, "Euler a", steps=10, denoising_strength=0.55, eta=0.7)
+    init, noise = seeded(SHAPE, 7400), seeded(SHAPE, 7401)
+    got = sampler.sample_img2img(p, init.clone(), noise.clone(), COND, UNCOND)
+    den, cfg, model = oracle_chain()
+    steps, t_enc = okd.setup_img2img_steps(10, 0.55, steps_given=False)
+    sig = den.get_sigmas(steps)
+    sched = sig[steps - t_enc - 1:]
+    xi = init + noise * sched[0] + noise * extra_noise
+    rng = Rng(7000)
+    cfg.total_steps = t_enc + 1
+    want = okd.sample_euler_ancestral(model, xi, sched, dict(cond=COND, uncond=UNCOND, cond_scale=p.cfg_scale), rng.next, eta=0.7)
+    assert rel(got, want) < 5e-6 and len(eng.calls) == t_enc + 1
+    info = p.extra_generation_params
+    assert info.get("Eta") == 0.7 and (info.get("Extra noise") == 0.2) == (extra_noise > 0)
+    assert torch.equal(sampler.model_wrap_cfg.init_latent, init)
+
+
+def test_dpm_fast_gets_its_sigma_range_and_evaluation_budget(ss):
+    """modules/sd_samplers_kdiffusion.py:155-161, 203-208: txt2img hands DPM fast the MODEL's range and n = steps; img2img the partial
+    schedule's first and LAST NON-ZERO sigma and n = its length - 1."""
+    den, cfg, model = oracle_chain()
+    x = seeded(SHAPE, 7500)
+    sampler, p, _ = make(ss, "DPM fast", steps=9)
+    got = sampler.sample(p, x.clone(), COND, UNCOND)
+    sig = den.get_sigmas(9)
+    rng = Rng(7000)
+    cfg.total_steps = 9
+    want = okd.sample_dpm_fast(model, x * sig[0], den.sigmas[0].item(), den.sigmas[-1].item(), 9, dict(cond=COND, uncond=UNCOND, cond_scale=6.0),
+                               rng.next, eta=1.0, s_noise=1.0)
+    # (k-diffusion draws at its last step too and multiplies the draw by su = 0 there; the product skips a zero-weight draw — nothing
+    # reads the job's generator after the loop, so only the count differs, by exactly that one)
+    assert rel(got, want) < 2e-5 and p.rng.i == rng.i - 1
+    sampler, p, _ = make(ss, "DPM fast", steps=12, denoising_strength=0.5)
+    init, noise = seeded(SHAPE, 7501), seeded(SHAPE, 7502)
+    got = sampler.sample_img2img(p, init.clone(), noise.clone(), COND, UNCOND)
+    den, cfg, model = oracle_chain()
+    steps, t_enc = okd.setup_img2img_steps(12, 0.5, steps_given=False)
+    sched = den.get_sigmas(steps)[steps - t_enc - 1:]
+    rng = Rng(7000)
+    cfg.total_steps = t_enc + 1
+    want = okd.sample_dpm_fast(model, init + noise * sched[0], float(sched[-2]), float(sched[0]), len(sched) - 1,
+                               dict(cond=COND, uncond=UNCOND, cond_scale=6.0), rng.next, eta=1.0, s_noise=1.0)
+    assert rel(got, want) < 2e-5 and p.rng.i == rng.i - 1
+
+
+def test_refiner_rule_is_noted_in_the_infotext_whenever_it_is_in_force(ss, monkeypatch):
+    """modules/sd_samplers_common.py:159-161 writes "Refiner switch by sampling steps" before it looks for a refiner."""
+    monkeypatch.setattr(ss.shared.opts, "refiner_switch_by_sample_steps", True, raising=False)
+    sampler, p, _ = make(ss, "Euler", steps=3)
+    sampler.sample(p, seeded(SHAPE, 7600), COND, UNCOND)
+    assert p.extra_generation_params.get("Refiner switch by sampling steps") is True
+    monkeypatch.setattr(ss.shared.opts, "refiner_switch_by_sample_steps", False, raising=False)
+    sampler, p, _ = make(ss, "Euler", steps=3)
+    sampler.sample(p, seeded(SHAPE, 7600), COND, UNCOND)
+    assert "Refiner switch by sampling steps" not in p.extra_generation_params
+
+
+@pytest.mark.parametrize("eta", [0.0, 0.4])
+def test_ddim_txt2img_and_img2img_through_the_sampler_object(ss, monkeypatch, eta):
+    """CompVisSampler (modules/sd_samplers_timesteps.py:75-163): timestep table, eta from opts.eta_ddim with its infotext key, img2img's
+    noising at the schedule's entry timestep, CFG in eps space (mode 1 of the fused combine)."""
+    monkeypatch.setattr(ss.shared.opts, "eta_ddim", eta, raising=False)
+    acp = okd.make_alphas_cumprod()
+
+    def chain():
+        cfg = okd.CFGDenoiser(lambda x_in, t_in, c: unet(x_in, t_in, c))
+        return cfg, (lambda x, t, **kw: cfg(x, t, kw["uncond"], kw["cond"], kw["cond_scale"]))
+
+    sampler, p, eng = make(ss, "DDIM", steps=8)
+    x = seeded(SHAPE, 7700)
+    got = sampler.sample(p, x.clone(), COND, UNCOND)
+    cfg, model = chain()
+    cfg.total_steps = 8
+    ts = okd.ddim_timesteps(8)
+    assert torch.equal(sampler.get_timesteps(p, 8), ts)
+    rng = Rng(7000)
+    want = okd.sample_ddim(model, x.clone(), ts, acp, dict(cond=COND, uncond=UNCOND, cond_scale=6.0), rng.next, eta=eta)
+    assert rel(got, want) < 5e-6 and len(eng.calls) == len(ts) - 1
+    assert (p.extra_generation_params.get("Eta DDIM") == eta) == (eta != 0.0)
+    # img2img: x_t = sqrt(a_t) x0 + sqrt(1 - a_t) noise at t = timesteps[t_enc], then the first t_enc timesteps
+    sampler, p, eng = make(ss, "DDIM", steps=10, denoising_strength=0.6)
+    init, noise = seeded(SHAPE, 7701), seeded(SHAPE, 7702)
+    got = sampler.sample_img2img(p, init.clone(), noise.clone(), COND, UNCOND)
+    steps, t_enc = okd.setup_img2img_steps(10, 0.6, steps_given=False)
+    ts = okd.ddim_timesteps(steps)
+    a = acp[ts[t_enc]]
+    xi = init * torch.sqrt(a) + noise * torch.sqrt(1 - a)
+    cfg, model = chain()
+    cfg.total_steps = t_enc + 1
+    rng = Rng(7000)
+    want = okd.sample_ddim(model, xi, ts[:t_enc], acp, dict(cond=COND, uncond=UNCOND, cond_scale=6.0), rng.next, eta=eta)
+    assert rel(got, want) < 5e-6
