@@ -615,7 +615,7 @@ def process_images(p: StableDiffusionProcessing) -> Processed:
             from PIL import Image
             from . import masking
             for i, arr in enumerate(batch_u8):
-                ov = overlays[lo + i] if lo + i < len(overlays) else None
+                ov = overlays[lo + i] if lo + i < len(overlays) and getattr(shared.opts, "overlay_inpaint", True) else None      # :1055-1060
                 batch_u8[i] = np.array(masking.apply_overlay(Image.fromarray(arr), getattr(p, "paste_to", None), ov)[0])
         images.extend(batch_u8)
         if p.keep_latents:

@@ -40,6 +40,7 @@ class Options:
     skip_early_cond: float = 0.0                   # :407
     img2img_extra_noise: float = 0.0
     inpainting_mask_weight: float = 1.0            # :216
+    overlay_inpaint: bool = True                   # :229 (inpainting: composite the unmasked original over the result)
     upscaler_for_img2img: str = None               # :106
     hires_fix_refiner_pass: str = "second pass"    # :185
     refiner_switch_by_sample_steps: bool = False   # :256
