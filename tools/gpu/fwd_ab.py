@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 
-import hipmem  # noqa: E402
+hipmem = None                   # tools/gpu/hipmem.py, imported by main(): tools/cpu/fwd_parity.py imports this module for its weights only
 
 PKG = "stable-diffusion-webui_amd"
 ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse", "cfg_pairs", "uniform_t", "gn_cat")
@@ -106,7 +106,11 @@ def main():
     ap.add_argument("--hw", type=int, default=64, help="latent height = width")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fwd_ab.json"))
+    ap.add_argument("--dump", default=None, help="write inputs and every setting's output to this .npz (tools/cpu/fwd_parity.py compares them with "
+                                                 "the fp32 CPU oracle on the same weights; use --rows 2: the oracle forward is CPU work)")
     args = ap.parse_args()
+    global hipmem
+    import hipmem
     t_start = time.time()
     _lib = sub("_lib")
     _lib.require_device()
@@ -225,6 +229,11 @@ def main():
         print(f"{s:48s} min {r['ms_min']:8.3f} ms  median {r['ms_median']:8.3f} ms  rel-L2 vs {base}: {rel:.3e}" + (f" vs previous: {rel_prev:.3e}" if rel_prev is not None else "") +
               f"{'  (bit-identical)' if r['identical_to_first'] else ''}{'' if finite else '  NON-FINITE OUTPUT'}", flush=True)
     save()
+    if args.dump:
+        ok = [s for s in args.settings if s not in failed]
+        np.savez_compressed(args.dump, x=x, t=t, ctx=ctx, y=(y if y is not None else np.zeros((0,), np.float32)), settings=np.array(ok),
+                            model=np.array(args.model), **{f"out_{i}": outs[s] for i, s in enumerate(ok)})
+        print(f"dumped inputs + {len(ok)} outputs -> {args.dump}", flush=True)
     if args.profile:
         for s in args.settings:
             if s in failed:
