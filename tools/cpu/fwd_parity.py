@@ -28,18 +28,32 @@ def main():
     z = np.load(sys.argv[1])
     model = str(z["model"])
     schema = importlib.import_module("stable-diffusion-webui_amd.schema")
-    cfg = {"sd15": schema.sd15_unet, "sdxl": schema.sdxl_unet, "tiny": schema.tiny_unet}[model]()
-    ocfg = {"sd15": ounet.sd15_config, "sdxl": ounet.sdxl_base_config, "tiny": ounet.tiny_config}[model]()
+    what = str(z["what"]) if "what" in z.files else "unet"
     rng = np.random.default_rng(0x5D15)                       # fwd_ab.main's pool: same generator, same first draw
     pool = rng.standard_normal(1 << 22, dtype=np.float32)
     t0 = time.time()
-    sd = {schema.UNET_PREFIX + key: torch.from_numpy(fwd_ab.synthetic_weight(pool, key, tuple(shape), kind).astype(np.float32))
-          for key, shape, kind in schema.unet_schema(cfg)}
-    net = ounet.build_unet(ocfg, sd).float().eval()
-    x, t, ctx = (torch.from_numpy(z[k]) for k in ("x", "t", "ctx"))
-    y = torch.from_numpy(z["y"]) if z["y"].size else None
-    with torch.no_grad():
-        want = net(x, t, ctx, y).numpy().astype(np.float64)
+    x = torch.from_numpy(z["x"])
+    if what == "vae":
+        from oracle import vae as ovae
+        cfg = {"sd15": schema.sd15_vae, "sdxl": schema.sdxl_vae, "tiny": schema.tiny_vae}[model]()
+        ocfg = {"sd15": ovae.sd15_vae_config, "sdxl": ovae.sd15_vae_config, "tiny": ovae.tiny_vae_config}[model]()     # (SDXL's VAE: the SD1.5 geometry, its own scale factor)
+        if model == "sdxl":
+            ocfg.scale_factor = cfg.scale_factor
+        sd = {schema.VAE_PREFIX + key: torch.from_numpy(fwd_ab.synthetic_weight(pool, key, tuple(shape), kind).astype(np.float32))
+              for key, shape, kind in schema.vae_schema(cfg)}
+        net = ovae.build_vae(ocfg, sd)
+        with torch.no_grad():
+            want = torch.cat([net.decode_first_stage(x[i:i + 1]) for i in range(x.shape[0])]).numpy().astype(np.float64)
+    else:
+        cfg = {"sd15": schema.sd15_unet, "sdxl": schema.sdxl_unet, "tiny": schema.tiny_unet}[model]()
+        ocfg = {"sd15": ounet.sd15_config, "sdxl": ounet.sdxl_base_config, "tiny": ounet.tiny_config}[model]()
+        sd = {schema.UNET_PREFIX + key: torch.from_numpy(fwd_ab.synthetic_weight(pool, key, tuple(shape), kind).astype(np.float32))
+              for key, shape, kind in schema.unet_schema(cfg)}
+        net = ounet.build_unet(ocfg, sd).float().eval()
+        t, ctx = torch.from_numpy(z["t"]), torch.from_numpy(z["ctx"])
+        y = torch.from_numpy(z["y"]) if z["y"].size else None
+        with torch.no_grad():
+            want = net(x, t, ctx, y).numpy().astype(np.float64)
     print(f"oracle forward: {x.shape[0]} rows in {time.time() - t0:.1f} s")
     base = None
     for i, s in enumerate(z["settings"]):

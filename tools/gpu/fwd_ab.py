@@ -2,6 +2,7 @@
 """Torch-free, same-process A/B of runtime knobs on the UNet forward of the headline workload (SD1.5, 64x64 latent, 16-row CFG batch).
 
     python tools/gpu/fwd_ab.py base conv_korder=0 "gn_cat=1" ... [--reps 3] [--fwd 10] [--profile] [--model sd15|sdxl|tiny] [--hw 64]
+    python tools/gpu/fwd_ab.py base ... --what vae --rows 8          (the job's batched VAE decode instead of the UNet forward)
 
 The C1 job is 20 such forwards + one VAE decode (the forwards are ~95 % of it), so a knob that moves the forward moves the job; what the
 whole-job sweep (tools/gpu/knob_sweep.py) adds is the sampler and the decode, at the price of `import torch` (1-2 minutes on a fresh
@@ -104,6 +105,7 @@ def main():
     ap.add_argument("--model", default="sd15", choices=("sd15", "sdxl", "tiny"))
     ap.add_argument("--rows", type=int, default=16, help="UNet batch rows (the CFG batch: 2 x images)")
     ap.add_argument("--hw", type=int, default=64, help="latent height = width")
+    ap.add_argument("--what", default="unet", choices=("unet", "vae"), help="unet: one UNet forward of --rows rows; vae: one batched VAE decode of --rows latents")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fwd_ab.json"))
     ap.add_argument("--dump", default=None, help="write inputs and every setting's output to this .npz (tools/cpu/fwd_parity.py compares them with "
@@ -116,52 +118,75 @@ def main():
     _lib.require_device()
     lib = _lib.lib
     schema = sub("schema")
-    engine_mod_cfg = {"sd15": schema.sd15_unet, "sdxl": schema.sdxl_unet, "tiny": schema.tiny_unet}[args.model]()
-    cfg = engine_mod_cfg
     hipmem.set_device(0)
-
     handle = lib.sdmi_engine_create(0)
     if not handle:
         raise SystemExit("sdmi_engine_create failed: " + _lib.last_error())
-    # the ctypes mirror of engine._unet_cfg_c (engine.py imports torch)
-    c = _lib.UNetConfigC()
-    c.in_channels, c.out_channels, c.model_channels = cfg.in_channels, cfg.out_channels, cfg.model_channels
-    c.num_levels = len(cfg.channel_mult)
-    ds = 1
-    for i, m in enumerate(cfg.channel_mult):
-        c.channel_mult[i] = m
-        c.attn_level[i] = 1 if ds in cfg.attention_resolutions else 0
-        c.transformer_depth[i] = cfg.depth_at(i)
-        ds *= 2
-    c.num_res_blocks, c.num_heads, c.num_head_channels = cfg.num_res_blocks, cfg.num_heads, cfg.num_head_channels
-    c.context_dim, c.adm_in_channels = cfg.context_dim, cfg.adm_in_channels or 0
-    _lib.check(lib.sdmi_unet_configure(handle, C.byref(c)), "unet_configure")
     rng = np.random.default_rng(0x5D15)
     pool = rng.standard_normal(1 << 22, dtype=np.float32)                 # (larger tensors tile it)
     nparam = 0
-    for key, shape, kind in schema.unet_schema(cfg):
-        w = synthetic_weight(pool, key, tuple(shape), kind)
-        nparam += w.size
-        shp = (C.c_int64 * w.ndim)(*w.shape)
-        _lib.check(lib.sdmi_unet_load_tensor(handle, key.encode(), C.c_void_p(w.ctypes.data), _lib.F16, w.ndim, shp, 0), f"load_tensor({key})")
-    _lib.check(lib.sdmi_unet_finalize(handle), "unet_finalize")
-    t_loaded = time.time()
-
     B, hw, L = args.rows, args.hw, 77
-    half = B // 2
-    lat = rng.standard_normal((half, cfg.in_channels, hw, hw), dtype=np.float32)
-    x = np.concatenate([lat, lat], 0).astype(np.float32)                      # the CFG denoiser's [cond | uncond] batch: same latent twice
-    t = np.full((B,), 601.0, dtype=np.float32)
-    ctx = rng.standard_normal((B, L, cfg.context_dim), dtype=np.float32)
-    y = rng.standard_normal((B, cfg.adm_in_channels), dtype=np.float32) if cfg.adm_in_channels else None
-    dx, dt, dctx = hipmem.DevBuf.from_numpy(x), hipmem.DevBuf.from_numpy(t), hipmem.DevBuf.from_numpy(ctx)
-    dy = hipmem.DevBuf.from_numpy(y) if y is not None else None
-    out_shape = (B, cfg.out_channels, hw, hw)
-    dout = hipmem.DevBuf(int(np.prod(out_shape)) * 4)
-    _lib.check(lib.sdmi_unet_set_context(handle, dctx.ptr, _lib.F32, B, L, None), "set_context")
+    x = t = ctx = y = None
+    if args.what == "vae":
+        # the batched VAE decode of the job's end (decode_latent_batch): B latents -> B x 3 x 8h x 8w fp32 images
+        vcfg = {"sd15": schema.sd15_vae, "sdxl": schema.sdxl_vae, "tiny": schema.tiny_vae}[args.model]()
+        vc = _lib.VAEConfigC()                                # the ctypes mirror of engine._vae_cfg_c
+        vc.ch, vc.num_levels = vcfg.ch, len(vcfg.ch_mult)
+        for i, m in enumerate(vcfg.ch_mult):
+            vc.ch_mult[i] = m
+        vc.num_res_blocks, vc.in_channels, vc.out_ch, vc.z_channels = vcfg.num_res_blocks, vcfg.in_channels, vcfg.out_ch, vcfg.z_channels
+        vc.scale_factor = vcfg.scale_factor
+        _lib.check(lib.sdmi_vae_configure(handle, C.byref(vc)), "vae_configure")
+        for key, shape, kind in schema.vae_schema(vcfg):
+            w = synthetic_weight(pool, key, tuple(shape), kind)
+            nparam += w.size
+            shp = (C.c_int64 * w.ndim)(*w.shape)
+            _lib.check(lib.sdmi_vae_load_tensor(handle, key.encode(), C.c_void_p(w.ctypes.data), _lib.F16, w.ndim, shp, 0), f"vae_load_tensor({key})")
+        _lib.check(lib.sdmi_vae_finalize(handle), "vae_finalize")
+        t_loaded = time.time()
+        f = 2 ** (len(vcfg.ch_mult) - 1)
+        x = rng.standard_normal((B, vcfg.z_channels, hw, hw), dtype=np.float32)
+        dx = hipmem.DevBuf.from_numpy(x)
+        out_shape = (B, vcfg.out_ch, hw * f, hw * f)
+        dout = hipmem.DevBuf(int(np.prod(out_shape)) * 4)
 
-    def forward():
-        _lib.check(lib.sdmi_unet_forward(handle, dx.ptr, dt.ptr, None, dy.ptr if dy else None, dout.ptr, _lib.F32, B, hw, hw, L, None), "unet_forward")
+        def forward():
+            _lib.check(lib.sdmi_vae_decode(handle, dx.ptr, _lib.F32, dout.ptr, B, hw, hw, None), "vae_decode")
+    else:
+        cfg = {"sd15": schema.sd15_unet, "sdxl": schema.sdxl_unet, "tiny": schema.tiny_unet}[args.model]()
+        c = _lib.UNetConfigC()                                # the ctypes mirror of engine._unet_cfg_c (engine.py imports torch)
+        c.in_channels, c.out_channels, c.model_channels = cfg.in_channels, cfg.out_channels, cfg.model_channels
+        c.num_levels = len(cfg.channel_mult)
+        ds = 1
+        for i, m in enumerate(cfg.channel_mult):
+            c.channel_mult[i] = m
+            c.attn_level[i] = 1 if ds in cfg.attention_resolutions else 0
+            c.transformer_depth[i] = cfg.depth_at(i)
+            ds *= 2
+        c.num_res_blocks, c.num_heads, c.num_head_channels = cfg.num_res_blocks, cfg.num_heads, cfg.num_head_channels
+        c.context_dim, c.adm_in_channels = cfg.context_dim, cfg.adm_in_channels or 0
+        _lib.check(lib.sdmi_unet_configure(handle, C.byref(c)), "unet_configure")
+        for key, shape, kind in schema.unet_schema(cfg):
+            w = synthetic_weight(pool, key, tuple(shape), kind)
+            nparam += w.size
+            shp = (C.c_int64 * w.ndim)(*w.shape)
+            _lib.check(lib.sdmi_unet_load_tensor(handle, key.encode(), C.c_void_p(w.ctypes.data), _lib.F16, w.ndim, shp, 0), f"load_tensor({key})")
+        _lib.check(lib.sdmi_unet_finalize(handle), "unet_finalize")
+        t_loaded = time.time()
+        half = B // 2
+        lat = rng.standard_normal((half, cfg.in_channels, hw, hw), dtype=np.float32)
+        x = np.concatenate([lat, lat], 0).astype(np.float32)                  # the CFG denoiser's [cond | uncond] batch: same latent twice
+        t = np.full((B,), 601.0, dtype=np.float32)
+        ctx = rng.standard_normal((B, L, cfg.context_dim), dtype=np.float32)
+        y = rng.standard_normal((B, cfg.adm_in_channels), dtype=np.float32) if cfg.adm_in_channels else None
+        dx, dt, dctx = hipmem.DevBuf.from_numpy(x), hipmem.DevBuf.from_numpy(t), hipmem.DevBuf.from_numpy(ctx)
+        dy = hipmem.DevBuf.from_numpy(y) if y is not None else None
+        out_shape = (B, cfg.out_channels, hw, hw)
+        dout = hipmem.DevBuf(int(np.prod(out_shape)) * 4)
+        _lib.check(lib.sdmi_unet_set_context(handle, dctx.ptr, _lib.F32, B, L, None), "set_context")
+
+        def forward():
+            _lib.check(lib.sdmi_unet_forward(handle, dx.ptr, dt.ptr, None, dy.ptr if dy else None, dout.ptr, _lib.F32, B, hw, hw, L, None), "unet_forward")
 
     def apply(setting):
         vals = dict(DEFAULTS)
@@ -182,7 +207,7 @@ def main():
     e0, e1 = hipmem.Event(), hipmem.Event()
     times = {s: [] for s in args.settings}
     outs, failed = {}, {}
-    res = {"model": args.model, "rows": B, "latent": hw, "params": nparam, "load_s": round(t_loaded - t_start, 1), "settings": {}}
+    res = {"model": args.model, "what": args.what, "rows": B, "latent": hw, "params": nparam, "load_s": round(t_loaded - t_start, 1), "settings": {}}
 
     def save():
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
@@ -231,7 +256,9 @@ def main():
     save()
     if args.dump:
         ok = [s for s in args.settings if s not in failed]
-        np.savez_compressed(args.dump, x=x, t=t, ctx=ctx, y=(y if y is not None else np.zeros((0,), np.float32)), settings=np.array(ok),
+        z0 = np.zeros((0,), np.float32)
+        np.savez_compressed(args.dump, x=x, t=(t if t is not None else z0), ctx=(ctx if ctx is not None else z0), y=(y if y is not None else z0),
+                            what=np.array(args.what), settings=np.array(ok),
                             model=np.array(args.model), **{f"out_{i}": outs[s] for i, s in enumerate(ok)})
         print(f"dumped inputs + {len(ok)} outputs -> {args.dump}", flush=True)
     if args.profile:

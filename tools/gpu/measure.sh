@@ -59,6 +59,7 @@ case "$WHAT" in
       [ -x tools/micro/$t ] && { timeout 150 tools/micro/$t 20 > gpurun_out/${TAG}_$t.txt 2>&1; echo "$t rc=$?"; tail -3 gpurun_out/${TAG}_$t.txt; }
     done
     timeout 120 python tools/gpu/fwd_ab.py base --reps 4 --fwd 10 --profile --out gpurun_out/${TAG}_fwd_ab_base.json > gpurun_out/${TAG}_fwd_ab_base.log 2>&1
+    timeout 120 python tools/gpu/fwd_ab.py base --what vae --rows 8 --reps 4 --fwd 5 --profile --out gpurun_out/${TAG}_fwd_ab_vae.json > gpurun_out/${TAG}_fwd_ab_vae.log 2>&1; grep -v "^    " gpurun_out/${TAG}_fwd_ab_vae.log | tail -3
     grep -v "^    " gpurun_out/${TAG}_fwd_ab_base.log | tail -4 ;;
   *) echo "unknown pass $WHAT"; exit 2 ;;
 esac
