@@ -233,7 +233,15 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         """:1252-1305: target size, latent vs image-space upscaler."""
         if self.enable_hr:
             self.latent_scale_mode = {"Latent": "bilinear", "Latent (nearest)": "nearest", "Latent (bicubic)": "bicubic",
-                                      "Latent (nearest-exact)": "nearest-exact"}.get(self.hr_upscaler)       # shared.py:54-62
+                                      "Latent (nearest-exact)": "nearest-exact",
+                                      # antialias = True only changes F.interpolate when it SHRINKS: enlarging, the bilinear filter's support
+                                      # stays one source pixel and the result is the plain mode's (to fp32 rounding); checked in sample_hr_pass
+                                      "Latent (antialiased)": "bilinear"}.get(self.hr_upscaler)               # shared.py:54-62
+            if self.hr_upscaler == "Latent (bicubic antialiased)":
+                # torch's antialiased bicubic is another filter (Keys a = -0.5 instead of -0.75) even when enlarging: not what
+                # sdmi_latent_resize computes.  A named gap (DESIGN.md section 6), not a silent substitution.
+                raise NotImplementedError("hires upscaler 'Latent (bicubic antialiased)' is not implemented by the engine "
+                                          "(use 'Latent (bicubic)' or an image-space upscaler)")
             if self.latent_scale_mode is None:
                 from . import upscaler
                 if not shared.sd_upscalers:
@@ -284,11 +292,15 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         """modules/processing.py:1364-1464.  Latent upscalers (shared.py:54-62) resample the undecoded first-pass latents on the
         device; image-space upscalers get the decoded uint8 images (PIL, exactly as the reference hands them to
         images.resize_image) and the result is re-encoded.  Fresh ImageRNG noise; second pass = sample_img2img at hr size."""
+        if shared.state.interrupted:                         # :1365-1366 — an interrupted first pass is returned as it is
+            return samples
         self.is_hr_pass = True
         target_w, target_h = self.hr_upscale_to_x, self.hr_upscale_to_y
         name = self.hr_sampler_name or self.sampler_name
         self.sampler = sd_samplers.create_sampler(name, self.sd_model)
         if self.latent_scale_mode is not None:
+            if self.hr_upscaler == "Latent (antialiased)" and (target_h // opt_f < samples.shape[2] or target_w // opt_f < samples.shape[3]):
+                raise NotImplementedError("'Latent (antialiased)' shrinking the first-pass latent: the antialiasing filter is not implemented")
             # K16 (SURVEY.md 2.3): [B,4,h,w] resample = F.interpolate(..., mode, antialias=False) (modules/processing.py:1392)
             samples = ops.latent_resize(samples, (target_h // opt_f, target_w // opt_f), self.latent_scale_mode)
             # :1395-1399 (at the default mask weight 1.0 the hires pass of an inpainting checkpoint is conditioned like txt2img)
@@ -309,6 +321,8 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
             image = ops.lincomb(torch.empty_like(decoded), [decoded, torch.ones_like(decoded)], [2.0, -1.0])   # image * 2 - 1
             samples = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(image))          # :1421
             image_conditioning = self.img2img_image_conditioning(decoded, samples)       # (sic) the [0,1] image, as :1423 passes it
+        if hasattr(shared.state, "nextjob"):
+            shared.state.nextjob()                            # :1425
         # :1427
         samples = samples[:, :, self.truncate_y // 2:samples.shape[2] - (self.truncate_y + 1) // 2,
                           self.truncate_x // 2:samples.shape[3] - (self.truncate_x + 1) // 2].contiguous()

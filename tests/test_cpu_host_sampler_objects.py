@@ -218,3 +218,29 @@ def test_ddim_txt2img_and_img2img_through_the_sampler_object(ss, monkeypatch, et
     rng = Rng(7000)
     want = okd.sample_ddim(model, xi, ts[:t_enc], acp, dict(cond=COND, uncond=UNCOND, cond_scale=6.0), rng.next, eta=eta)
     assert rel(got, want) < 5e-6
+
+
+def test_hires_init_resolves_upscaler_names_and_writes_the_infotext_keys():
+    """StableDiffusionProcessingTxt2Img.init (modules/processing.py:1213-1305): the six latent modes of shared.py:55-62 — the antialiased
+    bilinear one is the plain mode when enlarging, the antialiased bicubic one is a named gap, not a lookup error —, target size and
+    truncation arithmetic, the infotext keys."""
+    pr = sub("processing")
+    p = pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_scale=1.5, hr_second_pass_steps=7, hr_sampler_name="DPM++ 2M",
+                                            sampler_name="Euler a", width=512, height=768)
+    p.init(None, None, None)
+    assert (p.hr_upscale_to_x, p.hr_upscale_to_y, p.latent_scale_mode) == (768, 1152, "bilinear")
+    assert p.extra_generation_params == {"Denoising strength": 0.75, "Hires upscale": 1.5, "Hires sampler": "DPM++ 2M", "Hires schedule type": None,
+                                         "Hires steps": 7, "Hires upscaler": "Latent"}
+    p = pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_resize_x=1024, hr_resize_y=1024, hr_upscaler="Latent (antialiased)",
+                                            sampler_name="Euler a", width=512, height=768)
+    p.init(None, None, None)
+    # crop-to-fill: 512x768 -> 1024x1536, 512 rows cut = 64 latent rows (:1236-1250)
+    assert (p.hr_upscale_to_x, p.hr_upscale_to_y, p.truncate_x, p.truncate_y, p.latent_scale_mode) == (1024, 1536, 0, 64, "bilinear")
+    assert p.extra_generation_params["Hires resize"] == "1024x1024" and "Hires upscale" not in p.extra_generation_params
+    with pytest.raises(NotImplementedError, match="bicubic antialiased"):
+        pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler="Latent (bicubic antialiased)").init(None, None, None)
+    with pytest.raises(Exception, match="could not find upscaler"):
+        pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler="No such upscaler").init(None, None, None)
+    p = pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler="Lanczos")
+    p.init(None, None, None)
+    assert p.latent_scale_mode is None                       # image-space upscaler: decode -> PIL resize -> encode
