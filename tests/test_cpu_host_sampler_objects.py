@@ -244,3 +244,29 @@ def test_hires_init_resolves_upscaler_names_and_writes_the_infotext_keys():
     p = pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler="Lanczos")
     p.init(None, None, None)
     assert p.latent_scale_mode is None                       # image-space upscaler: decode -> PIL resize -> encode
+
+
+def test_lcm_and_restart_through_their_sampler_objects(ss):
+    """LCM (modules/sd_samplers_lcm.py: its own denoiser wrapper — 50 original timesteps, the consistency scaling folded into the affine
+    combine — and its own schedule) and Restart (sd_samplers_extra.py: Karras schedule, the restart plan's extra noise)."""
+    acp = okd.make_alphas_cumprod()
+    sampler, p, eng = make(ss, "LCM", steps=4, cfg_scale=1.5)
+    x = seeded(SHAPE, 7800)
+    got = sampler.sample(p, x.clone(), COND, UNCOND)
+    den = okd.LCMCompVisDenoiser(lambda xs, t, cond, ic=None: unet(xs, t, cond, ic), acp)
+    cfg = okd.CFGDenoiser(den)
+    cfg.total_steps = 4
+    sig = den.get_sigmas(4)
+    assert torch.allclose(sampler.get_sigmas(p, 4), sig, rtol=1e-6, atol=0)
+    rng = Rng(7000)
+    want = okd.sample_lcm(lambda xx, s, **kw: cfg(xx, s, kw["uncond"], kw["cond"], kw["cond_scale"]), x * sig[0], sig,
+                          dict(cond=COND, uncond=UNCOND, cond_scale=1.5), rng.next)
+    assert rel(got, want) < 5e-6 and p.rng.i == rng.i and len(eng.calls) == 4
+    sampler, p, eng = make(ss, "Restart", steps=8)
+    got = sampler.sample(p, x.clone(), COND, UNCOND)
+    den, cfg, model = oracle_chain()
+    sig = okd.get_sigmas_karras(8, den.sigmas[0].item(), den.sigmas[-1].item())
+    cfg.total_steps = 16
+    rng = Rng(7000)
+    want = okd.restart_sampler(model, x * sig[0], sig, dict(cond=COND, uncond=UNCOND, cond_scale=6.0), rng.next)
+    assert rel(got, want) < 5e-6 and p.rng.i == rng.i
