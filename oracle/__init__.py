@@ -38,4 +38,8 @@ PARITY UNPINNED: the remainder of the UNet forward (ResBlock, GEGLU feed-forward
 than Euler, with get_sigmas_karras / _exponential / _polyexponential — the reference's tests hold no numeric vector for them and
 the arithmetic lives in un-vendored third-party repos (ldm @ cf1d67a6, sgm @ 45c443b3, k-diffusion @ ab527a9a); they are restated
 from the published algorithms and anchored on the in-tree call sites and state-dict layout.
+What CAN be checked without those packages is (tests/test_oracle_properties.py): on Gaussian data the ideal denoiser, the probability-flow
+solution and the SDE's marginals are closed-form, so every k-diffusion restatement must converge to the exact flow at its published order
+(or keep the marginal variance), DPM++ SDE must be second order only on one Brownian path, and the Brownian tree must be a Brownian
+motion with consistent nested increments.  A transcription error fails those tests; they are not a pin, and the status above stands.
 """
