@@ -70,6 +70,8 @@ class StableDiffusionProcessing:
     all_subseeds: List[int] = None
     iteration: int = 0
     extra_generation_params: dict = field(default_factory=dict)
+    override_settings: dict = field(default_factory=dict)        # :156 — options for THIS job (API / pasted infotext), put back afterwards
+    override_settings_restore_afterwards: bool = True             # :157
     keep_latents: bool = True
 
     def __post_init__(self):
@@ -581,7 +583,28 @@ def decode_latent_batch(model, batch, target_device=None, check_for_nans=False):
 
 
 def process_images(p: StableDiffusionProcessing) -> Processed:
-    """modules/processing.py:819-1150 (process_images -> process_images_inner) for the engine path."""
+    """modules/processing.py:819-857: the job's option overrides are set for its duration and restored afterwards (the checkpoint / VAE
+    entries belong to the model loader and are not options of this path), the sampler / scheduler names are brought to the table's spelling
+    ("DPM++ 2M Karras" -> "DPM++ 2M" + "Karras"), then the job itself."""
+    opts = shared.opts
+    overrides = {k: v for k, v in (p.override_settings or {}).items() if k not in ("sd_model_checkpoint", "sd_vae")}
+    unknown = [k for k in overrides if not hasattr(opts, k)]
+    if unknown:
+        raise KeyError(unknown[0])                            # modules/options.py:151: opts.set looks the key up in data_labels
+    stored = {k: getattr(opts, k) for k in overrides}
+    try:
+        for k, v in overrides.items():
+            setattr(opts, k, v)
+        sd_samplers.fix_p_invalid_sampler_and_scheduler(p)
+        return _process_images_inner(p)
+    finally:
+        if p.override_settings_restore_afterwards:
+            for k, v in stored.items():
+                setattr(opts, k, v)
+
+
+def _process_images_inner(p: StableDiffusionProcessing) -> Processed:
+    """modules/processing.py:860-1150 (process_images_inner) for the engine path."""
     assert p.c is not None and p.uc is not None, "conditioning tensors p.c / p.uc are required (text encoder is out of scope)"
     n_total = p.batch_size * p.n_iter
     seed = 1000 if p.seed is None or isinstance(p.seed, (list, tuple)) or p.seed == -1 else int(p.seed)

@@ -1582,17 +1582,17 @@ samplers_k_diffusion = [
     ('DPM++ SDE', sample_dpmpp_sde, ['k_dpmpp_sde'], {'scheduler': 'karras', "second_order": True, "brownian_noise": True}),
     ('DPM++ 2M SDE', sample_dpmpp_2m_sde, ['k_dpmpp_2m_sde'], {'scheduler': 'exponential', "brownian_noise": True}),
     ('DPM++ 2M SDE Heun', sample_dpmpp_2m_sde, ['k_dpmpp_2m_sde_heun'], {'scheduler': 'exponential', "brownian_noise": True, "solver_type": "heun"}),
-    ('DPM++ 3M SDE', sample_dpmpp_3m_sde, ['k_dpmpp_3m_sde'], {'scheduler': 'exponential', 'discard_next_to_last_sigma': True, "brownian_noise": True}),
     ('DPM++ 2S a', sample_dpmpp_2s_ancestral, ['k_dpmpp_2s_a'], {'scheduler': 'karras', "uses_ensd": True, "second_order": True}),
+    ('DPM++ 3M SDE', sample_dpmpp_3m_sde, ['k_dpmpp_3m_sde'], {'scheduler': 'exponential', 'discard_next_to_last_sigma': True, "brownian_noise": True}),
     ('Euler a', sample_euler_ancestral, ['k_euler_a', 'k_euler_ancestral'], {"uses_ensd": True}),
     ('Euler', sample_euler, ['k_euler'], {}),
     ('LMS', sample_lms, ['k_lms'], {}),
     ('Heun', sample_heun, ['k_heun'], {"second_order": True}),
     ('DPM2', sample_dpm_2, ['k_dpm_2'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "second_order": True}),
     ('DPM2 a', sample_dpm_2_ancestral, ['k_dpm_2_a'], {'scheduler': 'karras', 'discard_next_to_last_sigma': True, "uses_ensd": True, "second_order": True}),
-    ('Restart', restart_sampler, ['restart'], {'scheduler': 'karras', "second_order": True}),
     ('DPM fast', sample_dpm_fast, ['k_dpm_fast'], {"uses_ensd": True}),
     ('DPM adaptive', sample_dpm_adaptive, ['k_dpm_ad'], {"uses_ensd": True}),
+    ('Restart', restart_sampler, ['restart'], {'scheduler': 'karras', "second_order": True}),
 ]
 sampler_extra_params = {                                 # modules/sd_samplers_kdiffusion.py:36-46
     'sample_euler': ['s_churn', 's_tmin', 's_tmax', 's_noise'],
@@ -1883,6 +1883,34 @@ def find_sampler_config(name):
     if name is not None:
         return all_samplers_map.get(name, None) or all_samplers_map.get(samplers_map.get(str(name).lower(), ""), None)
     return all_samplers[0]
+
+
+def get_sampler_and_scheduler(sampler_name, scheduler_name, *, convert_automatic=True):
+    """modules/sd_samplers.py:105-126: split a pre-1.9 combined name ("DPM++ 2M Karras", "Euler a SGMUniform" — what older API clients
+    and pasted infotexts still carry) into the sampler row and the scheduler label; unknown samplers fall back to the first row, unknown
+    schedulers to Automatic.  With ``convert_automatic`` a scheduler that is the row's own default is reported as Automatic."""
+    from .sd_schedulers import schedulers
+    first_row = all_samplers[0]
+    chosen = schedulers_map.get(scheduler_name, schedulers[0])
+    name = sampler_name or first_row.name
+    for sch in schedulers:                                    # every scheduler is tried in table order; a later match strips again
+        for suffix in (sch.label, sch.name, *(sch.aliases or [])):
+            if name.endswith(" " + suffix):
+                chosen, name = sch, name[:-(len(suffix) + 1)]
+                break
+    row = all_samplers_map.get(name, first_row)
+    if convert_automatic and row.options.get('scheduler', None) == chosen.name:
+        chosen = schedulers[0]
+    return row.name, chosen.label
+
+
+def fix_p_invalid_sampler_and_scheduler(p):
+    """modules/sd_samplers.py:129-133, called by process_images before the job: p.sampler_name / p.scheduler in the table's own spelling."""
+    before = (p.sampler_name, p.scheduler)
+    p.sampler_name, p.scheduler = get_sampler_and_scheduler(p.sampler_name, p.scheduler, convert_automatic=False)
+    if before != (p.sampler_name, p.scheduler):
+        import logging
+        logging.warning(f'Sampler Scheduler autocorrection: "{before[0]}" -> "{p.sampler_name}", "{before[1]}" -> "{p.scheduler}"')
 
 
 def create_sampler(name, model):

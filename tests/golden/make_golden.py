@@ -1285,6 +1285,47 @@ def gen_hypernetwork():
     print("hypernetwork.npz")
 
 
+SAMPLER_NAME_CASES = [("DPM++ 2M Karras", None), ("Euler a", None), ("Euler a SGMUniform", None), ("DPM++ SDE Karras", "Exponential"),
+                      ("nonexistent", "Karras"), (None, None), ("DPM++ 2M", "karras"), ("DPM++ 2M SDE Heun Exponential", None), ("LMS Karras", None),
+                      ("DDIM", "DDIM"), ("Euler a", "Align Your Steps"), ("Heun", "bogus"), ("DPM++ 3M SDE Exponential", "Karras"),
+                      ("Euler Polyexponential", None), ("DPM2 a Karras", None), ("UniPC", "SGM Uniform"), ("Euler a Uniform Karras", None),
+                      ("DPM++ 2M SDE Karras", None), ("DPM adaptive", "Automatic"), ("Restart", "Simple"), ("LCM", None), ("PLMS Beta", "Normal")]
+
+
+def gen_sampler_names():
+    """Execute get_sampler_and_scheduler (modules/sd_samplers.py:105-126: pre-1.9 combined names -> sampler row + scheduler label) over
+    the reference's OWN tables: sd_schedulers.schedulers from the file (loaded as in gen_schedulers) and the sampler rows' (name, options)
+    parsed from the table literals of sd_samplers_kdiffusion.py:11-27, sd_samplers_timesteps.py:12-17 and sd_samplers_lcm.py:100-104 (the
+    modules themselves import k_diffusion).  The function is exec'd from the file's text; nothing is copied into this repository."""
+    import ast
+    import functools
+    import json
+    import re
+    gen_schedulers()                                           # leaves the k_diffusion / modules.shared stand-ins in sys.modules
+    sched = load_by_path("ref_sd_schedulers_names", "modules/sd_schedulers.py")
+    Row = types.SimpleNamespace
+    rows = []
+    kd_src = open(os.path.join(REF, "modules/sd_samplers_kdiffusion.py")).read()
+    table = kd_src[kd_src.index("samplers_k_diffusion = ["):kd_src.index("]\n", kd_src.index("samplers_k_diffusion = ["))]
+    for m in re.finditer(r"\(\s*'([^']+)',\s*[^,\[]+,\s*\[[^\]]*\],\s*(\{[^}]*\})\s*\)", table):
+        rows.append(Row(name=m.group(1), options=ast.literal_eval(m.group(2))))
+    ts_src = open(os.path.join(REF, "modules/sd_samplers_timesteps.py")).read()
+    for m in re.finditer(r"\('([^']+)',\s*sd_samplers_timesteps_impl\.\w+,\s*\[[^\]]*\],\s*(\{[^}]*\})\)", ts_src):
+        rows.append(Row(name=m.group(1), options=ast.literal_eval(m.group(2))))
+    lcm_src = open(os.path.join(REF, "modules/sd_samplers_lcm.py")).read()
+    for m in re.finditer(r"\('([^']+)',\s*sample_lcm,\s*\[[^\]]*\],\s*(\{[^}]*\})\)", lcm_src):
+        rows.append(Row(name=m.group(1), options=ast.literal_eval(m.group(2))))
+    assert len(rows) == 20 and rows[0].name == "DPM++ 2M", [r.name for r in rows]
+    src = open(os.path.join(REF, "modules/sd_samplers.py")).read()
+    fn = re.search(r"def get_sampler_and_scheduler\(.*?\n    return sampler\.name, found_scheduler\.label\n", src, re.S).group(0)
+    ns = {"functools": functools, "samplers": rows, "all_samplers_map": {r.name: r for r in rows}, "sd_schedulers": sched}
+    exec(fn, ns)
+    out = [[list(c), bool(conv), list(ns["get_sampler_and_scheduler"](c[0], c[1], convert_automatic=conv))]
+           for c in SAMPLER_NAME_CASES for conv in (True, False)]
+    json.dump({"rows": [[r.name, r.options] for r in rows], "cases": out}, open(os.path.join(OUT, "sampler_names.json"), "w"), indent=0)
+    print("sampler_names.json", len(out))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_philox()
@@ -1310,3 +1351,4 @@ if __name__ == "__main__":
     gen_euler_twin()
     gen_zsnr()
     gen_hypernetwork()
+    gen_sampler_names()

@@ -2,6 +2,7 @@
 and the multi-process path works over gloo with world_size 2."""
 import importlib
 import os
+import types
 import subprocess
 import sys
 import textwrap
@@ -1249,3 +1250,50 @@ def test_engine_sampler_rows_fall_back_or_refuse_when_the_webui_job_needs_torch_
     assert s.stock_delegate.config is row and s.stock_delegate.calls == [("sample", p)] and s.stock_reason == "refiner checkpoint switch"
     # the B4 decode hook leaves a Hypertile-tiled VAE to torch
     assert bridge.hypertile_active(torch.nn.Module()) is False
+
+
+def test_sampler_rows_and_name_resolution_match_the_reference(golden_dir):
+    """The row ORDER, names and options of the reference's three sampler tables, and get_sampler_and_scheduler (modules/sd_samplers.py:
+    105-126: "DPM++ 2M Karras" -> ("DPM++ 2M", "Karras"), unknown names -> the first row / Automatic) against the reference function
+    executed over the reference's own tables (tests/golden/make_golden.py::gen_sampler_names); process_images applies it to the job
+    (fix_p_invalid_sampler_and_scheduler, modules/processing.py:842) together with the job's option overrides."""
+    import json
+    ss = sub("sd_samplers")
+    z = json.load(open(os.path.join(golden_dir, "sampler_names.json")))
+    assert [[r.name, r.options] for r in ss.all_samplers] == z["rows"]
+    for (name, sched), conv, want in z["cases"]:
+        assert list(ss.get_sampler_and_scheduler(name, sched, convert_automatic=conv)) == want, (name, sched, conv)
+    p = types.SimpleNamespace(sampler_name="DPM++ 2M Karras", scheduler=None)
+    ss.fix_p_invalid_sampler_and_scheduler(p)
+    assert (p.sampler_name, p.scheduler) == ("DPM++ 2M", "Karras")
+    # the job's option overrides: set for the job, restored afterwards (also when the job raises), unknown keys refused
+    processing, shared = sub("processing"), sub("shared")
+    seen = {}
+
+    def fake_inner(pp):
+        seen.update(eta=shared.opts.eta_ancestral, ensd=shared.opts.eta_noise_seed_delta, sampler=pp.sampler_name, scheduler=pp.scheduler)
+        if getattr(pp, "boom", False):
+            raise RuntimeError("job failed")
+        return "done"
+    orig = processing._process_images_inner
+    processing._process_images_inner = fake_inner
+    try:
+        before = (shared.opts.eta_ancestral, shared.opts.eta_noise_seed_delta)
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=None, sampler_name="Euler a SGMUniform",
+                                                        override_settings={"eta_ancestral": 0.5, "eta_noise_seed_delta": 31337, "sd_model_checkpoint": "x"})
+        assert processing.process_images(p) == "done"
+        assert seen == {"eta": 0.5, "ensd": 31337, "sampler": "Euler a", "scheduler": "SGM Uniform"}
+        assert (shared.opts.eta_ancestral, shared.opts.eta_noise_seed_delta) == before
+        p.boom = True
+        with pytest.raises(RuntimeError, match="job failed"):
+            processing.process_images(p)
+        assert (shared.opts.eta_ancestral, shared.opts.eta_noise_seed_delta) == before
+        p2 = processing.StableDiffusionProcessingTxt2Img(sd_model=None, sampler_name="Euler", override_settings={"eta_ancestral": 0.25},
+                                                         override_settings_restore_afterwards=False)
+        processing.process_images(p2)
+        assert shared.opts.eta_ancestral == 0.25
+        shared.opts.eta_ancestral = before[0]
+        with pytest.raises(KeyError):
+            processing.process_images(processing.StableDiffusionProcessingTxt2Img(sd_model=None, override_settings={"no_such_option": 1}))
+    finally:
+        processing._process_images_inner = orig
