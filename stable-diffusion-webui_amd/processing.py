@@ -623,6 +623,10 @@ def _process_images_inner(p: StableDiffusionProcessing) -> Processed:
     dev = p.sd_model.device
     for n in range(p.n_iter):
         p.iteration = n
+        if shared.state.skipped:                                     # :935-939 — "Skip" ends one batch, "Interrupt" the whole job
+            shared.state.skipped = False
+        if shared.state.interrupted or getattr(shared.state, "stopping_generation", False):
+            break
         shared.sd_model = p.sd_model                                 # :941 — the previous iteration may have ended on the refiner
         lo, hi = n * p.batch_size, (n + 1) * p.batch_size
         p.seeds = p.all_seeds[lo:hi]
@@ -659,6 +663,6 @@ def _process_images_inner(p: StableDiffusionProcessing) -> Processed:
             latents.append(samples)
     p.close()
     shared.sd_model = p.sd_model                                     # :941 reload_model_weights(): back from a refiner
-    same_size = len({tuple(t.shape[1:]) for t in device_u8}) == 1 and not getattr(p, "overlay_images", None)
+    same_size = len(device_u8) > 0 and len({tuple(t.shape[1:]) for t in device_u8}) == 1 and not getattr(p, "overlay_images", None)
     return Processed(p, images, seed, p.all_seeds, torch.cat(latents) if latents else None,
                      images_device=(device_u8[0] if len(device_u8) == 1 else torch.cat(device_u8)) if same_size else None)

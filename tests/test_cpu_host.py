@@ -1297,3 +1297,35 @@ def test_sampler_rows_and_name_resolution_match_the_reference(golden_dir):
             processing.process_images(processing.StableDiffusionProcessingTxt2Img(sd_model=None, override_settings={"no_such_option": 1}))
     finally:
         processing._process_images_inner = orig
+
+
+def test_process_images_iteration_loop_obeys_skip_and_interrupt(monkeypatch):
+    """modules/processing.py:935-939: a pending Skip is cleared when the next batch starts (it ended the previous one), Interrupt / stop
+    ends the job before the next batch; what was finished is returned.  The device work of a batch is stubbed out."""
+    processing, shared = sub("processing"), sub("shared")
+    calls = []
+
+    class P(processing.StableDiffusionProcessingTxt2Img):
+        def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
+            calls.append((self.iteration, list(seeds)))
+            if self.iteration == 0:
+                shared.state.skipped = True                   # "Skip" pressed during the first batch
+            if self.iteration == 1:
+                shared.state.interrupted = True               # "Interrupt" during the second
+            return torch.zeros(len(seeds), 4, 8, 8)
+
+    eng = types.SimpleNamespace(set_option=lambda *a: None)
+    model = types.SimpleNamespace(engine=eng, device=torch.device("cpu"), alphas_cumprod=sub("schema").make_alphas_cumprod())
+    monkeypatch.setattr(processing, "ImageRNG", lambda *a, **kw: None)
+    monkeypatch.setattr(processing, "decode_latent_batch", lambda m, x, **kw: torch.zeros(x.shape[0], 3, 64, 64))
+    monkeypatch.setattr(processing.ops, "image_to_u8", lambda x: torch.zeros(x.shape[0], 64, 64, 3, dtype=torch.uint8))
+    monkeypatch.setattr(processing.sd_models, "apply_alpha_schedule_override", lambda m, p=None: None)
+    monkeypatch.setattr(shared.state, "interrupted", False, raising=False)
+    monkeypatch.setattr(shared.state, "skipped", False, raising=False)
+    c = torch.zeros(6, 77, 8)
+    res = processing.process_images(P(sd_model=model, c=c, uc=c, seed=50, batch_size=2, n_iter=3, sampler_name="Euler a", width=64, height=64))
+    assert calls == [(0, [50, 51]), (1, [52, 53])]            # the third batch never started
+    assert len(res.images) == 4 and res.all_seeds == [50, 51, 52, 53, 54, 55] and shared.state.skipped is False
+    # interrupted before the first batch: an empty result, not an error
+    res = processing.process_images(P(sd_model=model, c=c, uc=c, seed=50, batch_size=2, n_iter=3, sampler_name="Euler a", width=64, height=64))
+    assert res.images == [] and res.latents is None and res.images_device is None
