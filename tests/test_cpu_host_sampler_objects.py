@@ -270,3 +270,58 @@ def test_lcm_and_restart_through_their_sampler_objects(ss):
     rng = Rng(7000)
     want = okd.restart_sampler(model, x * sig[0], sig, dict(cond=COND, uncond=UNCOND, cond_scale=6.0), rng.next)
     assert rel(got, want) < 5e-6 and p.rng.i == rng.i
+
+
+def test_whole_standalone_job_with_hires_on_stub_devices(ss, monkeypatch):
+    """process_images -> StableDiffusionProcessingTxt2Img.sample -> sample_hr_pass -> the sampler objects -> CFGDenoiser, wired as the
+    product wires them, with the engine, the noise source, the latent resampler and the VAE replaced by CPU stand-ins: the job's
+    bookkeeping (seeds, per-iteration slices, combined sampler name, option overrides, infotext of both passes, hires schedule) against
+    the same job written with the oracle's pieces."""
+    processing, shared = sub("processing"), sub("shared")
+    eng = StubEngine(C)
+    eng.set_option = lambda *a: None
+    model = types.SimpleNamespace(engine=eng, alphas_cumprod=okd.make_alphas_cumprod(), parameterization="eps", cond_stage_key="txt",
+                                  model=types.SimpleNamespace(conditioning_key="crossattn"), device=torch.device("cpu"))
+
+    class FakeRng:                                            # ImageRNG: first_noise per (shape, seeds), then per-step draws
+        def __init__(self, shape, seeds, **kw):
+            self.shape, self.seeds, self.n = tuple(shape), list(seeds), 0
+
+        def next(self):
+            self.n += 1
+            return torch.stack([seeded(self.shape, 100000 * self.n + s) for s in self.seeds])
+    monkeypatch.setattr(processing, "ImageRNG", FakeRng)
+    monkeypatch.setattr(processing.ops, "latent_resize", lambda x, size, mode: torch.nn.functional.interpolate(x, size=size, mode=mode, antialias=False))
+    monkeypatch.setattr(processing, "decode_latent_batch", lambda m, x, **kw: x[:, :3].repeat_interleave(8, 2).repeat_interleave(8, 3))
+    monkeypatch.setattr(processing.ops, "image_to_u8", lambda x: (x.clamp(-1, 1).add(1).mul(127.5)).to(torch.uint8).permute(0, 2, 3, 1).contiguous())
+    monkeypatch.setattr(processing.sd_models, "apply_alpha_schedule_override", lambda m, p=None: None)
+    monkeypatch.setattr(shared.state, "interrupted", False, raising=False)
+    monkeypatch.setattr(shared.state, "skipped", False, raising=False)
+    cond, uncond = seeded((4, 8, 6), 8100, 0.5), seeded((4, 8, 6), 8101, 0.5)
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond, uc=uncond, seed=77, batch_size=2, n_iter=2, steps=5, cfg_scale=5.0,
+                                                    width=64, height=64, sampler_name="DPM++ 2M Karras", enable_hr=True, hr_scale=2.0,
+                                                    hr_upscaler="Latent (nearest)", hr_second_pass_steps=3, denoising_strength=0.5,
+                                                    override_settings={"eta_noise_seed_delta": 7})
+    res = processing.process_images(p)
+    assert (p.sampler_name, p.scheduler) == ("DPM++ 2M", "Karras") and res.all_seeds == [77, 78, 79, 80]
+    assert len(res.images) == 4 and res.images[0].shape == (128, 128, 3) and res.latents.shape == (4, C, 16, 16)
+    assert shared.opts.eta_noise_seed_delta == 0
+    info = p.extra_generation_params
+    assert info["Schedule type"] == "Karras" and info["Hires upscale"] == 2.0 and info["Hires steps"] == 3 and info["Hires upscaler"] == "Latent (nearest)"
+    assert info["Denoising strength"] == 0.5 and info.get("Hires schedule type") is None
+    # the same job from the oracle's pieces, second image pair (iteration 1: seeds 79, 80; conds rows 2..3)
+    den, cfg, model_fn = oracle_chain()
+    sig = okd.get_sigmas_karras(5, den.sigmas[0].item(), den.sigmas[-1].item())
+    r1 = FakeRng((C, 8, 8), [79, 80])
+    cfg.total_steps = 5
+    extra = dict(cond=cond[2:4], uncond=uncond[2:4], cond_scale=5.0)
+    first = okd.sample_dpmpp_2m(model_fn, r1.next() * sig[0], sig, extra)
+    up = torch.nn.functional.interpolate(first, size=(16, 16), mode="nearest")
+    steps, t_enc = okd.setup_img2img_steps(3, 0.5, steps_given=True)
+    sig2 = okd.get_sigmas_karras(steps, den.sigmas[0].item(), den.sigmas[-1].item())
+    sched = sig2[steps - t_enc - 1:]
+    r2 = FakeRng((C, 16, 16), [79, 80])
+    den, cfg, model_fn = oracle_chain()
+    cfg.total_steps = t_enc + 1
+    want = okd.sample_dpmpp_2m(model_fn, up + r2.next() * sched[0], sched, extra)
+    assert rel(res.latents[2:4], want) < 1e-5
