@@ -325,3 +325,58 @@ def test_whole_standalone_job_with_hires_on_stub_devices(ss, monkeypatch):
     cfg.total_steps = t_enc + 1
     want = okd.sample_dpmpp_2m(model_fn, up + r2.next() * sched[0], sched, extra)
     assert rel(res.latents[2:4], want) < 1e-5
+
+
+def test_whole_standalone_img2img_job_with_a_latent_mask_on_stub_devices(ss, monkeypatch):
+    """process_images -> StableDiffusionProcessingImg2Img.init / sample -> sample_img2img -> CFGDenoiser with the inpainting blends
+    (modules/sd_samplers_cfg_denoiser.py:292-293 per step, modules/processing.py:1776-1784 at the end), the initial-noise multiplier, the
+    per-iteration slices of init latent / mask / image conditioning — against the same job written with the oracle's pieces."""
+    processing, shared = sub("processing"), sub("shared")
+    eng = StubEngine(C)
+    eng.set_option = lambda *a: None
+    pool = torch.nn.AvgPool2d(8)
+    model = types.SimpleNamespace(engine=eng, alphas_cumprod=okd.make_alphas_cumprod(), parameterization="eps", cond_stage_key="txt",
+                                  model=types.SimpleNamespace(conditioning_key="crossattn"), device=torch.device("cpu"),
+                                  encode_first_stage=lambda img: pool(img),                       # "moments": a 3-channel pooled image
+                                  get_first_stage_encoding=lambda m: torch.cat([m, m[:, :1]], 1).contiguous() * 0.5)
+
+    class FakeRng:
+        def __init__(self, shape, seeds, **kw):
+            self.shape, self.seeds, self.n = tuple(shape), list(seeds), 0
+
+        def next(self):
+            self.n += 1
+            return torch.stack([seeded(self.shape, 100000 * self.n + s) for s in self.seeds])
+    monkeypatch.setattr(processing, "ImageRNG", FakeRng)
+    monkeypatch.setattr(processing.ops, "lincomb", lambda out, terms, coefs: out.copy_(sum(float(c) * t for c, t in zip(coefs, terms))))
+    monkeypatch.setattr(processing.ops, "mask_blend", lambda x, init, mask, nmask: x.copy_(x * nmask + init * mask))
+    monkeypatch.setattr(processing, "decode_latent_batch", lambda m, x, **kw: x[:, :3].repeat_interleave(8, 2).repeat_interleave(8, 3))
+    monkeypatch.setattr(processing.ops, "image_to_u8", lambda x: (x.clamp(-1, 1).add(1).mul(127.5)).to(torch.uint8).permute(0, 2, 3, 1).contiguous())
+    monkeypatch.setattr(processing.sd_models, "apply_alpha_schedule_override", lambda m, p=None: None)
+    monkeypatch.setattr(shared.state, "interrupted", False, raising=False)
+    monkeypatch.setattr(shared.state, "skipped", False, raising=False)
+    cond, uncond = seeded((4, 8, 6), 8200, 0.5), seeded((4, 8, 6), 8201, 0.5)
+    init = torch.rand((4, 3, 64, 64), generator=torch.Generator().manual_seed(5))
+    keep = torch.zeros(4, 1, 8, 8)
+    keep[:, :, 2:6, 1:5] = 1.0                                # 1 = keep the original latent there
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=model, c=cond, uc=uncond, seed=300, batch_size=2, n_iter=2, steps=8, cfg_scale=4.0,
+                                                    width=64, height=64, sampler_name="Euler a", init_images=init, latent_mask=keep.expand(4, C, 8, 8).clone(),
+                                                    inpainting_fill=1, denoising_strength=0.6, initial_noise_multiplier=1.1)
+    res = processing.process_images(p)
+    info = p.extra_generation_params
+    assert info["Denoising strength"] == 0.6 and info["Noise multiplier"] == 1.1 and res.latents.shape == (4, C, 8, 8)
+    # oracle chain, iteration 1 (images 2, 3: seeds 302, 303)
+    init_lat = model.get_first_stage_encoding(model.encode_first_stage(init * 2 - 1))[2:4]
+    mask = keep[2:4].expand(2, C, 8, 8)
+    den = okd.CompVisDenoiser(lambda xs, t, c, ic=None: unet(xs, t, c, None), okd.make_alphas_cumprod())
+    cfg = okd.CFGDenoiser(den, mask=mask, nmask=1 - mask, init_latent=init_lat)
+    steps, t_enc = okd.setup_img2img_steps(8, 0.6, steps_given=False)
+    sched = den.get_sigmas(steps)[steps - t_enc - 1:]
+    cfg.total_steps = t_enc + 1
+    rng = FakeRng((C, 8, 8), [302, 303])
+    noise = rng.next() * 1.1
+    model_fn = lambda x, sigma, **kw: cfg(x, sigma, kw["uncond"], kw["cond"], kw["cond_scale"])   # noqa: E731
+    out = okd.sample_euler_ancestral(model_fn, init_lat + noise * sched[0], sched, dict(cond=cond[2:4], uncond=uncond[2:4], cond_scale=4.0), rng.next)
+    want = out * (1 - mask) + init_lat * mask
+    assert rel(res.latents[2:4], want) < 1e-5
+    assert torch.equal(res.latents[2:4][mask.bool()], init_lat[mask.bool()])      # the kept region is the original latent, exactly
