@@ -547,6 +547,20 @@ class Processed:
         self.sampler_name, self.cfg_scale, self.steps = p.sampler_name, p.cfg_scale, p.steps
         self.batch_size = p.batch_size
         self.latents = latents
+        # the sampling-side fields of the reference's Processed (:517-563) a caller may read back; the text / file / model-name fields
+        # (prompt, info, infotexts, sd_model_hash ...) belong to layers outside this path
+        self.prompt = p.prompt if not isinstance(p.prompt, list) else (p.prompt[0] if p.prompt else "")
+        self.negative_prompt = p.negative_prompt if not isinstance(p.negative_prompt, list) else (p.negative_prompt[0] if p.negative_prompt else "")
+        self.all_subseeds = list(getattr(p, "all_subseeds", None) or [])
+        self.subseed = self.all_subseeds[0] if self.all_subseeds else -1
+        self.subseed_strength = p.subseed_strength
+        self.seed_resize_from_w, self.seed_resize_from_h = p.seed_resize_from_w, p.seed_resize_from_h
+        self.image_cfg_scale = getattr(p, "image_cfg_scale", None)
+        self.denoising_strength = getattr(p, "denoising_strength", None)
+        self.extra_generation_params = p.extra_generation_params
+        self.index_of_first_image = 0
+        self.eta, self.s_churn, self.s_tmin, self.s_tmax, self.s_noise, self.s_min_uncond = p.eta, p.s_churn, p.s_tmin, p.s_tmax, p.s_noise, p.s_min_uncond
+        self.sampler_noise_scheduler_override = p.sampler_noise_scheduler_override
 
 
 def decode_latent_batch(model, batch, target_device=None, check_for_nans=False):
