@@ -12,7 +12,8 @@ values: outputs of this tool are compared with each other, never with the oracle
 
 Per setting: ms per forward (min / median over `--reps` rounds of `--fwd` timed forwards after one warm-up, settings interleaved),
 and the output's relative L2 distance and exact-equality flag against the first setting.  `--profile` adds the HIP-event kernel-class
-table of one forward per setting.  Settings use knob_sweep.py's syntax; `cfg_pairs` / `uniform_t` are engine options here
+table of one forward per setting.  Settings use knob_sweep.py's syntax, plus `gemm_override=<M,N,K,taps,kind:cfg:split;...>` as the last
+item of a setting (per-shape tile / split choices: what tools/gpu/shape_tune.py explores inside the job); `cfg_pairs` / `uniform_t` are engine options here
 (default 1 / 1: what the samplers ask for).  (Does not import oracle/.)
 """
 import argparse
@@ -97,7 +98,7 @@ def hash_u32(s):
     return h
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("settings", nargs="+")
     ap.add_argument("--reps", type=int, default=3)
@@ -110,7 +111,12 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fwd_ab.json"))
     ap.add_argument("--dump", default=None, help="write inputs and every setting's output to this .npz (tools/cpu/fwd_parity.py compares them with "
                                                  "the fp32 CPU oracle on the same weights; use --rows 2: the oracle forward is CPU work)")
-    args = ap.parse_args()
+    return ap
+
+
+def build(args):
+    """Engine + weights + inputs for ``args`` (what / model / rows / hw): a namespace with forward(), apply(setting), profile_once() and
+    the buffers — shared by main() below and tools/gpu/shape_screen.py."""
     global hipmem
     import hipmem
     t_start = time.time()
@@ -190,6 +196,12 @@ def main():
 
     def apply(setting):
         vals = dict(DEFAULTS)
+        override = ""
+        if "gemm_override=" in setting:                       # string knob, always LAST in a setting (its value holds , : ;):
+            setting, override = setting.split("gemm_override=", 1)      #   "conv_korder=0,gemm_override=4096,1280,1280,1,0:9:1;..."
+            setting = setting.rstrip(",") or "base"
+        if lib.sdmi_debug_set_str(b"gemm_override", override.encode()) and override:
+            _lib.check(1, "gemm_override")
         if setting != "base":
             for kv in setting.split(","):
                 k, v = kv.split("=")
@@ -204,6 +216,28 @@ def main():
             _lib.check(rc, k)
         # cached K / V^T of the text context depend on nothing a knob changes, but a knob may change the arena: one untimed forward follows
 
+
+    def profile_once():
+        """HIP-event kernel list of ONE forward under the current setting (one untimed forward first)."""
+        forward()
+        hipmem.sync()
+        _lib.check(lib.sdmi_profile_begin(), "profile_begin")
+        forward()
+        hipmem.sync()
+        buf = C.create_string_buffer(1 << 21)
+        _lib.check(lib.sdmi_profile_end(buf, len(buf)), "profile_end")
+        return json.loads(buf.value.decode())["kernels"]
+
+    import types
+    return types.SimpleNamespace(lib=lib, _lib=_lib, handle=handle, forward=forward, apply=apply, profile_once=profile_once, dout=dout,
+                                 out_shape=out_shape, x=x, t=t, ctx=ctx, y=y, nparam=nparam, t_start=t_start, t_loaded=t_loaded, B=B, hw=hw)
+
+
+def main(argv=None):
+    args = parser().parse_args(argv)
+    env = build(args)
+    lib, _lib, handle, forward, apply, dout, out_shape = env.lib, env._lib, env.handle, env.forward, env.apply, env.dout, env.out_shape
+    x, t, ctx, y, nparam, t_start, t_loaded, B, hw = env.x, env.t, env.ctx, env.y, env.nparam, env.t_start, env.t_loaded, env.B, env.hw
     e0, e1 = hipmem.Event(), hipmem.Event()
     times = {s: [] for s in args.settings}
     outs, failed = {}, {}
@@ -266,14 +300,7 @@ def main():
             if s in failed:
                 continue
             apply(s)
-            forward()
-            hipmem.sync()
-            _lib.check(lib.sdmi_profile_begin(), "profile_begin")
-            forward()
-            hipmem.sync()
-            buf = C.create_string_buffer(1 << 21)
-            _lib.check(lib.sdmi_profile_end(buf, len(buf)), "profile_end")
-            kernels = json.loads(buf.value.decode())["kernels"]
+            kernels = env.profile_once()
             groups = {}
             for k in kernels:
                 g = groups.setdefault(classify(k["name"]), [0.0, 0.0, 0])
