@@ -1,0 +1,75 @@
+// emu.cpp — the elementwise kernels of libsdmi (stable-diffusion-webui_amd/csrc/elementwise.hip, the file itself, unmodified) compiled as
+// plain C++ against tests/hostemu/hip/hip_runtime.h and run thread by thread on the CPU.  TEST INFRASTRUCTURE: it lets the CPU tier check
+// the ARITHMETIC of the shipped kernel source — Philox bit patterns, the uint8 conversion's truncation, the weight packing's index map,
+// the sampler-step contracts of include/sdmi.h — without a GPU.  Kernels that need workgroup barriers or cross-lane traffic
+// (dpm_error, small_linear_lds, softmax_rows, slerp's norm) compile but are not exported: one-thread-at-a-time execution is not their
+// semantics.  Nothing here is linked into the product.
+#include "common.h"
+#include "prof.h"
+
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace sdmi {
+static thread_local std::string g_emu_err;
+void set_error(const std::string& m) { g_emu_err = m; }
+const char* get_error() { return g_emu_err.c_str(); }
+bool prof_enabled() { return false; }
+void prof_begin() {}
+std::string prof_end() { return "{}"; }
+void prof_mark_start(const char*, double, double, hipStream_t) {}
+void prof_mark_stop(hipStream_t) {}
+alignas(16) float sa[1 << 16];                         // what `extern __shared__ float sa[]` (small_linear_lds) resolves to: that kernel is not run
+}  // namespace sdmi
+
+using namespace sdmi;
+extern "C" {
+const char* emu_last_error() { return get_error(); }
+int emu_philox(float* out, int64_t n, uint64_t seed, uint32_t offset) { return launch_philox(out, n, seed, offset, nullptr); }
+int emu_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W) { return launch_image_to_u8(img, out, B, C, H, W, nullptr); }
+int emu_latent_resize(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, int mode) {
+    return launch_latent_resize(in, out, planes, hi, wi, ho, wo, mode, nullptr);
+}
+int emu_cfg_prepare(const float* x, const float* c_in, void* xin, int out_dtype, int B, int reps, int64_t chw) {
+    return launch_cfg_prepare(x, c_in, xin, out_dtype, B, reps, chw, nullptr);
+}
+int emu_cfg_prepare_concat(const float* x, const float* c_in, const float* cond, void* xin, int out_dtype, int B, int reps, int C, int Cc, int64_t hw,
+                           uint32_t zero_reps) {
+    return launch_cfg_prepare_concat(x, c_in, cond, xin, out_dtype, B, reps, C, Cc, hw, zero_reps, nullptr);
+}
+int emu_cfg_combine(const float* x, const float* eps, const float* c_out, float cond_scale, int mode, const float* mask, const float* nmask,
+                    const float* init, float* den, int B, int64_t chw) {
+    return launch_cfg_combine(x, eps, c_out, cond_scale, mode, mask, nmask, init, den, B, chw, nullptr);
+}
+int emu_cfg_combine_affine(const float* x, const float* out, const float* c_out, const float* c_skip, float cond_scale, const float* mask,
+                           const float* nmask, const float* init, float* den, int B, int64_t chw) {
+    return launch_cfg_combine_affine(x, out, c_out, c_skip, cond_scale, mask, nmask, init, den, B, chw, nullptr);
+}
+int emu_euler_step(float* x, const float* den, const float* noise, float sigma, float sigma_down, float sigma_up, float s_noise, int64_t n) {
+    return launch_euler_step(x, den, noise, sigma, sigma_down, sigma_up, s_noise, n, nullptr);
+}
+int emu_dpmpp2m_step(float* x, const float* den, const float* old, float ratio, float em1, float c1, float c2, int64_t n) {
+    return launch_dpmpp2m_step(x, den, old, ratio, em1, c1, c2, n, nullptr);
+}
+int emu_ddim_step(float* x, const float* e, const float* noise, float* pred_x0, float a_t, float a_prev, float sigma_t, float somat, int64_t n) {
+    return launch_ddim_step(x, e, noise, pred_x0, a_t, a_prev, sigma_t, somat, n, nullptr);
+}
+int emu_axpby(float* y, const float* x, float a, const float* z, float b, int64_t n) { return launch_axpby(y, x, a, z, b, n, nullptr); }
+int emu_lincomb(float* out, const float* const* terms, const float* coefs, int n_terms, int64_t n) {
+    return launch_lincomb(out, terms, coefs, n_terms, n, nullptr);
+}
+int emu_mask_blend(float* x, const float* init, const float* mask, const float* nmask, int64_t n) { return launch_mask_blend(x, init, mask, nmask, n, nullptr); }
+int emu_timestep_embedding(const float* t, float* out, int B, int dim) { return launch_timestep_embedding(t, 1, out, B, dim, nullptr); }
+int emu_pack_conv_weight(const float* w, uint16_t* out_f16_bits, int O, int I, int kh, int kw, int O_pad, int I_pad, int geglu) {
+    return launch_pack_conv_weight(w, 1, (half_t*)out_f16_bits, O, I, kh, kw, O_pad, I_pad, geglu, nullptr);
+}
+int emu_pack_bias(const float* b, float* out, int O, int O_pad, int geglu) { return launch_pack_bias(b, 1, out, O, O_pad, geglu, nullptr); }
+int emu_nchw_to_nhwc(const float* x, uint16_t* out_f16_bits, int B, int C, int HW, int cpad, float scale) {
+    return launch_nchw_to_nhwc(x, 1, (half_t*)out_f16_bits, B, C, HW, cpad, scale, nullptr, nullptr, nullptr);
+}
+int emu_weight_kron(float* out, const float* w, const float* w1, const float* w2, int r1, int c1, int r2, int c2, int k, float scale) {
+    return launch_weight_kron(out, w, w1, w2, r1, c1, r2, c2, k, scale, nullptr);
+}
+int emu_weight_ia3(float* out, const float* w, const float* v, int rows, int cols, int on_input, float scale) {
+    return launch_weight_ia3(out, w, v, rows, cols, on_input, scale, nullptr);
+}
+}
