@@ -3,11 +3,15 @@
 // the ARITHMETIC of the shipped kernel source — Philox bit patterns, the uint8 conversion's truncation, the weight packing's index map,
 // the sampler-step contracts of include/sdmi.h — without a GPU.  Kernels that need workgroup barriers or cross-lane traffic
 // (dpm_error, small_linear_lds, softmax_rows, slerp's norm) compile but are not exported: one-thread-at-a-time execution is not their
-// semantics.  Nothing here is linked into the product.
+// semantics; they, and the GroupNorm / LayerNorm kernels of norm.hip, run in the header's THREADED mode (one OS thread per thread of the
+// running block, real barriers, shuffles through per-wave slots).  Nothing here is linked into the product.
 #include "common.h"
 #include "prof.h"
 
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+thread_local EmuBlock* emu_block = nullptr;
+thread_local unsigned emu_tid = 0;
+int emu_threaded = 0;
 
 namespace sdmi {
 static thread_local std::string g_emu_err;
@@ -18,12 +22,36 @@ void prof_begin() {}
 std::string prof_end() { return "{}"; }
 void prof_mark_start(const char*, double, double, hipStream_t) {}
 void prof_mark_stop(hipStream_t) {}
-alignas(16) float sa[1 << 16];                         // what `extern __shared__ float sa[]` (small_linear_lds) resolves to: that kernel is not run
+alignas(16) float sa[96 * 1024 / 4];                   // what `extern __shared__ float sa[]` (small_linear_lds: up to 96 KB of activations) resolves to
 }  // namespace sdmi
 
 using namespace sdmi;
 extern "C" {
 const char* emu_last_error() { return get_error(); }
+void emu_set_threaded(int on) { emu_threaded = on; }
+// ---- kernels that need the threaded mode ------------------------------------------------------------------------------------------
+int64_t emu_groupnorm_ws_bytes(int B, int HW, int groups) { return groupnorm_ws_bytes(B, HW, groups); }
+int emu_groupnorm(const uint16_t* x0, const uint16_t* x1, int c0, int c1, const float* gamma, const float* beta, uint16_t* out, int B, int HW, int groups,
+                  float eps, int silu, float* ws) {
+    return launch_groupnorm((const half_t*)x0, (const half_t*)x1, c0, c1, gamma, beta, (half_t*)out, B, HW, groups, eps, silu != 0, ws, nullptr);
+}
+int emu_layernorm(const uint16_t* x, const float* gamma, const float* beta, uint16_t* out, int64_t rows, int C, float eps) {
+    return launch_layernorm((const half_t*)x, gamma, beta, (half_t*)out, rows, C, eps, nullptr);
+}
+int emu_ln_rowstats(const uint16_t* x, float* stats, int64_t rows, int C, float eps) { return launch_ln_rowstats((const half_t*)x, stats, rows, C, eps, nullptr); }
+int emu_softmax_rows(const float* in, uint16_t* out, int64_t rows, int cols, int ldi, int ldo) {
+    return launch_softmax_rows(in, (half_t*)out, rows, cols, ldi, ldo, nullptr);
+}
+int emu_dpm_error(const float* lo, const float* hi, const float* prev, float atol, float rtol, float* partial256, int64_t n) {
+    return launch_dpm_error(lo, hi, prev, atol, rtol, partial256, n, nullptr);
+}
+int emu_small_linear(const float* a, const uint16_t* w, const float* bias, const float* add, float* out, int B, int N, int K, int lda, int ldo,
+                     int silu_in, int silu_out) {
+    return launch_small_linear(a, (const half_t*)w, bias, add, out, B, N, K, lda, ldo, silu_in != 0, silu_out != 0, nullptr);
+}
+int emu_slerp(float* out, const float* low, const float* high, float val, int C, int H, int W, float* scratch) {
+    return launch_slerp(out, low, high, val, C, H, W, scratch, nullptr);
+}
 int emu_philox(float* out, int64_t n, uint64_t seed, uint32_t offset) { return launch_philox(out, n, seed, offset, nullptr); }
 int emu_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int W) { return launch_image_to_u8(img, out, B, C, H, W, nullptr); }
 int emu_latent_resize(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, int mode) {

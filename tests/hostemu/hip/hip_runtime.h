@@ -1,16 +1,27 @@
-// host stand-in for <hip/hip_runtime.h>: enough of the HIP surface to compile the elementwise kernels of libsdmi as plain C++ and run
-// them thread by thread on the CPU (no barriers, no cross-lane traffic: kernels that need them are not emulated)
+// Host stand-in for <hip/hip_runtime.h> (TEST INFRASTRUCTURE, tests/test_cpu_kernel_emulation.py): enough of the HIP surface to compile
+// the elementwise and normalisation kernels of libsdmi as plain C++ and run them on the CPU.
+//   sequential mode (default)  every thread of every block runs to completion in turn: exact for kernels without workgroup barriers or
+//                              cross-lane traffic (__syncthreads is a no-op, shuffles return the caller's own value)
+//   threaded mode (emu_set_threaded(1))  one OS thread per thread of the running block; __syncthreads is a barrier over the block,
+//                              __shfl_xor / __shfl_down / __shfl exchange through a per-wavefront (64 lanes) slot array between two
+//                              barriers over the wave — every lane of a wave must reach the shuffle, as on the hardware when EXEC is full.
+// `__shared__` is function-static storage: blocks run one after the other, so a block's threads share it and the next block reuses it.
+// MFMA / LDS-DMA kernels (gemm.hip, attention.hip) are not emulated.
 #pragma once
+#include <pthread.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__
+#define __shared__ static
 #define __restrict__
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -18,19 +29,40 @@ typedef void* hipStream_t;
 typedef void* hipEvent_t;
 typedef int hipError_t;
 enum { hipSuccess = 0, hipMemcpyDeviceToDevice = 3, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-inline void __syncthreads() {}
-inline int __any(int p) { return p; }
-enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
-template <typename T> inline T __shfl_xor(T v, int) { return v; }
-template <typename T> inline T __shfl_down(T v, int) { return v; }
-template <typename T> inline T __shfl(T v, int) { return v; }
+
+struct EmuBlock {                                              // the running block in threaded mode
+    pthread_barrier_t all;
+    pthread_barrier_t wave[16];
+    uint64_t slot[16][64];
+};
+extern thread_local EmuBlock* emu_block;                       // null in sequential mode
+extern thread_local unsigned emu_tid;                          // linear thread id inside the block
+extern int emu_threaded;
+
+inline void __syncthreads() { if (emu_block) pthread_barrier_wait(&emu_block->all); }
+template <typename T> inline T emu_exchange(T v, unsigned src_lane_of_me) {
+    static_assert(sizeof(T) <= 8, "shuffles move at most 8 bytes");
+    if (!emu_block) return v;
+    const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
+    std::memcpy(&emu_block->slot[w][lane], &v, sizeof v);
+    pthread_barrier_wait(&emu_block->wave[w]);
+    T r;
+    std::memcpy(&r, &emu_block->slot[w][src_lane_of_me & 63], sizeof r);
+    pthread_barrier_wait(&emu_block->wave[w]);
+    return r;
+}
+template <typename T> inline T __shfl_xor(T v, int m) { return emu_exchange(v, (emu_tid & 63) ^ (unsigned)m); }
+template <typename T> inline T __shfl_down(T v, int d) { return emu_exchange(v, ((emu_tid & 63) + (unsigned)d) > 63 ? (emu_tid & 63) : (emu_tid & 63) + (unsigned)d); }
+template <typename T> inline T __shfl(T v, int l) { return emu_exchange(v, (unsigned)l); }
+inline int __any(int p) { return p; }                          // (only in kernels the emulation does not run)
 inline float __expf(float x) { return std::exp(x); }
 inline float __logf(float x) { return std::log(x); }
 inline float __fdividef(float a, float b) { return a / b; }
@@ -39,14 +71,34 @@ inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 template <typename T> inline T min(T a, T b) { return a < b ? a : b; }
 template <typename T> inline T max(T a, T b) { return a > b ? a : b; }
-// every thread of every block, one after the other
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                              \
-    do {                                                                                                          \
-        const dim3 g_ = (grid), b_ = (block);                                                                     \
-        gridDim = g_; blockDim = b_;                                                                              \
-        for (unsigned bz = 0; bz < g_.z; ++bz) for (unsigned by = 0; by < g_.y; ++by) for (unsigned bx = 0; bx < g_.x; ++bx) \
-            for (unsigned tz = 0; tz < b_.z; ++tz) for (unsigned ty = 0; ty < b_.y; ++ty) for (unsigned tx = 0; tx < b_.x; ++tx) { \
-                blockIdx = dim3(bx, by, bz); threadIdx = dim3(tx, ty, tz);                                        \
-                kernel(__VA_ARGS__);                                                                              \
-            }                                                                                                     \
-    } while (0)
+
+inline void emu_launch(dim3 g, dim3 b, const std::function<void()>& body) {
+    const unsigned nt = b.x * b.y * b.z;
+    for (unsigned bz = 0; bz < g.z; ++bz) for (unsigned by = 0; by < g.y; ++by) for (unsigned bx = 0; bx < g.x; ++bx) {
+        if (!emu_threaded) {
+            gridDim = g; blockDim = b; blockIdx = dim3(bx, by, bz);
+            for (unsigned tz = 0; tz < b.z; ++tz) for (unsigned ty = 0; ty < b.y; ++ty) for (unsigned tx = 0; tx < b.x; ++tx) {
+                threadIdx = dim3(tx, ty, tz);
+                body();
+            }
+            continue;
+        }
+        EmuBlock blk;
+        pthread_barrier_init(&blk.all, nullptr, nt);
+        const unsigned nw = (nt + 63) / 64;
+        for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&blk.wave[w], nullptr, std::min(64u, nt - w * 64));
+        std::vector<std::thread> ts;
+        ts.reserve(nt);
+        for (unsigned t = 0; t < nt; ++t)
+            ts.emplace_back([&, t]() {
+                gridDim = g; blockDim = b; blockIdx = dim3(bx, by, bz);
+                threadIdx = dim3(t % b.x, (t / b.x) % b.y, t / (b.x * b.y));
+                emu_block = &blk; emu_tid = t;
+                body();
+            });
+        for (auto& th : ts) th.join();
+        pthread_barrier_destroy(&blk.all);
+        for (unsigned w = 0; w < nw; ++w) pthread_barrier_destroy(&blk.wave[w]);
+    }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
