@@ -49,6 +49,12 @@ int emu_small_linear(const float* a, const uint16_t* w, const float* bias, const
                      int silu_in, int silu_out) {
     return launch_small_linear(a, (const half_t*)w, bias, add, out, B, N, K, lda, ldo, silu_in != 0, silu_out != 0, nullptr);
 }
+int emu_ctx_compare(const void* src, int dtype, const uint16_t* cached, int B, int L, int Lpad, int C, int* gate) {
+    return launch_ctx_compare(src, dtype, (const half_t*)cached, B, L, Lpad, C, gate, nullptr);
+}
+int emu_ctx_update_gated(const void* src, int dtype, uint16_t* cached, int B, int L, int Lpad, int C, const int* gate) {
+    return launch_ctx_update_gated(src, dtype, (half_t*)cached, B, L, Lpad, C, gate, nullptr);
+}
 int emu_slerp(float* out, const float* low, const float* high, float val, int C, int H, int W, float* scratch) {
     return launch_slerp(out, low, high, val, C, H, W, scratch, nullptr);
 }
@@ -96,6 +102,20 @@ int emu_nchw_to_nhwc(const float* x, uint16_t* out_f16_bits, int B, int C, int H
 }
 int emu_weight_kron(float* out, const float* w, const float* w1, const float* w2, int r1, int c1, int r2, int c2, int k, float scale) {
     return launch_weight_kron(out, w, w1, w2, r1, c1, r2, c2, k, scale, nullptr);
+}
+int emu_act_f16(uint16_t* x, int64_t n, int kind) { return launch_act_f16((half_t*)x, n, kind, nullptr); }
+int emu_axpy_f16(uint16_t* y, const uint16_t* x, const uint16_t* h, float a, int64_t n) {
+    return launch_axpy_f16((half_t*)y, (const half_t*)x, (const half_t*)h, a, n, nullptr);
+}
+int emu_lora_merge(float* out, const void* w, int w_dtype, const void* up, int up_dtype, const void* down, int down_dtype, int rows, int cols, int rank,
+                   float scale) {
+    return launch_lora_merge(out, w, w_dtype, up, up_dtype, down, down_dtype, rows, cols, rank, scale, nullptr);
+}
+int emu_weight_hadamard(float* out, const float* w, const float* a, const float* b, float scale, int64_t n) {
+    return launch_weight_hadamard(out, w, a, b, scale, n, nullptr);
+}
+int emu_weight_dora(float* out, const float* w, const float* delta, const float* dora_scale, int rows, int cin, int k, float mult) {
+    return launch_weight_dora(out, w, delta, dora_scale, rows, cin, k, mult, nullptr);
 }
 int emu_weight_ia3(float* out, const float* w, const float* v, int rows, int cols, int on_input, float scale) {
     return launch_weight_ia3(out, w, v, rows, cols, on_input, scale, nullptr);

@@ -42,6 +42,7 @@ struct EmuBlock {                                              // the running bl
     pthread_barrier_t all;
     pthread_barrier_t wave[16];
     uint64_t slot[16][64];
+    unsigned wave_lanes[16];
 };
 extern thread_local EmuBlock* emu_block;                       // null in sequential mode
 extern thread_local unsigned emu_tid;                          // linear thread id inside the block
@@ -59,10 +60,19 @@ template <typename T> inline T emu_exchange(T v, unsigned src_lane_of_me) {
     pthread_barrier_wait(&emu_block->wave[w]);
     return r;
 }
+inline int __any(int p) {                                      // wave-wide OR (threaded mode; sequentially a lane only sees itself)
+    if (!emu_block) return p;
+    const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
+    emu_block->slot[w][lane] = p ? 1u : 0u;
+    pthread_barrier_wait(&emu_block->wave[w]);
+    uint64_t any = 0;
+    for (unsigned l = 0; l < emu_block->wave_lanes[w]; ++l) any |= emu_block->slot[w][l];
+    pthread_barrier_wait(&emu_block->wave[w]);
+    return any != 0;
+}
 template <typename T> inline T __shfl_xor(T v, int m) { return emu_exchange(v, (emu_tid & 63) ^ (unsigned)m); }
 template <typename T> inline T __shfl_down(T v, int d) { return emu_exchange(v, ((emu_tid & 63) + (unsigned)d) > 63 ? (emu_tid & 63) : (emu_tid & 63) + (unsigned)d); }
 template <typename T> inline T __shfl(T v, int l) { return emu_exchange(v, (unsigned)l); }
-inline int __any(int p) { return p; }                          // (only in kernels the emulation does not run)
 inline float __expf(float x) { return std::exp(x); }
 inline float __logf(float x) { return std::log(x); }
 inline float __fdividef(float a, float b) { return a / b; }
@@ -86,7 +96,7 @@ inline void emu_launch(dim3 g, dim3 b, const std::function<void()>& body) {
         EmuBlock blk;
         pthread_barrier_init(&blk.all, nullptr, nt);
         const unsigned nw = (nt + 63) / 64;
-        for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&blk.wave[w], nullptr, std::min(64u, nt - w * 64));
+        for (unsigned w = 0; w < nw; ++w) { blk.wave_lanes[w] = std::min(64u, nt - w * 64); pthread_barrier_init(&blk.wave[w], nullptr, blk.wave_lanes[w]); }
         std::vector<std::thread> ts;
         ts.reserve(nt);
         for (unsigned t = 0; t < nt; ++t)
