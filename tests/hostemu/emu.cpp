@@ -17,17 +17,64 @@ namespace sdmi {
 static thread_local std::string g_emu_err;
 void set_error(const std::string& m) { g_emu_err = m; }
 const char* get_error() { return g_emu_err.c_str(); }
-bool prof_enabled() { return false; }
+static std::string g_emu_last_launch;                  // the profiler's launch name: which tile / kernel family a launch really took
+bool prof_enabled() { return true; }
 void prof_begin() {}
 std::string prof_end() { return "{}"; }
-void prof_mark_start(const char*, double, double, hipStream_t) {}
+void prof_mark_start(const char* name, double, double, hipStream_t) { g_emu_last_launch = name ? name : ""; }
 void prof_mark_stop(hipStream_t) {}
 alignas(16) float sa[96 * 1024 / 4];                   // what `extern __shared__ float sa[]` (small_linear_lds: up to 96 KB of activations) resolves to
+alignas(16) char smem[160 * 1024 + 16384];            // what `extern __shared__ char smem[]` of the GEMM kernels resolves to (one workgroup at a time)
+const half_t* zero_page() {
+    static half_t zeros[kZeroPageHalfs] = {};
+    return zeros;
+}
 }  // namespace sdmi
 
 using namespace sdmi;
+#include "../../include/sdmi.h"
 extern "C" {
+// the implicit-GEMM convolution / linear launch of the C ABI (capi.cpp desc_to_p + launch_gemm), threaded mode only
+struct emu_gemm_extras {                                       // the GemmP fields the public descriptor does not carry (engine-internal fusions)
+    float* stats_out; int stats_cpg; int stats_nchunk;         // GroupNorm partial sums from the epilogue; stats_nchunk is written back
+    const float* ln_stats; const float* ln_s; int ln_np; float ln_inv_c, ln_eps;   // EP_LNFOLD consumer side
+    float* lnp_out; int lnp_np;                                // LayerNorm partial row sums, producer side; lnp_np is written back
+    float bias_scale;
+};
+int emu_conv_gemm(const sdmi_conv_desc* d, int cfg, int split, int korder, emu_gemm_extras* x) {
+    GemmP p{};
+    p.a0 = (const half_t*)d->a0; p.a1 = (const half_t*)d->a1; p.w = (const half_t*)d->w;
+    p.bias = (const float*)d->bias; p.rowbias = (const float*)d->rowbias; p.resid = (const half_t*)d->resid; p.out = d->out;
+    p.c0 = d->c0; p.c1 = d->a1 ? d->c1 : 0; p.cin = p.c0 + p.c1;
+    p.lda0 = d->lda0 ? d->lda0 : d->c0; p.lda1 = d->lda1 ? d->lda1 : d->c1;
+    p.Hi = d->Hi; p.Wi = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.taps = d->taps; p.stride = d->stride ? d->stride : 1; p.pad = d->pad; p.up = d->up;
+    p.M = d->B * d->Ho * d->Wo; p.N = d->N; p.K = p.taps * p.cin;
+    p.ldo = d->ldo; p.ldr = d->ldr; p.ldw = p.K; p.ldrb = d->N;
+    p.rows_per_batch = d->Ho * d->Wo;
+    p.n_real = d->n_real ? d->n_real : d->N;
+    p.flags = d->flags;
+    p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+    p.bias_scale = 1.f;
+    if (d->splitk_workspace) p.splitk_ws = (float*)d->splitk_workspace;
+    g_force_gemm_cfg = cfg;                                   // -1: the engine's own choice (tuned table / score model)
+    g_force_gemm_split = split;
+    g_conv_korder = korder;
+    p.a_bs = d->a_bs; p.w_bs = d->w_bs; p.o_bs = d->o_bs; p.r_bs = d->r_bs;
+    if (x) {
+        p.stats_out = x->stats_out; p.stats_cpg = x->stats_cpg;
+        p.ln_stats = x->ln_stats; p.ln_s = x->ln_s; p.ln_np = x->ln_np; p.ln_inv_c = x->ln_inv_c; p.ln_eps = x->ln_eps;
+        p.lnp_out = x->lnp_out;
+        if (x->bias_scale != 0.f) p.bias_scale = x->bias_scale;
+    }
+    int nchunk = 0, np = 0;
+    const int rc = launch_gemm(p, d->batch > 0 ? d->batch : 1, d->force_generic == 1, d->force_generic != 2, nullptr, &nchunk, &np);
+    if (x) { x->stats_nchunk = nchunk; x->lnp_np = np; }
+    return rc;
+}
+int64_t emu_splitk_ws_bytes(int M, int N, int K) { return (int64_t)gemm_splitk_ws_bytes(M, N, K, 1); }
 const char* emu_last_error() { return get_error(); }
+const char* emu_last_launch() { return g_emu_last_launch.c_str(); }
 void emu_set_threaded(int on) { emu_threaded = on; }
 // ---- kernels that need the threaded mode ------------------------------------------------------------------------------------------
 int64_t emu_groupnorm_ws_bytes(int B, int HW, int groups) { return groupnorm_ws_bytes(B, HW, groups); }

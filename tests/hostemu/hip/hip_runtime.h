@@ -43,6 +43,7 @@ struct EmuBlock {                                              // the running bl
     pthread_barrier_t wave[16];
     uint64_t slot[16][64];
     unsigned wave_lanes[16];
+    alignas(16) unsigned char ma[16][64][16], mb[16][64][16];   // MFMA operand fragments of a wave's 64 lanes
 };
 extern thread_local EmuBlock* emu_block;                       // null in sequential mode
 extern thread_local unsigned emu_tid;                          // linear thread id inside the block
@@ -73,6 +74,61 @@ inline int __any(int p) {                                      // wave-wide OR (
 template <typename T> inline T __shfl_xor(T v, int m) { return emu_exchange(v, (emu_tid & 63) ^ (unsigned)m); }
 template <typename T> inline T __shfl_down(T v, int d) { return emu_exchange(v, ((emu_tid & 63) + (unsigned)d) > 63 ? (emu_tid & 63) : (emu_tid & 63) + (unsigned)d); }
 template <typename T> inline T __shfl(T v, int l) { return emu_exchange(v, (unsigned)l); }
+// ---- gfx950 builtins of the MFMA kernels (threaded mode only) -----------------------------------------------------------------------
+struct uint4 { unsigned x, y, z, w; };
+typedef _Float16 emu_h8 __attribute__((ext_vector_type(8)));
+typedef float emu_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned emu_u2 __attribute__((ext_vector_type(2)));
+// v_mfma_f32_16x16x32_f16: D (16 x 16) = A (16 x 32) B (32 x 16) + C.  Lane l supplies A[l % 16][8 (l / 16) .. + 7] and
+// B[8 (l / 16) .. + 7][l % 16] and owns D[4 (l / 16) + r][l % 16], r = 0 .. 3.  fp32 accumulation in k order.
+inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu_h8 a, emu_h8 b, emu_f4 c, int, int, int) {
+    EmuBlock* blk = emu_block;
+    if (!blk) std::abort();                                   // a wave-wide operation: threaded mode only
+    const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
+    std::memcpy(blk->ma[w][lane], &a, 16);
+    std::memcpy(blk->mb[w][lane], &b, 16);
+    pthread_barrier_wait(&blk->wave[w]);
+    const unsigned col = lane & 15;
+    emu_f4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const unsigned row = 4 * (lane >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            _Float16 av, bv;
+            std::memcpy(&av, blk->ma[w][(k >> 3) * 16 + row] + 2 * (k & 7), 2);
+            std::memcpy(&bv, blk->mb[w][(k >> 3) * 16 + col] + 2 * (k & 7), 2);
+            acc += (float)av * (float)bv;
+        }
+        d[r] = acc;
+    }
+    pthread_barrier_wait(&blk->wave[w]);
+    return d;
+}
+// global_load_lds (LDS-DMA): lane l copies `size` bytes from ITS global pointer to (wave-uniform LDS base) + offset + l * size; here the
+// copy completes at issue (the kernels wait with s_waitcnt before they read, and never issue into a buffer that is still being read)
+inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds, unsigned size, unsigned offset, unsigned) {
+    std::memcpy((char*)lds + offset + (emu_tid & 63) * size, g, size);
+}
+inline void __builtin_amdgcn_s_barrier() { if (emu_block) pthread_barrier_wait(&emu_block->all); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // (the kernels pass wave-uniform values)
+inline long long __builtin_amdgcn_s_memtime() { return 0; }
+inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
+// v_permlane16_swap: with the wave as four rows of 16 lanes, the odd rows of the first operand swap with the even rows of the second:
+// x' = [x.row0, y.row0, x.row2, y.row2], y' = [x.row1, y.row1, x.row3, y.row3]; returns (x', y')
+inline emu_u2 __builtin_amdgcn_permlane16_swap(unsigned x, unsigned y, bool, bool) {
+    EmuBlock* blk = emu_block;
+    if (!blk) std::abort();
+    const unsigned w = emu_tid >> 6, lane = emu_tid & 63, row = lane >> 4;
+    blk->slot[w][lane] = ((uint64_t)y << 32) | x;
+    pthread_barrier_wait(&blk->wave[w]);
+    const uint64_t below = blk->slot[w][(lane + 48) & 63], above = blk->slot[w][(lane + 16) & 63];      // lanes one row down / up
+    const unsigned xn = (row & 1) ? (unsigned)(below >> 32) : x;             // odd row of x' = the y of the row below
+    const unsigned yn = (row & 1) ? y : (unsigned)above;                     // even row of y' = the x of the row above
+    pthread_barrier_wait(&blk->wave[w]);
+    return emu_u2{xn, yn};
+}
 inline float __expf(float x) { return std::exp(x); }
 inline float __logf(float x) { return std::log(x); }
 inline float __fdividef(float a, float b) { return a / b; }
