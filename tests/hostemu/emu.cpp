@@ -25,6 +25,7 @@ void prof_mark_start(const char* name, double, double, hipStream_t) { g_emu_last
 void prof_mark_stop(hipStream_t) {}
 alignas(16) float sa[96 * 1024 / 4];                   // what `extern __shared__ float sa[]` (small_linear_lds: up to 96 KB of activations) resolves to
 alignas(16) char smem[160 * 1024 + 16384];            // what `extern __shared__ char smem[]` of the GEMM kernels resolves to (one workgroup at a time)
+alignas(16) float sc[16384];                            // `extern __shared__ float sc[]` of the generic attention kernel (M scores)
 const half_t* zero_page() {
     static half_t zeros[kZeroPageHalfs] = {};
     return zeros;
@@ -71,6 +72,20 @@ int emu_conv_gemm(const sdmi_conv_desc* d, int cfg, int split, int korder, emu_g
     const int rc = launch_gemm(p, d->batch > 0 ? d->batch : 1, d->force_generic == 1, d->force_generic != 2, nullptr, &nchunk, &np);
     if (x) { x->stats_nchunk = nchunk; x->lnp_np = np; }
     return rc;
+}
+// flash attention over Q [B, N, ldq], K [B, M, ldk], V^T [B, H*D, vt_ld] (include/sdmi.h sdmi_attention_vt); occ / kvt: the kernel-form knobs
+int emu_attention(const uint16_t* q, const uint16_t* k, const uint16_t* vt, uint16_t* out, int B, int H, int N, int M, int D, int ldq, int ldk,
+                  int vt_ld, int ldo, float scale, int causal, int generic, int occ, int kvt) {
+    AttnP p{};
+    p.q = (const half_t*)q; p.k = (const half_t*)k; p.vt = (const half_t*)vt; p.out = (half_t*)out;
+    p.B = B; p.H = H; p.N = N; p.M = M; p.D = D; p.ldq = ldq; p.ldk = ldk; p.vt_ld = vt_ld; p.ldo = ldo;
+    p.scale_log2 = scale * 1.44269504088896340736f;
+    p.causal = causal;
+    g_attn_occ = occ; g_attn_kvt = kvt;
+    return launch_attention(p, generic != 0, nullptr);
+}
+int emu_transpose_v(const uint16_t* v, uint16_t* vt, int B, int H, int M, int D, int ldv, int Mpad) {
+    return launch_transpose_v((const half_t*)v, (half_t*)vt, B, H, M, D, ldv, Mpad, nullptr);
 }
 int64_t emu_splitk_ws_bytes(int M, int N, int K) { return (int64_t)gemm_splitk_ws_bytes(M, N, K, 1); }
 const char* emu_last_error() { return get_error(); }

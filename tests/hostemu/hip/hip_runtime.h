@@ -6,7 +6,8 @@
 //                              __shfl_xor / __shfl_down / __shfl exchange through a per-wavefront (64 lanes) slot array between two
 //                              barriers over the wave — every lane of a wave must reach the shuffle, as on the hardware when EXEC is full.
 // `__shared__` is function-static storage: blocks run one after the other, so a block's threads share it and the next block reuses it.
-// MFMA / LDS-DMA kernels (gemm.hip, attention.hip) are not emulated.
+// The gfx950 builtins of the MFMA kernels (gemm.hip, attention.hip: the two MFMA shapes, LDS-DMA, the permlane swaps, ballot) are
+// emulated per wave in threaded mode; LDS-DMA completes at issue, so nothing here models the hardware's asynchrony.
 #pragma once
 #include <pthread.h>
 #include <cmath>
@@ -76,6 +77,7 @@ template <typename T> inline T __shfl_down(T v, int d) { return emu_exchange(v, 
 template <typename T> inline T __shfl(T v, int l) { return emu_exchange(v, (unsigned)l); }
 // ---- gfx950 builtins of the MFMA kernels (threaded mode only) -----------------------------------------------------------------------
 struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 typedef _Float16 emu_h8 __attribute__((ext_vector_type(8)));
 typedef float emu_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned emu_u2 __attribute__((ext_vector_type(2)));
@@ -103,6 +105,59 @@ inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu_h8 a, emu_h8 b, emu_f4 
     }
     pthread_barrier_wait(&blk->wave[w]);
     return d;
+}
+// v_mfma_f32_32x32x16_f16: D (32 x 32) = A (32 x 16) B (16 x 32) + C.  Lane l supplies A[l % 32][8 (l / 32) .. + 7] and
+// B[8 (l / 32) .. + 7][l % 32] and owns D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32], r = 0 .. 15.
+typedef float emu_f16v __attribute__((ext_vector_type(16)));
+inline emu_f16v __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_h8 a, emu_h8 b, emu_f16v c, int, int, int) {
+    EmuBlock* blk = emu_block;
+    if (!blk) std::abort();
+    const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
+    std::memcpy(blk->ma[w][lane], &a, 16);
+    std::memcpy(blk->mb[w][lane], &b, 16);
+    pthread_barrier_wait(&blk->wave[w]);
+    const unsigned col = lane & 31;
+    emu_f16v d = c;
+    for (int r = 0; r < 16; ++r) {
+        const unsigned row = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            _Float16 av, bv;
+            std::memcpy(&av, blk->ma[w][(k >> 3) * 32 + row] + 2 * (k & 7), 2);
+            std::memcpy(&bv, blk->mb[w][(k >> 3) * 32 + col] + 2 * (k & 7), 2);
+            acc += (float)av * (float)bv;
+        }
+        d[r] = acc;
+    }
+    pthread_barrier_wait(&blk->wave[w]);
+    return d;
+}
+// v_permlane32_swap_b32 x, y (inline assembly in attention.hip, replaced textually by this call): the upper 32 lanes of x swap with the
+// lower 32 lanes of y
+inline void emu_permlane32_swap(float& x, float& y) {
+    EmuBlock* blk = emu_block;
+    if (!blk) std::abort();
+    const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
+    uint32_t xb, yb;
+    std::memcpy(&xb, &x, 4); std::memcpy(&yb, &y, 4);
+    blk->slot[w][lane] = ((uint64_t)yb << 32) | xb;
+    pthread_barrier_wait(&blk->wave[w]);
+    const uint64_t other = blk->slot[w][lane ^ 32];
+    pthread_barrier_wait(&blk->wave[w]);
+    if (lane >= 32) xb = (uint32_t)(other >> 32);              // upper half of x := lower half of y
+    else yb = (uint32_t)other;                                 // lower half of y := upper half of x
+    std::memcpy(&x, &xb, 4); std::memcpy(&y, &yb, 4);
+}
+inline uint64_t __builtin_amdgcn_ballot_w64(bool p) {
+    EmuBlock* blk = emu_block;
+    if (!blk) return p ? 1 : 0;
+    const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
+    blk->slot[w][lane] = p ? 1u : 0u;
+    pthread_barrier_wait(&blk->wave[w]);
+    uint64_t m = 0;
+    for (unsigned l = 0; l < blk->wave_lanes[w]; ++l) m |= blk->slot[w][l] << l;
+    pthread_barrier_wait(&blk->wave[w]);
+    return m;
 }
 // global_load_lds (LDS-DMA): lane l copies `size` bytes from ITS global pointer to (wave-uniform LDS base) + offset + l * size; here the
 // copy completes at issue (the kernels wait with s_waitcnt before they read, and never issue into a buffer that is still being read)
