@@ -9,6 +9,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+if os.environ.get("SDMI_HOSTEMU") == "1":                      # the `-m gpu` tests against the host-emulated library (tests/hostemu/shim.py)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hostemu import shim as _hostemu_shim
+    _hostemu_shim.install()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -22,3 +28,14 @@ def pkg():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def hostemu_lib():
+    """Path of the host-emulated libsdmi (tests/hostemu/build.py); built once per source state, ~40 s."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hostemu import build as hostemu_build
+    path = os.environ.get("SDMI_LIB") if os.environ.get("SDMI_HOSTEMU") == "1" else hostemu_build.build()
+    if not path:
+        pytest.skip("host emulation needs clang++ on x86-64")
+    return path

@@ -7,29 +7,130 @@
 // running block, real barriers, shuffles through per-wave slots).  Nothing here is linked into the product.
 #include "common.h"
 #include "prof.h"
+#include <sys/mman.h>
+#include <cstdio>
+#include <map>
+#include <vector>
 
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local EmuBlock* emu_block = nullptr;
 thread_local unsigned emu_tid = 0;
 int emu_threaded = 0;
 
+// ---- the block runner: one fiber per GPU thread of the running block, switched in user space ------------------------------------------
+// emu_switch(&save_sp, to_sp): push the callee-saved registers, store the stack pointer, load the other one, pop, return
+#if defined(__x86_64__)
+extern "C" void emu_switch(void** save_sp, void* to_sp);
+asm(".text\n.globl emu_switch\n.type emu_switch,@function\nemu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size emu_switch, .-emu_switch\n");
+#else
+#error "tests/hostemu: the fiber switch is written for x86-64"
+#endif
+namespace {
+constexpr size_t kFiberStack = 512 << 10;
+struct EmuRunner {
+    EmuBlock blk;
+    char* stacks = nullptr;                                    // 1024 fiber stacks, mapped once (pages are touched on use)
+    void* sp[1024];
+    bool done[1024];
+    void* sched_sp = nullptr;
+    unsigned cur = 0, live = 0;
+    unsigned long progress = 0;
+    dim3 b;
+    const std::function<void()>* body = nullptr;
+};
+EmuRunner g_run;
+void emu_thread_exit(EmuRunner& r, unsigned t) {               // a returned thread leaves its wave's and the block's barriers
+    r.done[t] = true;
+    --r.live;
+    ++r.progress;
+    for (unsigned id : {t >> 6, 16u}) {
+        EmuBlock& k = r.blk;
+        if (--k.need[id] > 0 && k.arrived[id] >= k.need[id]) { k.arrived[id] = 0; ++k.gen[id]; }
+    }
+}
+void emu_fiber_main() {
+    EmuRunner& r = g_run;
+    (*r.body)();
+    emu_thread_exit(r, r.cur);
+    emu_switch(&r.sp[r.cur], r.sched_sp);
+    std::abort();                                              // a finished fiber is never resumed
+}
+}  // namespace
+void emu_yield() { emu_switch(&g_run.sp[g_run.cur], g_run.sched_sp); }
+void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>& body) {
+    EmuRunner& r = g_run;
+    const unsigned nt = b.x * b.y * b.z;
+    if (nt > 1024 || emu_block) std::abort();                  // (no nested launches)
+    if (!r.stacks) {
+        r.stacks = (char*)mmap(nullptr, 1024 * kFiberStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (r.stacks == (char*)MAP_FAILED) std::abort();
+    }
+    EmuBlock& k = r.blk;
+    const unsigned nw = (nt + 63) / 64;
+    for (unsigned w = 0; w < 17; ++w) { k.arrived[w] = 0; k.gen[w] = 0; k.need[w] = 0; }
+    for (unsigned w = 0; w < nw; ++w) k.need[w] = k.wave_lanes[w] = std::min(64u, nt - w * 64);
+    k.need[16] = nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        void** top = (void**)(r.stacks + (size_t)(t + 1) * kFiberStack);     // 16-byte aligned
+        top[-1] = nullptr;                                     // the fiber entry's (never used) return address
+        top[-2] = (void*)&emu_fiber_main;                      // popped by emu_switch's ret; rsp is then 8 mod 16, as after a call
+        for (int i = 3; i <= 8; ++i) top[-i] = nullptr;        // rbp rbx r12 .. r15
+        r.sp[t] = (void*)(top - 8);
+        r.done[t] = false;
+        k.wait_id[t] = 16; k.wait_gen[t] = ~0u;                // runnable
+    }
+    r.b = b; r.body = &body; r.live = nt;
+    gridDim = g; blockDim = b; blockIdx = bi;
+    emu_block = &k;
+    while (r.live) {
+        const unsigned long before = r.progress;
+        for (unsigned t = 0; t < nt; ++t) {
+            if (r.done[t] || k.gen[k.wait_id[t]] == k.wait_gen[t]) continue;
+            r.cur = t; emu_tid = t;
+            threadIdx = dim3(t % b.x, (t / b.x) % b.y, t / (b.x * b.y));
+            k.wait_gen[t] = ~0u;
+            const unsigned gsum_before = k.gen[16];
+            (void)gsum_before;
+            emu_switch(&r.sched_sp, r.sp[t]);
+            ++r.progress;
+        }
+        if (r.progress == before) {                            // every live thread is parked on a barrier that cannot complete
+            std::fprintf(stderr, "hostemu: deadlock in block (%u,%u,%u): %u threads parked\n", bi.x, bi.y, bi.z, r.live);
+            std::abort();
+        }
+    }
+    emu_block = nullptr;
+}
+
 namespace sdmi {
-static thread_local std::string g_emu_err;
-void set_error(const std::string& m) { g_emu_err = m; }
-const char* get_error() { return g_emu_err.c_str(); }
-static std::string g_emu_last_launch;                  // the profiler's launch name: which tile / kernel family a launch really took
+// the per-launch profiler is replaced (prof.cpp is not linked): the launch name tells which tile / kernel family a launch really took
+static std::string g_emu_last_launch;
+static std::vector<std::string> g_emu_launch_log;
+static bool g_emu_log_on = false;
 bool prof_enabled() { return true; }
-void prof_begin() {}
-std::string prof_end() { return "{}"; }
-void prof_mark_start(const char* name, double, double, hipStream_t) { g_emu_last_launch = name ? name : ""; }
+void prof_begin() { g_emu_launch_log.clear(); g_emu_log_on = true; }
+std::string prof_end() {                                       // {"kernels": [{"name": ..., "launches": n, "ms": 0, ...}]} like prof.cpp, in first-launch order
+    g_emu_log_on = false;
+    std::vector<std::string> order;
+    std::map<std::string, int> count;
+    for (const auto& n : g_emu_launch_log) if (count[n]++ == 0) order.push_back(n);
+    std::string out = "{\"kernels\": [";
+    for (size_t i = 0; i < order.size(); ++i)
+        out += std::string(i ? ", " : "") + "{\"name\": \"" + order[i] + "\", \"launches\": " + std::to_string(count[order[i]]) + ", \"ms\": 0, \"flops\": 0, \"bytes\": 0}";
+    return out + "]}";
+}
+void prof_mark_start(const char* name, double, double, hipStream_t) {
+    g_emu_last_launch = name ? name : "";
+    if (g_emu_log_on) g_emu_launch_log.push_back(g_emu_last_launch);
+}
 void prof_mark_stop(hipStream_t) {}
 alignas(16) float sa[96 * 1024 / 4];                   // what `extern __shared__ float sa[]` (small_linear_lds: up to 96 KB of activations) resolves to
-alignas(16) char smem[160 * 1024 + 16384];            // what `extern __shared__ char smem[]` of the GEMM kernels resolves to (one workgroup at a time)
+alignas(16) char smem[160 * 1024 + 16384];            // what `extern __shared__ char smem[]` of the GEMM / attention kernels resolves to (one workgroup at a time)
 alignas(16) float sc[16384];                            // `extern __shared__ float sc[]` of the generic attention kernel (M scores)
-const half_t* zero_page() {
-    static half_t zeros[kZeroPageHalfs] = {};
-    return zeros;
-}
 }  // namespace sdmi
 
 using namespace sdmi;
