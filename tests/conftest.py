@@ -15,6 +15,19 @@ if os.environ.get("SDMI_HOSTEMU") == "1":                      # the `-m gpu` te
     _hostemu_shim.install()
 
 
+def pytest_collection_modifyitems(config, items):
+    """SDMI_HOSTEMU_SELECT=<file of node ids>: keep only those (the CPU tier's selection of GPU tests for the emulated library)."""
+    path = os.environ.get("SDMI_HOSTEMU_SELECT")
+    if os.environ.get("SDMI_HOSTEMU") != "1" or not path:
+        return
+    keep = {ln.strip() for ln in open(path) if ln.strip() and not ln.startswith("#")}
+    chosen = [it for it in items if it.nodeid in keep]
+    dropped = [it for it in items if it.nodeid not in keep]
+    if dropped:
+        config.hook.pytest_deselected(items=dropped)
+        items[:] = chosen
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

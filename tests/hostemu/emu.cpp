@@ -8,6 +8,7 @@
 #include "common.h"
 #include "prof.h"
 #include <sys/mman.h>
+#include <chrono>
 #include <cstdio>
 #include <map>
 #include <vector>
@@ -35,6 +36,7 @@ struct EmuRunner {
     EmuBlock blk;
     char* stacks = nullptr;                                    // 1024 fiber stacks, mapped once (pages are touched on use)
     void* sp[1024];
+    dim3 tidx[1024];
     bool done[1024];
     void* sched_sp = nullptr;
     unsigned cur = 0, live = 0;
@@ -82,6 +84,8 @@ void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>
         r.sp[t] = (void*)(top - 8);
         r.done[t] = false;
         k.wait_id[t] = 16; k.wait_gen[t] = ~0u;                // runnable
+        k.mfma_parity[t] = 0;
+        r.tidx[t] = dim3(t % b.x, (t / b.x) % b.y, t / (b.x * b.y));
     }
     r.b = b; r.body = &body; r.live = nt;
     gridDim = g; blockDim = b; blockIdx = bi;
@@ -91,10 +95,8 @@ void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>
         for (unsigned t = 0; t < nt; ++t) {
             if (r.done[t] || k.gen[k.wait_id[t]] == k.wait_gen[t]) continue;
             r.cur = t; emu_tid = t;
-            threadIdx = dim3(t % b.x, (t / b.x) % b.y, t / (b.x * b.y));
+            threadIdx = r.tidx[t];
             k.wait_gen[t] = ~0u;
-            const unsigned gsum_before = k.gen[16];
-            (void)gsum_before;
             emu_switch(&r.sched_sp, r.sp[t]);
             ++r.progress;
         }
@@ -109,25 +111,34 @@ void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>
 namespace sdmi {
 // the per-launch profiler is replaced (prof.cpp is not linked): the launch name tells which tile / kernel family a launch really took
 static std::string g_emu_last_launch;
-static std::vector<std::string> g_emu_launch_log;
+static std::vector<std::pair<std::string, double>> g_emu_launch_log;      // (name, host milliseconds)
 static bool g_emu_log_on = false;
+static double g_emu_t0 = 0.0;
+static double emu_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 bool prof_enabled() { return true; }
 void prof_begin() { g_emu_launch_log.clear(); g_emu_log_on = true; }
-std::string prof_end() {                                       // {"kernels": [{"name": ..., "launches": n, "ms": 0, ...}]} like prof.cpp, in first-launch order
+std::string prof_end() {                                       // {"kernels": [{"name", "launches", "ms" (HOST time of the emulation), ...}]} like prof.cpp, in first-launch order
     g_emu_log_on = false;
     std::vector<std::string> order;
-    std::map<std::string, int> count;
-    for (const auto& n : g_emu_launch_log) if (count[n]++ == 0) order.push_back(n);
+    std::map<std::string, std::pair<int, double>> acc;
+    for (const auto& e : g_emu_launch_log) {
+        auto& a = acc[e.first];
+        if (a.first++ == 0) order.push_back(e.first);
+        a.second += e.second;
+    }
     std::string out = "{\"kernels\": [";
     for (size_t i = 0; i < order.size(); ++i)
-        out += std::string(i ? ", " : "") + "{\"name\": \"" + order[i] + "\", \"launches\": " + std::to_string(count[order[i]]) + ", \"ms\": 0, \"flops\": 0, \"bytes\": 0}";
+        out += std::string(i ? ", " : "") + "{\"name\": \"" + order[i] + "\", \"launches\": " + std::to_string(acc[order[i]].first) + ", \"ms\": " +
+               std::to_string(acc[order[i]].second) + ", \"flops\": 0, \"bytes\": 0}";
     return out + "]}";
 }
 void prof_mark_start(const char* name, double, double, hipStream_t) {
     g_emu_last_launch = name ? name : "";
-    if (g_emu_log_on) g_emu_launch_log.push_back(g_emu_last_launch);
+    g_emu_t0 = emu_now_ms();
 }
-void prof_mark_stop(hipStream_t) {}
+void prof_mark_stop(hipStream_t) {
+    if (g_emu_log_on) g_emu_launch_log.emplace_back(g_emu_last_launch, emu_now_ms() - g_emu_t0);
+}
 alignas(16) float sa[96 * 1024 / 4];                   // what `extern __shared__ float sa[]` (small_linear_lds: up to 96 KB of activations) resolves to
 alignas(16) char smem[160 * 1024 + 16384];            // what `extern __shared__ char smem[]` of the GEMM / attention kernels resolves to (one workgroup at a time)
 alignas(16) float sc[16384];                            // `extern __shared__ float sc[]` of the generic attention kernel (M scores)

@@ -74,7 +74,10 @@ struct EmuBlock {                                              // the running bl
     unsigned short wait_id[1024];                              // what a parked thread waits for: the scheduler resumes it when gen[wait_id] has moved on
     unsigned wait_gen[1024];
     uint64_t slot[16][64];
-    alignas(16) unsigned char ma[16][64][16], mb[16][64][16];   // MFMA operand fragments of a wave's 64 lanes
+    // MFMA operand fragments of a wave's 64 lanes, double-buffered by the parity of the lane's MFMA count: ONE barrier per MFMA (a lane
+    // can only write buffer p again after the barrier of its next MFMA, which every lane reaches after it has read buffer p)
+    alignas(16) unsigned char ma[2][16][64][16], mb[2][16][64][16];
+    unsigned char mfma_parity[1024];
 };
 extern thread_local EmuBlock* emu_block;                       // null in sequential mode
 extern thread_local unsigned emu_tid;                          // linear thread id inside the block
@@ -131,8 +134,9 @@ inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu_h8 a, emu_h8 b, emu_f4 
     if (emu_lone()) std::abort();                             // a wave-wide operation: threaded (or auto) mode only
     EmuBlock* blk = emu_block;
     const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
-    std::memcpy(blk->ma[w][lane], &a, 16);
-    std::memcpy(blk->mb[w][lane], &b, 16);
+    const unsigned par = blk->mfma_parity[emu_tid] ^= 1;
+    std::memcpy(blk->ma[par][w][lane], &a, 16);
+    std::memcpy(blk->mb[par][w][lane], &b, 16);
     emu_barrier(w);
     const unsigned col = lane & 15;
     emu_f4 d = c;
@@ -141,13 +145,12 @@ inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x32_f16(emu_h8 a, emu_h8 b, emu_f4 
         float acc = c[r];
         for (int k = 0; k < 32; ++k) {
             _Float16 av, bv;
-            std::memcpy(&av, blk->ma[w][(k >> 3) * 16 + row] + 2 * (k & 7), 2);
-            std::memcpy(&bv, blk->mb[w][(k >> 3) * 16 + col] + 2 * (k & 7), 2);
+            std::memcpy(&av, blk->ma[par][w][(k >> 3) * 16 + row] + 2 * (k & 7), 2);
+            std::memcpy(&bv, blk->mb[par][w][(k >> 3) * 16 + col] + 2 * (k & 7), 2);
             acc += (float)av * (float)bv;
         }
         d[r] = acc;
     }
-    emu_barrier(w);
     return d;
 }
 // v_mfma_f32_32x32x16_f16: D (32 x 32) = A (32 x 16) B (16 x 32) + C.  Lane l supplies A[l % 32][8 (l / 32) .. + 7] and
@@ -157,8 +160,9 @@ inline emu_f16v __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_h8 a, emu_h8 b, emu_f
     if (emu_lone()) std::abort();
     EmuBlock* blk = emu_block;
     const unsigned w = emu_tid >> 6, lane = emu_tid & 63;
-    std::memcpy(blk->ma[w][lane], &a, 16);
-    std::memcpy(blk->mb[w][lane], &b, 16);
+    const unsigned par = blk->mfma_parity[emu_tid] ^= 1;
+    std::memcpy(blk->ma[par][w][lane], &a, 16);
+    std::memcpy(blk->mb[par][w][lane], &b, 16);
     emu_barrier(w);
     const unsigned col = lane & 31;
     emu_f16v d = c;
@@ -167,13 +171,12 @@ inline emu_f16v __builtin_amdgcn_mfma_f32_32x32x16_f16(emu_h8 a, emu_h8 b, emu_f
         float acc = c[r];
         for (int k = 0; k < 16; ++k) {
             _Float16 av, bv;
-            std::memcpy(&av, blk->ma[w][(k >> 3) * 32 + row] + 2 * (k & 7), 2);
-            std::memcpy(&bv, blk->mb[w][(k >> 3) * 32 + col] + 2 * (k & 7), 2);
+            std::memcpy(&av, blk->ma[par][w][(k >> 3) * 32 + row] + 2 * (k & 7), 2);
+            std::memcpy(&bv, blk->mb[par][w][(k >> 3) * 32 + col] + 2 * (k & 7), 2);
             acc += (float)av * (float)bv;
         }
         d[r] = acc;
     }
-    emu_barrier(w);
     return d;
 }
 // v_permlane32_swap_b32 x, y (inline assembly in attention.hip, replaced textually by this call): the upper 32 lanes of x swap with the

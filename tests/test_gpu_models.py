@@ -197,6 +197,22 @@ def test_txt2img_tiny_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
     assert diff.mean() < 2.0          # uint8 images agree to rounding of a few levels
 
 
+@pytest.mark.parametrize("sampler,name,steps", [("euler_a", "Euler a", 3), ("dpmpp_2m", "DPM++ 2M", 3), ("ddim", "DDIM", 3), ("heun", "Heun", 2)])
+def test_txt2img_smallest_job_end_to_end_vs_oracle(dev, tiny, sampler, name, steps):
+    """One image, 8 x 8 latent, a few steps: the whole job (noise, CFG batch, UNet, sampler steps, VAE decode, uint8) at the smallest shape the
+    kernels take — the end-to-end case that is also cheap on the host-emulated library (tests/test_cpu_emulated_library.py)."""
+    from oracle import pipeline as opipe
+    processing = sub("processing")
+    cond, uncond = tiny["cond"][:1], tiny["uncond"][:1]
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=tiny["model"], c=cond, uc=uncond, seed=77, batch_size=1, steps=steps, cfg_scale=6.0,
+                                                    width=64, height=64, sampler_name=name)
+    res = processing.process_images(p)
+    lat, img, u8 = opipe.txt2img(tiny["oracle"], cond, uncond, [77], steps, sampler, 6.0, (8, 8))
+    assert rel_l2(res.latents.cpu(), lat) < 1e-2, sampler
+    assert len(res.images) == 1 and res.images[0].shape == (16, 16, 3) and res.images[0].dtype == np.uint8
+    assert np.abs(res.images[0].astype(np.int32) - u8[0].astype(np.int32)).mean() < 2.0
+
+
 @pytest.mark.parametrize("sampler,name", [("euler", "Euler"), ("heun", "Heun"), ("dpm_2", "DPM2")])
 def test_txt2img_stochastic_churn_vs_oracle(dev, tiny, sampler, name):
     """opts.s_churn / s_tmin / s_tmax / s_noise (modules/sd_samplers_kdiffusion.py:36-39, 164-183; Karras et al. Algorithm 2): the
