@@ -1,10 +1,11 @@
-// emu.cpp — the elementwise kernels of libsdmi (stable-diffusion-webui_amd/csrc/elementwise.hip, the file itself, unmodified) compiled as
-// plain C++ against tests/hostemu/hip/hip_runtime.h and run thread by thread on the CPU.  TEST INFRASTRUCTURE: it lets the CPU tier check
-// the ARITHMETIC of the shipped kernel source — Philox bit patterns, the uint8 conversion's truncation, the weight packing's index map,
-// the sampler-step contracts of include/sdmi.h — without a GPU.  Kernels that need workgroup barriers or cross-lane traffic
-// (dpm_error, small_linear_lds, softmax_rows, slerp's norm) compile but are not exported: one-thread-at-a-time execution is not their
-// semantics; they, and the GroupNorm / LayerNorm kernels of norm.hip, run in the header's THREADED mode (one OS thread per thread of the
-// running block, real barriers, shuffles through per-wave slots).  Nothing here is linked into the product.
+// emu.cpp — the runtime of the HOST-EMULATED libsdmi (TEST INFRASTRUCTURE; tests/hostemu/build.py links it with the library's own
+// capi.cpp, engine.cpp and the four kernel files compiled as plain C++ against tests/hostemu/hip/hip_runtime.h):
+//   * the block runner: every GPU thread of the running block is a fiber, switched in user space, round-robin (deterministic); a fiber
+//     parked on a barrier is skipped until the barrier's generation moves; a returned thread leaves its barriers; all-parked = deadlock;
+//   * what `extern __shared__` arrays resolve to, and a stand-in for prof.cpp that records launch names and host time;
+//   * thin emu_* entry points for the kernels that have no C-ABI entry of their own (launch functions called on host buffers by
+//     tests/test_cpu_kernel_emulation.py).
+// Nothing here is linked into, or imported by, the product.
 #include "common.h"
 #include "prof.h"
 #include <sys/mman.h>
