@@ -31,6 +31,19 @@ asm(".text\n.globl emu_switch\n.type emu_switch,@function\nemu_switch:\n"
 #else
 #error "tests/hostemu: the fiber switch is written for x86-64"
 #endif
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+#ifdef EMU_ASAN                                                // SDMI_HOSTEMU_ASAN=1 builds: tell the sanitizer about every stack switch
+#define EMU_ASAN_START(save, bottom, size) __sanitizer_start_switch_fiber((save), (bottom), (size))
+#define EMU_ASAN_FINISH(save, bottom, size) __sanitizer_finish_switch_fiber((save), (bottom), (size))
+#else
+#define EMU_ASAN_START(save, bottom, size) ((void)0)
+#define EMU_ASAN_FINISH(save, bottom, size) ((void)0)
+#endif
 namespace {
 constexpr size_t kFiberStack = 512 << 10;
 struct EmuRunner {
@@ -40,6 +53,10 @@ struct EmuRunner {
     dim3 tidx[1024];
     bool done[1024];
     void* sched_sp = nullptr;
+    void* sched_fake = nullptr;                                // sanitizer bookkeeping (unused otherwise)
+    void* fiber_fake[1024];
+    const void* sched_bottom = nullptr;
+    size_t sched_size = 0;
     unsigned cur = 0, live = 0;
     unsigned long progress = 0;
     dim3 b;
@@ -57,13 +74,21 @@ void emu_thread_exit(EmuRunner& r, unsigned t) {               // a returned thr
 }
 void emu_fiber_main() {
     EmuRunner& r = g_run;
+    EMU_ASAN_FINISH(nullptr, &r.sched_bottom, &r.sched_size);
     (*r.body)();
     emu_thread_exit(r, r.cur);
+    EMU_ASAN_START(nullptr, r.sched_bottom, r.sched_size);     // (null: this fiber's stack is not returned to)
     emu_switch(&r.sp[r.cur], r.sched_sp);
     std::abort();                                              // a finished fiber is never resumed
 }
 }  // namespace
-void emu_yield() { emu_switch(&g_run.sp[g_run.cur], g_run.sched_sp); }
+void emu_yield() {
+    EmuRunner& r = g_run;
+    const unsigned me = r.cur;
+    EMU_ASAN_START(&r.fiber_fake[me], r.sched_bottom, r.sched_size);
+    emu_switch(&r.sp[me], r.sched_sp);
+    EMU_ASAN_FINISH(r.fiber_fake[me], &r.sched_bottom, &r.sched_size);
+}
 void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>& body) {
     EmuRunner& r = g_run;
     const unsigned nt = b.x * b.y * b.z;
@@ -98,7 +123,9 @@ void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>
             r.cur = t; emu_tid = t;
             threadIdx = r.tidx[t];
             k.wait_gen[t] = ~0u;
+            EMU_ASAN_START(&r.sched_fake, r.stacks + (size_t)t * kFiberStack, kFiberStack);
             emu_switch(&r.sched_sp, r.sp[t]);
+            EMU_ASAN_FINISH(r.sched_fake, nullptr, nullptr);
             ++r.progress;
         }
         if (r.progress == before) {                            // every live thread is parked on a barrier that cannot complete
