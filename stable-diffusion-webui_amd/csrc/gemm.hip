@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
 #pragma unroll
             for (int q = q0; q < q0 + nq; ++q) {
                 const int ri = rinfo[q * 512];
-                const int yb = (ri << 8) >> 20, xb = (ri << 20) >> 20;
+                const int yb = (int)((unsigned)ri << 8) >> 20, xb = (int)((unsigned)ri << 20) >> 20;
                 unsigned colm = 0, mask = 0;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) colm |= ((unsigned)(xb + d) < (unsigned)xlim ? 1u : 0u) << d;
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_kernel(GemmP p) {
                     ok = pix < p.M;
                 } else {
                     const int ri = rinfo[q * 512];
-                    int yr = ((ri << 8) >> 20) + dy, xr = ((ri << 20) >> 20) + dx;     // sign-extended 12-bit fields
+                    int yr = ((int)((unsigned)ri << 8) >> 20) + dy, xr = ((int)((unsigned)ri << 20) >> 20) + dx;     // sign-extended 12-bit fields
                     if ((p.flags & EP_WRAP) && yr > -1024) {   // circular padding (rows past M keep yb = -2048 and stay invalid)
                         yr = yr < 0 ? yr + ylim : (yr >= ylim ? yr - ylim : yr);
                         xr = xr < 0 ? xr + xlim : (xr >= xlim ? xr - xlim : xr);
@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_pingpong_dx_kernel(GemmP p) {
 #pragma unroll
             for (int q = q0; q < q0 + nq; ++q) {
                 const int ri = rinfo[q * 512];
-                const int yr = ((ri << 8) >> 20) + dy, xr = ri & 0xfff;
+                const int yr = ((int)((unsigned)ri << 8) >> 20) + dy, xr = ri & 0xfff;
                 const bool ok = (unsigned)yr < (unsigned)p.Hi;            // rows past M carry yb = -2048
                 const int pix = (ri >> 24) * img_pix + yr * p.Wi + xr;
                 rptr[q] = (ok ? src + (long)pix * lda : p.zero) + chunk8;
