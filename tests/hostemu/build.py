@@ -55,7 +55,7 @@ def source_digest():
     h = hashlib.sha256()
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp", ".h", ".inc"))]
     files += [os.path.join(EMU, "emu.cpp"), os.path.join(EMU, "hip", "hip_runtime.h"), os.path.abspath(__file__), os.path.join(ROOT, "include", "sdmi.h")]
-    h.update((os.environ.get("SDMI_HOSTEMU_ASAN", "0") + os.environ.get("SDMI_HOSTEMU_UBSAN", "0")).encode())
+    h.update((os.environ.get("SDMI_HOSTEMU_ASAN", "0") + os.environ.get("SDMI_HOSTEMU_UBSAN", "0") + os.environ.get("SDMI_HOSTEMU_TSAN", "0")).encode())
     for f in files:
         h.update(f.encode())
         h.update(open(f, "rb").read())
@@ -86,6 +86,9 @@ def build():
     ubsan = os.environ.get("SDMI_HOSTEMU_UBSAN") == "1"     # misaligned vector accesses, signed index overflow, bad shifts, array bounds
     if ubsan:                                                  #   (run with LD_PRELOAD=<clang's libclang_rt.ubsan_standalone-x86_64.so>; reports go to stderr / UBSAN_OPTIONS=log_path)
         flags += ["-fsanitize=alignment,signed-integer-overflow,shift,bounds,integer-divide-by-zero", "-fno-sanitize-recover=all" if False else "-g1", "-shared-libsan"]
+    tsan = os.environ.get("SDMI_HOSTEMU_TSAN") == "1"       # races between GPU threads of a block that no barrier orders (LDS and global memory)
+    if tsan:                                                   #   (run with LD_PRELOAD=<clang's libclang_rt.tsan-x86_64.so>)
+        flags += ["-fsanitize=thread", "-g1", "-shared-libsan"]
     procs = []
     for u in units:                                            # one compiler process per translation unit (gemm.hip alone is half a minute)
         obj = os.path.join(work, os.path.basename(u) + ".o")
@@ -97,7 +100,7 @@ def build():
             raise RuntimeError(f"host-emulation build of {u} failed:\n{log[-4000:]}")
         objs.append(obj)
     tmp_out = os.path.join(work, "libsdmi_hostemu.so")
-    subprocess.run([cxx, "-shared", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if asan else []) + (["-fsanitize=undefined", "-shared-libsan"] if ubsan else []) + objs + ["-o", tmp_out], check=True, timeout=300)
+    subprocess.run([cxx, "-shared", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if asan else []) + (["-fsanitize=undefined", "-shared-libsan"] if ubsan else []) + (["-fsanitize=thread", "-shared-libsan"] if tsan else []) + objs + ["-o", tmp_out], check=True, timeout=300)
     os.makedirs(out_dir, exist_ok=True)
     os.replace(tmp_out, out)
     shutil.rmtree(work, ignore_errors=True)

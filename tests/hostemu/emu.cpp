@@ -37,6 +37,19 @@ asm(".text\n.globl emu_switch\n.type emu_switch,@function\nemu_switch:\n"
 #include <sanitizer/common_interface_defs.h>
 #endif
 #endif
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define EMU_TSAN 1
+#include <sanitizer/tsan_interface.h>
+#endif
+#endif
+#ifdef EMU_TSAN                                                // SDMI_HOSTEMU_TSAN=1 builds: every GPU thread is a sanitizer fiber; switches establish NO
+#define EMU_TSAN_SWITCH(f) __tsan_switch_to_fiber((f), 1)      // ordering (flag 1 = no_sync) — only barriers (emu_barrier) and block start / end do;
+#define EMU_TSAN_RESUME(f) __tsan_switch_to_fiber((f), 0)      // scheduler -> thread carries the scheduler's own writes (threadIdx ...), never another thread's
+#else
+#define EMU_TSAN_SWITCH(f) ((void)0)
+#define EMU_TSAN_RESUME(f) ((void)0)
+#endif
 #ifdef EMU_ASAN                                                // SDMI_HOSTEMU_ASAN=1 builds: tell the sanitizer about every stack switch
 #define EMU_ASAN_START(save, bottom, size) __sanitizer_start_switch_fiber((save), (bottom), (size))
 #define EMU_ASAN_FINISH(save, bottom, size) __sanitizer_finish_switch_fiber((save), (bottom), (size))
@@ -55,6 +68,9 @@ struct EmuRunner {
     void* sched_sp = nullptr;
     void* sched_fake = nullptr;                                // sanitizer bookkeeping (unused otherwise)
     void* fiber_fake[1024];
+    void* tsan_fiber[1024] = {};                               // (thread-sanitizer builds)
+    void* tsan_sched = nullptr;
+    char tsan_begin = 0, tsan_end = 0;                         // sync variables: block start happens-before every thread, every thread before block end
     const void* sched_bottom = nullptr;
     size_t sched_size = 0;
     unsigned cur = 0, live = 0;
@@ -63,7 +79,7 @@ struct EmuRunner {
     const std::function<void()>* body = nullptr;
 };
 EmuRunner g_run;
-void emu_thread_exit(EmuRunner& r, unsigned t) {               // a returned thread leaves its wave's and the block's barriers
+EMU_RUNTIME void emu_thread_exit(EmuRunner& r, unsigned t) {               // a returned thread leaves its wave's and the block's barriers
     r.done[t] = true;
     --r.live;
     ++r.progress;
@@ -72,24 +88,32 @@ void emu_thread_exit(EmuRunner& r, unsigned t) {               // a returned thr
         if (--k.need[id] > 0 && k.arrived[id] >= k.need[id]) { k.arrived[id] = 0; ++k.gen[id]; }
     }
 }
-void emu_fiber_main() {
+EMU_RUNTIME void emu_fiber_main() {
     EmuRunner& r = g_run;
     EMU_ASAN_FINISH(nullptr, &r.sched_bottom, &r.sched_size);
+#ifdef EMU_TSAN
+    __tsan_acquire(&r.tsan_begin);
+#endif
     (*r.body)();
+#ifdef EMU_TSAN
+    __tsan_release(&r.tsan_end);
+#endif
     emu_thread_exit(r, r.cur);
+    EMU_TSAN_SWITCH(r.tsan_sched);
     EMU_ASAN_START(nullptr, r.sched_bottom, r.sched_size);     // (null: this fiber's stack is not returned to)
     emu_switch(&r.sp[r.cur], r.sched_sp);
     std::abort();                                              // a finished fiber is never resumed
 }
 }  // namespace
-void emu_yield() {
+EMU_RUNTIME void emu_yield() {
     EmuRunner& r = g_run;
     const unsigned me = r.cur;
     EMU_ASAN_START(&r.fiber_fake[me], r.sched_bottom, r.sched_size);
+    EMU_TSAN_SWITCH(r.tsan_sched);
     emu_switch(&r.sp[me], r.sched_sp);
     EMU_ASAN_FINISH(r.fiber_fake[me], &r.sched_bottom, &r.sched_size);
 }
-void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>& body) {
+EMU_RUNTIME void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>& body) {
     EmuRunner& r = g_run;
     const unsigned nt = b.x * b.y * b.z;
     if (nt > 1024 || emu_block) std::abort();                  // (no nested launches)
@@ -114,6 +138,11 @@ void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>
         r.tidx[t] = dim3(t % b.x, (t / b.x) % b.y, t / (b.x * b.y));
     }
     r.b = b; r.body = &body; r.live = nt;
+#ifdef EMU_TSAN
+    r.tsan_sched = __tsan_get_current_fiber();
+    for (unsigned t = 0; t < nt; ++t) if (!r.tsan_fiber[t]) r.tsan_fiber[t] = __tsan_create_fiber(0);
+    __tsan_release(&r.tsan_begin);
+#endif
     gridDim = g; blockDim = b; blockIdx = bi;
     emu_block = &k;
     while (r.live) {
@@ -124,6 +153,7 @@ void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>
             threadIdx = r.tidx[t];
             k.wait_gen[t] = ~0u;
             EMU_ASAN_START(&r.sched_fake, r.stacks + (size_t)t * kFiberStack, kFiberStack);
+            EMU_TSAN_RESUME(r.tsan_fiber[t]);
             emu_switch(&r.sched_sp, r.sp[t]);
             EMU_ASAN_FINISH(r.sched_fake, nullptr, nullptr);
             ++r.progress;
@@ -134,6 +164,9 @@ void emu_run_block_threaded(dim3 g, dim3 b, dim3 bi, const std::function<void()>
         }
     }
     emu_block = nullptr;
+#ifdef EMU_TSAN
+    __tsan_acquire(&r.tsan_end);
+#endif
 }
 
 namespace sdmi {
@@ -228,6 +261,17 @@ int emu_transpose_v(const uint16_t* v, uint16_t* vt, int B, int H, int M, int D,
     return launch_transpose_v((const half_t*)v, (half_t*)vt, B, H, M, D, ldv, Mpad, nullptr);
 }
 int64_t emu_splitk_ws_bytes(int M, int N, int K) { return (int64_t)gemm_splitk_ws_bytes(M, N, K, 1); }
+// control for the sanitizer builds: neighbours exchange through LDS with / without the barrier that orders them
+__global__ void emu_race_control_kernel(int* out, int with_barrier) {
+    __shared__ int s[64];
+    s[threadIdx.x] = (int)threadIdx.x * 3;
+    if (with_barrier) __syncthreads();
+    out[threadIdx.x] = s[(threadIdx.x + 1) & 63];
+}
+int emu_race_control(int* out, int with_barrier) {
+    hipLaunchKernelGGL(emu_race_control_kernel, dim3(1), dim3(64), 0, nullptr, out, with_barrier);
+    return 0;
+}
 const char* emu_last_error() { return get_error(); }
 const char* emu_last_launch() { return g_emu_last_launch.c_str(); }
 void emu_set_threaded(int on) { emu_threaded = on; }

@@ -66,11 +66,25 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }
 
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+extern "C" void __tsan_acquire(void*);
+extern "C" void __tsan_release(void*);
+#define EMU_TSAN_RELEASE(a) __tsan_release(a)
+#define EMU_TSAN_ACQUIRE(a) __tsan_acquire(a)
+#endif
+#endif
+#define EMU_RUNTIME __attribute__((no_sanitize("thread")))   // the emulator's own bookkeeping is not what a sanitizer build looks at
+#ifndef EMU_TSAN_RELEASE
+#define EMU_TSAN_RELEASE(a) ((void)0)
+#define EMU_TSAN_ACQUIRE(a) ((void)0)
+#endif
 struct EmuBlock {                                              // the running block in threaded mode
     unsigned wave_lanes[16];
     // barriers: ids 0 .. 15 = the waves, 16 = the block.  `need` falls when a thread returns from the kernel, as on the hardware
     // (a finished wave no longer takes part in s_barrier)
     unsigned arrived[17], need[17], gen[17];
+    char tsan_sync[17];
     unsigned short wait_id[1024];                              // what a parked thread waits for: the scheduler resumes it when gen[wait_id] has moved on
     unsigned wait_gen[1024];
     uint64_t slot[16][64];
@@ -84,14 +98,16 @@ extern thread_local unsigned emu_tid;                          // linear thread 
 void emu_yield();                                              // to the block's scheduler (tests/hostemu/emu.cpp)
 extern int emu_threaded;                                      // 0 sequential, 1 threaded, 2 auto
 struct EmuNeedThreads {};
-inline void emu_barrier(unsigned id) {                        // the last arrival releases the others; waiting = yielding to the other threads
+EMU_RUNTIME inline void emu_barrier(unsigned id) {                        // the last arrival releases the others; waiting = yielding to the other threads
     EmuBlock* b = emu_block;
     const unsigned g = b->gen[id];
-    if (++b->arrived[id] >= b->need[id]) { b->arrived[id] = 0; ++b->gen[id]; return; }
+    EMU_TSAN_RELEASE(&b->tsan_sync[id]);                       // (thread-sanitizer builds: every arrival happens-before every departure)
+    if (++b->arrived[id] >= b->need[id]) { b->arrived[id] = 0; ++b->gen[id]; EMU_TSAN_ACQUIRE(&b->tsan_sync[id]); return; }
     b->wait_id[emu_tid] = (unsigned short)id; b->wait_gen[emu_tid] = g;
     while (b->gen[id] == g) emu_yield();
+    EMU_TSAN_ACQUIRE(&b->tsan_sync[id]);
 }
-inline bool emu_lone() {                                      // true: no running block (sequential execution); auto mode escalates instead
+EMU_RUNTIME inline bool emu_lone() {                                      // true: no running block (sequential execution); auto mode escalates instead
     if (emu_block) return false;
     if (emu_threaded == 2) throw EmuNeedThreads{};
     return true;
