@@ -262,14 +262,14 @@ int emu_transpose_v(const uint16_t* v, uint16_t* vt, int B, int H, int M, int D,
 }
 int64_t emu_splitk_ws_bytes(int M, int N, int K) { return (int64_t)gemm_splitk_ws_bytes(M, N, K, 1); }
 // control for the sanitizer builds: neighbours exchange through LDS with / without the barrier that orders them
-__global__ void emu_race_control_kernel(int* out, int with_barrier) {
+__global__ void emu_race_control_kernel(int* out, int with_barrier, int salt) {
     __shared__ int s[64];
-    s[threadIdx.x] = (int)threadIdx.x * 3;
+    s[threadIdx.x] = (int)threadIdx.x * 3 + salt;
     if (with_barrier) __syncthreads();
     out[threadIdx.x] = s[(threadIdx.x + 1) & 63];
 }
-int emu_race_control(int* out, int with_barrier) {
-    hipLaunchKernelGGL(emu_race_control_kernel, dim3(1), dim3(64), 0, nullptr, out, with_barrier);
+int emu_race_control(int* out, int with_barrier, int salt) {
+    hipLaunchKernelGGL(emu_race_control_kernel, dim3(1), dim3(64), 0, nullptr, out, with_barrier, salt);
     return 0;
 }
 const char* emu_last_error() { return get_error(); }
