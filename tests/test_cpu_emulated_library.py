@@ -25,14 +25,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SELECTION = os.path.join(ROOT, "tests", "hostemu", "cpu_tier_selection.txt")
 
 
-def test_emulated_library_exports_the_whole_c_abi(hostemu_lib):
+def test_emulated_library_exports_the_whole_c_abi(hostemu_lib, monkeypatch):
     lib = C.CDLL(hostemu_lib)
     declared = importlib.import_module("stable-diffusion-webui_amd._lib").declared_symbols()
     assert len(declared) > 60
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     lib.sdmi_device_ok.restype = C.c_int
-    assert lib.sdmi_device_ok() == 1                           # (the stand-in runtime reports one gfx950 "device")
+    monkeypatch.delenv("SDMI_HOSTEMU", raising=False)
+    assert lib.sdmi_device_ok() == 0                           # pointed at by SDMI_LIB alone it is NOT a device: the product's require_device() refuses
+    monkeypatch.setenv("SDMI_HOSTEMU", "1")
+    assert lib.sdmi_device_ok() == 1                           # only a test process that asked for the emulation sees a gfx950 "device"
 
 
 def test_gpu_parity_tests_pass_on_the_emulated_library(hostemu_lib):
