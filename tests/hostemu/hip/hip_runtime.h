@@ -43,7 +43,16 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : 2; }
+// SDMI_HOSTEMU_POISON=1: fresh "device" memory is filled with 0xFF (fp16 / fp32 NaN, huge integers) instead of whatever the allocator
+// returns — a result that depends on uninitialised device memory (fresh GPU pages are often zero, which hides it) turns into NaN
+inline hipError_t hipMalloc(void** p, size_t n) {
+    const size_t bytes = (n + 255) / 256 * 256 + 256;
+    *p = std::aligned_alloc(256, bytes);
+    if (!*p) return 2;
+    static const bool poison = [] { const char* e = std::getenv("SDMI_HOSTEMU_POISON"); return e && e[0] == '1'; }();
+    if (poison) std::memset(*p, 0xFF, bytes);
+    return hipSuccess;
+}
 template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
