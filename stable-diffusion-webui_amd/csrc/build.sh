@@ -9,6 +9,9 @@ pids=()
 for f in gemm.hip attention.hip norm.hip elementwise.hip; do
   hipcc $FLAGS -c "$f" -o "build/${f%.hip}.o" & pids+=($!)
 done
+# rowchain.hip: no NaN can arise in its softmax / GEGLU (finite operands, -inf only as a key mask), and without the flag every fmaxf of an
+# MFMA result costs an extra canonicalising v_max_f32 in an issue-bound loop
+hipcc $FLAGS -fno-honor-nans -c rowchain.hip -o build/rowchain.o & pids+=($!)
 hipcc $FLAGS -x hip -c engine.cpp -o build/engine.o & pids+=($!)
 hipcc $FLAGS -x hip -c capi.cpp -o build/capi.o & pids+=($!)
 hipcc $FLAGS -x hip -c prof.cpp -o build/prof.o & pids+=($!)

@@ -207,6 +207,39 @@ int sdmi_layernorm(const void* x, const void* gamma, const void* beta, void* out
     API_GUARD_END
 }
 
+int64_t sdmi_rowchain_ff_pack_bytes(int C, int hidden) { return (int64_t)rowchain_ff_pack_bytes(C, hidden); }
+int sdmi_rowchain_ff_pack(const void* w1, const void* b1, const void* w2, void* packs, int C, int hidden, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(w1 && w2 && packs, "null argument");
+    return launch_rowchain_ff_pack((const half_t*)w1, (const float*)b1, (const half_t*)w2, packs, C, hidden, false, (hipStream_t)stream);
+    API_GUARD_END
+}
+int sdmi_rowchain_ff(const void* x, void* out, const void* g, const void* b, const void* packs, const void* b2, int64_t rows, int C,
+                     int hidden, float eps, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(x && out && g && b && packs, "null argument");
+    return launch_rowchain_ff((const half_t*)x, (half_t*)out, (const float*)g, (const float*)b, packs, (const float*)b2, (long)rows, C,
+                              hidden, eps, (hipStream_t)stream);
+    API_GUARD_END
+}
+int64_t sdmi_rowchain_xattn_pack_bytes(int C, int B, int H) { return (int64_t)rowchain_xattn_pack_bytes(C, B, H); }
+int sdmi_rowchain_xattn_pack(const void* k, const void* vt, const void* wq, const void* wo, void* packs, int C, int B, int L, int Lpad,
+                             int H, float scale, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(k && vt && wq && wo && packs && B > 0, "null argument");
+    return launch_rowchain_xattn_pack((const half_t*)k, (const half_t*)vt, (const half_t*)wq, (const half_t*)wo, packs, C, B, L, Lpad, H,
+                                      scale, nullptr, (hipStream_t)stream);
+    API_GUARD_END
+}
+int sdmi_rowchain_xattn(const void* x, void* out, const void* g, const void* b, const void* packs, const void* bo, int64_t rows,
+                        int rows_per_image, int C, int H, float eps, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(x && out && g && b && packs && rows_per_image > 0, "null argument");
+    return launch_rowchain_xattn((const half_t*)x, (half_t*)out, (const float*)g, (const float*)b, packs, (const float*)bo, (long)rows,
+                                 rows_per_image, 0, C, H, eps, (hipStream_t)stream);
+    API_GUARD_END
+}
+
 int sdmi_philox_randn(void* out, int64_t n, uint64_t seed, uint32_t offset, void* stream) {
     API_GUARD_BEGIN
     return launch_philox((float*)out, n, seed, offset, (hipStream_t)stream);
@@ -590,6 +623,7 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     else if (n == "uniform_t") e->uniform_t = value != 0;
     else if (n == "cfg_pairs") e->cfg_pairs = value != 0;
     else if (n == "ln_fold") e->ln_fold = value;
+    else if (n == "fuse_rows") e->fuse_rows = value;
     else if (n == "arena_reuse") e->arena_reuse = value;
     else if (n == "streams") { if (value < 1 || value > 8) { sdmi::set_error("streams must be 1..8"); return 1; } e->n_streams = value; }
     else if (n == "vae_range_extend") e->vae_stream_scale = value ? 1.0f / 64.0f : 1.0f;

@@ -13,6 +13,25 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 namespace sdmi {
 
+// GEGLU's gate: val * gelu(g), gelu(g) = g * Phi(g) (ldm's GEGLU uses F.gelu's default, the exact erf form).  Phi is evaluated as a
+// logistic of an odd quintic,  Phi(g) ~ 1 / (1 + exp(-g (c0 + c1 g^2 + c2 g^4))),  fitted (minimax over [-8, 8], polynomial argument
+// clamped to +-10 where the logistic has long saturated) to |g Phi(g) - gelu(g)| <= 2.6e-5 and a relative error <= 2e-4 near zero —
+// below the fp16 rounding of the product it feeds (4.9e-4 relative) (tests/test_cpu_kernel_emulation.py pins the bound).  10 VALU operations,
+// two of them transcendental, against 18 / two for the A&S 7.1.26 erf it replaces (gemm.hip gelu_erf, kept for the plain GELU
+// epilogue): the GEGLU epilogues are VALU-issue bound next to the MFMAs (profiles/r05_*), so the count is the cost.
+#ifndef SDMI_GELU_SIG
+#define SDMI_GELU_SIG 1
+#endif
+__device__ __forceinline__ float geglu_gate(float val, float g) {
+    const float gc = fminf(fmaxf(g, -10.0f), 10.0f);
+    const float g2 = gc * gc;
+    // -log2(e) * (1.59501577, 7.40112920e-2, -7.03033577e-4)
+    float p = fmaf(1.01426306e-3f, g2, -0.106775724f);
+    p = fmaf(p, g2, -2.30112135f);
+    const float e = __builtin_amdgcn_exp2f(p * gc);          // exp(-g (c0 + c1 g^2 + c2 g^4))
+    return (val * g) * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 void set_error(const std::string& msg);
 const char* get_error();
 
@@ -164,6 +183,24 @@ struct AttnP {
 int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 // v [B, M, ldv] (head h at h*D) -> vt [B, H*D, Mpad] (zero padded)
 int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, int ldv, int Mpad, hipStream_t s);
+
+// ---- row-local chains of the transformer block (rowchain.hip) ----------------------------------------------
+bool rowchain_supports(int C);                      // row widths the fused chains are instantiated for (320)
+int rowchain_xattn_max_keys();                      // longest text context the cross-attention chain takes (96)
+size_t rowchain_ff_pack_bytes(int C, int hidden);
+size_t rowchain_xattn_pack_bytes(int C, int B, int H);
+// w1 [2*hidden][C]: value rows then gate rows (permuted = false) or the engine's GEGLU row packing (true); b1 likewise (may be null)
+int launch_rowchain_ff_pack(const half_t* w1, const float* b1, const half_t* w2, void* packs, int C, int hidden, bool permuted,
+                            hipStream_t s);
+// k [B*L][C], vt [B][C][Lpad], wq / wo [C][C]; scale = d^-1/2; gate: optional device flag, no-op when *gate == 0
+int launch_rowchain_xattn_pack(const half_t* k, const half_t* vt, const half_t* wq, const half_t* wo, void* packs, int C, int B, int L,
+                               int Lpad, int H, float scale, const int* gate, hipStream_t s);
+// out = x + W2 GEGLU(W1 LN(x) + b1) + b2 (rows % 128 == 0)
+int launch_rowchain_ff(const half_t* x, half_t* out, const float* gamma, const float* beta, const void* packs, const float* bias_out,
+                       long rows, int C, int hidden, float eps, hipStream_t s);
+// out = x + to_out(attention(to_q(LN(x)), K, V)) with to_q / to_out folded into the packed per-image key / value matrices
+int launch_rowchain_xattn(const half_t* x, half_t* out, const float* gamma, const float* beta, const void* packs, const float* bias_out,
+                          long rows, int rows_per_img, int img0, int C, int H, float eps, hipStream_t s);
 
 // ---- norms ------------------------------------------------------------------------------------------------
 // pre_nchunk > 0: `ws` already holds partial sums [B][pre_nchunk][groups][2] (written by the producing GEMM): skip the statistics pass

@@ -755,6 +755,16 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         }
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
+        // option "fuse_rows" bit 0: norm2 -> to_q -> attention over the text keys -> to_out -> + x1 as one launch (rowchain.hip)
+        const bool chain_ok = !fold && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0;
+        half_t* x2 = nullptr;
+        if (chain_ok && (e->fuse_rows & 1) && b.ctx_slot < (int)e->ctx_xa.size() && e->ctx_xa[b.ctx_slot] != nullptr) {
+            x2 = r.H(M * C);
+            if (!r.dry) {
+                SDMI_REQUIRE(e->ctx_valid && e->ctx_B == (r.Btot ? r.Btot : B), "context not set for this batch size");
+                TRY(launch_rowchain_xattn(x1, x2, b.ln2.g, b.ln2.b, e->ctx_xa[b.ctx_slot], b.o2.b, (long)M, HW, r.b0, C, st.heads, 1e-5f, r.s));
+            }
+        } else {
         half_t* q2 = nullptr;
         if (fold) {
             LnStats st2;
@@ -782,11 +792,31 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             // cache stores K compactly with exactly L rows per image (see set_context)
             TRY(launch_attention(p, e->force_generic, r.s));
         }
-        half_t* x2 = r.H(M * C);
+        x2 = r.H(M * C);
         r.lnp_want = fold && e->ln_fold >= 2;
         TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C));
+        }
         r.tap(bname + ".attn2+x", x2, B, H, Wd, C);
         // --- feed forward (GEGLU fused in the first GEMM's epilogue)
+        half_t* x3 = reuse ? pp[blk & 1] : r.H(M * C);                          // (block k reads pp[(k - 1) & 1] — or proj_in's buffer — and writes pp[k & 1])
+        // option "fuse_rows" bit 1: norm3 -> ff.net.0.proj (GEGLU) -> ff.net.2 -> + x2 as one launch: the 4C-wide hidden tensor stays on the CU
+        if (chain_ok && (e->fuse_rows & 2) && b.ff1.geglu && b.ff1.n_pad % 64 == 0 && b.ff2.cin_pad * 2 == b.ff1.n_pad && b.ff1.cin_pad == C &&
+            b.ff2.n_pad == C) {
+            if (!r.dry) {
+                const int hidden = b.ff2.cin_pad;
+                if (!b.ff_packs) {
+                    void* pk = nullptr;
+                    SDMI_CHECK_HIP(hipMalloc(&pk, rowchain_ff_pack_bytes(C, hidden)));
+                    e->owned.push_back(pk);
+                    b.ff_packs = (char*)pk;
+                }
+                if (b.ff_epoch != e->weights_epoch) {
+                    TRY(launch_rowchain_ff_pack(b.ff1.w, b.ff1.b, b.ff2.w, b.ff_packs, C, hidden, true, r.s));
+                    b.ff_epoch = e->weights_epoch;
+                }
+                TRY(launch_rowchain_ff(x2, x3, b.ln3.g, b.ln3.b, b.ff_packs, b.ff2.b, (long)M, C, hidden, 1e-5f, r.s));
+            }
+        } else {
         half_t* g = nullptr;
         if (fold) {
             LnStats st3;
@@ -799,9 +829,9 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             g = r.H(M * 4 * C);
             TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
         }
-        half_t* x3 = reuse ? pp[blk & 1] : r.H(M * C);                          // (block k reads pp[(k - 1) & 1] — or proj_in's buffer — and writes pp[k & 1])
         r.lnp_want = fold && e->ln_fold >= 2;                                   // read by the next block's norm1 (SDXL: depth > 1); unused after the last
         TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
+        }
         r.tap(bname, x3, B, H, Wd, C);
         cur = x3;
         ++blk;
@@ -819,7 +849,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
 // ------------------------------------------------------------------------------------------------------------
 static void ctx_free(sdmi_engine* e) {
     for (void* p : e->ctx_owned) (void)hipFree(p);
-    e->ctx_owned.clear(); e->ctx_k.clear(); e->ctx_vt.clear();
+    e->ctx_owned.clear(); e->ctx_k.clear(); e->ctx_vt.clear(); e->ctx_xa.clear();
     e->ctx_f16 = nullptr; e->ctx_valid = false;
 }
 
@@ -839,7 +869,8 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
     const int cd = u.cfg.context_dim;
     const int Lpad = rup(L, 64);
     const int* gate = nullptr;
-    if (conditional && e->ctx_valid && e->ctx_B == Bn && e->ctx_L == L && !e->ctx_k.empty() && !hn_has_dim(e, cd)) {
+    const int xa_mode = e->fuse_rows & 1;      // the fused cross-attention chain keeps its own per-image matrices beside K / V^T
+    if (conditional && e->ctx_valid && e->ctx_B == Bn && e->ctx_L == L && !e->ctx_k.empty() && !hn_has_dim(e, cd) && e->ctx_xa_mode == xa_mode) {
         if (!e->ctx_gate) {
             SDMI_CHECK_HIP(hipMalloc((void**)&e->ctx_gate, 256));
             e->owned.push_back(e->ctx_gate);
@@ -848,9 +879,10 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
         TRY(launch_ctx_compare(ctx, dtype, e->ctx_f16, Bn, L, Lpad, cd, e->ctx_gate, s));
         gate = e->ctx_gate;
     }
-    if (e->ctx_B != Bn || e->ctx_L != L || e->ctx_k.empty()) {
+    if (e->ctx_B != Bn || e->ctx_L != L || e->ctx_k.empty() || e->ctx_xa_mode != xa_mode) {
         SDMI_CHECK_HIP(hipStreamSynchronize(s));
         ctx_free(e);
+        e->ctx_xa_mode = xa_mode;
         void* p = nullptr;
         SDMI_CHECK_HIP(hipMalloc(&p, (size_t)Bn * Lpad * cd * sizeof(half_t)));
         e->ctx_owned.push_back(p);
@@ -860,8 +892,14 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
         collect_st(u, &sts);
         e->ctx_k.assign(u.n_ctx_slots, nullptr);
         e->ctx_vt.assign(u.n_ctx_slots, nullptr);
+        e->ctx_xa.assign(u.n_ctx_slots, nullptr);
         for (const STW* st : sts)
             for (const TBlockW& b : st->blocks) {
+                if (xa_mode && rowchain_supports(st->ch) && L <= rowchain_xattn_max_keys() && st->heads * st->dhead == st->ch && !b.q2.b) {
+                    SDMI_CHECK_HIP(hipMalloc(&p, rowchain_xattn_pack_bytes(st->ch, Bn, st->heads)));
+                    e->ctx_owned.push_back(p);
+                    e->ctx_xa[b.ctx_slot] = (char*)p;
+                }
                 SDMI_CHECK_HIP(hipMalloc(&p, (size_t)Bn * L * st->ch * sizeof(half_t)));
                 e->ctx_owned.push_back(p);
                 e->ctx_k[b.ctx_slot] = (half_t*)p;
@@ -921,6 +959,10 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
             TRY(run_conv(r, b.k2, c));
             // V^T[b] = Wv ctx[b]^T : [C][Lpad]
             TRY(run_vt(r, b.v2, ctx_v_src, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false, gate));
+            // fused cross-attention chain: Kq = (K_h Wq_h) d^-1/2 log2 e and VWo = V_h Wo_h^T per image and head (rowchain.hip)
+            if (e->ctx_xa[b.ctx_slot])
+                TRY(launch_rowchain_xattn_pack(e->ctx_k[b.ctx_slot], e->ctx_vt[b.ctx_slot], b.q2.w, b.o2.w, e->ctx_xa[b.ctx_slot], st->ch, Bn,
+                                               L, Lpad, st->heads, 1.0f / sqrtf((float)st->dhead), gate, s));
         }
     e->ctx_valid = true;
     return 0;

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "../../include/sdmi.h"
 
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -52,6 +53,10 @@ struct TBlockW {
     ConvW v1;                     // [C][C]   used as the "activation" operand of the V^T GEMM
     ConvW o1, q2, k2, v2, o2, ff1, ff2;
     int ctx_slot = -1;            // index into the per-layer context K / V^T cache
+    // row-local chains (engine option "fuse_rows", rowchain.hip): packed operand stream of ff.net.0.proj / ff.net.2, built lazily,
+    // rebuilt when it falls behind the engine's weights_epoch
+    mutable char* ff_packs = nullptr;
+    mutable long ff_epoch = -1;
 };
 struct STW {
     NormW norm;
@@ -201,6 +206,13 @@ struct sdmi_engine {
     // LayerNorm folded into the consuming GEMMs of the transformer blocks (norm1 -> to_q|to_k, to_v; norm2 -> attn2.to_q; norm3 ->
     // ff.net.0): only the per-row (mean, rstd) are computed, the normalised tensors never reach HBM.  Off by default until measured.
     int ln_fold = 0;                          // 1: row statistics from ln_rowstats_kernel; 2: also per-tile partial sums from the producing GEMMs' epilogues
+    // Row-local chains of the transformer blocks at the 320-wide level as single launches (rowchain.hip).  Bit 0: norm2 -> attn2 (to_q and
+    // to_out folded into per-image key / value matrices kept beside the K / V^T cache) -> + x; bit 1: norm3 -> GEGLU -> ff.net.2 -> + x.
+    // Default 2 (round 5, same-box A/Bs of the forward, profiles/r05_fwd_ab_*): the feed-forward chain is 203-219 us against 263 us of
+    // LayerNorm + GEGLU GEMM + GEMM; the cross-attention chain is issue-bound at 118-147 us against 115 us and stays opt-in.
+    int fuse_rows = [] { const char* e = getenv("SDMI_FUSE_ROWS"); return e ? atoi(e) : 2; }();
+    std::vector<char*> ctx_xa;                // per context slot: packed Kq / VWo stream [Bn][heads] (null: not built for this slot)
+    int ctx_xa_mode = 0;                      // value of (fuse_rows & 1) the context cache was allocated under
     long weights_epoch = 0;                   // bumped by every in-place weight / vector update: folded copies older than this are stale
     bool cfg_pairs = false;                   // rows [Bn/2, Bn) repeat the latent and timestep of rows [0, Bn/2): the layers in front of the first cross-attention run once (option "cfg_pairs")
     bool uniform_t = false;                   // every row of the call sits at the same timestep: the embedding path runs for one row (option "uniform_t")

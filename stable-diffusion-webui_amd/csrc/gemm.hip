@@ -393,7 +393,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                                         } else {
                                             av = fmaf(va[r], p.alpha, ba[r]); g = fmaf(vg[r], p.alpha, bg[r]);
                                         }
-                                        o[t][r] = (half_t)(av * gelu_erf(g));
+                                        o[t][r] = (half_t)(SDMI_GELU_SIG ? geglu_gate(av, g) : av * gelu_erf(g));
                                     }
                                 }
                                 swap16(o[0], o[1]);
@@ -581,13 +581,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                             for (int r = 0; r < 4; ++r) {
                                 const float a = st[1] * (va[r] * p.alpha - st[0] * sva[r]) + ba[r];
                                 const float g = st[1] * (vg[r] * p.alpha - st[0] * svg[r]) + bg[r];
-                                o[r] = (half_t)(a * gelu_erf(g));
+                                o[r] = (half_t)(SDMI_GELU_SIG ? geglu_gate(a, g) : a * gelu_erf(g));
                             }
                         } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float a = fmaf(va[r], p.alpha, ba[r]), g = fmaf(vg[r], p.alpha, bg[r]);
-                            o[r] = (half_t)(a * gelu_erf(g));
+                            o[r] = (half_t)(SDMI_GELU_SIG ? geglu_gate(a, g) : a * gelu_erf(g));
                         }
                         }
                         *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + nout) = o;
@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmP p) {
             float a = dot_row(p, a0, a1, wbase + (long)na * p.ldw, ri) * p.alpha;
             float gt = dot_row(p, a0, a1, wbase + (long)ng * p.ldw, ri) * p.alpha;
             if (p.bias) { a += p.bias[na]; gt += p.bias[ng]; }
-            ((half_t*)p.out)[z * p.o_bs + (long)m * p.ldo + no] = (half_t)(a * gelu_erf(gt));
+            ((half_t*)p.out)[z * p.o_bs + (long)m * p.ldo + no] = (half_t)(SDMI_GELU_SIG ? geglu_gate(a, gt) : a * gelu_erf(gt));
             continue;
         }
         float v = no < p.n_valid ? dot_row(p, a0, a1, wbase + (long)no * p.ldw, ri) * p.alpha : 0.f;

@@ -23,7 +23,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "stable-diffusion-webui_amd", "csrc")
 EMU = os.path.join(ROOT, "tests", "hostemu")
-KERNEL_FILES = ("elementwise.hip", "norm.hip", "gemm.hip", "attention.hip")
+KERNEL_FILES = ("elementwise.hip", "norm.hip", "gemm.hip", "attention.hip", "rowchain.hip")
 HOST_FILES = ("capi.cpp", "engine.cpp")
 
 
@@ -34,18 +34,18 @@ def compiler():
 
 def transformed(name):
     src = open(os.path.join(CSRC, name)).read().replace("extern __shared__ ", "extern ")
-    if name == "gemm.hip":
+    if name in ("gemm.hip", "rowchain.hip"):
         for old, new in (("typedef const __attribute__((address_space(1))) void* gptr_t;", "typedef const void* gptr_t;"),
-                         ("typedef __attribute__((address_space(3))) void* lptr_t;", "typedef void* lptr_t;"), ('"+s"(dx)', '"+r"(dx)')):
+                         ("typedef __attribute__((address_space(3))) void* lptr_t;", "typedef void* lptr_t;")) + ((('"+s"(dx)', '"+r"(dx)'),) if name == "gemm.hip" else ()):
             assert old in src, old
             src = src.replace(old, new)
-    if name in ("gemm.hip", "attention.hip"):
+    if name in ("gemm.hip", "attention.hip", "rowchain.hip"):
         src, n_wait = re.subn(r'asm volatile\("s_waitcnt[^;]*;', ";", src)
         assert n_wait > 0
-    if name == "attention.hip":
+    if name in ("attention.hip", "rowchain.hip"):
         src, n_swap = re.subn(r'asm volatile\("s_nop 1\\n\\tv_permlane32_swap_b32 %0, %1" : "\+v"\((\w+)\), "\+v"\((\w+)\)\);',
                               r"emu_permlane32_swap(\1, \2);", src)
-        assert n_swap >= 3
+        assert n_swap >= (3 if name == "attention.hip" else 1)
     src = re.sub(r'asm volatile\(""[^;]*;', ";", src)
     assert "asm volatile" not in src, name
     return src

@@ -245,6 +245,9 @@ inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds, unsigned 
 }
 inline void __builtin_amdgcn_s_barrier() { if (!emu_lone()) emu_barrier(16); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+// a wave's LDS operations execute in program order on the hardware (the builtin only pins the compiler's schedule); with one fiber per
+// lane the order between DIFFERENT lanes of a wave needs a real rendezvous
+inline void __builtin_amdgcn_wave_barrier() { if (!emu_lone()) emu_barrier(emu_tid >> 6); }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // (the kernels pass wave-uniform values)
 inline long long __builtin_amdgcn_s_memtime() { return 0; }

@@ -33,10 +33,11 @@ import numpy as np  # noqa: E402
 hipmem = None                   # tools/gpu/hipmem.py, imported by main(): tools/cpu/fwd_parity.py imports this module for its weights only
 
 PKG = "stable-diffusion-webui_amd"
-ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse", "cfg_pairs", "uniform_t", "gn_cat")
+FUSE_ROWS_DEFAULT = 2           # the engine's default for option "fuse_rows" (engine.h)
+ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse", "cfg_pairs", "uniform_t", "gn_cat", "fuse_rows")
 DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15,
             "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1, "gemm_split": 0, "gemm_pipe": -1, "gn_fuse": 1, "gn_small": 1, "ep_wide": 1,
-            "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0, "cfg_pairs": 1, "uniform_t": 1, "gn_cat": 0}
+            "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0, "cfg_pairs": 1, "uniform_t": 1, "gn_cat": 0, "fuse_rows": FUSE_ROWS_DEFAULT}
 assert all(k in DEFAULTS for k in ENGINE_OPTS if k in ("gn_cat", "cfg_pairs", "uniform_t", "ln_fold", "streams", "arena_reuse"))     # every option a setting may switch is reset by the next one
 
 
@@ -56,7 +57,7 @@ def classify(name):
         if re.search(r" x\d+$", name):
             return "1x1_batched"
         return "1x1"
-    for p in ("attention_mfma_self", "attention_mfma_cross", "groupnorm", "layernorm", "splitk", "small_linear"):
+    for p in ("attention_mfma_self", "attention_mfma_cross", "groupnorm", "layernorm", "splitk", "small_linear", "rowchain_xattn", "rowchain_ff"):
         if name.startswith(p):
             return p
     return "other"
@@ -214,7 +215,9 @@ def build(args):
             if rc and v == DEFAULTS.get(k):                   # an older library (SDMI_LIB two-builds A/B) does not know this knob
                 continue
             _lib.check(rc, k)
-        # cached K / V^T of the text context depend on nothing a knob changes, but a knob may change the arena: one untimed forward follows
+        # cached K / V^T of the text context depend on nothing a knob changes — except "fuse_rows", whose per-image matrices live beside them
+        if args.what == "unet":
+            _lib.check(lib.sdmi_unet_set_context(handle, dctx.ptr, _lib.F32, B, L, None), "set_context")
 
 
     def profile_once():
