@@ -624,6 +624,7 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     else if (n == "cfg_pairs") e->cfg_pairs = value != 0;
     else if (n == "ln_fold") e->ln_fold = value;
     else if (n == "fuse_rows") e->fuse_rows = value;
+    else if (n == "residual_fp32") e->residual_fp32 = value != 0;
     else if (n == "arena_reuse") e->arena_reuse = value;
     else if (n == "streams") { if (value < 1 || value > 8) { sdmi::set_error("streams must be 1..8"); return 1; } e->n_streams = value; }
     else if (n == "vae_range_extend") e->vae_stream_scale = value ? 1.0f / 64.0f : 1.0f;

@@ -121,6 +121,13 @@ struct GemmP {
     // per-row sums of its fp16-ROUNDED outputs over the tile's BN columns to lnp_out[(m * lnp_np + tile_n) * 2 + {0, 1}]
     float* lnp_out;
     int lnp_np;              // set by launch_gemm: N / BN of the chosen tile when the partials are produced, else 0
+    // Engine option "residual_fp32": the carried stream (ResBlock / transformer residual sums) as a (hi, lo) pair of fp16 tensors,
+    // x = hi + lo with hi = fp16(x) and lo = fp16(x - hi): ~22 bits of the fp32 sum survive the store, every GEMM that takes the
+    // stream as its A operand reads hi alone (the MFMA operand is fp16 either way), norms and residual adds read both.
+    // resid_lo: lo part of `resid` (same strides); out_lo: where the lo part of the fp16 output goes (same strides as out).
+    // launch_gemm then takes the 8-byte epilogue, no split-K and no statistics epilogues.
+    const half_t* resid_lo;
+    half_t* out_lo;
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
@@ -204,11 +211,13 @@ int launch_rowchain_xattn(const half_t* x, half_t* out, const float* gamma, cons
 
 // ---- norms ------------------------------------------------------------------------------------------------
 // pre_nchunk > 0: `ws` already holds partial sums [B][pre_nchunk][groups][2] (written by the producing GEMM): skip the statistics pass
+// x0_lo / x1_lo (engine option "residual_fp32"): the lo parts when the inputs are (hi, lo) fp16 pairs of the carried stream
 int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
-                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int pre_nchunk = 0);
+                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int pre_nchunk = 0,
+                     const half_t* x0_lo = nullptr, const half_t* x1_lo = nullptr);
 int64_t groupnorm_ws_bytes(int B, int HW, int groups);
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
-                     float eps, hipStream_t s);
+                     float eps, hipStream_t s, const half_t* x_lo = nullptr);
 // LayerNorm folded into the consuming GEMMs (GemmP::ln_stats): per-row (mean, rstd) of x [rows][C] -> stats [rows][2] ...
 int launch_ln_rowstats(const half_t* x, float* stats, int64_t rows, int C, float eps, hipStream_t s);
 // ... and the one-off weight fold: wf[n][k] = fp16(w[n][k] * gamma[k]) (k < C, 0 beyond), s[n] = sum_k wf[n][k],

@@ -51,10 +51,15 @@ struct Run {
     Run(sdmi_engine* e_, hipStream_t s_, bool dry_, Arena* ar_ = nullptr, int b0_ = 0, int Btot_ = 0)
         : e(e_), s(s_), dry(dry_), ar(ar_ ? ar_ : &e_->arena), b0(b0_), Btot(Btot_) {}
     half_t* H(size_t n) { return (half_t*)ar->take(n * sizeof(half_t)); }
+    // Option "residual_fp32": a tensor of the carried stream is a (hi, lo) pair of fp16 tensors, allocated back to back — S(n) takes
+    // room for both, lo(p, n) is the second half (null when the option is off: every consumer then sees a plain fp16 tensor).
+    bool acc() const { return e->residual_fp32; }
+    half_t* S(size_t n) { return H(acc() ? 2 * n : n); }
+    half_t* lo(const half_t* p, size_t n) const { return (acc() && p) ? const_cast<half_t*>(p) + n : nullptr; }
     // option "arena_reuse": a block's temporaries are released when the block returns — the next block's launches (same stream, so
     // ordered behind every reader) write over them while their lines are still in the 256 MB Infinity Cache, instead of every
     // activation of a forward (~10 GB) being written back to HBM once.  Not while block outputs are tapped or LayerNorm partials live.
-    bool reuse() const { return e->arena_reuse && !e->trace && !e->ln_fold; }
+    bool reuse() const { return e->arena_reuse && !e->trace && !e->ln_fold && !e->residual_fp32; }
     float* F(size_t n) { return (float*)ar->take(n * sizeof(float)); }
     void tap(const std::string& name, const half_t* p, int B, int H, int W, int C) {
         if (!dry && e->trace) e->taps.push_back({name, p, B, H, W, C});
@@ -354,6 +359,8 @@ struct ConvArgs {
     const float* rowbias = nullptr;
     int ldrb = 0;
     const half_t* resid = nullptr;
+    const half_t* resid_lo = nullptr;   // (hi, lo) stream tensors: GemmP::resid_lo / out_lo
+    half_t* out_lo = nullptr;
     int ldr = 0;
     void* out = nullptr;
     int ldo = 0;
@@ -391,6 +398,7 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.splitk_ws = splitk_ws;
     p.lnp_out = lnp_ws;
     p.a0 = a.a0; p.a1 = a.a1; p.w = W.w; p.bias = W.b; p.rowbias = a.rowbias; p.resid = a.resid; p.out = a.out;
+    p.resid_lo = a.resid_lo; p.out_lo = a.out_lo;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1; p.lda0 = a.c0; p.lda1 = a.c1;
     SDMI_REQUIRE(p.cin == W.cin_pad, "conv input channels do not match the packed weight");
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
@@ -416,8 +424,9 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
 
 // plain [rows, K] x W^T GEMM on token matrices
 static int run_linear(Run& r, const ConvW& W, const half_t* a, int rows, const half_t* resid, half_t* out, int ldo, float ss = 1.f,
-                      bool no_split = false) {
+                      bool no_split = false, const half_t* resid_lo = nullptr, half_t* out_lo = nullptr) {
     ConvArgs c;
+    c.resid_lo = resid_lo; c.out_lo = out_lo;
     c.alpha = ss; c.bias_scale = ss;
     c.no_split = no_split;
     c.a0 = a; c.c0 = W.cin_pad;
@@ -427,17 +436,18 @@ static int run_linear(Run& r, const ConvW& W, const half_t* a, int rows, const h
 }
 
 static int run_gn(Run& r, const NormW& n, const half_t* x0, const half_t* x1, int c0, int c1, int B, int HW, float eps,
-                  bool silu, half_t* out) {
+                  bool silu, half_t* out, const half_t* x0_lo = nullptr, const half_t* x1_lo = nullptr) {
     float* ws = r.F(groupnorm_ws_bytes(B, HW, 32) / sizeof(float));
     if (r.dry) return 0;
     SDMI_REQUIRE(n.c == c0 + c1, "GroupNorm channel mismatch");
+    if (x0_lo) return launch_groupnorm(x0, x1, c0, c1, n.g, n.b, out, B, HW, 32, eps, silu, ws, r.s, 0, x0_lo, x1_lo);
     if (x1 == nullptr && r.st_nchunk > 0 && r.st_tensor == x0)      // the producing GEMM already summed this tensor
         return launch_groupnorm(x0, nullptr, c0, 0, n.g, n.b, out, B, HW, 32, eps, silu, r.st_ws, r.s, r.st_nchunk);
     return launch_groupnorm(x0, x1, c0, c1, n.g, n.b, out, B, HW, 32, eps, silu, ws, r.s);
 }
-static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t* out) {
+static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t* out, const half_t* x_lo = nullptr) {
     if (r.dry) return 0;
-    return launch_layernorm(x, n.g, n.b, out, rows, n.c, 1e-5f, r.s);
+    return launch_layernorm(x, n.g, n.b, out, rows, n.c, 1e-5f, r.s, x_lo);
 }
 
 // ---- LayerNorm folded into the consuming GEMM (option "ln_fold") -----------------------------------------------------------
@@ -517,7 +527,7 @@ static int run_vt_ln(Run& r, const ConvW& Wv, const NormW& n, const half_t* x, c
 // scale-invariant once eps is multiplied by ss^2, the block-internal tensors stay at true scale, and the two layers that write the
 // stream scale their accumulator (alpha) and / or bias (bias_scale).
 static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, int c0, int c1, int B, int H, int Wd,
-                   float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f, half_t* out_buf = nullptr) {
+                   float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f, half_t* out_buf = nullptr, bool hilo = false) {
     const int HW = H * Wd;
     const size_t M = (size_t)B * HW;
     // arena_reuse: what outlives the block — its output and the GroupNorm partial sums the last conv leaves for the next norm — is taken
@@ -526,8 +536,12 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
     half_t* o_pre = reuse ? r.H(M * w.cout) : nullptr;
     float* st_pre = (reuse && ss == 1.f && w.cout % 32 == 0) ? r.F((size_t)B * 64 * 32 * 2) : nullptr;
     const size_t mk = r.ar->mark();
+    // option "residual_fp32" (UNet only, ss == 1): x0 / x1 and the output are (hi, lo) pairs of the carried stream
+    const bool acc = hilo && r.acc() && ss == 1.f && !out_buf;               // (hilo: the UNet's calls; the VAE's tensors are plain fp16)
+    const half_t* x0_lo = acc ? r.lo(x0, M * c0) : nullptr;
+    const half_t* x1_lo = (acc && x1) ? r.lo(x1, M * c1) : nullptr;
     half_t* t1 = r.H(M * w.cin);
-    TRY(run_gn(r, w.n1, x0, x1, c0, c1, B, HW, eps * ss * ss, true, t1));
+    TRY(run_gn(r, w.n1, x0, x1, c0, c1, B, HW, eps * ss * ss, true, t1, x0_lo, x1_lo));
     half_t* h1 = r.H(M * w.cout);
     {
         ConvArgs c;
@@ -540,22 +554,26 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
     half_t* t2 = r.H(M * w.cout);
     TRY(run_gn(r, w.n2, h1, nullptr, w.cout, 0, B, HW, eps, true, t2));
     const half_t* resid = x0;
+    const half_t* resid_lo = x0_lo;
     if (w.has_skip) {
-        half_t* sk = r.H(M * w.cout);
+        half_t* sk = acc ? r.S(M * w.cout) : r.H(M * w.cout);
         ConvArgs c;
         c.a0 = x0; c.a1 = x1; c.c0 = c0; c.c1 = c1; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd;
         c.out = sk; c.ldo = w.cout;
+        c.out_lo = acc ? r.lo(sk, M * w.cout) : nullptr;      // the skip_connection output is part of the stream
         c.bias_scale = ss;                                    // the input already carries ss
         TRY(run_conv(r, w.skip, c));
         resid = sk;
+        resid_lo = c.out_lo;
     } else {
         SDMI_REQUIRE(x1 == nullptr, "identity skip with a concatenated input");
     }
-    half_t* o = out_buf ? out_buf : (reuse ? o_pre : r.H(M * w.cout));       // (out_buf: the caller's, larger buffer — unet_run's shared CFG prefix)
+    half_t* o = out_buf ? out_buf : (reuse ? o_pre : (acc ? r.S(M * w.cout) : r.H(M * w.cout)));       // (out_buf: the caller's, larger buffer — unet_run's shared CFG prefix)
     {
         ConvArgs c;
         c.a0 = t2; c.c0 = w.cout; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
         c.resid = resid; c.ldr = w.cout; c.out = o; c.ldo = w.cout;
+        c.resid_lo = resid_lo; c.out_lo = acc ? r.lo(o, M * w.cout) : nullptr;
         c.alpha = ss; c.bias_scale = ss;
         c.stats_C = ss == 1.f ? w.cout : 0;                   // the block output usually feeds the next GroupNorm (ignored if not)
         c.stats_ws_pre = st_pre;
@@ -689,13 +707,17 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     half_t* cur_pre = reuse ? r.H(M * C) : nullptr;
     half_t* pp[2] = {reuse ? r.H(M * C) : nullptr, (reuse && st.blocks.size() > 1) ? r.H(M * C) : nullptr};
     const size_t mk = r.ar->mark();
+    // option "residual_fp32": x, the token stream and the output are (hi, lo) pairs (Run::S / Run::lo); the fused chains, the LayerNorm
+    // fold and the shared CFG prefix are not combined with it (unet_run / below)
+    const bool acc = r.acc();
+    const size_t MC = M * C;
     half_t* n0 = r.H(M * C);
-    TRY(run_gn(r, st.norm, x, nullptr, C, 0, B1, HW, 1e-6f, false, n0));
-    half_t* cur = reuse ? cur_pre : r.H(M * C);
+    TRY(run_gn(r, st.norm, x, nullptr, C, 0, B1, HW, 1e-6f, false, n0, r.lo(x, MC)));
+    half_t* cur = reuse ? cur_pre : r.S(M * C);
     // with "ln_fold" the GEMMs that write a LayerNorm's input also leave its row sums (Run::lnp_want; a no-op otherwise)
-    const bool fold_any = e->ln_fold && !hn_has_dim(e, C) && !e->force_generic && e->use_glds && g_vt_mode == 1 && HW == Npad && HW % 4 == 0;
+    const bool fold_any = e->ln_fold && !acc && !hn_has_dim(e, C) && !e->force_generic && e->use_glds && g_vt_mode == 1 && HW == Npad && HW % 4 == 0;
     r.lnp_want = fold_any && e->ln_fold >= 2;
-    TRY(run_linear(r, st.proj_in, n0, (int)M1, nullptr, cur, C));
+    TRY(run_linear(r, st.proj_in, n0, (int)M1, nullptr, cur, C, 1.f, false, nullptr, r.lo(cur, MC)));
     if (reuse) r.ar->rewind(mk);
     int bi = 0, blk = 0;
     for (const TBlockW& b : st.blocks) {
@@ -717,7 +739,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(run_attn(r, qk, qk + C, vt, a1, B, st.heads, HW, HW, st.dhead, 2 * C, 2 * C, Npad, C));
         }
         half_t* n1 = fold ? nullptr : r.H(M * C);
-        if (!fold) TRY(run_ln(r, b.ln1, cur, M1, n1));
+        if (!fold) TRY(run_ln(r, b.ln1, cur, M1, n1, r.lo(cur, MC)));
         if (fold) {
         } else if (!hn_has_dim(e, C)) {
             half_t* qk = r.H(M * 2 * C);
@@ -746,9 +768,9 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             a1 = r.H(M * C);
             TRY(run_attn(r, q, k, vt, a1, B, st.heads, HW, HW, st.dhead, C, C, Npad, C));
         }
-        half_t* x1 = r.H(M * C);
+        half_t* x1 = r.S(M * C);
         r.lnp_want = fold && e->ln_fold >= 2;
-        TRY(run_linear(r, b.o1, a1, (int)M1, cur, x1, C));
+        TRY(run_linear(r, b.o1, a1, (int)M1, cur, x1, C, 1.f, false, r.lo(cur, MC), r.lo(x1, MC)));
         if (B1 != B) {                                       // end of the shared prefix: the other half of the batch continues from a copy
             if (!r.dry) SDMI_CHECK_HIP(hipMemcpyAsync(x1 + M1 * C, x1, M1 * C * sizeof(half_t), hipMemcpyDeviceToDevice, r.s));
             B1 = B; M1 = M;
@@ -756,7 +778,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
         // option "fuse_rows" bit 0: norm2 -> to_q -> attention over the text keys -> to_out -> + x1 as one launch (rowchain.hip)
-        const bool chain_ok = !fold && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0;
+        const bool chain_ok = !fold && !acc && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0;
         half_t* x2 = nullptr;
         if (chain_ok && (e->fuse_rows & 1) && b.ctx_slot < (int)e->ctx_xa.size() && e->ctx_xa[b.ctx_slot] != nullptr) {
             x2 = r.H(M * C);
@@ -773,7 +795,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(run_linear_ln(r, b.q2, b.ln2, x1, st2, (int)M, q2, C));
         } else {
             half_t* n2 = r.H(M * C);
-            TRY(run_ln(r, b.ln2, x1, M, n2));
+            TRY(run_ln(r, b.ln2, x1, M, n2, r.lo(x1, MC)));
             q2 = r.H(M * C);
             TRY(run_linear(r, b.q2, n2, (int)M, nullptr, q2, C));
         }
@@ -792,13 +814,13 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             // cache stores K compactly with exactly L rows per image (see set_context)
             TRY(launch_attention(p, e->force_generic, r.s));
         }
-        x2 = r.H(M * C);
+        x2 = r.S(M * C);
         r.lnp_want = fold && e->ln_fold >= 2;
-        TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C));
+        TRY(run_linear(r, b.o2, a2, (int)M, x1, x2, C, 1.f, false, r.lo(x1, MC), r.lo(x2, MC)));
         }
         r.tap(bname + ".attn2+x", x2, B, H, Wd, C);
         // --- feed forward (GEGLU fused in the first GEMM's epilogue)
-        half_t* x3 = reuse ? pp[blk & 1] : r.H(M * C);                          // (block k reads pp[(k - 1) & 1] — or proj_in's buffer — and writes pp[k & 1])
+        half_t* x3 = reuse ? pp[blk & 1] : r.S(M * C);                          // (block k reads pp[(k - 1) & 1] — or proj_in's buffer — and writes pp[k & 1])
         // option "fuse_rows" bit 1: norm3 -> ff.net.0.proj (GEGLU) -> ff.net.2 -> + x2 as one launch: the 4C-wide hidden tensor stays on the CU
         if (chain_ok && (e->fuse_rows & 2) && b.ff1.geglu && b.ff1.n_pad % 64 == 0 && b.ff2.cin_pad * 2 == b.ff1.n_pad && b.ff1.cin_pad == C &&
             b.ff2.n_pad == C) {
@@ -825,20 +847,20 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             TRY(run_linear_ln(r, b.ff1, b.ln3, x2, st3, (int)M, g, 4 * C));
         } else {
             half_t* n3 = r.H(M * C);
-            TRY(run_ln(r, b.ln3, x2, M, n3));
+            TRY(run_ln(r, b.ln3, x2, M, n3, r.lo(x2, MC)));
             g = r.H(M * 4 * C);
             TRY(run_linear(r, b.ff1, n3, (int)M, nullptr, g, 4 * C));
         }
         r.lnp_want = fold && e->ln_fold >= 2;                                   // read by the next block's norm1 (SDXL: depth > 1); unused after the last
-        TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C));
+        TRY(run_linear(r, b.ff2, g, (int)M, x2, x3, C, 1.f, false, r.lo(x2, MC), r.lo(x3, MC)));
         }
         r.tap(bname, x3, B, H, Wd, C);
         cur = x3;
         ++blk;
         if (reuse) r.ar->rewind(mk);
     }
-    half_t* o = reuse ? o_pre : r.H(M * C);
-    TRY(run_linear(r, st.proj_out, cur, (int)M, x, o, C));
+    half_t* o = reuse ? o_pre : r.S(M * C);
+    TRY(run_linear(r, st.proj_out, cur, (int)M, x, o, C, 1.f, false, r.lo(x, MC), r.lo(o, MC)));
     *out = o;
     (void)L;
     return 0;
@@ -1026,7 +1048,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     // block (SD1.x / 2.x: the largest self-attention launch of the forward) run for Bn / 2 rows and are copied (three 21 MB device copies
     // at the C1 batch against ~0.48 ms of kernels).  Same function; the fp32 summation order of those layers follows the halved M.
     // Not with a vector conditioning (label_emb(y) differs per row), taps, LayerNorm fold, hypernetworks, arena reuse or batch slices.
-    const bool pairs = e->cfg_pairs && c.adm_in_channels == 0 && Bn % 2 == 0 && Bn >= 2 && !e->trace && !e->ln_fold && !r.reuse() &&
+    const bool pairs = e->cfg_pairs && !e->residual_fp32 && c.adm_in_channels == 0 && Bn % 2 == 0 && Bn >= 2 && !e->trace && !e->ln_fold && !r.reuse() &&
                        e->hypernets.empty() && (r.Btot == 0 || r.Btot == Bn);
     const int Bh = Bn / 2;
     bool shared = pairs;                                     // cur.p: rows [0, Bh) computed, buffer sized for Bn rows
@@ -1046,7 +1068,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
             }
             switch (Lr.kind) {
                 case UNetLayer::CONV_IN: {
-                    half_t* o = r.H((size_t)Bn * cur.H * cur.W * Lr.conv.n_pad);
+                    half_t* o = r.S((size_t)Bn * cur.H * cur.W * Lr.conv.n_pad);
                     if (shared) {
                         ConvArgs a;
                         a.a0 = xin; a.c0 = Lr.conv.cin_pad; a.B = Bh; a.Hi = cur.H; a.Wi = cur.W; a.Ho = cur.H; a.Wo = cur.W;
@@ -1058,6 +1080,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                     ConvArgs a;
                     a.a0 = xin; a.c0 = Lr.conv.cin_pad; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = cur.H; a.Wo = cur.W;
                     a.pad = 1; a.out = o; a.ldo = Lr.conv.n_pad;
+                    a.out_lo = r.lo(o, (size_t)Bn * cur.H * cur.W * Lr.conv.n_pad);
                     TRY(run_conv(r, Lr.conv, a));
                     cur = Act{o, Lr.conv.cout, cur.H, cur.W};
                     break;
@@ -1067,12 +1090,12 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                     if (skip && first) {
                         SDMI_REQUIRE(Lr.c0 == cur.C && Lr.c1 == skip->C, "skip concat channel mismatch");
                         SDMI_REQUIRE(cur.H == skip->H && cur.W == skip->W, "skip connection spatial mismatch");
-                        TRY(run_res(r, Lr.res, cur.p, skip->p, cur.C, skip->C, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o));
+                        TRY(run_res(r, Lr.res, cur.p, skip->p, cur.C, skip->C, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, nullptr, true));
                     } else if (shared) {
                         half_t* full = r.H((size_t)Bn * cur.H * cur.W * Lr.res.cout);
                         TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bh, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, full));
                     } else {
-                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o));
+                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, nullptr, true));
                     }
                     cur = Act{o, Lr.res.cout, cur.H, cur.W};
                     break;
@@ -1087,20 +1110,22 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                 }
                 case UNetLayer::DOWN: {
                     const int Ho = (cur.H + 2 - 3) / 2 + 1, Wo = (cur.W + 2 - 3) / 2 + 1;
-                    half_t* o = r.H((size_t)Bn * Ho * Wo * cur.C);
+                    half_t* o = r.S((size_t)Bn * Ho * Wo * cur.C);
                     ConvArgs a;
                     a.a0 = cur.p; a.c0 = cur.C; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = Ho; a.Wo = Wo;
                     a.stride = 2; a.pad = 1; a.out = o; a.ldo = cur.C;
+                    a.out_lo = r.lo(o, (size_t)Bn * Ho * Wo * cur.C);
                     TRY(run_conv(r, Lr.conv, a));
                     cur = Act{o, cur.C, Ho, Wo};
                     break;
                 }
                 case UNetLayer::UP: {
                     const int Ho = cur.H * 2, Wo = cur.W * 2;
-                    half_t* o = r.H((size_t)Bn * Ho * Wo * cur.C);
+                    half_t* o = r.S((size_t)Bn * Ho * Wo * cur.C);
                     ConvArgs a;
                     a.a0 = cur.p; a.c0 = cur.C; a.B = Bn; a.Hi = cur.H; a.Wi = cur.W; a.Ho = Ho; a.Wo = Wo;
                     a.up = 1; a.pad = 1; a.out = o; a.ldo = cur.C;
+                    a.out_lo = r.lo(o, (size_t)Bn * Ho * Wo * cur.C);
                     TRY(run_conv(r, Lr.conv, a));
                     cur = Act{o, cur.C, Ho, Wo};
                     break;
@@ -1129,7 +1154,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     // ---- out: GroupNorm32 + SiLU + conv 3x3 -> fp32 NCHW ---------------------------------------------------
     const size_t M = (size_t)Bn * cur.H * cur.W;
     half_t* tn = r.H(M * cur.C);
-    TRY(run_gn(r, u.out_norm, cur.p, nullptr, cur.C, 0, Bn, cur.H * cur.W, 1e-5f, true, tn));
+    TRY(run_gn(r, u.out_norm, cur.p, nullptr, cur.C, 0, Bn, cur.H * cur.W, 1e-5f, true, tn, r.lo(cur.p, M * cur.C)));
     float* eps = r.F((size_t)Bn * c.out_channels * cur.H * cur.W);
     {
         ConvArgs a;

@@ -213,6 +213,11 @@ struct sdmi_engine {
     int fuse_rows = [] { const char* e = getenv("SDMI_FUSE_ROWS"); return e ? atoi(e) : 2; }();
     std::vector<char*> ctx_xa;                // per context slot: packed Kq / VWo stream [Bn][heads] (null: not built for this slot)
     int ctx_xa_mode = 0;                      // value of (fuse_rows & 1) the context cache was allocated under
+    // Accuracy mode (option "residual_fp32", off by default — the engine's counterpart of the reference's --no-half / upcast options,
+    // modules/devices.py:284-295, modules/sd_hijack_optimizations.py:232-233): the UNet's carried stream — conv_in / ResBlock /
+    // transformer-block / proj_out / down- and upsample outputs and the skip_connection 1x1 — is kept as (hi, lo) fp16 pairs
+    // (GemmP::out_lo), i.e. with ~22 bits, so the residual sums are no longer rounded to fp16 once per block.  DESIGN.md section 7.
+    bool residual_fp32 = false;
     long weights_epoch = 0;                   // bumped by every in-place weight / vector update: folded copies older than this are stale
     bool cfg_pairs = false;                   // rows [Bn/2, Bn) repeat the latent and timestep of rows [0, Bn/2): the layers in front of the first cross-attention run once (option "cfg_pairs")
     bool uniform_t = false;                   // every row of the call sits at the same timestep: the embedding path runs for one row (option "uniform_t")

@@ -22,8 +22,12 @@ namespace sdmi {
 
 static constexpr int GN_MAX_C = 4096;
 
+// HILO (engine option "residual_fp32"): the input is the carried stream kept as a (hi, lo) pair of fp16 tensors — x = hi + lo with
+// hi = fp16(x), lo = fp16(x - hi), ~22 bits of x — and the statistics / normalisation are taken from the sum.  l0 / l1: the lo parts.
+template <bool HILO = false>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const half_t* x1, int c0, int c1, int HW,
-                                                       int groups, int rows_per_chunk, float* partial) {
+                                                       int groups, int rows_per_chunk, float* partial, const half_t* l0 = nullptr,
+                                                       const half_t* l1 = nullptr) {
     __shared__ float s_sum[GN_MAX_C];
     __shared__ float s_sq[GN_MAX_C];
     const int C = c0 + c1, VP = C / 8;
@@ -41,6 +45,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const h
             int cc, ld;
             if (c < c0) { src = x0; cc = c; ld = c0; } else { src = x1; cc = c - c0; ld = c1; }
             const half_t* base = src + (long)b * HW * ld + cc;
+            [[maybe_unused]] const half_t* lbase = HILO ? (c < c0 ? l0 : l1) + (long)b * HW * ld + cc : nullptr;
             float a[8], q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a[e] = 0.f; q[e] = 0.f; }
@@ -51,14 +56,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const h
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(base + (long)(pix + u * R) * ld);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u) {
+                    h8 lv = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if constexpr (HILO) lv = *reinterpret_cast<const h8*>(lbase + (long)(pix + u * R) * ld);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; a[e] += f; q[e] = fmaf(f, f, q[e]); }
+                    for (int e = 0; e < 8; ++e) { const float f = HILO ? (float)v[u][e] + (float)lv[e] : (float)v[u][e]; a[e] += f; q[e] = fmaf(f, f, q[e]); }
+                }
             }
             for (; pix < p_end; pix += R) {
                 const h8 v = *reinterpret_cast<const h8*>(base + (long)pix * ld);
+                h8 lv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (HILO) lv = *reinterpret_cast<const h8*>(lbase + (long)pix * ld);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; a[e] += f; q[e] = fmaf(f, f, q[e]); }
+                for (int e = 0; e < 8; ++e) { const float f = HILO ? (float)v[e] + (float)lv[e] : (float)v[e]; a[e] += f; q[e] = fmaf(f, f, q[e]); }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s_sum[tr * C + c + e] = a[e]; s_sq[tr * C + c + e] = q[e]; }   // one writer per slot
@@ -83,10 +93,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const h
     }
 }
 
+template <bool HILO = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const half_t* x1, int c0, int c1, int HW,
                                                        int groups, int nchunk, const float* partial,
                                                        const float* gamma, const float* beta, half_t* out, float eps,
-                                                       int silu) {
+                                                       int silu, const half_t* l0 = nullptr, const half_t* l1 = nullptr) {
     __shared__ float s_scale[GN_MAX_C];
     __shared__ float s_shift[GN_MAX_C];
     __shared__ float s_mean[64], s_rstd[64];
@@ -132,9 +143,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
     if (cv_u[1] >= VP) { cv_u[1] -= VP; ++pix_u[1]; }
     const half_t* x0b = x0 + (long)b * HW * c0;
     const half_t* x1b = x1 ? x1 + (long)b * HW * c1 : nullptr;
+    [[maybe_unused]] const half_t* l0b = HILO ? l0 + (long)b * HW * c0 : nullptr;
+    [[maybe_unused]] const half_t* l1b = (HILO && l1) ? l1 + (long)b * HW * c1 : nullptr;
     half_t* outb = out + (long)b * HW * C;
     while (pix_u[0] < HW) {
         h8 v[2];
+        [[maybe_unused]] h8 lv[2];
         int cs[2];
         bool ok[2];
 #pragma unroll
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
             unsigned cc, ld;
             if (c < c0) { src = x0b; cc = (unsigned)c; ld = (unsigned)c0; } else { src = x1b; cc = (unsigned)(c - c0); ld = (unsigned)c1; }
             v[u] = *reinterpret_cast<const h8*>(src + (__umul24(pix, ld) + cc));
+            if constexpr (HILO) lv[u] = *reinterpret_cast<const h8*>((c < c0 ? l0b : l1b) + (__umul24(pix, ld) + cc));
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float sc = e < 4 ? sa[e] : sb[e - 4], sh = e < 4 ? ha[e] : hb[e - 4];
-                float y = fmaf((float)v[u][e], sc, sh);
+                float y = fmaf(HILO ? (float)v[u][e] + (float)lv[u][e] : (float)v[u][e], sc, sh);
                 if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
                 o[e] = (half_t)y;
             }
@@ -260,8 +275,11 @@ static inline int gn_chunks(int B, int HW) {
 int64_t groupnorm_ws_bytes(int B, int HW, int groups) { return (int64_t)B * gn_chunks(B, HW) * groups * 2 * sizeof(float); }
 
 int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
-                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int pre_nchunk) {
+                     half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int pre_nchunk,
+                     const half_t* x0_lo, const half_t* x1_lo) {
     const int C = c0 + c1;
+    const bool hilo = x0_lo != nullptr;
+    SDMI_REQUIRE(!hilo || (pre_nchunk <= 0 && (x1 == nullptr) == (x1_lo == nullptr)), "GroupNorm (hi, lo) input: both sources, own statistics pass");
     SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
     SDMI_REQUIRE((long)HW * C < (1L << 31) && HW < (1 << 24), "GroupNorm: HW * C must stay below 2^31 elements per image (32-bit offsets)");
@@ -271,7 +289,7 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
         const long nv = (long)HW * (cpg / 8);
         // (<= 12 vectors per thread: the 24-vector instantiation needs all 256 VGPRs — one workgroup per SIMD — and ran the 32x32-latent
         // C = 1280 norm at 77 us against 33 us for the two-pass pair: GPU run 2 of round 3)
-        if (pre_nchunk <= 0 && g_gn_small && cpg % 8 == 0 && nv <= 12 * 256) {
+        if (pre_nchunk <= 0 && g_gn_small && cpg % 8 == 0 && nv <= 12 * 256 && !hilo) {
             snprintf(pname, sizeof pname, "groupnorm_silu_fused B%d HW%d C%d", B, HW, C);
             ProfScope ps(pname, 0.0, 2.0 * B * (double)HW * C * 2.0, s);                            // read once + write once
             const dim3 grid(groups, B);
@@ -288,15 +306,20 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     snprintf(pname, sizeof pname, pre_nchunk > 0 ? "groupnorm_silu_apply B%d HW%d C%d" : "groupnorm_silu B%d HW%d C%d", B, HW, C);
     ProfScope ps(pname, 0.0, (pre_nchunk > 0 ? 2.0 : 3.0) * B * (double)HW * C * 2.0, s);      // read (twice) + write once
     if (pre_nchunk <= 0) {
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws);
+        if (hilo) hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws, x0_lo, x1_lo);
+        else hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(nchunk, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, rows, ws, nullptr, nullptr);
         SDMI_CHECK_HIP(hipGetLastError());
     }
     const long nvec = (long)HW * (C / 8);
     // >= 16 vectors per thread so the per-workgroup prologue (partials -> mean/rstd -> per-channel scale/shift in LDS) is
     // amortised, while keeping ~4 workgroups per CU in flight
     int blocks = (int)std::max<long>(1, std::min<long>(nvec / (256 * 16), std::max(1, 1024 / B)));
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
-                       beta, out, eps, silu ? 1 : 0);
+    if (hilo)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
+                           beta, out, eps, silu ? 1 : 0, x0_lo, x1_lo);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
+                           beta, out, eps, silu ? 1 : 0, nullptr, nullptr);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -306,15 +329,17 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
 // works on RPW rows at once (all of their loads issued before the first reduction) so that a CU keeps enough bytes in
 // flight to cover HBM latency: with one 640-byte row per wave the kernel was latency-, not bandwidth-bound.
 // ---------------------------------------------------------------------------------------------------------------
-template <int K, int RPW>
+#define LN_VAL(r, k, e) (HILO ? (float)v[r][k][e] + (float)vl[HILO ? (r) : 0][HILO ? (k) : 0][e] : (float)v[r][k][e])
+template <int K, int RPW, bool HILO = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const float* gamma, const float* beta,
-                                                        half_t* out, long rows, int C, float eps) {
+                                                        half_t* out, long rows, int C, float eps, const half_t* xlo = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row0 = ((long)blockIdx.x * 4 + wave) * RPW;
     if (row0 >= rows) return;
     const int VP = C / 8;
     const float inv_c = 1.0f / (float)C;
     h8 v[RPW][K];
+    [[maybe_unused]] h8 vl[HILO ? RPW : 1][HILO ? K : 1];    // HILO: the lo parts of a (hi, lo) stream (gn_stats_kernel's note)
     float sum[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -325,6 +350,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const f
             const int cv = lane + k * 64;
             h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             v[r][k] = cv < VP ? *reinterpret_cast<const h8*>(src + cv * 8) : z;
+            if constexpr (HILO) vl[r][k] = cv < VP ? *reinterpret_cast<const h8*>(xlo + row * C + cv * 8) : z;
         }
     }
 #pragma unroll
@@ -333,7 +359,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const f
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a += (float)v[r][k][e];      // padding lanes hold zeros
+            for (int e = 0; e < 8; ++e) a += LN_VAL(r, k, e);      // padding lanes hold zeros
         sum[r] = a;
     }
     for (int off = 32; off > 0; off >>= 1)
@@ -349,7 +375,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const f
             const int cv = lane + k * 64;
             if (cv < VP) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = (float)v[r][k][e] - mean[r]; q = fmaf(d, d, q); }
+                for (int e = 0; e < 8; ++e) { const float d = LN_VAL(r, k, e) - mean[r]; q = fmaf(d, d, q); }
             }
         }
         sq[r] = q;
@@ -371,13 +397,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, const f
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float g = e < 4 ? g0[e] : g1[e - 4], bb = e < 4 ? b0[e] : b1[e - 4];
-                    o[e] = (half_t)(((float)v[r][k][e] - mean[r]) * rstd * g + bb);
+                    o[e] = (half_t)((LN_VAL(r, k, e) - mean[r]) * rstd * g + bb);
                 }
                 *reinterpret_cast<h8*>(out + (row0 + r) * C + cv * 8) = o;
             }
         }
     }
 }
+
+#undef LN_VAL
 
 // Row statistics only (LayerNorm folded into the consuming GEMMs, GemmP::ln_stats): the same two-pass arithmetic as
 // layernorm_kernel — mean, then the centred sum of squares, both from the fp16 values the GEMM will read — but nothing is written
@@ -494,15 +522,20 @@ int launch_ln_fold_weights(const half_t* w, const float* gamma, const float* bet
 }
 
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* out, int64_t rows, int C,
-                     float eps, hipStream_t s) {
+                     float eps, hipStream_t s, const half_t* x_lo) {
     SDMI_REQUIRE(C % 8 == 0 && C <= 3072, "LayerNorm: C % 8 == 0 and C <= 3072");
+    SDMI_REQUIRE(x_lo == nullptr || C <= 2048, "LayerNorm (hi, lo) input: C <= 2048");
     char pname[48];
     snprintf(pname, sizeof pname, "layernorm rows%ld C%d", (long)rows, C);
     ProfScope ps(pname, 0.0, 2.0 * (double)rows * C * 2.0, s);
     const int K = cdiv(C / 8, 64);
-#define SDMI_LN(KK, RR)                                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<KK, RR>), dim3(cdiv(rows, 4 * RR)), dim3(256), 0, s, x, gamma, beta, out,     \
-                       (long)rows, C, eps)
+#define SDMI_LN(KK, RR)                                                                                                        \
+    do {                                                                                                                       \
+        if (x_lo) hipLaunchKernelGGL((layernorm_kernel<KK, (KK <= 2 ? 1 : RR), true>), dim3(cdiv(rows, 4 * (KK <= 2 ? 1 : RR))), dim3(256), 0, s, x, gamma, \
+                                     beta, out, (long)rows, C, eps, x_lo);                                                     \
+        else hipLaunchKernelGGL((layernorm_kernel<KK, RR, false>), dim3(cdiv(rows, 4 * RR)), dim3(256), 0, s, x, gamma, beta, out, (long)rows, C, \
+                                eps, nullptr);                                                                                 \
+    } while (0)
     if (K == 1) SDMI_LN(1, 4);
     else if (K == 2) SDMI_LN(2, 2);
     else if (K == 3) SDMI_LN(3, 1);

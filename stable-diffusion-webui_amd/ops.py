@@ -171,6 +171,56 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
+def rowchain_ff_pack(w1: torch.Tensor, b1, w2: torch.Tensor) -> torch.Tensor:
+    """Packed operand stream of the fused feed-forward chain (csrc/rowchain.hip): w1 [2*hidden, C] = ff.net.0.proj.weight (value rows,
+    then gate rows), b1 [2*hidden] or None, w2 [C, hidden] = ff.net.2.weight."""
+    _lib.require_device()
+    hidden, c = w2.shape[1], w2.shape[0]
+    w1, w2 = w1.half().contiguous(), w2.half().contiguous()
+    b1 = b1.float().contiguous() if b1 is not None else None
+    packs = torch.empty(int(lib.sdmi_rowchain_ff_pack_bytes(c, hidden)), dtype=torch.uint8, device=w1.device)
+    check(lib.sdmi_rowchain_ff_pack(ptr(w1), ptr(b1) if b1 is not None else None, ptr(w2), ptr(packs), c, hidden, stream_ptr()),
+          "sdmi_rowchain_ff_pack")
+    return packs
+
+
+def rowchain_ff(x: torch.Tensor, gamma, beta, packs: torch.Tensor, b2, hidden: int, eps: float = 1e-5) -> torch.Tensor:
+    """x + ff(LayerNorm(x)) of a BasicTransformerBlock (GEGLU feed-forward) as one launch; x [rows, C] fp16, rows % 128 == 0."""
+    _lib.require_device()
+    c = x.shape[-1]
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    b2 = b2.float().contiguous() if b2 is not None else None
+    check(lib.sdmi_rowchain_ff(ptr(x), ptr(out), ptr(gamma.float().contiguous()), ptr(beta.float().contiguous()), ptr(packs),
+                               ptr(b2) if b2 is not None else None, x.numel() // c, c, hidden, float(eps), stream_ptr()), "sdmi_rowchain_ff")
+    return out
+
+
+def rowchain_xattn_pack(k: torch.Tensor, vt: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, heads: int, L: int, scale: float) -> torch.Tensor:
+    """Per-image, per-head folded key / value matrices of the fused cross-attention chain: k [B*L, C] = to_k(context), vt [B, C, Lpad] =
+    to_v(context) transposed, wq / wo [C, C] = attn2.to_q / to_out[0] weights."""
+    _lib.require_device()
+    b, c, lpad = vt.shape
+    packs = torch.empty(int(lib.sdmi_rowchain_xattn_pack_bytes(c, b, heads)), dtype=torch.uint8, device=k.device)
+    check(lib.sdmi_rowchain_xattn_pack(ptr(k.half().contiguous()), ptr(vt.half().contiguous()), ptr(wq.half().contiguous()),
+                                       ptr(wo.half().contiguous()), ptr(packs), c, b, L, lpad, heads, float(scale), stream_ptr()),
+          "sdmi_rowchain_xattn_pack")
+    return packs
+
+
+def rowchain_xattn(x: torch.Tensor, gamma, beta, packs: torch.Tensor, bo, rows_per_image: int, heads: int, eps: float = 1e-5) -> torch.Tensor:
+    """x + attn2(LayerNorm(x), context) of a BasicTransformerBlock as one launch; x [B*rows_per_image, C] fp16."""
+    _lib.require_device()
+    c = x.shape[-1]
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    bo = bo.float().contiguous() if bo is not None else None
+    check(lib.sdmi_rowchain_xattn(ptr(x), ptr(out), ptr(gamma.float().contiguous()), ptr(beta.float().contiguous()), ptr(packs),
+                                  ptr(bo) if bo is not None else None, x.numel() // c, rows_per_image, c, heads, float(eps), stream_ptr()),
+          "sdmi_rowchain_xattn")
+    return out
+
+
 def philox_randn(shape, seed: int, offset: int, device) -> torch.Tensor:
     """One draw of rng_philox.Generator(seed) at ``offset`` (modules/rng_philox.py:84-102), generated on the GPU."""
     _lib.require_device()

@@ -631,6 +631,10 @@ def _process_images_inner(p: StableDiffusionProcessing) -> Processed:
     for m in (p.sd_model, getattr(p, "refiner_sd_model", None), getattr(p, "hr_sd_model", None)):
         if m is not None:                                            # :895 model_hijack.apply_circular(p.tiling): every padded conv
             m.engine.set_option("tiling", 1 if p.tiling else 0)      # of the UNet and the VAE wraps around (sd_hijack.py:311-318)
+            # --no-half (modules/cmd_args.py; the reference then runs the model in fp32) / the engine's own accuracy switch: the UNet's
+            # residual stream is carried with ~22 bits instead of fp16 (engine option "residual_fp32")
+            if hasattr(m, "set_accuracy_mode"):
+                m.set_accuracy_mode(bool(shared.cmd_opts.no_half or getattr(shared.opts, "sdmi_accuracy_mode", False)))
     sd_models.apply_alpha_schedule_override(p.sd_model, p)           # :930
     p.init(None, p.all_seeds, None)
     images, latents, device_u8 = [], [], []

@@ -155,6 +155,15 @@ class SdModel:
         self.engine.set_option("vae_range_extend", 1 if on else 0)
         self.vae_range_extended = bool(on)
 
+    def set_accuracy_mode(self, on: bool):
+        """The engine's counterpart of the reference's --no-half / upcast switches (modules/devices.py:284-295 keeps GroupNorm in fp32
+        even on the GPU path; --no-half runs the whole model in fp32): the UNet's carried residual stream as (hi, lo) fp16 pairs —
+        one CFG forward 1.5e-3 -> 1.0e-3 from the fp32 oracle at the C1 shape for a measured +x % of its time (profiles/r05_parity.json)."""
+        on = bool(on)
+        if on != getattr(self, "accuracy_mode", False):
+            self.engine.set_option("residual_fp32", 1 if on else 0)
+            self.accuracy_mode = on
+
     def unet_checkpoint_tensor(self, engine_key: str) -> torch.Tensor:
         """The unmodified checkpoint weight of a UNet layer (extensions-builtin/Lora/networks.py:423-432 keeps the same thing
         as ``network_weights_backup``)."""

@@ -65,6 +65,7 @@ class Options:
     auto_vae_precision_bfloat16: bool = False      # :181  ("Automatically convert VAE to bfloat16")
     auto_vae_precision: bool = True                # :182  ("Automatically revert VAE to 32-bit floats")
     disable_mmap_load_safetensors: bool = False    # :285
+    sdmi_accuracy_mode: bool = False               # (engine option, not a webui setting) carry the UNet's residual stream with ~22 bits: sd_models.set_accuracy_mode
 
 
 opts = Options()

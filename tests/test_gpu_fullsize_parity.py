@@ -13,7 +13,7 @@ bench.py measures outside the headline configuration (tests/test_gpu_c1_parity.p
 
 The fp32 oracle outputs are committed fixtures (tests/golden/fullsize_*.npz, generated in the authoring container by
 tests/golden/make_fullsize_golden.py — minutes of CPU per leg); inputs are re-derived here from the same seeds.  Measured values go to
-gpurun_out/r04_parity_fullsize.json (copied to profiles/).  Stated tolerances (fp16 storage, fp32 accumulation — the same distance the
+gpurun_out/r05_parity_fullsize.json (copied to profiles/).  Stated tolerances (fp16 storage, fp32 accumulation — the same distance the
 C1 shapes have): UNet forward <= 2.5e-3, attention <= 5e-4, VAE decode <= 1.5e-3 (range-extended <= 5e-3: its
 residual stream carries 6 fewer mantissa-free exponent steps), VAE encode moments <= 2e-3, 50-step final latent <= 8e-3.
 """
@@ -30,7 +30,7 @@ from helpers import rel_l2, usable_cpus
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT_PATH = os.path.join(ROOT, "gpurun_out", "r04_parity_fullsize.json")
+REPORT_PATH = os.path.join(ROOT, "gpurun_out", "r05_parity_fullsize.json")
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_fullsize_golden as mfg  # noqa: E402  (input definitions: SPEC, seeded, xl_decoder_state_dict)
 

@@ -712,3 +712,58 @@ def test_attention_experiment_variants_match_production_kernel(dev):
             # same operation counts in the compiled loops (packed vs scalar forms of the same fp32 ops): the bits are expected equal
             assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (heads, n, m, variant)
 
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fused row-local chains of the transformer block (csrc/rowchain.hip)
+# ------------------------------------------------------------------------------------------------------------
+def test_rowchain_feed_forward_vs_fp32(dev):
+    """norm3 -> ff.net.0.proj (GEGLU) -> ff.net.2 -> + x as one launch, at the C1 level-0 width, against torch fp32 on the fp16-rounded
+    operands (exact-erf GELU, as ldm's GEGLU)."""
+    ops = sub("ops")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    C_, hidden, rows = 320, 1280, 4096
+    x = torch.randn(rows, C_, generator=g).half()
+    gam, bet = 1 + 0.1 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
+    w1 = (torch.randn(2 * hidden, C_, generator=g) / C_ ** 0.5).half()
+    b1 = 0.1 * torch.randn(2 * hidden, generator=g)
+    w2 = (torch.randn(C_, hidden, generator=g) / hidden ** 0.5).half()
+    b2 = 0.1 * torch.randn(C_, generator=g)
+    packs = ops.rowchain_ff_pack(w1.to(dev), b1.to(dev), w2.to(dev))
+    out = ops.rowchain_ff(x.to(dev), gam.to(dev), bet.to(dev), packs, b2.to(dev), hidden).float().cpu()
+    xf = x.float()
+    n = F.layer_norm(xf, (C_,), gam, bet, 1e-5)
+    hcat = F.linear(n, w1.float(), b1)
+    ref = xf + F.linear(hcat[:, :hidden] * F.gelu(hcat[:, hidden:]), w2.float(), b2)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 3.5e-4                          # measured 2.1e-4 (the fp16 rounding of the output)
+    assert rel_l2(out - xf, ref - xf) < 8e-4                  # measured 4.9e-4 on the branch alone (fp16 LayerNorm output and hidden tensor)
+
+
+@pytest.mark.parametrize("L", [77, 20])
+def test_rowchain_cross_attention_vs_fp32(dev, L):
+    """norm2 -> attn2 -> + x as one launch with to_q / to_out folded into the per-image key / value matrices, against torch fp32."""
+    ops = sub("ops")
+    g = torch.Generator(device="cpu").manual_seed(12 + L)
+    C_, B, H, D, rpi = 320, 3, 8, 40, 1024
+    Lpad = 128
+    x = torch.randn(B * rpi, C_, generator=g).half()
+    gam, bet = 1 + 0.1 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
+    k = torch.randn(B, L, C_, generator=g).half()
+    v = torch.randn(B, L, C_, generator=g).half()
+    vt = torch.zeros(B, C_, Lpad, dtype=torch.float16)
+    vt[:, :, :L] = v.transpose(1, 2)
+    wq = (torch.randn(C_, C_, generator=g) / C_ ** 0.5).half()
+    wo = (torch.randn(C_, C_, generator=g) / C_ ** 0.5).half()
+    bo = 0.1 * torch.randn(C_, generator=g)
+    packs = ops.rowchain_xattn_pack(k.reshape(B * L, C_).to(dev), vt.to(dev), wq.to(dev), wo.to(dev), H, L, D ** -0.5)
+    out = ops.rowchain_xattn(x.to(dev), gam.to(dev), bet.to(dev), packs, bo.to(dev), rpi, H).float().cpu()
+    xf = x.float()
+    q = F.linear(F.layer_norm(xf, (C_,), gam, bet, 1e-5), wq.float()).view(B, rpi, H, D).transpose(1, 2)
+    kk = k.float().view(B, L, H, D).transpose(1, 2)
+    vv = v.float().view(B, L, H, D).transpose(1, 2)
+    a = torch.softmax(q @ kk.transpose(-1, -2) * D ** -0.5, -1) @ vv
+    ref = xf + F.linear(a.transpose(1, 2).reshape(B * rpi, C_), wo.float(), bo)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out, ref) < 3.5e-4                          # measured 2.2e-4
+    assert rel_l2(out - xf, ref - xf) < 1.6e-3                # measured 1.1e-3 on the branch alone (fp16 Kq, probabilities, VWo)
