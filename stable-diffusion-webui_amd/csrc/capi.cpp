@@ -80,45 +80,55 @@ int sdmi_attention(const void* q, const void* k, const void* v, void* out, int B
     API_GUARD_END
 }
 
-// single-head attention over a wide head (the VAE AttnBlock: d = C = 512) with materialised scores, one image at a time so that
-// the workspace holds V^T for the batch plus ONE image's fp32 scores and fp16 probabilities — the launches of engine.cpp run_vae_attn
+// single-head attention over a wide head (the VAE AttnBlock: d = C = 512) with materialised scores, one image and one block of
+// kWideRows query rows at a time, so the workspace — V^T for the batch plus ONE block's fp32 scores and fp16 probabilities — stays
+// bounded (6 * 4096 * M bytes: 100 MB at a 1024^2 decode, 400 MB at 2048^2; the full N x M form was 1.6 GB / 25 GB) like
+// the memory-bounded forwards it replaces (modules/sd_hijack_optimizations.py:390-424, 613-676) — the launches of engine.cpp run_vae_attn
+static constexpr int kWideRows = 4096;
 int64_t sdmi_attention_wide_workspace_bytes(int B, int N, int M, int D) {
+    if (B <= 0 || N <= 0 || M <= 0 || D <= 0) return 0;
     const int64_t mpad = (M + 63) / 64 * 64;
-    return (int64_t)B * D * mpad * (int64_t)sizeof(half_t) + (int64_t)N * mpad * (int64_t)(sizeof(float) + sizeof(half_t));
+    const int64_t rows = N < kWideRows ? N : kWideRows;
+    return (int64_t)B * D * mpad * (int64_t)sizeof(half_t) + rows * mpad * (int64_t)(sizeof(float) + sizeof(half_t));
 }
 
 int sdmi_attention_wide(const void* q, const void* k, const void* v, void* out, int B, int N, int M, int D, int ldq, int ldk,
                         int ldv, int ldo, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
     API_GUARD_BEGIN
+    SDMI_REQUIRE(q && k && v && out && B > 0 && N > 0 && M > 0, "sdmi_attention_wide: null pointer or empty problem");
     SDMI_REQUIRE(D > 0 && D % 64 == 0 && D <= 1024, "sdmi_attention_wide: D must be a multiple of 64, at most 1024");
     SDMI_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "sdmi_attention_wide: row strides must be multiples of 8 elements");
+    SDMI_REQUIRE(ldq >= D && ldk >= D && ldv >= D && ldo >= D, "sdmi_attention_wide: row strides must be at least D");
     SDMI_REQUIRE(workspace && workspace_bytes >= sdmi_attention_wide_workspace_bytes(B, N, M, D), "attention workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int mpad = (M + 63) / 64 * 64;
+    const int rows_max = N < kWideRows ? N : kWideRows;
     half_t* vt = (half_t*)workspace;
     float* S = (float*)(vt + (size_t)B * D * mpad);
-    half_t* P = (half_t*)(S + (size_t)N * mpad);
+    half_t* P = (half_t*)(S + (size_t)rows_max * mpad);
     if (launch_transpose_v((const half_t*)v, vt, B, 1, M, D, ldv, mpad, s)) return 1;
-    for (int b = 0; b < B; ++b) {
-        GemmP p{};
-        p.a0 = (const half_t*)q + (size_t)b * N * ldq; p.c0 = D; p.cin = D; p.lda0 = ldq;
-        p.w = (const half_t*)k + (size_t)b * M * ldk; p.ldw = ldk;
-        p.out = S;
-        p.Hi = N; p.Wi = 1; p.Ho = N; p.Wo = 1; p.taps = 1; p.stride = 1;
-        p.M = N; p.N = mpad; p.n_valid = M; p.K = D; p.ldo = mpad; p.rows_per_batch = N; p.n_real = mpad;
-        p.flags = EP_OUT_F32;
-        p.alpha = scale;
-        if (launch_gemm(p, 1, false, true, s)) return 1;
-        if (launch_softmax_rows(S, P, N, M, mpad, mpad, s)) return 1;
-        GemmP g{};
-        g.a0 = P; g.c0 = mpad; g.cin = mpad; g.lda0 = mpad;
-        g.w = vt + (size_t)b * D * mpad; g.ldw = mpad;
-        g.out = (half_t*)out + (size_t)b * N * ldo;
-        g.Hi = N; g.Wi = 1; g.Ho = N; g.Wo = 1; g.taps = 1; g.stride = 1;
-        g.M = N; g.N = D; g.K = mpad; g.ldo = ldo; g.rows_per_batch = N; g.n_real = D;
-        g.alpha = 1.f;
-        if (launch_gemm(g, 1, false, true, s)) return 1;
-    }
+    for (int b = 0; b < B; ++b)
+        for (int r0 = 0; r0 < N; r0 += kWideRows) {
+            const int rows = N - r0 < kWideRows ? N - r0 : kWideRows;
+            GemmP p{};
+            p.a0 = (const half_t*)q + ((size_t)b * N + r0) * ldq; p.c0 = D; p.cin = D; p.lda0 = ldq;
+            p.w = (const half_t*)k + (size_t)b * M * ldk; p.ldw = ldk;
+            p.out = S;
+            p.Hi = rows; p.Wi = 1; p.Ho = rows; p.Wo = 1; p.taps = 1; p.stride = 1;
+            p.M = rows; p.N = mpad; p.n_valid = M; p.K = D; p.ldo = mpad; p.rows_per_batch = rows; p.n_real = mpad;
+            p.flags = EP_OUT_F32;
+            p.alpha = scale;
+            if (launch_gemm(p, 1, false, true, s)) return 1;
+            if (launch_softmax_rows(S, P, rows, M, mpad, mpad, s)) return 1;
+            GemmP g{};
+            g.a0 = P; g.c0 = mpad; g.cin = mpad; g.lda0 = mpad;
+            g.w = vt + (size_t)b * D * mpad; g.ldw = mpad;
+            g.out = (half_t*)out + ((size_t)b * N + r0) * ldo;
+            g.Hi = rows; g.Wi = 1; g.Ho = rows; g.Wo = 1; g.taps = 1; g.stride = 1;
+            g.M = rows; g.N = D; g.K = mpad; g.ldo = ldo; g.rows_per_batch = rows; g.n_real = D;
+            g.alpha = 1.f;
+            if (launch_gemm(g, 1, false, true, s)) return 1;
+        }
     return 0;
     API_GUARD_END
 }

@@ -1195,6 +1195,32 @@ int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, 
                  int Bn, int h, int w, int L, hipStream_t s) {
     SDMI_REQUIRE(e->unet.ready, "unet not finalized");
     SDMI_CHECK_HIP(hipSetDevice(e->device));
+    // Options "cfg_pairs" / "uniform_t" are promises of the CALLER about x and t (rows [Bn/2, Bn) repeat rows [0, Bn/2); one timestep for
+    // all rows) that the forward does not re-derive: a caller that sets them through sdmi_engine_set_option and then passes other data
+    // gets the second half silently overwritten.  SDMI_CHECK_PROMISES=1 (tests, tools/gpu A/B scripts) verifies them on the host — a
+    // synchronising copy, so it is a debugging switch, not a default.
+    const char* cpv = getenv("SDMI_CHECK_PROMISES");
+    const bool check_promises = cpv && atoi(cpv) != 0;
+    if (check_promises && (e->cfg_pairs || e->uniform_t)) {
+        const size_t elt = io_dtype == SDMI_F16 ? 2 : 4;
+        SDMI_CHECK_HIP(hipStreamSynchronize(s));
+        if (e->uniform_t && Bn > 1) {
+            std::vector<char> th((size_t)Bn * elt);
+            SDMI_CHECK_HIP(hipMemcpy(th.data(), t, th.size(), hipMemcpyDeviceToHost));
+            for (int b = 1; b < Bn; ++b)
+                SDMI_REQUIRE(memcmp(th.data(), th.data() + (size_t)b * elt, elt) == 0, "option uniform_t is set but the timesteps of the call differ");
+        }
+        if (e->cfg_pairs && Bn % 2 == 0 && Bn >= 2) {
+            const size_t half_bytes = (size_t)(Bn / 2) * e->unet.cfg.in_channels * h * w * elt;
+            std::vector<char> xh(2 * half_bytes), th((size_t)Bn * elt);
+            SDMI_CHECK_HIP(hipMemcpy(xh.data(), x, xh.size(), hipMemcpyDeviceToHost));
+            SDMI_CHECK_HIP(hipMemcpy(th.data(), t, th.size(), hipMemcpyDeviceToHost));
+            SDMI_REQUIRE(memcmp(xh.data(), xh.data() + half_bytes, half_bytes) == 0,
+                         "option cfg_pairs is set but rows [Bn/2, Bn) of x do not repeat rows [0, Bn/2)");
+            SDMI_REQUIRE(memcmp(th.data(), th.data() + th.size() / 2, th.size() / 2) == 0,
+                         "option cfg_pairs is set but the timesteps of the two halves differ");
+        }
+    }
     if (ctx) TRY(unet_set_context(e, ctx, io_dtype, Bn, L, s));
     // Option "streams" = n > 1: the rows of a call are independent (own timestep, own context rows), so the batch is cut into n
     // equal slices that run the same launch sequence on n HIP streams out of n arenas.  The GPU then always has a second, independent

@@ -255,6 +255,13 @@ def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Op
         COLLECTIVES["job"] += 1
         if mine is None:
             mine = torch.zeros((0, int(hw[0]), int(hw[1]), 3), dtype=torch.uint8, device=dev)
+    elif mine is None:
+        #  this rank owns images but has none to send — an interrupted / skipped job left its device buffer short while
+        # images_to_host was off.  It must still enter the gather with a tensor of the job's image size, or the other ranks wait in
+        # dist.gather forever; the size is the job's own (hires target if there is one), known locally: no extra collective.
+        h = int(getattr(q, "hr_upscale_to_y", 0) or getattr(q, "height", 0))
+        w = int(getattr(q, "hr_upscale_to_x", 0) or getattr(q, "width", 0))
+        mine = torch.zeros((0, h, w, 3), dtype=torch.uint8, device=dev)
     allv = gather_to_rank0(mine, counts)
     if dist.get_rank() == 0:
         res.images = list(allv.cpu().numpy())

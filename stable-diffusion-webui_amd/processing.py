@@ -668,6 +668,8 @@ def _process_images_inner(p: StableDiffusionProcessing) -> Processed:
         device_u8.append(u8)
         overlays = getattr(p, "overlay_images", None)
         if not overlays and not getattr(p, "images_to_host", True):   # a non-zero rank of a sharded job: rank 0 gets them over RCCL
+            if p.keep_latents:                                       # (the latents stay available on this rank either way)
+                latents.append(samples)
             continue
         batch_u8 = list(u8.cpu().numpy())
         if overlays:                                                 # :1063-1068, 1086: paste the generated crop back, composite the unmasked original over it

@@ -62,6 +62,14 @@ def mi355x_attnblock_forward(self, x):
     h_ = self.norm(x)
     q, k, v = self.q(h_), self.k(h_), self.v(h_)
     b, c, h, w = q.shape
+    if q.dtype == torch.float32 or getattr(shared.opts, "upcast_attn", False):
+        #  a VAE running in fp32 — --no-half-vae, or the webui's automatic fp32 retry after a NaN decode
+        # (modules/processing.py:636-665) — must not get fp16 attention operands: the in-tree optimizers keep the module dtype or upcast
+        # (modules/sd_hijack_optimizations.py:232-233, 572-580).  torch's fp32 attention on these 4096 x 512 tokens instead.
+        qt, kt, vt = (t.reshape(b, c, h * w).transpose(1, 2).float() for t in (q, k, v))
+        out = torch.softmax(qt @ kt.transpose(1, 2) * (int(c) ** (-0.5)), dim=-1) @ vt
+        out = out.to(q.dtype).transpose(1, 2).reshape(b, c, h, w)
+        return x + self.proj_out(out)
     tokens = lambda t: t.reshape(b, c, h * w).transpose(1, 2).half().contiguous()
     out = ops.attention(tokens(q), tokens(k), tokens(v), heads=1, scale=int(c) ** (-0.5))
     out = out.to(q.dtype).transpose(1, 2).reshape(b, c, h, w)

@@ -12,8 +12,10 @@ the shipped extension script calls with the webui's OWN modules as arguments —
   B5  install_lora_hook     wraps ``networks.load_networks`` of extensions-builtin/Lora (called from ExtraNetworkLora.activate,
                             extra_networks_lora.py:18-45): the stock function keeps the text-encoder part and the bookkeeping, then the
                             UNet part of the same network files is merged on the GPU into the engine's packed weights.
-  B6  install_clip_hook     points ``FrozenCLIPEmbedderWithCustomWords.encode_with_transformers`` (modules/sd_hijack_clip.py:351-360)
-                            of the loaded model at the engine's CLIP tower; tokenisation, chunking, emphasis and textual inversion stay.
+  B6  install_clip_hook     points ``encode_with_transformers`` of every text-encoder wrapper of the loaded model — CLIP-L of SD 1.x
+                            (modules/sd_hijack_clip.py:351-360), OpenCLIP-H of SD 2.x (sd_hijack_open_clip.py:26-30), CLIP-L + OpenCLIP-bigG
+                            of SDXL (sd_hijack_clip.py:369-377, sd_hijack_open_clip.py:57-66) — at the engine's tower; tokenisation,
+                            chunking, emphasis and textual inversion stay.
 
 ``EngineModelView`` is what those see as "the model": the webui's LatentDiffusion object supplies the schedule and the flags, the
 active ``Mi355xUnet`` supplies the engine and the checkpoint weights (the LoRA "weights backup").
@@ -269,40 +271,93 @@ def install_lora_hook(webui_networks, webui_sd_models, webui_shared, sd_unet_mod
 
 
 # ---- B6 ---------------------------------------------------------------------------------------------------------------------------
+def _clip_embedders(sd_model):
+    """The webui's hijacked text-encoder wrappers of a loaded model (modules/sd_hijack.py:205-243): ``cond_stage_model`` itself for
+    SD 1.x / 2.x, every wrapped entry of ``conditioner.embedders`` for SDXL."""
+    csm = getattr(sd_model, "cond_stage_model", None)
+    if csm is None:
+        return []
+    embedders = getattr(csm, "embedders", None)
+    if embedders is None:
+        return [csm]
+    return [e for e in embedders if hasattr(e, "wrapped") and hasattr(e, "encode_with_transformers")]
+
+
+def _clip_kind(embedder, is_sdxl: bool):
+    """-> (kind, torch text module, token-embedding module) of one wrapper, by STRUCTURE (the class names are the reference's:
+    sd_hijack_clip.py:318-377, sd_hijack_open_clip.py:10-71):
+      "clip_l"       FrozenCLIPEmbedderWithCustomWords           wrapped.transformer.text_model (transformers CLIPTextModel), SD 1.x
+      "clip_l_sdxl"  FrozenCLIPEmbedderForSDXLWithCustomWords    the same tower read at wrapped.layer / layer_idx, SDXL embedder 0
+      "openclip"     FrozenOpenCLIPEmbedderWithCustomWords       wrapped.model (open_clip text tower), penultimate layer + ln_final, SD 2.x
+      "openclip2"    FrozenOpenCLIPEmbedder2WithCustomWords      wrapped.model, penultimate WITHOUT ln_final + pooled projection, SDXL embedder 1"""
+    wrapped = getattr(embedder, "wrapped", None)
+    text_model = getattr(getattr(wrapped, "transformer", None), "text_model", None)
+    if text_model is not None:
+        sdxl_form = is_sdxl or "ForSDXL" in type(embedder).__name__
+        return ("clip_l_sdxl" if sdxl_form else "clip_l"), text_model, text_model.embeddings.token_embedding
+    model = getattr(wrapped, "model", None)
+    if model is not None and hasattr(model, "transformer") and hasattr(model, "token_embedding") and hasattr(model, "ln_final"):
+        two = "Embedder2" in type(embedder).__name__ or "Embedder2" in type(wrapped).__name__ or getattr(wrapped, "legacy", True) is False
+        return ("openclip2" if two else "openclip"), model, model.token_embedding
+    return None, None, None
+
+
 def install_clip_hook(sd_model, device_index: int = 0, lora_networks=None):
-    """SD 1.x checkpoints (FrozenCLIPEmbedderWithCustomWords over transformers' CLIPTextModel): the CLIP-L tower is packed into an engine
-    and ``encode_with_transformers`` of THIS model's embedder is rebound to it.  Token embeddings still come from the webui's
-    (textual-inversion patched) embedding layer and enter as ``inputs_embeds``.  Returns the encoder, or None when the checkpoint's text
-    encoder is not that class (SD 2.x / SDXL keep the torch towers: their hooks live in sd_hijack_clip.Mi355xClipTextEncoder and are
-    bound the same way once the webui exposes the wrapped towers).  Prompts with a text-encoder LoRA active are encoded by the torch
-    tower (``text_encoder_networks_active``): the engine tower is packed from the checkpoint weights and never sees those deltas."""
+    """Every text tower of the loaded checkpoint is packed into an engine and ``encode_with_transformers`` of ITS wrapper is rebound to
+    it: CLIP-L of SD 1.x (sd_hijack_clip.py:351-360), OpenCLIP-H of SD 2.x (sd_hijack_open_clip.py:26-30: the wrapped
+    ``encode_with_transformer``, penultimate layer), and both SDXL embedders — CLIP-L read at ``wrapped.layer`` / ``layer_idx``
+    (sd_hijack_clip.py:369-377) and OpenCLIP-bigG with its pooled projection (sd_hijack_open_clip.py:57-66); the conditioner that
+    concatenates them (modules/sd_models_xl.py:12-34) keeps calling the wrappers.  Token embeddings still come from the webui's
+    (textual-inversion patched) embedding layer and enter as ``inputs_embeds``.  Prompts with a text-encoder LoRA active on a tower are
+    encoded by that torch tower (``text_encoder_networks_active``): the packed tower never sees those deltas.
+    Returns the encoder (one tower) or the list of encoders (SDXL), None when the checkpoint has no tower this engine knows."""
     from . import schema
     from .engine import Engine
     from .sd_hijack_clip import Mi355xClipTextEncoder
-    csm = getattr(sd_model, "cond_stage_model", None)
-    wrapped = getattr(csm, "wrapped", None)
-    transformer = getattr(wrapped, "transformer", None)
-    text_model = getattr(transformer, "text_model", None)
-    if csm is None or text_model is None or getattr(sd_model, "is_sdxl", False):
-        return None
-    if hasattr(csm, "_mi355x_clip"):
-        uninstall_clip_hook(sd_model)
-    sd = {schema.CLIP_PREFIX + k: v for k, v in text_model.state_dict().items()}
-    eng = Engine(device_index)
-    enc = Mi355xClipTextEncoder(eng, schema.sd15_clip(), sd)
-    csm._mi355x_clip = enc
-    csm._torch_encode_with_transformers = csm.encode_with_transformers
+    is_sdxl = bool(getattr(sd_model, "is_sdxl", False))
+    made = []
+    for emb in _clip_embedders(sd_model):
+        kind, tower, tok_emb = _clip_kind(emb, is_sdxl)
+        if kind is None:
+            continue
+        if hasattr(emb, "_mi355x_clip"):
+            _unhook(emb)
+        wrapped = emb.wrapped
+        if kind in ("clip_l", "clip_l_sdxl"):
+            cfg = schema.sd15_clip()
+            sd = {schema.CLIP_PREFIX + k.replace("token_embedding.wrapped.", "token_embedding."): v for k, v in tower.state_dict().items()}
+        else:
+            width = int(tower.ln_final.weight.shape[0])
+            cfg = schema.openclip_bigg() if width == 1280 else schema.openclip_h()
+            raw = {"m." + k: v for k, v in tower.state_dict().items()}
+            tew = raw.get("m.token_embedding.wrapped.weight")          # EmbeddingsWithFixes keeps the nn.Embedding as .wrapped
+            if tew is not None:
+                raw["m.token_embedding.weight"] = tew
+            sd = schema.openclip_to_transformers_keys(raw, "m.")
+        enc = Mi355xClipTextEncoder(Engine(device_index), cfg, sd, layer=getattr(wrapped, "layer", "last"),
+                                    layer_idx=getattr(wrapped, "layer_idx", None))
+        emb._mi355x_clip = enc
+        emb._torch_encode_with_transformers = emb.encode_with_transformers
 
-    def encode_with_transformers(tokens):
-        if text_encoder_networks_active(csm, lora_networks):
-            # The Lora extension applies text-encoder deltas lazily, inside the patched torch Linear / MultiheadAttention forwards
-            # (extensions-builtin/Lora/networks.py:411-480, 578-605) — forwards the packed tower never runs.  While a loaded network
-            # touches this text encoder with a non-zero multiplier, the prompt goes through the torch tower, deltas included.
-            return csm._torch_encode_with_transformers(tokens)
-        emb = text_model.embeddings.token_embedding(tokens)   # EmbeddingsWithFixes: textual-inversion vectors spliced in
-        return enc.encode_with_transformers(tokens, inputs_embeds=emb)
-    csm.encode_with_transformers = encode_with_transformers
-    return enc
+        def encode_with_transformers(tokens, emb=emb, enc=enc, kind=kind, tok_emb=tok_emb):
+            if text_encoder_networks_active(emb, lora_networks):
+                # The Lora extension applies text-encoder deltas lazily, inside the patched torch Linear / MultiheadAttention forwards
+                # (extensions-builtin/Lora/networks.py:411-480, 578-605) — forwards the packed tower never runs.  While a loaded network
+                # touches this text encoder with a non-zero multiplier, the prompt goes through the torch tower, deltas included.
+                return emb._torch_encode_with_transformers(tokens)
+            e = tok_emb(tokens)                               # EmbeddingsWithFixes: textual-inversion vectors spliced in
+            if kind == "clip_l":
+                return enc.encode_with_transformers(tokens, inputs_embeds=e)
+            if kind == "clip_l_sdxl":
+                return enc.encode_with_transformers_sdxl(tokens, inputs_embeds=e)
+            if kind == "openclip":
+                return enc.encode_with_transformer_openclip(tokens, inputs_embeds=e)
+            return enc.encode_with_transformer_openclip2(tokens, inputs_embeds=e)
+        emb.encode_with_transformers = encode_with_transformers
+        made.append(enc)
+    if not made:
+        return None
+    return made[0] if len(made) == 1 else made
 
 
 def text_encoder_networks_active(cond_stage_model, lora_networks=None) -> bool:
@@ -334,9 +389,13 @@ def _mtime(filename):
         return None
 
 
+def _unhook(emb):
+    if hasattr(emb, "_torch_encode_with_transformers"):
+        emb.encode_with_transformers = emb._torch_encode_with_transformers
+        emb._mi355x_clip.engine.close()
+        del emb._torch_encode_with_transformers, emb._mi355x_clip
+
+
 def uninstall_clip_hook(sd_model):
-    csm = getattr(sd_model, "cond_stage_model", None)
-    if csm is not None and hasattr(csm, "_torch_encode_with_transformers"):
-        csm.encode_with_transformers = csm._torch_encode_with_transformers
-        csm._mi355x_clip.engine.close()
-        del csm._torch_encode_with_transformers, csm._mi355x_clip
+    for emb in _clip_embedders(sd_model):
+        _unhook(emb)

@@ -1329,3 +1329,121 @@ def test_process_images_iteration_loop_obeys_skip_and_interrupt(monkeypatch):
     # interrupted before the first batch: an empty result, not an error
     res = processing.process_images(P(sd_model=model, c=c, uc=c, seed=50, batch_size=2, n_iter=3, sampler_name="Euler a", width=64, height=64))
     assert res.images == [] and res.latents is None and res.images_device is None
+
+
+def test_clip_hook_binds_sd2_and_sdxl_text_towers(monkeypatch):
+    """B6 for every text-encoder wrapper the webui builds (modules/sd_hijack.py:205-243): SD 2.x's FrozenOpenCLIPEmbedderWithCustomWords and
+    both SDXL embedders get ``encode_with_transformers`` rebound to an engine tower of the right configuration, fed with the webui's own
+    (textual-inversion patched) token embeddings; a text-encoder LoRA on one tower sends THAT tower's prompts through torch; uninstall
+    restores the wrappers.  The engine and the packed tower are stand-ins here (no GPU): what is tested is the binding."""
+    import types
+    bridge, schema = sub("webui_bridge"), sub("schema")
+    made = []
+
+    class FakeEngine:
+        def __init__(self, device):
+            self.device, self.closed = device, False
+
+        def close(self):
+            self.closed = True
+
+    class FakeEncoder:
+        def __init__(self, engine, cfg, state_dict, prefix=None, slot=0, layer="last", layer_idx=None):
+            self.engine, self.cfg, self.sd, self.layer, self.layer_idx, self.calls = engine, cfg, state_dict, layer, layer_idx, []
+            made.append(self)
+
+        def _rec(self, how, tokens, inputs_embeds):
+            self.calls.append((how, tuple(tokens.shape), None if inputs_embeds is None else tuple(inputs_embeds.shape)))
+            return torch.zeros(tokens.shape[0], tokens.shape[1], 4)
+        encode_with_transformers = lambda self, t, inputs_embeds=None: self._rec("clip_l", t, inputs_embeds)
+        encode_with_transformers_sdxl = lambda self, t, inputs_embeds=None: self._rec("clip_l_sdxl", t, inputs_embeds)
+        encode_with_transformer_openclip = lambda self, t, inputs_embeds=None: self._rec("openclip", t, inputs_embeds)
+        encode_with_transformer_openclip2 = lambda self, t, inputs_embeds=None: self._rec("openclip2", t, inputs_embeds)
+    monkeypatch.setattr(sub("engine"), "Engine", FakeEngine)
+    monkeypatch.setattr(sub("sd_hijack_clip"), "Mi355xClipTextEncoder", FakeEncoder)
+
+    class EmbeddingsWithFixes(torch.nn.Module):               # modules/sd_hijack.py: keeps the nn.Embedding as .wrapped
+        def __init__(self, wrapped):
+            super().__init__()
+            self.wrapped = wrapped
+
+        def forward(self, ids):
+            return self.wrapped(ids)
+
+    def open_clip_tower(width, layers=2):                     # the attributes of open_clip's text tower the hook and the key map read
+        m = torch.nn.Module()
+        m.token_embedding = EmbeddingsWithFixes(torch.nn.Embedding(50, width))
+        m.positional_embedding = torch.nn.Parameter(torch.zeros(77, width))
+        m.transformer = torch.nn.Module()
+        blocks = []
+        for _ in range(layers):
+            b = torch.nn.Module()
+            b.ln_1, b.ln_2 = torch.nn.LayerNorm(width), torch.nn.LayerNorm(width)
+            b.attn = torch.nn.MultiheadAttention(width, 2)
+            b.mlp = torch.nn.Module()
+            b.mlp.c_fc, b.mlp.c_proj = torch.nn.Linear(width, 4 * width), torch.nn.Linear(4 * width, width)
+            blocks.append(b)
+        m.transformer.resblocks = torch.nn.ModuleList(blocks)
+        m.ln_final = torch.nn.LayerNorm(width)
+        m.text_projection = torch.nn.Parameter(torch.zeros(width, width))
+        return m
+
+    def hf_tower(width=8):                                    # transformers' CLIPTextModel.text_model, as far as the hook reads it
+        tm = torch.nn.Module()
+        tm.embeddings = torch.nn.Module()
+        tm.embeddings.token_embedding = EmbeddingsWithFixes(torch.nn.Embedding(50, width))
+        tm.final_layer_norm = torch.nn.LayerNorm(width)
+        return tm
+
+    def wrapper(clsname, wrapped):
+        cls = type(clsname, (torch.nn.Module,), {"forward": lambda self, x: x})
+        w = cls()
+        w.wrapped = wrapped
+        w.stock_calls = []
+        w.encode_with_transformers = lambda tokens, w=w: w.stock_calls.append(tuple(tokens.shape)) or "torch"
+        return w
+
+    tokens = torch.zeros(3, 77, dtype=torch.long)
+    # ---- SD 2.x: one OpenCLIP-H tower, penultimate layer
+    inner = torch.nn.Module()
+    inner.model, inner.layer = open_clip_tower(16), "penultimate"
+    sd2 = types.SimpleNamespace(cond_stage_model=wrapper("FrozenOpenCLIPEmbedderWithCustomWords", inner), is_sdxl=False)
+    enc = bridge.install_clip_hook(sd2, lora_networks=types.SimpleNamespace(loaded_networks=[]))
+    assert enc is made[-1] and enc.cfg == schema.openclip_h() and enc.layer == "penultimate"
+    keys = set(enc.sd)
+    assert schema.CLIP_PREFIX + "embeddings.token_embedding.weight" in keys and schema.CLIP_PREFIX + "encoder.layers.1.self_attn.q_proj.weight" in keys
+    assert schema.CLIP_PREFIX + "text_projection.weight" in keys and schema.CLIP_PREFIX + "final_layer_norm.bias" in keys
+    sd2.cond_stage_model.encode_with_transformers(tokens)
+    assert enc.calls == [("openclip", (3, 77), (3, 77, 16))] and sd2.cond_stage_model.stock_calls == []
+    bridge.uninstall_clip_hook(sd2)
+    assert enc.engine.closed and sd2.cond_stage_model.encode_with_transformers(tokens) == "torch" and not hasattr(sd2.cond_stage_model, "_mi355x_clip")
+    # ---- SDXL: conditioner.embedders = [CLIP-L read at hidden_states[11], OpenCLIP-bigG with the pooled projection, a non-text embedder]
+    l_inner = torch.nn.Module()
+    l_inner.transformer = torch.nn.Module()
+    l_inner.transformer.text_model = hf_tower()
+    l_inner.layer, l_inner.layer_idx = "hidden", 11
+    g_inner = torch.nn.Module()
+    g_inner.model, g_inner.layer, g_inner.legacy = open_clip_tower(1280, layers=1), "penultimate", False
+    emb_l = wrapper("FrozenCLIPEmbedderForSDXLWithCustomWords", l_inner)
+    emb_g = wrapper("FrozenOpenCLIPEmbedder2WithCustomWords", g_inner)
+    conditioner = types.SimpleNamespace(embedders=[emb_l, emb_g, types.SimpleNamespace(note="ConcatTimestepEmbedderND: no text")])
+    sdxl = types.SimpleNamespace(cond_stage_model=conditioner, is_sdxl=True)
+    lora = types.SimpleNamespace(loaded_networks=[])
+    encs = bridge.install_clip_hook(sdxl, lora_networks=lora)
+    assert isinstance(encs, list) and len(encs) == 2
+    assert encs[0].cfg == schema.sd15_clip() and (encs[0].layer, encs[0].layer_idx) == ("hidden", 11)
+    assert encs[1].cfg == schema.openclip_bigg()
+    assert schema.CLIP_PREFIX + "embeddings.token_embedding.weight" in encs[0].sd          # (EmbeddingsWithFixes' .wrapped. level removed)
+    emb_l.encode_with_transformers(tokens)
+    emb_g.encode_with_transformers(tokens)
+    assert encs[0].calls == [("clip_l_sdxl", (3, 77), (3, 77, 8))] and encs[1].calls == [("openclip2", (3, 77), (3, 77, 1280))]
+    # a text-encoder LoRA on the bigG tower: its prompts go through torch, CLIP-L stays on the engine
+    lora.loaded_networks = [types.SimpleNamespace(te_multiplier=0.8, modules={"lora_te2_x": types.SimpleNamespace(sd_module=g_inner.model.ln_final)})]
+    emb_l.encode_with_transformers(tokens)
+    assert emb_g.encode_with_transformers(tokens) == "torch"
+    assert len(encs[0].calls) == 2 and len(encs[1].calls) == 1 and emb_g.stock_calls == [(3, 77)]
+    # installing again replaces the towers (checkpoint reload), uninstall restores both wrappers
+    encs2 = bridge.install_clip_hook(sdxl, lora_networks=lora)
+    assert encs[0].engine.closed and encs[1].engine.closed and encs2[0] is not encs[0]
+    bridge.uninstall_clip_hook(sdxl)
+    assert emb_l.encode_with_transformers(tokens) == "torch" and all(e.engine.closed for e in encs2)

@@ -82,6 +82,27 @@ def test_unet_accuracy_mode_carries_the_residual_stream_with_22_bits(dev, tiny):
     assert torch.isfinite(acc).all() and e_acc < 0.9 * e_base and e_acc < 4e-3
 
 
+def test_engine_promise_options_are_checkable(dev, tiny, monkeypatch):
+    """cfg_pairs / uniform_t are promises of the caller about x and t; SDMI_CHECK_PROMISES=1 makes the engine verify them."""
+    eng = tiny["model"].engine
+    lib = sub("_lib")
+    x = seeded((2, 4, 16, 16), 3)
+    xx, t, ctx = torch.cat([x, x]).to(dev), torch.full((4,), 500.0).to(dev), tiny["cond"].to(dev)
+    monkeypatch.setenv("SDMI_CHECK_PROMISES", "1")
+    ok = eng.unet_forward(xx, t, ctx, uniform_t=True, cfg_pairs=True)
+    assert torch.isfinite(ok).all()
+    bad_x = xx.clone()
+    bad_x[3, 0, 0, 0] += 1.0
+    with pytest.raises(lib.SdmiError, match="cfg_pairs"):
+        eng.unet_forward(bad_x, t, ctx, uniform_t=True, cfg_pairs=True)
+    bad_t = t.clone()
+    bad_t[1] = 400.0
+    with pytest.raises(lib.SdmiError, match="uniform_t"):
+        eng.unet_forward(xx, bad_t, ctx, uniform_t=True, cfg_pairs=False)
+    monkeypatch.delenv("SDMI_CHECK_PROMISES")
+    eng.unet_forward(xx, t, ctx, uniform_t=False, cfg_pairs=False)
+
+
 def test_unet_generic_and_mfma_paths_agree(dev, tiny):
     """Independent HIP implementations (MFMA+LDS vs one-thread-per-output) of every GEMM / attention in the UNet."""
     eng = tiny["model"].engine
