@@ -121,13 +121,12 @@ struct GemmP {
     // per-row sums of its fp16-ROUNDED outputs over the tile's BN columns to lnp_out[(m * lnp_np + tile_n) * 2 + {0, 1}]
     float* lnp_out;
     int lnp_np;              // set by launch_gemm: N / BN of the chosen tile when the partials are produced, else 0
-    // Engine option "residual_fp32": the carried stream (ResBlock / transformer residual sums) as a (hi, lo) pair of fp16 tensors,
-    // x = hi + lo with hi = fp16(x) and lo = fp16(x - hi): ~22 bits of the fp32 sum survive the store, every GEMM that takes the
-    // stream as its A operand reads hi alone (the MFMA operand is fp16 either way), norms and residual adds read both.
-    // resid_lo: lo part of `resid` (same strides); out_lo: where the lo part of the fp16 output goes (same strides as out).
-    // launch_gemm then takes the 8-byte epilogue, no split-K and no statistics epilogues.
-    const half_t* resid_lo;
-    half_t* out_lo;
+    // Engine option "residual_fp32" (flag EP_HILO): the carried stream (ResBlock / transformer residual sums) as a (hi, lo) pair of fp16
+    // tensors, x = hi + lo with hi = fp16(x) and lo = fp16(x - hi): ~22 bits of the fp32 sum survive the store, every GEMM that takes
+    // the stream as its A operand reads hi alone (the MFMA operand is fp16 either way), norms and residual adds read both.  The two extra
+    // pointers travel in fields such a launch cannot use otherwise — out_lo in `splitk_ws` (no split-K), resid_lo in `lnp_out` (no
+    // LayerNorm partials): two more kernel-argument pointers cost the 256-row ping-pong instantiations 2-12 SGPR spills (round 5).
+    // Accessors: gemm_out_lo / gemm_resid_lo below.  launch_gemm then takes the 8-byte epilogue and no statistics epilogues.
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
@@ -140,9 +139,13 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000,      // 0x100..0x1000: tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
        EP_LNFOLD = 0x4000,             // see GemmP::ln_stats
+       EP_HILO = 0x8000,               // (hi, lo) stream tensors: see GemmP (out_lo in splitk_ws, resid_lo in lnp_out)
        EP_NARROW = 0x2000              // 8-byte epilogue accesses (set by launch_gemm when the 16-byte form's alignment rules fail, or
                                        // by the "ep_wide" knob): gemm_epilogue's swap16 note
      };
+
+__host__ __device__ inline half_t* gemm_out_lo(const GemmP& p) { return (p.flags & EP_HILO) ? reinterpret_cast<half_t*>(p.splitk_ws) : nullptr; }
+__host__ __device__ inline const half_t* gemm_resid_lo(const GemmP& p) { return (p.flags & EP_HILO) ? reinterpret_cast<const half_t*>(p.lnp_out) : nullptr; }
 
 // stats_nchunk_out (optional): the number of row chunks per image of the GroupNorm partial sums written to p.stats_out, or 0 when the
 // launch could not produce them (split-K, a tile spanning two images, a group straddling column tiles ...)

@@ -398,7 +398,6 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.splitk_ws = splitk_ws;
     p.lnp_out = lnp_ws;
     p.a0 = a.a0; p.a1 = a.a1; p.w = W.w; p.bias = W.b; p.rowbias = a.rowbias; p.resid = a.resid; p.out = a.out;
-    p.resid_lo = a.resid_lo; p.out_lo = a.out_lo;
     p.c0 = a.c0; p.c1 = a.c1; p.cin = a.c0 + a.c1; p.lda0 = a.c0; p.lda1 = a.c1;
     SDMI_REQUIRE(p.cin == W.cin_pad, "conv input channels do not match the packed weight");
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
@@ -408,6 +407,11 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.rows_per_batch = a.Ho * a.Wo;
     p.n_real = a.n_real ? a.n_real : W.n_pad;
     p.flags = a.flags | (W.geglu ? EP_GEGLU : 0);
+    if (a.out_lo || a.resid_lo) {                          // (hi, lo) stream tensors ride in the split-K / LayerNorm-partial fields (GemmP, EP_HILO)
+        p.flags |= EP_HILO;
+        p.splitk_ws = reinterpret_cast<float*>(a.out_lo);
+        p.lnp_out = reinterpret_cast<float*>(const_cast<half_t*>(a.resid_lo));
+    }
     if (r.e->tiling && W.taps == 9 && a.pad == 1) p.flags |= EP_WRAP;    // Conv2d(padding=1, padding_mode='circular')
     p.alpha = a.alpha;
     p.bias_scale = a.bias_scale;

@@ -633,8 +633,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
                 else rr = *reinterpret_cast<const h4*>(p.resid + rbs + (long)m * p.ldr + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                if (p.resid_lo) {                            // (hi, lo) residual: GemmP::resid_lo
-                    const h4 rl = *reinterpret_cast<const h4*>(p.resid_lo + rbs + (long)m * p.ldr + n);
+                if (const half_t* rlo = gemm_resid_lo(p)) {  // (hi, lo) residual (EP_HILO)
+                    const h4 rl = *reinterpret_cast<const h4*>(rlo + rbs + (long)m * p.ldr + n);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)rl[r];
                 }
@@ -652,11 +652,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
                 *reinterpret_cast<h4*>((half_t*)p.out + ob + (long)m * p.ldo + n) = o;
-                if (p.out_lo) {                              // what the fp16 rounding dropped, as a second fp16 tensor
+                if (half_t* olo = gemm_out_lo(p)) {          // what the fp16 rounding dropped, as a second fp16 tensor (EP_HILO)
                     h4 l;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) l[r] = (half_t)(v[r] - (float)o[r]);
-                    *reinterpret_cast<h4*>(p.out_lo + ob + (long)m * p.ldo + n) = l;
+                    *reinterpret_cast<h4*>(olo + ob + (long)m * p.ldo + n) = l;
                 }
             }
         }
@@ -2065,7 +2065,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         SDMI_REQUIRE(!force_generic && use_glds && gemm_mfma_supported(p), "EP_LNFOLD runs on the LDS-direct MFMA kernels only");
     }
     if (force_generic || !gemm_mfma_supported(p)) {
-        SDMI_REQUIRE(!p.resid_lo && !p.out_lo, "(hi, lo) stream tensors need the MFMA kernels (shape not supported / force_generic)");
+        SDMI_REQUIRE(!(p.flags & EP_HILO), "(hi, lo) stream tensors need the MFMA kernels (shape not supported / force_generic)");
         const bool geglu = p.flags & EP_GEGLU;
         const long total = (long)p.M * (geglu ? p.N / 2 : p.N);
         int blocks = (int)std::min<long>((total + 255) / 256, 65535L * 8);
@@ -2082,17 +2082,19 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         if (p.flags & EP_TRANSPOSE) wide = wide && p.rows_per_batch % 8 == 0 && p.M % 8 == 0;
         if (!wide) p.flags |= EP_NARROW;
     }
-    // (hi, lo) stream tensors (GemmP::resid_lo / out_lo, engine option "residual_fp32"): the 8-byte epilogue carries them; no split-K
-    // (the reduce pass would need them too), no GroupNorm / LayerNorm statistics from fp16-rounded outputs (the norm reads hi + lo)
-    const bool hilo = p.resid_lo != nullptr || p.out_lo != nullptr;
+    // (hi, lo) stream tensors (EP_HILO, engine option "residual_fp32"): the 8-byte epilogue carries them; no split-K (the reduce pass
+    // would need them too; its workspace field carries out_lo), no GroupNorm / LayerNorm statistics from fp16-rounded outputs (the norm
+    // reads hi + lo)
+    const bool hilo = (p.flags & EP_HILO) != 0;
     if (hilo) {
-        SDMI_REQUIRE(!force_generic && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE | EP_OUT_F32 | EP_LNFOLD | EP_BIAS_ROW)) && (!p.resid_lo || p.resid),
+        SDMI_REQUIRE(!force_generic && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE | EP_OUT_F32 | EP_LNFOLD | EP_BIAS_ROW)) &&
+                         (gemm_resid_lo(p) == nullptr || p.resid != nullptr),
                      "(hi, lo) stream tensors: plain fp16 row-major epilogue on the MFMA kernels only");
         p.flags |= EP_NARROW;
-        p.stats_out = nullptr; p.lnp_out = nullptr;
+        p.stats_out = nullptr;
     }
     int split = 1;
-    const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE)) && p.N % 4 == 0 && !hilo;
+    const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE | EP_HILO)) && p.N % 4 == 0;
     SDMI_REQUIRE(!(p.flags & EP_TRANSPOSE) || (p.rows_per_batch % 4 == 0 && p.M % 4 == 0 && !(p.flags & (EP_GEGLU | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW)) &&
                                                !p.resid && !p.rowbias),
                  "EP_TRANSPOSE: rows per image must be a multiple of 4; no residual / GEGLU / fp32 output");
@@ -2145,7 +2147,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         }
     }
     // LayerNorm row partials from this launch's epilogue (GemmP::lnp_out): the 16-byte plain epilogue of an unsplit fp16 launch only
-    if (p.lnp_out && use_glds && split <= 1 && batch == 1 && p.stats_nchunk == 0 &&
+    if (p.lnp_out && !hilo && use_glds && split <= 1 && batch == 1 && p.stats_nchunk == 0 &&
         !(p.flags & (EP_NARROW | EP_GEGLU | EP_TRANSPOSE | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW | EP_QUICK_GELU | EP_GELU | EP_LNFOLD)) &&
         kCfgBM[cfg] % 32 == 0 && cfg != CFG_64x64 && (phase || kCfgBM[cfg] < 256)) {   // (64x64: one 16-row tile per wave, no row-tile
                                                                                          // pairs; two-stage 256-row tiles: not instantiated)

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import ops, shared
 
 try:
     from modules import sd_hijack_optimizations as _ref

@@ -169,7 +169,7 @@ def test_c1_unet_cfg_forward_16_rows_vs_oracle(dev, sd15):
         "per_row": per_row, "oracle_seconds": round(t_oracle, 1), "error_budget": budget})
     print(f"[c1 unet] engine {e_engine:.3e} (rows 0-3 {e_engine_4:.3e}); reference fp16 emulation {e_emu:.3e}")
     sd15["c1_forward"] = dict(x=x, t=t, ctx16=ctx16, ref4=ref[:4].clone(), got4=got[:4].clone(), emu4=emu.clone())
-    assert e_engine < 2e-3
+    assert e_engine < 1.95e-3                                # 1.25 x the measured 1.51e-3 (16 rows) / 1.58e-3 (rows 0-3), profiles/r05_parity.json
     assert e_engine_4 < e_emu * 1.05
     if emu_rows:
         # the emulated pattern lands where the engine does (1.58e-3 vs 1.51-1.57e-3) and is closer to the engine than the fp32 oracle is
@@ -331,7 +331,7 @@ def test_c1_groupnorm_statistics_fused_into_producing_gemm(dev, sd15):
                                       "fused_vs_separate_first_resblock_rel_l2": e1, "fused_vs_separate_unet_output_rel_l2": e})
     print(f"[c1 gn fusion] {n_gn} producers carry the statistics, {n_apply1} norms read them; fused vs separate: first ResBlock {e1:.3e}, UNet output {e:.3e}")
     assert e1 < 3e-4
-    assert e < 2.5e-3
+    assert e < 2.3e-3                                        # 1.25 x the measured 1.82e-3 (two independent draws of the 1.5e-3 rounding noise)
 
 
 @pytest.mark.parametrize("d,heads,n,b", [(40, 8, 4096, 2), (80, 8, 1024, 2), (160, 8, 256, 2)])
@@ -416,12 +416,12 @@ def test_c1_vae_decode_512_vs_oracle_and_reference_class(dev, sd15, golden_dir):
         out = e2.vae_decode(seeded(zshape, zseed).to(dev)).cpu()
         e2.close()
         fix[key] = rel_l2(out[:, :, ::sub_stride, ::sub_stride], want)
-        assert fix[key] < 2.5e-3, (key, fix[key])         # fp32 weights rounded to fp16 at load + fp16 activations [1.77e-3]
+        assert fix[key] < 2.2e-3, (key, fix[key])         # fp32 weights rounded to fp16 at load + fp16 activations [1.76e-3]
     report("vae_decode_c1", {"shape": "z [2,4,64,64] -> [2,3,512,512]", "engine_vs_fp32_oracle_rel_l2": e_engine,
                              "reference_fp16_emulation_vs_fp32_oracle": e_emu, **u8,
                              "engine_vs_reference_VAEDecoder_class": fix, "error_budget": budget})
     print(f"[c1 vae] engine {e_engine:.3e}; reference fp16 emulation {e_emu:.3e}; vs reference class {fix}")
-    assert e_engine < 1.5e-3 and e_engine < e_emu * 1.05
+    assert e_engine < 1.4e-3 and e_engine < e_emu * 1.05       # measured 1.12e-3
     assert u8["uint8_max_abs_diff"] <= 1
 
 
@@ -463,8 +463,45 @@ def test_c1_euler_a_20_steps_512_final_latent_vs_oracle(dev, sd15, golden_dir):
         assert out["fixture_vs_live_oracle"] < 1.5e-3        # another host's BLAS summation order, amplified over 20 chaotic steps
     report("euler_a_20_steps_c1", out)
     print(f"[c1 e2e] {out}")
-    assert e < 5e-3
+    assert e < 3.55e-3                                       # 1.25 x the measured 2.84e-3 (profiles/r05_parity.json)
     assert e < 1.1 * out["reference_fp16_emulation_vs_fp32_oracle_final_latent"]
+
+
+@pytest.mark.skipif(not FULL, reason="SDMI_PARITY_FULL=1: two live 20-step oracle runs (about 2.5 minutes of host time)")
+def test_c1_euler_a_20_steps_at_the_benched_batch_of_8_vs_oracle(dev, sd15):
+    """The whole C1 job AT THE BENCHED BATCH: 8 images (16-row CFG forwards with the shared prefix — the tile table and launch sequence
+    bench.py times), 20-step Euler a, cfg 7, seeds 1000..1007, each image with its own prompt pair.  Images 0 and 7 are compared with
+    live fp32 oracle runs of those images alone (rows are independent; the oracle at batch 8 would be 8x the host time).  The batch-1
+    test above runs a 2-row dispatch: different tiles (test_bench_batch_dispatch...: two dispatches differ by 1.8e-3 per forward)."""
+    from oracle import pipeline as opipe
+    from oracle import kdiffusion as kd
+    model = sd15["model"]
+    conds, unconds = [], []
+    for i in range(8):
+        g = torch.Generator().manual_seed(50_000 + i)        # image 0: the prompt pair of the batch-1 test
+        conds.append(torch.randn(1, 77, 768, generator=g))
+        unconds.append(torch.randn(1, 77, 768, generator=g))
+    sampler = sub("sd_samplers").create_sampler("Euler a", model)
+
+    class P:
+        steps, cfg_scale, eta, scheduler, is_hr_pass = 20, 7.0, None, None, False
+        sampler_noise_scheduler_override, extra_generation_params = None, {}
+        rng = sub("rng").ImageRNG((4, 64, 64), [1000 + i for i in range(8)], device=dev)
+    p = P()
+    got = sampler.sample(p, p.rng.next(), torch.cat(conds).to(dev), torch.cat(unconds).to(dev)).cpu()
+    om = opipe.OracleModel.__new__(opipe.OracleModel)
+    om.unet, om.vae = sd15["unet"], sd15["vae"]
+    om.alphas_cumprod = kd.make_alphas_cumprod()
+    out = {"config": "SD1.5 512x512, 20-step Euler a, cfg 7, batch 8 (the benched dispatch), seeds 1000..1007", "images": {}}
+    t0 = time.time()
+    for i in (0, 7):
+        live = opipe.sample(om, conds[i], unconds[i], [1000 + i], 20, "euler_a", 7.0, (64, 64))
+        out["images"][str(i)] = rel_l2(got[i:i + 1], live)
+    out["oracle_seconds"] = round(time.time() - t0, 1)
+    report("euler_a_20_steps_c1_batch8", out)
+    print(f"[c1 e2e batch 8] {out}")
+    assert torch.isfinite(got).all()
+    assert max(out["images"].values()) < 3.6e-3              # 1.25 x the measured 2.88e-3 (image 0) / 2.80e-3 (image 7); batch 1: 2.84e-3
 
 
 def test_c3_sdxl_base_full_size_unet_forward_vs_oracle(dev):
@@ -495,7 +532,7 @@ def test_c3_sdxl_base_full_size_unet_forward_vs_oracle(dev):
     report("unet_c3_sdxl_forward", {"shape": "x [2,4,32,32], context [2,77,2048], y [2,2816]", "engine_vs_fp32_oracle_rel_l2": e,
                                     "reference_fp16_emulation_vs_fp32_oracle": e_emu})
     print(f"[c3 sdxl unet] engine {e:.3e}; reference fp16 emulation {e_emu:.3e}")
-    assert e < 3e-3 and e < 1.1 * e_emu
+    assert e < 2.0e-3 and e < 1.1 * e_emu                    # measured 1.62e-3
 
 
 def test_c1_small_linear_lds_staged_form_gives_the_same_bits(dev, sd15):
@@ -554,5 +591,5 @@ def test_c1_cfg_pairs_shared_prefix_vs_per_row_forward_and_oracle(dev, sd15):
                                  "per_row_vs_fp32_oracle_rows_0_8": e_rows})
     print(f"[c1 cfg_pairs] shared vs per-row {e_pair:.3e}; vs oracle {e_shared:.3e} (per-row path {e_rows:.3e})")
     assert torch.equal(twin[:8], twin[8:])
-    assert e_pair < 2.5e-3 and e_shared < 2e-3
+    assert e_pair < 2.25e-3 and e_shared < 1.86e-3           # measured 1.80e-3 / 1.49e-3
     eng.unet_forward(x.to(dev), t.to(dev), None)              # (leaves both per-call options off for the tests that follow)

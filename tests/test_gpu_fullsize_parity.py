@@ -86,7 +86,7 @@ def test_c4_sd15_unet_forward_at_128x128_latent(dev, sd15_unet_engine, golden_di
     report("unet_c4_sd15_128x128_latent", {"shape": "x [2,4,128,128], context [2,77,768]", "engine_vs_fp32_oracle_rel_l2": e,
                                            "per_row": [rel_l2(got[i], want[i]) for i in range(2)]})
     print(f"[c4 unet 128x128] engine {e:.3e}")
-    assert e < 2.5e-3
+    assert e < 1.9e-3                                        # 1.25 x the measured 1.52e-3
 
 
 @pytest.mark.parametrize("d,heads,n", [(40, 8, 16384), (64, 10, 4096), (64, 20, 1024)])
@@ -129,7 +129,7 @@ def test_c3_sdxl_base_unet_forward_at_128x128_latent(dev, golden_dir):
     e = rel_l2(got, want)
     report("unet_c3_sdxl_128x128_latent", {"shape": "x [1,4,128,128], context [1,77,2048], y [1,2816]", "engine_vs_fp32_oracle_rel_l2": e})
     print(f"[c3 sdxl 128x128] engine {e:.3e}")
-    assert e < 3e-3
+    assert e < 1.67e-3                                       # 1.25 x the measured 1.34e-3
 
 
 def _check_image(got, fx, tol):
@@ -149,7 +149,7 @@ def test_c4_vae_decode_1024_and_encode_512(dev, golden_dir):
     s = mfg.SPEC["vae1024"]
     z = mfg.seeded(*s["z"]) * s["z_scale"]
     got = eng.vae_decode(z.to(dev)).cpu()
-    out = {"decode_1024": _check_image(got, fixture(golden_dir, "vae1024"), 1.5e-3)}
+    out = {"decode_1024": _check_image(got, fixture(golden_dir, "vae1024"), 1.47e-3)}      # 1.25 x the measured 1.17e-3
     x = mfg.seeded(*mfg.SPEC["enc512"]["x"]).clamp(-1, 1)
     mom = eng.vae_encode_moments(x.to(dev)).cpu()
     want = torch.from_numpy(fixture(golden_dir, "enc512")["moments"])
@@ -158,7 +158,7 @@ def test_c4_vae_decode_1024_and_encode_512(dev, golden_dir):
     eng.close()
     report("vae_c4_decode_1024_encode_512", out)
     print(f"[c4 vae] {out}")
-    assert out["encode_512_moments_rel_l2"] < 2e-3
+    assert out["encode_512_moments_rel_l2"] < 1.4e-3      # measured 1.12e-3
 
 
 def test_c3_sdxl_vae_config_decode_1024_range_extended(dev, golden_dir):
@@ -176,7 +176,7 @@ def test_c3_sdxl_vae_config_decode_1024_range_extended(dev, golden_dir):
     got = eng.vae_decode(z).cpu()
     eng.close()
     assert torch.isfinite(got).all()
-    out = _check_image(got, fixture(golden_dir, "vae1024_xl"), 5e-3)
+    out = _check_image(got, fixture(golden_dir, "vae1024_xl"), 1.08e-3)      # 1.25 x the measured 8.6e-4 (range-extended decode)
     report("vae_c3_sdxl_config_decode_1024_range_extended", out)
     print(f"[c3 vae range-extended 1024] {out}")
 
@@ -204,7 +204,7 @@ def test_c2_dpmpp_2m_karras_50_steps_final_latent(dev, golden_dir):
     report("dpmpp_2m_karras_50_steps_c2", {"config": "SD1.5 512x512, 50-step DPM++ 2M Karras, cfg 7, batch 1, seed 2000",
                                            "engine_vs_fp32_oracle_final_latent_rel_l2": e})
     print(f"[c2 e2e] engine {e:.3e}")
-    assert e < 8e-3
+    assert e < 1.66e-3                                       # 1.25 x the measured 1.33e-3 (50 steps)
 
 
 # ---- round 4: the c3 / c4a / c4b jobs COMPOSED end to end at full size (few steps: the oracle side is minutes of host CPU, committed as
@@ -249,7 +249,7 @@ def test_c4a_hires_fix_job_composed_at_full_size_batch_2(dev, sd15_full_model, g
                                     "image0_u8_mean_abs_levels": float(d.float().mean()), "image0_u8_max_levels": int(max(d.max(), dw.max())),
                                     "image0_u8_within_1_level": float((d <= 1).float().mean())})
     print(f"[c4a hires e2e] latent {e:.3e}, image 0 mean |du8| {float(d.float().mean()):.3f}, max {int(max(d.max(), dw.max()))}")
-    assert e < 5e-3
+    assert e < 5e-3                                          # 1.22 x the measured 4.10e-3 (hires: 2 + 2 UNet evaluations at two sizes)
     assert float(d.float().mean()) < 0.6 and float((d <= 2).float().mean()) > 0.995
 
 
@@ -277,7 +277,7 @@ def test_c4b_img2img_job_composed_at_full_size_batch_2(dev, sd15_full_model, gol
                                       "images_u8_mean_abs_levels": float(d.float().mean()), "images_u8_max_levels": int(d.max()),
                                       "images_u8_within_1_level": float((d <= 1).float().mean())})
     print(f"[c4b img2img e2e] latent {e:.3e} (init {e_init}), images mean |du8| {float(d.float().mean()):.3f}, max {int(d.max())}")
-    assert e < 5e-3
+    assert e < 4.3e-3                                        # 1.25 x the measured 3.45e-3
     assert float(d.float().mean()) < 0.6 and float((d <= 2).float().mean()) > 0.995
 
 
@@ -307,7 +307,7 @@ def test_c3_sdxl_three_step_job_at_128x128_latent(dev, golden_dir):
     report("c3_sdxl_e2e_3_steps", {"config": "SDXL-base 1024x1024 (128x128 latent), 3 Euler-a evaluations, cfg 5, batch 1, seed 4200",
                                    "engine_vs_fp32_oracle_final_latent_rel_l2": e})
     print(f"[c3 sdxl e2e] engine {e:.3e}")
-    assert e < 5e-3
+    assert e < 2.58e-3                                       # 1.25 x the measured 2.07e-3
 
 
 def test_bench_batch_dispatch_reproduces_the_two_row_forward(dev, sd15_unet_engine):
@@ -324,6 +324,6 @@ def test_bench_batch_dispatch_reproduces_the_two_row_forward(dev, sd15_unet_engi
         out[f"rows_{2 * reps}"] = {"max_rel_l2_vs_2_rows": max(errs), "bit_identical_pairs": sum(torch.equal(big[2 * i:2 * i + 2], two) for i in range(reps))}
         # two fp16 realisations of the same forward, each ~1.5e-3 from fp32 and nearly independent of each other (the engine against its
         # own rounding pattern emulated on the oracle: 1.9e-3, profiles/r04_parity.json): sqrt(2) x 1.5e-3 is the scale; measured 1.82e-3
-        assert max(errs) < 2.5e-3, (reps, errs)
+        assert max(errs) < 2.27e-3, (reps, errs)
         assert all(torch.equal(big[0:2], big[2 * i:2 * i + 2]) for i in range(reps))      # inside one launch sequence rows are treated alike
     report("c4a_batch_dispatch_vs_2_rows", out)
