@@ -578,6 +578,9 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "gn_fuse") g_gn_fuse = value;
     else if (n == "gn_small") g_gn_small = value;
     else if (n == "ep_wide") g_ep_wide = value;
+    else if (n == "rc_ff8") g_rc_ff8 = value;
+    else if (n == "rc_dbg_lo") g_rc_dbg = (g_rc_dbg & 0xFFFFFFFF00000000ull) | (unsigned)value;
+    else if (n == "rc_dbg_hi") g_rc_dbg = (g_rc_dbg & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32);
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "attn_occ") g_attn_occ = value;
     else if (n == "attn_lds_pad") g_attn_lds_pad = value;

@@ -195,6 +195,8 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, int ldv, int Mpad, hipStream_t s);
 
 // ---- row-local chains of the transformer block (rowchain.hip) ----------------------------------------------
+extern unsigned long long g_rc_dbg;                 // tuning only: RowChainP::dbg
+extern int g_rc_ff8;                                // 1: 8-wave feed-forward chain + its pack layout (rowchain.hip)
 bool rowchain_supports(int C);                      // row widths the fused chains are instantiated for (320)
 int rowchain_xattn_max_keys();                      // longest text context the cross-attention chain takes (96)
 size_t rowchain_ff_pack_bytes(int C, int hidden);

@@ -70,6 +70,7 @@ struct RowChainP {
     int nchunk;               // feed-forward: hidden / 32; cross-attention: heads
     float eps;
     const half_t* zero;       // the zero page (padding lanes of the row staging)
+    long long* dbg;           // VAR 10 (SDMI_RC_PARTS builds): per wave (sync, stage 1 + GEGLU, stage 2) cycle sums and the iteration count
 };
 
 __device__ __forceinline__ float rc_gelu_erf(float g) {      // gemm.hip's gelu_erf (exact-erf GELU, A&S 7.1.26), instruction for instruction
@@ -221,6 +222,12 @@ __device__ __forceinline__ void rc_issue(const char* src, char* dst, int wave, i
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+__device__ __forceinline__ long long rc_stamp() {            // s_memtime, serialised against the LDS / scalar queue
+    const long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+}
+
 __device__ __forceinline__ void rc_phase_sync() {          // my loads have landed; everybody's have; everybody left the previous phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -277,13 +284,17 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     const unsigned lane16 = (unsigned)lane * 16u;
 
     // iteration j.  S1: chunk j exists (stage 1, and pack j + 1 is fetched); S2: chunk j - 1 exists (GEGLU + stage 2); PAR = j & 1
+    [[maybe_unused]] long long tm[4] = {0, 0, 0, 0};
     constexpr int LE = (VAR == 7 || VAR == 9) ? 1 : 3;       // one operand piece every LE steps
     constexpr bool SB = !(VAR == 8 || VAR == 9);             // a sched_barrier closes every step
     auto phase = [&](int j, auto s1c, auto s2c, auto parc) {
         constexpr bool S1 = decltype(s1c)::value, S2 = decltype(s2c)::value;
         constexpr int PAR = decltype(parc)::value;
         constexpr int N1 = S1 ? 2 * NDC : 0, N2 = S2 ? 2 * NDB : 0, NS = N1 + N2;
+        [[maybe_unused]] long long tq0 = 0, tq1 = 0, tq2 = 0;
+        if constexpr (VAR == 10) tq0 = rc_stamp();
         if constexpr (VAR != 5) rc_phase_sync();
+        if constexpr (VAR == 10) tq1 = rc_stamp();
         const char* reg = smem + (j & 1) * PACK;
         const char* b1 = reg + ka_off;
         const char* b2 = reg + 2 * G::B1UNIT + va_off;
@@ -327,8 +338,13 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
                 constexpr int r = i / 2;
                 pb[r >> 3][r & 7] = (half_t)(VAR == 1 ? sv[PAR ^ 1][r] + sg[PAR ^ 1][r] : SDMI_GELU_SIG ? geglu_gate(sv[PAR ^ 1][r], sg[PAR ^ 1][r]) : sv[PAR ^ 1][r] * rc_gelu_erf(sg[PAR ^ 1][r]));
             }
+            if constexpr (VAR == 10 && i == N1 - 1) tq2 = rc_stamp();
             if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (VAR == 10 && S1 && S2) {
+            const long long tq3 = rc_stamp();
+            tm[0] += tq1 - tq0; tm[1] += tq2 - tq1; tm[2] += tq3 - tq2; tm[3] += 1;
+        }
         if constexpr (S1 && VAR != 2) {      // pieces the step loop had no slot for (NS / LE slots)
 #pragma unroll
             for (int k = NS / LE; k < NP / 4; ++k) rc_issue_piece<NP>(gnext, lane16, lnext, k);
@@ -354,8 +370,145 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
         for (int db = 0; db < NDB; ++db) o[db][0] = (float)xf[db][0];
     }
 
+    if constexpr (VAR == 10) {
+        if (p.dbg && lane == 0) {
+            long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 4;
+            for (int i = 0; i < 4; ++i) d[i] = tm[i];
+        }
+    }
     rc_phase_sync();                                         // every wave is past its last operand read
     rc_store<C>(p, (long)blockIdx.x * 128 + wave * 32, smem + wave * G::B1UNIT, lane, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// feed-forward chain, 8-wave form (knob rc_ff8; pack layout 1).  The 4-wave kernel above is issue-bound: with ONE wave per SIMD the
+// LDS-direct loads (17 per wave and chunk, ~100 cycles of issue each), the fragment reads and the GEGLU VALU work are issued by the same
+// in-order wave that issues the MFMAs — T = T_mfma + 0.65 T_other measured (profiles/r05_rowchain_parts.txt).  Here each SIMD holds TWO
+// waves of the same 32 rows (waves w and w + 4), each under 256 registers: wave (rg, ch) computes the scores of half of the chunk's
+// hidden units (its B1 unit = 16 value + 16 gate rows: 20 MFMAs), applies GEGLU to them — the 8 results per lane ARE the stage-2 operand
+// fragment pb[ch] —, hands that fragment to its partner through LDS, and accumulates O^T for half of the output columns (10 MFMAs).
+// The two waves of a SIMD issue into each other's gaps, as in the ping-pong GEMM.  Two barriers per chunk.
+// ---------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void rowchain_ff8_kernel(RowChainP p) {
+    typedef RcGeo<C> G;
+    constexpr int PACK = G::FFPACK, NP = PACK / 1024, PF = 4;
+    constexpr int NDC = G::NDC, NDBH = G::NDB / 2;           // output blocks per wave
+    static_assert(G::NDB % 2 == 0, "two column halves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave & 3, ch = wave >> 2;
+    const int half = lane >> 5, lq = lane & 31;
+    const long row0 = (long)blockIdx.x * 128 + rg * 32;
+    char* const xchg = smem + 2 * PACK;                      // [8 waves][64 lanes] x 16 bytes: the GEGLU fragments handed to the partner wave
+    const char* const gsrc = p.packs + wave * 1024;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto issue_pack = [&](int j) {
+        const char* g = gsrc + (long)j * PACK;
+        char* l = smem + (j & 1) * PACK + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < NP / 8; ++k) __builtin_amdgcn_global_load_lds((gptr_t)(g + k * 8192 + lane16), (lptr_t)(l + k * 8192), 16, 0, 0);
+        if constexpr (NP % 8 != 0) {
+            if (wave < NP % 8)
+                __builtin_amdgcn_global_load_lds((gptr_t)(g + (NP / 8) * 8192 + lane16), (lptr_t)(l + (NP / 8) * 8192), 16, 0, 0);
+        }
+    };
+
+    // prologue: the row groups through the second pack buffer (staged by the ch = 0 waves, read by both), pack 0 meanwhile
+    char* const xreg = smem + PACK + rg * G::B1UNIT;
+    if (ch == 0) rc_stage_rows<C>(p.x + row0 * C, xreg, lane, p.zero);
+    issue_pack(0);
+    if (ch == 0) { if (wave < NP % 8) wait_vm<NP / 8 + 1>(); else wait_vm<NP / 8>(); }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    h8 xf[NDC];
+    rc_load_ln<C>(xreg, lq, p.gamma, p.beta, p.eps, half, xf);
+
+    f16v o[NDBH];
+#pragma unroll
+    for (int db = 0; db < NDBH; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
+    const int ka_off = ch * G::B1UNIT + krow * G::B1STR + half * 16;
+    const int va_off = 2 * G::B1UNIT + (ch * NDBH * 32 + lq) * G::B2STR + half * 16;
+    const int nch = p.nchunk;
+
+    for (int j = 0; j < nch; ++j) {
+        rc_phase_sync();                                     // pack j has landed everywhere; everybody is past stage 2 of chunk j - 1
+        if (j + 1 < nch) issue_pack(j + 1);
+        const char* reg = smem + (j & 1) * PACK;
+        // ---- stage 1: this wave's B1 unit
+        f16v sc = rc_init<C>(reg + ch * G::B1UNIT, half);
+        const char* b1 = reg + ka_off;
+        h8 ring[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ring[i] = rc_lds(b1 + i * 32);
+        rc_static_for<NDC>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i % PF], xf[i], sc, 0, 0, 0);
+            if constexpr (i + PF < NDC) ring[i % PF] = rc_lds(b1 + (i + PF) * 32);
+        });
+        // ---- GEGLU: sc[r] (r < 8) = value, sc[8 + r] = gate of hidden unit 16 ch + 8 half + r: the stage-2 fragment pb[ch]
+        h8 mine;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mine[r] = (half_t)(SDMI_GELU_SIG ? geglu_gate(sc[r], sc[8 + r]) : sc[r] * rc_gelu_erf(sc[8 + r]));
+        *reinterpret_cast<h8*>(xchg + (wave * 64 + lane) * 16) = mine;
+        // stage-2 fragments of sb = ch can be prefetched before the hand-off
+        const char* b2 = reg + va_off;
+        h8 va[NDBH];
+#pragma unroll
+        for (int db = 0; db < NDBH; ++db) va[db] = rc_lds(b2 + db * 32 * G::B2STR + ch * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const h8 theirs = *reinterpret_cast<const h8*>(xchg + ((wave ^ 4) * 64 + lane) * 16);
+        // ---- stage 2: this wave's half of the output columns
+#pragma unroll
+        for (int db = 0; db < NDBH; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[db], mine, o[db], 0, 0, 0);
+#pragma unroll
+        for (int db = 0; db < NDBH; ++db) {
+            const h8 a = rc_lds(b2 + db * 32 * G::B2STR + (ch ^ 1) * 32);
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, theirs, o[db], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: residual rows staged by the ch = 0 waves, both waves add their column halves in place, coalesced stores
+    rc_phase_sync();
+    char* const oreg = smem + rg * G::B1UNIT;
+    constexpr int SLOTS = G::B1STR / 16, NPIECE = G::B1UNIT / 1024;
+    if (ch == 0) {
+        rc_stage_rows<C>(p.x + row0 * C, oreg, lane, p.zero);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    char* xrow = oreg + lq * G::B1STR;
+#pragma unroll
+    for (int db = 0; db < NDBH; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = (ch * NDBH + db) * 32 + g * 8 + half * 4;
+            const h4 res = *reinterpret_cast<const h4*>(xrow + c0 * 2);
+            const f4 bb = *reinterpret_cast<const f4*>(p.bias_out + c0);
+            h4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (half_t)((o[db][g * 4 + e] + bb[e]) + (float)res[e]);
+            *reinterpret_cast<h4*>(xrow + c0 * 2) = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    half_t* owave = p.out + row0 * C;
+#pragma unroll
+    for (int i = ch; i < NPIECE; i += 2) {                   // the two waves of a row group take alternate 1 KB pieces
+        const int n = i * 64 + lane;
+        const int r = (n * 1599) >> 16;
+        const int c = n - r * SLOTS;
+        const h8 v = *reinterpret_cast<const h8*>(oreg + n * 16);
+        if (r < 32 && c < C / 8) *reinterpret_cast<h8*>(owave + r * C + c * 8) = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -545,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void rowchain_xattn_kernel(RowChainP p) {
 // of 64 rows = 32 value + 32 gate rows of one chunk, elementwise.hip geglu_row), b1 likewise, w2 [C][hidden] -> (hidden / 32 + 1) packs
 template <int C>
 __global__ __launch_bounds__(256) void rowchain_ff_pack_kernel(const half_t* w1, const float* b1, const half_t* w2, char* packs,
-                                                               int hidden, int permuted) {
+                                                               int hidden, int permuted, int layout) {
     typedef RcGeo<C> G;
     constexpr int PACK = G::FFPACK, NCHUNK16 = PACK / 16, U16 = G::B1UNIT / 16, SLOTS = G::B1STR / 16, V16 = G::B2UNIT / 16;
     const int nch = hidden / 32;
@@ -554,28 +707,29 @@ __global__ __launch_bounds__(256) void rowchain_ff_pack_kernel(const half_t* w1,
         const int j = (int)(idx / NCHUNK16), ci = (int)(idx - (long)j * NCHUNK16);
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (ci < 2 * U16) {
-            const int u = ci / U16, cu = ci - u * U16;           // u: 0 value, 1 gate
-            const int r = cu / SLOTS, c = cu - r * SLOTS;
+            const int u = ci / U16, cu = ci - u * U16;           // layout 0: unit 0 = value rows, 1 = gate rows of the chunk's 32 hidden units
+            const int r = cu / SLOTS, c = cu - r * SLOTS;        // layout 1: unit u = 16 value rows then 16 gate rows of hidden units 16u .. 16u + 15
+            // unit row rr -> (gate?, hidden unit of the chunk)
+            auto src_of = [&](int rr) -> long {
+                const int gate = layout ? (rr >> 4) : u;
+                const int hu = j * 32 + (layout ? 16 * u + (rr & 15) : rr);
+                return permuted ? (long)(hu >> 5) * 64 + (hu & 31) + 32 * gate : (long)gate * hidden + hu;
+            };
             if (j < nch) {
                 if (r < 32 && c < C / 8) {
-                    const int hu = j * 32 + r;
-                    const long src_row = permuted ? (long)(hu >> 5) * 64 + (hu & 31) + 32 * u : (long)u * hidden + hu;
-                    v = *reinterpret_cast<const uint4*>(w1 + src_row * C + c * 8);
+                    v = *reinterpret_cast<const uint4*>(w1 + src_of(r) * C + c * 8);
                 } else if (r >= 32 && cu * 16 >= G::B1TAB && cu * 16 < G::B1TAB + 128) {
                     const int t0 = (cu * 16 - G::B1TAB) / 4;       // table entries t0 .. t0 + 3
                     float f[4];
-                    for (int e = 0; e < 4; ++e) {
-                        const int hu = j * 32 + t0 + e;
-                        const long src_row = permuted ? (long)(hu >> 5) * 64 + (hu & 31) + 32 * u : (long)u * hidden + hu;
-                        f[e] = b1 ? b1[src_row] : 0.f;
-                    }
+                    for (int e = 0; e < 4; ++e) f[e] = b1 ? b1[src_of(t0 + e)] : 0.f;
                     v = __builtin_bit_cast(uint4, f4{f[0], f[1], f[2], f[3]});
                 }
             }
         } else {
             const int cb = ci - 2 * U16;
             const int n = cb / 5, c = cb - n * 5;
-            if (j >= 1 && c < 4 && cb < V16) v = *reinterpret_cast<const uint4*>(w2 + (long)n * hidden + (j - 1) * 32 + c * 8);
+            const int jj = layout ? j : j - 1;                   // layout 0 skews the B2 unit by one chunk (rowchain_ff_kernel)
+            if (jj >= 0 && jj < nch && c < 4 && cb < V16) v = *reinterpret_cast<const uint4*>(w2 + (long)n * hidden + jj * 32 + c * 8);
         }
         *reinterpret_cast<uint4*>(packs + idx * 16) = v;
     }
@@ -652,6 +806,10 @@ __global__ __launch_bounds__(256) void rowchain_xattn_pack_kernel(const half_t* 
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
+// 1: the 8-wave feed-forward kernel + pack layout 1 (SDMI_RC_FF8 / sdmi_debug_set "rc_ff8"); packs built under one value are not read under the other
+unsigned long long g_rc_dbg = 0;     // device pointer for RowChainP::dbg (sdmi_debug_set rc_dbg_lo / rc_dbg_hi)
+int g_rc_ff8 = [] { const char* e = getenv("SDMI_RC_FF8"); return e ? atoi(e) : 0; }();
+
 bool rowchain_supports(int C) { return C == 320; }
 int rowchain_xattn_max_keys() { return 96; }
 
@@ -671,7 +829,7 @@ int launch_rowchain_ff_pack(const half_t* w1, const float* b1, const half_t* w2,
     SDMI_REQUIRE(rowchain_supports(C) && hidden % 32 == 0 && hidden > 0, "rowchain feed-forward: C = 320, hidden % 32 == 0");
     const long total = (long)rowchain_ff_pack_bytes(C, hidden) / 16;
     hipLaunchKernelGGL(rowchain_ff_pack_kernel<320>, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, w1, b1,
-                       w2, (char*)packs, hidden, permuted ? 1 : 0);
+                       w2, (char*)packs, hidden, permuted ? 1 : 0, g_rc_ff8 ? 1 : 0);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -710,6 +868,7 @@ int launch_rowchain_ff(const half_t* x, half_t* out, const float* gamma, const f
     if (var == 7) kern = rowchain_ff_kernel<320, 7>;
     if (var == 8) kern = rowchain_ff_kernel<320, 8>;
     if (var == 9) kern = rowchain_ff_kernel<320, 9>;
+    if (var == 10) kern = rowchain_ff_kernel<320, 10>;
 #endif
     (void)var;
     static void (*attr)(RowChainP) = nullptr;
@@ -717,7 +876,18 @@ int launch_rowchain_ff(const half_t* x, half_t* out, const float* gamma, const f
     RowChainP p{};
     p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.packs = (const char*)packs; p.bias_out = bias_out ? bias_out : reinterpret_cast<const float*>(zero_page()); p.zero = zero_page();
     p.M = (int)rows; p.rows_per_img = (int)rows; p.nchunk = hidden / 32; p.eps = eps;
+    p.dbg = reinterpret_cast<long long*>(g_rc_dbg);
     ProfScope ps("rowchain_ff", 2.0 * rows * C * (3.0 * hidden), 4.0 * rows * C, s);
+    if (g_rc_ff8) {
+        constexpr int SMEM8 = std::max(2 * G::FFPACK + 8 * 64 * 16, G::FFPACK + 4 * G::B1UNIT);     // packs + hand-off slots | pack 0 + row staging
+        static_assert(SMEM8 <= 160 * 1024, "LDS budget of the 8-wave form");
+        void (*k8)(RowChainP) = rowchain_ff8_kernel<320>;
+        static bool attr8 = false;
+        if (!attr8) { if (rc_set_smem(k8, SMEM8)) return 1; attr8 = true; }
+        hipLaunchKernelGGL(k8, dim3((unsigned)(rows / 128)), dim3(512), SMEM8, s, p);
+        SDMI_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(rows / 128)), dim3(256), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;

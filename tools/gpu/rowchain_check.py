@@ -86,6 +86,21 @@ def main():
     def ff():
         _lib.check(lib.sdmi_rowchain_ff(dx.ptr, dout.ptr, dg.ptr, db.ptr, dpk.ptr, db2.ptr, rows, Cw, hidden, 1e-5, None), "rowchain_ff")
     us = timed(ff)
+    if os.environ.get("SDMI_RC_VAR") == "10":                 # section timers of the 4-wave kernel (SDMI_RC_PARTS builds)
+        nw = rows // 128 * 4
+        dbg = hipmem.DevBuf(nw * 4 * 8)
+        hipmem._hip.hipMemset(dbg.ptr, 0, dbg.nbytes)
+        addr = dbg.ptr.value
+        _lib.check(lib.sdmi_debug_set(b"rc_dbg_lo", C.c_int(addr & 0xFFFFFFFF if addr & 0xFFFFFFFF < 2 ** 31 else (addr & 0xFFFFFFFF) - 2 ** 32)), "rc_dbg_lo")
+        _lib.check(lib.sdmi_debug_set(b"rc_dbg_hi", C.c_int(addr >> 32)), "rc_dbg_hi")
+        ff(); hipmem.sync()
+        t = dbg.to_numpy(np.int64, (nw, 4)).astype(np.float64)
+        it = t[:, 3].mean()
+        res["ff_sections_cycles_per_iteration"] = {"sync": float(t[:, 0].mean() / it), "stage1_geglu": float(t[:, 1].mean() / it),
+                                                   "stage2": float(t[:, 2].mean() / it), "iterations": float(it),
+                                                   "us_per_launch": us, "implied_GHz": float((t[:, :3].sum(1).mean()) / (us * 1e3) * (rows / 128 / 256))}
+        print("sections", res["ff_sections_cycles_per_iteration"], flush=True)
+        _lib.check(lib.sdmi_debug_set(b"rc_dbg_lo", 0), "rc_dbg_lo"); _lib.check(lib.sdmi_debug_set(b"rc_dbg_hi", 0), "rc_dbg_hi")
     out = dout.to_numpy(np.float16, (rows, Cw))[sample].astype(np.float64)
     xs = x[sample].astype(np.float64)
     n = ln(xs, g, b).astype(np.float16).astype(np.float64)
