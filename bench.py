@@ -29,7 +29,7 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   "cpu_baseline": the fp32 CPU oracle (restated reference path) timed on this host on a bounded sample.
 `config.images_per_s_every_row_computed` re-times a few jobs with the CFG denoiser's common-subexpression option off (`cfg_pairs`: the
 layers in front of the first cross-attention are the same function value for the cond and the uncond row of an image and are computed
-once — every row's output is still produced), `config.dropin_images_per_s` the same job through the B1 / B4 boundaries.
+once — every row's output is still produced; docs/DESIGN_experiments.md A.1), `config.dropin_images_per_s` the same job through the B1 / B4 boundaries.
 """
 import argparse
 import ctypes
@@ -654,7 +654,7 @@ def main():
                    "algorithmic_tflop_per_image": tflop_per_image,
                    "cfg_pairs": "on (samplers' default): both halves of the CFG batch share latent and timestep, so conv_in, the first ResBlock and "
                                 "GroupNorm / proj_in / norm1 / self-attention of the first transformer block are computed once per image and copied; every "
-                                "row's output is produced (DESIGN.md 9.1)",
+                                "row's output is produced (docs/DESIGN_experiments.md A.1)",
                    "images_per_s_every_row_computed": per_row,
                    "dropin_images_per_s": dropin,
                    "dropin_path": "torch stand-in of the reference's CFGDenoiser + Euler-a loop calling Mi355xUnet.forward per step + engine VAE decode (bench.py dropin_path)",

@@ -51,7 +51,7 @@ __device__ __forceinline__ float tree_max(const f16v (&sc)[NKB]) {
     return v[0];
 }
 
-// VAR = forms of the d = 40 level-0 self-attention loop (profiles/r02_attention_experiments.md); selected
+// VAR = forms of the d = 40 level-0 self-attention loop (docs/DESIGN_experiments.md, profiles/r02_attention_experiments.md); selected
 // with SDMI_ATTN_OCC=<VAR> / sdmi_debug_set("attn_occ", VAR); 15 is the default for d = 40 (see g_attn_occ):
 //   0  round-1 kernel: register budget for 2 workgroups per CU (D <= 80) or 1; one ds_read -> wait -> MFMA chain per MFMA
 //   5  128 VGPRs (4 workgroups per CU) + lazy rescale: the O accumulators are multiplied by alpha only when some lane's running

@@ -1670,7 +1670,7 @@ template <bool LNF = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) {
     if (p.gate && *p.gate == 0) return;
     // (row, column-quad) pairs walked by the grid stride's quotient / remainder: no 64-bit division per element (static ISA review,
-    // DESIGN.md section 9)
+    // docs/DESIGN_experiments.md)
     const int NQ = p.N / 4;
     const int stride = (int)gridDim.x * 256;                 // M * N / 4 < 2^31: split-K is admitted for the small-M layers only
     const int sp = stride / NQ, sr = stride - sp * NQ;
@@ -1900,7 +1900,7 @@ int g_force_gemm_cfg = [] { const char* e = getenv("SDMI_GEMM_CFG"); return e ? 
 int g_force_gemm_split = 0;
 // Experiment knob (default off): tile config forced for the short-K launches only (K / 64 < 8: the q / k / v / out projections and
 // proj_in / proj_out, ~5 % of the C1 job at 2-3x their HBM floor with one 256x320 tile per CU) — e.g. SDMI_SHORTK_CFG=<128x64 id>
-// to try several co-resident workgroups per CU in a same-box A/B (lead 2).
+// to try several co-resident workgroups per CU in a same-box A/B (docs/DESIGN_experiments.md, lead 2).
 int g_shortk_gemm_cfg = [] { const char* e = getenv("SDMI_SHORTK_CFG"); return e ? atoi(e) : -1; }();
 int g_shortk_max_k = [] { const char* e = getenv("SDMI_SHORTK_MAXK"); return e ? atoi(e) : 448; }();
 int g_geglu_gemm_cfg = [] { const char* e = getenv("SDMI_GEGLU_CFG"); return e ? atoi(e) : -1; }();

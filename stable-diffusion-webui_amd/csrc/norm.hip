@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
     __syncthreads();
     // grid-stride walk over the (pixel, 8-channel vector) pairs of image b, two vectors per thread in flight.  The pair is advanced
     // by the stride's quotient / remainder instead of dividing the linear index each time: the 64-bit divisions by the runtime VP
-    // were ~130 of the loop's 330 VALU instructions (23 of them quarter-rate multiplies) — static ISA review, DESIGN.md section 9.
+    // were ~130 of the loop's 330 VALU instructions (23 of them quarter-rate multiplies) — static ISA review, docs/DESIGN_experiments.md.
     const int stride = (int)gridDim.x * 256;                       // HW * C < 2^31, HW < 2^24 (launch_groupnorm)
     const int sp = stride / VP, sr = stride - sp * VP;
     const int sp2 = (2 * stride) / VP, sr2 = 2 * stride - sp2 * VP;
