@@ -782,7 +782,9 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
         // option "fuse_rows" bit 0: norm2 -> to_q -> attention over the text keys -> to_out -> + x1 as one launch (rowchain.hip)
-        const bool chain_ok = !fold && !acc && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0;
+        // (not with option "streams" > 1: the feed-forward pack is built lazily on the stream of the slice that meets it first, and the
+        // other slices would read it with no event dependency on that stream — the same rule as ln_fold's folded weights)
+        const bool chain_ok = !fold && !acc && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0 && e->n_streams <= 1;
         half_t* x2 = nullptr;
         if (chain_ok && (e->fuse_rows & 1) && b.ctx_slot < (int)e->ctx_xa.size() && e->ctx_xa[b.ctx_slot] != nullptr) {
             x2 = r.H(M * C);

@@ -502,7 +502,9 @@ __global__ __launch_bounds__(512, 2) void rowchain_ff8_kernel(RowChainP p) {
     asm volatile("" ::: "memory");
     half_t* owave = p.out + row0 * C;
 #pragma unroll
-    for (int i = ch; i < NPIECE; i += 2) {                   // the two waves of a row group take alternate 1 KB pieces
+    for (int ii = 0; ii < (NPIECE + 1) / 2; ++ii) {          // the two waves of a row group take alternate 1 KB pieces
+        const int i = 2 * ii + ch;
+        if (i >= NPIECE) break;
         const int n = i * 64 + lane;
         const int r = (n * 1599) >> 16;
         const int c = n - r * SLOTS;

@@ -101,7 +101,7 @@ def main():
             c, fv, fd = fe[n]
             wv = wr.get(n, [1, 0.0, 0.0])
             f.write(f"| `{short(n)}` | {c} | {2 * fv / c / 1024:.1f} | {wv[1] / max(wv[0], 1) / 1024:.1f} | {fd / c / 1e3:.1f} |\n")
-            if "gemm_mfma" in n:
+            if any(pfx in n for pfx in ("gemm_mfma", "splitk", "rowchain_")):      # bench.py FAMILY_PREFIXES
                 fam["calls"] += c; fam["fetch_kb"] += 2 * fv; fam["write_kb"] += wv[1] * c / max(wv[0], 1)
     per_launch = (fam["fetch_kb"] + fam["write_kb"]) * 1024 / max(fam["calls"], 1)
     # the ping-pong instantiations (3x3 convs and the large 1x1 / linear layers share them under the tap-major K order): measured
@@ -115,7 +115,7 @@ def main():
     alg = alg_all = None
     bk = os.path.join(G, "bench_kernels_c1.json")
     if os.path.exists(bk):
-        allk = [k for k in json.load(open(bk)) if k["name"].startswith("gemm_mfma")]
+        allk = [k for k in json.load(open(bk)) if k["name"].startswith(("gemm_mfma", "splitk", "rowchain_"))]
         ks = [k for k in allk if "pp" in k["name"].split(" ")[0]]
         if ks:
             alg = sum(k["bytes"] for k in ks) / max(sum(k["launches"] for k in ks), 1)
