@@ -675,8 +675,15 @@ __device__ __forceinline__ int swz(int r) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2>
+// LIN (round 5): the 1x1 / linear launches (one tap, stride 1, no upsampling, no wrap: row m of the GEMM is pixel m of the source).
+// The general gather rebuilds every load's address from (tap, channel block, row) each K step — ~40 VALU / SALU instructions per
+// 16-byte load, 315 instructions around the 16 MFMAs of a 128x64 tile's K step: the 4-wave tiles were ISSUE-bound on address
+// arithmetic, not latency-bound (M4096 N1280 K1280: 2.5 workgroups per CU x 20 steps x ~1400 cycles = the 30 us every tile shape
+// measured in rounds 3-4).  Here every load slot keeps a running pointer: one 64-bit add per load per K step.
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2,
+          bool LIN = false>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
+    static_assert(!LIN || (GLDS && !KORD), "the linear walk exists for the LDS-direct path");
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
     constexpr int WTM = BM / WR, WTN = BN / WC;
@@ -690,7 +697,8 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the MFMA tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: LDS bases and tile offsets stay scalar
     const int wr = wave / WC, wc = wave % WC;
 
     // ---- XCD-aware tile id remap (bijective for any grid size) -------------------------------------------
@@ -716,10 +724,10 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     const half_t* wbase = p.w + z * p.w_bs;
 
     // ---- per-thread row bookkeeping for the A gather ---------------------------------------------------------
-    GRow rows[A_IT];
+    GRow rows[LIN ? 1 : A_IT];
     const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
+    for (int it = 0; it < (LIN ? 0 : A_IT); ++it) {
         const int idx = it * NT + tid;
         const int m = m0 + idx / CPR;
         GRow gr;
@@ -749,9 +757,40 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     }
     uint4 ra[GLDS ? 1 : A_IT], rb[GLDS ? 1 : B_IT];
 
+    // LIN: running pointer + per-step increment of every load slot (rows beyond M / columns beyond n_valid: the zero page, increment 0);
+    // adelta = what takes a slot from the end of source 0 to the start of source 1 (two-source K = a channel concatenation)
+    const half_t* acur[LIN ? A_IT : 1];
+    const half_t* bcur[LIN ? B_IT : 1];
+    int ainc[LIN ? A_IT : 1], binc[LIN ? B_IT : 1];
+    long adelta[LIN ? A_IT : 1];
+    if constexpr (LIN) {
+        const int k0 = k_first * BK;
+        const bool first = k0 < p.c0;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
+            const int m = m0 + r;
+            const bool ok = m < p.M;
+            const half_t* q0 = a0 + (long)m * p.lda0 + c * 8;                       // channel 0 of source 0, this slot's chunk
+            const half_t* q1 = a1 ? a1 + (long)m * p.lda1 + c * 8 : p.zero;
+            acur[it] = !ok ? p.zero : first ? q0 + k0 : q1 + (k0 - p.c0);
+            ainc[it] = ok ? BK : 0;
+            adelta[it] = ok && a1 ? (long)(reinterpret_cast<const char*>(q1) - reinterpret_cast<const char*>(q0 + p.c0)) : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
+            const bool ok = n0 + r < p.n_valid;
+            bcur[it] = ok ? wbase + (long)(n0 + r) * p.ldw + k0 + c * 8 : p.zero;
+            binc[it] = ok ? BK : 0;
+        }
+    }
+
     // (tap, cbase) of the NEXT stage to issue; advanced incrementally (no integer division in the K loop)
-    int nx_tap = 0, nx_cbase = 0;
-    if (k_first > 0) {
+    int nx_tap = 0, nx_cbase = LIN ? k_first * BK : 0;
+    if (!LIN && k_first > 0) {
         if constexpr (KORD) {                            // channel block outer, tap inner (3x3 convs, GemmP::korder)
             const int blk = k_first / 9;
             nx_tap = k_first - blk * 9;
@@ -763,6 +802,26 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         }
     }
     auto stage_issue = [&](int sb) {
+        if constexpr (LIN) {
+            char* abuf = smem + sb * STAGE;
+            char* bbuf = abuf + A_BYTES;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                __builtin_amdgcn_global_load_lds((gptr_t)acur[it], (lptr_t)(abuf + (it * NT + wave * 64) * 16), 16, 0, 0);
+                acur[it] += ainc[it];
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                __builtin_amdgcn_global_load_lds((gptr_t)bcur[it], (lptr_t)(bbuf + (it * NT + wave * 64) * 16), 16, 0, 0);
+                bcur[it] += binc[it];
+            }
+            nx_cbase += BK;
+            if (nx_cbase == p.c0 && a1) {                  // the next stage starts source 1 (c0 is a multiple of BK: gemm_mfma_supported)
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it)
+                    acur[it] = reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(acur[it]) + adelta[it]);
+            }
+        } else {
         const int tap = nx_tap, cbase = nx_cbase, k0 = nx_tap * p.cin + nx_cbase;
         if constexpr (KORD) {
             if (++nx_tap == 9) { nx_tap = 0; nx_cbase += BK; }
@@ -808,6 +867,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
             } else {
                 rb[it] = *reinterpret_cast<const uint4*>(g);
             }
+        }
         }
     };
     auto stage_commit = [&](int sb) {
@@ -863,7 +923,12 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
             if (rem >= 2) wait_vmcnt<2 * LPS>();
             else if (rem == 1) wait_vmcnt<LPS>();
             else wait_vmcnt<0>();
-            __syncthreads();                                 // stage kt visible to all; everyone is done with step kt - 1's slot
+            // stage kt visible to all; everyone is done with step kt - 1's slot (its fragment reads fed MFMAs already issued).  A bare
+            // s_barrier: __syncthreads() is fence + barrier and the fence compiles to `s_waitcnt vmcnt(0)` — with it every step waited
+            // for the NS - 2 stages just issued and the ring ran as a two-stage loop (round 4's "ring = no faster", r04_ring_check.txt,
+            // measured THAT; found in the ISA in round 5)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (kt + NS - 1 < nk) stage_issue(fill);
             compute(slot);
             if (++slot == NS) slot = 0;
@@ -1734,11 +1799,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
     }
 }
 
-template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2>
+template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2,
+          bool LIN = false>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = NS * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM, NS>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM, NS, LIN>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1817,8 +1883,27 @@ static int launch_pingpong(const GemmP& p, int batch, hipStream_t s) {
     return launch_pingpong2<BM, BN, false>(p, batch, s);
 }
 
+// 1 (default): 1x1 / linear launches on the LDS-direct 4-wave tiles take the running-pointer K walk (gemm_mfma_kernel LIN).  0: the
+// general gather everywhere (rounds 1-4) — for same-box A/Bs (debug knob "gemm_lin").  Same loads, same accumulation order: same bits.
+int g_gemm_lin = [] { const char* e = getenv("SDMI_GEMM_LIN"); return e ? atoi(e) : 1; }();
+static bool gemm_is_linear(const GemmP& p) {
+    return g_gemm_lin && p.taps == 1 && p.stride == 1 && p.pad == 0 && !p.up && !(p.flags & EP_WRAP) && !p.korder &&
+           p.Wo == p.Wi && p.rows_per_batch == p.Hi * p.Wi;                              // row m of the GEMM is pixel m of either source
+}
+
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
+    if constexpr (GLDS && BM < 256) {                      // linear walk: the forms the 1x1 layers of the UNet / VAE / CLIP run in
+        if (gemm_is_linear(p) && !(p.flags & EP_LNFOLD)) {
+            if (p.lnp_np > 0) return launch_cfg2<BM, BN, WR, WC, BK, true, false, false, false, false, 2, 2, true>(p, batch, s);
+            if constexpr ((BN / WC) % 64 == 0) {
+                if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, BK, true, true, false, false, false, 0, 2, true>(p, batch, s);
+            }
+            if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, BK, true, false, true, false, false, 0, 2, true>(p, batch, s);
+            if (p.stats_nchunk > 0) return launch_cfg2<BM, BN, WR, WC, BK, true, false, false, false, true, 0, 2, true>(p, batch, s);
+            return launch_cfg2<BM, BN, WR, WC, BK, true, false, false, false, false, 0, 2, true>(p, batch, s);
+        }
+    }
     if constexpr (BM >= 256) {                             // the two-stage 256-row tiles (the ping-pong kernel's fallback) carry no LayerNorm forms
         if (p.flags & EP_LNFOLD) { set_error("EP_LNFOLD on a 256-row tile needs the ping-pong kernel (gemm_pipe 3 / 4)"); return 1; }
     }
@@ -1848,6 +1933,14 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
 // ring-buffered instantiations (NS stages): plain / GEGLU / transposed / GroupNorm-statistics epilogues, tap-major K walk
 template <int BM, int BN, int WR, int WC, int NS>
 static int launch_ring(const GemmP& p, int batch, hipStream_t s) {
+    if (gemm_is_linear(p)) {
+        if constexpr ((BN / WC) % 64 == 0) {
+            if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, 64, true, true, false, false, false, 0, NS, true>(p, batch, s);
+        }
+        if (p.flags & EP_TRANSPOSE) return launch_cfg2<BM, BN, WR, WC, 64, true, false, true, false, false, 0, NS, true>(p, batch, s);
+        if (p.stats_nchunk > 0) return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, true, 0, NS, true>(p, batch, s);
+        return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, false, 0, NS, true>(p, batch, s);
+    }
     if constexpr ((BN / WC) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, 64, true, true, false, false, false, 0, NS>(p, batch, s);
     }
