@@ -681,9 +681,14 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // arithmetic, not latency-bound (M4096 N1280 K1280: 2.5 workgroups per CU x 20 steps x ~1400 cycles = the 30 us every tile shape
 // measured in rounds 3-4).  Here every load slot keeps a running pointer: one 64-bit add per load per K step.
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2,
-          bool LIN = false>
+          bool LIN = false, bool LIN3 = false>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
-    static_assert(!LIN || (GLDS && !KORD), "the linear walk exists for the LDS-direct path");
+    // LIN3: the same idea for the plain 3x3 convolutions (stride 1, padding 1, no upsampling, no wrap, tap-major walk): per load slot the
+    // pointer of the row's own pixel in the current source and a 9-bit mask of the taps that fall inside the image; per K step one
+    // block-uniform offset ((dy - 1) Wi + dx - 1) lda + channel — a bit test, a 64-bit add and a select per load.
+    static_assert(!(LIN || LIN3) || (GLDS && !KORD), "the lean walks exist for the LDS-direct path");
+    static_assert(!(LIN && LIN3), "one walk");
+    constexpr bool LEAN = LIN || LIN3;
     if (p.gate && *p.gate == 0) return;
     constexpr int NT = WR * WC * 64;
     constexpr int WTM = BM / WR, WTN = BN / WC;
@@ -724,10 +729,10 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     const half_t* wbase = p.w + z * p.w_bs;
 
     // ---- per-thread row bookkeeping for the A gather ---------------------------------------------------------
-    GRow rows[LIN ? 1 : A_IT];
+    GRow rows[LEAN ? 1 : A_IT];
     const int ylim = p.up ? 2 * p.Hi : p.Hi, xlim = p.up ? 2 * p.Wi : p.Wi;
 #pragma unroll
-    for (int it = 0; it < (LIN ? 0 : A_IT); ++it) {
+    for (int it = 0; it < (LEAN ? 0 : A_IT); ++it) {
         const int idx = it * NT + tid;
         const int m = m0 + idx / CPR;
         GRow gr;
@@ -759,10 +764,49 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
 
     // LIN: running pointer + per-step increment of every load slot (rows beyond M / columns beyond n_valid: the zero page, increment 0);
     // adelta = what takes a slot from the end of source 0 to the start of source 1 (two-source K = a channel concatenation)
-    const half_t* acur[LIN ? A_IT : 1];
-    const half_t* bcur[LIN ? B_IT : 1];
-    int ainc[LIN ? A_IT : 1], binc[LIN ? B_IT : 1];
-    long adelta[LIN ? A_IT : 1];
+    const half_t* acur[LEAN ? A_IT : 1];
+    const half_t* bcur[LEAN ? B_IT : 1];
+    int ainc[LIN ? A_IT : 1], binc[LEAN ? B_IT : 1];
+    long adelta[LEAN ? A_IT : 1];
+    unsigned amask[LIN3 ? A_IT : 1];
+    // (tap, cbase) of the NEXT stage to issue; advanced incrementally (no integer division in the K loop)
+    int nx_tap = 0, nx_cbase = LIN ? k_first * BK : 0;
+    if constexpr (LIN3) {
+        const int k0 = k_first * BK;
+        nx_tap = k0 / p.cin;
+        nx_cbase = k0 - nx_tap * p.cin;
+        const bool first = nx_cbase < p.c0;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
+            const int m = m0 + r;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int b = mm / p.rows_per_batch;
+            const int rem = mm - b * p.rows_per_batch;
+            const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = yo + t / 3 - 1, xx = xo + t % 3 - 1;
+                mk |= (unsigned)(ok && (unsigned)yy < (unsigned)p.Hi && (unsigned)xx < (unsigned)p.Wi) << t;
+            }
+            amask[it] = mk;
+            const half_t* q0 = a0 + (long)mm * p.lda0 + c * 8;                      // the row's own pixel, channel 0 of source 0
+            const half_t* q1 = a1 ? a1 + (long)mm * p.lda1 + c * 8 : p.zero;
+            acur[it] = first ? q0 : q1;
+            adelta[it] = a1 ? (long)(reinterpret_cast<const char*>(q1) - reinterpret_cast<const char*>(q0)) : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int idx = it * NT + tid;
+            const int r = idx / CPR, c = (idx % CPR) ^ swz<BK>(r);
+            const bool ok = n0 + r < p.n_valid;
+            bcur[it] = ok ? wbase + (long)(n0 + r) * p.ldw + k0 + c * 8 : p.zero;
+            binc[it] = ok ? BK : 0;
+        }
+    }
     if constexpr (LIN) {
         const int k0 = k_first * BK;
         const bool first = k0 < p.c0;
@@ -788,9 +832,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         }
     }
 
-    // (tap, cbase) of the NEXT stage to issue; advanced incrementally (no integer division in the K loop)
-    int nx_tap = 0, nx_cbase = LIN ? k_first * BK : 0;
-    if (!LIN && k_first > 0) {
+    if (!LEAN && k_first > 0) {
         if constexpr (KORD) {                            // channel block outer, tap inner (3x3 convs, GemmP::korder)
             const int blk = k_first / 9;
             nx_tap = k_first - blk * 9;
@@ -802,7 +844,32 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         }
     }
     auto stage_issue = [&](int sb) {
-        if constexpr (LIN) {
+        if constexpr (LIN3) {
+            char* abuf = smem + sb * STAGE;
+            char* bbuf = abuf + A_BYTES;
+            const int tap = nx_tap, cbase = nx_cbase;
+            const bool first = cbase < p.c0;
+            const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+            const long uoff = (long)((dy - 1) * p.Wi + (dx - 1)) * (first ? p.lda0 : p.lda1) + (first ? cbase : cbase - p.c0);   // elements, block-uniform
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const half_t* g = ((amask[it] >> tap) & 1u) ? acur[it] + uoff : p.zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(abuf + (it * NT + wave * 64) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                __builtin_amdgcn_global_load_lds((gptr_t)bcur[it], (lptr_t)(bbuf + (it * NT + wave * 64) * 16), 16, 0, 0);
+                bcur[it] += binc[it];
+            }
+            nx_cbase += BK;
+            const bool wrapped = nx_cbase >= p.cin;
+            if (wrapped) { nx_cbase = 0; ++nx_tap; }
+            if (a1 && (wrapped || nx_cbase == p.c0)) {     // the next stage reads the other source (c0, c1 are multiples of BK: gemm_mfma_supported)
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it)
+                    acur[it] = reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(acur[it]) + (wrapped ? -adelta[it] : adelta[it]));
+            }
+        } else if constexpr (LIN) {
             char* abuf = smem + sb * STAGE;
             char* bbuf = abuf + A_BYTES;
 #pragma unroll
@@ -904,6 +971,72 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
         }
     };
 
+    // LIN, ring tiles: one K step with the LDS-direct loads of the stage that refills the ring spread between the MFMAs (one 1 KiB piece
+    // per GAP MFMAs) instead of in a burst ahead of them — a burst of LPS pieces from all four waves queues in the CU's address unit (17 cycles per piece at the
+    // 60 B/clk the L2 delivers, tools/micro/fill_rate.hip) while the MFMA pipe waits; fragment reads of the second half-step go out
+    // ahead of the first half's MFMAs.  Same MFMA order as compute(): same bits.
+    auto compute_lin = [&](int sb, int fillsb, bool more) {
+        constexpr int KS = BK / 32, LPS = A_IT + B_IT, NMMA = KS * TM * TN;
+        constexpr int GAP = NMMA / LPS > 0 ? NMMA / LPS : 1;
+        const char* abuf = smem + sb * STAGE;
+        const char* bbuf = abuf + A_BYTES;
+        char* fa = smem + fillsb * STAGE;
+        char* fb = fa + A_BYTES;
+        const int lr = lane & 15, lk = lane >> 4;
+        h8 af[2][TM], bf[2][TN];
+        auto frags = [&](int ks) {
+            const int sw = ((ks * 4 + lk) ^ swz<BK>(lr)) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[ks & 1][i] = *reinterpret_cast<const h8*>(abuf + (wr * WTM + i * 16 + lr) * ROWB + sw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[ks & 1][j] = *reinterpret_cast<const h8*>(bbuf + (wc * WTN + j * 16 + lr) * ROWB + sw);
+        };
+        frags(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
+                    // the next half-step's fragments go out a quarter into this one's MFMAs: with an LDS-direct load pending the compiler
+                    // waits for ALL outstanding LDS reads at the first use of any (lgkmcnt(0), never a partial count) — reads issued ahead
+                    // of the MFMAs would all be waited for before the first one
+                    if (ks + 1 < KS && i * TN + j == (TM * TN) / 4) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        frags(ks + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const int m = (ks * TM + i) * TN + j;              // a constant once the loops are unrolled
+                    if (m % GAP == GAP - 1 && m / GAP < LPS) {
+                        const int q = m / GAP;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) {
+                            if (q < A_IT) {
+                                __builtin_amdgcn_global_load_lds((gptr_t)acur[q < A_IT ? q : 0], (lptr_t)(fa + (q * NT + wave * 64) * 16), 16, 0, 0);
+                                acur[q < A_IT ? q : 0] += ainc[q < A_IT ? q : 0];
+                            } else {
+                                const int b = q >= A_IT ? q - A_IT : 0;
+                                __builtin_amdgcn_global_load_lds((gptr_t)bcur[b], (lptr_t)(fb + (b * NT + wave * 64) * 16), 16, 0, 0);
+                                bcur[b] += binc[b];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        }
+        static_assert(NMMA / GAP >= LPS, "every piece of a stage must find its slot between the MFMAs");
+        if (more) {
+            nx_cbase += BK;
+            if (nx_cbase == p.c0 && a1) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it)
+                    acur[it] = reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(acur[it]) + adelta[it]);
+            }
+        }
+    };
+
     if constexpr (NS > 2) {
         // ---- ring of NS stages (round 4): NS - 1 K steps of LDS-direct loads in flight, counted vmcnt, one barrier per K step -----
         // The two-stage loop below waits for step k+1's loads at the end of step k: a workgroup's K loop is a chain of nk load
@@ -929,8 +1062,12 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
             // measured THAT; found in the ISA in round 5)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + NS - 1 < nk) stage_issue(fill);
-            compute(slot);
+            if constexpr (LIN) {
+                compute_lin(slot, fill, kt + NS - 1 < nk);
+            } else {
+                if (kt + NS - 1 < nk) stage_issue(fill);
+                compute(slot);
+            }
             if (++slot == NS) slot = 0;
             if (++fill == NS) fill = 0;
         }
@@ -944,6 +1081,8 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_mfma_kernel(GemmP p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
+        // (LIN: the loads stay in a burst AHEAD of the MFMAs here — spread between them, compute_lin's way, they are issued later and this
+        // loop waits for them at the end of the same step: 128x160 on M4096 N1280 K1280 24.9 -> 34.0 us, r05_ring_check_linear_walk.txt)
         if (more) stage_issue(cur ^ 1);
         compute(cur);
         if (more) stage_commit(cur ^ 1);
@@ -1800,11 +1939,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
 }
 
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS, bool GEGLU, bool TR = false, bool KORD = false, bool STATS = false, int LNM = 0, int NS = 2,
-          bool LIN = false>
+          bool LIN = false, bool LIN3 = false>
 static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = NS * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
-    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM, NS, LIN>;
+    auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM, NS, LIN, LIN3>;
     static bool attr_set = false;
     if (!attr_set) {
         SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -1891,8 +2030,19 @@ static bool gemm_is_linear(const GemmP& p) {
            p.Wo == p.Wi && p.rows_per_batch == p.Hi * p.Wi;                              // row m of the GEMM is pixel m of either source
 }
 
+static bool gemm_is_plain3x3(const GemmP& p) {
+    return g_gemm_lin && p.taps == 9 && p.stride == 1 && p.pad == 1 && !p.up && !(p.flags & EP_WRAP) && !p.korder &&
+           p.Wo == p.Wi && p.Ho == p.Hi && p.rows_per_batch == p.Hi * p.Wi;
+}
+
 template <int BM, int BN, int WR, int WC, int BK, bool GLDS>
 static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
+    if constexpr (GLDS && BM < 256) {                      // lean 3x3 walk: plain / GroupNorm-statistics epilogues (the VAE's 128-channel convs, conv_in / conv_out)
+        if (gemm_is_plain3x3(p) && !(p.flags & (EP_LNFOLD | EP_GEGLU | EP_TRANSPOSE)) && p.lnp_np == 0) {
+            if (p.stats_nchunk > 0) return launch_cfg2<BM, BN, WR, WC, BK, true, false, false, false, true, 0, 2, false, true>(p, batch, s);
+            return launch_cfg2<BM, BN, WR, WC, BK, true, false, false, false, false, 0, 2, false, true>(p, batch, s);
+        }
+    }
     if constexpr (GLDS && BM < 256) {                      // linear walk: the forms the 1x1 layers of the UNet / VAE / CLIP run in
         if (gemm_is_linear(p) && !(p.flags & EP_LNFOLD)) {
             if (p.lnp_np > 0) return launch_cfg2<BM, BN, WR, WC, BK, true, false, false, false, false, 2, 2, true>(p, batch, s);
@@ -1934,6 +2084,7 @@ static int launch_cfg(const GemmP& p, int batch, hipStream_t s) {
 template <int BM, int BN, int WR, int WC, int NS>
 static int launch_ring(const GemmP& p, int batch, hipStream_t s) {
     if (gemm_is_linear(p)) {
+        if (p.lnp_np > 0) return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, false, 2, NS, true>(p, batch, s);
         if constexpr ((BN / WC) % 64 == 0) {
             if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, 64, true, true, false, false, false, 0, NS, true>(p, batch, s);
         }
@@ -1941,6 +2092,7 @@ static int launch_ring(const GemmP& p, int batch, hipStream_t s) {
         if (p.stats_nchunk > 0) return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, true, 0, NS, true>(p, batch, s);
         return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, false, 0, NS, true>(p, batch, s);
     }
+    if (p.lnp_np > 0) return launch_cfg2<BM, BN, WR, WC, 64, true, false, false, false, false, 2, NS>(p, batch, s);
     if constexpr ((BN / WC) % 64 == 0) {
         if (p.flags & EP_GEGLU) return launch_cfg2<BM, BN, WR, WC, 64, true, true, false, false, false, 0, NS>(p, batch, s);
     }
@@ -2024,7 +2176,7 @@ static bool cfg_valid(int cfg, const GemmP& p) {
     // 256x128: not in pick_cfg's candidate list (the two-stage form was never best in round 1); instantiated for the ping-pong kernel
     // so that the shape tuner / gemm_cfg=6 can try it on the N = 128 VAE convs (now 128x128 two-stage at ~750 TFLOP/s)
     if ((p.flags & EP_GEGLU) && (cfg == CFG_256x320 || cfg == CFG_128x320 || cfg == CFG_128x160 || cfg == CFG_256x128 || cfg == CFG_128x160_R4 || cfg == CFG_128x160_R3)) return false;   // wave tile not a multiple of 64
-    if (cfg >= CFG_128x160_R4 && (p.korder || (p.flags & EP_LNFOLD) || p.lnp_out)) return false;     // ring forms: tap-major, no LayerNorm epilogues
+    if (cfg >= CFG_128x160_R4 && (p.korder || (p.flags & EP_LNFOLD))) return false;     // ring forms: tap-major, no folded LayerNorm
     return true;
 }
 

@@ -22,9 +22,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fwd_ab  # noqa: E402
 
-# tile configurations a shape may be forced to (gemm.hip GemmCfg; the ring-buffered forms 10-13 measured no faster: r04_ring_check.txt)
-CFG_BN = {0: 128, 2: 64, 3: 128, 4: 256, 5: 320, 6: 128, 7: 64, 8: 320, 9: 160}
-CFG_NAME = {0: "128x128", 2: "64x64", 3: "128x128k32", 4: "256x256", 5: "256x320", 6: "256x128", 7: "128x64", 8: "128x320", 9: "128x160"}
+# tile configurations a shape may be forced to (gemm.hip GemmCfg; 10-13: the ring-buffered 4-wave forms — candidates again since round 5
+# gave them a bare barrier: round 4 had measured them with a drained ring)
+CFG_BN = {0: 128, 2: 64, 3: 128, 4: 256, 5: 320, 6: 128, 7: 64, 8: 320, 9: 160, 10: 160, 11: 128, 12: 64, 13: 160}
+CFG_NAME = {0: "128x128", 2: "64x64", 3: "128x128k32", 4: "256x256", 5: "256x320", 6: "256x128", 7: "128x64", 8: "128x320", 9: "128x160",
+            10: "128x160r4", 11: "128x128r4", 12: "128x64r3", 13: "128x160r3"}
 
 
 def parse(name):
@@ -42,7 +44,7 @@ def candidates(key):
     M, N, K, taps, kind = key
     out = []
     for cfg, bn in CFG_BN.items():
-        if N % bn or (kind == 1 and cfg in (5, 6, 8, 9)):
+        if N % bn or (kind == 1 and cfg in (5, 6, 8, 9, 10, 13)):
             continue
         splits = [1]
         if kind == 0 and K >= 64 * 16 and ((M + 127) // 128) * ((N + 127) // 128) < 512:      # a split-K workspace exists for these
