@@ -93,16 +93,61 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* x0, const h
     }
 }
 
-template <bool HILO = false>
+// U 16-byte vectors per thread are in flight at a time, and the first U are requested BEFORE the prologue (they do not depend on it):
+// with two in flight and the loads behind the prologue (rounds 1-4) a workgroup was a chain of load latencies — 8 dependent trips for
+// its 16 vectors per thread at ~1.3 workgroups per CU: B16 HW1024 C640 ran at 18 us against 9 us for a plain copy of the same bytes
+// (profiles/r05_copy_rate.txt).  The per-channel tables live in dynamic LDS (2 C floats) so that small-C launches keep their occupancy.
+template <bool HILO = false, int U = 8>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const half_t* x1, int c0, int c1, int HW,
                                                        int groups, int nchunk, const float* partial,
                                                        const float* gamma, const float* beta, half_t* out, float eps,
                                                        int silu, const half_t* l0 = nullptr, const half_t* l1 = nullptr) {
-    __shared__ float s_scale[GN_MAX_C];
-    __shared__ float s_shift[GN_MAX_C];
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // [C] scale | [C] shift (floats)
     __shared__ float s_mean[64], s_rstd[64];
     const int C = c0 + c1, VP = C / 8, cpg = C / groups;
+    float* s_scale = reinterpret_cast<float*>(smem);
+    float* s_shift = s_scale + C;
     const int b = blockIdx.y, tid = threadIdx.x;
+    // grid-stride walk over the (pixel, 8-channel vector) pairs of image b.  The pair is advanced by the stride's quotient / remainder
+    // instead of dividing the linear index each time: the 64-bit divisions by the runtime VP were ~130 of the loop's 330 VALU
+    // instructions (23 of them quarter-rate multiplies) — static ISA review, docs/DESIGN_experiments.md.
+    const int stride = (int)gridDim.x * 256;                       // HW * C < 2^31, HW < 2^24 (launch_groupnorm)
+    const int sp = stride / VP, sr = stride - sp * VP;
+    const int spU = (U * stride) / VP, srU = U * stride - spU * VP;
+    const int i_init = (int)blockIdx.x * 256 + tid;
+    int pix_u[U], cv_u[U];
+    unsigned iv[U];                                                // linear vector index: the output offset is iv * 8
+    pix_u[0] = i_init / VP; cv_u[0] = i_init - pix_u[0] * VP; iv[0] = (unsigned)i_init;
+#pragma unroll
+    for (int u = 1; u < U; ++u) {
+        iv[u] = iv[u - 1] + (unsigned)stride;
+        pix_u[u] = pix_u[u - 1] + sp; cv_u[u] = cv_u[u - 1] + sr;
+        if (cv_u[u] >= VP) { cv_u[u] -= VP; ++pix_u[u]; }
+    }
+    const half_t* x0b = x0 + (long)b * HW * c0;
+    const half_t* x1b = x1 ? x1 + (long)b * HW * c1 : nullptr;
+    [[maybe_unused]] const half_t* l0b = HILO ? l0 + (long)b * HW * c0 : nullptr;
+    [[maybe_unused]] const half_t* l1b = (HILO && l1) ? l1 + (long)b * HW * c1 : nullptr;
+    half_t* outb = out + (long)b * HW * C;
+    h8 v[U];
+    [[maybe_unused]] h8 lv[HILO ? U : 1];
+    int cs[U];
+    bool ok[U];
+    auto request = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = pix_u[u] < HW;
+            const unsigned pix = ok[u] ? (unsigned)pix_u[u] : 0u;
+            const int c = (ok[u] ? cv_u[u] : 0) * 8;
+            cs[u] = c;
+            const half_t* src;
+            unsigned cc, ld;
+            if (c < c0) { src = x0b; cc = (unsigned)c; ld = (unsigned)c0; } else { src = x1b; cc = (unsigned)(c - c0); ld = (unsigned)c1; }
+            v[u] = *reinterpret_cast<const h8*>(src + (__umul24(pix, ld) + cc));
+            if constexpr (HILO) lv[u] = *reinterpret_cast<const h8*>((c < c0 ? l0b : l1b) + (__umul24(pix, ld) + cc));
+        }
+    };
+    request();
     {
         // 8 threads per group reduce the chunk partials in a fixed order (deterministic), then an 8-lane shuffle tree
         const int g = tid >> 3, l8 = tid & 7;
@@ -129,42 +174,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
         s_shift[c] = beta[c] - s_mean[g] * sc;
     }
     __syncthreads();
-    // grid-stride walk over the (pixel, 8-channel vector) pairs of image b, two vectors per thread in flight.  The pair is advanced
-    // by the stride's quotient / remainder instead of dividing the linear index each time: the 64-bit divisions by the runtime VP
-    // were ~130 of the loop's 330 VALU instructions (23 of them quarter-rate multiplies) — static ISA review, docs/DESIGN_experiments.md.
-    const int stride = (int)gridDim.x * 256;                       // HW * C < 2^31, HW < 2^24 (launch_groupnorm)
-    const int sp = stride / VP, sr = stride - sp * VP;
-    const int sp2 = (2 * stride) / VP, sr2 = 2 * stride - sp2 * VP;
-    const int i_init = (int)blockIdx.x * 256 + tid;
-    int pix_u[2], cv_u[2];
-    unsigned iv[2] = {(unsigned)i_init, (unsigned)(i_init + stride)};      // linear vector index: the output offset is iv * 8
-    pix_u[0] = i_init / VP; cv_u[0] = i_init - pix_u[0] * VP;
-    pix_u[1] = pix_u[0] + sp; cv_u[1] = cv_u[0] + sr;
-    if (cv_u[1] >= VP) { cv_u[1] -= VP; ++pix_u[1]; }
-    const half_t* x0b = x0 + (long)b * HW * c0;
-    const half_t* x1b = x1 ? x1 + (long)b * HW * c1 : nullptr;
-    [[maybe_unused]] const half_t* l0b = HILO ? l0 + (long)b * HW * c0 : nullptr;
-    [[maybe_unused]] const half_t* l1b = (HILO && l1) ? l1 + (long)b * HW * c1 : nullptr;
-    half_t* outb = out + (long)b * HW * C;
-    while (pix_u[0] < HW) {
-        h8 v[2];
-        [[maybe_unused]] h8 lv[2];
-        int cs[2];
-        bool ok[2];
+    while (true) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            ok[u] = pix_u[u] < HW;
-            const unsigned pix = ok[u] ? (unsigned)pix_u[u] : 0u;
-            const int c = (ok[u] ? cv_u[u] : 0) * 8;
-            cs[u] = c;
-            const half_t* src;
-            unsigned cc, ld;
-            if (c < c0) { src = x0b; cc = (unsigned)c; ld = (unsigned)c0; } else { src = x1b; cc = (unsigned)(c - c0); ld = (unsigned)c1; }
-            v[u] = *reinterpret_cast<const h8*>(src + (__umul24(pix, ld) + cc));
-            if constexpr (HILO) lv[u] = *reinterpret_cast<const h8*>((c < c0 ? l0b : l1b) + (__umul24(pix, ld) + cc));
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
             const f4 sa = *reinterpret_cast<const f4*>(&s_scale[cs[u]]), sb = *reinterpret_cast<const f4*>(&s_scale[cs[u] + 4]);
             const f4 ha = *reinterpret_cast<const f4*>(&s_shift[cs[u]]), hb = *reinterpret_cast<const f4*>(&s_shift[cs[u] + 4]);
@@ -172,18 +184,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float sc = e < 4 ? sa[e] : sb[e - 4], sh = e < 4 ? ha[e] : hb[e - 4];
-                float y = fmaf(HILO ? (float)v[u][e] + (float)lv[u][e] : (float)v[u][e], sc, sh);
+                float y = fmaf(HILO ? (float)v[u][e] + (float)lv[HILO ? u : 0][e] : (float)v[u][e], sc, sh);
                 if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
                 o[e] = (half_t)y;
             }
             *reinterpret_cast<h8*>(outb + iv[u] * 8u) = o;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            iv[u] += 2u * (unsigned)stride;
-            pix_u[u] += sp2; cv_u[u] += sr2;
+        for (int u = 0; u < U; ++u) {
+            iv[u] += (unsigned)(U * stride);
+            pix_u[u] += spU; cv_u[u] += srU;
             if (cv_u[u] >= VP) { cv_u[u] -= VP; ++pix_u[u]; }
         }
+        if (pix_u[0] >= HW) break;
+        request();
     }
 }
 
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const half_t* x0, c
     }
 }
 
+int g_gn_apply_blocks = 0;
 int g_gn_small = [] { const char* e = getenv("SDMI_GN_SMALL"); return e ? atoi(e) : 1; }();
 
 static inline int gn_chunks(int B, int HW) {
@@ -311,14 +326,21 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
         SDMI_CHECK_HIP(hipGetLastError());
     }
     const long nvec = (long)HW * (C / 8);
-    // >= 16 vectors per thread so the per-workgroup prologue (partials -> mean/rstd -> per-channel scale/shift in LDS) is
-    // amortised, while keeping ~4 workgroups per CU in flight
-    int blocks = (int)std::max<long>(1, std::min<long>(nvec / (256 * 16), std::max(1, 1024 / B)));
+    // Whole trips of 8 vectors per thread (a ragged last trip costs a full load latency for a fraction of the bytes), as few of them as
+    // ~8 workgroups per CU over the batch allow: one trip for every UNet tensor of the benchmarked job.  The first trip's loads overlap
+    // the prologue.  (Tried: fewer, longer-lived workgroups so that each streams >= 4x the bytes its prologue reads — the chunk partials of
+    // its image + gamma / beta, 16 + 15 KB at C = 1920 with 64 chunks: slower, 1.28 -> 1.34 ms of GroupNorm per forward; the trips are
+    // dependent and the prologues of co-resident workgroups overlap.)
+    const long cap = std::max(1, 2048 / B);
+    const long trips = std::max<long>(1, cdiv(nvec, 2048 * cap));
+    int blocks = (int)std::max<long>(1, cdiv(nvec, 2048 * trips));
+    if (g_gn_apply_blocks > 0) blocks = g_gn_apply_blocks;       // tests: several trips per thread on a small tensor
+    const size_t smem = (size_t)2 * C * sizeof(float);
     if (hilo)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
+        hipLaunchKernelGGL((gn_apply_kernel<true, 4>), dim3(blocks, B), dim3(256), smem, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
                            beta, out, eps, silu ? 1 : 0, x0_lo, x1_lo);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(blocks, B), dim3(256), 0, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
+        hipLaunchKernelGGL((gn_apply_kernel<false, 8>), dim3(blocks, B), dim3(256), smem, s, x0, x1, c0, c1, HW, groups, nchunk, ws, gamma,
                            beta, out, eps, silu ? 1 : 0, nullptr, nullptr);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;

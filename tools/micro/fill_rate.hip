@@ -69,7 +69,73 @@ static void run(const char* name, const char* buf, size_t bytes, int waves, int 
            total / wgs / (ms * 1e6));
 }
 
-int main() {
+// read + write streams (what a normalisation kernel is): out[i] = in[i] over `bytes`, 16 bytes per lane, `per_wg` bytes per workgroup
+// visit, grid-stride over the tensor (a one-shot grid when wgs * per_wg >= bytes).  UNROLL loads are issued before the first store.
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void copy_kernel(const f4v* __restrict__ in, f4v* __restrict__ out, size_t n16, int per_wg16) {
+    const size_t stride = (size_t)gridDim.x * per_wg16;
+    for (size_t base = (size_t)blockIdx.x * per_wg16; base < n16; base += stride) {
+        for (int i = threadIdx.x; i < per_wg16; i += 256 * UNROLL) {
+            f4v v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const size_t j = base + i + u * 256;
+                if (i + u * 256 < per_wg16 && j < n16) v[u] = NT ? __builtin_nontemporal_load(in + j) : in[j];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const size_t j = base + i + u * 256;
+                if (i + u * 256 < per_wg16 && j < n16) {
+                    if (NT) __builtin_nontemporal_store(v[u], out + j); else out[j] = v[u];
+                }
+            }
+        }
+    }
+}
+
+template <int UNROLL, bool NT>
+static void run_copy(const char* name, const f4v* in, f4v* out, size_t bytes, int wgs, int per_wg_bytes) {
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    const size_t n16 = bytes / 16;
+    if (wgs == 0) wgs = (int)((bytes + per_wg_bytes - 1) / per_wg_bytes);
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        HIP_OK(hipEventRecord(e0));
+        hipLaunchKernelGGL((copy_kernel<UNROLL, NT>), dim3(wgs), dim3(256), 0, 0, in, out, n16, per_wg_bytes / 16);
+        HIP_OK(hipEventRecord(e1));
+        HIP_OK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    printf("  %-28s %6d workgroups x %6d B per visit, %d loads ahead  %7.1f us  %5.2f TB/s (read + write)\n", name, wgs, per_wg_bytes, UNROLL, best * 1e3,
+           2.0 * bytes / best * 1e-9);
+}
+
+static void copies() {
+    for (size_t mb : {21, 42, 84, 168}) {
+        const size_t bytes = mb << 20;
+        f4v *in, *out;
+        HIP_OK(hipMalloc(&in, bytes)); HIP_OK(hipMalloc(&out, bytes));
+        HIP_OK(hipMemset(in, 1, bytes)); HIP_OK(hipMemset(out, 0, bytes));
+        printf("copy of %zu MB (the tensor was written by the previous launch: cache state of a consumer)\n", mb);
+        run_copy<1, false>("one-shot", in, out, bytes, 0, 10240);
+        run_copy<1, false>("one-shot", in, out, bytes, 0, 16384);
+        run_copy<4, false>("one-shot", in, out, bytes, 0, 16384);
+        run_copy<4, false>("one-shot", in, out, bytes, 0, 65536);
+        run_copy<4, false>("grid-stride", in, out, bytes, 1024, 16384);
+        run_copy<4, false>("grid-stride", in, out, bytes, 2048, 16384);
+        run_copy<4, false>("grid-stride", in, out, bytes, 2048, 65536);
+        run_copy<8, false>("grid-stride", in, out, bytes, 2048, 32768);
+        run_copy<4, true>("grid-stride, nontemporal", in, out, bytes, 2048, 16384);
+        HIP_OK(hipFree(in)); HIP_OK(hipFree(out));
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'c') { copies(); return 0; }
     float* sink;
     HIP_OK(hipMalloc(&sink, 64));
     const size_t sizes[] = {(size_t)2 << 20, (size_t)64 << 20, (size_t)1 << 30};
