@@ -434,6 +434,55 @@ def test_wide_epilogue_is_bit_identical_to_the_8_byte_epilogue(dev, cfg, pipe):
     assert rel_l2(outs[1][0].float().cpu(), ref) < 6e-4
 
 
+LEAN_WALK_CASES = [
+    # cfg, B, H, W, c0, c1, cout, taps, split
+    (7, 2, 32, 32, 320, 0, 640, 1, 0),          # 128x64 two-stage, linear walk
+    (7, 3, 10, 10, 192, 64, 128, 1, 0),         # two sources, ragged M
+    (12, 2, 16, 16, 1280, 0, 1280, 1, 0),       # 128x64 ring of 3 (the tuned choice of the 8x8-level linear layers): 20 K steps through the ring
+    (13, 2, 16, 16, 2560, 0, 1280, 1, 4),       # 128x160 ring of 3, split-K 4
+    (10, 1, 32, 32, 1280, 0, 1280, 1, 0),       # 128x160 ring of 4
+    (11, 1, 32, 32, 640, 640, 640, 1, 0),       # 128x128 ring of 4, two sources
+    (0, 2, 24, 24, 128, 0, 128, 9, 0),          # 128x128 two-stage, lean 3x3 walk (the VAE's 128-channel convs)
+    (2, 1, 16, 16, 320, 0, 64, 9, 0),           # 64x64 (conv_out's tile), lean 3x3 walk
+    (7, 2, 12, 20, 128, 64, 320, 9, 0),         # 3x3, two sources, non-square
+]
+
+
+@pytest.mark.parametrize("case", LEAN_WALK_CASES)
+def test_lean_k_walks_and_ring_tiles_give_the_bits_of_the_general_gather(dev, case):
+    """Round 5: 1x1 launches and plain 3x3 convs on the 4-wave tiles walk K with running pointers (gemm.hip LIN / LIN3), and the ring tiles
+    synchronise with a bare s_barrier under counted vmcnt waits — real asynchrony, which the CPU emulation of the kernel source cannot
+    order.  Same loads, same K order => the bits of the general gather (knob gemm_lin 0) and, for a ring tile, of its two-stage twin;
+    repeated launches must agree (a staging race shows as a changing tile)."""
+    ops, lib = sub("ops"), sub("_lib")
+    cfg, B, H, W, c0, c1, cout, taps, split = case
+    k = 3 if taps == 9 else 1
+    x0 = seeded((B, H, W, c0), 11)
+    x1 = seeded((B, H, W, c1), 12) if c1 else None
+    w = seeded((cout, c0 + c1, k, k), 13, scale=((c0 + c1) * k * k) ** -0.5)
+    b = seeded((cout,), 14, 0.1)
+    xin = torch.cat([x0, x1], dim=3) if c1 else x0
+    ref = _conv_ref(h(xin), h(w), b)
+    res = seeded(tuple(ref.shape), 15)
+    ref = ref + h(res)
+    wp = ops.pack_conv_weight(w.half().to(dev))
+    args = dict(a1=None if x1 is None else x1.half().to(dev), bias=ops.pack_bias(b.to(dev), wp.shape[0]), resid=res.half().to(dev), taps=taps)
+    twin = {12: 7, 13: 9, 10: 9, 11: 0}.get(cfg)
+    outs = []
+    try:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_split", split)); lib.check(lib.lib.sdmi_debug_set(b"conv_korder", 0))
+        for c, lin in ((cfg, 1), (cfg, 1), (cfg, 1), (cfg, 0)) + (((twin, 1),) if twin is not None else ()):
+            lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", c)); lib.check(lib.lib.sdmi_debug_set(b"gemm_lin", lin))
+            outs.append(ops.conv_gemm(x0.half().to(dev), wp, **args))
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_cfg", -1)); lib.check(lib.lib.sdmi_debug_set(b"gemm_split", 0))
+        lib.check(lib.lib.sdmi_debug_set(b"gemm_lin", 1)); lib.check(lib.lib.sdmi_debug_set(b"conv_korder", -1))
+    torch.cuda.synchronize()
+    assert rel_l2(outs[0].float().cpu(), ref) < 6e-4, case
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), case
+
+
 def test_mfma_glds_and_register_staging_agree_bitwise(dev):
     """Same LDS image, same MFMA order => identical bits; catches any mismatch in the LDS-direct load path."""
     ops = sub("ops")
