@@ -228,7 +228,9 @@ int sdmi_dpm_error_partials(const void* x_low_f32, const void* x_high_f32, const
 
 /* Latent upscale of the hires-fix pass: torch.nn.functional.interpolate(samples, size=(ho, wo), mode, antialias=False) on
  * `planes` = B*C fp32 planes of hi x wi (modules/processing.py:1392 with the "Latent*" upscalers of modules/shared.py:54-62).
- * mode: 0 "nearest", 1 "nearest-exact", 2 "bilinear", 3 "bicubic" (align_corners = False, ATen index arithmetic). */
+ * mode: 0 "nearest", 1 "nearest-exact", 2 "bilinear", 3 "bicubic" (align_corners = False, ATen index arithmetic); 4 / 5: bilinear /
+ * bicubic with antialias = True ("Latent (antialiased)", "Latent (bicubic antialiased)": ATen's separable area filter — windows that
+ * widen with the scale when shrinking, weights renormalised inside the image, Keys a = -0.5 for the cubic). */
 int sdmi_latent_resize(const void* in_f32, void* out_f32, int planes, int hi, int wi, int ho, int wo, int mode, void* stream);
 
 /* x = init*mask + nmask*x, all fp32 tensors of n elements: the inpainting blend CFGDenoiser applies before / after

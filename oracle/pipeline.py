@@ -203,12 +203,13 @@ def txt2img(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", c
 
 @torch.no_grad()
 def txt2img_hires(model: OracleModel, cond, uncond, seeds, steps, sampler="euler_a", cfg_scale=7.0, latent_hw=(64, 64),
-                  hr_scale=2.0, denoising_strength=0.75, mode="bilinear"):
-    """txt2img + latent hires fix (modules/processing.py:1349-1464): first pass, F.interpolate of the latent (not decoded),
-    fresh ImageRNG noise with the same seeds (:1429), second pass = sample_img2img with steps given (:1454)."""
+                  hr_scale=2.0, denoising_strength=0.75, mode="bilinear", antialias=False):
+    """txt2img + latent hires fix (modules/processing.py:1349-1464): first pass, F.interpolate of the latent (not decoded; mode and
+    antialias flag of the "Latent*" upscaler, modules/shared.py:55-62), fresh ImageRNG noise with the same seeds (:1429), second pass =
+    sample_img2img with steps given (:1454)."""
     first = sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, latent_hw)
     th, tw = int(latent_hw[0] * hr_scale), int(latent_hw[1] * hr_scale)
-    up = torch.nn.functional.interpolate(first, size=(th, tw), mode=mode, antialias=False)
+    up = torch.nn.functional.interpolate(first, size=(th, tw), mode=mode, antialias=antialias)
     return sample(model, cond, uncond, seeds, steps, sampler, cfg_scale, (th, tw), init_latent=up,
                   denoising_strength=denoising_strength, img2img_steps_given=True)
 

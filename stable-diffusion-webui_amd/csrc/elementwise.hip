@@ -332,6 +332,34 @@ __global__ __launch_bounds__(256) void latent_resize_kernel(const float* in, flo
             const float hy = 1.f - ly, hx = 1.f - lx;
             v = hy * (hx * src[(long)y0 * wi + x0] + lx * src[(long)y0 * wi + x1]) +
                 ly * (hx * src[(long)y1 * wi + x0] + lx * src[(long)y1 * wi + x1]);
+        } else if (mode >= 4) {
+            // antialias = True (modes 4 bilinear, 5 bicubic): torch's separable area filter — per axis the window of source samples within
+            // `support` = (interp size / 2) * max(scale, 1) of the output sample's centre scale * (i + 0.5), weights filter((j + 0.5 - centre)
+            // / max(scale, 1)) renormalised to sum 1 over the part of the window inside the image (no border replication); triangle
+            // filter for bilinear, Keys cubic with a = -0.5 for bicubic (the plain mode's is -0.75).  Shrinking widens the window with
+            // the scale; enlarging it is 2 / 4-5 samples.
+            const float half = mode == 4 ? 1.f : 2.f;
+            const float suy = half * fmaxf(sh, 1.f), sux = half * fmaxf(sw, 1.f);
+            const float ivy = sh >= 1.f ? 1.f / sh : 1.f, ivx = sw >= 1.f ? 1.f / sw : 1.f;
+            const float cyc = sh * ((float)y + 0.5f), cxc = sw * ((float)x + 0.5f);
+            const int ymin = max((int)(cyc - suy + 0.5f), 0), xmin = max((int)(cxc - sux + 0.5f), 0);
+            const int ysize = min((int)(cyc + suy + 0.5f), hi) - ymin, xsize = min((int)(cxc + sux + 0.5f), wi) - xmin;
+            auto filt = [&](float t) {
+                t = fabsf(t);
+                if (mode == 4) return t < 1.f ? 1.f - t : 0.f;
+                return t < 1.f ? cubic1(t, -0.5f) : (t < 2.f ? cubic2(t, -0.5f) : 0.f);
+            };
+            float wys = 0.f, wxs = 0.f;
+            for (int a = 0; a < ysize; ++a) wys += filt(((float)(a + ymin) - cyc + 0.5f) * ivy);
+            for (int b = 0; b < xsize; ++b) wxs += filt(((float)(b + xmin) - cxc + 0.5f) * ivx);
+            v = 0.f;
+            for (int a = 0; a < ysize; ++a) {
+                const float wy = filt(((float)(a + ymin) - cyc + 0.5f) * ivy) / wys;
+                float row = 0.f;
+                for (int b = 0; b < xsize; ++b)
+                    row = row + (filt(((float)(b + xmin) - cxc + 0.5f) * ivx) / wxs) * src[(long)(a + ymin) * wi + b + xmin];
+                v = v + wy * row;
+            }
         } else {
             const float A = -0.75f;
             const float fy = sh * ((float)y + 0.5f) - 0.5f, fx = sw * ((float)x + 0.5f) - 0.5f;
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(256) void latent_resize_kernel(const float* in, flo
     }
 }
 int launch_latent_resize(const float* in, float* out, int planes, int hi, int wi, int ho, int wo, int mode, hipStream_t s) {
-    SDMI_REQUIRE(mode >= 0 && mode <= 3 && planes > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, "latent_resize: bad arguments");
+    SDMI_REQUIRE(mode >= 0 && mode <= 5 && planes > 0 && hi > 0 && wi > 0 && ho > 0 && wo > 0, "latent_resize: bad arguments");
     const long n = (long)planes * ho * wo;
     hipLaunchKernelGGL(latent_resize_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, in, out, planes, hi, wi, ho, wo, mode);
     SDMI_CHECK_HIP(hipGetLastError());

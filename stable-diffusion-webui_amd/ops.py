@@ -254,14 +254,19 @@ def mask_blend(x: torch.Tensor, init: torch.Tensor, mask: torch.Tensor, nmask: t
     return x
 
 
-def latent_resize(x: torch.Tensor, size, mode: str = "bilinear") -> torch.Tensor:
-    """F.interpolate(x, size=size, mode=mode, antialias=False) for fp32 NCHW latents (modules/processing.py:1392)."""
+def latent_resize(x: torch.Tensor, size, mode: str = "bilinear", antialias: bool = False) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode=mode, antialias=antialias) for fp32 NCHW latents (modules/processing.py:1392; antialias with
+    the bilinear / bicubic modes only, as in torch)."""
     _lib.require_device()
     x = x.float().contiguous()
     b, c, hi, wi = x.shape
     ho, wo = int(size[0]), int(size[1])
     out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=x.device)
     code = {"nearest": 0, "nearest-exact": 1, "bilinear": 2, "bicubic": 3}[mode]
+    if antialias:
+        if mode not in ("bilinear", "bicubic"):
+            raise ValueError("antialias is defined for the bilinear and bicubic modes")     # torch raises the same way
+        code += 2
     check(lib.sdmi_latent_resize(ptr(x), ptr(out), b * c, hi, wi, ho, wo, code, stream_ptr()), "sdmi_latent_resize")
     return out
 

@@ -235,15 +235,9 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         """:1252-1305: target size, latent vs image-space upscaler."""
         if self.enable_hr:
             self.latent_scale_mode = {"Latent": "bilinear", "Latent (nearest)": "nearest", "Latent (bicubic)": "bicubic",
-                                      "Latent (nearest-exact)": "nearest-exact",
-                                      # antialias = True only changes F.interpolate when it SHRINKS: enlarging, the bilinear filter's support
-                                      # stays one source pixel and the result is the plain mode's (to fp32 rounding); checked in sample_hr_pass
-                                      "Latent (antialiased)": "bilinear"}.get(self.hr_upscaler)               # shared.py:54-62
-            if self.hr_upscaler == "Latent (bicubic antialiased)":
-                # torch's antialiased bicubic is another filter (Keys a = -0.5 instead of -0.75) even when enlarging: not what
-                # sdmi_latent_resize computes.  A named gap (DESIGN.md section 6), not a silent substitution.
-                raise NotImplementedError("hires upscaler 'Latent (bicubic antialiased)' is not implemented by the engine "
-                                          "(use 'Latent (bicubic)' or an image-space upscaler)")
+                                      "Latent (nearest-exact)": "nearest-exact", "Latent (antialiased)": "bilinear",
+                                      "Latent (bicubic antialiased)": "bicubic"}.get(self.hr_upscaler)       # shared.py:54-62
+            self.latent_scale_antialias = self.hr_upscaler in ("Latent (antialiased)", "Latent (bicubic antialiased)")
             if self.latent_scale_mode is None:
                 from . import upscaler
                 if not shared.sd_upscalers:
@@ -301,10 +295,9 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
         name = self.hr_sampler_name or self.sampler_name
         self.sampler = sd_samplers.create_sampler(name, self.sd_model)
         if self.latent_scale_mode is not None:
-            if self.hr_upscaler == "Latent (antialiased)" and (target_h // opt_f < samples.shape[2] or target_w // opt_f < samples.shape[3]):
-                raise NotImplementedError("'Latent (antialiased)' shrinking the first-pass latent: the antialiasing filter is not implemented")
-            # K16: [B,4,h,w] resample = F.interpolate(..., mode, antialias=False) (modules/processing.py:1392)
-            samples = ops.latent_resize(samples, (target_h // opt_f, target_w // opt_f), self.latent_scale_mode)
+            # K16: [B,4,h,w] resample = F.interpolate(..., mode, antialias) (modules/processing.py:1392)
+            samples = ops.latent_resize(samples, (target_h // opt_f, target_w // opt_f), self.latent_scale_mode,
+                                        antialias=getattr(self, "latent_scale_antialias", False))
             # :1395-1399 (at the default mask weight 1.0 the hires pass of an inpainting checkpoint is conditioned like txt2img)
             weight = self.inpainting_mask_weight if self.inpainting_mask_weight is not None else shared.opts.inpainting_mask_weight
             if weight < 1.0 and self._conditioning_key() in {'hybrid', 'concat'}:

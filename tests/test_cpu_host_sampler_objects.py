@@ -221,9 +221,8 @@ def test_ddim_txt2img_and_img2img_through_the_sampler_object(ss, monkeypatch, et
 
 
 def test_hires_init_resolves_upscaler_names_and_writes_the_infotext_keys():
-    """StableDiffusionProcessingTxt2Img.init (modules/processing.py:1213-1305): the six latent modes of shared.py:55-62 — the antialiased
-    bilinear one is the plain mode when enlarging, the antialiased bicubic one is a named gap, not a lookup error —, target size and
-    truncation arithmetic, the infotext keys."""
+    """StableDiffusionProcessingTxt2Img.init (modules/processing.py:1213-1305): the six latent modes of shared.py:55-62 (mode + the
+    antialias flag of the two antialiased ones), target size and truncation arithmetic, the infotext keys."""
     pr = sub("processing")
     p = pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_scale=1.5, hr_second_pass_steps=7, hr_sampler_name="DPM++ 2M",
                                             sampler_name="Euler a", width=512, height=768)
@@ -236,9 +235,14 @@ def test_hires_init_resolves_upscaler_names_and_writes_the_infotext_keys():
     p.init(None, None, None)
     # crop-to-fill: 512x768 -> 1024x1536, 512 rows cut = 64 latent rows (:1236-1250)
     assert (p.hr_upscale_to_x, p.hr_upscale_to_y, p.truncate_x, p.truncate_y, p.latent_scale_mode) == (1024, 1536, 0, 64, "bilinear")
+    assert p.latent_scale_antialias is True
     assert p.extra_generation_params["Hires resize"] == "1024x1024" and "Hires upscale" not in p.extra_generation_params
-    with pytest.raises(NotImplementedError, match="bicubic antialiased"):
-        pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler="Latent (bicubic antialiased)").init(None, None, None)
+    for name, (mode, aa) in {"Latent": ("bilinear", False), "Latent (antialiased)": ("bilinear", True), "Latent (bicubic)": ("bicubic", False),
+                             "Latent (bicubic antialiased)": ("bicubic", True), "Latent (nearest)": ("nearest", False),
+                             "Latent (nearest-exact)": ("nearest-exact", False)}.items():          # modules/shared.py:55-62, all six
+        q = pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler=name)
+        q.init(None, None, None)
+        assert (q.latent_scale_mode, q.latent_scale_antialias) == (mode, aa), name
     with pytest.raises(Exception, match="could not find upscaler"):
         pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler="No such upscaler").init(None, None, None)
     p = pr.StableDiffusionProcessingTxt2Img(sd_model=None, enable_hr=True, hr_upscaler="Lanczos")
@@ -291,7 +295,7 @@ def test_whole_standalone_job_with_hires_on_stub_devices(ss, monkeypatch):
             self.n += 1
             return torch.stack([seeded(self.shape, 100000 * self.n + s) for s in self.seeds])
     monkeypatch.setattr(processing, "ImageRNG", FakeRng)
-    monkeypatch.setattr(processing.ops, "latent_resize", lambda x, size, mode: torch.nn.functional.interpolate(x, size=size, mode=mode, antialias=False))
+    monkeypatch.setattr(processing.ops, "latent_resize", lambda x, size, mode, antialias=False: torch.nn.functional.interpolate(x, size=size, mode=mode, antialias=antialias))
     monkeypatch.setattr(processing, "decode_latent_batch", lambda m, x, **kw: x[:, :3].repeat_interleave(8, 2).repeat_interleave(8, 3))
     monkeypatch.setattr(processing.ops, "image_to_u8", lambda x: (x.clamp(-1, 1).add(1).mul(127.5)).to(torch.uint8).permute(0, 2, 3, 1).contiguous())
     monkeypatch.setattr(processing.sd_models, "apply_alpha_schedule_override", lambda m, p=None: None)

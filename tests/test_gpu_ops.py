@@ -651,6 +651,17 @@ def test_layernorm_vs_torch(dev, c):
 # ------------------------------------------------------------------------------------------------------------
 # sampler arithmetic
 # ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic"])
+@pytest.mark.parametrize("src,dst", [((64, 64), (128, 128)), ((16, 24), (25, 31)), ((40, 30), (24, 21)), ((96, 96), (20, 36))])
+def test_latent_resize_antialiased_matches_torch_interpolate(dev, mode, src, dst):
+    """"Latent (antialiased)" / "Latent (bicubic antialiased)": F.interpolate(..., antialias=True) (modules/shared.py:57, 59)."""
+    ops = sub("ops")
+    x = seeded((2, 4) + src, 61)
+    want = F.interpolate(x, size=dst, mode=mode, antialias=True)
+    got = ops.latent_resize(x.to(dev), dst, mode, antialias=True)
+    assert got.shape == want.shape and float((got.cpu() - want).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("mode", ["nearest", "nearest-exact", "bilinear", "bicubic"])
 @pytest.mark.parametrize("src,dst", [((64, 64), (128, 128)), ((16, 24), (25, 31)), ((40, 30), (24, 21))])
 def test_latent_resize_matches_torch_interpolate(dev, mode, src, dst):
