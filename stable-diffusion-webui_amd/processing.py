@@ -204,6 +204,7 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
     hr_c: Optional[torch.Tensor] = None              # hires prompt conditioning (calculate_hr_conds, :1468-1490); default: p.c / p.uc
     hr_uc: Optional[torch.Tensor] = None
     hr_sd_model: Any = None                          # hires checkpoint (:1253-1259, 1360-1361): another resident SdModel
+    firstpass_image: Any = None                      # a PIL image to run the hires pass ON instead of generating the first pass (:182, 1310-1332)
     hr_upscale_to_x: int = 0
     hr_upscale_to_y: int = 0
     truncate_x: int = 0
@@ -265,16 +266,30 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds, subseed_strength, prompts):
         """modules/processing.py:1307-1362"""
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
-        x = self.rng.next()
-        samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning,
-                                      image_conditioning=self.txt2img_image_conditioning(x))
-        del x
-        if not self.enable_hr:
-            return samples
-        decoded_samples = None
-        if self.latent_scale_mode is None:                   # image-space upscaler: the first pass is decoded (:1353-1354)
-            # decoded by the model that is loaded NOW (the refiner, if it switched in during the first pass): :1353-1354 use shared.sd_model
-            decoded_samples = decode_latent_batch(self.sampler.sd_model if self.sampler is not None else self.sd_model, samples)
+        if self.firstpass_image is not None and self.enable_hr:
+            # :1310-1332 — no first pass: the given picture is what the hires pass starts from.  Image-space upscalers take it as the
+            # "decoded first pass" in [-1, 1]; latent upscalers get its VAE encoding (images_tensor_to_samples, the 'Full' method: the
+            # engine has no approximate encoders)
+            if getattr(shared.opts, "sd_vae_encode_method", "Full") != "Full":
+                raise NotImplementedError(f"sd_vae_encode_method {shared.opts.sd_vae_encode_method!r}: the engine encodes with the full VAE only")
+            image = np.moveaxis(np.array(self.firstpass_image).astype(np.float32) / 255.0, 2, 0)
+            image = torch.from_numpy(np.expand_dims(image, 0)).to(self.sd_model.device, dtype=torch.float32)
+            image = ops.lincomb(torch.empty_like(image), [image, torch.ones_like(image)], [2.0, -1.0])        # image * 2 - 1
+            if self.latent_scale_mode is None:
+                samples, decoded_samples = None, image
+            else:
+                samples, decoded_samples = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(image)), None
+        else:
+            x = self.rng.next()
+            samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning,
+                                          image_conditioning=self.txt2img_image_conditioning(x))
+            del x
+            if not self.enable_hr:
+                return samples
+            decoded_samples = None
+            if self.latent_scale_mode is None:               # image-space upscaler: the first pass is decoded (:1353-1354)
+                # decoded by the model that is loaded NOW (the refiner, if it switched in during the first pass): :1353-1354 use shared.sd_model
+                decoded_samples = decode_latent_batch(self.sampler.sd_model if self.sampler is not None else self.sd_model, samples)
         first_model = self.sd_model
         if self.hr_sd_model is not None:                     # :1360-1361 reload_model_weights(hr_checkpoint_info): both stay resident
             self.sd_model = self.hr_sd_model
@@ -312,7 +327,7 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
             for x_sample in u8:
                 image = upscaler.resize_image(0, Image.fromarray(x_sample), target_w, target_h, upscaler_name=self.hr_upscaler)
                 batch_images.append(np.moveaxis(np.array(image).astype(np.float32) / 255.0, 2, 0))
-            decoded = torch.from_numpy(np.array(batch_images)).to(samples.device, dtype=torch.float32)
+            decoded = torch.from_numpy(np.array(batch_images)).to(decoded_samples.device, dtype=torch.float32)
             image = ops.lincomb(torch.empty_like(decoded), [decoded, torch.ones_like(decoded)], [2.0, -1.0])   # image * 2 - 1
             samples = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(image))          # :1421
             image_conditioning = self.img2img_image_conditioning(decoded, samples)       # (sic) the [0,1] image, as :1423 passes it

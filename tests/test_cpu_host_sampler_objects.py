@@ -331,6 +331,74 @@ def test_whole_standalone_job_with_hires_on_stub_devices(ss, monkeypatch):
     assert rel(res.latents[2:4], want) < 1e-5
 
 
+def test_firstpass_image_replaces_the_first_pass_of_a_hires_job(ss, monkeypatch):
+    """modules/processing.py:1310-1332: with p.firstpass_image set, no first pass is sampled — a latent upscaler gets the picture's VAE
+    encoding (images_tensor_to_samples: image * 2 - 1 through the full encoder), an image-space upscaler the picture itself as the
+    "decoded first pass" in [-1, 1]; the hires pass (resample / resize + encode, fresh noise, sample_img2img) is the ordinary one."""
+    import numpy as np
+    from PIL import Image
+    processing, shared, upscaler = sub("processing"), sub("shared"), sub("upscaler")
+    pool = torch.nn.AvgPool2d(8)
+    model = types.SimpleNamespace(engine=None, device=torch.device("cpu"), cond_stage_key="txt", model=types.SimpleNamespace(conditioning_key="crossattn"),
+                                  encode_first_stage=lambda img: pool(img),
+                                  get_first_stage_encoding=lambda m: torch.cat([m, m[:, :1]], 1).contiguous() * 0.5)
+    calls = []
+
+    class FakeSampler:
+        sd_model = model
+
+        def sample(self, *a, **kw):
+            raise AssertionError("the first pass must not be sampled")
+
+        def sample_img2img(self, p, x, noise, c, uc, steps=None, image_conditioning=None):
+            calls.append((x.clone(), noise.clone(), steps, image_conditioning))
+            return x + noise
+
+    class FakeRng:
+        def __init__(self, shape, seeds, **kw):
+            self.shape, self.seeds = tuple(shape), list(seeds)
+
+        def next(self):
+            return torch.stack([seeded(self.shape, 500 + sd) for sd in self.seeds])
+    monkeypatch.setattr(processing.sd_samplers, "create_sampler", lambda name, m: FakeSampler())
+    monkeypatch.setattr(processing, "ImageRNG", FakeRng)
+    monkeypatch.setattr(processing.ops, "lincomb", lambda out, ts, cs: sum(c * t for c, t in zip(cs, ts)))
+    monkeypatch.setattr(processing.ops, "latent_resize", lambda x, size, mode, antialias=False: torch.nn.functional.interpolate(x, size=size, mode=mode, antialias=antialias))
+    to_u8 = lambda x: (255.0 * torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0)).to(torch.uint8).permute(0, 2, 3, 1).contiguous()   # :1401-1406
+    monkeypatch.setattr(processing.ops, "image_to_u8", to_u8)
+    monkeypatch.setattr(shared.state, "interrupted", False, raising=False)
+    pic = Image.fromarray(np.random.default_rng(5).integers(0, 256, (64, 64, 3), dtype=np.uint8))
+    as_tensor = torch.from_numpy(np.moveaxis(np.array(pic).astype(np.float32) / 255.0, 2, 0)[None])
+    # latent upscaler: encode, resample the latent
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, seed=7, batch_size=1, steps=6, width=64, height=64, enable_hr=True, hr_scale=2.0,
+                                                    hr_upscaler="Latent (bicubic antialiased)", hr_second_pass_steps=4, firstpass_image=pic)
+    p.seeds, p.iteration = [7], 0
+    p.init(None, None, None)
+    out = p.sample(seeded((1, 8, 6), 1), seeded((1, 8, 6), 2), [7], [0], 0.0, ["x"])
+    enc = model.get_first_stage_encoding(model.encode_first_stage(as_tensor * 2 - 1))
+    want_x = torch.nn.functional.interpolate(enc, size=(16, 16), mode="bicubic", antialias=True)
+    x, noise, steps, ic = calls.pop()
+    assert torch.allclose(x, want_x, atol=1e-6) and steps == 4 and tuple(noise.shape) == (1, 4, 16, 16) and torch.equal(out, x + noise)
+    # image-space upscaler: the picture is the decoded first pass
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, seed=7, batch_size=1, steps=6, width=64, height=64, enable_hr=True, hr_scale=2.0,
+                                                    hr_upscaler="Lanczos", firstpass_image=pic)
+    p.seeds, p.iteration = [7], 0
+    p.init(None, None, None)
+    p.sample(seeded((1, 8, 6), 1), seeded((1, 8, 6), 2), [7], [0], 0.0, ["x"])
+    # (the picture goes through the reference's own round trip first: [-1, 1] floats back to truncated uint8, :1401-1406)
+    big = upscaler.resize_image(0, Image.fromarray(to_u8(as_tensor * 2 - 1)[0].numpy()), 128, 128, upscaler_name="Lanczos")
+    big = torch.from_numpy(np.moveaxis(np.array(big).astype(np.float32) / 255.0, 2, 0)[None])
+    x, noise, steps, ic = calls.pop()
+    assert torch.allclose(x, model.get_first_stage_encoding(model.encode_first_stage(big * 2 - 1)), atol=1e-6) and steps == 6
+    # without hires the picture is ignored (:1310's condition)
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=model, seed=7, batch_size=1, steps=6, width=64, height=64, firstpass_image=pic)
+    p.seeds, p.iteration = [7], 0
+    p.rng = FakeRng((4, 8, 8), [7])
+    p.init(None, None, None)
+    with pytest.raises(AssertionError, match="first pass must not be sampled"):
+        p.sample(seeded((1, 8, 6), 1), seeded((1, 8, 6), 2), [7], [0], 0.0, ["x"])
+
+
 def test_whole_standalone_img2img_job_with_a_latent_mask_on_stub_devices(ss, monkeypatch):
     """process_images -> StableDiffusionProcessingImg2Img.init / sample -> sample_img2img -> CFGDenoiser with the inpainting blends
     (modules/sd_samplers_cfg_denoiser.py:292-293 per step, modules/processing.py:1776-1784 at the end), the initial-noise multiplier, the
