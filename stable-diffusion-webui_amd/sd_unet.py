@@ -71,14 +71,14 @@ class Mi355xUnet(SdUnet):
         self._ctx_key = self._last_ctx = None
 
     def forward(self, x, timesteps, context, *args, **kwargs):
-        if kwargs.get("control") is not None or args:
-            raise NotImplementedError("extra UNet inputs (ControlNet residuals etc.) are not supported by the engine UNet")
         from . import shared
-        if shared.webui is not None:                          # ToMe / Hypertile patch the torch UNet this adapter replaces: refuse, never ignore
-            from .webui_bridge import patched_unet_reason, REFUSAL
+        if shared.webui is not None:                          # ToMe / Hypertile patch the torch UNet this adapter replaces: never ignored —
+            from .webui_bridge import patched_unet_reason     # the call goes to the patched torch UNet
             why = patched_unet_reason(getattr(shared.webui, "sd_model", None))
             if why is not None:
-                raise NotImplementedError(REFUSAL.format(why=why))
+                return self._torch_unet_forward(why, x, timesteps, context, *args, **kwargs)
+        if kwargs.get("control") is not None or args:
+            raise NotImplementedError("extra UNet inputs (ControlNet residuals etc.) are not supported by the engine UNet")
         if x.dtype not in (torch.float16, torch.float32):
             x = x.float()
         y = kwargs.get("y", None)
@@ -90,6 +90,29 @@ class Mi355xUnet(SdUnet):
         self.engine.set_context_cached(context)
         ctx = None
         return self.engine.unet_forward(x, timesteps, ctx, y)
+
+
+    def _torch_unet_forward(self, why, x, timesteps, context, *args, **kwargs):
+        """This one call through the webui's OWN UNet, with whatever patched it (tomesd around attn1, Hypertile's tiled self-attention)
+        in force.  modules/sd_unet.py:86-93 routes UNetModel.forward to ``current_unet`` while one is set, so the option steps aside for
+        the duration of the call; apply_unet parked the torch UNet on the CPU when the option was activated (:55), so it is brought back
+        to the device first (and stays: 288 GB of HBM hold both).  The mi355x cross-attention optimization keeps working inside it."""
+        from . import shared, webui_bridge
+        ref = webui_bridge.webui_sd_unet_module()
+        sd_model = getattr(shared.webui, "sd_model", None)
+        unet = getattr(getattr(sd_model, "model", None), "diffusion_model", None)
+        if ref is None or unet is None:
+            raise NotImplementedError(webui_bridge.REFUSAL.format(why=why))
+        first = next(unet.parameters(), None)
+        if first is not None and first.device != x.device:
+            unet.to(x.device)
+        self.torch_fallback_reason = why                      # what tests and the infotext hook can read back
+        saved = ref.current_unet
+        ref.current_unet = None
+        try:
+            return unet(x, timesteps, context, *args, **kwargs)
+        finally:
+            ref.current_unet = saved
 
 
 class Mi355xUnetOption(SdUnetOption):

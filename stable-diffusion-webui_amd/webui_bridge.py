@@ -142,22 +142,25 @@ def patched_unet_reason(sd_model):
     return None
 
 
-REFUSAL = ("{why}: it patches the torch UNet, which the [MI355X] SD Unet replaces. Set Settings -> SD Unet to None for this job "
-           "(the mi355x cross-attention optimization keeps working inside the torch UNet), or turn the feature off.")
+REFUSAL = ("{why}: it patches the torch UNet, which the [MI355X] SD Unet replaces, and the webui's torch UNet cannot be reached from here. "
+           "Set Settings -> SD Unet to None for this job (the mi355x cross-attention optimization keeps working inside the torch UNet), "
+           "or turn the feature off.")
+
+_webui_sd_unet = None
 
 
-def job_needs_stock_sampler(p):
-    """Per-job reasons (only ``p`` knows them, and ``p`` is not there yet when the row's constructor runs) to hand a sampling call to
-    the stock sampler: a refiner CHECKPOINT switch (modules/sd_samplers_common.py:158-202 reloads weights mid-job; the engine's own
-    refiner is a second resident engine the webui's p does not carry)."""
-    if getattr(p, "refiner_checkpoint_info", None) is not None and getattr(p, "refiner_sd_model", None) is None:
-        return "refiner checkpoint switch"
-    return None
+def webui_sd_unet_module():
+    """modules.sd_unet of the webui this package is bound to (install_samplers / install_lora_hook were handed it), else an imported one."""
+    if _webui_sd_unet is not None:
+        return _webui_sd_unet
+    import sys
+    return sys.modules.get("modules.sd_unet")
 
 
-def _check_job(p, sd_model):
-    """Raises for jobs the engine UNet cannot honour at all (ToMe / Hypertile, including the hires-pass ratios that are applied
-    after the sampler was built: modules/processing.py:1442)."""
+def job_needs_torch_unet(p, sd_model):
+    """Why this sampling call must run on the webui's torch UNet: ToMe / Hypertile patch it (including the hires-pass ratios that are
+    applied after the sampler was built: modules/processing.py:1442).  Such a call goes to the stock sampler, and every UNet evaluation
+    under it to the patched torch UNet (Mi355xUnet._torch_unet_forward) — SURVEY.md section 7 (vi): fall back, never ignore."""
     from . import shared
     why = patched_unet_reason(sd_model)
     if why is None and hasattr(p, "get_token_merging_ratio"):
@@ -167,19 +170,27 @@ def _check_job(p, sd_model):
         why = "Hypertile is enabled for the U-Net second pass"
     if why is None and getattr(shared.opts, "hypertile_enable_unet", False):
         why = "Hypertile is enabled for the U-Net"
-    if why is not None:
-        raise NotImplementedError(REFUSAL.format(why=why))
+    return why
+
+
+def job_needs_stock_sampler(p, sd_model=None):
+    """Per-job reasons (only ``p`` knows them, and ``p`` is not there yet when the row's constructor runs) to hand a sampling call to
+    the stock sampler: a refiner CHECKPOINT switch (modules/sd_samplers_common.py:158-202 reloads weights mid-job; the engine's own
+    refiner is a second resident engine the webui's p does not carry), or a torch UNet that ToMe / Hypertile patched."""
+    if getattr(p, "refiner_checkpoint_info", None) is not None and getattr(p, "refiner_sd_model", None) is None:
+        return "refiner checkpoint switch"
+    return job_needs_torch_unet(p, sd_model) if sd_model is not None else None
 
 
 def _engine_sampler_with_job_checks(engine_sampler, stock_ctor, model):
-    """``sample`` / ``sample_img2img`` of the engine sampler, preceded by the per-job checks; a job that needs the stock sampler
-    gets one built on the spot (same row, so same config) and the call is forwarded."""
+    """``sample`` / ``sample_img2img`` of the engine sampler, preceded by the per-job checks; a job that needs the stock sampler (refiner
+    checkpoint switch; ToMe / Hypertile on the torch UNet) gets one built on the spot (same row, so same config) and the call is
+    forwarded."""
     for name in ("sample", "sample_img2img"):
         fused = getattr(engine_sampler, name)
 
         def call(p, *args, _fused=fused, _name=name, **kwargs):
-            _check_job(p, model)
-            why = job_needs_stock_sampler(p)
+            why = job_needs_stock_sampler(p, model)
             if why is None:
                 return _fused(p, *args, **kwargs)
             stock = stock_ctor(model)
@@ -195,6 +206,8 @@ def install_samplers(webui_sd_samplers, sd_unet_module, script_callbacks=None) -
     engine sampler when the engine UNet is the active ``sd_unet.current_unet`` AND no per-step script callback is registered;
     the stock sampler otherwise."""
     from . import sd_samplers as amd, shared
+    global _webui_sd_unet
+    _webui_sd_unet = sd_unet_module
     replaced = []
     rows = list(webui_sd_samplers.all_samplers)
     for i, row in enumerate(rows):

@@ -1210,11 +1210,12 @@ def test_engine_samplers_read_the_webuis_own_opts_and_state(webui):
     assert amd_shared.opts.eta_ancestral == 1.0 and amd_shared.webui is None and amd_shared.MaskBlendArgs is not webui.scripts.MaskBlendArgs
 
 
-def test_engine_sampler_rows_fall_back_or_refuse_when_the_webui_job_needs_torch_side_hooks(webui):
-    """VERDICT r3 missing #1 / #2: a row builds the STOCK sampler while any cfg_denoiser / cfg_denoised / cfg_after_cfg / extra_noise
-    script callback is registered (modules/sd_samplers_cfg_denoiser.py:212, 279, 307; sd_samplers_kdiffusion.py:146-151); ToMe
-    (modules/sd_models.py:1011-1034) and Hypertile (extensions-builtin/hypertile) jobs are refused by the sampler AND by
-    Mi355xUnet.forward — never silently ignored; a refiner-checkpoint job is forwarded to a stock sampler built on the spot."""
+def test_engine_sampler_rows_fall_back_when_the_webui_job_needs_torch_side_hooks(webui):
+    """VERDICT r3 missing #1 / #2, r4 missing #6: a row builds the STOCK sampler while any cfg_denoiser / cfg_denoised / cfg_after_cfg /
+    extra_noise script callback is registered (modules/sd_samplers_cfg_denoiser.py:212, 279, 307; sd_samplers_kdiffusion.py:146-151); ToMe
+    (modules/sd_models.py:1011-1034) and Hypertile (extensions-builtin/hypertile) jobs are never silently ignored: the sampling call is
+    forwarded to a stock sampler built on the spot and every UNet evaluation under it goes to the webui's own — patched — torch UNet
+    (SURVEY.md section 7 (vi)); a refiner-checkpoint job is forwarded the same way."""
     import types
     ss, bridge = sub("sd_samplers"), sub("webui_bridge")
     webui.sd_unet.current_unet = webui.unet
@@ -1229,35 +1230,52 @@ def test_engine_sampler_rows_fall_back_or_refuse_when_the_webui_job_needs_torch_
     assert isinstance(row.constructor(model), ss.KDiffusionSampler)
     x = torch.zeros(1, 4, 8, 8)
 
-    def refused(p=None, **model_attrs):
+    # the webui's torch UNet, as modules/sd_unet.py:86-93 leaves it: forward goes to current_unet while one is set
+    seen = []
+
+    class TorchUnet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, x, timesteps=None, context=None, *args, **kwargs):
+            if webui.sd_unet.current_unet is not None:
+                return webui.sd_unet.current_unet.forward(x, timesteps, context, *args, **kwargs)
+            seen.append((tuple(x.shape), kwargs.get("y")))
+            return x + 1.0
+    model.model.diffusion_model = TorchUnet()
+
+    def forwarded(reason, p=None, **model_attrs):
+        """sample / sample_img2img of an engine row land in a stock sampler, with the reason noted"""
         s = row.constructor(model)
         s.config = row
         for k, v in model_attrs.items():
             setattr(model, k, v)
         try:
-            with pytest.raises(NotImplementedError, match="SD Unet to None"):
-                s.sample(p or _job(), x, None, None)
-            with pytest.raises(NotImplementedError, match="SD Unet to None"):
-                s.sample_img2img(p or _job(), x, x, None, None)
+            n = len(webui.stock_calls)
+            assert s.sample(p or _job(), x, None, None) == "stock-samples" and reason in s.stock_reason
+            assert s.sample_img2img(p or _job(), x, x, None, None) == "stock-samples" and len(webui.stock_calls) == n + 2
         finally:
             for k in model_attrs:
                 delattr(model, k)
-    # ToMe applied to the model (first pass: processing.py:841 runs before the sampler is built) ...
+    # ToMe applied to the model (first pass: processing.py:841 runs before the sampler is built): the UNet call reaches the torch UNet,
+    # with the option restored afterwards ...
     model.applied_token_merged_ratio = 0.5
-    with pytest.raises(NotImplementedError, match="token merging is active"):
-        webui.unet.forward(x, torch.zeros(1), torch.zeros(1, 77, 64))
+    out = model.model.diffusion_model(x, torch.zeros(1), torch.zeros(1, 77, 64), y=None)
+    assert torch.equal(out, x + 1.0) and seen == [((1, 4, 8, 8), None)] and webui.sd_unet.current_unet is webui.unet
+    assert "token merging is active" in webui.unet.torch_fallback_reason
     del model.applied_token_merged_ratio
-    refused(applied_token_merged_ratio=0.5)
+    forwarded("token merging is active", applied_token_merged_ratio=0.5)
     # ... or only requested for the hires pass (applied at processing.py:1442, AFTER the hires sampler was built)
-    refused(_job(is_hr_pass=True, get_token_merging_ratio=lambda for_hr=False: 0.3 if for_hr else 0.0))
+    forwarded("token merging is requested", _job(is_hr_pass=True, get_token_merging_ratio=lambda for_hr=False: 0.3 if for_hr else 0.0))
     # Hypertile: the options, and the live module flags hypertile_hook_model leaves on the torch UNet
     webui.shared.opts.hypertile_enable_unet = True
-    refused()
+    forwarded("Hypertile")
     webui.shared.opts.hypertile_enable_unet = False
     webui.shared.opts.hypertile_enable_unet_secondpass = True
-    refused(_job(is_hr_pass=True))
+    forwarded("second pass", _job(is_hr_pass=True))
     s_ok = row.constructor(model)                             # first pass of the same settings: nothing is tiled yet
-    assert bridge.patched_unet_reason(model) is None
+    assert bridge.patched_unet_reason(model) is None and bridge.job_needs_stock_sampler(_job(), model) is None
     webui.shared.opts.hypertile_enable_unet_secondpass = False
     attn = torch.nn.Linear(2, 2)
     model.model.add_module("attn1", attn)
@@ -1266,8 +1284,13 @@ def test_engine_sampler_rows_fall_back_or_refuse_when_the_webui_job_needs_torch_
     assert not bridge.hypertile_unet_active(model)
     getattr(attn, "__webui_hypertile_params").enabled = True
     assert bridge.hypertile_unet_active(model) and "Hypertile" in bridge.patched_unet_reason(model)
-    with pytest.raises(NotImplementedError, match="Hypertile"):
+    assert torch.equal(webui.unet.forward(x, torch.zeros(1), torch.zeros(1, 77, 64)), x + 1.0) and len(seen) == 2
+    assert "Hypertile" in webui.unet.torch_fallback_reason and webui.sd_unet.current_unet is webui.unet
+    # a torch UNet that cannot be reached (no diffusion_model on the bound model) is still a loud refusal, never a silent engine run
+    saved, model.model.diffusion_model = model.model.diffusion_model, None
+    with pytest.raises(NotImplementedError, match="SD Unet to None"):
         webui.unet.forward(x, torch.zeros(1), torch.zeros(1, 77, 64))
+    model.model.diffusion_model = saved
     getattr(attn, "__webui_hypertile_params").enabled = False
     # refiner checkpoint: the stock sampler of the same row takes the call
     n_stock = len(webui.stock_calls)
