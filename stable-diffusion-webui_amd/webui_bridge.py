@@ -321,8 +321,9 @@ def install_clip_hook(sd_model, device_index: int = 0, lora_networks=None):
     ``encode_with_transformer``, penultimate layer), and both SDXL embedders — CLIP-L read at ``wrapped.layer`` / ``layer_idx``
     (sd_hijack_clip.py:369-377) and OpenCLIP-bigG with its pooled projection (sd_hijack_open_clip.py:57-66); the conditioner that
     concatenates them (modules/sd_models_xl.py:12-34) keeps calling the wrappers.  Token embeddings still come from the webui's
-    (textual-inversion patched) embedding layer and enter as ``inputs_embeds``.  Prompts with a text-encoder LoRA active on a tower are
-    encoded by that torch tower (``text_encoder_networks_active``): the packed tower never sees those deltas.
+    (textual-inversion patched) embedding layer and enter as ``inputs_embeds``.  A text-encoder LoRA on a tower is merged by the Lora
+    extension's own ``network_apply_weights`` (run over the tower's modules when the set of networks touching it changes) and the tower is
+    packed again from the merged weights; only a Lora extension without that entry point sends such prompts through the torch tower.
     Returns the encoder (one tower) or the list of encoders (SDXL), None when the checkpoint has no tower this engine knows."""
     from . import schema
     from .engine import Engine
@@ -336,41 +337,85 @@ def install_clip_hook(sd_model, device_index: int = 0, lora_networks=None):
         if hasattr(emb, "_mi355x_clip"):
             _unhook(emb)
         wrapped = emb.wrapped
-        if kind in ("clip_l", "clip_l_sdxl"):
-            cfg = schema.sd15_clip()
-            sd = {schema.CLIP_PREFIX + k.replace("token_embedding.wrapped.", "token_embedding."): v for k, v in tower.state_dict().items()}
-        else:
-            width = int(tower.ln_final.weight.shape[0])
-            cfg = schema.openclip_bigg() if width == 1280 else schema.openclip_h()
-            raw = {"m." + k: v for k, v in tower.state_dict().items()}
-            tew = raw.get("m.token_embedding.wrapped.weight")          # EmbeddingsWithFixes keeps the nn.Embedding as .wrapped
-            if tew is not None:
-                raw["m.token_embedding.weight"] = tew
-            sd = schema.openclip_to_transformers_keys(raw, "m.")
-        enc = Mi355xClipTextEncoder(Engine(device_index), cfg, sd, layer=getattr(wrapped, "layer", "last"),
-                                    layer_idx=getattr(wrapped, "layer_idx", None))
+
+        def packed_tower(kind=kind, tower=tower, wrapped=wrapped):
+            """The torch tower's CURRENT weights as an engine tower (whatever the Lora extension has merged into them included)."""
+            if kind in ("clip_l", "clip_l_sdxl"):
+                cfg = schema.sd15_clip()
+                sd = {schema.CLIP_PREFIX + k.replace("token_embedding.wrapped.", "token_embedding."): v for k, v in tower.state_dict().items()}
+            else:
+                width = int(tower.ln_final.weight.shape[0])
+                cfg = schema.openclip_bigg() if width == 1280 else schema.openclip_h()
+                raw = {"m." + k: v for k, v in tower.state_dict().items()}
+                tew = raw.get("m.token_embedding.wrapped.weight")          # EmbeddingsWithFixes keeps the nn.Embedding as .wrapped
+                if tew is not None:
+                    raw["m.token_embedding.weight"] = tew
+                sd = schema.openclip_to_transformers_keys(raw, "m.")
+            return Mi355xClipTextEncoder(Engine(device_index), cfg, sd, layer=getattr(wrapped, "layer", "last"),
+                                         layer_idx=getattr(wrapped, "layer_idx", None))
+        enc = packed_tower()
         emb._mi355x_clip = enc
+        emb._mi355x_clip_networks = ()                        # the text-encoder networks merged into the packed weights
         emb._torch_encode_with_transformers = emb.encode_with_transformers
 
-        def encode_with_transformers(tokens, emb=emb, enc=enc, kind=kind, tok_emb=tok_emb):
-            if text_encoder_networks_active(emb, lora_networks):
-                # The Lora extension applies text-encoder deltas lazily, inside the patched torch Linear / MultiheadAttention forwards
-                # (extensions-builtin/Lora/networks.py:411-480, 578-605) — forwards the packed tower never runs.  While a loaded network
-                # touches this text encoder with a non-zero multiplier, the prompt goes through the torch tower, deltas included.
-                return emb._torch_encode_with_transformers(tokens)
-            e = tok_emb(tokens)                               # EmbeddingsWithFixes: textual-inversion vectors spliced in
-            if kind == "clip_l":
-                return enc.encode_with_transformers(tokens, inputs_embeds=e)
-            if kind == "clip_l_sdxl":
-                return enc.encode_with_transformers_sdxl(tokens, inputs_embeds=e)
-            if kind == "openclip":
-                return enc.encode_with_transformer_openclip(tokens, inputs_embeds=e)
-            return enc.encode_with_transformer_openclip2(tokens, inputs_embeds=e)
+        def encode_with_transformers(tokens, emb=emb, kind=kind, tok_emb=tok_emb, tower=tower, packed_tower=packed_tower):
+            # The Lora extension applies text-encoder deltas lazily, inside the patched torch Linear / MultiheadAttention forwards
+            # (extensions-builtin/Lora/networks.py:411-480, 578-605) — forwards the packed tower never runs.  network_apply_weights
+            # (:411) is that application for ONE module: restore the backup, add every loaded network's delta IN PLACE, idempotent for
+            # an unchanged set.  When the set of networks touching this tower changes, it is run over the tower's modules here and the
+            # tower is packed again from the merged weights: the reference's own merge arithmetic, the engine's encoder.
+            wanted = text_encoder_networks_request(emb, lora_networks)
+            if wanted != emb._mi355x_clip_networks:
+                import sys
+                apply = getattr(lora_networks if lora_networks is not None else sys.modules.get("networks"), "network_apply_weights", None)
+                if apply is None:                             # a Lora extension without that entry point: the torch tower, deltas included
+                    return emb._torch_encode_with_transformers(tokens) if wanted else _engine_encode(emb._mi355x_clip, kind, tokens, tok_emb)
+                for module in tower.modules():
+                    if getattr(module, "network_layer_name", None) is not None:
+                        apply(module)
+                old = emb._mi355x_clip
+                emb._mi355x_clip = packed_tower()
+                emb._mi355x_clip_networks = wanted
+                if getattr(old, "engine", None) is not None:
+                    old.engine.close()
+            return _engine_encode(emb._mi355x_clip, kind, tokens, tok_emb)
         emb.encode_with_transformers = encode_with_transformers
         made.append(enc)
     if not made:
         return None
     return made[0] if len(made) == 1 else made
+
+
+def _engine_encode(enc, kind, tokens, tok_emb):
+    e = tok_emb(tokens)                                       # EmbeddingsWithFixes: textual-inversion vectors spliced in
+    if kind == "clip_l":
+        return enc.encode_with_transformers(tokens, inputs_embeds=e)
+    if kind == "clip_l_sdxl":
+        return enc.encode_with_transformers_sdxl(tokens, inputs_embeds=e)
+    if kind == "openclip":
+        return enc.encode_with_transformer_openclip(tokens, inputs_embeds=e)
+    return enc.encode_with_transformer_openclip2(tokens, inputs_embeds=e)
+
+
+def text_encoder_networks_request(cond_stage_model, lora_networks=None) -> tuple:
+    """(name, te_multiplier, dyn_dim) of every loaded network of the built-in Lora extension that touches ``cond_stage_model`` with a
+    non-zero text-encoder multiplier, in load order: what ``network_apply_weights`` merges into that tower's weights (() = none)."""
+    import sys
+    lora_networks = lora_networks if lora_networks is not None else sys.modules.get("networks")
+    loaded = getattr(lora_networks, "loaded_networks", None)
+    if not loaded:
+        return ()
+    mine, out = None, []
+    for net in loaded:
+        if not getattr(net, "te_multiplier", 0):
+            continue
+        for module in getattr(net, "modules", {}).values():
+            if mine is None:
+                mine = {id(m) for m in cond_stage_model.modules()} if hasattr(cond_stage_model, "modules") else set()
+            if id(getattr(module, "sd_module", None)) in mine:
+                out.append((getattr(net, "name", None), net.te_multiplier, getattr(net, "dyn_dim", None)))
+                break
+    return tuple(out)
 
 
 def text_encoder_networks_active(cond_stage_model, lora_networks=None) -> bool:

@@ -1488,13 +1488,40 @@ def test_clip_hook_binds_sd2_and_sdxl_text_towers(monkeypatch):
     emb_l.encode_with_transformers(tokens)
     emb_g.encode_with_transformers(tokens)
     assert encs[0].calls == [("clip_l_sdxl", (3, 77), (3, 77, 8))] and encs[1].calls == [("openclip2", (3, 77), (3, 77, 1280))]
-    # a text-encoder LoRA on the bigG tower: its prompts go through torch, CLIP-L stays on the engine
-    lora.loaded_networks = [types.SimpleNamespace(te_multiplier=0.8, modules={"lora_te2_x": types.SimpleNamespace(sd_module=g_inner.model.ln_final)})]
+    # a text-encoder LoRA on the bigG tower.  A Lora extension without network_apply_weights: its prompts go through torch, CLIP-L stays on
+    # the engine ...
+    lora.loaded_networks = [types.SimpleNamespace(name="style", te_multiplier=0.8, dyn_dim=None,
+                                                  modules={"lora_te2_x": types.SimpleNamespace(sd_module=g_inner.model.ln_final)})]
+    assert bridge.text_encoder_networks_request(emb_g, lora) == (("style", 0.8, None),) and bridge.text_encoder_networks_request(emb_l, lora) == ()
     emb_l.encode_with_transformers(tokens)
     assert emb_g.encode_with_transformers(tokens) == "torch"
     assert len(encs[0].calls) == 2 and len(encs[1].calls) == 1 and emb_g.stock_calls == [(3, 77)]
+    # ... with it (extensions-builtin/Lora/networks.py:411: restore the backup, add the loaded networks' deltas IN PLACE) the deltas are merged
+    # into the torch tower's weights once per change of the set, and the tower is packed again from them: the prompt stays on the engine
+    applied = []
+
+    def network_apply_weights(module):                        # what the stub merges: +1 on the layer the network names
+        applied.append(module)
+        if module is g_inner.model.ln_final:
+            with torch.no_grad():
+                module.weight.copy_(torch.full_like(module.weight, 2.0 if lora.loaded_networks else 1.0))
+    lora.network_apply_weights = network_apply_weights
+    g_inner.model.ln_final.network_layer_name = "1_model_ln_final"
+    n_made = len(made)
+    assert emb_g.encode_with_transformers(tokens).shape == (3, 77, 4) and emb_g.stock_calls == [(3, 77)]      # engine, not torch
+    merged = made[-1]
+    assert len(made) == n_made + 1 and applied == [g_inner.model.ln_final] and encs[1].engine.closed and emb_g._mi355x_clip is merged
+    assert float(merged.sd[schema.CLIP_PREFIX + "final_layer_norm.weight"].mean()) == 2.0 and merged.calls[-1][0] == "openclip2"
+    emb_g.encode_with_transformers(tokens)                    # same set of networks: no new merge, no new tower
+    assert len(made) == n_made + 1 and len(applied) == 1 and len(merged.calls) == 2
+    lora.loaded_networks = []                                 # the network is unloaded: weights restored through the same entry point, tower repacked
+    emb_g.encode_with_transformers(tokens)
+    assert len(made) == n_made + 2 and merged.engine.closed and float(made[-1].sd[schema.CLIP_PREFIX + "final_layer_norm.weight"].mean()) == 1.0
+    emb_l.encode_with_transformers(tokens)                    # the CLIP-L tower was never touched
+    assert emb_l._mi355x_clip is encs[0] and not encs[0].engine.closed
     # installing again replaces the towers (checkpoint reload), uninstall restores both wrappers
+    current = [emb_l._mi355x_clip, emb_g._mi355x_clip]
     encs2 = bridge.install_clip_hook(sdxl, lora_networks=lora)
-    assert encs[0].engine.closed and encs[1].engine.closed and encs2[0] is not encs[0]
+    assert all(e.engine.closed for e in current) and encs2[0] is not encs[0]
     bridge.uninstall_clip_hook(sdxl)
     assert emb_l.encode_with_transformers(tokens) == "torch" and all(e.engine.closed for e in encs2)
