@@ -638,6 +638,44 @@ def _gfx950_assembly(name, extra_flags=()):
     return _ASM_CACHE[name]
 
 
+def test_the_k_loops_of_the_4_wave_gemm_tiles_stay_lean():
+    """Round 5's finding kept as a rule.  The 4-wave tiles were bound by ISSUE, not by latency or bandwidth: the general gather rebuilt
+    every LDS-direct load's address per K step — 315 instructions around the 16 MFMAs of a 128x64 tile (2.5 workgroups per CU x 20 steps x
+    ~1400 issue cycles = the 30 us every tile, occupancy and prefetch depth had measured on M4096 N1280 K1280).  The running-pointer walks
+    (gemm.hip LIN for 1x1 launches, LIN3 for the plain 3x3 convs) must keep their K loops at a fraction of that; counted over the basic
+    blocks hipcc marks as loop bodies."""
+    import re
+    text = _gfx950_assembly("gemm")
+
+    def loop_instructions(kname):
+        body = re.search(r"^%s:[^\n]*\n(.*?)\.Lfunc_end" % re.escape(kname), text, re.S | re.M).group(1)
+        n = mfma = 0
+        inside = False
+        for line in body.split("\n"):
+            t = line.strip()
+            if not t:
+                continue
+            if t.startswith(".LBB") or t.startswith("; %bb."):
+                inside = "in Loop" in t or "Loop Header" in t
+                continue
+            if t.startswith((";", ".")):
+                continue
+            if inside:
+                n += 1
+                mfma += t.startswith("v_mfma")
+        return n, mfma
+    # tile -> (MFMAs per K step and wave, cap of the linear walk, cap of the lean 3x3 walk)       measured: 83 / 134, 113 / 166, 65 / 103
+    for tile, (per_step, cap_lin, cap_lin3) in {"Li128ELi64ELi4ELi1ELi64E": (16, 100, 160), "Li128ELi128ELi2ELi2ELi64E": (32, 135, 200),
+                                                "Li64ELi64ELi4ELi1ELi64E": (8, 80, 125)}.items():
+        base = "_ZN4sdmi16gemm_mfma_kernelI" + tile + "Lb1ELb0ELb0ELb0ELb0ELi0ELi2E"
+        general, m0 = loop_instructions(base + "Lb0ELb0EEEvNS_5GemmPE")
+        lin, m1 = loop_instructions(base + "Lb1ELb0EEEvNS_5GemmPE")
+        lin3, m2 = loop_instructions(base + "Lb0ELb1EEEvNS_5GemmPE")
+        assert m0 == m1 == m2 == per_step, (tile, m0, m1, m2)                  # the loop found IS the K loop, not unrolled
+        assert lin <= cap_lin and lin3 <= cap_lin3, (tile, lin, lin3)
+        assert general >= 1.4 * lin3 and general >= 2 * lin, (tile, general, lin, lin3)
+
+
 def test_kernels_compile_without_scratch_or_spills():
     """Code-object metadata of every kernel in csrc/*.hip: no private (scratch) segment, no VGPR / SGPR spills — a spill in the
     GEMM or attention loops costs more than any tuning gained (the first attention rewrite went to scratch through captured
