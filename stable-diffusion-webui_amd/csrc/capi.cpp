@@ -591,6 +591,7 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "gemm_pipe") g_gemm_pipe = value < 0 ? g_gemm_pipe_default : value;
     else if (n == "gemm_lin") g_gemm_lin = value < 0 ? 1 : value;
     else if (n == "gn_apply_blocks") g_gn_apply_blocks = value < 0 ? 0 : value;
+    else if (n == "gn_band_elems") g_gn_band_elems = value < 0 ? 0 : value;
     else if (n == "gemm_dbgflags") g_gemm_dbgflags = value & 0x1F00;
     else if (n == "gemm_dbg_lo") g_gemm_dbg = (g_gemm_dbg & 0xFFFFFFFF00000000ull) | (unsigned)value;
     else if (n == "gemm_dbg_hi") g_gemm_dbg = (g_gemm_dbg & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32);

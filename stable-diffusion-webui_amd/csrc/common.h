@@ -167,6 +167,7 @@ extern int g_conv_korder;           // 2 (default) row-shared walk where admitte
 extern int g_conv_korder_default;   // value restored by sdmi_debug_set("conv_korder", -1)
 extern int g_tile_order;            // -1 heuristic (default), 0 / 1 force
 extern int g_vt_mode;               // 1 (default): V^T through EP_TRANSPOSE on token-major tiles; 0: weights-as-rows GEMM (round 1)
+extern long g_gn_band_elems;      // tests: element count per image from which launch_groupnorm normalises in bands of rows (0 = 2^31)
 extern int g_gn_apply_blocks;     // tests: workgroups per image of gn_apply_kernel (0 = launch_groupnorm's own choice)
 extern int g_gemm_lin;              // 1 (default) = running-pointer K walk for 1x1 / linear launches on the 4-wave LDS-direct tiles
 extern int g_gemm_pipe;             // 0 = two-stage kernels only, 3 = ping-pong 256-row tiles, 4 = also 128x320 (default)

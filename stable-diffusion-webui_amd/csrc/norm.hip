@@ -287,7 +287,63 @@ static inline int gn_chunks(int B, int HW) {
     return n;
 }
 
-int64_t groupnorm_ws_bytes(int B, int HW, int groups) { return (int64_t)B * gn_chunks(B, HW) * groups * 2 * sizeof(float); }
+// Images beyond the 32-bit offsets of the kernels (HW * C >= 2^31 elements or HW >= 2^24 pixels: a 4096 x 4096 VAE decode at 128 channels)
+// are normalised in `nb` equal bands of rows (nb a power of two dividing HW): per (image, band) one statistics launch over the band as if it
+// were an image of its own, the partial sums of all bands of an image side by side in the workspace and scaled by 1 / nb (exact: a power
+// of two), so that the apply launches — again one per (image, band), each reducing ALL of the image's partials with the band's pixel count —
+// normalise with the image's mean and variance.  Host-side only: the kernels are the ones every other tensor runs.
+// g_gn_band_elems (tests): the element limit that triggers banding, so the path runs on small tensors too.
+long g_gn_band_elems = 0;
+static inline long gn_band_limit() { return g_gn_band_elems > 0 ? g_gn_band_elems : (1L << 31); }
+static inline int gn_row_limit() { return g_gn_band_elems > 0 ? (1 << 30) : (1 << 24); }
+static int gn_bands(int HW, int C) {                      // 1: no banding; 0: the image does not split
+    if ((long)HW * C < gn_band_limit() && HW < gn_row_limit()) return 1;
+    for (int nb = 2; nb <= 8192; nb *= 2)
+        if (HW % nb == 0 && (long)(HW / nb) * C < gn_band_limit() && HW / nb < gn_row_limit()) return nb;
+    return 0;
+}
+
+int64_t groupnorm_ws_bytes(int B, int HW, int groups) {
+    int64_t chunks = gn_chunks(B, HW);
+    if ((long)HW * 8 >= gn_band_limit() || HW >= gn_row_limit()) {          // may be banded for some C <= GN_MAX_C: room for the worst case
+        int nb = 2;
+        while (nb < 8192 && !((long)(HW / nb) * GN_MAX_C < gn_band_limit() && HW / nb < gn_row_limit())) nb *= 2;
+        chunks = std::max<int64_t>(chunks, (int64_t)nb * 64);
+    }
+    return (int64_t)B * chunks * groups * 2 * sizeof(float);
+}
+
+static int groupnorm_banded(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta, half_t* out, int B,
+                            int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int nb) {
+    const int C = c0 + c1, HWb = HW / nb;
+    const int nchunk_b = gn_chunks(1, HWb), rows = cdiv(HWb, nchunk_b), nchunk = nb * nchunk_b;
+    char pname[64];
+    snprintf(pname, sizeof pname, "groupnorm_silu_banded B%d HW%d C%d x%d", B, HW, C, nb);
+    ProfScope ps(pname, 0.0, 3.0 * B * (double)HW * C * 2.0, s);
+    const long per_image = (long)nchunk * groups * 2;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < nb; ++k) {
+            const long row0 = (long)b * HW + (long)k * HWb;
+            hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(nchunk_b, 1), dim3(256), 0, s, x0 + row0 * c0, x1 ? x1 + row0 * c1 : nullptr, c0, c1, HWb,
+                               groups, rows, ws + b * per_image + (long)k * nchunk_b * groups * 2, nullptr, nullptr);
+            SDMI_CHECK_HIP(hipGetLastError());
+        }
+    if (launch_axpby(ws, ws, 1.0f / (float)nb, nullptr, 0.f, (int64_t)B * per_image, s)) return 1;
+    const long nvec = (long)HWb * (C / 8);
+    const long trips = std::max<long>(1, cdiv(nvec, 2048L * 2048));
+    int blocks = (int)std::max<long>(1, cdiv(nvec, 2048 * trips));
+    if (g_gn_apply_blocks > 0) blocks = g_gn_apply_blocks;
+    const size_t smem = (size_t)2 * C * sizeof(float);
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < nb; ++k) {
+            const long row0 = (long)b * HW + (long)k * HWb;
+            hipLaunchKernelGGL((gn_apply_kernel<false, 8>), dim3(blocks, 1), dim3(256), smem, s, x0 + row0 * c0, x1 ? x1 + row0 * c1 : nullptr, c0, c1,
+                               HWb, groups, nchunk, ws + b * per_image, gamma, beta, out + row0 * C, eps, silu ? 1 : 0, nullptr, nullptr);
+            SDMI_CHECK_HIP(hipGetLastError());
+        }
+    return 0;
+}
+
 
 int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const float* gamma, const float* beta,
                      half_t* out, int B, int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int pre_nchunk,
@@ -297,7 +353,11 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
     SDMI_REQUIRE(!hilo || (pre_nchunk <= 0 && (x1 == nullptr) == (x1_lo == nullptr)), "GroupNorm (hi, lo) input: both sources, own statistics pass");
     SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
-    SDMI_REQUIRE((long)HW * C < (1L << 31) && HW < (1 << 24), "GroupNorm: HW * C must stay below 2^31 elements per image (32-bit offsets)");
+    if (const int nb = gn_bands(HW, C); nb != 1) {
+        SDMI_REQUIRE(nb > 1, "GroupNorm: an image of 2^31 elements or more must split into equal power-of-two bands of rows below that limit");
+        SDMI_REQUIRE(!hilo && pre_nchunk <= 0, "GroupNorm beyond 2^31 elements per image: fp16 input with its own statistics pass only");
+        return groupnorm_banded(x0, x1, c0, c1, gamma, beta, out, B, HW, groups, eps, silu, ws, s, nb);
+    }
     char pname[64];
     {
         const int cpg = C / groups;
