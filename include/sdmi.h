@@ -359,7 +359,11 @@ int64_t sdmi_engine_arena_bytes(sdmi_engine* e);
 int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value);   /* "force_generic", "glds", "trace" (activation taps),
                                                                                "tiling" (p.tiling: padded 3x3 convs wrap around, modules/sd_hijack.py:311-318),
                                                                                "vae_range_extend" (VAE decoder residual stream at 1/64 scale: the
-                                                                               engine's form of the fp16 -> fp32 VAE fallback, modules/processing.py:636-665) */
+                                                                               engine's form of the fp16 -> fp32 VAE fallback, modules/processing.py:636-665),
+                                                                               "cfg_pairs" / "uniform_t" (promises of the caller about the next forwards' x and t:
+                                                                               rows [Bn/2, Bn) repeat rows [0, Bn/2); one timestep for all rows),
+                                                                               "auto_promises" (both derived per forward from x and t by a synchronising compare:
+                                                                               for callers that cannot know), "fuse_rows", "residual_fp32"  */
 
 /* Activation taps for the parity error budget (tests/test_gpu_c1_parity.py): with option "trace" = 1 the engine records, by
  * the reference's module name ("input_blocks.4.1", "middle_block.1.transformer_blocks.0", "decoder.up.2.block.1", ...), the

@@ -638,6 +638,7 @@ int sdmi_engine_set_option(sdmi_engine* e, const char* name, int value) {
     else if (n == "tiling") e->tiling = value != 0;
     else if (n == "uniform_t") e->uniform_t = value != 0;
     else if (n == "cfg_pairs") e->cfg_pairs = value != 0;
+    else if (n == "auto_promises") e->auto_promises = value != 0;
     else if (n == "ln_fold") e->ln_fold = value;
     else if (n == "fuse_rows") e->fuse_rows = value;
     else if (n == "residual_fp32") e->residual_fp32 = value != 0;

@@ -1227,6 +1227,29 @@ int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, 
                          "option cfg_pairs is set but the timesteps of the two halves differ");
         }
     }
+    // Option "auto_promises": the same two facts DERIVED from the call's data, for a caller that cannot know them (the webui's stock CFG
+    // denoiser behind Mi355xUnet.forward hands over an anonymous batch): cfg_pairs / uniform_t hold for this call exactly if the compare
+    // says so, and are restored afterwards.  One synchronising copy of x and t per forward (1 MB at the C1 batch).
+    struct Restore {
+        sdmi_engine* e; bool pairs, uni, on;
+        ~Restore() { if (on) { e->cfg_pairs = pairs; e->uniform_t = uni; } }
+    } restore{e, e->cfg_pairs, e->uniform_t, e->auto_promises};
+    if (e->auto_promises) {
+        const size_t elt = io_dtype == SDMI_F16 ? 2 : 4;
+        const size_t half_bytes = (size_t)(Bn / 2) * e->unet.cfg.in_channels * h * w * elt;
+        std::vector<char> th((size_t)Bn * elt), xh(Bn % 2 == 0 && Bn >= 2 ? 2 * half_bytes : 0);
+        SDMI_CHECK_HIP(hipStreamSynchronize(s));
+        SDMI_CHECK_HIP(hipMemcpy(th.data(), t, th.size(), hipMemcpyDeviceToHost));
+        bool uni = true;
+        for (int b = 1; b < Bn && uni; ++b) uni = memcmp(th.data(), th.data() + (size_t)b * elt, elt) == 0;
+        bool pairs = uni && !xh.empty();
+        if (pairs) {
+            SDMI_CHECK_HIP(hipMemcpy(xh.data(), x, xh.size(), hipMemcpyDeviceToHost));
+            pairs = memcmp(xh.data(), xh.data() + half_bytes, half_bytes) == 0;
+        }
+        e->uniform_t = uni;
+        e->cfg_pairs = pairs;
+    }
     if (ctx) TRY(unet_set_context(e, ctx, io_dtype, Bn, L, s));
     // Option "streams" = n > 1: the rows of a call are independent (own timestep, own context rows), so the batch is cut into n
     // equal slices that run the same launch sequence on n HIP streams out of n arenas.  The GPU then always has a second, independent

@@ -221,6 +221,8 @@ struct sdmi_engine {
     long weights_epoch = 0;                   // bumped by every in-place weight / vector update: folded copies older than this are stale
     bool cfg_pairs = false;                   // rows [Bn/2, Bn) repeat the latent and timestep of rows [0, Bn/2): the layers in front of the first cross-attention run once (option "cfg_pairs")
     bool uniform_t = false;                   // every row of the call sits at the same timestep: the embedding path runs for one row (option "uniform_t")
+    bool auto_promises = false;               // option "auto_promises": cfg_pairs / uniform_t are DERIVED per call from x and t (a synchronising device -> host
+                                              // compare) instead of promised by the caller — for callers that cannot know: the stock CFG denoiser behind Mi355xUnet.forward
     bool tiling = false;                      // p.tiling: every padded 3x3 conv wraps around (modules/sd_hijack.py:311-318)
     // activation taps (parity error budget): with `trace` on, every block output of the last forward is recorded by name
     // — the arena never reuses memory within a forward, so the tensors stay readable until the next forward

@@ -182,7 +182,7 @@ class Engine:
 
     def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
                      y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, uniform_t: bool = False,
-                     cfg_pairs: bool = False) -> torch.Tensor:
+                     cfg_pairs: bool = False, auto_promises: bool = False) -> torch.Tensor:
         """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections.  ``uniform_t``: the
         caller guarantees that all rows share one timestep (the samplers' CFG batch): the timestep-embedding path then runs for one row
         (engine option "uniform_t"; same bits)."""
@@ -195,6 +195,12 @@ class Engine:
         if cfg_pairs != self._cfg_pairs:
             self.set_option("cfg_pairs", 1 if cfg_pairs else 0)
             self._cfg_pairs = cfg_pairs
+        # ``auto_promises``: the caller knows neither — the engine derives both from x and timesteps for this call (engine option
+        # "auto_promises": one synchronising device -> host compare per forward); for the stock CFG denoiser behind Mi355xUnet.forward
+        auto_promises = bool(auto_promises and CFG_PAIRS)
+        if auto_promises != getattr(self, "_auto_promises", False):
+            self.set_option("auto_promises", 1 if auto_promises else 0)
+            self._auto_promises = auto_promises
         x = x.contiguous()
         dt = x.dtype
         timesteps = timesteps.to(dt).contiguous()

@@ -89,7 +89,11 @@ class Mi355xUnet(SdUnet):
         # new rows with its cached fp16 copy in a kernel and predicates the re-projection launches on the result.
         self.engine.set_context_cached(context)
         ctx = None
-        return self.engine.unet_forward(x, timesteps, ctx, y)
+        # This adapter gets an anonymous batch from the webui's own CFG denoiser: whether it is [x | x] at one timestep (the plain CFG
+        # batch, for which the engine shares the layers in front of the first cross-attention) only the data says.  opts.mi355x_auto_cfg_pairs
+        # lets the engine look (a synchronising compare per evaluation; the engine's own samplers know and never need it).
+        auto = bool(getattr(shared.opts, "mi355x_auto_cfg_pairs", False))
+        return self.engine.unet_forward(x, timesteps, ctx, y, auto_promises=auto)
 
 
     def _torch_unet_forward(self, why, x, timesteps, context, *args, **kwargs):

@@ -66,6 +66,7 @@ class Options:
     auto_vae_precision: bool = True                # :182  ("Automatically revert VAE to 32-bit floats")
     disable_mmap_load_safetensors: bool = False    # :285
     sdmi_accuracy_mode: bool = False               # (engine option, not a webui setting) carry the UNet's residual stream with ~22 bits: sd_models.set_accuracy_mode
+    mi355x_auto_cfg_pairs: bool = False            # (engine option) Mi355xUnet.forward behind the webui's stock CFG denoiser: let the engine find the [x | x] batch itself (sd_unet.py)
 
 
 opts = Options()

@@ -103,6 +103,25 @@ def test_engine_promise_options_are_checkable(dev, tiny, monkeypatch):
     eng.unet_forward(xx, t, ctx, uniform_t=False, cfg_pairs=False)
 
 
+def test_engine_derives_the_cfg_batch_promises_itself_when_asked(dev, tiny):
+    """Engine option "auto_promises" (Mi355xUnet.forward behind the webui's stock CFG denoiser, opts.mi355x_auto_cfg_pairs): cfg_pairs /
+    uniform_t are derived from the call's x and t — a [x | x] batch at one timestep takes the shared-prefix path (the bits of the promised
+    form), anything else the per-row path (the bits of the plain call) —, and the caller's own settings are back afterwards."""
+    eng = tiny["model"].engine
+    x = seeded((2, 4, 16, 16), 3)
+    xx, t, ctx = torch.cat([x, x]).to(dev), torch.full((4,), 500.0).to(dev), tiny["cond"].to(dev)
+    plain = eng.unet_forward(xx, t, ctx)
+    promised = eng.unet_forward(xx, t, ctx, uniform_t=True, cfg_pairs=True)
+    auto = eng.unet_forward(xx, t, ctx, auto_promises=True)
+    assert torch.equal(auto, promised)
+    other = xx.clone()
+    other[3, 0, 0, 0] += 1.0                                   # not a repeated half any more: per-row, nothing overwritten
+    assert torch.equal(eng.unet_forward(other, t, ctx, auto_promises=True), eng.unet_forward(other, t, ctx))
+    ramp = torch.tensor([500.0, 400.0, 500.0, 400.0]).to(dev)     # halves repeat, but two timesteps: neither promise holds
+    assert torch.equal(eng.unet_forward(xx, ramp, ctx, auto_promises=True), eng.unet_forward(xx, ramp, ctx))
+    assert torch.equal(eng.unet_forward(xx, t, ctx), plain)       # option off again: the plain call's bits
+
+
 def test_unet_generic_and_mfma_paths_agree(dev, tiny):
     """Independent HIP implementations (MFMA+LDS vs one-thread-per-output) of every GEMM / attention in the UNet."""
     eng = tiny["model"].engine
