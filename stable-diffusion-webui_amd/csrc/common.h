@@ -121,12 +121,14 @@ struct GemmP {
     // per-row sums of its fp16-ROUNDED outputs over the tile's BN columns to lnp_out[(m * lnp_np + tile_n) * 2 + {0, 1}]
     float* lnp_out;
     int lnp_np;              // set by launch_gemm: N / BN of the chosen tile when the partials are produced, else 0
-    // Engine option "residual_fp32" (flag EP_HILO): the carried stream (ResBlock / transformer residual sums) as a (hi, lo) pair of fp16
-    // tensors, x = hi + lo with hi = fp16(x) and lo = fp16(x - hi): ~22 bits of the fp32 sum survive the store, every GEMM that takes
-    // the stream as its A operand reads hi alone (the MFMA operand is fp16 either way), norms and residual adds read both.  The two extra
-    // pointers travel in fields such a launch cannot use otherwise — out_lo in `splitk_ws` (no split-K), resid_lo in `lnp_out` (no
-    // LayerNorm partials): two more kernel-argument pointers cost the 256-row ping-pong instantiations 2-12 SGPR spills (round 5).
-    // Accessors: gemm_out_lo / gemm_resid_lo below.  launch_gemm then takes the 8-byte epilogue and no statistics epilogues.
+    // Engine option "residual_fp32" (flag EP_HILO): a tensor of the carried stream (ResBlock / transformer residual sums, the first conv's
+    // output) as a (hi, lo) pair of fp16 tensors, x = hi + lo with hi = fp16(x) and lo = fp16(x - hi): ~22 bits of the fp32 sum survive
+    // the store, every GEMM that takes the stream as its A operand reads hi alone (the MFMA operand is fp16 either way), norms and
+    // residual adds read both.  The two extra pointers travel in the fields of the LayerNorm-fold CONSUMER, which such a launch never is
+    // (a folded layer writes q / k / v / the GEGLU hidden tensor and carries no residual) — out_lo in `ln_stats`, resid_lo in `ln_s`:
+    // two more kernel-argument pointers cost the 256-row ping-pong instantiations 2-12 SGPR spills (round 5).  Accessors: gemm_out_lo /
+    // gemm_resid_lo below.  Round 6: split-K (the reduce pass carries the pair), the GroupNorm-statistics epilogue (sums of hi + lo) and
+    // the 16-byte epilogue all take (hi, lo) launches — round 5 routed them through the 8-byte epilogue without any of the three.
 };
 
 enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
@@ -139,13 +141,15 @@ enum { EP_OUT_F32 = 1, EP_GEGLU = 2, EP_NCHW = 4, EP_BIAS_ROW = 8,
        EP_DBG_NO_BAR_A = 0x100, EP_DBG_NO_BAR_B = 0x200, EP_DBG_NO_GLDS = 0x400, EP_DBG_NO_VMWAIT = 0x800,
        EP_DBG_NO_DSREAD = 0x1000,      // 0x100..0x1000: tuning experiments only (sdmi_debug_set "gemm_dbgflags"): results are wrong
        EP_LNFOLD = 0x4000,             // see GemmP::ln_stats
-       EP_HILO = 0x8000,               // (hi, lo) stream tensors: see GemmP (out_lo in splitk_ws, resid_lo in lnp_out)
+       EP_HILO = 0x8000,               // (hi, lo) stream tensors: see GemmP (out_lo in ln_stats, resid_lo in ln_s)
        EP_NARROW = 0x2000              // 8-byte epilogue accesses (set by launch_gemm when the 16-byte form's alignment rules fail, or
                                        // by the "ep_wide" knob): gemm_epilogue's swap16 note
      };
 
-__host__ __device__ inline half_t* gemm_out_lo(const GemmP& p) { return (p.flags & EP_HILO) ? reinterpret_cast<half_t*>(p.splitk_ws) : nullptr; }
-__host__ __device__ inline const half_t* gemm_resid_lo(const GemmP& p) { return (p.flags & EP_HILO) ? reinterpret_cast<const half_t*>(p.lnp_out) : nullptr; }
+__host__ __device__ inline half_t* gemm_out_lo(const GemmP& p) {
+    return (p.flags & EP_HILO) ? reinterpret_cast<half_t*>(const_cast<float*>(p.ln_stats)) : nullptr;
+}
+__host__ __device__ inline const half_t* gemm_resid_lo(const GemmP& p) { return (p.flags & EP_HILO) ? reinterpret_cast<const half_t*>(p.ln_s) : nullptr; }
 
 // stats_nchunk_out (optional): the number of row chunks per image of the GroupNorm partial sums written to p.stats_out, or 0 when the
 // launch could not produce them (split-K, a tile spanning two images, a group straddling column tiles ...)
@@ -275,7 +279,7 @@ int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int 
 
 // NCHW (f16|f32) * scale -> NHWC fp16 with channels zero-padded to cpad; optional 1x1 channel mix (pqc) first.
 int launch_nchw_to_nhwc(const void* x, int dtype, half_t* out, int B, int C, int HW, int cpad, float scale,
-                        const float* mix_w, const float* mix_b, hipStream_t s);
+                        const float* mix_w, const float* mix_b, hipStream_t s, bool lo_ch = false);
 // fp32 NCHW -> user dtype NCHW copy
 int launch_copy_out(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
 int launch_convert_to_f16(const void* src, int dtype, half_t* dst, int64_t n, hipStream_t s);
@@ -291,7 +295,8 @@ int launch_small_linear(const float* a, const half_t* w, const float* bias, cons
                         int N, int K, int lda, int ldo, bool silu_in, bool silu_out, hipStream_t s);
 // row softmax: in fp32 [rows, cols] -> out fp16 [rows, ldo] (zero-filled up to ldo)
 int launch_softmax_rows(const float* in, half_t* out, int64_t rows, int cols, int ldi, int ldo, hipStream_t s);
-// weight repack: OIHW (f16|f32) -> [O_pad][kh*kw][I_pad] fp16 (zero padded); geglu: permute output rows
+// weight repack: OIHW (f16|f32) -> [O_pad][kh*kw][I_pad] fp16 (zero padded); geglu bit 0: permute output rows; bit 1: input channels
+// [I, 2I) repeat [0, I) (the UNet's conv_in: launch_nchw_to_nhwc's lo channels)
 int launch_pack_conv_weight(const void* w, int dtype, half_t* out, int O, int I, int kh, int kw, int O_pad,
                             int I_pad, int geglu, hipStream_t s);
 // fp32 vector permute for GEGLU bias

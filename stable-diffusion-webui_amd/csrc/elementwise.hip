@@ -629,7 +629,7 @@ int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int 
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* x, half_t* out, int C, long HW, int cpad, float scale,
-                                                          const float* mix_w, const float* mix_b, long npix) {
+                                                          const float* mix_w, const float* mix_b, long npix, int lo_ch) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
         const long b = i / HW, pix = i - b * HW;
         float v[16];
@@ -645,19 +645,28 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* x, half_t* o
         } else {
             for (int c = 0; c < C; ++c) dst[c] = (half_t)v[c];
         }
-        for (int c = C; c < cpad; ++c) dst[c] = (half_t)0.f;
+        int cz = C;
+        if (lo_ch) {                                         // (hi, lo) input: what the fp16 rounding dropped, in channels [C, 2C)
+            for (int c = 0; c < C; ++c) dst[C + c] = (half_t)(v[c] - (float)(half_t)v[c]);
+            cz = 2 * C;
+        }
+        for (int c = cz; c < cpad; ++c) dst[c] = (half_t)0.f;
     }
 }
+// lo_ch (engine option "residual_fp32", UNet input): channels [C, 2C) of the output take fp16(x - fp16(x)); the packed conv_in weights
+// repeat their input channels there (launch_pack_conv_weight, flag bit 1), so the first conv sees the latent with ~22 bits — free: the
+// K dimension is padded to 64 either way, and with zeros in those channels (the default) the repeated weights contribute exactly 0.
 int launch_nchw_to_nhwc(const void* x, int dtype, half_t* out, int B, int C, int HW, int cpad, float scale, const float* mix_w,
-                        const float* mix_b, hipStream_t s) {
+                        const float* mix_b, hipStream_t s, bool lo_ch) {
     SDMI_REQUIRE(C <= 16 && cpad >= C, "nchw_to_nhwc: C <= 16");
+    SDMI_REQUIRE(!lo_ch || (2 * C <= cpad && !mix_w), "nchw_to_nhwc: the lo channels need room in the padding");
     const long npix = (long)B * HW;
     if (dtype == 0)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(ew_blocks(npix)), dim3(256), 0, s, (const half_t*)x, out, C, (long)HW,
-                           cpad, scale, mix_w, mix_b, npix);
+                           cpad, scale, mix_w, mix_b, npix, lo_ch ? 1 : 0);
     else
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_blocks(npix)), dim3(256), 0, s, (const float*)x, out, C, (long)HW,
-                           cpad, scale, mix_w, mix_b, npix);
+                           cpad, scale, mix_w, mix_b, npix, lo_ch ? 1 : 0);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -998,19 +1007,21 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const T* w, half_
         const int row = (int)(idx / ((long)I_pad * KK));
         // invert the row permutation: which source channel lands in `row`?
         int o = row;
-        if (geglu && row < O) {
+        if ((geglu & 1) && row < O) {
             const int g = row >> 6, r = row & 63;
             o = r < 32 ? g * 32 + r : O / 2 + g * 32 + (r - 32);
         }
         float v = 0.f;
-        if (o < O && i < I && row < O) v = (float)w[((long)o * I + i) * KK + tap];
+        const int is = ((geglu & 2) && i >= I && i < 2 * I) ? i - I : i;     // flag bit 1: input channels [I, 2I) repeat [0, I)
+        if (o < O && is < I && row < O) v = (float)w[((long)o * I + is) * KK + tap];
         out[idx] = (half_t)v;
     }
 }
 int launch_pack_conv_weight(const void* w, int dtype, half_t* out, int O, int I, int kh, int kw, int O_pad, int I_pad, int geglu,
                             hipStream_t s) {
     const long n = (long)O_pad * kh * kw * I_pad;
-    SDMI_REQUIRE(!geglu || (O % 64 == 0 && O_pad == O), "GEGLU packing needs O % 64 == 0");
+    SDMI_REQUIRE(!(geglu & 1) || (O % 64 == 0 && O_pad == O), "GEGLU packing needs O % 64 == 0");
+    SDMI_REQUIRE(!(geglu & 2) || 2 * I <= I_pad, "repeated input channels need room in the padding");
     if (dtype == 0)
         hipLaunchKernelGGL(pack_conv_weight_kernel<half_t>, dim3(ew_blocks(n)), dim3(256), 0, s, (const half_t*)w, out, O, I, kh * kw,
                            O_pad, I_pad, geglu);

@@ -53,13 +53,15 @@ struct Run {
     half_t* H(size_t n) { return (half_t*)ar->take(n * sizeof(half_t)); }
     // Option "residual_fp32": a tensor of the carried stream is a (hi, lo) pair of fp16 tensors, allocated back to back — S(n) takes
     // room for both, lo(p, n) is the second half (null when the option is off: every consumer then sees a plain fp16 tensor).
-    bool acc() const { return e->residual_fp32; }
+    // (the pairs need the LDS-direct MFMA kernels: under force_generic / use_glds = 0 — cross-check settings — the forward falls back to
+    // the plain fp16 stream instead of failing the job)
+    bool acc() const { return e->residual_fp32 && !e->force_generic && e->use_glds; }
     half_t* S(size_t n) { return H(acc() ? 2 * n : n); }
     half_t* lo(const half_t* p, size_t n) const { return (acc() && p) ? const_cast<half_t*>(p) + n : nullptr; }
     // option "arena_reuse": a block's temporaries are released when the block returns — the next block's launches (same stream, so
     // ordered behind every reader) write over them while their lines are still in the 256 MB Infinity Cache, instead of every
     // activation of a forward (~10 GB) being written back to HBM once.  Not while block outputs are tapped or LayerNorm partials live.
-    bool reuse() const { return e->arena_reuse && !e->trace && !e->ln_fold && !e->residual_fp32; }
+    bool reuse() const { return e->arena_reuse && !e->trace && !e->ln_fold && !acc(); }
     float* F(size_t n) { return (float*)ar->take(n * sizeof(float)); }
     void tap(const std::string& name, const half_t* p, int B, int H, int W, int C) {
         if (!dry && e->trace) e->taps.push_back({name, p, B, H, W, C});
@@ -97,7 +99,7 @@ static const RawTensor* find_raw(const std::map<std::string, RawTensor>& m, cons
 
 // pack `names` (each a conv / linear "<name>.weight" [+ ".bias"]) stacked along the output dim into one ConvW
 static int pack_stack(sdmi_engine* e, const std::map<std::string, RawTensor>& m, const std::vector<std::string>& names,
-                      bool pad64, bool geglu, ConvW* out) {
+                      bool pad64, bool geglu, ConvW* out, bool dup_in = false) {
     int cin = -1, taps = -1, total = 0;
     bool any_bias = false;
     for (auto& n : names) {
@@ -132,11 +134,12 @@ static int pack_stack(sdmi_engine* e, const std::map<std::string, RawTensor>& m,
         const int O = (int)w->shape[0];
         const int Opad = (names.size() == 1) ? out->n_pad : O;
         const int kh = taps == 9 ? 3 : 1;
+        const int pflags = (geglu ? 1 : 0) | ((dup_in && 2 * cin <= out->cin_pad) ? 2 : 0);      // launch_pack_conv_weight's flag bits
         TRY(launch_pack_conv_weight(w->ptr, w->dtype, out->w + (size_t)row * taps * out->cin_pad, O, cin, kh, kh, Opad,
-                                    out->cin_pad, geglu ? 1 : 0, 0));
+                                    out->cin_pad, pflags, 0));
         if (e->recording_unet_sites)
             e->unet_sites[names[i] + ".weight"].push_back({out->w + (size_t)row * taps * out->cin_pad, O, cin, kh, Opad,
-                                                           out->cin_pad, geglu ? 1 : 0});
+                                                           out->cin_pad, pflags});
         const RawTensor* b = find_raw(m, names[i] + ".bias");
         if (b) TRY(launch_pack_bias(b->ptr, b->dtype, out->b + row, O, Opad, geglu ? 1 : 0, 0));
         if (b && e->recording_unet_sites) e->unet_vec_sites[names[i] + ".bias"].push_back({out->b + row, O, Opad, geglu ? 1 : 0});
@@ -145,8 +148,8 @@ static int pack_stack(sdmi_engine* e, const std::map<std::string, RawTensor>& m,
     return 0;
 }
 static int pack_one(sdmi_engine* e, const std::map<std::string, RawTensor>& m, const std::string& name, bool pad64,
-                    bool geglu, ConvW* out) {
-    return pack_stack(e, m, {name}, pad64, geglu, out);
+                    bool geglu, ConvW* out, bool dup_in = false) {
+    return pack_stack(e, m, {name}, pad64, geglu, out, dup_in);
 }
 static int pack_norm(sdmi_engine* e, const std::map<std::string, RawTensor>& m, const std::string& name, NormW* out) {
     const RawTensor* g = find_raw(m, name + ".weight");
@@ -283,7 +286,8 @@ static int unet_build(sdmi_engine* e) {
         std::vector<UNetLayer> blk;
         UNetLayer L;
         L.kind = UNetLayer::CONV_IN;
-        TRY(pack_one(e, m, "input_blocks.0.0", true, false, &L.conv));
+        // (input channels repeated into the zero padding: the accuracy mode feeds the latent's lo half there — launch_nchw_to_nhwc)
+        TRY(pack_one(e, m, "input_blocks.0.0", true, false, &L.conv, true));
         blk.push_back(L);
         u.input.push_back(blk);
     }
@@ -407,10 +411,10 @@ static int run_conv(Run& r, const ConvW& W, const ConvArgs& a) {
     p.rows_per_batch = a.Ho * a.Wo;
     p.n_real = a.n_real ? a.n_real : W.n_pad;
     p.flags = a.flags | (W.geglu ? EP_GEGLU : 0);
-    if (a.out_lo || a.resid_lo) {                          // (hi, lo) stream tensors ride in the split-K / LayerNorm-partial fields (GemmP, EP_HILO)
+    if (a.out_lo || a.resid_lo) {                          // (hi, lo) stream tensors ride in the LayerNorm-fold consumer's fields (GemmP, EP_HILO)
         p.flags |= EP_HILO;
-        p.splitk_ws = reinterpret_cast<float*>(a.out_lo);
-        p.lnp_out = reinterpret_cast<float*>(const_cast<half_t*>(a.resid_lo));
+        p.ln_stats = reinterpret_cast<const float*>(a.out_lo);
+        p.ln_s = reinterpret_cast<const float*>(a.resid_lo);
     }
     if (r.e->tiling && W.taps == 9 && a.pad == 1) p.flags |= EP_WRAP;    // Conv2d(padding=1, padding_mode='circular')
     p.alpha = a.alpha;
@@ -444,10 +448,9 @@ static int run_gn(Run& r, const NormW& n, const half_t* x0, const half_t* x1, in
     float* ws = r.F(groupnorm_ws_bytes(B, HW, 32) / sizeof(float));
     if (r.dry) return 0;
     SDMI_REQUIRE(n.c == c0 + c1, "GroupNorm channel mismatch");
-    if (x0_lo) return launch_groupnorm(x0, x1, c0, c1, n.g, n.b, out, B, HW, 32, eps, silu, ws, r.s, 0, x0_lo, x1_lo);
-    if (x1 == nullptr && r.st_nchunk > 0 && r.st_tensor == x0)      // the producing GEMM already summed this tensor
-        return launch_groupnorm(x0, nullptr, c0, 0, n.g, n.b, out, B, HW, 32, eps, silu, r.st_ws, r.s, r.st_nchunk);
-    return launch_groupnorm(x0, x1, c0, c1, n.g, n.b, out, B, HW, 32, eps, silu, ws, r.s);
+    if (x1 == nullptr && r.st_nchunk > 0 && r.st_tensor == x0)      // the producing GEMM already summed this tensor (hi + lo of a pair)
+        return launch_groupnorm(x0, nullptr, c0, 0, n.g, n.b, out, B, HW, 32, eps, silu, r.st_ws, r.s, r.st_nchunk, x0_lo, nullptr);
+    return launch_groupnorm(x0, x1, c0, c1, n.g, n.b, out, B, HW, 32, eps, silu, ws, r.s, 0, x0_lo, x1_lo);
 }
 static int run_ln(Run& r, const NormW& n, const half_t* x, int64_t rows, half_t* out, const half_t* x_lo = nullptr) {
     if (r.dry) return 0;
@@ -530,10 +533,16 @@ static int run_vt_ln(Run& r, const ConvW& Wv, const NormW& n, const half_t* x, c
 // `ss` (VAE range-extended decode only): the residual stream — x0 / x1 in, *out out — is stored multiplied by ss; GroupNorm is
 // scale-invariant once eps is multiplied by ss^2, the block-internal tensors stay at true scale, and the two layers that write the
 // stream scale their accumulator (alpha) and / or bias (bias_scale).
+// `hilo` (the UNet's calls under option "residual_fp32"): x0 / x1 and the output are (hi, lo) pairs of the carried stream, the lo half
+// `lo_rows` rows behind the hi half (0: the B * H * W rows of this call; unet_run's shared CFG prefix computes B = Bn / 2 rows of
+// buffers sized for Bn) — and so is the first conv's output, which only GroupNorm reads (every tensor that is not
+// a matrix-core operand keeps ~22 bits).
 static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, int c0, int c1, int B, int H, int Wd,
-                   float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f, half_t* out_buf = nullptr, bool hilo = false) {
+                   float eps, const float* embs, int emb_ld, half_t** out, float ss = 1.f, half_t* out_buf = nullptr, bool hilo = false,
+                   size_t lo_rows = 0) {
     const int HW = H * Wd;
     const size_t M = (size_t)B * HW;
+    const size_t LR = lo_rows ? lo_rows : M;
     // arena_reuse: what outlives the block — its output and the GroupNorm partial sums the last conv leaves for the next norm — is taken
     // first, everything after the mark is released on return
     const bool reuse = r.reuse();
@@ -541,22 +550,23 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
     float* st_pre = (reuse && ss == 1.f && w.cout % 32 == 0) ? r.F((size_t)B * 64 * 32 * 2) : nullptr;
     const size_t mk = r.ar->mark();
     // option "residual_fp32" (UNet only, ss == 1): x0 / x1 and the output are (hi, lo) pairs of the carried stream
-    const bool acc = hilo && r.acc() && ss == 1.f && !out_buf;               // (hilo: the UNet's calls; the VAE's tensors are plain fp16)
-    const half_t* x0_lo = acc ? r.lo(x0, M * c0) : nullptr;
-    const half_t* x1_lo = (acc && x1) ? r.lo(x1, M * c1) : nullptr;
+    const bool acc = hilo && r.acc() && ss == 1.f;                           // (hilo: the UNet's calls; the VAE's tensors are plain fp16)
+    const half_t* x0_lo = acc ? r.lo(x0, LR * c0) : nullptr;
+    const half_t* x1_lo = (acc && x1) ? r.lo(x1, LR * c1) : nullptr;
     half_t* t1 = r.H(M * w.cin);
     TRY(run_gn(r, w.n1, x0, x1, c0, c1, B, HW, eps * ss * ss, true, t1, x0_lo, x1_lo));
-    half_t* h1 = r.H(M * w.cout);
+    half_t* h1 = acc ? r.S(M * w.cout) : r.H(M * w.cout);
     {
         ConvArgs c;
         c.a0 = t1; c.c0 = w.cin; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
         if (embs) { c.rowbias = embs + w.emb_off; c.ldrb = emb_ld; }
         c.out = h1; c.ldo = w.cout;
+        c.out_lo = acc ? r.lo(h1, M * w.cout) : nullptr;
         c.stats_C = w.cout;                                   // h1 is read by norm2 only
         TRY(run_conv(r, w.c1, c));
     }
     half_t* t2 = r.H(M * w.cout);
-    TRY(run_gn(r, w.n2, h1, nullptr, w.cout, 0, B, HW, eps, true, t2));
+    TRY(run_gn(r, w.n2, h1, nullptr, w.cout, 0, B, HW, eps, true, t2, acc ? r.lo(h1, M * w.cout) : nullptr));
     const half_t* resid = x0;
     const half_t* resid_lo = x0_lo;
     if (w.has_skip) {
@@ -564,6 +574,7 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
         ConvArgs c;
         c.a0 = x0; c.a1 = x1; c.c0 = c0; c.c1 = c1; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd;
         c.out = sk; c.ldo = w.cout;
+        c.resid_lo = nullptr;
         c.out_lo = acc ? r.lo(sk, M * w.cout) : nullptr;      // the skip_connection output is part of the stream
         c.bias_scale = ss;                                    // the input already carries ss
         TRY(run_conv(r, w.skip, c));
@@ -577,7 +588,7 @@ static int run_res(Run& r, const ResW& w, const half_t* x0, const half_t* x1, in
         ConvArgs c;
         c.a0 = t2; c.c0 = w.cout; c.B = B; c.Hi = H; c.Wi = Wd; c.Ho = H; c.Wo = Wd; c.pad = 1;
         c.resid = resid; c.ldr = w.cout; c.out = o; c.ldo = w.cout;
-        c.resid_lo = resid_lo; c.out_lo = acc ? r.lo(o, M * w.cout) : nullptr;
+        c.resid_lo = resid_lo; c.out_lo = acc ? r.lo(o, (out_buf ? LR : M) * w.cout) : nullptr;
         c.alpha = ss; c.bias_scale = ss;
         c.stats_C = ss == 1.f ? w.cout : 0;                   // the block output usually feeds the next GroupNorm (ignored if not)
         c.stats_ws_pre = st_pre;
@@ -711,8 +722,8 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
     half_t* cur_pre = reuse ? r.H(M * C) : nullptr;
     half_t* pp[2] = {reuse ? r.H(M * C) : nullptr, (reuse && st.blocks.size() > 1) ? r.H(M * C) : nullptr};
     const size_t mk = r.ar->mark();
-    // option "residual_fp32": x, the token stream and the output are (hi, lo) pairs (Run::S / Run::lo); the fused chains, the LayerNorm
-    // fold and the shared CFG prefix are not combined with it (unet_run / below)
+    // option "residual_fp32": x, the token stream and the output are (hi, lo) pairs (Run::S / Run::lo); the fused chains and the
+    // LayerNorm fold are not combined with it
     const bool acc = r.acc();
     const size_t MC = M * C;
     half_t* n0 = r.H(M * C);
@@ -777,6 +788,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         TRY(run_linear(r, b.o1, a1, (int)M1, cur, x1, C, 1.f, false, r.lo(cur, MC), r.lo(x1, MC)));
         if (B1 != B) {                                       // end of the shared prefix: the other half of the batch continues from a copy
             if (!r.dry) SDMI_CHECK_HIP(hipMemcpyAsync(x1 + M1 * C, x1, M1 * C * sizeof(half_t), hipMemcpyDeviceToDevice, r.s));
+            if (!r.dry && acc) SDMI_CHECK_HIP(hipMemcpyAsync(x1 + MC + M1 * C, x1 + MC, M1 * C * sizeof(half_t), hipMemcpyDeviceToDevice, r.s));
             B1 = B; M1 = M;
         }
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
@@ -1044,7 +1056,10 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     // ---- input: NCHW -> NHWC fp16, channels zero-padded to the packed conv_in width ----------------------------
     const ConvW& cin_w = u.input[0][0].conv;
     half_t* xin = r.H((size_t)Bn * h * w * cin_w.cin_pad);
-    if (!r.dry) TRY(launch_nchw_to_nhwc(x, io_dtype, xin, Bn, c.in_channels, h * w, cin_w.cin_pad, 1.0f, nullptr, nullptr, r.s));
+    // (accuracy mode: an fp32 latent enters conv_in as a (hi, lo) pair in the zero-padded input channels — its fp16 rounding alone is
+    // 2.9e-4 of the first activation)
+    const bool xin_lo = r.acc() && io_dtype != SDMI_F16 && 2 * c.in_channels <= cin_w.cin_pad;
+    if (!r.dry) TRY(launch_nchw_to_nhwc(x, io_dtype, xin, Bn, c.in_channels, h * w, cin_w.cin_pad, 1.0f, nullptr, nullptr, r.s, xin_lo));
 
     std::vector<Act> hs;
     Act cur{nullptr, 0, h, w};
@@ -1054,13 +1069,15 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
     // block (SD1.x / 2.x: the largest self-attention launch of the forward) run for Bn / 2 rows and are copied (three 21 MB device copies
     // at the C1 batch against ~0.48 ms of kernels).  Same function; the fp32 summation order of those layers follows the halved M.
     // Not with a vector conditioning (label_emb(y) differs per row), taps, LayerNorm fold, hypernetworks, arena reuse or batch slices.
-    const bool pairs = e->cfg_pairs && !e->residual_fp32 && c.adm_in_channels == 0 && Bn % 2 == 0 && Bn >= 2 && !e->trace && !e->ln_fold && !r.reuse() &&
+    const bool pairs = e->cfg_pairs && c.adm_in_channels == 0 && Bn % 2 == 0 && Bn >= 2 && !e->trace && !e->ln_fold && !r.reuse() &&
                        e->hypernets.empty() && (r.Btot == 0 || r.Btot == Bn);
     const int Bh = Bn / 2;
     bool shared = pairs;                                     // cur.p: rows [0, Bh) computed, buffer sized for Bn rows
     auto dup = [&](const Act& a) -> int {                    // copy the computed half of a full-size activation to the other half
         const size_t n = (size_t)Bh * a.H * a.W * a.C;
         if (!r.dry) SDMI_CHECK_HIP(hipMemcpyAsync((half_t*)a.p + n, a.p, n * sizeof(half_t), hipMemcpyDeviceToDevice, r.s));
+        if (!r.dry && r.acc())                               // (hi, lo) pair: the lo half sits 2 n elements behind the hi half
+            SDMI_CHECK_HIP(hipMemcpyAsync((half_t*)a.p + 3 * n, a.p + 2 * n, n * sizeof(half_t), hipMemcpyDeviceToDevice, r.s));
         return 0;
     };
     auto run_block = [&](const std::vector<UNetLayer>& blk, const Act* skip, const std::string& bname) -> int {
@@ -1079,6 +1096,7 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                         ConvArgs a;
                         a.a0 = xin; a.c0 = Lr.conv.cin_pad; a.B = Bh; a.Hi = cur.H; a.Wi = cur.W; a.Ho = cur.H; a.Wo = cur.W;
                         a.pad = 1; a.out = o; a.ldo = Lr.conv.n_pad;
+                        a.out_lo = r.lo(o, (size_t)Bn * cur.H * cur.W * Lr.conv.n_pad);
                         TRY(run_conv(r, Lr.conv, a));
                         cur = Act{o, Lr.conv.cout, cur.H, cur.W};
                         break;
@@ -1098,8 +1116,9 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
                         SDMI_REQUIRE(cur.H == skip->H && cur.W == skip->W, "skip connection spatial mismatch");
                         TRY(run_res(r, Lr.res, cur.p, skip->p, cur.C, skip->C, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, nullptr, true));
                     } else if (shared) {
-                        half_t* full = r.H((size_t)Bn * cur.H * cur.W * Lr.res.cout);
-                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bh, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, full));
+                        half_t* full = r.S((size_t)Bn * cur.H * cur.W * Lr.res.cout);
+                        TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bh, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, full, true,
+                                    (size_t)Bn * cur.H * cur.W));
                     } else {
                         TRY(run_res(r, Lr.res, cur.p, nullptr, cur.C, 0, Bn, cur.H, cur.W, 1e-5f, embs, emb_ld, &o, 1.f, nullptr, true));
                     }

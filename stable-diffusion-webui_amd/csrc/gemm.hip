@@ -84,6 +84,125 @@ __device__ __forceinline__ void swap16(h4& x, h4& y) {
 }
 __device__ __forceinline__ h8 join8(h4 lo, h4 hi) { return h8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
 
+// (hi, lo) stream tensors (EP_HILO, engine option "residual_fp32"): the epilogue of a launch whose output and / or residual is a pair of
+// fp16 tensors, x = hi + lo (GemmP).  A SEPARATE region, entered from gemm_epilogue behind one block-uniform branch, so that the default
+// path's code and register allocation stay what they were (round 6: the same handling written into the default path's loops cost the
+// 256x320 instantiations 40-155 VGPR spills).  Row-tile pairs in the 16-byte layout (swap16), column tile outer so that the
+// GroupNorm-statistics form keeps 8 live sums, the (hi, lo) residual of pair a + 1 requested before pair a is converted and stored.
+// v = alpha * acc + bias_scale * bias [+ rowbias] [+ resid_hi + resid_lo];  hi = fp16(v), lo = fp16(v - hi);  STATS: per (image, row
+// chunk, group) sums of hi + lo — what the consumer's GroupNorm reads — in gemm_epilogue's layout and (fixed) order.
+template <int TM, int TN, int WTM, int WTN, int WR_, int BN_, bool STATS>
+__device__ __forceinline__ void gemm_epilogue_hilo(const GemmP& p, f4 (&acc)[TM][TN], int m0, int n0, int wr, int wc, int lane, long z,
+                                                   char* smem) {
+    static_assert(TM % 2 == 0, "row-tile pairs");
+    const half_t* rlo = gemm_resid_lo(p);
+    half_t* olo = gemm_out_lo(p);
+    const long ob = z * p.o_bs, rbs = z * p.r_bs;
+    const int sel = (lane >> 4) & 1, nw = (lane >> 5) * 8, lr = lane & 15;
+    const int mw = m0 + wr * WTM + sel * 16 + lr;            // the lane's store row in pair 0 (pair a: + 32 a)
+    const int mrow = m0 + wr * WTM + lr;                     // the lane's accumulator row in tile 0 (tile i: + 16 i)
+    [[maybe_unused]] float* cs = reinterpret_cast<float*>(smem);
+    [[maybe_unused]] float* cq = cs + WR_ * BN_;
+    if constexpr (STATS) __syncthreads();                    // every wave is done reading the operand tiles that lived here
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;      // accumulator layout: 4 columns
+        const int nn = n0 + wc * WTN + j * 16 + nw;                  // 16-byte layout: 8 columns
+        f4 bb = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            bb = *reinterpret_cast<const f4*>(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bb[r] *= p.bias_scale;
+        }
+        [[maybe_unused]] f4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+        constexpr bool RING = true;
+        h8 rh = {0, 0, 0, 0, 0, 0, 0, 0}, rl = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto ld = [&](const half_t* base, int a) {
+            return *reinterpret_cast<const h8*>(base + rbs + (long)min(mw + a * 32, p.M - 1) * p.ldr + nn);
+        };
+        if (RING && p.resid) { rh = ld(p.resid, 0); if (rlo) rl = ld(rlo, 0); }
+#pragma unroll
+        for (int a = 0; a < TM / 2; ++a) {
+            const int mx = mrow + 2 * a * 16, my = mx + 16;
+            f4 vx = acc[2 * a][j], vy = acc[2 * a + 1][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vx[r] = fmaf(vx[r], p.alpha, bb[r]); vy[r] = fmaf(vy[r], p.alpha, bb[r]); }
+            if (p.rowbias) {
+                vx += *reinterpret_cast<const f4*>(p.rowbias + (long)(min(mx, p.M - 1) / p.rows_per_batch) * p.ldrb + n);
+                vy += *reinterpret_cast<const f4*>(p.rowbias + (long)(min(my, p.M - 1) / p.rows_per_batch) * p.ldrb + n);
+            }
+            if (p.resid) {
+                if constexpr (!RING) { rh = ld(p.resid, a); if (rlo) rl = ld(rlo, a); }
+                const h8 ch = rh, cl = rl;
+                if (RING && a + 1 < TM / 2) { rh = ld(p.resid, a + 1); if (rlo) rl = ld(rlo, a + 1); }
+                h4 rx = {ch[0], ch[1], ch[2], ch[3]}, ry = {ch[4], ch[5], ch[6], ch[7]};
+                swap16(rx, ry);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { vx[r] += (float)rx[r]; vy[r] += (float)ry[r]; }
+                if (rlo) {
+                    h4 lx = {cl[0], cl[1], cl[2], cl[3]}, ly = {cl[4], cl[5], cl[6], cl[7]};
+                    swap16(lx, ly);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { vx[r] += (float)lx[r]; vy[r] += (float)ly[r]; }
+                }
+            }
+            h4 ox, oy, lx, ly;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ox[r] = (half_t)vx[r]; oy[r] = (half_t)vy[r];
+                lx[r] = (half_t)(vx[r] - (float)ox[r]); ly[r] = (half_t)(vy[r] - (float)oy[r]);
+            }
+            if constexpr (STATS) {
+                const bool okx = mx < p.M, oky = my < p.M;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = okx ? (float)ox[r] + (float)lx[r] : 0.f;
+                    sv[r] += f;
+                    qv[r] = fmaf(f, f, qv[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = oky ? (float)oy[r] + (float)ly[r] : 0.f;
+                    sv[r] += f;
+                    qv[r] = fmaf(f, f, qv[r]);
+                }
+            }
+            swap16(ox, oy);
+            swap16(lx, ly);
+            const int ms = mw + a * 32;
+            if (ms < p.M) {
+                *reinterpret_cast<h8*>((half_t*)p.out + ob + (long)ms * p.ldo + nn) = join8(ox, oy);
+                if (olo) *reinterpret_cast<h8*>(olo + ob + (long)ms * p.ldo + nn) = join8(lx, ly);
+            }
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sv[r] += __shfl_xor(sv[r], off); qv[r] += __shfl_xor(qv[r], off); }
+            if ((lane & 15) == 0) {
+                const int c = wc * WTN + j * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<f4*>(cs + wr * BN_ + c) = sv;
+                *reinterpret_cast<f4*>(cq + wr * BN_ + c) = qv;
+            }
+        }
+    }
+    if constexpr (STATS) {
+        __syncthreads();
+        const int tid = threadIdx.x, cpg = p.stats_cpg, ngl = BN_ / cpg;
+        if (tid < ngl) {
+            float a = 0.f, q = 0.f;
+            for (int w = 0; w < WR_; ++w)
+                for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[w * BN_ + c]; q += cq[w * BN_ + c]; }
+            const int b = m0 / p.rows_per_batch;             // (a tile lies inside one image: launch_gemm's admission rule)
+            const int chunk = (m0 - b * p.rows_per_batch) / (TM * 16 * WR_);
+            const int G = p.N / cpg, g = n0 / cpg + tid;
+            float* dst = p.stats_out + (((long)b * p.stats_nchunk + chunk) * G + g) * 2;
+            dst[0] = a; dst[1] = q;
+        }
+    }
+}
+
 // Epilogue shared by the GEMM kernels.  Lane holds, for accumulator tile (i, j):
 //   m = m0 + wr*WTM + i*16 + (lane & 15),  n = n0 + wc*WTN + j*16 + (lane>>4)*4 + r   (r = 0..3: 4 consecutive channels)
 typedef float f2e __attribute__((ext_vector_type(2)));
@@ -210,6 +329,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
         // + the L2 write-back of the fence, more than the 13 us reduce launches it saved.  Removed again: it also cost the production
         // 256x320 instantiation 6 SGPR spills.)
         return;
+    }
+    // (not the statistics form of the 256x320 tiles: 160 accumulator registers per lane leave no room for it — launch_gemm keeps the
+    // consumer's own statistics pass for those launches)
+    if constexpr (!GEGLU && LNM == 0 && TM % 2 == 0 && !(STATS && TM * TN >= 40)) {
+        if ((flags & EP_HILO) && !(flags & EP_NARROW)) {     // (hi, lo) stream tensors: their own region (block-uniform branch)
+            gemm_epilogue_hilo<TM, TN, WTM, WTN, WR_, BN_, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
+            return;
+        }
     }
     if constexpr (STATS && !GEGLU) {
         // ---- GroupNorm-statistics variant (GemmP::stats_out; launch_gemm admits only fp16 row-major outputs with a column bias,
@@ -1925,6 +2052,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
                 const h4 rr = *reinterpret_cast<const h4*>(p.resid + z * p.r_bs + (long)m * p.ldr + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                if constexpr (!LNF) {
+                    if (const half_t* rlo = gemm_resid_lo(p)) {      // (hi, lo) residual (EP_HILO)
+                        const h4 rl = *reinterpret_cast<const h4*>(rlo + z * p.r_bs + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rl[r];
+                    }
+                }
             }
             if (p.flags & EP_OUT_F32) {
                 *reinterpret_cast<f4*>((float*)p.out + z * p.o_bs + (long)m * p.ldo + n) = v;
@@ -1933,6 +2067,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, int batch) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
                 *reinterpret_cast<h4*>((half_t*)p.out + z * p.o_bs + (long)m * p.ldo + n) = o;
+                if constexpr (!LNF) {
+                    if (half_t* olo = gemm_out_lo(p)) {              // what the fp16 rounding dropped (EP_HILO)
+                        h4 l;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) l[r] = (half_t)(v[r] - (float)o[r]);
+                        *reinterpret_cast<h4*>(olo + z * p.o_bs + (long)m * p.ldo + n) = l;
+                    }
+                }
             }
         }
     }
@@ -2327,19 +2469,21 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
         if (p.flags & EP_TRANSPOSE) wide = wide && p.rows_per_batch % 8 == 0 && p.M % 8 == 0;
         if (!wide) p.flags |= EP_NARROW;
     }
-    // (hi, lo) stream tensors (EP_HILO, engine option "residual_fp32"): the 8-byte epilogue carries them; no split-K (the reduce pass
-    // would need them too; its workspace field carries out_lo), no GroupNorm / LayerNorm statistics from fp16-rounded outputs (the norm
-    // reads hi + lo)
+    // (hi, lo) stream tensors (EP_HILO, engine option "residual_fp32"): plain fp16 row-major launches.  Round 6: they take split-K (the
+    // reduce pass carries the pair), the GroupNorm-statistics epilogue (sums of hi + lo: what the norm reads) and 16-byte accesses —
+    // gemm_epilogue_hilo, a separate region of the epilogue on the tiles with row-tile pairs; elsewhere the 8-byte general path.
+    // No LayerNorm row partials (the option and "ln_fold" are not combined).
     const bool hilo = (p.flags & EP_HILO) != 0;
     if (hilo) {
-        SDMI_REQUIRE(!force_generic && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE | EP_OUT_F32 | EP_LNFOLD | EP_BIAS_ROW)) &&
+        SDMI_REQUIRE(!force_generic && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE | EP_OUT_F32 | EP_LNFOLD | EP_BIAS_ROW | EP_QUICK_GELU | EP_GELU)) &&
                          (gemm_resid_lo(p) == nullptr || p.resid != nullptr),
                      "(hi, lo) stream tensors: plain fp16 row-major epilogue on the MFMA kernels only");
-        p.flags |= EP_NARROW;
-        p.stats_out = nullptr;
+        auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+        if (!al16(gemm_out_lo(p)) || !al16(gemm_resid_lo(p))) p.flags |= EP_NARROW;
+        p.lnp_out = nullptr;
     }
     int split = 1;
-    const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE | EP_HILO)) && p.N % 4 == 0;
+    const bool can_split = p.splitk_ws != nullptr && !(p.flags & (EP_GEGLU | EP_NCHW | EP_TRANSPOSE)) && p.N % 4 == 0;
     SDMI_REQUIRE(!(p.flags & EP_TRANSPOSE) || (p.rows_per_batch % 4 == 0 && p.M % 4 == 0 && !(p.flags & (EP_GEGLU | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW)) &&
                                                !p.resid && !p.rowbias),
                  "EP_TRANSPOSE: rows per image must be a multiple of 4; no residual / GEGLU / fp32 output");
@@ -2385,8 +2529,9 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     if (p.stats_out && g_gn_fuse && use_glds && split <= 1 && batch == 1 && !(p.flags & (EP_GEGLU | EP_TRANSPOSE | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW | EP_QUICK_GELU | EP_GELU)) && p.stats_cpg > 0) {
         const int BMc = kCfgBM[cfg], BNc = kCfgBN[cfg];
         // a tile must lie inside one image, a group inside one column tile; few enough chunks that gn_apply's prologue stays short
+        // ((hi, lo) launches: the statistics form lives in gemm_epilogue_hilo — row-tile pairs, 16-byte accesses)
         if (p.rows_per_batch % BMc == 0 && BNc % p.stats_cpg == 0 && p.N % p.stats_cpg == 0 && p.rows_per_batch / BMc <= 64 &&
-            p.M % p.rows_per_batch == 0) {
+            p.M % p.rows_per_batch == 0 && (!hilo || (cfg != CFG_64x64 && cfg != CFG_256x320 && !(p.flags & EP_NARROW)))) {
             p.stats_nchunk = p.rows_per_batch / BMc;
             if (stats_nchunk_out) *stats_nchunk_out = p.stats_nchunk;
         }

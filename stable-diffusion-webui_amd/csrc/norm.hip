@@ -206,9 +206,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* x0, const h
 // (image, group) holds the group's HW x cpg values in registers (<= NVT 16-byte vectors per thread, NVT = 4 or 12), so the tensor is read ONCE;
 // mean first, then the centred sum of squares (two-pass in registers), fixed reduction order (lane partials -> wave shuffle tree ->
 // LDS -> every thread adds the 4 wave sums in order): deterministic.  Needs cpg % 8 == 0 (C = 256, 512, 1280, 2560 at 32 groups).
-template <int NVT>
+// HILO (engine option "residual_fp32"): the input as (hi, lo) fp16 pairs — the value is hi + lo (gn_stats_kernel's note); NVT <= 6 there.
+template <int NVT, bool HILO = false>
 __global__ __launch_bounds__(256) void gn_fused_small_kernel(const half_t* x0, const half_t* x1, int c0, int c1, int HW, int groups,
-                                                             const float* gamma, const float* beta, half_t* out, float eps, int silu) {
+                                                             const float* gamma, const float* beta, half_t* out, float eps, int silu,
+                                                             const half_t* l0 = nullptr, const half_t* l1 = nullptr) {
     __shared__ float red[2][4];
     const int C = c0 + c1, cpg = C / groups, VW = cpg / 8;
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -217,6 +219,9 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const half_t* x0, c
     const half_t* x0b = x0 + (long)b * HW * c0;
     const half_t* x1b = x1 ? x1 + (long)b * HW * c1 : nullptr;
     h8 v[NVT];
+    [[maybe_unused]] h8 vl[HILO ? NVT : 1];
+    [[maybe_unused]] const half_t* l0b = HILO ? l0 + (long)b * HW * c0 : nullptr;
+    [[maybe_unused]] const half_t* l1b = (HILO && l1) ? l1 + (long)b * HW * c1 : nullptr;
     int off[NVT], cch[NVT];                                  // element offset of the vector in the OUTPUT image (pixel * C + channel); channel
     float s = 0.f;
     // (pixel, vector) pairs advanced by the stride's quotient / remainder: no division by the runtime VW per vector
@@ -232,13 +237,17 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const half_t* x0, c
         const half_t* src = c < c0 ? x0b + (long)pp * c0 + c : x1b + (long)pp * c1 + (c - c0);
         h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         v[k] = ok ? *reinterpret_cast<const h8*>(src) : z;
+        if constexpr (HILO) {
+            const half_t* srcl = c < c0 ? l0b + (long)pp * c0 + c : l1b + (long)pp * c1 + (c - c0);
+            vl[k] = ok ? *reinterpret_cast<const h8*>(srcl) : z;
+        }
         pix += sp; vc += sr;
         if (vc >= VW) { vc -= VW; ++pix; }
     }
 #pragma unroll
     for (int k = 0; k < NVT; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)v[k][e];      // vectors past the end hold zeros
+        for (int e = 0; e < 8; ++e) s += HILO ? (float)v[k][e] + (float)vl[HILO ? k : 0][e] : (float)v[k][e];      // vectors past the end hold zeros
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((tid & 63) == 0) red[0][tid >> 6] = s;
     __syncthreads();
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const half_t* x0, c
     for (int k = 0; k < NVT; ++k)
         if (off[k] >= 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = (float)v[k][e] - mean; q = fmaf(d, d, q); }
+            for (int e = 0; e < 8; ++e) { const float d = (HILO ? (float)v[k][e] + (float)vl[HILO ? k : 0][e] : (float)v[k][e]) - mean; q = fmaf(d, d, q); }
         }
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     if ((tid & 63) == 0) red[1][tid >> 6] = q;
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const half_t* x0, c
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gm = e < 4 ? g0[e] : g1[e - 4], bt = e < 4 ? b0[e] : b1[e - 4];
-            float y = fmaf(((float)v[k][e] - mean) * rstd, gm, bt);
+            float y = fmaf(((HILO ? (float)v[k][e] + (float)vl[HILO ? k : 0][e] : (float)v[k][e]) - mean) * rstd, gm, bt);
             if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
             o[e] = (half_t)y;
         }
@@ -305,7 +314,7 @@ static int gn_bands(int HW, int C) {                      // 1: no banding; 0: t
 
 int64_t groupnorm_ws_bytes(int B, int HW, int groups) {
     int64_t chunks = gn_chunks(B, HW);
-    if ((long)HW * 8 >= gn_band_limit() || HW >= gn_row_limit()) {          // may be banded for some C <= GN_MAX_C: room for the worst case
+    if ((long)HW * GN_MAX_C >= gn_band_limit() || HW >= gn_row_limit()) {   // may be banded for some C <= GN_MAX_C (gn_bands bands from HW * C >= the limit): room for the worst case
         int nb = 2;
         while (nb < 8192 && !((long)(HW / nb) * GN_MAX_C < gn_band_limit() && HW / nb < gn_row_limit())) nb *= 2;
         chunks = std::max<int64_t>(chunks, (int64_t)nb * 64);
@@ -317,6 +326,9 @@ static int groupnorm_banded(const half_t* x0, const half_t* x1, int c0, int c1, 
                             int HW, int groups, float eps, bool silu, float* ws, hipStream_t s, int nb) {
     const int C = c0 + c1, HWb = HW / nb;
     const int nchunk_b = gn_chunks(1, HWb), rows = cdiv(HWb, nchunk_b), nchunk = nb * nchunk_b;
+    // the caller sized `ws` with groupnorm_ws_bytes: nb * nchunk_b chunks of partials per image must fit what that provisions
+    SDMI_REQUIRE((int64_t)B * nchunk * groups * 2 * (int64_t)sizeof(float) <= groupnorm_ws_bytes(B, HW, groups),
+                 "banded GroupNorm: partial sums exceed the workspace groupnorm_ws_bytes provisions");
     char pname[64];
     snprintf(pname, sizeof pname, "groupnorm_silu_banded B%d HW%d C%d x%d", B, HW, C, nb);
     ProfScope ps(pname, 0.0, 3.0 * B * (double)HW * C * 2.0, s);
@@ -350,7 +362,7 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
                      const half_t* x0_lo, const half_t* x1_lo) {
     const int C = c0 + c1;
     const bool hilo = x0_lo != nullptr;
-    SDMI_REQUIRE(!hilo || (pre_nchunk <= 0 && (x1 == nullptr) == (x1_lo == nullptr)), "GroupNorm (hi, lo) input: both sources, own statistics pass");
+    SDMI_REQUIRE(!hilo || (x1 == nullptr) == (x1_lo == nullptr), "GroupNorm (hi, lo) input: both sources as pairs");
     SDMI_REQUIRE(C % 8 == 0 && c0 % 8 == 0, "GroupNorm channels must be multiples of 8");
     SDMI_REQUIRE(C <= GN_MAX_C && groups <= 32 && C % groups == 0, "GroupNorm: C <= 4096, groups <= 32, C % groups == 0");
     if (const int nb = gn_bands(HW, C); nb != 1) {
@@ -364,13 +376,14 @@ int launch_groupnorm(const half_t* x0, const half_t* x1, int c0, int c1, const f
         const long nv = (long)HW * (cpg / 8);
         // (<= 12 vectors per thread: the 24-vector instantiation needs all 256 VGPRs — one workgroup per SIMD — and ran the 32x32-latent
         // C = 1280 norm at 77 us against 33 us for the two-pass pair: GPU run 2 of round 3)
-        if (pre_nchunk <= 0 && g_gn_small && cpg % 8 == 0 && nv <= 12 * 256 && !hilo) {
+        if (pre_nchunk <= 0 && g_gn_small && cpg % 8 == 0 && nv <= (hilo ? 6 : 12) * 256) {
             snprintf(pname, sizeof pname, "groupnorm_silu_fused B%d HW%d C%d", B, HW, C);
-            ProfScope ps(pname, 0.0, 2.0 * B * (double)HW * C * 2.0, s);                            // read once + write once
+            ProfScope ps(pname, 0.0, (hilo ? 3.0 : 2.0) * B * (double)HW * C * 2.0, s);             // read once + write once
             const dim3 grid(groups, B);
-#define SDMI_GNS(NVT) hipLaunchKernelGGL((gn_fused_small_kernel<NVT>), grid, dim3(256), 0, s, x0, x1, c0, c1, HW, groups, gamma, beta, out, eps, silu ? 1 : 0)
-            if (nv <= 4 * 256) SDMI_GNS(4);
-            else SDMI_GNS(12);
+#define SDMI_GNS(NVT, HL) hipLaunchKernelGGL((gn_fused_small_kernel<NVT, HL>), grid, dim3(256), 0, s, x0, x1, c0, c1, HW, groups, gamma, beta, out, eps, silu ? 1 : 0, x0_lo, x1_lo)
+            if (hilo) { if (nv <= 2 * 256) SDMI_GNS(2, true); else SDMI_GNS(6, true); }
+            else if (nv <= 4 * 256) SDMI_GNS(4, false);
+            else SDMI_GNS(12, false);
 #undef SDMI_GNS
             SDMI_CHECK_HIP(hipGetLastError());
             return 0;

@@ -157,8 +157,11 @@ class SdModel:
 
     def set_accuracy_mode(self, on: bool):
         """The engine's counterpart of the reference's --no-half / upcast switches (modules/devices.py:284-295 keeps GroupNorm in fp32
-        even on the GPU path; --no-half runs the whole model in fp32): the UNet's carried residual stream as (hi, lo) fp16 pairs —
-        one CFG forward 1.5e-3 -> 1.0e-3 from the fp32 oracle at the C1 shape for a measured +x % of its time (profiles/r05_parity.json)."""
+        even on the GPU path; --no-half runs the whole model in fp32): every UNet tensor that is not a matrix-core operand — the carried
+        residual stream, the skip_connection and first-conv outputs, the latent on its way into conv_in — as (hi, lo) fp16 pairs
+        (~22 bits).  One CFG forward at the C1 shape: 1.5e-3 -> below 1e-3 from the fp32 oracle (tests/test_gpu_c1_parity.py::
+        test_c1_unet_forward_accuracy_mode_vs_oracle; measured values and cost in profiles/r06_parity.json).
+        Engines that cannot take the pairs (force_generic / use_glds = 0 cross-check settings) run the plain fp16 stream."""
         on = bool(on)
         if on != getattr(self, "accuracy_mode", False):
             self.engine.set_option("residual_fp32", 1 if on else 0)

@@ -37,8 +37,9 @@ def r16(t):
 class Emu:
     """Walks an oracle UNetModel with the engine's store pattern.  ``stream_fp32``: the carried tensors keep fp32."""
 
-    def __init__(self, net: ou.UNetModel, stream_fp32: bool, skip_fp32: bool = False, h1_fp32: bool = False):
+    def __init__(self, net: ou.UNetModel, stream_fp32: bool, skip_fp32: bool = False, h1_fp32: bool = False, xin_fp32: bool = False):
         self.net, self.stream_fp32, self.skip_fp32, self.h1_fp32 = net, stream_fp32, skip_fp32, h1_fp32
+        self.xin_fp32 = xin_fp32      # conv_in takes the latent as a (hi, lo) pair in its zero-padded input channels: x is not rounded
 
     def carried(self, t):
         return t if self.stream_fp32 else r16(t)
@@ -114,7 +115,7 @@ class Emu:
             elif isinstance(layer, ou.Upsample):
                 h = self.carried(layer.conv(F.interpolate(r16(h), scale_factor=2, mode="nearest")))
             else:                                             # conv_in: the input x arrives as fp32 and is stored fp16 by the layout kernel
-                h = self.carried(layer(r16(h)))
+                h = self.carried(layer(h if self.xin_fp32 else r16(h)))
         return h
 
     def __call__(self, x, timesteps, context):
@@ -138,6 +139,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--first", type=int, default=0, help="skip the first N store patterns")
     ap.add_argument("--save", default="", help="write the emulated outputs (fp16 stream / all-fp32 non-operand tensors) to this .npz: "
                                                "tests/golden/emu_engine_c1.npz is read by tests/test_gpu_c1_parity.py")
     args = ap.parse_args()
@@ -162,14 +164,17 @@ def main():
         for name, kw in (("engine pattern, fp16 residual stream (today)", dict(stream_fp32=False)),
                          ("engine pattern, fp32 residual stream (residual_fp32)", dict(stream_fp32=True)),
                          ("engine pattern, fp32 residual stream + fp32 skip_connection output", dict(stream_fp32=True, skip_fp32=True)),
-                         ("... + fp32 conv1 output (every tensor that is not a matrix-core operand in fp32)", dict(stream_fp32=True, skip_fp32=True, h1_fp32=True))):
+                         ("... + fp32 conv1 output (every tensor that is not a matrix-core operand in fp32)", dict(stream_fp32=True, skip_fp32=True, h1_fp32=True)),
+                         ("... + the latent into conv_in as a (hi, lo) pair", dict(stream_fp32=True, skip_fp32=True, h1_fp32=True, xin_fp32=True)))[args.first:]:
             got = Emu(net, **kw)(x, t, ctx)
             print(f"{name}: rel-L2 {rel_l2(got, ref):.3e}   per row {[f'{rel_l2(got[i], ref[i]):.2e}' for i in range(args.rows)]}", flush=True)
             saved.append((got, rel_l2(got, ref)))
     if args.save:
         import numpy as np
+        assert args.first == 0, "--save needs every store pattern"
         np.savez_compressed(args.save, rows=args.rows, fp16_stream=saved[0][0].numpy(), fp32_stream=saved[1][0].numpy(),
                             fp32_stream_skip=saved[2][0].numpy(), fp32_all_non_operand=saved[3][0].numpy(),
+                            fp32_all_non_operand_xin=saved[4][0].numpy(), fp32_oracle=ref.numpy(),
                             rel_l2_vs_fp32_oracle=np.array([e for _, e in saved]))
         print("wrote", args.save)
 

@@ -26,6 +26,14 @@ and tests/test_gpu_fullsize_parity.py compares the HIP engine with the committed
   c3_sdxl_e2e  SDXL-base, batch 1, 3 Euler-a steps with CFG 5 at a 128x128 latent (vector conditioning y / uy through the CFG
                denoiser): final latent
 
+  round 6 — the BASELINE.json jobs at their full step counts (one image each; tests/test_gpu_fullsize_parity.py runs the engine at the
+  BENCHED batch with this image as image 0 / 7, so the driver's default `pytest -m gpu` holds every config end to end):
+  c1_b8_img7     image 7 of the C1 batch (Philox seed 1007, prompt generator 50007): 20-step Euler a, cfg 7 — image 0 is
+                 c1_euler_a_b1.npz (make_c1_golden.py)
+  c3_sdxl_e2e30  SDXL-base, 30 Euler-a steps, cfg 5, 128x128 latent, seed 4300: final latent
+  c4a_hires20    txt2img 512x512 20 Euler-a steps -> bilinear latent upscale -> second pass with steps given (20, denoise 0.75) ->
+                 decode at 1024x1024 (sub-sampled), seed 4400
+
 Attention products above 4096 query rows are evaluated in row blocks (oracle.unet.QUERY_CHUNK: softmax rows are independent, the
 result is the unchunked product's) — the memory bound modules/sub_quadratic_attention.py puts on the reference's own product.
 """
@@ -53,6 +61,11 @@ SPEC = {
     "c4a_hires": dict(prompt_seed=50_004, seeds=[4000, 4001], steps=2, cfg=7.0, denoising_strength=0.75),
     "c4b_img2img": dict(prompt_seed=50_005, seeds=[4100, 4101], steps=4, cfg=7.0, denoising_strength=0.5, image_seed=441),
     "c3_sdxl_e2e": dict(prompt_seed=50_003, seeds=[4200], steps=3, cfg=5.0),
+    # round 6: the BASELINE.json jobs at their FULL step counts, one image each; the engine runs them at the benched batch with this
+    # image as image 0 (prompt pair of image i: generator seed prompt_seed + i, Philox seed seeds[0] + i)
+    "c1_b8_img7": dict(prompt_seed=50_007, seeds=[1007], steps=20, cfg=7.0),
+    "c3_sdxl_e2e30": dict(prompt_seed=50_013, seeds=[4300], steps=30, cfg=5.0),
+    "c4a_hires20": dict(prompt_seed=50_014, seeds=[4400], steps=20, cfg=7.0, denoising_strength=0.75),
 }
 
 
@@ -75,7 +88,7 @@ def xl_decoder_state_dict(schema, gain):
 def main(legs):
     from oracle import kdiffusion as kd, pipeline as opipe, unet as ou, vae as ov
     schema = importlib.import_module("stable-diffusion-webui_amd.schema")
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(int(os.environ.get("SDMI_GOLDEN_THREADS", min(32, os.cpu_count() or 1))))
     ou.QUERY_CHUNK = ov.QUERY_CHUNK = 2048
     done = {}
 
@@ -191,6 +204,48 @@ def main(legs):
                            y=y.half().float(), uy=uy.half().float())
         print(f"[c3_sdxl_e2e] {time.time() - t0:.0f}s", flush=True)
         save("c3_sdxl_e2e", final_latent=lat.numpy())
+        del om
+    if "c1_b8_img7" in legs:
+        s = SPEC["c1_b8_img7"]
+        sd = schema.synthetic_state_dict(schema.sd15_unet(), None, dtype=torch.float16)
+        om = opipe.OracleModel(sd, ou.sd15_config(), None)
+        del sd
+        g = torch.Generator().manual_seed(s["prompt_seed"])
+        cond, uncond = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+        t0 = time.time()
+        lat = opipe.sample(om, cond, uncond, s["seeds"], s["steps"], "euler_a", s["cfg"], (64, 64))
+        print(f"[c1_b8_img7] {time.time() - t0:.0f}s", flush=True)
+        save("c1_b8_img7", final_latent=lat.numpy())
+        del om
+    if "c4a_hires20" in legs:
+        s = SPEC["c4a_hires20"]
+        sd = schema.synthetic_state_dict(schema.sd15_unet(), schema.sd15_vae(), dtype=torch.float16)
+        om = opipe.OracleModel(sd, ou.sd15_config(), ov.sd15_vae_config())
+        del sd
+        g = torch.Generator().manual_seed(s["prompt_seed"])
+        cond, uncond = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+        t0 = time.time()
+        lat = opipe.txt2img_hires(om, cond.half().float(), uncond.half().float(), s["seeds"], s["steps"], "euler_a", s["cfg"], (64, 64),
+                                  hr_scale=2.0, denoising_strength=s["denoising_strength"])
+        print(f"[c4a_hires20] sampling {time.time() - t0:.0f}s", flush=True)
+        with torch.no_grad():
+            img = om.vae.decode_first_stage(lat[:1])
+        print(f"[c4a_hires20] {time.time() - t0:.0f}s", flush=True)
+        save("c4a_hires20", final_latent=lat.numpy(), image0_sub4=img[:, :, ::4, ::4].numpy(), image0_window=img[:, :, 448:576, 448:576].numpy())
+        del om
+    if "c3_sdxl_e2e30" in legs:
+        s = SPEC["c3_sdxl_e2e30"]
+        sd = schema.synthetic_state_dict(schema.sdxl_unet(), None, dtype=torch.float16)
+        om = opipe.OracleModel(sd, ou.sdxl_base_config(), None)
+        del sd
+        g = torch.Generator().manual_seed(s["prompt_seed"])
+        cond, uncond = torch.randn(1, 77, 2048, generator=g), torch.randn(1, 77, 2048, generator=g)
+        y, uy = torch.randn(1, 2816, generator=g), torch.randn(1, 2816, generator=g)
+        t0 = time.time()
+        lat = opipe.sample(om, cond.half().float(), uncond.half().float(), s["seeds"], s["steps"], "euler_a", s["cfg"], (128, 128),
+                           y=y.half().float(), uy=uy.half().float())
+        print(f"[c3_sdxl_e2e30] {time.time() - t0:.0f}s", flush=True)
+        save("c3_sdxl_e2e30", final_latent=lat.numpy())
         del om
     return done
 

@@ -214,6 +214,7 @@ struct emu_gemm_extras {                                       // the GemmP fiel
     const float* ln_stats; const float* ln_s; int ln_np; float ln_inv_c, ln_eps;   // EP_LNFOLD consumer side
     float* lnp_out; int lnp_np;                                // LayerNorm partial row sums, producer side; lnp_np is written back
     float bias_scale;
+    uint16_t* out_lo; const uint16_t* resid_lo;                // (hi, lo) stream tensors (EP_HILO): the lo halves of the output / the residual
 };
 int emu_conv_gemm(const sdmi_conv_desc* d, int cfg, int split, int korder, emu_gemm_extras* x) {
     GemmP p{};
@@ -240,6 +241,11 @@ int emu_conv_gemm(const sdmi_conv_desc* d, int cfg, int split, int korder, emu_g
         p.ln_stats = x->ln_stats; p.ln_s = x->ln_s; p.ln_np = x->ln_np; p.ln_inv_c = x->ln_inv_c; p.ln_eps = x->ln_eps;
         p.lnp_out = x->lnp_out;
         if (x->bias_scale != 0.f) p.bias_scale = x->bias_scale;
+        if (x->out_lo || x->resid_lo) {                       // as engine.cpp run_conv hands them over
+            p.flags |= EP_HILO;
+            p.ln_stats = reinterpret_cast<const float*>(x->out_lo);
+            p.ln_s = reinterpret_cast<const float*>(x->resid_lo);
+        }
     }
     int nchunk = 0, np = 0;
     const int rc = launch_gemm(p, d->batch > 0 ? d->batch : 1, d->force_generic == 1, d->force_generic != 2, nullptr, &nchunk, &np);
@@ -280,6 +286,15 @@ int64_t emu_groupnorm_ws_bytes(int B, int HW, int groups) { return groupnorm_ws_
 int emu_groupnorm(const uint16_t* x0, const uint16_t* x1, int c0, int c1, const float* gamma, const float* beta, uint16_t* out, int B, int HW, int groups,
                   float eps, int silu, float* ws) {
     return launch_groupnorm((const half_t*)x0, (const half_t*)x1, c0, c1, gamma, beta, (half_t*)out, B, HW, groups, eps, silu != 0, ws, nullptr);
+}
+// (hi, lo) input pairs (engine option "residual_fp32"); pre_nchunk > 0: `ws` already holds the producing GEMM's partial sums
+int emu_groupnorm_hilo(const uint16_t* x0, const uint16_t* x1, int c0, int c1, const float* gamma, const float* beta, uint16_t* out, int B, int HW,
+                       int groups, float eps, int silu, float* ws, int pre_nchunk, const uint16_t* x0_lo, const uint16_t* x1_lo) {
+    return launch_groupnorm((const half_t*)x0, (const half_t*)x1, c0, c1, gamma, beta, (half_t*)out, B, HW, groups, eps, silu != 0, ws, nullptr,
+                            pre_nchunk, (const half_t*)x0_lo, (const half_t*)x1_lo);
+}
+int emu_nchw_to_nhwc_lo(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int lo_ch) {
+    return launch_nchw_to_nhwc(x, 1, (half_t*)out, B, C, HW, cpad, 1.0f, nullptr, nullptr, nullptr, lo_ch != 0);
 }
 int emu_layernorm(const uint16_t* x, const float* gamma, const float* beta, uint16_t* out, int64_t rows, int C, float eps) {
     return launch_layernorm((const half_t*)x, gamma, beta, (half_t*)out, rows, C, eps, nullptr);

@@ -13,7 +13,7 @@ bench.py measures outside the headline configuration (tests/test_gpu_c1_parity.p
 
 The fp32 oracle outputs are committed fixtures (tests/golden/fullsize_*.npz, generated in the authoring container by
 tests/golden/make_fullsize_golden.py — minutes of CPU per leg); inputs are re-derived here from the same seeds.  Measured values go to
-gpurun_out/r05_parity_fullsize.json (copied to profiles/).  Stated tolerances (fp16 storage, fp32 accumulation — the same distance the
+gpurun_out/r06_parity_fullsize.json (copied to profiles/).  Stated tolerances (fp16 storage, fp32 accumulation — the same distance the
 C1 shapes have): UNet forward <= 2.5e-3, attention <= 5e-4, VAE decode <= 1.5e-3 (range-extended <= 5e-3: its
 residual stream carries 6 fewer mantissa-free exponent steps), VAE encode moments <= 2e-3, 50-step final latent <= 8e-3.
 """
@@ -30,7 +30,7 @@ from helpers import rel_l2, usable_cpus
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPORT_PATH = os.path.join(ROOT, "gpurun_out", "r05_parity_fullsize.json")
+REPORT_PATH = os.path.join(ROOT, "gpurun_out", "r06_parity_fullsize.json")
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_fullsize_golden as mfg  # noqa: E402  (input definitions: SPEC, seeded, xl_decoder_state_dict)
 
@@ -181,7 +181,41 @@ def test_c3_sdxl_vae_config_decode_1024_range_extended(dev, golden_dir):
     print(f"[c3 vae range-extended 1024] {out}")
 
 
-def test_c2_dpmpp_2m_karras_50_steps_final_latent(dev, golden_dir):
+def _prompt_rows(prompt_seed, n, ctx_dim, adm=0, half_round=False):
+    """Prompt pair (and SDXL vector pair) of image i from generator prompt_seed + i — image 0 is the pair the committed oracle run used."""
+    conds, unconds, ys, uys = [], [], [], []
+    for i in range(n):
+        g = torch.Generator().manual_seed(prompt_seed + i)
+        conds.append(torch.randn(1, 77, ctx_dim, generator=g))
+        unconds.append(torch.randn(1, 77, ctx_dim, generator=g))
+        if adm:
+            ys.append(torch.randn(1, adm, generator=g))
+            uys.append(torch.randn(1, adm, generator=g))
+    r = (lambda t: t.half().float()) if half_round else (lambda t: t)
+    out = [r(torch.cat(conds)), r(torch.cat(unconds))]
+    if adm:
+        out += [r(torch.cat(ys)), r(torch.cat(uys))]
+    return out
+
+
+def _sample(model, dev, name, steps, cfg, seeds, hw, cond, uncond, y=None, uy=None):
+    sampler = sub("sd_samplers").create_sampler(name, model)
+
+    class P:
+        eta, scheduler, is_hr_pass = None, None, False       # Automatic = the sampler's own schedule
+        sampler_noise_scheduler_override, extra_generation_params = None, {}
+    p = P()
+    p.steps, p.cfg_scale = steps, cfg
+    p.rng = sub("rng").ImageRNG((4, hw, hw), list(seeds), device=dev)
+    if y is not None:
+        p.y, p.uy = y.to(dev), uy.to(dev)
+    return sampler.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev)).cpu()
+
+
+def test_c2_dpmpp_2m_karras_50_steps_at_the_benched_batch_of_8(dev, golden_dir):
+    """BASELINE.json configs[2] per GPU: 50-step DPM++ 2M Karras, cfg 7, 512x512, BATCH 8 (16-row CFG forwards with the shared prefix — the
+    dispatch `bench.py --config c2` times; round 5 compared a batch of 1).  Image 0 (seed 2000, prompt generator 50002) against the committed
+    fp32 oracle run of that image alone (rows are independent), in the default configuration and in the accuracy mode."""
     schema = sub("schema")
     s = mfg.SPEC["c2_dpmpp2m"]
     want = torch.from_numpy(fixture(golden_dir, "c2_dpmpp2m")["final_latent"])
@@ -189,22 +223,24 @@ def test_c2_dpmpp_2m_karras_50_steps_final_latent(dev, golden_dir):
     sd = schema.synthetic_state_dict(ucfg, vcfg, dtype=torch.float16)
     model = sub("sd_models").SdModel(sd, ucfg, vcfg, device=0, vae_decoder_only=True)
     del sd
-    g = torch.Generator().manual_seed(s["prompt_seed"])
-    cond, uncond = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
-    sampler = sub("sd_samplers").create_sampler("DPM++ 2M", model)
-
-    class P:
-        steps, cfg_scale, eta, scheduler, is_hr_pass = s["steps"], s["cfg"], None, None, False      # Automatic = the sampler's own: karras
-        sampler_noise_scheduler_override, extra_generation_params = None, {}
-        rng = sub("rng").ImageRNG((4, 64, 64), [s["seed"]], device=dev)
-    p = P()
-    got = sampler.sample(p, p.rng.next(), cond.to(dev), uncond.to(dev)).cpu()
-    model.engine.close()
-    e = rel_l2(got, want)
-    report("dpmpp_2m_karras_50_steps_c2", {"config": "SD1.5 512x512, 50-step DPM++ 2M Karras, cfg 7, batch 1, seed 2000",
-                                           "engine_vs_fp32_oracle_final_latent_rel_l2": e})
-    print(f"[c2 e2e] engine {e:.3e}")
-    assert e < 1.66e-3                                       # 1.25 x the measured 1.33e-3 (50 steps)
+    cond, uncond = _prompt_rows(s["prompt_seed"], 8, 768)
+    seeds = [s["seed"] + i for i in range(8)]
+    out = {"config": "SD1.5 512x512, 50-step DPM++ 2M Karras, cfg 7, batch 8 (the benched dispatch), seeds 2000..2007; image 0 vs the oracle"}
+    try:
+        got = _sample(model, dev, "DPM++ 2M", s["steps"], s["cfg"], seeds, 64, cond, uncond)
+        one = _sample(model, dev, "DPM++ 2M", s["steps"], s["cfg"], seeds[:1], 64, cond[:1], uncond[:1])
+        model.set_accuracy_mode(True)
+        acc = _sample(model, dev, "DPM++ 2M", s["steps"], s["cfg"], seeds, 64, cond, uncond)
+    finally:
+        model.set_accuracy_mode(False)
+        model.engine.close()
+    e, e1, ea = rel_l2(got[:1], want), rel_l2(one, want), rel_l2(acc[:1], want)
+    out.update({"engine_vs_fp32_oracle_final_latent_rel_l2": e, "batch_1_dispatch": e1, "accuracy_mode_final_latent_rel_l2": ea})
+    report("dpmpp_2m_karras_50_steps_c2_batch8", out)
+    print(f"[c2 e2e batch 8] engine {e:.3e} (batch-1 dispatch {e1:.3e}); accuracy mode {ea:.3e}")
+    assert torch.isfinite(got).all() and torch.isfinite(acc).all()
+    assert e < 2.2e-3 and e1 < 1.66e-3                       # batch 1: 1.25 x the measured 1.33e-3 (50 steps)
+    assert ea < 1.5e-3
 
 
 # ---- round 4: the c3 / c4a / c4b jobs COMPOSED end to end at full size (few steps: the oracle side is minutes of host CPU, committed as
@@ -327,3 +363,65 @@ def test_bench_batch_dispatch_reproduces_the_two_row_forward(dev, sd15_unet_engi
         assert max(errs) < 2.27e-3, (reps, errs)
         assert all(torch.equal(big[0:2], big[2 * i:2 * i + 2]) for i in range(reps))      # inside one launch sequence rows are treated alike
     report("c4a_batch_dispatch_vs_2_rows", out)
+
+
+# ---- round 6: the BASELINE.json jobs at their FULL step counts and at the BENCHED batch, against committed one-image oracle runs -----------
+def test_c3_sdxl_30_step_job_at_the_benched_batch_of_4(dev, golden_dir):
+    """BASELINE.json configs[3] as `bench.py --config c3` runs it: SDXL-base, 1024x1024 (128x128 latent), 30-step Euler a, cfg 5, batch 4 with
+    the vector conditioning on every UNet row.  Image 0 (seed 4300, prompt generator 50013) against the committed fp32 oracle run of that image
+    alone (tests/golden/fullsize_c3_sdxl_e2e30.npz), default configuration and accuracy mode."""
+    schema = sub("schema")
+    s = mfg.SPEC["c3_sdxl_e2e30"]
+    want = torch.from_numpy(fixture(golden_dir, "c3_sdxl_e2e30")["final_latent"])
+    cfg = schema.sdxl_unet()
+    sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
+    model = sub("sd_models").SdModel(sd, cfg, None, device=0, load_vae=False)
+    del sd
+    cond, uncond, y, uy = _prompt_rows(s["prompt_seed"], 4, 2048, adm=2816, half_round=True)
+    seeds = [s["seeds"][0] + i for i in range(4)]
+    try:
+        got = _sample(model, dev, "Euler a", s["steps"], s["cfg"], seeds, 128, cond, uncond, y, uy)
+        model.set_accuracy_mode(True)
+        acc = _sample(model, dev, "Euler a", s["steps"], s["cfg"], seeds, 128, cond, uncond, y, uy)
+    finally:
+        model.set_accuracy_mode(False)
+        model.engine.close()
+    e, ea = rel_l2(got[:1], want), rel_l2(acc[:1], want)
+    report("c3_sdxl_e2e_30_steps_batch4", {"config": "SDXL-base 1024x1024 (128x128 latent), 30-step Euler a, cfg 5, batch 4 (the benched dispatch), seeds 4300..4303; image 0 vs the oracle",
+                                           "engine_vs_fp32_oracle_final_latent_rel_l2": e, "accuracy_mode_final_latent_rel_l2": ea})
+    print(f"[c3 sdxl e2e 30 steps, batch 4] engine {e:.3e}; accuracy mode {ea:.3e}")
+    assert torch.isfinite(got).all() and torch.isfinite(acc).all()
+    assert e < 1.0e-2 and ea < 1.0e-2
+
+
+def test_c4a_hires_fix_20_plus_20_at_the_benched_batch_of_8(dev, sd15_full_model, golden_dir):
+    """BASELINE.json configs[4] (C4a) as `bench.py --config c4a` runs it: txt2img 512x512, 20 Euler-a steps -> bilinear latent upscale to
+    128x128 -> second pass with 20 steps given at denoising 0.75 -> decode at 1024x1024, through process_images at batch 8.  Image 0 (seed 4400,
+    prompt generator 50014) against the committed fp32 oracle run of that image alone (tests/golden/fullsize_c4a_hires20.npz): final latent,
+    and the uint8 picture."""
+    processing = sub("processing")
+    s = mfg.SPEC["c4a_hires20"]
+    fx = fixture(golden_dir, "c4a_hires20")
+    cond, uncond = _prompt_rows(s["prompt_seed"], 8, 768, half_round=True)
+    out = {"config": "SD1.5 512 -> 1024 latent hires fix, 20 + 20 Euler-a steps (denoise 0.75), cfg 7, batch 8 (the benched dispatch), seeds 4400..4407; image 0 vs the oracle"}
+    want = torch.from_numpy(fx["final_latent"])
+    for mode in ("default", "accuracy_mode"):
+        sd15_full_model.set_accuracy_mode(mode == "accuracy_mode")
+        try:
+            p = processing.StableDiffusionProcessingTxt2Img(sd_model=sd15_full_model, c=cond, uc=uncond, seed=s["seeds"][0], batch_size=8, steps=s["steps"],
+                                                            cfg_scale=s["cfg"], width=512, height=512, sampler_name="Euler a", enable_hr=True,
+                                                            hr_scale=2.0, denoising_strength=s["denoising_strength"])
+            res = processing.process_images(p)
+        finally:
+            sd15_full_model.set_accuracy_mode(False)
+        assert tuple(res.latents.shape) == (8, 4, 128, 128)
+        e = rel_l2(res.latents[:1].float().cpu(), want)
+        img0 = torch.from_numpy(np.asarray(res.images[0])).permute(2, 0, 1)[None]              # uint8 [1, 3, 1024, 1024]
+        d = (img0[:, :, ::4, ::4].int() - _u8_levels(torch.from_numpy(fx["image0_sub4"])).int()).abs()
+        dw = (img0[:, :, 448:576, 448:576].int() - _u8_levels(torch.from_numpy(fx["image0_window"])).int()).abs()
+        out[mode] = {"final_latent_rel_l2": e, "image0_u8_mean_abs_levels": float(d.float().mean()), "image0_u8_max_levels": int(max(d.max(), dw.max())),
+                     "image0_u8_within_1_level": float((d <= 1).float().mean())}
+        print(f"[c4a hires 20 + 20, batch 8, {mode}] latent {e:.3e}, image 0 mean |du8| {float(d.float().mean()):.3f}, max {int(max(d.max(), dw.max()))}")
+    report("c4a_hires_e2e_20_plus_20_batch8", out)
+    assert out["default"]["final_latent_rel_l2"] < 1.5e-2 and out["accuracy_mode"]["final_latent_rel_l2"] < 1.5e-2
+    assert out["default"]["image0_u8_mean_abs_levels"] < 1.0

@@ -69,17 +69,26 @@ def test_unet_accuracy_mode_carries_the_residual_stream_with_22_bits(dev, tiny):
     ctx = tiny["cond"]
     ref = om.unet(x.half().float(), t, ctx.half().float())
     base = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
+    ref32 = om.unet(x, t, ctx.half().float())                # the accuracy mode hands conv_in the fp32 latent as a (hi, lo) pair
+    xp, tp = torch.cat([x[:2], x[:2]]), torch.full((4,), 500.25)
+    ctx_same = torch.cat([ctx[:2], ctx[:2]])
     eng.set_option("residual_fp32", 1)
     try:
         acc = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
         acc2 = eng.unet_forward(x.to(dev), t.to(dev), None).cpu()
+        # round 6: the shared CFG prefix is combined with the option — both halves of every (hi, lo) tensor are copied
+        rows = eng.unet_forward(xp.to(dev), tp.to(dev), ctx.to(dev)).cpu()
+        pairs = eng.unet_forward(xp.to(dev), tp.to(dev), None, uniform_t=True, cfg_pairs=True).cpu()
+        twin = eng.unet_forward(xp.to(dev), tp.to(dev), ctx_same.to(dev), uniform_t=True, cfg_pairs=True).cpu()
+        eng.unet_forward(xp.to(dev), tp.to(dev), ctx.to(dev))  # (leaves both per-call options off)
     finally:
         eng.set_option("residual_fp32", 0)
     again = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
     assert torch.equal(base, again) and torch.equal(acc, acc2)
-    e_base, e_acc = rel_l2(base, ref), rel_l2(acc, ref)
-    print(f"[tiny unet] default {e_base:.3e}  residual_fp32 {e_acc:.3e}")
+    e_base, e_acc = rel_l2(base, ref), rel_l2(acc, ref32)
+    print(f"[tiny unet] default {e_base:.3e}  residual_fp32 {e_acc:.3e}  shared prefix vs per-row {rel_l2(pairs, rows):.3e}")
     assert torch.isfinite(acc).all() and e_acc < 0.9 * e_base and e_acc < 4e-3
+    assert torch.equal(twin[:2], twin[2:]) and rel_l2(pairs, rows) < 6e-3 and rel_l2(pairs, om.unet(xp, tp, ctx.half().float())) < 4e-3
 
 
 def test_engine_promise_options_are_checkable(dev, tiny, monkeypatch):
