@@ -550,7 +550,7 @@ def test_c1_euler_a_20_steps_at_the_benched_batch_of_8_vs_oracle(dev, sd15, gold
     print(f"[c1 e2e batch 8] {out}")
     assert torch.isfinite(got).all() and torch.isfinite(acc).all()
     assert max(out["images"].values()) < 3.6e-3              # 1.25 x the measured 2.88e-3 (image 0) / 2.80e-3 (image 7); batch 1: 2.84e-3
-    assert max(out["accuracy_mode_images"].values()) < 3.0e-3
+    assert max(out["accuracy_mode_images"].values()) < 2.28e-3   # 1.25 x the measured 1.82e-3 / 1.76e-3 (profiles/r06_parity.json)
 
 
 def test_c3_sdxl_base_full_size_unet_forward_vs_oracle(dev):
