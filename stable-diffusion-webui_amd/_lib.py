@@ -93,9 +93,6 @@ _SIGS = {
     "sdmi_rowchain_ff_pack_bytes": (_i64, [_i, _i]),
     "sdmi_rowchain_ff_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sdmi_rowchain_ff": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp]),
-    "sdmi_rowchain_xattn_pack_bytes": (_i64, [_i, _i, _i]),
-    "sdmi_rowchain_xattn_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "sdmi_rowchain_xattn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp]),
     "sdmi_philox_randn": (_i, [_vp, _i64, C.c_uint64, C.c_uint32, _vp]),
     "sdmi_slerp": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp]),
     "sdmi_cfg_prepare_input": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp]),

@@ -939,12 +939,9 @@ static int launch_attn_d(const AttnP& p, hipStream_t s) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     constexpr int SMEM = 2 * (KVT * (DK * 2 + 16) + DV * (KVT * 2 + 16));
     auto kern = attn_mfma_kernel<D, KVT, VAR>;
-    static int attr_set = -1;
+    static PerDeviceOnce attr;
     const int smem = SMEM + (g_attn_lds_pad > 0 ? g_attn_lds_pad : 0);
-    if (attr_set < smem) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = smem;
-    }
+    if (attr.need(smem)) SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     dim3 grid(cdiv(p.N, 128), p.B * p.H);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
@@ -956,11 +953,8 @@ static int launch_attn_pp(const AttnP& p, hipStream_t s) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     constexpr int SMEM = 3 * (64 * (DK * 2 + 16) + DV * (64 * 2 + 16)) + 64 * (DK * 2 + 16) + NG * 256 * 16;   // 3 pairs, K(0), dump slots
     auto kern = attn_pp_kernel<D, FOLD, NG, TIMING>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
+    static PerDeviceOnce attr;
+    if (attr.need()) SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     dim3 grid(cdiv(p.N, NG * 128), p.B * p.H);
     hipLaunchKernelGGL(kern, grid, dim3(NG * 256), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
@@ -1032,12 +1026,8 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
         }
     }
     SDMI_REQUIRE(p.D <= 512 && p.M <= 16384, "generic attention supports D <= 512 and M <= 16384");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_generic_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
-        attr_set = true;
-    }
+    static PerDeviceOnce attr;
+    if (attr.need()) SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
     hipLaunchKernelGGL(attn_generic_kernel, dim3(p.N, p.B * p.H), dim3(64), p.M * sizeof(float), s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;

@@ -232,23 +232,7 @@ int sdmi_rowchain_ff(const void* x, void* out, const void* g, const void* b, con
                               hidden, eps, (hipStream_t)stream);
     API_GUARD_END
 }
-int64_t sdmi_rowchain_xattn_pack_bytes(int C, int B, int H) { return (int64_t)rowchain_xattn_pack_bytes(C, B, H); }
-int sdmi_rowchain_xattn_pack(const void* k, const void* vt, const void* wq, const void* wo, void* packs, int C, int B, int L, int Lpad,
-                             int H, float scale, void* stream) {
-    API_GUARD_BEGIN
-    SDMI_REQUIRE(k && vt && wq && wo && packs && B > 0, "null argument");
-    return launch_rowchain_xattn_pack((const half_t*)k, (const half_t*)vt, (const half_t*)wq, (const half_t*)wo, packs, C, B, L, Lpad, H,
-                                      scale, nullptr, (hipStream_t)stream);
-    API_GUARD_END
-}
-int sdmi_rowchain_xattn(const void* x, void* out, const void* g, const void* b, const void* packs, const void* bo, int64_t rows,
-                        int rows_per_image, int C, int H, float eps, void* stream) {
-    API_GUARD_BEGIN
-    SDMI_REQUIRE(x && out && g && b && packs && rows_per_image > 0, "null argument");
-    return launch_rowchain_xattn((const half_t*)x, (half_t*)out, (const float*)g, (const float*)b, packs, (const float*)bo, (long)rows,
-                                 rows_per_image, 0, C, H, eps, (hipStream_t)stream);
-    API_GUARD_END
-}
+
 
 int sdmi_philox_randn(void* out, int64_t n, uint64_t seed, uint32_t offset, void* stream) {
     API_GUARD_BEGIN
@@ -578,9 +562,6 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "gn_fuse") g_gn_fuse = value;
     else if (n == "gn_small") g_gn_small = value;
     else if (n == "ep_wide") g_ep_wide = value;
-    else if (n == "rc_ff8") g_rc_ff8 = value;
-    else if (n == "rc_dbg_lo") g_rc_dbg = (g_rc_dbg & 0xFFFFFFFF00000000ull) | (unsigned)value;
-    else if (n == "rc_dbg_hi") g_rc_dbg = (g_rc_dbg & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32);
     else if (n == "attn_kvt") g_attn_kvt = value;
     else if (n == "attn_occ") g_attn_occ = value;
     else if (n == "attn_lds_pad") g_attn_lds_pad = value;

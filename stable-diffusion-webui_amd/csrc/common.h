@@ -54,6 +54,22 @@ const char* get_error();
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute (MaxDynamicSharedMemorySize) is a per-DEVICE setting, and one process may drive several devices (one engine +
+// one host thread per device: parallel.DevicePool) — launch helpers remember what they set per (call site, device).  need(want) is true
+// when `want` exceeds what this call site has set on the CURRENT device so far (a process-wide flag skipped the call on the
+// second device and the launch failed with more than 64 KB of dynamic LDS).
+struct PerDeviceOnce {
+    int level[64] = {};
+    bool need(int want = 1) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) d = 0;
+        d &= 63;
+        if (level[d] >= want) return false;
+        level[d] = want;
+        return true;
+    }
+};
+
 // A 256-byte zeroed device buffer per device used as the source of padding lanes in LDS-direct loads.
 // Device page of zeros that padded / out-of-image operand lanes are pointed at.  32 KB: the ping-pong GEMM adds a channel
 // offset of up to Cin halfs to it instead of re-selecting the pointer per load.
@@ -201,25 +217,15 @@ int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 // v [B, M, ldv] (head h at h*D) -> vt [B, H*D, Mpad] (zero padded)
 int launch_transpose_v(const half_t* v, half_t* vt, int B, int H, int M, int D, int ldv, int Mpad, hipStream_t s);
 
-// ---- row-local chains of the transformer block (rowchain.hip) ----------------------------------------------
-extern unsigned long long g_rc_dbg;                 // tuning only: RowChainP::dbg
-extern int g_rc_ff8;                                // 1: 8-wave feed-forward chain + its pack layout (rowchain.hip)
-bool rowchain_supports(int C);                      // row widths the fused chains are instantiated for (320)
-int rowchain_xattn_max_keys();                      // longest text context the cross-attention chain takes (96)
+// ---- the feed-forward chain of the transformer block (rowchain.hip) ------------------------------------------
+bool rowchain_supports(int C);                      // row widths the fused chain is instantiated for (320)
 size_t rowchain_ff_pack_bytes(int C, int hidden);
-size_t rowchain_xattn_pack_bytes(int C, int B, int H);
 // w1 [2*hidden][C]: value rows then gate rows (permuted = false) or the engine's GEGLU row packing (true); b1 likewise (may be null)
 int launch_rowchain_ff_pack(const half_t* w1, const float* b1, const half_t* w2, void* packs, int C, int hidden, bool permuted,
                             hipStream_t s);
-// k [B*L][C], vt [B][C][Lpad], wq / wo [C][C]; scale = d^-1/2; gate: optional device flag, no-op when *gate == 0
-int launch_rowchain_xattn_pack(const half_t* k, const half_t* vt, const half_t* wq, const half_t* wo, void* packs, int C, int B, int L,
-                               int Lpad, int H, float scale, const int* gate, hipStream_t s);
 // out = x + W2 GEGLU(W1 LN(x) + b1) + b2 (rows % 128 == 0)
 int launch_rowchain_ff(const half_t* x, half_t* out, const float* gamma, const float* beta, const void* packs, const float* bias_out,
                        long rows, int C, int hidden, float eps, hipStream_t s);
-// out = x + to_out(attention(to_q(LN(x)), K, V)) with to_q / to_out folded into the packed per-image key / value matrices
-int launch_rowchain_xattn(const half_t* x, half_t* out, const float* gamma, const float* beta, const void* packs, const float* bias_out,
-                          long rows, int rows_per_img, int img0, int C, int H, float eps, hipStream_t s);
 
 // ---- norms ------------------------------------------------------------------------------------------------
 // pre_nchunk > 0: `ws` already holds partial sums [B][pre_nchunk][groups][2] (written by the producing GEMM): skip the statistics pass

@@ -943,11 +943,8 @@ int launch_small_linear(const float* a, const half_t* w, const float* bias, cons
     const size_t lds = (size_t)rows * K * sizeof(float);
     if (g_small_linear_lds && B <= 16 && lds <= 96 * 1024 && N >= 256) {         // activations fit LDS: staged once per workgroup
         auto kern = rows == 4 ? small_linear_lds_kernel<4, 4> : small_linear_lds_kernel<16, 4>;
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[rows == 4]) {
-            SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set[rows == 4] = true;
-        }
+        static PerDeviceOnce attr[2];
+        if (attr[rows == 4].need()) SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         const int blocks = std::min(cdiv(N, 16), 256);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a, w, bias, add, out, B, N, K, lda, ldo, silu_in ? 1 : 0, silu_out ? 1 : 0);
         SDMI_CHECK_HIP(hipGetLastError());

@@ -793,18 +793,12 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         }
         r.tap(bname + ".attn1+x", x1, B, H, Wd, C);
         // --- cross attention (K / V^T of the context are cached per layer by set_context)
-        // option "fuse_rows" bit 0: norm2 -> to_q -> attention over the text keys -> to_out -> + x1 as one launch (rowchain.hip)
+        // option "fuse_rows" bit 1 (below): the feed-forward third of the block as one launch (rowchain.hip)
         // (not with option "streams" > 1: the feed-forward pack is built lazily on the stream of the slice that meets it first, and the
         // other slices would read it with no event dependency on that stream — the same rule as ln_fold's folded weights)
         const bool chain_ok = !fold && !acc && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0 && e->n_streams <= 1;
         half_t* x2 = nullptr;
-        if (chain_ok && (e->fuse_rows & 1) && b.ctx_slot < (int)e->ctx_xa.size() && e->ctx_xa[b.ctx_slot] != nullptr) {
-            x2 = r.H(M * C);
-            if (!r.dry) {
-                SDMI_REQUIRE(e->ctx_valid && e->ctx_B == (r.Btot ? r.Btot : B), "context not set for this batch size");
-                TRY(launch_rowchain_xattn(x1, x2, b.ln2.g, b.ln2.b, e->ctx_xa[b.ctx_slot], b.o2.b, (long)M, HW, r.b0, C, st.heads, 1e-5f, r.s));
-            }
-        } else {
+        {
         half_t* q2 = nullptr;
         if (fold) {
             LnStats st2;
@@ -889,7 +883,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
 // ------------------------------------------------------------------------------------------------------------
 static void ctx_free(sdmi_engine* e) {
     for (void* p : e->ctx_owned) (void)hipFree(p);
-    e->ctx_owned.clear(); e->ctx_k.clear(); e->ctx_vt.clear(); e->ctx_xa.clear();
+    e->ctx_owned.clear(); e->ctx_k.clear(); e->ctx_vt.clear();
     e->ctx_f16 = nullptr; e->ctx_valid = false;
 }
 
@@ -909,8 +903,7 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
     const int cd = u.cfg.context_dim;
     const int Lpad = rup(L, 64);
     const int* gate = nullptr;
-    const int xa_mode = e->fuse_rows & 1;      // the fused cross-attention chain keeps its own per-image matrices beside K / V^T
-    if (conditional && e->ctx_valid && e->ctx_B == Bn && e->ctx_L == L && !e->ctx_k.empty() && !hn_has_dim(e, cd) && e->ctx_xa_mode == xa_mode) {
+    if (conditional && e->ctx_valid && e->ctx_B == Bn && e->ctx_L == L && !e->ctx_k.empty() && !hn_has_dim(e, cd)) {
         if (!e->ctx_gate) {
             SDMI_CHECK_HIP(hipMalloc((void**)&e->ctx_gate, 256));
             e->owned.push_back(e->ctx_gate);
@@ -919,10 +912,9 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
         TRY(launch_ctx_compare(ctx, dtype, e->ctx_f16, Bn, L, Lpad, cd, e->ctx_gate, s));
         gate = e->ctx_gate;
     }
-    if (e->ctx_B != Bn || e->ctx_L != L || e->ctx_k.empty() || e->ctx_xa_mode != xa_mode) {
+    if (e->ctx_B != Bn || e->ctx_L != L || e->ctx_k.empty()) {
         SDMI_CHECK_HIP(hipStreamSynchronize(s));
         ctx_free(e);
-        e->ctx_xa_mode = xa_mode;
         void* p = nullptr;
         SDMI_CHECK_HIP(hipMalloc(&p, (size_t)Bn * Lpad * cd * sizeof(half_t)));
         e->ctx_owned.push_back(p);
@@ -932,14 +924,8 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
         collect_st(u, &sts);
         e->ctx_k.assign(u.n_ctx_slots, nullptr);
         e->ctx_vt.assign(u.n_ctx_slots, nullptr);
-        e->ctx_xa.assign(u.n_ctx_slots, nullptr);
         for (const STW* st : sts)
             for (const TBlockW& b : st->blocks) {
-                if (xa_mode && rowchain_supports(st->ch) && L <= rowchain_xattn_max_keys() && st->heads * st->dhead == st->ch && !b.q2.b) {
-                    SDMI_CHECK_HIP(hipMalloc(&p, rowchain_xattn_pack_bytes(st->ch, Bn, st->heads)));
-                    e->ctx_owned.push_back(p);
-                    e->ctx_xa[b.ctx_slot] = (char*)p;
-                }
                 SDMI_CHECK_HIP(hipMalloc(&p, (size_t)Bn * L * st->ch * sizeof(half_t)));
                 e->ctx_owned.push_back(p);
                 e->ctx_k[b.ctx_slot] = (half_t*)p;
@@ -999,10 +985,6 @@ static int unet_set_context(sdmi_engine* e, const void* ctx, int dtype, int Bn, 
             TRY(run_conv(r, b.k2, c));
             // V^T[b] = Wv ctx[b]^T : [C][Lpad]
             TRY(run_vt(r, b.v2, ctx_v_src, cd, Bn, Lpad, Lpad, e->ctx_vt[b.ctx_slot], false, gate));
-            // fused cross-attention chain: Kq = (K_h Wq_h) d^-1/2 log2 e and VWo = V_h Wo_h^T per image and head (rowchain.hip)
-            if (e->ctx_xa[b.ctx_slot])
-                TRY(launch_rowchain_xattn_pack(e->ctx_k[b.ctx_slot], e->ctx_vt[b.ctx_slot], b.q2.w, b.o2.w, e->ctx_xa[b.ctx_slot], st->ch, Bn,
-                                               L, Lpad, st->heads, 1.0f / sqrtf((float)st->dhead), gate, s));
         }
     e->ctx_valid = true;
     return 0;

@@ -53,7 +53,7 @@ struct TBlockW {
     ConvW v1;                     // [C][C]   used as the "activation" operand of the V^T GEMM
     ConvW o1, q2, k2, v2, o2, ff1, ff2;
     int ctx_slot = -1;            // index into the per-layer context K / V^T cache
-    // row-local chains (engine option "fuse_rows", rowchain.hip): packed operand stream of ff.net.0.proj / ff.net.2, built lazily,
+    // feed-forward chain (engine option "fuse_rows", rowchain.hip): packed operand stream of ff.net.0.proj / ff.net.2, built lazily,
     // rebuilt when it falls behind the engine's weights_epoch
     mutable char* ff_packs = nullptr;
     mutable long ff_epoch = -1;
@@ -206,13 +206,10 @@ struct sdmi_engine {
     // LayerNorm folded into the consuming GEMMs of the transformer blocks (norm1 -> to_q|to_k, to_v; norm2 -> attn2.to_q; norm3 ->
     // ff.net.0): only the per-row (mean, rstd) are computed, the normalised tensors never reach HBM.  Off by default until measured.
     int ln_fold = 0;                          // 1: row statistics from ln_rowstats_kernel; 2: also per-tile partial sums from the producing GEMMs' epilogues
-    // Row-local chains of the transformer blocks at the 320-wide level as single launches (rowchain.hip).  Bit 0: norm2 -> attn2 (to_q and
-    // to_out folded into per-image key / value matrices kept beside the K / V^T cache) -> + x; bit 1: norm3 -> GEGLU -> ff.net.2 -> + x.
-    // Default 2 (round 5, same-box A/Bs of the forward, profiles/r05_fwd_ab_*): the feed-forward chain is 203-219 us against 263 us of
-    // LayerNorm + GEGLU GEMM + GEMM; the cross-attention chain is issue-bound at 118-147 us against 115 us and stays opt-in.
+    // The feed-forward chain of the transformer blocks at the 320-wide level as a single launch (rowchain.hip), option "fuse_rows" bit 1:
+    // norm3 -> GEGLU -> ff.net.2 -> + x.  Default 2 (round 5, same-box A/Bs of the forward, profiles/r05_fwd_ab_*): 203-219 us against
+    // 263 us of LayerNorm + GEGLU GEMM + GEMM.  (Bit 0 was the cross-attention chain: measured slower, removed in round 6; the bit is ignored.)
     int fuse_rows = [] { const char* e = getenv("SDMI_FUSE_ROWS"); return e ? atoi(e) : 2; }();
-    std::vector<char*> ctx_xa;                // per context slot: packed Kq / VWo stream [Bn][heads] (null: not built for this slot)
-    int ctx_xa_mode = 0;                      // value of (fuse_rows & 1) the context cache was allocated under
     // Accuracy mode (option "residual_fp32", off by default — the engine's counterpart of the reference's --no-half / upcast options,
     // modules/devices.py:284-295, modules/sd_hijack_optimizations.py:232-233): the UNet's carried stream — conv_in / ResBlock /
     // transformer-block / proj_out / down- and upsample outputs and the skip_connection 1x1 — is kept as (hi, lo) fp16 pairs

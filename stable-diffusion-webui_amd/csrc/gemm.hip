@@ -101,105 +101,152 @@ __device__ __forceinline__ void gemm_epilogue_hilo(const GemmP& p, f4 (&acc)[TM]
     const int sel = (lane >> 4) & 1, nw = (lane >> 5) * 8, lr = lane & 15;
     const int mw = m0 + wr * WTM + sel * 16 + lr;            // the lane's store row in pair 0 (pair a: + 32 a)
     const int mrow = m0 + wr * WTM + lr;                     // the lane's accumulator row in tile 0 (tile i: + 16 i)
-    [[maybe_unused]] float* cs = reinterpret_cast<float*>(smem);
-    [[maybe_unused]] float* cq = cs + WR_ * BN_;
-    if constexpr (STATS) __syncthreads();                    // every wave is done reading the operand tiles that lived here
+    auto ld = [&](const half_t* base, int a, int j) {
+        return *reinterpret_cast<const h8*>(base + rbs + (long)min(mw + a * 32, p.M - 1) * p.ldr + n0 + wc * WTN + j * 16 + nw);
+    };
+    // one (pair a, column tile j) cell: v = alpha acc + bias [+ rowbias] [+ resid hi + lo]; returns the pair (hi, lo) in the 16-byte layout
+    // and, for the statistics form, leaves the accumulator-layout values in vx / vy
+    auto cell = [&](int a, int j, const f4& bb, const h8& ch, const h8& cl, f4& vx, f4& vy, h4& ox, h4& oy, h4& lx, h4& ly) {
+        const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;
+        vx = acc[2 * a][j]; vy = acc[2 * a + 1][j];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wc * WTN + j * 16 + (lane >> 4) * 4;      // accumulator layout: 4 columns
-        const int nn = n0 + wc * WTN + j * 16 + nw;                  // 16-byte layout: 8 columns
+        for (int r = 0; r < 4; ++r) { vx[r] = fmaf(vx[r], p.alpha, bb[r]); vy[r] = fmaf(vy[r], p.alpha, bb[r]); }
+        if (p.rowbias) {
+            const int mx = mrow + 2 * a * 16;
+            vx += *reinterpret_cast<const f4*>(p.rowbias + (long)(min(mx, p.M - 1) / p.rows_per_batch) * p.ldrb + n);
+            vy += *reinterpret_cast<const f4*>(p.rowbias + (long)(min(mx + 16, p.M - 1) / p.rows_per_batch) * p.ldrb + n);
+        }
+        if (p.resid) {
+            h4 rx = {ch[0], ch[1], ch[2], ch[3]}, ry = {ch[4], ch[5], ch[6], ch[7]};
+            swap16(rx, ry);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vx[r] += (float)rx[r]; vy[r] += (float)ry[r]; }
+            if (rlo) {
+                h4 sx = {cl[0], cl[1], cl[2], cl[3]}, sy = {cl[4], cl[5], cl[6], cl[7]};
+                swap16(sx, sy);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { vx[r] += (float)sx[r]; vy[r] += (float)sy[r]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ox[r] = (half_t)vx[r]; oy[r] = (half_t)vy[r];
+            lx[r] = (half_t)(vx[r] - (float)ox[r]); ly[r] = (half_t)(vy[r] - (float)oy[r]);
+        }
+    };
+    auto store = [&](int a, int j, h4 ox, h4 oy, h4 lx, h4 ly) {
+        swap16(ox, oy);
+        swap16(lx, ly);
+        const int ms = mw + a * 32;
+        if (ms < p.M) {
+            const long o = ob + (long)ms * p.ldo + n0 + wc * WTN + j * 16 + nw;
+            *reinterpret_cast<h8*>((half_t*)p.out + o) = join8(ox, oy);
+            if (olo) *reinterpret_cast<h8*>(olo + o) = join8(lx, ly);
+        }
+    };
+    auto col_bias = [&](int j) {
         f4 bb = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
-            bb = *reinterpret_cast<const f4*>(p.bias + n);
+            bb = *reinterpret_cast<const f4*>(p.bias + n0 + wc * WTN + j * 16 + (lane >> 4) * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bb[r] *= p.bias_scale;
         }
-        [[maybe_unused]] f4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
-        constexpr bool RING = true;
-        h8 rh = {0, 0, 0, 0, 0, 0, 0, 0}, rl = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto ld = [&](const half_t* base, int a) {
-            return *reinterpret_cast<const h8*>(base + rbs + (long)min(mw + a * 32, p.M - 1) * p.ldr + nn);
-        };
-        if (RING && p.resid) { rh = ld(p.resid, 0); if (rlo) rl = ld(rlo, 0); }
+        return bb;
+    };
+    const h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (!STATS) {
+        // plain form: row-tile pair OUTER, column tile inner, as the default path — consecutive column tiles of a row are written back to
+        // back, so the 32-byte pieces of a line meet in the L2 (column-tile-outer measured 80.9 us against 35.4 us for the fp16 launch on
+        // M65536 N320 K320: 2.6 TB/s).  The (hi, lo) residual of cell (a + 1, j) is requested as soon as cell (a, j) has consumed its
+        // registers: a one-deep ring with a whole row pair of cover.
+        constexpr bool RING = TN <= 5;
+        f4 bcw[RING ? TN : 1];
+        h8 rh[RING ? TN : 1], rl[RING ? TN : 1];
+        if constexpr (RING) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bcw[j] = col_bias(j);
+                rh[j] = p.resid ? ld(p.resid, 0, j) : z8;
+                rl[j] = rlo ? ld(rlo, 0, j) : z8;
+            }
+        }
 #pragma unroll
         for (int a = 0; a < TM / 2; ++a) {
-            const int mx = mrow + 2 * a * 16, my = mx + 16;
-            f4 vx = acc[2 * a][j], vy = acc[2 * a + 1][j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { vx[r] = fmaf(vx[r], p.alpha, bb[r]); vy[r] = fmaf(vy[r], p.alpha, bb[r]); }
-            if (p.rowbias) {
-                vx += *reinterpret_cast<const f4*>(p.rowbias + (long)(min(mx, p.M - 1) / p.rows_per_batch) * p.ldrb + n);
-                vy += *reinterpret_cast<const f4*>(p.rowbias + (long)(min(my, p.M - 1) / p.rows_per_batch) * p.ldrb + n);
-            }
-            if (p.resid) {
-                if constexpr (!RING) { rh = ld(p.resid, a); if (rlo) rl = ld(rlo, a); }
-                const h8 ch = rh, cl = rl;
-                if (RING && a + 1 < TM / 2) { rh = ld(p.resid, a + 1); if (rlo) rl = ld(rlo, a + 1); }
-                h4 rx = {ch[0], ch[1], ch[2], ch[3]}, ry = {ch[4], ch[5], ch[6], ch[7]};
-                swap16(rx, ry);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { vx[r] += (float)rx[r]; vy[r] += (float)ry[r]; }
-                if (rlo) {
-                    h4 lx = {cl[0], cl[1], cl[2], cl[3]}, ly = {cl[4], cl[5], cl[6], cl[7]};
-                    swap16(lx, ly);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { vx[r] += (float)lx[r]; vy[r] += (float)ly[r]; }
+            for (int j = 0; j < TN; ++j) {
+                f4 vx, vy;
+                h4 ox, oy, lx, ly;
+                if constexpr (RING) {
+                    const h8 ch = rh[j], cl = rl[j];
+                    if (a + 1 < TM / 2) {
+                        if (p.resid) rh[j] = ld(p.resid, a + 1, j);
+                        if (rlo) rl[j] = ld(rlo, a + 1, j);
+                    }
+                    cell(a, j, bcw[j], ch, cl, vx, vy, ox, oy, lx, ly);
+                } else {
+                    const h8 ch = p.resid ? ld(p.resid, a, j) : z8, cl = rlo ? ld(rlo, a, j) : z8;
+                    cell(a, j, col_bias(j), ch, cl, vx, vy, ox, oy, lx, ly);
                 }
+                store(a, j, ox, oy, lx, ly);
             }
+        }
+        return;
+    }
+    // statistics form: column tile OUTER so that the lane's column sums over its TM rows are 8 live values (gemm_epilogue's STATS note)
+    [[maybe_unused]] float* cs = reinterpret_cast<float*>(smem);
+    [[maybe_unused]] float* cq = cs + WR_ * BN_;
+    __syncthreads();                                         // every wave is done reading the operand tiles that lived here
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const f4 bb = col_bias(j);
+        f4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+        h8 rh = p.resid ? ld(p.resid, 0, j) : z8, rl = rlo ? ld(rlo, 0, j) : z8;
+#pragma unroll
+        for (int a = 0; a < TM / 2; ++a) {
+            const h8 ch = rh, cl = rl;
+            if (a + 1 < TM / 2) {
+                if (p.resid) rh = ld(p.resid, a + 1, j);
+                if (rlo) rl = ld(rlo, a + 1, j);
+            }
+            f4 vx, vy;
             h4 ox, oy, lx, ly;
+            cell(a, j, bb, ch, cl, vx, vy, ox, oy, lx, ly);
+            const bool okx = mrow + 2 * a * 16 < p.M, oky = mrow + (2 * a + 1) * 16 < p.M;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ox[r] = (half_t)vx[r]; oy[r] = (half_t)vy[r];
-                lx[r] = (half_t)(vx[r] - (float)ox[r]); ly[r] = (half_t)(vy[r] - (float)oy[r]);
+                const float f = okx ? (float)ox[r] + (float)lx[r] : 0.f;
+                sv[r] += f;
+                qv[r] = fmaf(f, f, qv[r]);
             }
-            if constexpr (STATS) {
-                const bool okx = mx < p.M, oky = my < p.M;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float f = okx ? (float)ox[r] + (float)lx[r] : 0.f;
-                    sv[r] += f;
-                    qv[r] = fmaf(f, f, qv[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float f = oky ? (float)oy[r] + (float)ly[r] : 0.f;
-                    sv[r] += f;
-                    qv[r] = fmaf(f, f, qv[r]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float f = oky ? (float)oy[r] + (float)ly[r] : 0.f;
+                sv[r] += f;
+                qv[r] = fmaf(f, f, qv[r]);
             }
-            swap16(ox, oy);
-            swap16(lx, ly);
-            const int ms = mw + a * 32;
-            if (ms < p.M) {
-                *reinterpret_cast<h8*>((half_t*)p.out + ob + (long)ms * p.ldo + nn) = join8(ox, oy);
-                if (olo) *reinterpret_cast<h8*>(olo + ob + (long)ms * p.ldo + nn) = join8(lx, ly);
-            }
+            store(a, j, ox, oy, lx, ly);
         }
-        if constexpr (STATS) {
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1)
+        for (int off = 1; off < 16; off <<= 1)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { sv[r] += __shfl_xor(sv[r], off); qv[r] += __shfl_xor(qv[r], off); }
-            if ((lane & 15) == 0) {
-                const int c = wc * WTN + j * 16 + (lane >> 4) * 4;
-                *reinterpret_cast<f4*>(cs + wr * BN_ + c) = sv;
-                *reinterpret_cast<f4*>(cq + wr * BN_ + c) = qv;
-            }
+            for (int r = 0; r < 4; ++r) { sv[r] += __shfl_xor(sv[r], off); qv[r] += __shfl_xor(qv[r], off); }
+        if ((lane & 15) == 0) {
+            const int c = wc * WTN + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<f4*>(cs + wr * BN_ + c) = sv;
+            *reinterpret_cast<f4*>(cq + wr * BN_ + c) = qv;
         }
     }
-    if constexpr (STATS) {
-        __syncthreads();
-        const int tid = threadIdx.x, cpg = p.stats_cpg, ngl = BN_ / cpg;
-        if (tid < ngl) {
-            float a = 0.f, q = 0.f;
-            for (int w = 0; w < WR_; ++w)
-                for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[w * BN_ + c]; q += cq[w * BN_ + c]; }
-            const int b = m0 / p.rows_per_batch;             // (a tile lies inside one image: launch_gemm's admission rule)
-            const int chunk = (m0 - b * p.rows_per_batch) / (TM * 16 * WR_);
-            const int G = p.N / cpg, g = n0 / cpg + tid;
-            float* dst = p.stats_out + (((long)b * p.stats_nchunk + chunk) * G + g) * 2;
-            dst[0] = a; dst[1] = q;
-        }
+    __syncthreads();
+    const int tid = threadIdx.x, cpg = p.stats_cpg, ngl = BN_ / cpg;
+    if (tid < ngl) {
+        float a = 0.f, q = 0.f;
+        for (int w = 0; w < WR_; ++w)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[w * BN_ + c]; q += cq[w * BN_ + c]; }
+        const int b = m0 / p.rows_per_batch;                 // (a tile lies inside one image: launch_gemm's admission rule)
+        const int chunk = (m0 - b * p.rows_per_batch) / (TM * 16 * WR_);
+        const int G = p.N / cpg, g = n0 / cpg + tid;
+        float* dst = p.stats_out + (((long)b * p.stats_nchunk + chunk) * G + g) * 2;
+        dst[0] = a; dst[1] = q;
     }
 }
 
@@ -330,9 +377,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
         // 256x320 instantiation 6 SGPR spills.)
         return;
     }
-    // (not the statistics form of the 256x320 tiles: 160 accumulator registers per lane leave no room for it — launch_gemm keeps the
-    // consumer's own statistics pass for those launches)
-    if constexpr (!GEGLU && LNM == 0 && TM % 2 == 0 && !(STATS && TM * TN >= 40)) {
+    // (not on the 256x320 tiles: 160 accumulator registers per lane leave no room for its rings — launch_gemm steers (hi, lo) launches
+    // to the 128x320 tile; one that lands there anyway (a forced configuration) takes the 8-byte general path below, without statistics)
+    if constexpr (!GEGLU && LNM == 0 && TM % 2 == 0 && TM * TN < 40) {
         if ((flags & EP_HILO) && !(flags & EP_NARROW)) {     // (hi, lo) stream tensors: their own region (block-uniform branch)
             gemm_epilogue_hilo<TM, TN, WTM, WTN, WR_, BN_, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
             return;
@@ -2086,11 +2133,8 @@ static int launch_cfg2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = NS * (BM + BN) * BK * 2;
     constexpr int NT = WR * WC * 64;
     auto kern = gemm_mfma_kernel<BM, BN, WR, WC, BK, GLDS, GEGLU, TR, KORD, STATS, LNM, NS, LIN, LIN3>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
+    static PerDeviceOnce attr;
+    if (attr.need()) SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     const int tiles = cdiv(p.M, BM) * (p.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(NT), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
@@ -2101,11 +2145,8 @@ template <int BM, int BN, bool GEGLU, bool TR = false, bool KORD = false, bool S
 static int launch_pingpong2(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BN) * 128 + 8192;      // tile buffers + packed gather words
     auto kern = gemm_mfma_pingpong_kernel<BM, BN, GEGLU, false, TR, KORD, STATS, LNM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
+    static PerDeviceOnce attr;
+    if (attr.need()) SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     const int tiles = cdiv(p.M, BM) * (p.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(512), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
@@ -2116,11 +2157,8 @@ static int launch_pingpong_dx(const GemmP& p, int batch, hipStream_t s) {
     constexpr int SMEM = 2 * (BM + BM / 16 + 1 + BN) * 128 + 8192;  // tile buffers (activations with guard rows) + packed gather words
     const bool stats = p.stats_nchunk > 0;
     auto kern = stats ? gemm_mfma_pingpong_dx_kernel<BM, BN, true> : gemm_mfma_pingpong_dx_kernel<BM, BN, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[stats]) {
-        SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set[stats] = true;
-    }
+    static PerDeviceOnce attr[2];
+    if (attr[stats].need()) SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     const int tiles = cdiv(p.M, BM) * (p.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles, p.splitk > 1 ? p.splitk : 1, batch), dim3(512), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
@@ -2487,7 +2525,14 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     SDMI_REQUIRE(!(p.flags & EP_TRANSPOSE) || (p.rows_per_batch % 4 == 0 && p.M % 4 == 0 && !(p.flags & (EP_GEGLU | EP_NCHW | EP_OUT_F32 | EP_BIAS_ROW)) &&
                                                !p.resid && !p.rowbias),
                  "EP_TRANSPOSE: rows per image must be a multiple of 4; no residual / GEGLU / fp32 output");
-    const int cfg = pick_cfg(p, batch, &split, can_split);
+    const int cfg_picked = pick_cfg(p, batch, &split, can_split);
+    // (hi, lo) launch on the 256x320 tile (160 accumulator registers: no room for gemm_epilogue_hilo's rings, no statistics form): the
+    // 128x320 tile instead — the 8-byte path + the consumer's own statistics pass over the pair cost more than the tile change (round 6,
+    // profiles/r06_fwd_ab_accuracy.txt: M65536 N320 K320 80.9 us against 35.4 us for the fp16 launch)
+    int cfg_sel = cfg_picked;
+    if (hilo && cfg_picked == CFG_256x320 && split <= 1 && cfg_valid(CFG_128x320, p) && g_force_gemm_cfg < 0) cfg_sel = CFG_128x320;
+    const int cfg = cfg_sel;
+    if (hilo && cfg == CFG_256x320) p.flags |= EP_NARROW;     // (a forced configuration: the 8-byte general path carries the pair there)
     // ping-pong kernel: every weight row must exist (no n_valid masking) and a (tap, source) segment must fit the zero page
     const bool phase = use_glds && (g_gemm_pipe == 3 || g_gemm_pipe == 4) &&
                        (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_256x128 || (cfg == CFG_128x320 && g_gemm_pipe == 4)) && p.n_valid == p.N &&

@@ -1,35 +1,34 @@
-// rowchain.hip — the row-local chains of a BasicTransformerBlock as ONE launch each (gfx950; fp16 operands, fp32 accumulate).
+// rowchain.hip — the feed-forward chain of a BasicTransformerBlock as ONE launch (gfx950; fp16 operands, fp32 accumulate).
 //
 // Everything a transformer block does after its self-attention is local to a token row
-// (/root/reference/modules/sd_hijack_unet.py:83-102 around ldm's BasicTransformerBlock._forward):
-//     x2 = x1 + to_out( softmax( to_q(LN2(x1)) K^T * d^-1/2 ) V )          K, V: the 77 text keys (attn2)
+// (/root/reference/modules/sd_hijack_unet.py:83-102 around ldm's BasicTransformerBlock._forward); this file fuses the last third,
 //     x3 = x2 + W2 ( (W1v LN3(x2) + b1v) * gelu(W1g LN3(x2) + b1g) ) + b2    (ff: GEGLU -> Linear)
-// As separate launches (LayerNorm, q GEMM, attention, out GEMM | LayerNorm, GEGLU GEMM, GEMM) the 42 MB token stream of the 320-wide
-// level is written and re-read seven times, the 4C-wide hidden tensor (168 MB) is written and read once, and M65536 N320 K320 is
-// fabric-bound as a standalone GEMM (profiles/r04_*).  Here a workgroup owns 128 whole rows and the chain never leaves the CU.
+// As separate launches (LayerNorm, GEGLU GEMM, GEMM) the 42 MB token stream of the 320-wide level is written and re-read three times and
+// the 4C-wide hidden tensor (168 MB) is written and read once.  Here a workgroup owns 128 whole rows and the chain never leaves the CU.
 //
-// Both chains have the shape of flash attention WITHOUT the online softmax, with the row's width C as the "head size":
+// The chain has the shape of flash attention WITHOUT the online softmax, with the row's width C as the "head size":
 //     stage 1   S^T[u][row] = B1_j[u][:] . n[row][:]          u = the 32 rows of a B1 unit, contraction over C
-//     middle    P = f(S)    per row, inside one lane           (softmax over a head's keys | GEGLU)
+//     middle    P = f(S)    per row, inside one lane           (GEGLU)
 //     stage 2   O^T[c][row] += B2_j[c][u] P[u][row]           c = 0 .. C-1, contraction over the unit's 32 columns
-// and they use attention.hip's formulation: v_mfma_f32_32x32x16_f16 with the MATRIX rows coming from LDS as the A operand and the
-// token rows as the B operand held in registers — a lane owns one token row (q = lane & 31) and half of its columns, so LayerNorm,
-// softmax and GEGLU need no cross-lane traffic beyond one v_permlane32_swap, and P feeds stage 2 straight from the accumulator registers
-// (B1 rows are read with bits 2/3 of the row index swapped, so the 8 values a lane packs are 8 consecutive units: attention.hip header).
-//
-//   feed-forward    j = 40 chunks of 32 hidden units: B1 = the chunk's 32 value rows and its 32 gate rows of ff.net.0.proj, B2 = the
-//                   chunk's 32 columns of ff.net.2.  Same flops as the two GEMMs.
-//   cross-attention j = head h: B1 = Kq_h = (K_h Wq_h) * d^-1/2 log2(e)  [96 keys x C],  B2 = VWo_h = (V_h Wo_h^T)^T  [C x 96 keys]
-//                   — to_q and to_out are FOLDED into the per-image key / value matrices (computed once per context by
-//                   rowchain_xattn_pack_kernel, like the K / V^T cache itself), so each head is one C-wide contraction on either side of
-//                   its softmax instead of a d = 40 one: 1.5x the flops of the unfused graph at the 320-wide level, all of them
-//                   full-rate MFMA tiles, and q, the attention output and both LayerNorm outputs never exist.
+// and uses attention.hip's formulation: v_mfma_f32_32x32x16_f16 with the MATRIX rows coming from LDS as the A operand and the token
+// rows as the B operand held in registers — a lane owns one token row (q = lane & 31) and half of its columns, so LayerNorm and GEGLU
+// need no cross-lane traffic beyond one v_permlane32_swap, and P feeds stage 2 straight from the accumulator registers (B1 rows are
+// read with bits 2/3 of the row index swapped, so the 8 values a lane packs are 8 consecutive units: attention.hip header).
+//   j = 40 chunks of 32 hidden units: B1 = the chunk's 32 value rows and its 32 gate rows of ff.net.0.proj, B2 = the chunk's 32 columns
+//   of ff.net.2.  Same flops as the two GEMMs.
 //
 // Register budget: the row fragments (C / 16 x h8 = 80 VGPRs), the O^T accumulators (C / 32 x 16 = 160) and the score blocks make
 // this a one-wave-per-SIMD kernel (4 waves x 32 rows, up to 512 registers).  The operands are streamed by the same waves with LDS-direct
 // loads: the packed operand stream in HBM IS the LDS image (padded rows, accumulator-init tables in the unit tails), so a stage is a
-// linear copy of whole 1 KB pieces, one phase ahead of its use, one barrier per phase.  The middle op of chunk j and stage 2 of chunk
-// j - 1 sit in the same basic block, so the VALU work runs under the MFMAs of the previous chunk.
+// linear copy of whole 1 KB pieces, one phase ahead of its use, one barrier per phase.  GEGLU of chunk j - 1 sits between the stage-1
+// MFMAs of chunk j.
+//
+// Round 6 froze the file at this form.  Removed: the cross-attention chain (norm2 -> to_q -> attention over the 77 text
+// keys -> to_out as one launch with to_q / to_out folded into per-image key / value matrices: 118-166 us in the forward against 115 us for
+// the four launches it replaced), the 8-wave feed-forward form (two waves per SIMD: +5 %) and the component-removal timing variants —
+// measurements and analysis stay in profiles/r05_rowchain_parts.txt, r05_fwd_ab_fuse_rows.txt, r05_fwd_ab_ff8.txt and DESIGN.md 9.2; the
+// code is in the history (round 5).  What limits the chain — one in-order wave per SIMD, a fresh 1 KB LDS fragment per MFMA — is the
+// design (one token row per lane), not the schedule, so neither register blocking nor a 640-wide instantiation was built.
 #include "common.h"
 #include "prof.h"
 #include <algorithm>
@@ -53,7 +52,6 @@ struct RcGeo {
     static constexpr int B2STR = 80;                          // 32 halfs + 16 bytes: 5 slots
     static constexpr int B2UNIT = C * B2STR;
     static constexpr int FFPACK = (2 * B1UNIT + B2UNIT + 4095) / 4096 * 4096;            // feed-forward pack (whole pieces for all 4 waves)
-    static constexpr int XA_A = (3 * B1UNIT + 4095) / 4096 * 4096, XA_B = (3 * B2UNIT + 4095) / 4096 * 4096;   // cross-attention regions (3 key blocks)
     static_assert(C % 64 == 0, "row width must be a multiple of 64 (whole 1 KB pieces)");
 };
 
@@ -62,15 +60,12 @@ struct RowChainP {
     half_t* out;              // [M][C]
     const float* gamma;       // LayerNorm affine [C]
     const float* beta;
-    const char* packs;        // packed operand stream (rowchain_*_pack_kernel)
-    const float* bias_out;    // [C] (the launchers substitute zeros for a null pointer)
+    const char* packs;        // packed operand stream (rowchain_ff_pack_kernel)
+    const float* bias_out;    // [C] (the launcher substitutes zeros for a null pointer)
     int M;                    // rows, a multiple of 128
-    int rows_per_img;         // cross-attention: tokens per image (a multiple of 128); the pack stream is per image
-    int img0;                 // first image of this call inside the pack stream (batch slices)
-    int nchunk;               // feed-forward: hidden / 32; cross-attention: heads
+    int nchunk;               // hidden / 32
     float eps;
     const half_t* zero;       // the zero page (padding lanes of the row staging)
-    long long* dbg;           // VAR 10 (SDMI_RC_PARTS builds): per wave (sync, stage 1 + GEGLU, stage 2) cycle sums and the iteration count
 };
 
 __device__ __forceinline__ float rc_gelu_erf(float g) {      // gemm.hip's gelu_erf (exact-erf GELU, A&S 7.1.26), instruction for instruction
@@ -222,12 +217,6 @@ __device__ __forceinline__ void rc_issue(const char* src, char* dst, int wave, i
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ long long rc_stamp() {            // s_memtime, serialised against the LDS / scalar queue
-    const long long t = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return t;
-}
-
 __device__ __forceinline__ void rc_phase_sync() {          // my loads have landed; everybody's have; everybody left the previous phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -247,9 +236,7 @@ constexpr int kRcPF = 8;
 // sliced between them, then O += B2(j - 1) P(j - 1) (20 MFMAs).  Two score sets alternate (template parity), two pack buffers in LDS;
 // pack j + 1 is issued during iteration j.
 // ---------------------------------------------------------------------------------------------------------------
-// VAR (SDMI_RC_VAR, timing experiments only — results are wrong for VAR > 0): 1 no GEGLU arithmetic, 2 no operand fetches after the first
-// pack, 3 no LDS fragment reads in the step loop, 4 no MFMAs, 5 no phase synchronisation
-template <int C, int VAR = 0>
+template <int C>
 __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     typedef RcGeo<C> G;
     constexpr int PACK = G::FFPACK, NP = PACK / 1024, PF = kRcPF;
@@ -284,17 +271,12 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     const unsigned lane16 = (unsigned)lane * 16u;
 
     // iteration j.  S1: chunk j exists (stage 1, and pack j + 1 is fetched); S2: chunk j - 1 exists (GEGLU + stage 2); PAR = j & 1
-    [[maybe_unused]] long long tm[4] = {0, 0, 0, 0};
-    constexpr int LE = (VAR == 7 || VAR == 9) ? 1 : 3;       // one operand piece every LE steps
-    constexpr bool SB = !(VAR == 8 || VAR == 9);             // a sched_barrier closes every step
+    constexpr int LE = 3;                                    // one operand piece every LE steps
     auto phase = [&](int j, auto s1c, auto s2c, auto parc) {
         constexpr bool S1 = decltype(s1c)::value, S2 = decltype(s2c)::value;
         constexpr int PAR = decltype(parc)::value;
         constexpr int N1 = S1 ? 2 * NDC : 0, N2 = S2 ? 2 * NDB : 0, NS = N1 + N2;
-        [[maybe_unused]] long long tq0 = 0, tq1 = 0, tq2 = 0;
-        if constexpr (VAR == 10) tq0 = rc_stamp();
-        if constexpr (VAR != 5) rc_phase_sync();
-        if constexpr (VAR == 10) tq1 = rc_stamp();
+        rc_phase_sync();
         const char* reg = smem + (j & 1) * PACK;
         const char* b1 = reg + ka_off;
         const char* b2 = reg + 2 * G::B1UNIT + va_off;
@@ -317,35 +299,24 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
         h8 pb[2];
         if constexpr (S2 && !S1) {           // last iteration: nothing to hide the GEGLU under
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (half_t)(VAR == 1 ? sv[PAR ^ 1][r] + sg[PAR ^ 1][r] : SDMI_GELU_SIG ? geglu_gate(sv[PAR ^ 1][r], sg[PAR ^ 1][r]) : sv[PAR ^ 1][r] * rc_gelu_erf(sg[PAR ^ 1][r]));
+            for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (half_t)(SDMI_GELU_SIG ? geglu_gate(sv[PAR ^ 1][r], sg[PAR ^ 1][r]) : sv[PAR ^ 1][r] * rc_gelu_erf(sg[PAR ^ 1][r]));
         }
         rc_static_for<NS>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const h8 a = ring[i % PF];
-            if constexpr (VAR == 4) {
-                if constexpr (i < N1 && i % 2 == 0) asm volatile("" : "+v"(sv[PAR]) : "v"(a), "v"(xf[i / 2]));
-                else if constexpr (i < N1) asm volatile("" : "+v"(sg[PAR]) : "v"(a), "v"(xf[i / 2]));
-                else asm volatile("" : "+v"(o[(i - N1) % NDB]) : "v"(a), "v"(pb[(i - N1) / NDB]));
-            } else {
             if constexpr (i < N1 && i % 2 == 0) sv[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[i / 2], sv[PAR], 0, 0, 0);
             else if constexpr (i < N1) sg[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[i / 2], sg[PAR], 0, 0, 0);
             else o[(i - N1) % NDB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[(i - N1) / NDB], o[(i - N1) % NDB], 0, 0, 0);
-            }
-            if constexpr (i + PF < NS && VAR != 3) ring[i % PF] = rc_lds(addr(std::integral_constant<int, (i + PF < NS ? i + PF : 0)>{}));
-            if constexpr (S1 && i % LE == LE - 1 && VAR != 2) rc_issue_piece<NP>(gnext, lane16, lnext, i / LE);
+            if constexpr (i + PF < NS) ring[i % PF] = rc_lds(addr(std::integral_constant<int, (i + PF < NS ? i + PF : 0)>{}));
+            if constexpr (S1 && i % LE == LE - 1) rc_issue_piece<NP>(gnext, lane16, lnext, i / LE);
             // GEGLU of chunk j - 1, element r = (i - 1) / 2 at the odd stage-1 steps 1 .. 31
             if constexpr (S1 && S2 && i % 2 == 1 && i / 2 < 16) {
                 constexpr int r = i / 2;
-                pb[r >> 3][r & 7] = (half_t)(VAR == 1 ? sv[PAR ^ 1][r] + sg[PAR ^ 1][r] : SDMI_GELU_SIG ? geglu_gate(sv[PAR ^ 1][r], sg[PAR ^ 1][r]) : sv[PAR ^ 1][r] * rc_gelu_erf(sg[PAR ^ 1][r]));
+                pb[r >> 3][r & 7] = (half_t)(SDMI_GELU_SIG ? geglu_gate(sv[PAR ^ 1][r], sg[PAR ^ 1][r]) : sv[PAR ^ 1][r] * rc_gelu_erf(sg[PAR ^ 1][r]));
             }
-            if constexpr (VAR == 10 && i == N1 - 1) tq2 = rc_stamp();
-            if constexpr (SB) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);               // a sched_barrier closes every step
         });
-        if constexpr (VAR == 10 && S1 && S2) {
-            const long long tq3 = rc_stamp();
-            tm[0] += tq1 - tq0; tm[1] += tq2 - tq1; tm[2] += tq3 - tq2; tm[3] += 1;
-        }
-        if constexpr (S1 && VAR != 2) {      // pieces the step loop had no slot for (NS / LE slots)
+        if constexpr (S1) {                  // pieces the step loop had no slot for (NS / LE slots)
 #pragma unroll
             for (int k = NS / LE; k < NP / 4; ++k) rc_issue_piece<NP>(gnext, lane16, lnext, k);
         }
@@ -354,7 +325,6 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     using F = std::false_type;
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    if constexpr (VAR != 6) {
     phase(0, T{}, F{}, P0{});
     int j = 1;
     for (; j + 1 < nch; j += 2) {            // two chunks per trip: no join between the parities, so no register shuffling
@@ -364,333 +334,8 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     if (j < nch) { phase(j, T{}, T{}, P1{}); ++j; }
     if (nch & 1) phase(nch, F{}, T{}, P1{});
     else phase(nch, F{}, T{}, P0{});
-    } else {
-        rc_phase_sync();
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) o[db][0] = (float)xf[db][0];
-    }
-
-    if constexpr (VAR == 10) {
-        if (p.dbg && lane == 0) {
-            long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 4;
-            for (int i = 0; i < 4; ++i) d[i] = tm[i];
-        }
-    }
     rc_phase_sync();                                         // every wave is past its last operand read
     rc_store<C>(p, (long)blockIdx.x * 128 + wave * 32, smem + wave * G::B1UNIT, lane, o);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// feed-forward chain, 8-wave form (knob rc_ff8; pack layout 1).  The 4-wave kernel above is issue-bound: with ONE wave per SIMD the
-// LDS-direct loads (17 per wave and chunk, ~100 cycles of issue each), the fragment reads and the GEGLU VALU work are issued by the same
-// in-order wave that issues the MFMAs — T = T_mfma + 0.65 T_other measured (profiles/r05_rowchain_parts.txt).  Here each SIMD holds TWO
-// waves of the same 32 rows (waves w and w + 4), each under 256 registers: wave (rg, ch) computes the scores of half of the chunk's
-// hidden units (its B1 unit = 16 value + 16 gate rows: 20 MFMAs), applies GEGLU to them — the 8 results per lane ARE the stage-2 operand
-// fragment pb[ch] —, hands that fragment to its partner through LDS, and accumulates O^T for half of the output columns (10 MFMAs).
-// The two waves of a SIMD issue into each other's gaps, as in the ping-pong GEMM.  Two barriers per chunk.
-// ---------------------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(512, 2) void rowchain_ff8_kernel(RowChainP p) {
-    typedef RcGeo<C> G;
-    constexpr int PACK = G::FFPACK, NP = PACK / 1024, PF = 4;
-    constexpr int NDC = G::NDC, NDBH = G::NDB / 2;           // output blocks per wave
-    static_assert(G::NDB % 2 == 0, "two column halves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave & 3, ch = wave >> 2;
-    const int half = lane >> 5, lq = lane & 31;
-    const long row0 = (long)blockIdx.x * 128 + rg * 32;
-    char* const xchg = smem + 2 * PACK;                      // [8 waves][64 lanes] x 16 bytes: the GEGLU fragments handed to the partner wave
-    const char* const gsrc = p.packs + wave * 1024;
-    const unsigned lane16 = (unsigned)lane * 16u;
-    auto issue_pack = [&](int j) {
-        const char* g = gsrc + (long)j * PACK;
-        char* l = smem + (j & 1) * PACK + wave * 1024;
-#pragma unroll
-        for (int k = 0; k < NP / 8; ++k) __builtin_amdgcn_global_load_lds((gptr_t)(g + k * 8192 + lane16), (lptr_t)(l + k * 8192), 16, 0, 0);
-        if constexpr (NP % 8 != 0) {
-            if (wave < NP % 8)
-                __builtin_amdgcn_global_load_lds((gptr_t)(g + (NP / 8) * 8192 + lane16), (lptr_t)(l + (NP / 8) * 8192), 16, 0, 0);
-        }
-    };
-
-    // prologue: the row groups through the second pack buffer (staged by the ch = 0 waves, read by both), pack 0 meanwhile
-    char* const xreg = smem + PACK + rg * G::B1UNIT;
-    if (ch == 0) rc_stage_rows<C>(p.x + row0 * C, xreg, lane, p.zero);
-    issue_pack(0);
-    if (ch == 0) { if (wave < NP % 8) wait_vm<NP / 8 + 1>(); else wait_vm<NP / 8>(); }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    h8 xf[NDC];
-    rc_load_ln<C>(xreg, lq, p.gamma, p.beta, p.eps, half, xf);
-
-    f16v o[NDBH];
-#pragma unroll
-    for (int db = 0; db < NDBH; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
-    const int ka_off = ch * G::B1UNIT + krow * G::B1STR + half * 16;
-    const int va_off = 2 * G::B1UNIT + (ch * NDBH * 32 + lq) * G::B2STR + half * 16;
-    const int nch = p.nchunk;
-
-    for (int j = 0; j < nch; ++j) {
-        rc_phase_sync();                                     // pack j has landed everywhere; everybody is past stage 2 of chunk j - 1
-        if (j + 1 < nch) issue_pack(j + 1);
-        const char* reg = smem + (j & 1) * PACK;
-        // ---- stage 1: this wave's B1 unit
-        f16v sc = rc_init<C>(reg + ch * G::B1UNIT, half);
-        const char* b1 = reg + ka_off;
-        h8 ring[PF];
-#pragma unroll
-        for (int i = 0; i < PF; ++i) ring[i] = rc_lds(b1 + i * 32);
-        rc_static_for<NDC>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i % PF], xf[i], sc, 0, 0, 0);
-            if constexpr (i + PF < NDC) ring[i % PF] = rc_lds(b1 + (i + PF) * 32);
-        });
-        // ---- GEGLU: sc[r] (r < 8) = value, sc[8 + r] = gate of hidden unit 16 ch + 8 half + r: the stage-2 fragment pb[ch]
-        h8 mine;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) mine[r] = (half_t)(SDMI_GELU_SIG ? geglu_gate(sc[r], sc[8 + r]) : sc[r] * rc_gelu_erf(sc[8 + r]));
-        *reinterpret_cast<h8*>(xchg + (wave * 64 + lane) * 16) = mine;
-        // stage-2 fragments of sb = ch can be prefetched before the hand-off
-        const char* b2 = reg + va_off;
-        h8 va[NDBH];
-#pragma unroll
-        for (int db = 0; db < NDBH; ++db) va[db] = rc_lds(b2 + db * 32 * G::B2STR + ch * 32);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const h8 theirs = *reinterpret_cast<const h8*>(xchg + ((wave ^ 4) * 64 + lane) * 16);
-        // ---- stage 2: this wave's half of the output columns
-#pragma unroll
-        for (int db = 0; db < NDBH; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[db], mine, o[db], 0, 0, 0);
-#pragma unroll
-        for (int db = 0; db < NDBH; ++db) {
-            const h8 a = rc_lds(b2 + db * 32 * G::B2STR + (ch ^ 1) * 32);
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, theirs, o[db], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: residual rows staged by the ch = 0 waves, both waves add their column halves in place, coalesced stores
-    rc_phase_sync();
-    char* const oreg = smem + rg * G::B1UNIT;
-    constexpr int SLOTS = G::B1STR / 16, NPIECE = G::B1UNIT / 1024;
-    if (ch == 0) {
-        rc_stage_rows<C>(p.x + row0 * C, oreg, lane, p.zero);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    char* xrow = oreg + lq * G::B1STR;
-#pragma unroll
-    for (int db = 0; db < NDBH; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = (ch * NDBH + db) * 32 + g * 8 + half * 4;
-            const h4 res = *reinterpret_cast<const h4*>(xrow + c0 * 2);
-            const f4 bb = *reinterpret_cast<const f4*>(p.bias_out + c0);
-            h4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (half_t)((o[db][g * 4 + e] + bb[e]) + (float)res[e]);
-            *reinterpret_cast<h4*>(xrow + c0 * 2) = v;
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    half_t* owave = p.out + row0 * C;
-#pragma unroll
-    for (int ii = 0; ii < (NPIECE + 1) / 2; ++ii) {          // the two waves of a row group take alternate 1 KB pieces
-        const int i = 2 * ii + ch;
-        if (i >= NPIECE) break;
-        const int n = i * 64 + lane;
-        const int r = (n * 1599) >> 16;
-        const int c = n - r * SLOTS;
-        const h8 v = *reinterpret_cast<const h8*>(oreg + n * 16);
-        if (r < 32 && c < C / 8) *reinterpret_cast<h8*>(owave + r * C + c * 8) = v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// cross-attention chain.  Per (image, head): region A image = NKB B1 units (32 keys each: Kq), region B image = NKB B2 units (VWo).
-// Iteration h:  phase 1  S(h) from region A with softmax(h - 1) sliced between the MFMAs      while region B <- VWo(h - 1)
-//               phase 2  O += VWo(h - 1) P(h - 1) from region B                               while region A <- Kq(h + 1)
-// ---------------------------------------------------------------------------------------------------------------
-template <int C, int NKB, int VAR = 0>
-__global__ __launch_bounds__(256, 1) void rowchain_xattn_kernel(RowChainP p) {
-    typedef RcGeo<C> G;
-    static_assert(NKB == 3, "three 32-key blocks");
-    constexpr int ABYTES = G::XA_A, BBYTES = G::XA_B, HEAD = ABYTES + BBYTES;
-    constexpr int NPA = ABYTES / 1024, NPB = BBYTES / 1024, PF = kRcPF;
-    constexpr int NDC = G::NDC, NDB = G::NDB, NV = NKB * 16;      // NV: scores per lane and head
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const regA = smem;
-    char* const regB = smem + ABYTES;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, lq = lane & 31;
-    const long row0 = (long)blockIdx.x * 128;
-    const long row = row0 + wave * 32 + lq;
-    const int H = p.nchunk;
-    const char* packs = p.packs + ((long)(p.img0 + (int)(row0 / p.rows_per_img)) * H) * HEAD;
-
-    // prologue: the wave's rows through its staging region in region B (free until VWo(0) is fetched in iteration 1), then Kq(0)
-    char* const xreg = regB + wave * G::B1UNIT;
-    static_assert(ABYTES + 4 * G::B1UNIT <= 160 * 1024, "row staging beside region A");
-    rc_stage_rows<C>(p.x + (row0 + wave * 32) * C, xreg, lane, p.zero);
-    rc_issue<NPA>(packs, regA, wave, lane);
-    wait_vm<NPA / 4>();
-    __builtin_amdgcn_wave_barrier();
-    h8 xf[NDC];
-    rc_load_ln<C>(xreg, lq, p.gamma, p.beta, p.eps, half, xf);
-
-    f16v o[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    f16v sc[2][NKB];                         // scores of heads of even / odd index
-    h8 pb[NKB][2];
-    const int krow = (lq & 0x13) | ((lq & 4) << 1) | ((lq & 8) >> 1);
-    const int ka_off = krow * G::B1STR + half * 16;
-    const int va_off = lq * G::B2STR + half * 16;
-    const char* const gsrc = packs + wave * 1024;          // wave-uniform
-    const unsigned lane16 = (unsigned)lane * 16u;
-    char* const lA = regA + wave * 1024;
-    char* const lB = regB + wave * 1024;
-
-    // softmax of one head's NV scores, cut into slices: slice t of 3 * (NV / 4) + 3 (see the step loop)
-    float mx = 0.f, rs = 0.f, inv = 0.f;
-    auto softmax_slice = [&](auto tc, auto parc) {
-        constexpr int t = decltype(tc)::value, Q = NV / 4;
-        constexpr int PAR = decltype(parc)::value;
-#define RC_S(v) sc[PAR][(v) >> 4][(v) & 15]
-        if constexpr (t < Q) {                                        // running maximum, 4 scores per slice
-            const float m4 = fmaxf(fmaxf(RC_S(4 * t), RC_S(4 * t + 1)), fmaxf(RC_S(4 * t + 2), RC_S(4 * t + 3)));
-            mx = t == 0 ? m4 : fmaxf(mx, m4);
-        } else if constexpr (t == Q) {
-            float lo, hi;
-            rc_pair(mx, lo, hi);
-            mx = fmaxf(lo, hi);
-        } else if constexpr (t < 2 * Q + 1) {                         // exponentials (scores are in the log2 domain) and their sum
-            constexpr int u = t - Q - 1;
-            float e4 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { RC_S(4 * u + e) = __builtin_amdgcn_exp2f(RC_S(4 * u + e) - mx); e4 += RC_S(4 * u + e); }
-            rs = u == 0 ? e4 : rs + e4;
-        } else if constexpr (t == 2 * Q + 1) {
-            float lo, hi;
-            rc_pair(rs, lo, hi);
-            inv = 1.0f / (lo + hi);
-        } else if constexpr (t < 3 * Q + 2) {                         // normalised probabilities, packed for stage 2
-            constexpr int u = t - 2 * Q - 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int v = 4 * u + e;
-                pb[v >> 4][(v >> 3) & 1][v & 7] = (half_t)(RC_S(v) * inv);
-            }
-        }
-    };
-#undef RC_S
-    constexpr int NSLICE = 3 * (NV / 4) + 2;
-
-    auto iter = [&](int h, auto s1c, auto s2c, auto parc) {
-        constexpr bool S1 = decltype(s1c)::value, S2 = decltype(s2c)::value;
-        constexpr int PAR = decltype(parc)::value;
-        using PPREV = std::integral_constant<int, PAR ^ 1>;
-        // ---- phase 1: S(h) from region A, softmax(h - 1) between the MFMAs; region B <- VWo(h - 1)
-        rc_phase_sync();
-        {
-            constexpr int NS = S1 ? NKB * NDC : 0;
-            const char* b1 = regA + ka_off;
-            const char* gB = gsrc + (long)(h - 1) * HEAD + ABYTES;
-            auto addr = [&](auto ic) -> const char* {
-                constexpr int i = decltype(ic)::value;
-                return b1 + (i / NDC) * G::B1UNIT + (i % NDC) * 32;          // (key blocks round robin — independent accumulators — measured slower: 119 vs 105 us)
-            };
-            h8 ring[PF];
-            if constexpr (S1) {
-#pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) sc[PAR][kb] = rc_init<C>(regA + kb * G::B1UNIT, half);
-                rc_static_for<PF>([&](auto ic) { ring[decltype(ic)::value] = rc_lds(addr(ic)); });
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (S2 && !S1) {       // last iteration: softmax of the last head with nothing to hide it under
-                rc_issue<NPB>(packs + (long)(h - 1) * HEAD + ABYTES, regB, wave, lane);
-                rc_static_for<NSLICE>([&](auto tc) { softmax_slice(tc, PPREV{}); });
-            }
-            rc_static_for<NS>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const h8 a = ring[i % PF];
-                if constexpr (VAR == 4) asm volatile("" : "+v"(sc[PAR][i / NDC]) : "v"(a), "v"(xf[i % NDC]));
-                else sc[PAR][i / NDC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[i % NDC], sc[PAR][i / NDC], 0, 0, 0);
-                if constexpr (i + PF < NS) ring[i % PF] = rc_lds(addr(std::integral_constant<int, (i + PF < NS ? i + PF : 0)>{}));
-                if constexpr (S2 && i % 3 == 2 && VAR != 2) rc_issue_piece<NPB>(gB, lane16, lB, i / 3);
-                if constexpr (S2 && i < NSLICE && VAR != 1) softmax_slice(ic, PPREV{});
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (S1 && S2) {
-#pragma unroll
-                for (int k = NS / 3; k < NPB / 4; ++k) rc_issue_piece<NPB>(gB, lane16, lB, k);
-                static_assert(NSLICE <= NKB * NDC, "the softmax slices must fit the stage-1 steps");
-            }
-        }
-        // ---- phase 2: O += VWo(h - 1) P(h - 1) from region B; region A <- Kq(h + 1)
-        rc_phase_sync();
-        {
-            constexpr int NS = S2 ? NKB * 2 * NDB : 0;
-            const char* b2 = regB + va_off;
-            const char* gA = gsrc + (long)(h + 1) * HEAD;
-            // (after the image's last head this fetches the next image's first Kq — or the stream's tail padding — and nobody reads it)
-            constexpr bool more = S1;
-            auto addr = [&](auto ic) -> const char* {
-                constexpr int i = decltype(ic)::value;
-                return b2 + (i / (2 * NDB)) * G::B2UNIT + (i % NDB) * 32 * G::B2STR + ((i % (2 * NDB)) / NDB) * 32;
-            };
-            h8 ring[PF];
-            if constexpr (S2) rc_static_for<PF>([&](auto ic) { ring[decltype(ic)::value] = rc_lds(addr(ic)); });
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!S2 && more) rc_issue<NPA>(packs + (long)(h + 1) * HEAD, regA, wave, lane);
-            rc_static_for<NS>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int kb = i / (2 * NDB), db = i % NDB, sb = (i % (2 * NDB)) / NDB;
-                const h8 a = ring[i % PF];
-                if constexpr (VAR == 4) asm volatile("" : "+v"(o[db]) : "v"(a), "v"(pb[kb][sb]));
-                else o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb[kb][sb], o[db], 0, 0, 0);
-                if constexpr (i + PF < NS) ring[i % PF] = rc_lds(addr(std::integral_constant<int, (i + PF < NS ? i + PF : 0)>{}));
-                if constexpr (more && i % 3 == 2 && VAR != 2) rc_issue_piece<NPA>(gA, lane16, lA, i / 3);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if constexpr (S1 && S2) {
-#pragma unroll
-                for (int k = NS / 3; k < NPA / 4; ++k) rc_issue_piece<NPA>(gA, lane16, lA, k);
-            }
-        }
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    if constexpr (VAR != 6) {
-    iter(0, T{}, F{}, P0{});
-    int h = 1;
-    for (; h + 1 < H; h += 2) {
-        iter(h, T{}, T{}, P1{});
-        iter(h + 1, T{}, T{}, P0{});
-    }
-    if (h < H) { iter(h, T{}, T{}, P1{}); ++h; }
-    if (H & 1) iter(H, F{}, T{}, P1{});
-    else iter(H, F{}, T{}, P0{});
-    } else {
-        rc_phase_sync();
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) o[db][0] = (float)xf[db][0];
-    }
-
-    rc_phase_sync();
-    rc_store<C>(p, row0 + wave * 32, smem + wave * G::B1UNIT, lane, o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -700,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void rowchain_xattn_kernel(RowChainP p) {
 // of 64 rows = 32 value + 32 gate rows of one chunk, elementwise.hip geglu_row), b1 likewise, w2 [C][hidden] -> (hidden / 32 + 1) packs
 template <int C>
 __global__ __launch_bounds__(256) void rowchain_ff_pack_kernel(const half_t* w1, const float* b1, const half_t* w2, char* packs,
-                                                               int hidden, int permuted, int layout) {
+                                                               int hidden, int permuted) {
     typedef RcGeo<C> G;
     constexpr int PACK = G::FFPACK, NCHUNK16 = PACK / 16, U16 = G::B1UNIT / 16, SLOTS = G::B1STR / 16, V16 = G::B2UNIT / 16;
     const int nch = hidden / 32;
@@ -709,12 +354,12 @@ __global__ __launch_bounds__(256) void rowchain_ff_pack_kernel(const half_t* w1,
         const int j = (int)(idx / NCHUNK16), ci = (int)(idx - (long)j * NCHUNK16);
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (ci < 2 * U16) {
-            const int u = ci / U16, cu = ci - u * U16;           // layout 0: unit 0 = value rows, 1 = gate rows of the chunk's 32 hidden units
-            const int r = cu / SLOTS, c = cu - r * SLOTS;        // layout 1: unit u = 16 value rows then 16 gate rows of hidden units 16u .. 16u + 15
+            const int u = ci / U16, cu = ci - u * U16;           // unit 0 = value rows, 1 = gate rows of the chunk's 32 hidden units
+            const int r = cu / SLOTS, c = cu - r * SLOTS;
             // unit row rr -> (gate?, hidden unit of the chunk)
             auto src_of = [&](int rr) -> long {
-                const int gate = layout ? (rr >> 4) : u;
-                const int hu = j * 32 + (layout ? 16 * u + (rr & 15) : rr);
+                const int gate = u;
+                const int hu = j * 32 + rr;
                 return permuted ? (long)(hu >> 5) * 64 + (hu & 31) + 32 * gate : (long)gate * hidden + hu;
             };
             if (j < nch) {
@@ -730,76 +375,8 @@ __global__ __launch_bounds__(256) void rowchain_ff_pack_kernel(const half_t* w1,
         } else {
             const int cb = ci - 2 * U16;
             const int n = cb / 5, c = cb - n * 5;
-            const int jj = layout ? j : j - 1;                   // layout 0 skews the B2 unit by one chunk (rowchain_ff_kernel)
+            const int jj = j - 1;                                // the B2 unit is skewed by one chunk (rowchain_ff_kernel)
             if (jj >= 0 && jj < nch && c < 4 && cb < V16) v = *reinterpret_cast<const uint4*>(w2 + (long)n * hidden + jj * 32 + c * 8);
-        }
-        *reinterpret_cast<uint4*>(packs + idx * 16) = v;
-    }
-}
-
-// cross-attention: k [B * L][C] (compact rows), vt [B][C][Lpad], wq / wo [C][C] (Linear weights [out][in]) -> per (image, head)
-// [ NKB B1 units: Kq[key][c] = scale_log2 * sum_d k[key][h D + d] wq[h D + d][c], table 0 / -inf |
-//   NKB B2 units: VWo[n][key] = sum_d vt[h D + d][key] wo[n][h D + d] ]                                (fp32 sums, rounded once)
-template <int C, int NKB>
-__global__ __launch_bounds__(256) void rowchain_xattn_pack_kernel(const half_t* k, const half_t* vt, const half_t* wq, const half_t* wo,
-                                                                  char* packs, int B, int L, int Lpad, int H, float scale_log2,
-                                                                  const int* gate) {
-    if (gate && *gate == 0) return;
-    typedef RcGeo<C> G;
-    static_assert(NKB == 3, "three 32-key blocks");
-    constexpr int ABYTES = G::XA_A, BBYTES = G::XA_B, HEAD = ABYTES + BBYTES, HEAD16 = HEAD / 16, A16 = ABYTES / 16;
-    constexpr int U16 = G::B1UNIT / 16, SLOTS = G::B1STR / 16, V16 = G::B2UNIT / 16;
-    const int D = C / H;
-    const long total = (long)B * H * HEAD16;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int bh = (int)(idx / HEAD16), ci = (int)(idx - (long)bh * HEAD16);
-        const int b = bh / H, h = bh - b * H;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (ci < A16) {
-            const int u = ci / U16, cu = ci - u * U16;
-            const int r = cu / SLOTS, c = cu - r * SLOTS;
-            const int key = u * 32 + r;
-            if (u >= NKB) { *reinterpret_cast<uint4*>(packs + idx * 16) = v; continue; }      // region padding
-            if (r < 32 && c < C / 8) {
-                if (key < L) {
-                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    const half_t* kr = k + ((long)b * L + key) * C + h * D;
-                    for (int d = 0; d < D; ++d) {
-                        const float kv = (float)kr[d];
-                        const h8 w = *reinterpret_cast<const h8*>(wq + (long)(h * D + d) * C + c * 8);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(kv, (float)w[e], acc[e]);
-                    }
-                    h8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(acc[e] * scale_log2);
-                    v = __builtin_bit_cast(uint4, o);
-                }
-            } else if (r >= 32 && cu * 16 >= G::B1TAB && cu * 16 < G::B1TAB + 128) {
-                const int t0 = (cu * 16 - G::B1TAB) / 4;
-                float f[4];
-                for (int e = 0; e < 4; ++e) f[e] = (u * 32 + t0 + e < L) ? 0.f : -INFINITY;
-                v = __builtin_bit_cast(uint4, f4{f[0], f[1], f[2], f[3]});
-            }
-        } else {
-            const int cb = ci - A16;
-            const int u = cb / V16, cu = cb - u * V16;
-            const int n = cu / 5, c = cu - n * 5;
-            if (c < 4 && u < NKB) {
-                h8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int key = u * 32 + c * 8 + e;
-                    float acc = 0.f;
-                    if (key < L) {
-                        const half_t* vr = vt + ((long)b * C + h * D) * Lpad + key;
-                        const half_t* wr = wo + (long)n * C + h * D;
-                        for (int d = 0; d < D; ++d) acc = fmaf((float)vr[(long)d * Lpad], (float)wr[d], acc);
-                    }
-                    o[e] = (half_t)acc;
-                }
-                v = __builtin_bit_cast(uint4, o);
-            }
         }
         *reinterpret_cast<uint4*>(packs + idx * 16) = v;
     }
@@ -808,22 +385,12 @@ __global__ __launch_bounds__(256) void rowchain_xattn_pack_kernel(const half_t* 
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-// 1: the 8-wave feed-forward kernel + pack layout 1 (SDMI_RC_FF8 / sdmi_debug_set "rc_ff8"); packs built under one value are not read under the other
-unsigned long long g_rc_dbg = 0;     // device pointer for RowChainP::dbg (sdmi_debug_set rc_dbg_lo / rc_dbg_hi)
-int g_rc_ff8 = [] { const char* e = getenv("SDMI_RC_FF8"); return e ? atoi(e) : 0; }();
-
 bool rowchain_supports(int C) { return C == 320; }
-int rowchain_xattn_max_keys() { return 96; }
 
 size_t rowchain_ff_pack_bytes(int C, int hidden) {
     if (C != 320 || hidden % 32) return 0;
     typedef RcGeo<320> G;
     return (size_t)(hidden / 32 + 1) * G::FFPACK;
-}
-size_t rowchain_xattn_pack_bytes(int C, int B, int H) {
-    if (C != 320) return 0;
-    typedef RcGeo<320> G;
-    return (size_t)B * H * (G::XA_A + G::XA_B) + G::XA_A;      // + one region of tail padding (the kernel's look-ahead fetch)
 }
 
 int launch_rowchain_ff_pack(const half_t* w1, const float* b1, const half_t* w2, void* packs, int C, int hidden, bool permuted,
@@ -831,18 +398,7 @@ int launch_rowchain_ff_pack(const half_t* w1, const float* b1, const half_t* w2,
     SDMI_REQUIRE(rowchain_supports(C) && hidden % 32 == 0 && hidden > 0, "rowchain feed-forward: C = 320, hidden % 32 == 0");
     const long total = (long)rowchain_ff_pack_bytes(C, hidden) / 16;
     hipLaunchKernelGGL(rowchain_ff_pack_kernel<320>, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, w1, b1,
-                       w2, (char*)packs, hidden, permuted ? 1 : 0, g_rc_ff8 ? 1 : 0);
-    SDMI_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_rowchain_xattn_pack(const half_t* k, const half_t* vt, const half_t* wq, const half_t* wo, void* packs, int C, int B, int L,
-                               int Lpad, int H, float scale, const int* gate, hipStream_t s) {
-    SDMI_REQUIRE(rowchain_supports(C) && H > 0 && C % H == 0 && L > 0 && L <= rowchain_xattn_max_keys() && Lpad >= L,
-                 "rowchain cross-attention: C = 320, at most 96 keys");
-    const long total = (long)rowchain_xattn_pack_bytes(C, B, H) / 16;
-    hipLaunchKernelGGL((rowchain_xattn_pack_kernel<320, 3>), dim3((unsigned)std::min<long>((total + 255) / 256, 16384)), dim3(256), 0, s,
-                       k, vt, wq, wo, (char*)packs, B, L, Lpad, H, scale * 1.4426950408889634f, gate);
+                       w2, (char*)packs, hidden, permuted ? 1 : 0);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -858,65 +414,13 @@ int launch_rowchain_ff(const half_t* x, half_t* out, const float* gamma, const f
     SDMI_REQUIRE(rowchain_supports(C) && hidden % 32 == 0 && rows > 0 && rows % 128 == 0, "rowchain feed-forward: C = 320, rows % 128 == 0");
     typedef RcGeo<320> G;
     constexpr int SMEM = std::max(2 * G::FFPACK, G::FFPACK + 4 * G::B1UNIT);      // two pack buffers | pack 0 + the prologue's row staging
-    static const int var = [] { const char* e = getenv("SDMI_RC_VAR"); return e ? atoi(e) : 0; }();
     void (*kern)(RowChainP) = rowchain_ff_kernel<320>;
-#ifdef SDMI_RC_PARTS
-    if (var == 1) kern = rowchain_ff_kernel<320, 1>;
-    if (var == 2) kern = rowchain_ff_kernel<320, 2>;
-    if (var == 3) kern = rowchain_ff_kernel<320, 3>;
-    if (var == 4) kern = rowchain_ff_kernel<320, 4>;
-    if (var == 5) kern = rowchain_ff_kernel<320, 5>;
-    if (var == 6) kern = rowchain_ff_kernel<320, 6>;
-    if (var == 7) kern = rowchain_ff_kernel<320, 7>;
-    if (var == 8) kern = rowchain_ff_kernel<320, 8>;
-    if (var == 9) kern = rowchain_ff_kernel<320, 9>;
-    if (var == 10) kern = rowchain_ff_kernel<320, 10>;
-#endif
-    (void)var;
-    static void (*attr)(RowChainP) = nullptr;
-    if (attr != kern) { if (rc_set_smem(kern, SMEM)) return 1; attr = kern; }
+    static PerDeviceOnce attr;                               // (per device: one process may drive several — common.h)
+    if (attr.need() && rc_set_smem(kern, SMEM)) return 1;
     RowChainP p{};
     p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.packs = (const char*)packs; p.bias_out = bias_out ? bias_out : reinterpret_cast<const float*>(zero_page()); p.zero = zero_page();
-    p.M = (int)rows; p.rows_per_img = (int)rows; p.nchunk = hidden / 32; p.eps = eps;
-    p.dbg = reinterpret_cast<long long*>(g_rc_dbg);
+    p.M = (int)rows; p.nchunk = hidden / 32; p.eps = eps;
     ProfScope ps("rowchain_ff", 2.0 * rows * C * (3.0 * hidden), 4.0 * rows * C, s);
-    if (g_rc_ff8) {
-        constexpr int SMEM8 = std::max(2 * G::FFPACK + 8 * 64 * 16, G::FFPACK + 4 * G::B1UNIT);     // packs + hand-off slots | pack 0 + row staging
-        static_assert(SMEM8 <= 160 * 1024, "LDS budget of the 8-wave form");
-        void (*k8)(RowChainP) = rowchain_ff8_kernel<320>;
-        static bool attr8 = false;
-        if (!attr8) { if (rc_set_smem(k8, SMEM8)) return 1; attr8 = true; }
-        hipLaunchKernelGGL(k8, dim3((unsigned)(rows / 128)), dim3(512), SMEM8, s, p);
-        SDMI_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(rows / 128)), dim3(256), SMEM, s, p);
-    SDMI_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_rowchain_xattn(const half_t* x, half_t* out, const float* gamma, const float* beta, const void* packs, const float* bias_out,
-                          long rows, int rows_per_img, int img0, int C, int H, float eps, hipStream_t s) {
-    SDMI_REQUIRE(rowchain_supports(C) && rows > 0 && rows_per_img % 128 == 0 && rows % rows_per_img == 0,
-                 "rowchain cross-attention: C = 320, tokens per image % 128 == 0");
-    typedef RcGeo<320> G;
-    constexpr int SMEM = std::max(G::XA_A + G::XA_B, G::XA_A + 4 * G::B1UNIT);
-    static const int var = [] { const char* e = getenv("SDMI_RC_VAR"); return e ? atoi(e) : 0; }();
-    void (*kern)(RowChainP) = rowchain_xattn_kernel<320, 3>;
-#ifdef SDMI_RC_PARTS
-    if (var == 1) kern = rowchain_xattn_kernel<320, 3, 1>;
-    if (var == 2) kern = rowchain_xattn_kernel<320, 3, 2>;
-    if (var == 4) kern = rowchain_xattn_kernel<320, 3, 4>;
-    if (var == 6) kern = rowchain_xattn_kernel<320, 3, 6>;
-#endif
-    (void)var;
-    static void (*attr)(RowChainP) = nullptr;
-    if (attr != kern) { if (rc_set_smem(kern, SMEM)) return 1; attr = kern; }
-    RowChainP p{};
-    p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.packs = (const char*)packs; p.bias_out = bias_out ? bias_out : reinterpret_cast<const float*>(zero_page()); p.zero = zero_page();
-    p.M = (int)rows; p.rows_per_img = rows_per_img; p.img0 = img0; p.nchunk = H; p.eps = eps;
-    // flops of the launch as it runs (folded form, 96 key columns per head)
-    ProfScope ps("rowchain_xattn", 2.0 * rows * C * (2.0 * 96 * H), 4.0 * rows * C, s);
     hipLaunchKernelGGL(kern, dim3((unsigned)(rows / 128)), dim3(256), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());
     return 0;

@@ -196,31 +196,6 @@ def rowchain_ff(x: torch.Tensor, gamma, beta, packs: torch.Tensor, b2, hidden: i
     return out
 
 
-def rowchain_xattn_pack(k: torch.Tensor, vt: torch.Tensor, wq: torch.Tensor, wo: torch.Tensor, heads: int, L: int, scale: float) -> torch.Tensor:
-    """Per-image, per-head folded key / value matrices of the fused cross-attention chain: k [B*L, C] = to_k(context), vt [B, C, Lpad] =
-    to_v(context) transposed, wq / wo [C, C] = attn2.to_q / to_out[0] weights."""
-    _lib.require_device()
-    b, c, lpad = vt.shape
-    packs = torch.empty(int(lib.sdmi_rowchain_xattn_pack_bytes(c, b, heads)), dtype=torch.uint8, device=k.device)
-    check(lib.sdmi_rowchain_xattn_pack(ptr(k.half().contiguous()), ptr(vt.half().contiguous()), ptr(wq.half().contiguous()),
-                                       ptr(wo.half().contiguous()), ptr(packs), c, b, L, lpad, heads, float(scale), stream_ptr()),
-          "sdmi_rowchain_xattn_pack")
-    return packs
-
-
-def rowchain_xattn(x: torch.Tensor, gamma, beta, packs: torch.Tensor, bo, rows_per_image: int, heads: int, eps: float = 1e-5) -> torch.Tensor:
-    """x + attn2(LayerNorm(x), context) of a BasicTransformerBlock as one launch; x [B*rows_per_image, C] fp16."""
-    _lib.require_device()
-    c = x.shape[-1]
-    x = x.contiguous()
-    out = torch.empty_like(x)
-    bo = bo.float().contiguous() if bo is not None else None
-    check(lib.sdmi_rowchain_xattn(ptr(x), ptr(out), ptr(gamma.float().contiguous()), ptr(beta.float().contiguous()), ptr(packs),
-                                  ptr(bo) if bo is not None else None, x.numel() // c, rows_per_image, c, heads, float(eps), stream_ptr()),
-          "sdmi_rowchain_xattn")
-    return out
-
-
 def philox_randn(shape, seed: int, offset: int, device) -> torch.Tensor:
     """One draw of rng_philox.Generator(seed) at ``offset`` (modules/rng_philox.py:84-102), generated on the GPU."""
     _lib.require_device()

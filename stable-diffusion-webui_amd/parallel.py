@@ -203,7 +203,7 @@ def process_images_sharded(p, runner=None, world: Optional[int] = None, rank: Op
     slice elsewhere.  ``runner`` defaults to processing.process_images; ``world`` / ``rank`` override the process group (used to
     replay one rank's slice in a single process; implies no gather)."""
     from . import processing
-    runner = runner or processing.process_images
+    runner = runner or processing.process_images_one_device
     explicit = world is not None
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
@@ -281,3 +281,157 @@ def _with_rows(q, a, b, n):
     r.batch_size = min(q.batch_size, b - a)
     r.n_iter = (b - a) // r.batch_size
     return r
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# ONE process, N devices ("one process driving 8 devices with one host thread per device ... the webui front-end
+# stays a single process behind queue_lock", modules/call_queue.py:8-13; the reference itself selects ONE device, modules/cmd_args.py:106,
+# modules/devices.py:35-44).  The torchrun path above needs one process per GPU, which a webui is not: here a pool keeps one engine (a
+# replica of the checkpoint) and one worker thread per device inside the webui's own process, and a job is cut exactly as shard_job cuts
+# it for ranks — contiguous image ranges, seeds seed + global index, per-call batch size kept — so the result is the single-device job's,
+# image for image and bit for bit (same per-call batch size).  No collective: a replica is packed from the checkpoint dict the first
+# model holds (SdModel._checkpoint; device-to-device copies when it already lives on a GPU), the images come back as host arrays.
+# ------------------------------------------------------------------------------------------------------------------------------
+_MODEL_FIELDS = ("sd_model", "hr_sd_model", "refiner_sd_model")
+
+
+class DevicePool:
+    """Engines of one checkpoint on several devices of this process, and the job splitter over them.
+
+        pool = DevicePool(model, devices=[0, 1, 2, 3])        # replicas packed once per checkpoint
+        res = pool.process_images(p)                          # p.sd_model is ``model``; Processed of the whole job
+
+    ``devices`` may name a device twice (two engines on one GPU: how the single-GPU test box exercises the threads).  ``serial=True`` runs
+    the workers one after the other in the calling thread (the host-emulated CPU tier, whose "device" is not re-entrant)."""
+
+    def __init__(self, model, devices, serial: bool = False):
+        assert len(devices) >= 1
+        self.devices = [int(d) for d in devices]
+        self.serial = bool(serial)
+        self._replicas = {}                                   # (id(source model), slot) -> replica
+        self._sources = {}
+        self.primary = model
+        for slot in range(len(self.devices)):
+            self.replica(model, slot)
+
+    def replica(self, model, slot: int):
+        """The engine-side twin of ``model`` for worker ``slot``: the model itself where its device matches (slot 0 keeps the primary),
+        otherwise a second SdModel packed from the same checkpoint dict on that worker's device, with the first model's per-model
+        settings (accuracy mode, range-extended VAE, external VAE) carried over."""
+        key = (id(model), slot)
+        if key in self._replicas:
+            return self._replicas[key]
+        dev = self.devices[slot]
+        first_slot_of_dev = self.devices.index(dev)
+        if model.engine.device == dev and first_slot_of_dev == slot:
+            rep = model
+        else:
+            from . import sd_models, shared
+            keep = shared.sd_model
+            try:
+                rep = sd_models.SdModel(model._checkpoint, model.unet_cfg, model.vae_cfg, device=dev, load_vae=model.has_vae,
+                                        vae_decoder_only=model._vae_decoder_only, parameterization=model.parameterization,
+                                        cond_stage_key=model.cond_stage_key, conditioning_key=model.model.conditioning_key,
+                                        embedder=model.embedder, noise_augmentor=model.noise_augmentor, depth_model=model.depth_model)
+            finally:
+                shared.sd_model = keep                        # the constructor publishes itself as the reference's global: the primary stays
+            rep.alphas_cumprod = model.alphas_cumprod.clone()
+            if getattr(model, "accuracy_mode", False):
+                rep.set_accuracy_mode(True)
+            if model.vae_range_extended:
+                rep.set_vae_range_extended(True)
+        self._replicas[key] = rep
+        self._sources[id(model)] = model
+        return rep
+
+    def close(self):
+        for (mid, slot), rep in list(self._replicas.items()):
+            if rep is not self._sources.get(mid):
+                rep.engine.close()
+        self._replicas.clear()
+
+    # ------------------------------------------------------------------------------------------------------
+    def _job_for(self, p, slot: int):
+        """``p`` as worker ``slot`` sees it: its models replaced by that worker's replicas, its per-image tensors on that device."""
+        import copy
+        q = copy.copy(p)
+        dev = torch.device("cuda", self.devices[slot])
+        for f in _MODEL_FIELDS:
+            m = getattr(p, f, None)
+            if m is not None:
+                setattr(q, f, self.replica(m, slot))
+        for f in _PER_IMAGE_FIELDS + ("latent_mask", "image_mask", "init_latent", "firstpass_image"):
+            v = getattr(p, f, None)
+            if torch.is_tensor(v):
+                setattr(q, f, v.to(dev))
+        q.images_to_host = True
+        return q
+
+    def process_images(self, p, runner=None):
+        """The whole job ``p`` over the pool's devices; returns the ``Processed`` a single-device ``process_images(p)`` would return
+        (images in job order as host arrays, ``all_seeds`` of the whole job, latents concatenated on the primary's device when kept)."""
+        import threading
+        n = len(self.devices)
+        n_total = p.batch_size * p.n_iter
+        results, errors = [None] * n, [None] * n
+
+        def work(slot):
+            try:
+                dev = self.devices[slot]
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(dev)                # torch's current device is per thread
+                q = self._job_for(p, slot)
+                results[slot] = process_images_sharded(q, runner=runner, world=n, rank=slot)
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize(dev)
+            except BaseException as ex:                       # re-raised in the caller's thread
+                errors[slot] = ex
+
+        if self.serial or n == 1:
+            for slot in range(n):
+                work(slot)
+        else:
+            threads = [threading.Thread(target=work, args=(slot,), name=f"sdmi-device-{self.devices[slot]}-{slot}") for slot in range(n)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        for ex in errors:
+            if ex is not None:
+                raise ex
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.primary.engine.device)
+        res = results[0]
+        lat_dev = self.primary.device
+        for r in results[1:]:
+            res.images = list(res.images) + list(r.images)
+            if res.latents is not None and r.latents is not None:
+                res.latents = torch.cat([res.latents.to(lat_dev), r.latents.to(lat_dev)])
+            elif r.latents is not None and not res.images:
+                res.latents = r.latents.to(lat_dev)
+            for f in ("infotexts",):
+                if isinstance(getattr(res, f, None), list) and isinstance(getattr(r, f, None), list):
+                    setattr(res, f, getattr(res, f) + getattr(r, f))
+        res.images_device = None
+        whole, _, _, all_seeds = shard_job(p, 1, 0)
+        res.all_seeds = all_seeds
+        res.all_subseeds = list(whole.subseed)
+        res.batch_size = p.batch_size
+        res.shard = (0, n_total)
+        res.devices = list(self.devices)
+        return res
+
+
+_POOLS = {}
+
+
+def process_images_devices(p, devices, runner=None, serial: bool = False):
+    """``process_images`` over several devices of THIS process (module-level pool per (checkpoint object, device list): the replicas
+    are packed once and live as long as the first model does).  The extension calls this when ``opts.mi355x_devices`` names more than
+    one device (extension/scripts/mi355x_engine.py); ``bench.py`` keeps the one-process-per-GPU path above."""
+    key = (id(p.sd_model), tuple(int(d) for d in devices), bool(serial))
+    pool = _POOLS.get(key)
+    if pool is None or pool.primary is not p.sd_model:
+        pool = DevicePool(p.sd_model, devices, serial=serial)
+        _POOLS[key] = pool
+    return pool.process_images(p, runner=runner)

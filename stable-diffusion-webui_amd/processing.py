@@ -604,7 +604,28 @@ def decode_latent_batch(model, batch, target_device=None, check_for_nans=False):
     return out
 
 
+def job_devices() -> list:
+    """``opts.mi355x_devices`` ("0,1,2,3"; empty = the model's own device): the devices of THIS process a job is spread over."""
+    spec = getattr(shared.opts, "mi355x_devices", "") or ""
+    if isinstance(spec, (list, tuple)):
+        return [int(d) for d in spec]
+    return [int(d) for d in str(spec).replace(";", ",").split(",") if d.strip() != ""]
+
+
 def process_images(p: StableDiffusionProcessing) -> Processed:
+    """modules/processing.py:819 — the entry point.  One process, N devices (the webui front-end stays a single
+    process behind queue_lock, modules/call_queue.py:8-13): with more than one device in ``opts.mi355x_devices`` the job's
+    batch_size x n_iter images are cut into contiguous ranges, one per device, each run by a worker thread on that device's own engine
+    (parallel.DevicePool — the split of parallel.shard_job, so the images are the single-device job's, bit for bit)."""
+    devs = job_devices()
+    if len(devs) > 1 and p.batch_size * p.n_iter > 1:
+        from . import parallel
+        serial = bool(getattr(shared.opts, "mi355x_devices_serial", False))
+        return parallel.process_images_devices(p, devs, runner=process_images_one_device, serial=serial)
+    return process_images_one_device(p)
+
+
+def process_images_one_device(p: StableDiffusionProcessing) -> Processed:
     """modules/processing.py:819-857: the job's option overrides are set for its duration and restored afterwards (the checkpoint / VAE
     entries belong to the model loader and are not options of this path), the sampler / scheduler names are brought to the table's spelling
     ("DPM++ 2M Karras" -> "DPM++ 2M" + "Karras"), then the job itself."""

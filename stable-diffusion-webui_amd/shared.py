@@ -65,6 +65,8 @@ class Options:
     auto_vae_precision_bfloat16: bool = False      # :181  ("Automatically convert VAE to bfloat16")
     auto_vae_precision: bool = True                # :182  ("Automatically revert VAE to 32-bit floats")
     disable_mmap_load_safetensors: bool = False    # :285
+    mi355x_devices: str = ""                       # (engine option) "0,1,2,3": devices of THIS process a job's images are spread over (parallel.DevicePool); empty = one
+    mi355x_devices_serial: bool = False            # run the pool's workers one after the other (the host-emulated CPU tier)
     sdmi_accuracy_mode: bool = False               # (engine option, not a webui setting) carry the UNet's residual stream with ~22 bits: sd_models.set_accuracy_mode
     mi355x_auto_cfg_pairs: bool = False            # (engine option) Mi355xUnet.forward behind the webui's stock CFG denoiser: let the engine find the [x | x] batch itself (sd_unet.py)
 

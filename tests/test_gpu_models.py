@@ -1425,6 +1425,61 @@ def test_sharded_job_replayed_rank_by_rank_equals_the_single_process_job(dev, ti
         sub("shared").sd_model = tiny["model"]
 
 
+def test_one_process_device_pool_reproduces_the_single_device_job(dev, tiny):
+    """SURVEY.md section 8e, the form a webui needs (ONE process behind queue_lock, modules/call_queue.py:8-13, driving N devices with one
+    host thread per device): parallel.DevicePool keeps an engine per device — replicas packed from the first model's checkpoint dict — and
+    cuts the job as shard_job does.  The boxes this suite runs on have one GPU, so the pool gets that device TWICE: two engines, two worker
+    threads launching concurrently on two streams of one device (the threads, the per-thread device binding, the replica packing and the
+    merge are what is under test; serial workers under the host-emulated tier, whose "device" is not re-entrant).  The merged job must be
+    the single-device job image for image and bit for bit — through the pool directly and through process_images with opts.mi355x_devices."""
+    par, processing, shared = sub("parallel"), sub("processing"), sub("shared")
+    serial = os.environ.get("SDMI_HOSTEMU") == "1"
+    g = torch.Generator().manual_seed(17)
+    cond, uncond = torch.randn(6, 77, 64, generator=g), torch.randn(6, 77, 64, generator=g)
+    model = tiny["model"]
+
+    def mk(bs, n_iter, **kw):
+        n = bs * n_iter
+        return processing.StableDiffusionProcessingTxt2Img(sd_model=model, c=cond[:n], uc=uncond[:n], seed=777, batch_size=bs, n_iter=n_iter,
+                                                           cfg_scale=6.0, sampler_name="Euler a", steps=3, **kw)
+    pool = par.DevicePool(model, [0, 0], serial=serial)
+    try:
+        assert pool.replica(model, 0) is model and pool.replica(model, 1) is not model and pool.replica(model, 1).engine.handle != model.engine.handle
+        assert shared.sd_model is model                        # the replica's constructor did not take over the reference's global
+        cases = ((2, 2, dict(width=64, height=64)), (1, 3, dict(width=64, height=64)),
+                 (1, 2, dict(width=64, height=64, enable_hr=True, hr_scale=2.0, hr_upscaler="Latent", denoising_strength=0.6)))
+        for bs, n_iter, kw in (cases[:1] if serial else cases):      # (the emulated tier runs one case here and the entry-point case below: host time)
+            whole = processing.process_images_one_device(mk(bs, n_iter, **kw))
+            pooled = pool.process_images(mk(bs, n_iter, **kw))
+            assert len(pooled.images) == len(whole.images) == bs * n_iter and pooled.all_seeds == whole.all_seeds and pooled.shard == (0, bs * n_iter)
+            for i, (a, b) in enumerate(zip(pooled.images, whole.images)):
+                assert np.array_equal(a, b), (bs, n_iter, i)
+            assert torch.equal(pooled.latents.cpu(), whole.latents.cpu())
+        # the same through the entry point, switched by the option
+        shared.opts.mi355x_devices, shared.opts.mi355x_devices_serial = "0,0", serial
+        try:
+            whole = processing.process_images_one_device(mk(2, 2, width=64, height=64))
+            via_opts = processing.process_images(mk(2, 2, width=64, height=64))
+        finally:
+            shared.opts.mi355x_devices, shared.opts.mi355x_devices_serial = "", False
+        assert getattr(via_opts, "devices", None) == [0, 0] and all(np.array_equal(a, b) for a, b in zip(via_opts.images, whole.images))
+        if serial:
+            return
+        # an accuracy-mode job: the replica follows the first model's setting
+        shared.opts.sdmi_accuracy_mode = True
+        try:
+            whole = processing.process_images_one_device(mk(1, 2, width=64, height=64))       # (bit-identity holds at equal per-call batch size)
+            pooled = pool.process_images(mk(1, 2, width=64, height=64))
+        finally:
+            shared.opts.sdmi_accuracy_mode = False
+            model.set_accuracy_mode(False)
+        assert all(np.array_equal(a, b) for a, b in zip(pooled.images, whole.images))
+    finally:
+        pool.close()
+        par._POOLS.clear()
+        shared.sd_model = model
+
+
 def test_img2img_pil_front_end_fill_only_masked_and_overlay(dev, tiny):
     """The reference's PIL front-end of img2img / inpainting (modules/processing.py:1608-1745, 1063-1086) on the tiny model: mask
     from an RGBA layer, blur, "fill" masked content, whole-picture and "only masked" modes, overlay compositing.  Checked: the job run

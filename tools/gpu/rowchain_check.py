@@ -86,21 +86,6 @@ def main():
     def ff():
         _lib.check(lib.sdmi_rowchain_ff(dx.ptr, dout.ptr, dg.ptr, db.ptr, dpk.ptr, db2.ptr, rows, Cw, hidden, 1e-5, None), "rowchain_ff")
     us = timed(ff)
-    if os.environ.get("SDMI_RC_VAR") == "10":                 # section timers of the 4-wave kernel (SDMI_RC_PARTS builds)
-        nw = rows // 128 * 4
-        dbg = hipmem.DevBuf(nw * 4 * 8)
-        hipmem._hip.hipMemset(dbg.ptr, 0, dbg.nbytes)
-        addr = dbg.ptr.value
-        _lib.check(lib.sdmi_debug_set(b"rc_dbg_lo", C.c_int(addr & 0xFFFFFFFF if addr & 0xFFFFFFFF < 2 ** 31 else (addr & 0xFFFFFFFF) - 2 ** 32)), "rc_dbg_lo")
-        _lib.check(lib.sdmi_debug_set(b"rc_dbg_hi", C.c_int(addr >> 32)), "rc_dbg_hi")
-        ff(); hipmem.sync()
-        t = dbg.to_numpy(np.int64, (nw, 4)).astype(np.float64)
-        it = t[:, 3].mean()
-        res["ff_sections_cycles_per_iteration"] = {"sync": float(t[:, 0].mean() / it), "stage1_geglu": float(t[:, 1].mean() / it),
-                                                   "stage2": float(t[:, 2].mean() / it), "iterations": float(it),
-                                                   "us_per_launch": us, "implied_GHz": float((t[:, :3].sum(1).mean()) / (us * 1e3) * (rows / 128 / 256))}
-        print("sections", res["ff_sections_cycles_per_iteration"], flush=True)
-        _lib.check(lib.sdmi_debug_set(b"rc_dbg_lo", 0), "rc_dbg_lo"); _lib.check(lib.sdmi_debug_set(b"rc_dbg_hi", 0), "rc_dbg_hi")
     out = dout.to_numpy(np.float16, (rows, Cw))[sample].astype(np.float64)
     xs = x[sample].astype(np.float64)
     n = ln(xs, g, b).astype(np.float16).astype(np.float64)
@@ -112,48 +97,10 @@ def main():
                  "finite": bool(np.isfinite(out).all())}
     print("rowchain_ff   ", res["ff"], flush=True)
 
-    # ---- cross-attention
-    k = rng.standard_normal((B * L, Cw), dtype=np.float32).astype(np.float16)
-    v = rng.standard_normal((B, L, Cw), dtype=np.float32).astype(np.float16)
-    vt = np.zeros((B, Cw, Lpad), np.float16)
-    vt[:, :, :L] = v.transpose(0, 2, 1)
-    wq = (rng.standard_normal((Cw, Cw)) / np.sqrt(Cw)).astype(np.float16)
-    wo = (rng.standard_normal((Cw, Cw)) / np.sqrt(Cw)).astype(np.float16)
-    bo = (0.1 * rng.standard_normal(Cw)).astype(np.float32)
-    dk, dvt, dwq, dwo, dbo = (hipmem.DevBuf.from_numpy(a) for a in (k, vt, wq, wo, bo))
-    dxp = hipmem.DevBuf(lib.sdmi_rowchain_xattn_pack_bytes(Cw, B, H))
-    scale = D ** -0.5
-
-    def pack():
-        _lib.check(lib.sdmi_rowchain_xattn_pack(dk.ptr, dvt.ptr, dwq.ptr, dwo.ptr, dxp.ptr, Cw, B, L, Lpad, H, scale, None), "xattn_pack")
-    us_pack = timed(pack)
-
-    def xa():
-        _lib.check(lib.sdmi_rowchain_xattn(dx.ptr, dout.ptr, dg.ptr, db.ptr, dxp.ptr, dbo.ptr, rows, rpi, Cw, H, 1e-5, None), "rowchain_xattn")
-    us = timed(xa)
-    out = dout.to_numpy(np.float16, (rows, Cw))[sample].astype(np.float64)
-    q = ln(xs, g, b) @ wq.astype(np.float64).T
-    ref = np.zeros_like(xs)
-    for i, r in enumerate(sample):
-        bi = r // rpi
-        kk, vv = k[bi * L:(bi + 1) * L].astype(np.float64), v[bi].astype(np.float64)
-        o = np.zeros(Cw)
-        for hh in range(H):
-            s = kk[:, hh * D:(hh + 1) * D] @ q[i, hh * D:(hh + 1) * D] * scale
-            p = np.exp(s - s.max())
-            p /= p.sum()
-            o[hh * D:(hh + 1) * D] = p @ vv[:, hh * D:(hh + 1) * D]
-        ref[i] = o @ wo.astype(np.float64).T
-    ref = xs + ref + bo
-    flops_unfused = 2.0 * rows * Cw * (2 * Cw) + 4.0 * rows * L * Cw
-    res["xattn"] = {"us": round(us, 1), "pack_us": round(us_pack, 1), "tflops_as_run": round(2.0 * rows * Cw * 2 * 96 * H / us / 1e6, 1),
-                    "tflops_of_the_graph_it_replaces": round(flops_unfused / us / 1e6, 1), "rel_l2": rel(out, ref),
-                    "rel_l2_delta": rel(out - xs, ref - xs), "finite": bool(np.isfinite(out).all())}
-    print("rowchain_xattn", res["xattn"], flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
-    ok = res["ff"]["rel_l2"] < 5e-4 and res["xattn"]["rel_l2"] < 5e-4 and res["ff"]["rel_l2_delta"] < 2e-3 and res["xattn"]["rel_l2_delta"] < 3e-3
+    ok = res["ff"]["rel_l2"] < 5e-4 and res["ff"]["rel_l2_delta"] < 2e-3
     print("ok" if ok else "MISMATCH")
     return 0 if ok else 1
 
