@@ -336,6 +336,18 @@ int sdmi_unet_set_context(sdmi_engine* e, const void* context, int io_dtype, int
 int sdmi_unet_set_context_cached(sdmi_engine* e, const void* context, int io_dtype, int Bn, int L, void* stream);
 int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y,
                       void* out, int io_dtype, int Bn, int h, int w, int L, void* stream);
+/* The same with the caller's PROMISES about this call's data as an argument of the call (round 6; ADVICE r4 / VERDICT r5: as sticky
+ * engine options — sdmi_engine_set_option "uniform_t" / "cfg_pairs", still accepted by sdmi_unet_forward — a stale promise silently
+ * overwrote the second half of a later batch).  call_flags, valid for THIS call only:
+ *   SDMI_CALL_UNIFORM_T   every row sits at the same timestep (the samplers' CFG batch, modules/sd_samplers_cfg_denoiser.py:230-246):
+ *                         the timestep-embedding path runs for one row; same bits
+ *   SDMI_CALL_CFG_PAIRS   rows [Bn/2, Bn) repeat the latent and timestep of rows [0, Bn/2) (the [cond | uncond] batch): the layers in
+ *                         front of the first cross-attention run for one half
+ *   SDMI_CALL_DERIVE      neither is known (the stock CFG denoiser behind SdUnet.forward, modules/sd_unet.py:86-93): the engine derives
+ *                         both from x and timesteps — one synchronising device -> host compare */
+enum { SDMI_CALL_UNIFORM_T = 1, SDMI_CALL_CFG_PAIRS = 2, SDMI_CALL_DERIVE = 4 };
+int sdmi_unet_forward_ex(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y,
+                         void* out, int io_dtype, int Bn, int h, int w, int L, int call_flags, void* stream);
 
 /* image = decoder(post_quant_conv(z / scale_factor)), all B latents in one batched pass.
  * Replaces decode_latent_batch's per-image loop (modules/processing.py:625-672) -> decode_first_stage

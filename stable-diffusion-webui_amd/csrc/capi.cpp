@@ -536,6 +536,21 @@ int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, cons
     return unet_forward(e, x, timesteps, context, y, out, io_dtype, Bn, h, w, L, (hipStream_t)stream);
     API_GUARD_END
 }
+int sdmi_unet_forward_ex(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y, void* out,
+                         int io_dtype, int Bn, int h, int w, int L, int call_flags, void* stream) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr, "null engine");
+    // the promises hold for this call only: whatever the (legacy) sticky options say is put back afterwards
+    struct Restore {
+        sdmi_engine* e; bool uni, pairs, derive;
+        ~Restore() { e->uniform_t = uni; e->cfg_pairs = pairs; e->auto_promises = derive; }
+    } restore{e, e->uniform_t, e->cfg_pairs, e->auto_promises};
+    e->uniform_t = (call_flags & SDMI_CALL_UNIFORM_T) != 0;
+    e->cfg_pairs = (call_flags & SDMI_CALL_CFG_PAIRS) != 0;
+    e->auto_promises = (call_flags & SDMI_CALL_DERIVE) != 0;
+    return unet_forward(e, x, timesteps, context, y, out, io_dtype, Bn, h, w, L, (hipStream_t)stream);
+    API_GUARD_END
+}
 int sdmi_vae_decode(sdmi_engine* e, const void* z, int io_dtype, void* out, int B, int h, int w, void* stream) {
     API_GUARD_BEGIN
     return vae_decode(e, z, io_dtype, (float*)out, B, h, w, (hipStream_t)stream);

@@ -160,12 +160,13 @@ __device__ __forceinline__ void gemm_epilogue_hilo(const GemmP& p, f4 (&acc)[TM]
         // M65536 N320 K320: 2.6 TB/s).  The (hi, lo) residual of cell (a + 1, j) is requested as soon as cell (a, j) has consumed its
         // registers: a one-deep ring with a whole row pair of cover.
         constexpr bool RING = TN <= 5;
-        f4 bcw[RING ? TN : 1];
+        constexpr bool HOIST = RING && TM * TN < 40;         // (256x320: 160 accumulator registers — the column bias is fetched per cell)
+        f4 bcw[HOIST ? TN : 1];
         h8 rh[RING ? TN : 1], rl[RING ? TN : 1];
         if constexpr (RING) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bcw[j] = col_bias(j);
+                if constexpr (HOIST) bcw[j] = col_bias(j);
                 rh[j] = p.resid ? ld(p.resid, 0, j) : z8;
                 rl[j] = rlo ? ld(rlo, 0, j) : z8;
             }
@@ -182,7 +183,7 @@ __device__ __forceinline__ void gemm_epilogue_hilo(const GemmP& p, f4 (&acc)[TM]
                         if (p.resid) rh[j] = ld(p.resid, a + 1, j);
                         if (rlo) rl[j] = ld(rlo, a + 1, j);
                     }
-                    cell(a, j, bcw[j], ch, cl, vx, vy, ox, oy, lx, ly);
+                    cell(a, j, HOIST ? bcw[HOIST ? j : 0] : col_bias(j), ch, cl, vx, vy, ox, oy, lx, ly);
                 } else {
                     const h8 ch = p.resid ? ld(p.resid, a, j) : z8, cl = rlo ? ld(rlo, a, j) : z8;
                     cell(a, j, col_bias(j), ch, cl, vx, vy, ox, oy, lx, ly);
@@ -377,9 +378,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f4 (&acc)[TM][TN],
         // 256x320 instantiation 6 SGPR spills.)
         return;
     }
-    // (not on the 256x320 tiles: 160 accumulator registers per lane leave no room for its rings — launch_gemm steers (hi, lo) launches
-    // to the 128x320 tile; one that lands there anyway (a forced configuration) takes the 8-byte general path below, without statistics)
-    if constexpr (!GEGLU && LNM == 0 && TM % 2 == 0 && TM * TN < 40) {
+    // (not the statistics form of the 256x320 tiles: 160 accumulator registers per lane leave no room for it — launch_gemm keeps the
+    // consumer's own statistics pass for those launches)
+    if constexpr (!GEGLU && LNM == 0 && TM % 2 == 0 && !(STATS && TM * TN >= 40)) {
         if ((flags & EP_HILO) && !(flags & EP_NARROW)) {     // (hi, lo) stream tensors: their own region (block-uniform branch)
             gemm_epilogue_hilo<TM, TN, WTM, WTN, WR_, BN_, STATS>(p, acc, m0, n0, wr, wc, lane, z, smem);
             return;
@@ -2526,13 +2527,11 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
                                                !p.resid && !p.rowbias),
                  "EP_TRANSPOSE: rows per image must be a multiple of 4; no residual / GEGLU / fp32 output");
     const int cfg_picked = pick_cfg(p, batch, &split, can_split);
-    // (hi, lo) launch on the 256x320 tile (160 accumulator registers: no room for gemm_epilogue_hilo's rings, no statistics form): the
-    // 128x320 tile instead — the 8-byte path + the consumer's own statistics pass over the pair cost more than the tile change (round 6,
-    // profiles/r06_fwd_ab_accuracy.txt: M65536 N320 K320 80.9 us against 35.4 us for the fp16 launch)
-    int cfg_sel = cfg_picked;
-    if (hilo && cfg_picked == CFG_256x320 && split <= 1 && cfg_valid(CFG_128x320, p) && g_force_gemm_cfg < 0) cfg_sel = CFG_128x320;
-    const int cfg = cfg_sel;
-    if (hilo && cfg == CFG_256x320) p.flags |= EP_NARROW;     // (a forced configuration: the 8-byte general path carries the pair there)
+    // ((hi, lo) launches on the 256x320 tile — 160 accumulator registers per lane — take gemm_epilogue_hilo's plain form without the
+    // hoisted bias, and no statistics form: the consumer keeps its own statistics pass there.  Measured alternatives, round 6
+    // (profiles/r06_fwd_ab_accuracy*.txt): the 8-byte general path 80.9 us, the 128x320 tile 65.8 us on M65536 N320 K320 (fp16 launch:
+    // 35.4 us); the level-0 convolutions 189 us on 128x320 with the statistics form against 123 us + a 17 us longer norm on 256x320.)
+    const int cfg = cfg_picked;
     // ping-pong kernel: every weight row must exist (no n_valid masking) and a (tap, source) segment must fit the zero page
     const bool phase = use_glds && (g_gemm_pipe == 3 || g_gemm_pipe == 4) &&
                        (cfg == CFG_256x320 || cfg == CFG_256x256 || cfg == CFG_256x128 || (cfg == CFG_128x320 && g_gemm_pipe == 4)) && p.n_valid == p.N &&

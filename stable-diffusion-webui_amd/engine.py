@@ -57,8 +57,6 @@ class Engine:
         self.unet_cfg: Optional[UNetConfig] = None
         self.vae_cfg: Optional[VAEConfig] = None
         self._ctx_key = None
-        self._uniform_t = False                               # mirrors of the engine options (unet_forward)
-        self._cfg_pairs = False
 
     def close(self):
         if getattr(self, "handle", None):
@@ -186,21 +184,12 @@ class Engine:
         """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections.  ``uniform_t``: the
         caller guarantees that all rows share one timestep (the samplers' CFG batch): the timestep-embedding path then runs for one row
         (engine option "uniform_t"; same bits)."""
-        if uniform_t != self._uniform_t:
-            self.set_option("uniform_t", 1 if uniform_t else 0)
-            self._uniform_t = uniform_t
         # ``cfg_pairs``: the caller guarantees rows [Bn/2, Bn) repeat the latent AND the timestep of rows [0, Bn/2) (the CFG denoiser's
-        # [cond | uncond] batch): the layers in front of the first cross-attention then run for one half (engine option "cfg_pairs")
-        cfg_pairs = bool(cfg_pairs and CFG_PAIRS)
-        if cfg_pairs != self._cfg_pairs:
-            self.set_option("cfg_pairs", 1 if cfg_pairs else 0)
-            self._cfg_pairs = cfg_pairs
-        # ``auto_promises``: the caller knows neither — the engine derives both from x and timesteps for this call (engine option
-        # "auto_promises": one synchronising device -> host compare per forward); for the stock CFG denoiser behind Mi355xUnet.forward
-        auto_promises = bool(auto_promises and CFG_PAIRS)
-        if auto_promises != getattr(self, "_auto_promises", False):
-            self.set_option("auto_promises", 1 if auto_promises else 0)
-            self._auto_promises = auto_promises
+        # [cond | uncond] batch): the layers in front of the first cross-attention then run for one half.
+        # ``auto_promises``: the caller knows neither — the engine derives both from x and timesteps for this call (one synchronising
+        # device -> host compare per forward); for the stock CFG denoiser behind Mi355xUnet.forward.
+        # All three are arguments of THIS call (sdmi_unet_forward_ex, round 6): nothing sticky is left in the engine for a later caller.
+        flags = (1 if uniform_t else 0) | (2 if (cfg_pairs and CFG_PAIRS) else 0) | (4 if (auto_promises and CFG_PAIRS) else 0)
         x = x.contiguous()
         dt = x.dtype
         timesteps = timesteps.to(dt).contiguous()
@@ -215,8 +204,8 @@ class Engine:
             y = y.to(dt).contiguous()
         if out is None:
             out = torch.empty((bn, self.unet_cfg.out_channels, h, w), dtype=dt, device=x.device)
-        check(lib.sdmi_unet_forward(self.handle, ptr(x), ptr(timesteps), ptr(context), ptr(y), ptr(out), dtype_code(x),
-                                    bn, h, w, l, stream_ptr()), "unet_forward")
+        check(lib.sdmi_unet_forward_ex(self.handle, ptr(x), ptr(timesteps), ptr(context), ptr(y), ptr(out), dtype_code(x),
+                                       bn, h, w, l, flags, stream_ptr()), "unet_forward")
         return out
 
     def vae_decode(self, z: torch.Tensor) -> torch.Tensor:

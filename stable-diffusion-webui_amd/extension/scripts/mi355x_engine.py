@@ -45,6 +45,13 @@ def _register_samplers_and_lora():
             sd_samplers_common = webui_scripts = None
         bridge.bind_shared(shared, sd_samplers_common, webui_scripts)         # modules.shared.opts / state / cmd_opts reach the engine samplers
         done["samplers"] = bridge.install_samplers(sd_samplers, sd_unet, script_callbacks)   # modules/sd_samplers.py:11-16 rows, same names
+        try:                                                                  # refiner checkpoint switch on the engine path (sd_samplers_common.py:158-202)
+            from modules import devices as webui_devices
+        except ImportError:
+            webui_devices = None
+        if hasattr(sd_models, "reload_model_weights"):
+            bridge.install_refiner_switch(sd_models, shared, sd_unet, webui_devices)
+            done["refiner"] = True
     except ImportError:
         sd_unet = None
     try:

@@ -175,25 +175,39 @@ class LCMCompVisDenoiser(CompVisDenoiser):
         return k_out + k_skip, k_out * c_out, c_in
 
 
+# Inside a webui the refiner is a CHECKPOINT the webui loads over its model mid-job (modules/sd_samplers_common.py:184-185
+# sd_models.reload_model_weights): webui_bridge.install_samplers puts the function that does that, on the engine path, here.
+webui_refiner_switch = None
+
+
+def refiner_progress(cfg_denoiser, sigma=None) -> float:
+    """modules/sd_samplers_common.py:159-170: how far the job is, by steps or by the timestep nearest to sigma."""
+    if shared.opts.refiner_switch_by_sample_steps or sigma is None:
+        return cfg_denoiser.step / cfg_denoiser.total_steps
+    try:       # torch.max(sigma) only to handle rare case where we might have different sigmas in the same batch
+        timestep = torch.argmin(torch.abs(cfg_denoiser.inner_model.sigmas - torch.max(sigma).cpu()))
+    except AttributeError:  # for samplers that don't use sigmas (DDIM) sigma is actually the timestep
+        timestep = torch.max(sigma).to(dtype=int)
+    return (999 - int(timestep)) / 1000
+
+
 def apply_refiner(cfg_denoiser, sigma=None):
     """modules/sd_samplers_common.py:158-202.  The reference reloads the refiner checkpoint over the base model
     (sd_models.reload_model_weights) and recomputes the conds with it; with 288 GB of HBM both engines stay resident:
     ``p.refiner_sd_model`` is a second SdModel, ``p.refiner_c / refiner_uc`` (and ``refiner_y / refiner_uy`` for SDXL) are the
-    conds encoded by ITS text encoder, and the switch is a pointer swap on the sampler."""
+    conds encoded by ITS text encoder, and the switch is a pointer swap on the sampler.  A webui job carries
+    ``p.refiner_checkpoint_info`` instead: ``webui_refiner_switch`` (webui_bridge) then performs the reference's own reload and binds
+    the sampler to the engine UNet the webui activated for the new checkpoint."""
     opts = shared.opts
     p = cfg_denoiser.p
     if (opts.refiner_switch_by_sample_steps or sigma is None) and getattr(p, "extra_generation_params", None) is not None:
         p.extra_generation_params["Refiner switch by sampling steps"] = True      # :159-161: noted whenever that rule is in force, refiner or not
-    if getattr(p, "refiner_sd_model", None) is None:          # (the reference evaluates the progress first; without a refiner the
-        return False                                          #  answer is False either way and the device read-back is saved)
-    if opts.refiner_switch_by_sample_steps or sigma is None:
-        completed_ratio = cfg_denoiser.step / cfg_denoiser.total_steps
-    else:
-        try:       # torch.max(sigma) only to handle rare case where we might have different sigmas in the same batch
-            timestep = torch.argmin(torch.abs(cfg_denoiser.inner_model.sigmas - torch.max(sigma).cpu()))
-        except AttributeError:  # for samplers that don't use sigmas (DDIM) sigma is actually the timestep
-            timestep = torch.max(sigma).to(dtype=int)
-        completed_ratio = (999 - int(timestep)) / 1000
+    if getattr(p, "refiner_sd_model", None) is None:
+        if webui_refiner_switch is not None and getattr(p, "refiner_checkpoint_info", None) is not None:
+            return webui_refiner_switch(cfg_denoiser, refiner_progress(cfg_denoiser, sigma))
+        return False                                          # (the reference evaluates the progress first; without a refiner the answer is
+                                                              #  False either way and the device read-back is saved)
+    completed_ratio = refiner_progress(cfg_denoiser, sigma)
     refiner_switch_at = getattr(p, "refiner_switch_at", None)
     refiner = getattr(p, "refiner_sd_model", None)
     if refiner_switch_at is not None and completed_ratio < refiner_switch_at:

@@ -175,11 +175,76 @@ def job_needs_torch_unet(p, sd_model):
 
 def job_needs_stock_sampler(p, sd_model=None):
     """Per-job reasons (only ``p`` knows them, and ``p`` is not there yet when the row's constructor runs) to hand a sampling call to
-    the stock sampler: a refiner CHECKPOINT switch (modules/sd_samplers_common.py:158-202 reloads weights mid-job; the engine's own
-    refiner is a second resident engine the webui's p does not carry), or a torch UNet that ToMe / Hypertile patched."""
-    if getattr(p, "refiner_checkpoint_info", None) is not None and getattr(p, "refiner_sd_model", None) is None:
+    the stock sampler: a refiner CHECKPOINT switch while the webui's checkpoint loader is out of reach (install_refiner_switch binds it:
+    round 6 — until then such jobs always went to the stock sampler), or a torch UNet that ToMe / Hypertile patched."""
+    from . import sd_samplers as amd
+    if getattr(p, "refiner_checkpoint_info", None) is not None and getattr(p, "refiner_sd_model", None) is None and amd.webui_refiner_switch is None:
         return "refiner checkpoint switch"
     return job_needs_torch_unet(p, sd_model) if sd_model is not None else None
+
+
+def install_refiner_switch(webui_sd_models, webui_shared, sd_unet_module, webui_devices=None):
+    """The refiner CHECKPOINT switch of a webui job on the engine path (modules/sd_samplers_common.py:158-202, statement for statement
+    after the progress test the caller already made): the webui reloads its model with the refiner checkpoint
+    (``sd_models.reload_model_weights(info=...)`` — which ends in ``sd_unet.apply_unet()``, modules/sd_models.py:1000: with "SD Unet:
+    Automatic" that activates the engine UNet listed for the refiner checkpoint, modules/sd_unet.py:14-31), recomputes the conds with the new
+    text encoder (``p.setup_conds()``), and the engine sampler continues on the newly activated engine: new model view, new wrapped
+    denoiser, the new conds in the sampler loop's extra_args (CFGDenoiser.update_inner_model, modules/sd_samplers_cfg_denoiser.py:93-98).
+    If the webui did NOT activate an engine UNet for the refiner checkpoint (the user pinned "SD Unet: None" or another option) the job
+    cannot continue on this path and says so."""
+    from . import sd_samplers as amd, shared
+
+    def switch(cfg_denoiser, completed_ratio):
+        p = cfg_denoiser.p
+        opts = shared.opts
+        refiner_switch_at = getattr(p, "refiner_switch_at", None)
+        info = getattr(p, "refiner_checkpoint_info", None)
+        if refiner_switch_at is not None and completed_ratio < refiner_switch_at:
+            return False
+        if info is None or getattr(webui_shared.sd_model, "sd_checkpoint_info", None) == info:
+            return False
+        if getattr(p, "enable_hr", False):
+            is_second_pass = p.is_hr_pass
+            if opts.hires_fix_refiner_pass == "first pass" and is_second_pass:
+                return False
+            if opts.hires_fix_refiner_pass == "second pass" and not is_second_pass:
+                return False
+            if opts.hires_fix_refiner_pass != "second pass":
+                p.extra_generation_params['Hires refiner'] = opts.hires_fix_refiner_pass
+        p.extra_generation_params['Refiner'] = info.short_title
+        p.extra_generation_params['Refiner switch at'] = refiner_switch_at
+        skip = getattr(webui_sd_models, "SkipWritingToConfig", None)
+        if skip is not None:
+            with skip():
+                webui_sd_models.reload_model_weights(info=info)
+        else:
+            webui_sd_models.reload_model_weights(info=info)
+        if webui_devices is not None and hasattr(webui_devices, "torch_gc"):
+            webui_devices.torch_gc()
+        p.setup_conds()
+        view = engine_model_view(webui_shared.sd_model, sd_unet_module)
+        if view is None:
+            raise RuntimeError("refiner switch: the webui did not activate an engine UNet for the refiner checkpoint "
+                               f"'{info.short_title}' (set 'SD Unet' to Automatic, or to None for this job)")
+        sampler = cfg_denoiser.sampler
+        sampler.sd_model = view
+        shared.sd_model = view
+        cfg_denoiser.model_wrap = None                        # rebuilt over the new checkpoint's alphas_cumprod
+        cfg_denoiser._ctx_key = None                          # the cached K / V projections belong to the other engine
+        cfg_denoiser._cond_sel = cfg_denoiser._uncond_sel = None
+        c, uc = p.get_conds()
+        args = sampler.sampler_extra_args
+        args['cond'], args['uncond'] = c, uc
+        args.pop('y', None)
+        args.pop('uy', None)                                  # SDXL: the vector conditioning rides inside the dict conds (CFGDenoiser._reconstruct_conds)
+        return True
+    amd.webui_refiner_switch = switch
+    return switch
+
+
+def uninstall_refiner_switch():
+    from . import sd_samplers as amd
+    amd.webui_refiner_switch = None
 
 
 def _engine_sampler_with_job_checks(engine_sampler, stock_ctor, model):
