@@ -224,9 +224,8 @@ size_t rowchain_ff_pack_bytes(int C, int hidden);
 int launch_rowchain_ff_pack(const half_t* w1, const float* b1, const half_t* w2, void* packs, int C, int hidden, bool permuted,
                             hipStream_t s);
 // out = x + W2 GEGLU(W1 LN(x) + b1) + b2 (rows % 128 == 0)
-// x_lo / out_lo (engine option "residual_fp32"): the lo halves when the token stream is a (hi, lo) pair of fp16 tensors
 int launch_rowchain_ff(const half_t* x, half_t* out, const float* gamma, const float* beta, const void* packs, const float* bias_out,
-                       long rows, int C, int hidden, float eps, hipStream_t s, const half_t* x_lo = nullptr, half_t* out_lo = nullptr);
+                       long rows, int C, int hidden, float eps, hipStream_t s);
 
 // ---- norms ------------------------------------------------------------------------------------------------
 // pre_nchunk > 0: `ws` already holds partial sums [B][pre_nchunk][groups][2] (written by the producing GEMM): skip the statistics pass

@@ -796,7 +796,10 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
         // option "fuse_rows" bit 1 (below): the feed-forward third of the block as one launch (rowchain.hip)
         // (not with option "streams" > 1: the feed-forward pack is built lazily on the stream of the slice that meets it first, and the
         // other slices would read it with no event dependency on that stream — the same rule as ln_fold's folded weights)
-        const bool chain_ok = !fold && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0 && e->n_streams <= 1;
+        // (not with (hi, lo) token streams: a pair form of the chain was built and measured in round 6 — the lo rows passing through the
+        // wave's one LDS staging region after the hi rows, in and out: 324 us against 269 us for LayerNorm + GEGLU GEMM + GEMM on the pair,
+        // profiles/r06_fwd_ab_accuracy_with_hilo_chain.txt — and removed again)
+        const bool chain_ok = !fold && !acc && !e->force_generic && e->use_glds && rowchain_supports(C) && HW % 128 == 0 && e->n_streams <= 1;
         half_t* x2 = nullptr;
         {
         half_t* q2 = nullptr;
@@ -848,7 +851,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
                     TRY(launch_rowchain_ff_pack(b.ff1.w, b.ff1.b, b.ff2.w, b.ff_packs, C, hidden, true, r.s));
                     b.ff_epoch = e->weights_epoch;
                 }
-                TRY(launch_rowchain_ff(x2, x3, b.ln3.g, b.ln3.b, b.ff_packs, b.ff2.b, (long)M, C, hidden, 1e-5f, r.s, r.lo(x2, MC), r.lo(x3, MC)));
+                TRY(launch_rowchain_ff(x2, x3, b.ln3.g, b.ln3.b, b.ff_packs, b.ff2.b, (long)M, C, hidden, 1e-5f, r.s));
             }
         } else {
         half_t* g = nullptr;

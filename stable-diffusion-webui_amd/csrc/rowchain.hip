@@ -66,8 +66,6 @@ struct RowChainP {
     int nchunk;               // hidden / 32
     float eps;
     const half_t* zero;       // the zero page (padding lanes of the row staging)
-    const half_t* x_lo;       // HILO (engine option "residual_fp32"): the token stream as (hi, lo) fp16 pairs — x = x + x_lo on the way in
-    half_t* out_lo;           // (LayerNorm input and residual), out / out_lo = fp16(v) / fp16(v - fp16(v)) on the way out
 };
 
 __device__ __forceinline__ float rc_gelu_erf(float g) {      // gemm.hip's gelu_erf (exact-erf GELU, A&S 7.1.26), instruction for instruction
@@ -110,37 +108,27 @@ __device__ __forceinline__ void rc_stage_rows(const half_t* xwave, char* region,
 
 // The lane's half of its staged row -> LayerNorm -> fp16 fragments (B operand of stage 1): xf[dc] = n[row][dc*16 + half*8 .. +8).
 // Two-pass statistics from the fp16 values, as norm.hip's layernorm_kernel.
-// HILO: the row is a (hi, lo) pair — on entry xf already holds the hi halves and the region holds the LO rows (the kernel staged them
-// over the hi rows once those were in registers: one staging region per wave is all the LDS has room for); every pass re-reads the lo
-// fragments from LDS, so the value hi + lo is never held for the whole row.
-template <int C, bool HILO = false>
+template <int C>
 __device__ __forceinline__ void rc_load_ln(const char* region, int lq, const float* gamma, const float* beta, float eps, int half,
                                            h8 (&xf)[C / 16]) {
     constexpr int NDC = C / 16;
     const char* xrow = region + lq * RcGeo<C>::B1STR + half * 16;
-    if constexpr (!HILO) {
 #pragma unroll
-        for (int dc = 0; dc < NDC; ++dc) xf[dc] = *reinterpret_cast<const h8*>(xrow + dc * 32);
-    }
-    const h8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int dc = 0; dc < NDC; ++dc) xf[dc] = *reinterpret_cast<const h8*>(xrow + dc * 32);
     float s = 0.f;
 #pragma unroll
-    for (int dc = 0; dc < NDC; ++dc) {
-        const h8 l = HILO ? *reinterpret_cast<const h8*>(xrow + dc * 32) : z8;
+    for (int dc = 0; dc < NDC; ++dc)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += HILO ? (float)xf[dc][e] + (float)l[e] : (float)xf[dc][e];
-    }
+        for (int e = 0; e < 8; ++e) s += (float)xf[dc][e];
     float lo, hi;
     rc_pair(s, lo, hi);
     const float inv_c = 1.0f / (float)C;
     const float mean = (lo + hi) * inv_c;
     float q = 0.f;
 #pragma unroll
-    for (int dc = 0; dc < NDC; ++dc) {
-        const h8 l = HILO ? *reinterpret_cast<const h8*>(xrow + dc * 32) : z8;
+    for (int dc = 0; dc < NDC; ++dc)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = (HILO ? (float)xf[dc][e] + (float)l[e] : (float)xf[dc][e]) - mean; q = fmaf(d, d, q); }
-    }
+        for (int e = 0; e < 8; ++e) { const float d = (float)xf[dc][e] - mean; q = fmaf(d, d, q); }
     rc_pair(q, lo, hi);
     const float rstd = rsqrtf(fmaf(lo + hi, inv_c, eps));
 #pragma unroll
@@ -148,12 +136,11 @@ __device__ __forceinline__ void rc_load_ln(const char* region, int lq, const flo
         const int c0 = dc * 16 + half * 8;
         const f4 g0 = *reinterpret_cast<const f4*>(gamma + c0), g1 = *reinterpret_cast<const f4*>(gamma + c0 + 4);
         const f4 b0 = *reinterpret_cast<const f4*>(beta + c0), b1 = *reinterpret_cast<const f4*>(beta + c0 + 4);
-        const h8 l = HILO ? *reinterpret_cast<const h8*>(xrow + dc * 32) : z8;
         h8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float g = e < 4 ? g0[e] : g1[e - 4], bb = e < 4 ? b0[e] : b1[e - 4];
-            o[e] = (half_t)(((HILO ? (float)xf[dc][e] + (float)l[e] : (float)xf[dc][e]) - mean) * rstd * g + bb);
+            o[e] = (half_t)(((float)xf[dc][e] - mean) * rstd * g + bb);
         }
         xf[dc] = o;
     }
@@ -178,75 +165,15 @@ __device__ __forceinline__ f16v rc_init(const char* unit, int half) {
 // out[row][c] = O + bias + x:  o[db][r] is O[row][db*32 + (r & 3) + 8 * (r >> 2) + 4 * half].  Through the wave's LDS staging region:
 // the residual rows arrive as coalesced pieces (rc_stage_rows), every lane adds its accumulators to its row in place, and the finished
 // rows leave as coalesced 16-byte stores.  Call with all waves past their last operand read (the regions overlay the operand buffers).
-// HILO: the residual is a (hi, lo) pair and so is the output — the hi rows, then the lo rows pass through the region and are added to
-// the accumulators in registers; fp16(v) leaves through the region, then fp16(v - fp16(v)).
 template <int C>
-__device__ __forceinline__ void rc_rows_out(const char* region, half_t* owave, int lane) {
+__device__ __forceinline__ void rc_store(const RowChainP& p, long wave_row0, char* region, int lane, const f16v (&o)[C / 32]) {
     typedef RcGeo<C> G;
     constexpr int SLOTS = G::B1STR / 16, NPIECE = G::B1UNIT / 1024;
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-        const int n = i * 64 + lane;
-        const int r = (n * 1599) >> 16;
-        const int c = n - r * SLOTS;
-        const h8 v = *reinterpret_cast<const h8*>(region + n * 16);
-        if (r < 32 && c < C / 8) *reinterpret_cast<h8*>(owave + r * C + c * 8) = v;
-    }
-}
-__device__ __forceinline__ void rc_region_turn() {         // my LDS accesses are done and so are my wave's: the region may change hands
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-template <int C, bool HILO = false>
-__device__ __forceinline__ void rc_store(const RowChainP& p, long wave_row0, char* region, int lane, f16v (&o)[C / 32]) {
-    typedef RcGeo<C> G;
     const int half = lane >> 5, lq = lane & 31;
     rc_stage_rows<C>(p.x + wave_row0 * C, region, lane, p.zero);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     char* xrow = region + lq * G::B1STR;
-    if constexpr (HILO) {
-#pragma unroll
-        for (int db = 0; db < C / 32; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = db * 32 + g * 8 + half * 4;
-                const h4 res = *reinterpret_cast<const h4*>(xrow + c0 * 2);
-                const f4 bb = *reinterpret_cast<const f4*>(p.bias_out + c0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[db][g * 4 + e] = (o[db][g * 4 + e] + bb[e]) + (float)res[e];
-            }
-        rc_region_turn();
-        rc_stage_rows<C>(p.x_lo + wave_row0 * C, region, lane, p.zero);
-        rc_region_turn();
-#pragma unroll
-        for (int db = 0; db < C / 32; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = db * 32 + g * 8 + half * 4;
-                const h4 res = *reinterpret_cast<const h4*>(xrow + c0 * 2);
-                h4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { o[db][g * 4 + e] += (float)res[e]; v[e] = (half_t)o[db][g * 4 + e]; }
-                *reinterpret_cast<h4*>(xrow + c0 * 2) = v;
-            }
-        rc_region_turn();
-        rc_rows_out<C>(region, p.out + wave_row0 * C, lane);
-        rc_region_turn();
-#pragma unroll
-        for (int db = 0; db < C / 32; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = db * 32 + g * 8 + half * 4;
-                h4 l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) l[e] = (half_t)(o[db][g * 4 + e] - (float)(half_t)o[db][g * 4 + e]);
-                *reinterpret_cast<h4*>(xrow + c0 * 2) = l;
-            }
-        rc_region_turn();
-        rc_rows_out<C>(region, p.out_lo + wave_row0 * C, lane);
-        return;
-    }
 #pragma unroll
     for (int db = 0; db < C / 32; ++db)
 #pragma unroll
@@ -260,7 +187,15 @@ __device__ __forceinline__ void rc_store(const RowChainP& p, long wave_row0, cha
             *reinterpret_cast<h4*>(xrow + c0 * 2) = v;
         }
     __builtin_amdgcn_wave_barrier();
-    rc_rows_out<C>(region, p.out + wave_row0 * C, lane);
+    half_t* owave = p.out + wave_row0 * C;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int n = i * 64 + lane;
+        const int r = (n * 1599) >> 16;
+        const int c = n - r * SLOTS;
+        const h8 v = *reinterpret_cast<const h8*>(region + n * 16);
+        if (r < 32 && c < C / 8) *reinterpret_cast<h8*>(owave + r * C + c * 8) = v;
+    }
 }
 
 // The packed stream is the LDS image: piece k of this wave (1 KB pieces dealt round-robin to the 4 waves) is a lane-linear copy.
@@ -301,7 +236,7 @@ constexpr int kRcPF = 8;
 // sliced between them, then O += B2(j - 1) P(j - 1) (20 MFMAs).  Two score sets alternate (template parity), two pack buffers in LDS;
 // pack j + 1 is issued during iteration j.
 // ---------------------------------------------------------------------------------------------------------------
-template <int C, bool HILO = false>
+template <int C>
 __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     typedef RcGeo<C> G;
     constexpr int PACK = G::FFPACK, NP = PACK / 1024, PF = kRcPF;
@@ -320,17 +255,7 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     wait_vm<NP / 4>();                                       // the rows have landed (loads retire in order); pack 0 may still be in flight
     __builtin_amdgcn_wave_barrier();
     h8 xf[NDC];
-    if constexpr (HILO) {                                    // hi halves into registers, then the lo rows over them in the region
-        const char* xrow = xreg + lq * G::B1STR + half * 16;
-#pragma unroll
-        for (int dc = 0; dc < NDC; ++dc) xf[dc] = *reinterpret_cast<const h8*>(xrow + dc * 32);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        rc_stage_rows<C>(p.x_lo + ((long)blockIdx.x * 128 + wave * 32) * C, xreg, lane, p.zero);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (pack 0 has landed too: it was issued ahead of these)
-        __builtin_amdgcn_wave_barrier();
-    }
-    rc_load_ln<C, HILO>(xreg, lq, p.gamma, p.beta, p.eps, half, xf);
+    rc_load_ln<C>(xreg, lq, p.gamma, p.beta, p.eps, half, xf);
 
     f16v o[NDB];
 #pragma unroll
@@ -410,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void rowchain_ff_kernel(RowChainP p) {
     if (nch & 1) phase(nch, F{}, T{}, P1{});
     else phase(nch, F{}, T{}, P0{});
     rc_phase_sync();                                         // every wave is past its last operand read
-    rc_store<C, HILO>(p, (long)blockIdx.x * 128 + wave * 32, smem + wave * G::B1UNIT, lane, o);
+    rc_store<C>(p, (long)blockIdx.x * 128 + wave * 32, smem + wave * G::B1UNIT, lane, o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -485,19 +410,16 @@ static int rc_set_smem(K kern, int bytes) {
 }
 
 int launch_rowchain_ff(const half_t* x, half_t* out, const float* gamma, const float* beta, const void* packs, const float* bias_out,
-                       long rows, int C, int hidden, float eps, hipStream_t s, const half_t* x_lo, half_t* out_lo) {
-    SDMI_REQUIRE((x_lo == nullptr) == (out_lo == nullptr), "rowchain feed-forward: (hi, lo) input and output go together");
+                       long rows, int C, int hidden, float eps, hipStream_t s) {
     SDMI_REQUIRE(rowchain_supports(C) && hidden % 32 == 0 && rows > 0 && rows % 128 == 0, "rowchain feed-forward: C = 320, rows % 128 == 0");
     typedef RcGeo<320> G;
     constexpr int SMEM = std::max(2 * G::FFPACK, G::FFPACK + 4 * G::B1UNIT);      // two pack buffers | pack 0 + the prologue's row staging
-    const bool hilo = x_lo != nullptr;
-    void (*kern)(RowChainP) = hilo ? rowchain_ff_kernel<320, true> : rowchain_ff_kernel<320, false>;
-    static PerDeviceOnce attr[2];                            // (per device: one process may drive several — common.h)
-    if (attr[hilo].need() && rc_set_smem(kern, SMEM)) return 1;
+    void (*kern)(RowChainP) = rowchain_ff_kernel<320>;
+    static PerDeviceOnce attr;                               // (per device: one process may drive several — common.h)
+    if (attr.need() && rc_set_smem(kern, SMEM)) return 1;
     RowChainP p{};
     p.x = x; p.out = out; p.gamma = gamma; p.beta = beta; p.packs = (const char*)packs; p.bias_out = bias_out ? bias_out : reinterpret_cast<const float*>(zero_page()); p.zero = zero_page();
     p.M = (int)rows; p.nchunk = hidden / 32; p.eps = eps;
-    p.x_lo = x_lo; p.out_lo = out_lo;
     ProfScope ps("rowchain_ff", 2.0 * rows * C * (3.0 * hidden), 4.0 * rows * C, s);
     hipLaunchKernelGGL(kern, dim3((unsigned)(rows / 128)), dim3(256), SMEM, s, p);
     SDMI_CHECK_HIP(hipGetLastError());

@@ -293,11 +293,6 @@ int emu_groupnorm_hilo(const uint16_t* x0, const uint16_t* x1, int c0, int c1, c
     return launch_groupnorm((const half_t*)x0, (const half_t*)x1, c0, c1, gamma, beta, (half_t*)out, B, HW, groups, eps, silu != 0, ws, nullptr,
                             pre_nchunk, (const half_t*)x0_lo, (const half_t*)x1_lo);
 }
-// the fused feed-forward chain on a (hi, lo) token stream (engine option "residual_fp32": engine.cpp run_st passes the pair)
-int emu_rowchain_ff_hilo(const uint16_t* x, const uint16_t* x_lo, uint16_t* out, uint16_t* out_lo, const float* g, const float* b, const void* packs,
-                         const float* b2, int64_t rows, int C, int hidden, float eps) {
-    return launch_rowchain_ff((const half_t*)x, (half_t*)out, g, b, packs, b2, (long)rows, C, hidden, eps, nullptr, (const half_t*)x_lo, (half_t*)out_lo);
-}
 int emu_nchw_to_nhwc_lo(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int lo_ch) {
     return launch_nchw_to_nhwc(x, 1, (half_t*)out, B, C, HW, cpad, 1.0f, nullptr, nullptr, nullptr, lo_ch != 0);
 }
