@@ -346,6 +346,12 @@ int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, cons
  *   SDMI_CALL_DERIVE      neither is known (the stock CFG denoiser behind SdUnet.forward, modules/sd_unet.py:86-93): the engine derives
  *                         both from x and timesteps — one synchronising device -> host compare */
 enum { SDMI_CALL_UNIFORM_T = 1, SDMI_CALL_CFG_PAIRS = 2, SDMI_CALL_DERIVE = 4 };
+/* Extra UNet inputs of SdUnet.forward(x, timesteps, context, *args, **kwargs) (modules/sd_unet.py:76-77, 87-91 pass them through): the
+ * ControlNet residuals `control` of ldm's ControlledUnetModel.forward (cldm.py) for the NEXT sdmi_unet_forward[_ex] call only — n =
+ * (number of input blocks) + 1 device tensors in the io dtype of that call, NCHW, tensor i shaped like input block i's output
+ * [Bn, C_i, h_i, w_i] and the last like the middle block's; numel[i] is checked against that shape.  They are added to the skip
+ * connections as the output blocks read them and to the middle block's output; only_mid_control: the last one alone.  n = 0 clears. */
+int sdmi_unet_set_control(sdmi_engine* e, const void* const* tensors, const int64_t* numel, int n, int only_mid_control);
 int sdmi_unet_forward_ex(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y,
                          void* out, int io_dtype, int Bn, int h, int w, int L, int call_flags, void* stream);
 

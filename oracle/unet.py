@@ -295,7 +295,11 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(), nn.Conv2d(mc, cfg.out_channels, 3, padding=1))
 
-    def forward(self, x, timesteps, context, y=None):
+    def forward(self, x, timesteps, context, y=None, control=None, only_mid_control=False):
+        """``control`` (ControlNet residuals; the webui's SdUnet.forward hands extra inputs through, modules/sd_unet.py:76-77, 87-91): the
+        published ControlledUnetModel.forward (lllyasviel/ControlNet cldm/cldm.py — third party, absent here: restated) — a list with one
+        tensor per input block output plus one for the middle block, consumed from the END: the last entry is added to the middle block's
+        output, the others to the skip connections as the output blocks pop them."""
         emb = self.time_embed(timestep_embedding(timesteps, self.cfg.model_channels))
         if self.cfg.adm_in_channels is not None:
             emb = emb + self.label_emb(y)
@@ -305,8 +309,14 @@ class UNetModel(nn.Module):
             h = module(h, emb, context)
             hs.append(h)
         h = self.middle_block(h, emb, context)
+        control = list(control) if control is not None else None
+        if control is not None:
+            h = h + control.pop()
         for module in self.output_blocks:
-            h = torch.cat([h, hs.pop()], dim=1)
+            if only_mid_control or control is None:
+                h = torch.cat([h, hs.pop()], dim=1)
+            else:
+                h = torch.cat([h, hs.pop() + control.pop()], dim=1)
             h = module(h, emb, context)
         return self.out(h)
 

@@ -135,6 +135,7 @@ _SIGS = {
     "sdmi_unet_set_context": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sdmi_unet_set_context_cached": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sdmi_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sdmi_unet_set_control": (_i, [_vp, _vp, _vp, _i, _i]),
     "sdmi_unet_forward_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sdmi_vae_decode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "sdmi_vae_encode": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp]),

@@ -536,6 +536,16 @@ int sdmi_unet_forward(sdmi_engine* e, const void* x, const void* timesteps, cons
     return unet_forward(e, x, timesteps, context, y, out, io_dtype, Bn, h, w, L, (hipStream_t)stream);
     API_GUARD_END
 }
+int sdmi_unet_set_control(sdmi_engine* e, const void* const* tensors, const int64_t* numel, int n, int only_mid_control) {
+    API_GUARD_BEGIN
+    SDMI_REQUIRE(e != nullptr && n >= 0 && (n == 0 || (tensors && numel)), "null argument");
+    e->control.assign(tensors, tensors + n);
+    e->control_numel.assign(numel, numel + n);
+    e->only_mid_control = only_mid_control != 0;
+    for (int i = 0; i < n; ++i) SDMI_REQUIRE(tensors[i] != nullptr, "null control tensor");
+    return 0;
+    API_GUARD_END
+}
 int sdmi_unet_forward_ex(sdmi_engine* e, const void* x, const void* timesteps, const void* context, const void* y, void* out,
                          int io_dtype, int Bn, int h, int w, int L, int call_flags, void* stream) {
     API_GUARD_BEGIN

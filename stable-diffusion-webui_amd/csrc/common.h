@@ -286,6 +286,9 @@ int launch_image_to_u8(const float* img, uint8_t* out, int B, int C, int H, int 
 // NCHW (f16|f32) * scale -> NHWC fp16 with channels zero-padded to cpad; optional 1x1 channel mix (pqc) first.
 int launch_nchw_to_nhwc(const void* x, int dtype, half_t* out, int B, int C, int HW, int cpad, float scale,
                         const float* mix_w, const float* mix_b, hipStream_t s, bool lo_ch = false);
+// dst (NHWC fp16, optionally a (hi, lo) pair) = src + ctrl (NCHW, f16 | f32): ControlNet residuals into the UNet's skip connections
+int launch_add_nchw_residual(const half_t* src, const half_t* src_lo, const void* ctrl, int dtype, half_t* dst, half_t* dst_lo, int B, int C,
+                             int HW, hipStream_t s);
 // fp32 NCHW -> user dtype NCHW copy
 int launch_copy_out(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
 int launch_convert_to_f16(const void* src, int dtype, half_t* dst, int64_t n, hipStream_t s);

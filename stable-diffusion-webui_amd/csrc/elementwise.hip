@@ -671,6 +671,47 @@ int launch_nchw_to_nhwc(const void* x, int dtype, half_t* out, int B, int C, int
     return 0;
 }
 
+// dst[b][p][c] = src[b][p][c] (+ src_lo) + ctrl[b][c][p]: a ControlNet residual (NCHW, the caller's dtype) added to an NHWC activation of
+// the UNet (engine.cpp unet_run: the skip connections and the middle block's output).  A thread owns 8 channels of one pixel; adjacent
+// threads own adjacent pixels, so each of the 8 strided reads of ctrl is coalesced across the wave.  (hi, lo) activations in, pair out.
+template <typename T>
+__global__ __launch_bounds__(256) void add_nchw_residual_kernel(const half_t* src, const half_t* src_lo, const T* ctrl, half_t* dst, half_t* dst_lo,
+                                                                 int C, long HW, long total) {
+    const int CV = C / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pix = i % HW;
+        const long rest = i / HW;
+        const int cv = (int)(rest % CV);
+        const long b = rest / CV;
+        const long o = (b * HW + pix) * C + cv * 8;
+        const h8 v = *reinterpret_cast<const h8*>(src + o);
+        h8 l = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (src_lo) l = *reinterpret_cast<const h8*>(src_lo + o);
+        h8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = ((float)v[e] + (float)l[e]) + (float)ctrl[(b * C + cv * 8 + e) * HW + pix];
+            oh[e] = (half_t)f;
+            ol[e] = (half_t)(f - (float)oh[e]);
+        }
+        *reinterpret_cast<h8*>(dst + o) = oh;
+        if (dst_lo) *reinterpret_cast<h8*>(dst_lo + o) = ol;
+    }
+}
+int launch_add_nchw_residual(const half_t* src, const half_t* src_lo, const void* ctrl, int dtype, half_t* dst, half_t* dst_lo, int B, int C,
+                             int HW, hipStream_t s) {
+    SDMI_REQUIRE(C % 8 == 0 && (src_lo == nullptr) == (dst_lo == nullptr), "add_nchw_residual: C % 8 == 0; (hi, lo) in means (hi, lo) out");
+    const long total = (long)B * HW * (C / 8);
+    if (dtype == 0)
+        hipLaunchKernelGGL(add_nchw_residual_kernel<half_t>, dim3(ew_blocks(total)), dim3(256), 0, s, src, src_lo, (const half_t*)ctrl, dst, dst_lo,
+                           C, (long)HW, total);
+    else
+        hipLaunchKernelGGL(add_nchw_residual_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, src, src_lo, (const float*)ctrl, dst, dst_lo,
+                           C, (long)HW, total);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void convert_kernel(const TI* src, TO* dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (TO)src[i];

@@ -1147,14 +1147,37 @@ static int unet_run(Run& r, const void* x, const void* t, const void* y, void* o
         return 0;
     };
     if (!r.dry) e->taps.clear();
+    // ControlNet residuals (sdmi_unet_set_control; ldm cldm.py ControlledUnetModel.forward): control[i] is added to input block i's
+    // output where the output blocks read it as their skip connection — the stream itself goes on without it — and the last entry to the
+    // middle block's output.  One transposing add per tensor (they arrive NCHW) into a buffer of its own: the arena layout of a forward
+    // with residuals differs from one without, so the dry pass sees them too.  Rows of a batch slice (option "streams") start at b0.
+    const bool have_ctl = !e->control.empty();
+    const size_t n_ctl = e->control.size();
+    if (have_ctl) SDMI_REQUIRE(n_ctl == u.input.size() + 1, "control: one tensor per input block output and one for the middle block");
+    auto add_control = [&](Act a, size_t idx, Act* out) -> int {
+        const size_t n = (size_t)Bn * a.H * a.W * a.C;
+        half_t* o = r.S(n);
+        if (!r.dry) {
+            const size_t full = (size_t)(r.Btot ? r.Btot : Bn) * a.C * a.H * a.W;
+            SDMI_REQUIRE((size_t)e->control_numel[idx] == full, "control tensor " + std::to_string(idx) + " does not have the shape of the activation it is added to");
+            const size_t elt = io_dtype == SDMI_F16 ? 2 : 4;
+            const char* src = (const char*)e->control[idx] + (size_t)r.b0 * a.C * a.H * a.W * elt;
+            TRY(launch_add_nchw_residual(a.p, r.lo(a.p, n), src, io_dtype, o, r.lo(o, n), Bn, a.C, a.H * a.W, r.s));
+        }
+        *out = Act{o, a.C, a.H, a.W};
+        return 0;
+    };
     int bidx = 0;
     for (auto& blk : u.input) {
         TRY(run_block(blk, nullptr, "input_blocks." + std::to_string(bidx++)));
         if (shared) TRY(dup(cur));                           // the skip connection is read for all Bn rows (the next block goes on with Bh)
-        hs.push_back(cur);
+        Act sk = cur;
+        if (have_ctl && !e->only_mid_control) TRY(add_control(cur, hs.size(), &sk));
+        hs.push_back(sk);
     }
     shared = false;                                          // (a UNet without a transformer on the way down: every hs entry is complete)
     TRY(run_block(u.middle, nullptr, "middle_block"));
+    if (have_ctl) TRY(add_control(cur, n_ctl - 1, &cur));
     bidx = 0;
     for (auto& blk : u.output) {
         Act sk = hs.back();
@@ -1254,6 +1277,10 @@ int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, 
         e->uniform_t = uni;
         e->cfg_pairs = pairs;
     }
+    struct ClearControl {                                    // the residuals belong to this call alone
+        sdmi_engine* e;
+        ~ClearControl() { e->control.clear(); e->control_numel.clear(); e->only_mid_control = false; }
+    } clear_control{e};
     if (ctx) TRY(unet_set_context(e, ctx, io_dtype, Bn, L, s));
     // Option "streams" = n > 1: the rows of a call are independent (own timestep, own context rows), so the batch is cut into n
     // equal slices that run the same launch sequence on n HIP streams out of n arenas.  The GPU then always has a second, independent

@@ -226,6 +226,11 @@ struct sdmi_engine {
     bool trace = false;
     struct Tap { std::string name; const half_t* ptr; int B, H, W, C; };
     std::vector<Tap> taps;
+    // ControlNet residuals for the NEXT forward only (sdmi_unet_set_control; consumed and cleared by it): one NCHW tensor per input
+    // block output + one for the middle block, in the caller's io dtype (ldm cldm.py ControlledUnetModel.forward)
+    std::vector<const void*> control;
+    std::vector<int64_t> control_numel;
+    bool only_mid_control = false;
     // context cache (persistent between forwards)
     half_t* ctx_f16 = nullptr;                // [Bn][Lpad][ctx_dim]
     std::vector<half_t*> ctx_k;               // per slot [Bn*Lpad][C]

@@ -180,7 +180,7 @@ class Engine:
 
     def unet_forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: Optional[torch.Tensor] = None,
                      y: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, uniform_t: bool = False,
-                     cfg_pairs: bool = False, auto_promises: bool = False) -> torch.Tensor:
+                     cfg_pairs: bool = False, auto_promises: bool = False, control=None, only_mid_control: bool = False) -> torch.Tensor:
         """eps = UNet(x, timesteps, context[, y]); x [Bn,Cin,h,w]; context None reuses the cached projections.  ``uniform_t``: the
         caller guarantees that all rows share one timestep (the samplers' CFG batch): the timestep-embedding path then runs for one row
         (engine option "uniform_t"; same bits)."""
@@ -204,6 +204,13 @@ class Engine:
             y = y.to(dt).contiguous()
         if out is None:
             out = torch.empty((bn, self.unet_cfg.out_channels, h, w), dtype=dt, device=x.device)
+        if control is not None:
+            # ControlNet residuals (ldm cldm.py ControlledUnetModel.forward): one tensor per input block output + the middle block's,
+            # handed to the engine for THIS call (sdmi_unet_set_control); kept alive here until the launch is enqueued
+            control = [c.to(device=x.device, dtype=dt).contiguous() for c in control]
+            ptrs = (C.c_void_p * len(control))(*[c.data_ptr() for c in control])
+            numel = (C.c_int64 * len(control))(*[c.numel() for c in control])
+            check(lib.sdmi_unet_set_control(self.handle, ptrs, numel, len(control), 1 if only_mid_control else 0), "unet_set_control")
         check(lib.sdmi_unet_forward_ex(self.handle, ptr(x), ptr(timesteps), ptr(context), ptr(y), ptr(out), dtype_code(x),
                                        bn, h, w, l, flags, stream_ptr()), "unet_forward")
         return out

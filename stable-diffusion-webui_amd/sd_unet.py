@@ -77,8 +77,11 @@ class Mi355xUnet(SdUnet):
             why = patched_unet_reason(getattr(shared.webui, "sd_model", None))
             if why is not None:
                 return self._torch_unet_forward(why, x, timesteps, context, *args, **kwargs)
-        if kwargs.get("control") is not None or args:
-            raise NotImplementedError("extra UNet inputs (ControlNet residuals etc.) are not supported by the engine UNet")
+        # extra inputs (modules/sd_unet.py:76-77, 87-91 pass *args / **kwargs through): ``y`` and the ControlNet residuals of ldm's
+        # ControlledUnetModel.forward (``control`` / ``only_mid_control``, cldm.py) are the engine's; anything else is refused loudly
+        extra = set(kwargs) - {"y", "control", "only_mid_control"}
+        if args or extra:
+            raise NotImplementedError(f"extra UNet inputs {sorted(extra) or 'given positionally'} are not supported by the engine UNet")
         if x.dtype not in (torch.float16, torch.float32):
             x = x.float()
         y = kwargs.get("y", None)
@@ -93,7 +96,8 @@ class Mi355xUnet(SdUnet):
         # batch, for which the engine shares the layers in front of the first cross-attention) only the data says.  opts.mi355x_auto_cfg_pairs
         # lets the engine look (a synchronising compare per evaluation; the engine's own samplers know and never need it).
         auto = bool(getattr(shared.opts, "mi355x_auto_cfg_pairs", False))
-        return self.engine.unet_forward(x, timesteps, ctx, y, auto_promises=auto)
+        return self.engine.unet_forward(x, timesteps, ctx, y, auto_promises=auto, control=kwargs.get("control"),
+                                        only_mid_control=bool(kwargs.get("only_mid_control", False)))
 
 
     def _torch_unet_forward(self, why, x, timesteps, context, *args, **kwargs):

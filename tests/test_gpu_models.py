@@ -91,6 +91,55 @@ def test_unet_accuracy_mode_carries_the_residual_stream_with_22_bits(dev, tiny):
     assert torch.equal(twin[:2], twin[2:]) and rel_l2(pairs, rows) < 6e-3 and rel_l2(pairs, om.unet(xp, tp, ctx.half().float())) < 4e-3
 
 
+def test_unet_control_residuals_through_the_sdunet_boundary(dev, tiny):
+    """Extra UNet inputs of SdUnet.forward (modules/sd_unet.py:76-77, 87-91 hand *args / **kwargs through): the ControlNet residuals of
+    ldm's ControlledUnetModel.forward — one tensor per input block output + the middle block's, added to the skip connections as the
+    output blocks read them and to the middle block's output — against the oracle's restatement; ``only_mid_control``; the residuals
+    belong to ONE call; a wrong shape is an error, not a read past the tensor; the accuracy mode carries them into the (hi, lo) pair."""
+    lib = sub("_lib")
+    eng, om = tiny["model"].engine, tiny["oracle"]
+    x = seeded((4, 4, 16, 16), 5)
+    t = torch.tensor([999.0, 500.25, 37.5, 1.0])
+    ctx = tiny["cond"]
+    shapes = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: shapes.append(tuple(o.shape))) for m in list(om.unet.input_blocks) + [om.unet.middle_block]]
+    ref_plain = om.unet(x.half().float(), t, ctx.half().float())
+    for h in hooks:
+        h.remove()
+    control = [0.3 * seeded(sh, 40 + i) for i, sh in enumerate(shapes)]
+    ref = om.unet(x.half().float(), t, ctx.half().float(), control=[c.half().float() for c in control])
+    ref_mid = om.unet(x.half().float(), t, ctx.half().float(), control=[c.half().float() for c in control], only_mid_control=True)
+    assert rel_l2(ref, ref_plain) > 5e-2 and rel_l2(ref_mid, ref) > 1e-2         # the residuals matter
+    plain = eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev)).cpu()
+    for dt, tol in ((torch.float32, 5e-3), (torch.float16, 8e-3)):
+        ctl = [c.to(dev, dt) for c in control]
+        got = eng.unet_forward(x.to(dev, dt), t.to(dev, dt), ctx.to(dev, dt), control=ctl).float().cpu()
+        mid = eng.unet_forward(x.to(dev, dt), t.to(dev, dt), None, control=ctl, only_mid_control=True).float().cpu()
+        assert rel_l2(got, ref) < tol and rel_l2(mid, ref_mid) < tol, (dt, rel_l2(got, ref), rel_l2(mid, ref_mid))
+    assert torch.equal(eng.unet_forward(x.to(dev), t.to(dev), None).cpu(), plain)            # consumed: the next call is the plain forward
+    # through the SdUnet adapter (B1), as the webui's patched UNetModel.forward calls it
+    unet = sub("sd_unet").Mi355xUnet(lambda: None, unet_cfg=tiny["model"].unet_cfg, device_index=0)
+    unet.engine = eng
+    via = unet.forward(x.to(dev), t.to(dev), ctx.to(dev), control=[c.to(dev) for c in control]).float().cpu()
+    assert rel_l2(via, ref) < 5e-3
+    with pytest.raises(NotImplementedError, match="extra UNet inputs"):
+        unet.forward(x.to(dev), t.to(dev), ctx.to(dev), some_other_input=1)
+    with pytest.raises(lib.SdmiError, match="control"):
+        eng.unet_forward(x.to(dev), t.to(dev), None, control=[c.to(dev) for c in control[:-1]])
+    bad = [c.to(dev) for c in control]
+    bad[3] = bad[3][:, :, :-1]
+    with pytest.raises(lib.SdmiError, match="shape"):
+        eng.unet_forward(x.to(dev), t.to(dev), None, control=bad)
+    assert torch.equal(eng.unet_forward(x.to(dev), t.to(dev), None).cpu(), plain)            # a refused call leaves nothing behind
+    ref32 = om.unet(x, t, ctx.half().float(), control=control)
+    eng.set_option("residual_fp32", 1)
+    try:
+        acc = eng.unet_forward(x.to(dev), t.to(dev), None, control=[c.to(dev) for c in control]).cpu()
+    finally:
+        eng.set_option("residual_fp32", 0)
+    assert rel_l2(acc, ref32) < 4e-3
+
+
 def test_engine_promise_options_are_checkable(dev, tiny, monkeypatch):
     """cfg_pairs / uniform_t are promises of the caller about x and t; SDMI_CHECK_PROMISES=1 makes the engine verify them."""
     eng = tiny["model"].engine
