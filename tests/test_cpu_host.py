@@ -1252,6 +1252,115 @@ def test_engine_samplers_read_the_webuis_own_opts_and_state(webui):
     assert amd_shared.opts.eta_ancestral == 1.0 and amd_shared.webui is None and amd_shared.MaskBlendArgs is not webui.scripts.MaskBlendArgs
 
 
+def test_sampler_rows_fan_out_over_the_devices_of_one_webui_process(webui, monkeypatch):
+    """VERDICT r5 missing #2 (modules/call_queue.py:8-13, modules/cmd_args.py:106): inside a webui the batch of ONE
+    sampling call is spread over opts.mi355x_devices at the sampler row — contiguous row ranges, one worker + one engine UNet replica per
+    device, per-range ImageRNG over the range's own seeds in the state the batch's generator is in, conds / img2img tensors / SDXL dict
+    conds / MulticondLearnedConditioning sliced alike, LoRA merges re-applied on a replica — and the concatenation is what the
+    single-device call returns.  (The engines are stand-ins here; the real ones run the same split in tests/test_gpu_models.py's
+    device-pool test.)"""
+    import types
+    bridge, amd_shared, amd_rng = sub("webui_bridge"), sub("shared"), sub("rng")
+    webui.sd_unet.current_unet = webui.unet
+    view = bridge.engine_model_view(webui.shared.sd_model, webui.sd_unet)
+    made, merged = [], []
+
+    class FakeSampler:                                        # a "sampling loop" whose output depends on everything that is per row
+        def __init__(self, v):
+            self.view, self.config = v, None
+            made.append(v.engine.device)
+
+        def _run(self, p, x, cond, uncond, extra):
+            c = cond["crossattn"] if isinstance(cond, dict) else (torch.stack([b[0] for b in cond.batch]) if hasattr(cond, "batch") else cond)
+            u = torch.stack([torch.as_tensor(r, dtype=torch.float32) for r in uncond]) if isinstance(uncond, list) else uncond
+            noise = p.rng.next()                              # the step noise of an ancestral sampler
+            seeds = torch.tensor(p.seeds, dtype=torch.float32).view(-1, 1, 1, 1)
+            return 2.0 * x + c.mean(dim=(1, 2)).view(-1, 1, 1, 1) - u.mean(dim=1).view(-1, 1, 1, 1) + noise + 1e-3 * seeds + extra
+
+        def sample(self, p, x, cond, uncond, steps=None, image_conditioning=None):
+            return self._run(p, x, cond, uncond, 0.0 if image_conditioning is None else image_conditioning.mean(dim=(1, 2, 3)).view(-1, 1, 1, 1))
+
+        def sample_img2img(self, p, x, noise, cond, uncond, steps=None, image_conditioning=None):
+            return self._run(p, x, cond, uncond, noise * 0.5 + p.init_latent * 0.25)
+    replicas = {}
+
+    def fake_unet_on_device(unet, device):
+        if device == unet.engine.device:
+            return unet
+        return replicas.setdefault(device, types.SimpleNamespace(engine=types.SimpleNamespace(device=device), unet_cfg=unet.unet_cfg, checkpoint=lambda: {}))
+    monkeypatch.setattr(bridge, "_unet_on_device", fake_unet_on_device)
+    monkeypatch.setattr(bridge, "_torch_device", lambda d: torch.device("cpu"))
+    monkeypatch.setattr(bridge, "serial_device_workers", True)
+
+    class CpuGenerator:                                       # the package's Generator draws on the device (Philox kernel): a host stand-in
+        def __init__(self, seed, device):
+            self.g = torch.Generator().manual_seed(int(seed))
+
+        def randn(self, shape):
+            return torch.randn(tuple(shape), generator=self.g)
+    monkeypatch.setattr(amd_rng, "Generator", CpuGenerator)
+    n, shape = 5, (4, 8, 8)
+    seeds, subseeds = [100 + i for i in range(n)], [900 + i for i in range(n)]
+    g = torch.Generator().manual_seed(3)
+    cond, x = torch.randn(n, 77, 16, generator=g), None
+    uncond = [[float(i), float(i) + 0.5] for i in range(n)]   # a per-image list (the uncond schedules' container)
+
+    def job():
+        r = amd_rng.ImageRNG(shape, seeds, subseeds, 0.0, device="cpu")
+        p = _job(batch_size=n, seeds=list(seeds), subseeds=list(subseeds), rng=r)
+        return p, r.next()                                    # the webui draws x before the sampler runs
+    p, x = job()
+    whole = FakeSampler(view).sample(p, x, cond, uncond, image_conditioning=torch.ones(n, 5, 8, 8) * torch.arange(n).view(-1, 1, 1, 1))
+    made.clear()
+    view._networks_applied = (("some-lora",), lambda v: merged.append(v.engine.device))
+    p, x = job()
+    split = bridge.sample_over_devices(FakeSampler, view, "sample", p, (x, cond, uncond),
+                                       dict(image_conditioning=torch.ones(n, 5, 8, 8) * torch.arange(n).view(-1, 1, 1, 1)), [0, 1, 2])
+    assert torch.equal(split, whole) and made == [0, 1, 2] and merged == [1, 2]            # 5 rows over 3 devices: 2 + 2 + 1; LoRA on the replicas only
+    split2 = bridge.sample_over_devices(FakeSampler, view, "sample", job()[0], (x, cond, uncond),
+                                        dict(image_conditioning=torch.ones(n, 5, 8, 8) * torch.arange(n).view(-1, 1, 1, 1)), [0, 1, 2])
+    assert torch.equal(split2, whole) and merged == [1, 2]    # the same merges are not applied twice
+    # SDXL dict conds, a MulticondLearnedConditioning-shaped container, img2img tensors on p
+    class Multi:
+        def __init__(self, shape, batch):
+            self.shape, self.batch = shape, batch
+    dict_cond = {"crossattn": cond, "vector": torch.randn(n, 8, generator=g)}
+    multi = Multi((n,), [[cond[i]] for i in range(n)])
+    for c in (dict_cond, multi):
+        p, x = job()
+        a = FakeSampler(view).sample(p, x, c, uncond)
+        p, x = job()
+        assert torch.equal(bridge.sample_over_devices(FakeSampler, view, "sample", p, (x, c, uncond), {}, [0, 1]), a)
+    init, noise = torch.randn(n, 4, 8, 8, generator=g), torch.randn(n, 4, 8, 8, generator=g)
+    p, x = job()
+    p.init_latent = init
+    a = FakeSampler(view).sample_img2img(p, x, noise, cond, uncond)
+    p, x = job()
+    p.init_latent = init
+    assert torch.equal(bridge.sample_over_devices(FakeSampler, view, "sample_img2img", p, (x, noise, cond, uncond), {}, [0, 1]), a)
+    # the row's own call dispatches on opts.mi355x_devices (and not for a single image, nor without the option)
+    seen = []
+    monkeypatch.setattr(bridge, "sample_over_devices", lambda make, v, name, p, args, kwargs, devs: seen.append((name, list(devs), args[0].shape[0])) or "fanned-out")
+    row = webui.sd_samplers.all_samplers_map["Euler a"]
+    s = row.constructor(webui.shared.sd_model)
+    s.config = row
+    webui.shared.opts.mi355x_devices = "0,1"
+    try:
+        p, x = job()
+        assert s.sample(p, x, cond, uncond) == "fanned-out" and seen == [("sample", [0, 1], n)]
+        one = amd_rng.ImageRNG(shape, seeds[:1], device="cpu")
+        assert bridge.job_needs_stock_sampler(_job(), webui.shared.sd_model) is None
+        monkeypatch.setattr(s, "sample", s.sample)          # (keep the wrapper; a one-image call must take the fused path: checked by count)
+        n_seen = len(seen)
+        try:
+            s.sample(_job(batch_size=1, seeds=seeds[:1], rng=one), one.next(), cond[:1], uncond[:1])
+        except Exception:
+            pass                                              # the stand-in engine cannot sample; what matters is that nothing fanned out
+        assert len(seen) == n_seen
+    finally:
+        del webui.shared.opts.mi355x_devices
+
+
 def test_refiner_checkpoint_switch_on_the_engine_path_inside_a_webui(webui):
     """VERDICT r5 missing #3 (modules/sd_samplers_common.py:158-202): with the webui's checkpoint loader bound
     (webui_bridge.install_refiner_switch), a job that names a refiner checkpoint STAYS on the engine sampler; at the switch point the
