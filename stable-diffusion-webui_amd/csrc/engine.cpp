@@ -235,6 +235,12 @@ static int build_st(sdmi_engine* e, const std::string& name, int ch, int heads, 
         TRY(pack_one(e, m, tb + ".attn2.to_out.0", true, false, &b.o2));
         TRY(pack_one(e, m, tb + ".ff.net.0.proj", true, true, &b.ff1));
         TRY(pack_one(e, m, tb + ".ff.net.2", true, false, &b.ff2));
+        // room for the fused feed-forward chain's packed operand stream (rowchain.hip; filled lazily, refilled after weight updates): taken
+        // here, not inside a forward — a hipMalloc between two launches of a forward synchronises the device
+        if (rowchain_supports(ch) && b.ff1.geglu && b.ff2.cin_pad * 2 == b.ff1.n_pad && b.ff1.cin_pad == ch && b.ff2.n_pad == ch) {
+            const size_t pb = rowchain_ff_pack_bytes(ch, b.ff2.cin_pad);
+            if (pb) TRY(dev_alloc(e, (void**)&b.ff_packs, pb));
+        }
         b.ctx_slot = e->unet.n_ctx_slots++;
         st->blocks.push_back(b);
     }
@@ -841,7 +847,7 @@ static int run_st(Run& r, const STW& st, const half_t* x, int B, int H, int Wd, 
             b.ff2.n_pad == C) {
             if (!r.dry) {
                 const int hidden = b.ff2.cin_pad;
-                if (!b.ff_packs) {
+                if (!b.ff_packs) {                            // (normally taken at build time: build_st; a model built before the option was set)
                     void* pk = nullptr;
                     SDMI_CHECK_HIP(hipMalloc(&pk, rowchain_ff_pack_bytes(C, hidden)));
                     e->owned.push_back(pk);

@@ -279,6 +279,14 @@ class StableDiffusionProcessingTxt2Img(StableDiffusionProcessing):
                 samples, decoded_samples = None, image
             else:
                 samples, decoded_samples = self.sd_model.get_first_stage_encoding(self.sd_model.encode_first_stage(image)), None
+            # the reference carries ONE row here and lets torch broadcast it against the batch's noise and conds in the second pass
+            # (:1429-1454); the engine's kernels take whole batches, so the row is repeated for every image of the batch
+            nb = len(seeds) if seeds is not None else self.batch_size
+            if nb > 1:
+                if samples is not None:
+                    samples = samples.expand(nb, *samples.shape[1:]).contiguous()
+                if decoded_samples is not None:
+                    decoded_samples = decoded_samples.expand(nb, *decoded_samples.shape[1:]).contiguous()
         else:
             x = self.rng.next()
             samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning,
