@@ -4,6 +4,7 @@
 #include <cstring>
 
 namespace sdmi {
+extern int g_vae_attn_rows;
 int unet_forward(sdmi_engine* e, const void* x, const void* t, const void* ctx, const void* y, void* out, int io_dtype,
                  int Bn, int h, int w, int L, hipStream_t s);
 int vae_decode(sdmi_engine* e, const void* z, int io_dtype, float* out, int B, int h, int w, hipStream_t s);
@@ -578,6 +579,7 @@ int sdmi_debug_set(const char* name, int value) {
     const std::string n(name);
     if (n == "gemm_cfg") g_force_gemm_cfg = value;
     else if (n == "gemm_shortk_cfg") g_shortk_gemm_cfg = value;
+    else if (n == "vae_attn_rows") g_vae_attn_rows = value;
     else if (n == "gemm_shortk_maxk") g_shortk_max_k = value;
     else if (n == "gemm_geglu_cfg") g_geglu_gemm_cfg = value;
     else if (n == "vt_mode") g_vt_mode = value;

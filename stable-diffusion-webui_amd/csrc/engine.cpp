@@ -1449,6 +1449,7 @@ static int vae_build(sdmi_engine* e) {
 
 // single-head spatial attention of the VAE mid block (N = H*W tokens, d = C = 512): scores materialised through the
 // GEMM kernel (fp32), row softmax, then P V — modules/sd_hijack_optimizations.py:554-610 computes the same product chunked.
+int g_vae_attn_rows = [] { const char* e = getenv("SDMI_VAE_ATTN_ROWS"); return e ? atoi(e) : 16384; }();   // query rows per block of the VAE's attention (debug knob "vae_attn_rows")
 static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H, int Wd, half_t** out, float ss = 1.f) {
     const int C = a.c, HW = H * Wd, Npad = rup(HW, 64);
     const size_t M = (size_t)B * HW;
@@ -1458,30 +1459,41 @@ static int run_vae_attn(Run& r, const VAEAttnW& a, const half_t* x, int B, int H
     TRY(run_linear(r, a.qk, n0, (int)M, nullptr, qk, 2 * C));
     half_t* vt = r.H((size_t)B * C * Npad);
     TRY(run_vt(r, a.v, n0, C, B, HW, Npad, vt, true));
-    float* S = r.F((size_t)B * HW * Npad);
-    half_t* P = r.H((size_t)B * HW * Npad);
+    // Scores are materialised (one head, d = 512: softmax_rows between two batched GEMMs).  Beyond `g_vae_attn_rows` query rows the
+    // product runs in blocks of that many rows over the whole key set — softmax rows are independent, so the result is the unblocked
+    // product's (modules/sub_quadratic_attention.py / sd_hijack_optimizations.py:554-610 chunk the reference's product the same way):
+    // a 2048x2048 decode (N = 65536) would otherwise need 17 GB of fp32 scores per image, a 4096x4096 one 275 GB (round 6).
+    const int RB = (g_vae_attn_rows > 0 && HW > g_vae_attn_rows) ? g_vae_attn_rows : HW;
+    const int nblk = cdiv(HW, RB);
+    float* S = r.F((size_t)(nblk == 1 ? B : 1) * RB * Npad);
+    half_t* P = r.H((size_t)(nblk == 1 ? B : 1) * RB * Npad);
     half_t* o = r.H(M * C);
     if (!r.dry) {
-        GemmP p{};
-        p.a0 = qk; p.c0 = C; p.cin = C; p.lda0 = 2 * C;
-        p.w = qk + C; p.ldw = 2 * C;
-        p.out = S;
-        p.Hi = HW; p.Wi = 1; p.Ho = HW; p.Wo = 1; p.taps = 1; p.stride = 1;
-        p.M = HW; p.N = Npad; p.n_valid = HW; p.K = C; p.ldo = Npad; p.rows_per_batch = HW; p.n_real = Npad;
-        p.flags = EP_OUT_F32;
-        p.alpha = 1.0f / sqrtf((float)C);
-        p.a_bs = (long)HW * 2 * C; p.w_bs = (long)HW * 2 * C; p.o_bs = (long)HW * Npad;
-        TRY(launch_gemm(p, B, r.e->force_generic, r.e->use_glds, r.s));
-        TRY(launch_softmax_rows(S, P, (int64_t)B * HW, HW, Npad, Npad, r.s));
-        GemmP g{};
-        g.a0 = P; g.c0 = Npad; g.cin = Npad; g.lda0 = Npad;
-        g.w = vt; g.ldw = Npad;
-        g.out = o;
-        g.Hi = HW; g.Wi = 1; g.Ho = HW; g.Wo = 1; g.taps = 1; g.stride = 1;
-        g.M = HW; g.N = C; g.K = Npad; g.ldo = C; g.rows_per_batch = HW; g.n_real = C;
-        g.alpha = 1.f;
-        g.a_bs = (long)HW * Npad; g.w_bs = (long)C * Npad; g.o_bs = (long)HW * C;
-        TRY(launch_gemm(g, B, r.e->force_generic, r.e->use_glds, r.s));
+        for (int b = 0; b < (nblk == 1 ? 1 : B); ++b)
+            for (int k = 0; k < nblk; ++k) {
+                const int row0 = k * RB, rows = std::min(RB, HW - row0), nb = nblk == 1 ? B : 1;
+                const size_t img = (size_t)b * HW;
+                GemmP p{};
+                p.a0 = qk + (img + row0) * 2 * C; p.c0 = C; p.cin = C; p.lda0 = 2 * C;
+                p.w = qk + img * 2 * C + C; p.ldw = 2 * C;
+                p.out = S;
+                p.Hi = rows; p.Wi = 1; p.Ho = rows; p.Wo = 1; p.taps = 1; p.stride = 1;
+                p.M = rows; p.N = Npad; p.n_valid = HW; p.K = C; p.ldo = Npad; p.rows_per_batch = rows; p.n_real = Npad;
+                p.flags = EP_OUT_F32;
+                p.alpha = 1.0f / sqrtf((float)C);
+                p.a_bs = (long)HW * 2 * C; p.w_bs = (long)HW * 2 * C; p.o_bs = (long)RB * Npad;
+                TRY(launch_gemm(p, nb, r.e->force_generic, r.e->use_glds, r.s));
+                TRY(launch_softmax_rows(S, P, (int64_t)nb * rows, HW, Npad, Npad, r.s));
+                GemmP g{};
+                g.a0 = P; g.c0 = Npad; g.cin = Npad; g.lda0 = Npad;
+                g.w = vt + (size_t)b * C * Npad; g.ldw = Npad;
+                g.out = o + (img + row0) * C;
+                g.Hi = rows; g.Wi = 1; g.Ho = rows; g.Wo = 1; g.taps = 1; g.stride = 1;
+                g.M = rows; g.N = C; g.K = Npad; g.ldo = C; g.rows_per_batch = rows; g.n_real = C;
+                g.alpha = 1.f;
+                g.a_bs = (long)RB * Npad; g.w_bs = (long)C * Npad; g.o_bs = (long)HW * C;
+                TRY(launch_gemm(g, nb, r.e->force_generic, r.e->use_glds, r.s));
+            }
     }
     half_t* y = r.H(M * C);
     TRY(run_linear(r, a.proj, o, (int)M, x, y, C, ss));

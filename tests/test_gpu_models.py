@@ -269,6 +269,30 @@ def test_vae_decode_and_encode_tiny_vs_oracle(dev, tiny):
     assert rel_l2(lat.cpu(), om.vae.encode_first_stage_mean(img.half().float())) < 5e-3
 
 
+def test_vae_attention_in_blocks_of_query_rows(dev, tiny):
+    """The VAE's mid-block attention materialises its scores (one head, d = C); beyond `vae_attn_rows` query rows the product runs in
+    row blocks over the whole key set (engine.cpp run_vae_attn, round 6: a 4096x4096 decode would need 275 GB of fp32 scores; the
+    reference chunks the same product, modules/sd_hijack_optimizations.py:554-610).  Softmax rows are independent: the blocked decode
+    is the unblocked one up to the rounding of another GEMM dispatch, it meets the oracle, and batch rows are kept apart."""
+    lib = sub("_lib")
+    eng, om = tiny["model"].engine, tiny["oracle"]
+    z = seeded((2, 4, 16, 16), 31)                             # 256 tokens in the mid block
+    whole = eng.vae_decode(z.to(dev)).cpu()
+    ref = om.vae.decode_first_stage(z)
+    try:
+        lib.check(lib.lib.sdmi_debug_set(b"vae_attn_rows", 64))        # 4 blocks per image
+        blocked = eng.vae_decode(z.to(dev)).cpu()
+        lib.check(lib.lib.sdmi_debug_set(b"vae_attn_rows", 96))        # a ragged last block (96 + 96 + 64)
+        ragged = eng.vae_decode(z.to(dev)).cpu()
+        enc_b = tiny["model"].encode_first_stage(torch.tanh(seeded((1, 3, 32, 32), 32)).to(dev)).cpu()
+    finally:
+        lib.check(lib.lib.sdmi_debug_set(b"vae_attn_rows", 16384))
+    enc = tiny["model"].encode_first_stage(torch.tanh(seeded((1, 3, 32, 32), 32)).to(dev)).cpu()
+    assert torch.isfinite(blocked).all() and rel_l2(blocked, whole) < 1.5e-3 and rel_l2(ragged, whole) < 1.5e-3
+    assert rel_l2(blocked, ref) < 6e-3 and rel_l2(ragged, ref) < 6e-3 and rel_l2(enc_b, enc) < 1.5e-3
+    assert torch.equal(eng.vae_decode(z.to(dev)).cpu(), whole)          # the knob is back: the unblocked bits
+
+
 def test_vae_decoder_against_reference_class_fixture(dev, golden_dir):
     """HIP decoder vs the output of the reference's own VAEDecoder class (modules/models/sd3/sd3_impls.py:305-355)."""
     import os

@@ -57,7 +57,7 @@ def classify(name):
         if re.search(r" x\d+$", name):
             return "1x1_batched"
         return "1x1"
-    for p in ("attention_mfma_self", "attention_mfma_cross", "groupnorm", "layernorm", "splitk", "small_linear", "rowchain_xattn", "rowchain_ff"):
+    for p in ("attention_mfma_self", "attention_mfma_cross", "groupnorm", "layernorm", "splitk", "small_linear", "rowchain_ff"):
         if name.startswith(p):
             return p
     return "other"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Torch-free check + timing of the fused row-local chains (csrc/rowchain.hip) at the C1 level-0 shape: 16 images x 4096 tokens x 320.
+"""Torch-free check + timing of the fused feed-forward chain (csrc/rowchain.hip) at the C1 level-0 shape: 16 images x 4096 tokens x 320.
 
     python tools/gpu/rowchain_check.py [--rows 65536] [--iters 20] [--out gpurun_out/rowchain_check.json]
 
