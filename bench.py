@@ -185,7 +185,7 @@ def make_job(args, model, rank, world, local_only=False, replay=None):
     return run_once, (lo, hi)
 
 
-def dropin_path(args, model, jobs=3):
+def dropin_path(args, model, jobs=3, auto_promises=False):
     """What a webui user gets WITHOUT the engine's own process_images / sampler mirror: the reference's Python loop around the plugin
     boundaries.  A torch-side stand-in of that loop — per step `torch.cat` of cond | uncond and of x (modules/sd_samplers_cfg_denoiser.py:
     236-246), x * c_in, fp16 `Mi355xUnet.forward` through the SdUnet boundary B1 with the context validated on the device
@@ -230,13 +230,21 @@ def dropin_path(args, model, jobs=3):
         img = model.engine.vae_decode(x / model.scale_factor * model.scale_factor)    # decode_first_stage: z / scale_factor inside the engine config
         u8 = (255.0 * torch.clamp((img + 1.0) / 2.0, 0.0, 1.0)).permute(0, 2, 3, 1).to(torch.uint8).cpu()
         return u8
-    job()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(jobs):
+    # auto_promises: Mi355xUnet.forward lets the engine derive the [x | x] / one-timestep facts from the data of each call
+    # (opts.mi355x_auto_cfg_pairs: a synchronising device -> host compare per evaluation, then the shared CFG prefix)
+    shared_mod = sub("shared")
+    prev = getattr(shared_mod.opts, "mi355x_auto_cfg_pairs", True)
+    shared_mod.opts.mi355x_auto_cfg_pairs = bool(auto_promises)
+    try:
         job()
-    torch.cuda.synchronize()
-    return B * jobs / (time.time() - t0)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(jobs):
+            job()
+        torch.cuda.synchronize()
+        return B * jobs / (time.time() - t0)
+    finally:
+        shared_mod.opts.mi355x_auto_cfg_pairs = prev
 
 
 def pmc_traffic(args):
@@ -613,12 +621,16 @@ def main():
             roof, kernels = roofline_block(args, run_local)
         else:
             roof, kernels = roofline_block(args, run_once)
-    dropin = None
+    dropin = dropin_auto = None
     if rank == 0 and world == 1 and not args.no_dropin and not (args.hires or args.img2img) and args.sampler == "Euler a":
         try:
             dropin = round(dropin_path(args, model, jobs=min(3, max(1, args.steps))), 4)
         except Exception as ex:                                # the drop-in stand-in must never cost the bench line
             dropin = f"failed: {type(ex).__name__}: {ex}"
+        try:
+            dropin_auto = round(dropin_path(args, model, jobs=min(3, max(1, args.steps)), auto_promises=True), 4)
+        except Exception as ex:
+            dropin_auto = f"failed: {type(ex).__name__}: {ex}"
     per_row = None
     if rank == 0 and world == 1 and not args.no_dropin:
         # transparency leg: the same job with the CFG denoiser's common-subexpression options off — every UNet row computed on its own, as the
@@ -691,7 +703,10 @@ def main():
                    "accuracy_mode": "engine option residual_fp32 (--no-half / opts.sdmi_accuracy_mode): <= 1e-3 per UNet forward from the fp32 oracle "
                                     "(tests/test_gpu_c1_parity.py); NOT the configuration of `value`",
                    "dropin_images_per_s": dropin,
-                   "dropin_path": "torch stand-in of the reference's CFGDenoiser + Euler-a loop calling Mi355xUnet.forward per step + engine VAE decode (bench.py dropin_path)",
+                   "dropin_auto_promises_images_per_s": dropin_auto,
+                   "dropin_path": "torch stand-in of the reference's CFGDenoiser + Euler-a loop calling Mi355xUnet.forward per step + engine VAE decode (bench.py dropin_path); "
+                                  "dropin_images_per_s: every row computed; dropin_auto_promises_images_per_s: the engine derives the [x | x] / one-timestep facts per call "
+                                  "(opts.mi355x_auto_cfg_pairs, the extension's default since round 6)",
                    # whole job against the MFMA ceiling, two ways: on the REFERENCE graph's flops (what an image costs the reference: the
                    # yardstick that stays comparable across rounds), and on the flops the engine actually executes — with cfg_pairs the
                    # shared prefix runs once per image pair, so the like-for-like rate is the every-row-computed one

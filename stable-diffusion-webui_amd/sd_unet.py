@@ -95,7 +95,7 @@ class Mi355xUnet(SdUnet):
         # This adapter gets an anonymous batch from the webui's own CFG denoiser: whether it is [x | x] at one timestep (the plain CFG
         # batch, for which the engine shares the layers in front of the first cross-attention) only the data says.  opts.mi355x_auto_cfg_pairs
         # lets the engine look (a synchronising compare per evaluation; the engine's own samplers know and never need it).
-        auto = bool(getattr(shared.opts, "mi355x_auto_cfg_pairs", False))
+        auto = bool(getattr(shared.opts, "mi355x_auto_cfg_pairs", True))
         return self.engine.unet_forward(x, timesteps, ctx, y, auto_promises=auto, control=kwargs.get("control"),
                                         only_mid_control=bool(kwargs.get("only_mid_control", False)))
 

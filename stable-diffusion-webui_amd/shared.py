@@ -68,7 +68,7 @@ class Options:
     mi355x_devices: str = ""                       # (engine option) "0,1,2,3": devices of THIS process a job's images are spread over (parallel.DevicePool); empty = one
     mi355x_devices_serial: bool = False            # run the pool's workers one after the other (the host-emulated CPU tier)
     sdmi_accuracy_mode: bool = False               # (engine option, not a webui setting) carry the UNet's residual stream with ~22 bits: sd_models.set_accuracy_mode
-    mi355x_auto_cfg_pairs: bool = False            # (engine option) Mi355xUnet.forward behind the webui's stock CFG denoiser: let the engine find the [x | x] batch itself (sd_unet.py)
+    mi355x_auto_cfg_pairs: bool = True             # (engine option; default ON since round 6: 19.56 -> 20.05 images/s on the drop-in path, bench.py dropin legs) Mi355xUnet.forward behind the webui's stock CFG denoiser: the engine finds the [x | x] batch itself (sd_unet.py)
 
 
 opts = Options()

@@ -177,6 +177,42 @@ def test_c1_unet_cfg_forward_16_rows_vs_oracle(dev, sd15):
         assert emu_rows["fp16_stream"]["engine_vs_emulated"] < 1.6 * e_engine_4          # two independent fp16 realisations would sit at sqrt(2)
 
 
+def test_c1_fused_feed_forward_chain_on_the_rows_of_the_real_level_0_blocks(dev, sd15):
+    """the fused chain (`fuse_rows` 2: norm3 -> GEGLU -> ff.net.2 -> + x as ONE launch at the 320-wide level) was
+    only held against fp32 on random weights at one shape, and in aggregate by the 16-row forward.  Here, in isolation, on the rows it
+    really sees: the traced C1 forward hands back, for every level-0 transformer block, the chain's input (`...attn2+x`) and output; the
+    fp32 reference of the chain on that fp16 input, with that block's weights, must be met to the rounding of the branch (the fp16
+    LayerNorm output and hidden tensor), and the chain must be what ran (no taps of an unfused hidden tensor exist either way: the
+    launch name says so)."""
+    import torch.nn.functional as F
+    eng, net = sd15["model"].engine, sd15["unet"]
+    x, t, ctx = seeded((16, 4, 64, 64), 101), torch.linspace(999.0, 1.0, 16), seeded((16, 77, 768), 102)
+    eng.set_option("trace", 1)
+    try:
+        eng.unet_forward(x.to(dev), t.to(dev), ctx.to(dev))
+        torch.cuda.synchronize()
+        taps = {k: v.float().cpu() for k, v in eng.taps().items()}
+    finally:
+        eng.set_option("trace", 0)
+    rows = {}
+    for name, mod in net.named_modules():
+        if not name.endswith("transformer_blocks.0") or mod.norm3.normalized_shape[0] != 320:
+            continue
+        xin, out = taps[name + ".attn2+x"], taps[name]          # NCHW fp16 values: [16, 320, 64, 64]
+        tok = xin.permute(0, 2, 3, 1).reshape(-1, 320)[::7]      # every 7th token row of the 65536 (the fp32 reference on the host)
+        got = out.permute(0, 2, 3, 1).reshape(-1, 320)[::7]
+        with torch.no_grad():
+            n = F.layer_norm(tok, (320,), mod.norm3.weight, mod.norm3.bias, mod.norm3.eps)
+            a, gate = mod.ff.net[0].proj(n).chunk(2, dim=-1)
+            ref = tok + mod.ff.net[2](a * F.gelu(gate))
+        rows[name] = {"rel_l2": rel_l2(got, ref), "rel_l2_of_the_branch": rel_l2(got - tok, ref - tok)}
+    assert len(rows) == 5, sorted(rows)                        # input_blocks.1 / 2, output_blocks.9 / 10 / 11
+    report("fused_feed_forward_chain_on_real_level0_rows", rows)
+    print(f"[c1 ff chain] {rows}")
+    for name, r in rows.items():
+        assert r["rel_l2"] < 4e-4 and r["rel_l2_of_the_branch"] < 1.5e-3, (name, r)      # random weights, one shape: 2.1e-4 / 4.9e-4 (test_gpu_ops)
+
+
 def test_c1_unet_forward_accuracy_mode_vs_oracle(dev, sd15, golden_dir):
     """Engine option "residual_fp32" on the C1 forward: the configuration the engine offers for north_star's <= 1e-3.  Round 6: EVERY
     tensor that is not a matrix-core operand keeps ~22 bits — the carried stream, the skip_connection outputs, the first conv's output of
