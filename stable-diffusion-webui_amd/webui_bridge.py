@@ -264,12 +264,14 @@ def _torch_device(index: int):
     return torch.device("cuda", int(index))
 
 
-def _unet_on_device(unet, device: int):
-    """The active engine UNet itself on its own device, else a replica of it on ``device`` (packed once per checkpoint activation)."""
+def _unet_on_device(unet, device: int, nth: int = 0):
+    """The active engine UNet itself for the FIRST worker on its own device, else a replica of it on ``device`` (packed once per
+    checkpoint activation).  ``nth``: which worker of that device asks — an engine serves one caller at a time, so a device named twice
+    in opts.mi355x_devices gets a second engine, never two threads on one."""
     from .sd_unet import Mi355xUnet
-    if int(device) == int(unet.engine.device):
+    if int(device) == int(unet.engine.device) and nth == 0:
         return unet
-    key = (id(unet), id(unet.engine), int(device))
+    key = (id(unet), id(unet.engine), int(device), int(nth))
     rep = _unet_replicas.get(key)
     if rep is None:
         for k in [k for k in _unet_replicas if k[0] == id(unet) and k[1] != id(unet.engine)]:      # replicas of a deactivated engine
@@ -341,7 +343,7 @@ def sample_over_devices(make_sampler, view, name, p, args, kwargs, devices):
             dev = _torch_device(devs[slot])
             if torch.cuda.is_available() and dev.type == "cuda":
                 torch.cuda.set_device(dev)
-            unet = _unet_on_device(view._unet, devs[slot])
+            unet = _unet_on_device(view._unet, devs[slot], devs[:slot].count(devs[slot]))
             v = view if unet is view._unet else EngineModelView(view._sd_model, unet)
             if v is not view and lora is not None and getattr(unet, "_networks_applied", None) != lora[0]:
                 lora[1](v)                                    # the LoRA / LyCORIS merges of the primary engine, on this replica

@@ -1284,8 +1284,8 @@ def test_sampler_rows_fan_out_over_the_devices_of_one_webui_process(webui, monke
             return self._run(p, x, cond, uncond, noise * 0.5 + p.init_latent * 0.25)
     replicas = {}
 
-    def fake_unet_on_device(unet, device):
-        if device == unet.engine.device:
+    def fake_unet_on_device(unet, device, nth=0):
+        if device == unet.engine.device and nth == 0:
             return unet
         return replicas.setdefault(device, types.SimpleNamespace(engine=types.SimpleNamespace(device=device), unet_cfg=unet.unet_cfg, checkpoint=lambda: {}))
     monkeypatch.setattr(bridge, "_unet_on_device", fake_unet_on_device)

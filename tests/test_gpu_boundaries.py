@@ -1,6 +1,7 @@
 """GPU tests of the drop-in boundaries: the SdUnet adapter (B1), the SdOptimization attention
 forward inside an unmodified torch CrossAttention module (B2), the VAE decode hook (B4) and the sampler registry (B3)."""
 import importlib
+import os
 import types
 
 import numpy as np
@@ -53,9 +54,65 @@ def test_sd_unet_adapter_forward_contract(dev):
         ref3 = ou.build_unet(ou.tiny_config(), sd)(x.float().cpu(), t.float().cpu(), ctx_b.float().cpu())
         assert rel_l2(out3.float().cpu(), ref3) < 8e-3
         assert torch.equal(unet.forward(x, t, ctx_b), out3)      # equal content at another address: cache hit, same bits
-        with pytest.raises(NotImplementedError):
-            unet.forward(x, t, reused, control=[x])
+        with pytest.raises(NotImplementedError):              # extra inputs the engine does not know are refused, loudly
+            unet.forward(x, t, reused, some_other_extra_input=[x])
+        with pytest.raises(sub("_lib").SdmiError, match="control"):      # ControlNet residuals are the engine's since round 6: a malformed
+            unet.forward(x, t, reused, control=[x])                      # list is an error of the call, not a silent run
+        assert torch.equal(unet.forward(x, t, reused), out3)             # ... and leaves nothing behind
     finally:
+        unet.deactivate()
+
+
+def test_sampler_row_fans_out_over_two_engines_with_the_real_sampler(dev):
+    """webui_bridge.sample_over_devices with REAL engines and the real Euler-a sampler: the box has one GPU, so the option names it twice
+    — the second worker gets its own engine UNet replica (an engine serves one caller at a time), both sample concurrently in their
+    threads (one after the other under the host-emulated tier), and the concatenated latents are the single-call latents bit for bit
+    at equal per-call batch size (4 rows -> 2 + 2 against two 2-row calls) and to fp16 rounding against the 4-row call."""
+    import types
+    schema, sd_unet, bridge, amd, rng = sub("schema"), sub("sd_unet"), sub("webui_bridge"), sub("sd_samplers"), sub("rng")
+    cfg = schema.tiny_unet()
+    sd = schema.synthetic_state_dict(cfg, None, dtype=torch.float16)
+    unet = sd_unet.Mi355xUnetOption("tiny", lambda: sd, cfg).create_unet()
+    unet.activate()
+    webui_model = types.SimpleNamespace(alphas_cumprod=schema.make_alphas_cumprod(), model=types.SimpleNamespace(conditioning_key="crossattn"),
+                                        parameterization="eps", is_sdxl=False, cond_stage_key="txt")
+    view = bridge.EngineModelView(webui_model, unet)
+    sub("shared").sd_model = view
+    row = amd.all_samplers_map["Euler a"]
+    seeds = [500, 501, 502, 503]
+    g = torch.Generator().manual_seed(5)
+    cond, uncond = torch.randn(4, 77, 64, generator=g).to(dev), torch.randn(4, 77, 64, generator=g).to(dev)
+
+    def job(lo, hi):
+        class P:
+            steps, cfg_scale, eta, scheduler, is_hr_pass, batch_size, iteration = 3, 6.0, None, None, False, hi - lo, 0
+            sampler_noise_scheduler_override, extra_generation_params = None, {}
+        p = P()
+        p.seeds = seeds[lo:hi]
+        p.rng = rng.ImageRNG((4, 16, 16), seeds[lo:hi], device=dev)
+        return p, p.rng.next()
+    monkey_serial = os.environ.get("SDMI_HOSTEMU") == "1"
+    prev = bridge.serial_device_workers
+    bridge.serial_device_workers = monkey_serial
+    try:
+        def single(lo, hi):
+            p, x = job(lo, hi)
+            s = row.constructor(view)
+            s.config = row
+            return s.sample(p, x, cond[lo:hi], uncond[lo:hi]).cpu()
+        whole = single(0, 4)
+        halves = torch.cat([single(0, 2), single(2, 4)])
+        p, x = job(0, 4)
+        view._row_config = row
+        fanned = bridge.sample_over_devices(row.constructor, view, "sample", p, (x, cond, uncond), {}, [0, 0]).cpu()
+        reps = [k for k in bridge._unet_replicas if k[0] == id(unet)]
+        assert len(reps) == 1 and bridge._unet_replicas[reps[0]].engine.handle != unet.engine.handle
+        assert torch.equal(fanned, halves)
+        assert rel_l2(fanned, whole) < 1e-2                   # the 4-row dispatch: other tiles (chaotic tiny model)
+    finally:
+        bridge.serial_device_workers = prev
+        for k in [k for k in bridge._unet_replicas if k[0] == id(unet)]:
+            bridge._unet_replicas.pop(k).deactivate()
         unet.deactivate()
 
 
