@@ -344,6 +344,20 @@ class DevicePool:
         self._sources[id(model)] = model
         return rep
 
+    def for_each_model(self, fn, model=None):
+        """``fn(replica)`` for every worker's twin of ``model`` (default: the pool's first model), one after the other in the calling
+        thread — how per-model state that lives outside the checkpoint reaches the replicas: ``pool.for_each_model(lambda m:
+        networks.load_networks(m, names, state_dicts, ...))`` merges a LoRA into every device's engine (the loader keeps module-level
+        state, so this is not something to do from the workers)."""
+        model = model or self.primary
+        done = []
+        for slot in range(len(self.devices)):
+            rep = self.replica(model, slot)
+            if not any(rep is d for d in done):
+                fn(rep)
+                done.append(rep)
+        return done
+
     def close(self):
         for (mid, slot), rep in list(self._replicas.items()):
             if rep is not self._sources.get(mid):
@@ -375,12 +389,22 @@ class DevicePool:
         n_total = p.batch_size * p.n_iter
         results, errors = [None] * n, [None] * n
 
+        # the workers' jobs — and with them any replica a hires / refiner checkpoint still needs — are built here, one after the other in
+        # the calling thread, before a worker starts
+        jobs = []
+        for slot in range(n):
+            if torch.cuda.is_available():
+                torch.cuda.set_device(self.devices[slot])
+            jobs.append(self._job_for(p, slot))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.primary.engine.device)
+
         def work(slot):
             try:
                 dev = self.devices[slot]
                 if torch.cuda.is_available():
                     torch.cuda.set_device(dev)                # torch's current device is per thread
-                q = self._job_for(p, slot)
+                q = jobs[slot]
                 results[slot] = process_images_sharded(q, runner=runner, world=n, rank=slot)
                 if torch.cuda.is_available():
                     torch.cuda.synchronize(dev)

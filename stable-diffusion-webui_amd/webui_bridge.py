@@ -336,6 +336,24 @@ def sample_over_devices(make_sampler, view, name, p, args, kwargs, devices):
     devs = [int(d) for d in devices][:n]
     results, errors = [None] * len(devs), [None] * len(devs)
     lora = getattr(view, "_networks_applied", None)
+    # replicas are packed, and the primary engine's LoRA / LyCORIS merges re-applied on them, HERE — one after the other in the calling
+    # thread (the network loader keeps module-level state: networks.loaded_networks) — before any worker starts
+    views, touched = [], False
+    for slot in range(len(devs)):
+        dev = _torch_device(devs[slot])
+        if torch.cuda.is_available() and dev.type == "cuda":
+            torch.cuda.set_device(dev)
+        unet = _unet_on_device(view._unet, devs[slot], devs[:slot].count(devs[slot]))
+        v = view if unet is view._unet else EngineModelView(view._sd_model, unet)
+        if v is not view and lora is not None and getattr(unet, "_networks_applied", None) != lora[0]:
+            lora[1](v)
+            unet._networks_applied = lora[0]
+            touched = True
+        views.append(v)
+    if touched:
+        lora[1](view)                                         # (leaves the loader's module state describing the primary again)
+    if torch.cuda.is_available() and x.device.type == "cuda":
+        torch.cuda.set_device(x.device)
 
     def work(slot):
         try:
@@ -343,11 +361,7 @@ def sample_over_devices(make_sampler, view, name, p, args, kwargs, devices):
             dev = _torch_device(devs[slot])
             if torch.cuda.is_available() and dev.type == "cuda":
                 torch.cuda.set_device(dev)
-            unet = _unet_on_device(view._unet, devs[slot], devs[:slot].count(devs[slot]))
-            v = view if unet is view._unet else EngineModelView(view._sd_model, unet)
-            if v is not view and lora is not None and getattr(unet, "_networks_applied", None) != lora[0]:
-                lora[1](v)                                    # the LoRA / LyCORIS merges of the primary engine, on this replica
-                unet._networks_applied = lora[0]
+            v = views[slot]
             sampler = make_sampler(v)
             sampler.config = getattr(view, "_row_config", None) or getattr(sampler, "config", None)
             q = _job_rows(p, lo, hi, n, dev)

@@ -1316,10 +1316,11 @@ def test_sampler_rows_fan_out_over_the_devices_of_one_webui_process(webui, monke
     p, x = job()
     split = bridge.sample_over_devices(FakeSampler, view, "sample", p, (x, cond, uncond),
                                        dict(image_conditioning=torch.ones(n, 5, 8, 8) * torch.arange(n).view(-1, 1, 1, 1)), [0, 1, 2])
-    assert torch.equal(split, whole) and made == [0, 1, 2] and merged == [1, 2]            # 5 rows over 3 devices: 2 + 2 + 1; LoRA on the replicas only
+    assert torch.equal(split, whole) and made == [0, 1, 2] and merged == [1, 2, 0]         # 5 rows over 3 devices: 2 + 2 + 1; LoRA merged on the replicas
+                                                                                           # (then once more on the primary: the loader's module state)
     split2 = bridge.sample_over_devices(FakeSampler, view, "sample", job()[0], (x, cond, uncond),
                                         dict(image_conditioning=torch.ones(n, 5, 8, 8) * torch.arange(n).view(-1, 1, 1, 1)), [0, 1, 2])
-    assert torch.equal(split2, whole) and merged == [1, 2]    # the same merges are not applied twice
+    assert torch.equal(split2, whole) and merged == [1, 2, 0]          # the same merges are not applied twice
     # SDXL dict conds, a MulticondLearnedConditioning-shaped container, img2img tensors on p
     class Multi:
         def __init__(self, shape, batch):

@@ -85,7 +85,7 @@ def test_sampler_row_fans_out_over_two_engines_with_the_real_sampler(dev):
 
     def job(lo, hi):
         class P:
-            steps, cfg_scale, eta, scheduler, is_hr_pass, batch_size, iteration = 3, 6.0, None, None, False, hi - lo, 0
+            steps, cfg_scale, eta, scheduler, is_hr_pass, batch_size, iteration = 2, 6.0, None, None, False, hi - lo, 0
             sampler_noise_scheduler_override, extra_generation_params = None, {}
         p = P()
         p.seeds = seeds[lo:hi]

@@ -1518,6 +1518,7 @@ def test_one_process_device_pool_reproduces_the_single_device_job(dev, tiny):
     pool = par.DevicePool(model, [0, 0], serial=serial)
     try:
         assert pool.replica(model, 0) is model and pool.replica(model, 1) is not model and pool.replica(model, 1).engine.handle != model.engine.handle
+        assert [m.engine.handle for m in pool.for_each_model(lambda m: None)] == [model.engine.handle, pool.replica(model, 1).engine.handle]
         assert shared.sd_model is model                        # the replica's constructor did not take over the reference's global
         cases = ((2, 2, dict(width=64, height=64)), (1, 3, dict(width=64, height=64)),
                  (1, 2, dict(width=64, height=64, enable_hr=True, hr_scale=2.0, hr_upscaler="Latent", denoising_strength=0.6)))
