@@ -718,7 +718,7 @@ def main():
     }
     if kernels is not None:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_{args.config}.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_{args.config if args.named else 'custom'}.json"), "w") as f:
             json.dump(kernels, f, indent=1)
     print(json.dumps(out), flush=True)
 

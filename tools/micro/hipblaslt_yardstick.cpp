@@ -70,6 +70,9 @@ int main(int argc, char** argv) {
         {"L0 conv 320->320  as GEMM M65536 N320  K2880     ", 65536,  320, 2880, 0},
         {"L1 conv 640->640  as GEMM M16384 N640  K5760     ", 16384,  640, 5760, 0},
         {"L2 conv 1280->1280 as GEMM M4096 N1280 K11520    ",  4096, 1280, 11520, 0},
+        // the 8x8-latent level (16 rows x 64 pixels): weight-streaming shapes, split-K 8 + a reduce pass in the engine
+        {"L3 conv 1280->1280 as GEMM M1024 N1280 K11520    ",  1024, 1280, 11520, 0},
+        {"L3 conv 2560->1280 as GEMM M1024 N1280 K23040    ",  1024, 1280, 23040, 0},
     };
     hipblasLtHandle_t lt;
     LT_OK(hipblasLtCreate(&lt));
