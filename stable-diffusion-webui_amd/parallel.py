@@ -450,12 +450,17 @@ _POOLS = {}
 
 
 def process_images_devices(p, devices, runner=None, serial: bool = False):
-    """``process_images`` over several devices of THIS process (module-level pool per (checkpoint object, device list): the replicas
-    are packed once and live as long as the first model does).  The extension calls this when ``opts.mi355x_devices`` names more than
+    """``process_images`` over several devices of THIS process (one module-level pool per device list: the replicas are packed once
+    per checkpoint and released when a job arrives with another one).  The extension calls this when ``opts.mi355x_devices`` names more than
     one device (extension/scripts/mi355x_engine.py); ``bench.py`` keeps the one-process-per-GPU path above."""
-    key = (id(p.sd_model), tuple(int(d) for d in devices), bool(serial))
+    key = (tuple(int(d) for d in devices), bool(serial))
     pool = _POOLS.get(key)
-    if pool is None or pool.primary is not p.sd_model:
+    if pool is not None and pool.primary is not p.sd_model:
+        # another checkpoint: the old pool's replicas (one packed model per extra device) are released before the new ones are packed —
+        # a pool holds its first model, so a cached pool per checkpoint would keep every checkpoint ever loaded resident on every device
+        pool.close()
+        pool = None
+    if pool is None:
         pool = DevicePool(p.sd_model, devices, serial=serial)
         _POOLS[key] = pool
     return pool.process_images(p, runner=runner)
