@@ -18,6 +18,7 @@
 #include <hipblaslt/hipblaslt.h>
 #include <cmath>
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -74,6 +75,17 @@ int main(int argc, char** argv) {
         {"L3 conv 1280->1280 as GEMM M1024 N1280 K11520    ",  1024, 1280, 11520, 0},
         {"L3 conv 2560->1280 as GEMM M1024 N1280 K23040    ",  1024, 1280, 23040, 0},
     };
+    // second table (argv[2] == "ksweep"): the level-1 / level-2 projection shapes at K = 320 ... 5120 — time against K separates a launch's
+    // fixed part (ramp, first loads, epilogue with its residual, tail) from its K loop, for the engine and for the library alike
+    static const Shape ksweep[] = {
+        {"M4096  N1280 K320   +res", 4096, 1280,  320, 1}, {"M4096  N1280 K640   +res", 4096, 1280,  640, 1},
+        {"M4096  N1280 K1280  +res", 4096, 1280, 1280, 1}, {"M4096  N1280 K2560  +res", 4096, 1280, 2560, 1},
+        {"M4096  N1280 K5120  +res", 4096, 1280, 5120, 1},
+        {"M16384 N640  K320   +res", 16384, 640,  320, 1}, {"M16384 N640  K640   +res", 16384, 640,  640, 1},
+        {"M16384 N640  K1280  +res", 16384, 640, 1280, 1}, {"M16384 N640  K2560  +res", 16384, 640, 2560, 1},
+        {"M4096  N1280 K1280      ", 4096, 1280, 1280, 0}, {"M16384 N640  K640       ", 16384, 640,  640, 0},
+    };
+    const bool sweep = argc > 2 && std::string(argv[2]) == "ksweep";
     hipblasLtHandle_t lt;
     LT_OK(hipblasLtCreate(&lt));
     const size_t ws_bytes = 256u << 20;
@@ -84,7 +96,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     printf("%-52s %10s %10s %8s %10s %10s %6s %9s\n", "shape", "engine us", "TFLOP/s", "", "hipBLASLt", "TFLOP/s", "algos", "rel-L2");
-    for (const Shape& sh : shapes) {
+    std::vector<Shape> todo;
+    if (sweep) todo.assign(std::begin(ksweep), std::end(ksweep)); else todo.assign(std::begin(shapes), std::end(shapes));
+    for (const Shape& sh : todo) {
         const long M = sh.M, N = sh.N, K = sh.K;
         const long na = M * K, nw = N * K, no = M * N;
         std::vector<half_t> ha(na), hw(nw), hr(no);
