@@ -86,6 +86,7 @@ int main(int argc, char** argv) {
         {"M4096  N1280 K1280      ", 4096, 1280, 1280, 0}, {"M16384 N640  K640       ", 16384, 640,  640, 0},
     };
     const bool sweep = argc > 2 && std::string(argv[2]) == "ksweep";
+    if (const char* ov = getenv("SDMI_GEMM_OVERRIDE")) SDMI_OK(sdmi_debug_set_str("gemm_override", ov));   // force tiles per shape (engine column)
     hipblasLtHandle_t lt;
     LT_OK(hipblasLtCreate(&lt));
     const size_t ws_bytes = 256u << 20;
