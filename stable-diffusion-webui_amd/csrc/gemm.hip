@@ -2396,7 +2396,7 @@ static float cfg_score(const GemmP& p, int batch, int cfg, int split) {
 // tools/gpu/shape_tune.py: every candidate tile / split of a shape is timed INSIDE the whole job, where its operands sit in the
 // cache state they really have — isolated micro-benchmarks mis-ranked tiles twice in round 1); (2) the table those runs produced
 // for the shapes of the benchmarked workload.  Anything not listed falls through to the score model below.
-struct ShapeKey { int M, N, K, taps, kind; };            // kind: 0 plain epilogue, 1 GEGLU, 2 transposed output
+struct ShapeKey { int M, N, K, taps, kind; };            // kind: 0 plain epilogue, 1 GEGLU, 2 transposed output; + 4: the (hi, lo) launch of that kind
 struct ShapeChoice { ShapeKey k; int cfg, split; };
 static std::vector<ShapeChoice> g_gemm_override;
 static const ShapeChoice kTunedShapes[] = {
@@ -2420,11 +2420,15 @@ int gemm_set_override(const char* spec) {
     return 0;
 }
 static const ShapeChoice* find_shape(const GemmP& p) {
-    const int kind = (p.flags & EP_GEGLU) ? 1 : (p.flags & EP_TRANSPOSE) ? 2 : 0;
-    for (const ShapeChoice& sc : g_gemm_override)
-        if (sc.k.M == p.M && sc.k.N == p.N && sc.k.K == p.K && sc.k.taps == p.taps && sc.k.kind == kind) return &sc;
-    for (const ShapeChoice& sc : kTunedShapes)
-        if (sc.cfg >= 0 && sc.k.M == p.M && sc.k.N == p.N && sc.k.K == p.K && sc.k.taps == p.taps && sc.k.kind == kind) return &sc;
+    // (hi, lo) launches of the accuracy mode (EP_HILO: twice the epilogue bytes) may carry their own entries, kind + 4; without one
+    // they take the entry of the plain launch of the same shape
+    const int base_kind = (p.flags & EP_GEGLU) ? 1 : (p.flags & EP_TRANSPOSE) ? 2 : 0;
+    for (int kind : {(p.flags & EP_HILO) ? base_kind + 4 : base_kind, base_kind}) {
+        for (const ShapeChoice& sc : g_gemm_override)
+            if (sc.k.M == p.M && sc.k.N == p.N && sc.k.K == p.K && sc.k.taps == p.taps && sc.k.kind == kind) return &sc;
+        for (const ShapeChoice& sc : kTunedShapes)
+            if (sc.cfg >= 0 && sc.k.M == p.M && sc.k.N == p.N && sc.k.K == p.K && sc.k.taps == p.taps && sc.k.kind == kind) return &sc;
+    }
     return nullptr;
 }
 
@@ -2591,7 +2595,7 @@ int launch_gemm(const GemmP& p_in, int batch, bool force_generic, bool use_glds,
     std::string pname;
     if (prof_enabled()) {
         pname = std::string(kCfgName[cfg]) + (phase ? "pp" : "") + (split > 1 ? "_splitk" + std::to_string(p.splitk) : "") + (p.taps == 9 ? "_conv3x3" : "_1x1") +
-                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + (p.korder == 2 ? "_dx" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
+                ((p.flags & EP_GEGLU) ? "_geglu" : "") + ((p.flags & EP_TRANSPOSE) ? "_tr" : "") + ((p.flags & EP_HILO) ? "_hl" : "") + (p.tile_order ? "_mf" : "") + (p.stats_nchunk ? "_gn" : "") + (p.korder == 2 ? "_dx" : "") + " M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) +
                 ((p.flags & EP_LNFOLD) ? " ln" : "") + (batch > 1 ? " x" + std::to_string(batch) : "");
     }
     ProfScope ps(pname.c_str(), pf_flops, pf_bytes, s);

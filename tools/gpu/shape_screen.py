@@ -37,17 +37,18 @@ def parse(name):
     if not m:
         return None
     head = name.split(" ")[0]
-    return (int(m.group(1)), int(m.group(2)), int(m.group(3)), 9 if "conv3x3" in head else 1, 1 if "_geglu" in head else 2 if "_tr" in head else 0)
+    kind = 1 if "_geglu" in head else 2 if "_tr" in head else 0
+    return (int(m.group(1)), int(m.group(2)), int(m.group(3)), 9 if "conv3x3" in head else 1, kind + (4 if "_hl" in head else 0))   # + 4: (hi, lo) launch
 
 
 def candidates(key):
     M, N, K, taps, kind = key
     out = []
     for cfg, bn in CFG_BN.items():
-        if N % bn or (kind == 1 and cfg in (5, 6, 8, 9, 10, 13)):
+        if N % bn or (kind % 4 == 1 and cfg in (5, 6, 8, 9, 10, 13)):
             continue
         splits = [1]
-        if kind == 0 and K >= 64 * 16 and ((M + 127) // 128) * ((N + 127) // 128) < 512:      # a split-K workspace exists for these
+        if kind % 4 == 0 and K >= 64 * 16 and ((M + 127) // 128) * ((N + 127) // 128) < 512:      # a split-K workspace exists for these
             splits += [s for s in (2, 3, 4, 6, 8) if K // 64 // s >= 4]
         out += [(cfg, s) for s in splits]
     return out
@@ -72,6 +73,7 @@ def main():
     ap.add_argument("--top", type=int, default=30, help="shapes screened, by their share of the forward")
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--min-gain", type=float, default=0.03, help="a winner must beat the default by this fraction of the shape's time")
+    ap.add_argument("--with", dest="with_", default="", help="knobs every setting of the screen carries, e.g. residual_fp32=1 (the accuracy mode)")
     ap.set_defaults(out=os.path.join(ROOT, "gpurun_out", "shape_screen.json"))
     argv = sys.argv[1:]
     args = ap.parse_args((["base"] if not any(not a.startswith("-") for a in argv[:1]) else []) + argv)
@@ -86,7 +88,9 @@ def main():
                     best[key] = (us, n)
         return best
 
-    env.apply("base")
+    pre = (args.with_ + ",") if args.with_ else ""
+    base_setting = args.with_ or "base"
+    env.apply(base_setting)
     base = measure()
     targets = sorted(base, key=lambda k: -base[k][0] * base[k][1])[:args.top]
     cands = {k: candidates(k) for k in targets}
@@ -96,7 +100,7 @@ def main():
     for r in range(rounds):
         ov = ";".join(f"{k[0]},{k[1]},{k[2]},{k[3]},{k[4]}:{cands[k][r][0]}:{cands[k][r][1]}" for k in targets if r < len(cands[k]))
         try:
-            env.apply("gemm_override=" + ov)
+            env.apply(pre + "gemm_override=" + ov)
             got = measure()
         except (env._lib.SdmiError, RuntimeError) as ex:       # a candidate the library refuses for its shape: the whole round is void
             print(f"round {r}: {ex}", flush=True)
@@ -104,7 +108,7 @@ def main():
         for k in targets:
             if r < len(cands[k]) and k in got:
                 seen[k][cands[k][r]] = got[k][0]
-    env.apply("base")
+    env.apply(base_setting)
     report, winners = [], []
     for k in targets:
         us0, n = base[k]
@@ -124,7 +128,7 @@ def main():
         e0, e1 = hipmem.Event(), hipmem.Event()
         times = {"base": [], "winners": []}
         for rep in range(max(args.reps, 3)):
-            for name, setting in (("base", "base"), ("winners", "gemm_override=" + ov)):
+            for name, setting in (("base", base_setting), ("winners", pre + "gemm_override=" + ov)):
                 env.apply(setting)
                 env.forward()
                 hipmem.sync()
