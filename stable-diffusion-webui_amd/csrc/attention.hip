@@ -356,10 +356,14 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 17 || VAR =
         } else
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;      // scale > 0: max commutes with the scaling
         }
-        const float m_new = fmaxf(m_run, mx);
+        // Exponent base m_run: with tau = 0 the running maximum (P <= 1).  The lazy forms re-base — all 64 lanes together, O^T rescaled —
+        // only when some query's tile maximum exceeds its base by more than tau; until then the base stands and P <= 2^tau (fp16 P, fp32
+        // sums: any tau <= 15 is exact up to the rounding of P, whose relative precision does not depend on its scale).  With a wave-wide
+        // test and i.i.d. scores a plain running maximum moves in ~65 % of the 64 tiles of a 4096-key row; with tau = 8 only in the first.
+        const bool max_moved = !LAZY_RESCALE || __builtin_amdgcn_ballot_w64(mx > m_run + p.tau) != 0;   // wave-uniform
+        const float m_new = max_moved ? fmaxf(m_run, mx) : m_run;
         if constexpr (TIMING) { asm volatile("" :: "v"(m_new)); tc = stamp(); }
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        const bool max_moved = !LAZY_RESCALE || __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;   // wave-uniform
         m_run = m_new;
         const f2v mneg = {-m_new, -m_new};
         f2v rs = {0.f, 0.f};
@@ -930,6 +934,10 @@ int g_attn_kvt = [] { const char* e = getenv("SDMI_ATTN_KVT"); return e ? atoi(e
 // default 15 since round 2: same-box A/Bs on the C1 job — 0 -> 5: self-attention 72.4 -> 69.5 ms per job (profiles/r02_knob_sweep.md);
 // 5 -> 15: 68.2 -> 66.6 and 70.0 -> 68.7 ms on two boxes (profiles/r02_attention_experiments.md)
 int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e) : 15; }();
+// slack of the lazy re-basing in log2 units (AttnP::tau); 0 = the round-2 behaviour (bit-identical to the non-lazy forms).  Default 8 since
+// round 6: level-0 self-attention 545.4 -> 525.0 us isolated (-3.7 %; 4 and 12 the same), C1 forward 16.893 -> 16.812 ms in a same-box A/B,
+// 3.8e-4 from the tau = 0 output = the distance of two fp16 realisations of P (profiles/r06_attn_ab_tau.txt, r06_fwd_ab_tau.txt)
+int g_attn_tau = [] { const char* e = getenv("SDMI_ATTN_TAU"); return e ? atoi(e) : 8; }();
 int g_attn_fold_min_m = [] { const char* e = getenv("SDMI_ATTN_FOLD_MIN_M"); return e ? atoi(e) : 8192; }();   // 0: never
 int g_attn_lds_pad = 0;      // tuning only: extra dynamic LDS per workgroup (bytes) = an occupancy limiter (32 KB + pad per workgroup of 160 KB)
 int g_attn_pp_min_m = [] { const char* e = getenv("SDMI_ATTN_PP_MIN_M"); return e ? atoi(e) : 256; }();   // shortest key sequence the 8-wave kernel takes
@@ -961,7 +969,9 @@ static int launch_attn_pp(const AttnP& p, hipStream_t s) {
     return 0;
 }
 
-int launch_attention(const AttnP& p, bool force_generic, hipStream_t s) {
+int launch_attention(const AttnP& p_in, bool force_generic, hipStream_t s) {
+    AttnP p = p_in;
+    p.tau = (float)(g_attn_tau < 0 ? 0 : g_attn_tau > 12 ? 12 : g_attn_tau);
     SDMI_REQUIRE(p.B > 0 && p.H > 0 && p.N > 0 && p.M > 0 && p.D > 0, "empty attention");
     SDMI_REQUIRE(p.vt_ld >= (p.M + 63) / 64 * 64, "vt_ld must be >= M rounded up to 64");
     const double pf_flops = 4.0 * p.B * p.H * (double)p.N * p.M * p.D;

@@ -593,6 +593,7 @@ int sdmi_debug_set(const char* name, int value) {
     else if (n == "attn_occ") g_attn_occ = value;
     else if (n == "attn_lds_pad") g_attn_lds_pad = value;
     else if (n == "attn_fold_min_m") g_attn_fold_min_m = value;
+    else if (n == "attn_tau") g_attn_tau = value;
     else if (n == "attn_dbg_lo") g_attn_dbg = (g_attn_dbg & 0xFFFFFFFF00000000ull) | (unsigned)value;
     else if (n == "attn_dbg_hi") g_attn_dbg = (g_attn_dbg & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32);
     else if (n == "gemm_split") g_force_gemm_split = value;

@@ -197,6 +197,7 @@ extern int g_attn_kvt;
 extern int g_attn_occ;
 extern int g_attn_lds_pad;
 extern int g_attn_fold_min_m;
+extern int g_attn_tau;
 extern unsigned long long g_attn_dbg;   // device pointer (0 = off) for AttnP::dbg
 extern int g_gemm_dbgflags;
 extern unsigned long long g_gemm_dbg;   // device pointer (0 = off): 5 x int64 per wave of section cycle sums
@@ -212,6 +213,8 @@ struct AttnP {
     float scale_log2;      // softmax scale * log2(e)
     int causal;            // 1: key j is visible to query i only if j <= i (CLIP text encoder; requires N == M)
     long long* dbg;        // tuning only (SDMI_ATTN_PARTS builds, attn_occ = 18): per-wave section cycle sums, 8 x int64 per wave
+    float tau;             // set by launch_attention from g_attn_tau: slack (log2 units) a score may exceed the exponent base by before
+                           // the lazy-rescale forms re-base (0: re-base whenever some query's running maximum moves)
 };
 int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 // v [B, M, ldv] (head h at h*D) -> vt [B, H*D, Mpad] (zero padded)

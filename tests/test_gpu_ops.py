@@ -24,6 +24,9 @@ def dev():
     return torch.device("cuda", 0)
 
 
+ATTN_TAU_DEFAULT = 8          # csrc/attention.hip g_attn_tau
+
+
 def h(t):
     return t.half().float()       # the fp16-rounded value the kernel sees
 
@@ -577,11 +580,13 @@ def test_attention_role_offset_kernel(dev, variant):
 
     def run(q, k, v, heads, occ):
         lib.check(lib.lib.sdmi_debug_set(b"attn_occ", occ))
+        lib.check(lib.lib.sdmi_debug_set(b"attn_tau", 0))       # (variant 15's bits as the yardstick: re-based whenever a running maximum moves)
         try:
             out = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
             torch.cuda.synchronize()
         finally:
             lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
+            lib.check(lib.lib.sdmi_debug_set(b"attn_tau", ATTN_TAU_DEFAULT))
         return out
 
     for d, heads, n, m in ((40, 8, 512, 512), (40, 2, 256, 256), (40, 1, 300, 333), (40, 2, 1024, 576), (40, 1, 256, 290), (40, 8, 4096, 4096),
@@ -765,13 +770,65 @@ def test_attention_experiment_variants_match_production_kernel(dev):
         for variant in (5, 15):
             try:
                 lib.check(lib.lib.sdmi_debug_set(b"attn_occ", variant))
+                lib.check(lib.lib.sdmi_debug_set(b"attn_tau", 0))       # same re-basing rule as 0: whenever a running maximum moves
                 got = ops.attention(q, k, v, heads)
                 torch.cuda.synchronize()
             finally:
                 lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
+                lib.check(lib.lib.sdmi_debug_set(b"attn_tau", ATTN_TAU_DEFAULT))
             # same operation counts in the compiled loops (packed vs scalar forms of the same fp32 ops): the bits are expected equal
             assert torch.equal(got, base) or rel_l2(got.float().cpu(), base.float().cpu()) < 1e-4, (heads, n, m, variant)
 
+
+
+def test_attention_lazy_rebase_slack(dev):
+    """Round 6: the lazy forms of the d = 40 kernel re-base the exponent (and rescale O^T) only when some query's tile maximum exceeds the
+    base in use by more than tau (log2 units; knob attn_tau, default 8) — P <= 2^tau instead of <= 1, the same softmax up to the rounding of
+    P to fp16.  tau = 0 is the old rule and gives variant 0's bits; the default holds fp32 to the same bound and stays within two fp16
+    realisations of tau = 0; rows built against the bookkeeping: scores that climb by less than tau per tile (never re-based after the first
+    tile: P grows to 2^tau-ish), by more than tau per tile (re-based in every tile), one spike far above everything late in the row,
+    and a first tile far below zero."""
+    ops, lib = sub("ops"), sub("_lib")
+
+    def run(q, k, v, heads, tau, occ=15):
+        lib.check(lib.lib.sdmi_debug_set(b"attn_occ", occ))
+        lib.check(lib.lib.sdmi_debug_set(b"attn_tau", tau))
+        try:
+            out = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
+            torch.cuda.synchronize()
+        finally:
+            lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
+            lib.check(lib.lib.sdmi_debug_set(b"attn_tau", ATTN_TAU_DEFAULT))
+        return out.float().cpu()
+
+    for heads, n, m in ((8, 512, 512), (2, 200, 77), (1, 130, 333), (2, 1024, 4096), (1, 256, 290)):
+        q, k, v = seeded((2, n, heads * 40), 141), seeded((2, m, heads * 40), 142), seeded((2, m, heads * 40), 143)
+        ref = _attn_ref(h(q), h(k), h(v), heads)
+        old, new = run(q, k, v, heads, 0), run(q, k, v, heads, ATTN_TAU_DEFAULT)
+        v0 = run(q, k, v, heads, 0, occ=0)
+        assert torch.equal(old, v0) or rel_l2(old, v0) < 1e-4, (heads, n, m)
+        assert rel_l2(old, ref) < 5e-4 and rel_l2(new, ref) < 5e-4, (heads, n, m, rel_l2(old, ref), rel_l2(new, ref))
+        assert rel_l2(new, old) < 6e-4, (heads, n, m, rel_l2(new, old))
+    d, n, m = 40, 256, 640                               # 10 KV tiles of 64 keys
+    q = torch.zeros(1, n, d)
+    q[..., 0] = 1.0
+    q[:, :, 1:] = 0.05 * seeded((1, n, d - 1), 151)
+    scale = d ** -0.5
+    tile = torch.arange(m) // 64
+    for name, per_tile in (("climbs by 3 per tile", 3.0), ("climbs by 11 per tile", 11.0), ("falls by 5 per tile", -5.0)):
+        k = 0.05 * seeded((1, m, d), 152)
+        k[0, :, 0] = (per_tile * tile.float() - (60.0 if per_tile > 0 else 0.0)) / (scale * 1.4426950408889634)     # log2-unit steps
+        v = seeded((1, m, d), 153)
+        ref = _attn_ref(h(q), h(k), h(v), 1)
+        for tau in (0, 4, ATTN_TAU_DEFAULT, 12):
+            e = rel_l2(run(q, k, v, 1, tau), ref)
+            assert e < 5e-4, (name, tau, e)
+    k = 0.05 * seeded((1, m, d), 154)
+    k[0, 500, 0] = 40.0 / scale                          # one key 40 nats above the rest, in the 8th tile
+    v = seeded((1, m, d), 155)
+    ref = _attn_ref(h(q), h(k), h(v), 1)
+    for tau in (0, ATTN_TAU_DEFAULT):
+        assert rel_l2(run(q, k, v, 1, tau), ref) < 5e-4, tau
 
 
 # ------------------------------------------------------------------------------------------------------------
