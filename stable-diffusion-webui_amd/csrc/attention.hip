@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 17 || VAR =
             float mlo = mx, mhi = mx;
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mlo), "+v"(mhi));
             mx = fmaxf(mlo, mhi);
-            const bool up = t == 0 || mx > 0.f;                // per query; the first tile always sets the shift (it may be negative)
+            // per query; the first tile always sets the shift (it may be negative); later tiles raise it only when a score exceeds it by
+            // more than tau (AttnP::tau: P <= 2^tau until then)
+            const bool up = t == 0 || mx > fmaxf(p.tau, 0.f);
             if (__builtin_amdgcn_ballot_w64(up) != 0) {
                 asm volatile("");                                 // a real (wave-uniform) branch: rare after the first few tiles
                 // new shift = the smallest fp16 number >= shift + mx (both halves of the wave compute the same value for a query)
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(256, ((VAR == 15 || VAR == 16 || VAR == 17 || VAR =
         // only when some query's tile maximum exceeds its base by more than tau; until then the base stands and P <= 2^tau (fp16 P, fp32
         // sums: any tau <= 15 is exact up to the rounding of P, whose relative precision does not depend on its scale).  With a wave-wide
         // test and i.i.d. scores a plain running maximum moves in ~65 % of the 64 tiles of a 4096-key row; with tau = 8 only in the first.
-        const bool max_moved = !LAZY_RESCALE || __builtin_amdgcn_ballot_w64(mx > m_run + p.tau) != 0;   // wave-uniform
+        // (the round-1 form, VAR 0 — head sizes 64 / 80 / 128 / 160 and the 77-key launches — rescales in every tile only under knob attn_tau -1)
+        const bool max_moved = (!LAZY_RESCALE && p.tau < 0.f) || __builtin_amdgcn_ballot_w64(mx > m_run + fmaxf(p.tau, 0.f)) != 0;   // wave-uniform
         const float m_new = max_moved ? fmaxf(m_run, mx) : m_run;
         if constexpr (TIMING) { asm volatile("" :: "v"(m_new)); tc = stamp(); }
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -971,7 +974,7 @@ static int launch_attn_pp(const AttnP& p, hipStream_t s) {
 
 int launch_attention(const AttnP& p_in, bool force_generic, hipStream_t s) {
     AttnP p = p_in;
-    p.tau = (float)(g_attn_tau < 0 ? 0 : g_attn_tau > 12 ? 12 : g_attn_tau);
+    p.tau = (float)(g_attn_tau < 0 ? -1 : g_attn_tau > 12 ? 12 : g_attn_tau);
     SDMI_REQUIRE(p.B > 0 && p.H > 0 && p.N > 0 && p.M > 0 && p.D > 0, "empty attention");
     SDMI_REQUIRE(p.vt_ld >= (p.M + 63) / 64 * 64, "vt_ld must be >= M rounded up to 64");
     const double pf_flops = 4.0 * p.B * p.H * (double)p.N * p.M * p.D;

@@ -809,6 +809,8 @@ def test_attention_lazy_rebase_slack(dev):
         assert torch.equal(old, v0) or rel_l2(old, v0) < 1e-4, (heads, n, m)
         assert rel_l2(old, ref) < 5e-4 and rel_l2(new, ref) < 5e-4, (heads, n, m, rel_l2(old, ref), rel_l2(new, ref))
         assert rel_l2(new, old) < 6e-4, (heads, n, m, rel_l2(new, old))
+        fold = run(q, k, v, heads, ATTN_TAU_DEFAULT, occ=17)       # the folded-shift form (hires default): shift raised with the same slack
+        assert rel_l2(fold, ref) < 5e-4, (heads, n, m, rel_l2(fold, ref))
     d, n, m = 40, 256, 640                               # 10 KV tiles of 64 keys
     q = torch.zeros(1, n, d)
     q[..., 0] = 1.0
@@ -820,15 +822,17 @@ def test_attention_lazy_rebase_slack(dev):
         k[0, :, 0] = (per_tile * tile.float() - (60.0 if per_tile > 0 else 0.0)) / (scale * 1.4426950408889634)     # log2-unit steps
         v = seeded((1, m, d), 153)
         ref = _attn_ref(h(q), h(k), h(v), 1)
-        for tau in (0, 4, ATTN_TAU_DEFAULT, 12):
-            e = rel_l2(run(q, k, v, 1, tau), ref)
-            assert e < 5e-4, (name, tau, e)
+        for occ in (15, 17):
+            for tau in (0, 4, ATTN_TAU_DEFAULT, 12):
+                e = rel_l2(run(q, k, v, 1, tau, occ=occ), ref)
+                assert e < 5e-4, (name, occ, tau, e)
     k = 0.05 * seeded((1, m, d), 154)
     k[0, 500, 0] = 40.0 / scale                          # one key 40 nats above the rest, in the 8th tile
     v = seeded((1, m, d), 155)
     ref = _attn_ref(h(q), h(k), h(v), 1)
-    for tau in (0, ATTN_TAU_DEFAULT):
-        assert rel_l2(run(q, k, v, 1, tau), ref) < 5e-4, tau
+    for occ in (15, 17):
+        for tau in (0, ATTN_TAU_DEFAULT):
+            assert rel_l2(run(q, k, v, 1, tau, occ=occ), ref) < 5e-4, (occ, tau)
 
 
 # ------------------------------------------------------------------------------------------------------------
