@@ -766,7 +766,14 @@ def test_attention_experiment_variants_match_production_kernel(dev):
     for heads, n, m in ((8, 512, 512), (2, 200, 77), (1, 130, 333), (1, 128, 64), (1, 70, 128), (2, 256, 192)):
         q, k, v = seeded((2, n, heads * 40), 41).half().to(dev), seeded((2, m, heads * 40), 42).half().to(dev), seeded((2, m, heads * 40), 43).half().to(dev)
         lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 0))
-        base = ops.attention(q, k, v, heads)
+        lib.check(lib.lib.sdmi_debug_set(b"attn_tau", 0))           # (0 re-bases lazily too since round 6: every form under the same rule)
+        try:
+            base = ops.attention(q, k, v, heads)
+            lib.check(lib.lib.sdmi_debug_set(b"attn_tau", -1))      # ... and the round-1 behaviour (O^T rescaled in every tile) has the same bits
+            assert torch.equal(base, ops.attention(q, k, v, heads)), (heads, n, m)
+        finally:
+            lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
+            lib.check(lib.lib.sdmi_debug_set(b"attn_tau", ATTN_TAU_DEFAULT))
         for variant in (5, 15):
             try:
                 lib.check(lib.lib.sdmi_debug_set(b"attn_occ", variant))
