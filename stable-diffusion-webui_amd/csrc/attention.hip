@@ -941,7 +941,10 @@ int g_attn_occ = [] { const char* e = getenv("SDMI_ATTN_OCC"); return e ? atoi(e
 // round 6: level-0 self-attention 545.4 -> 525.0 us isolated (-3.7 %; 4 and 12 the same), C1 forward 16.893 -> 16.812 ms in a same-box A/B,
 // 3.8e-4 from the tau = 0 output = the distance of two fp16 realisations of P (profiles/r06_attn_ab_tau.txt, r06_fwd_ab_tau.txt)
 int g_attn_tau = [] { const char* e = getenv("SDMI_ATTN_TAU"); return e ? atoi(e) : 8; }();
-int g_attn_fold_min_m = [] { const char* e = getenv("SDMI_ATTN_FOLD_MIN_M"); return e ? atoi(e) : 8192; }();   // 0: never
+// shortest d = 40 self-attention the folded-shift form (17) takes; 0: never.  8192 (the hires pass only) until round 6; with the re-basing
+// slack the form's bookkeeping block runs once per row instead of in most tiles and it leads at N = 4096 too: 525.3 -> 487.6 us per
+// level-0 launch (profiles/r06_attn_ab_forms_with_slack.txt), attention error 2.9e-4 -> 3.6e-4 (cap 5e-4), UNet forward parity unchanged
+int g_attn_fold_min_m = [] { const char* e = getenv("SDMI_ATTN_FOLD_MIN_M"); return e ? atoi(e) : 1024; }();
 int g_attn_lds_pad = 0;      // tuning only: extra dynamic LDS per workgroup (bytes) = an occupancy limiter (32 KB + pad per workgroup of 160 KB)
 int g_attn_pp_min_m = [] { const char* e = getenv("SDMI_ATTN_PP_MIN_M"); return e ? atoi(e) : 256; }();   // shortest key sequence the 8-wave kernel takes
 

@@ -25,6 +25,7 @@ def dev():
 
 
 ATTN_TAU_DEFAULT = 8          # csrc/attention.hip g_attn_tau
+ATTN_FOLD_MIN_M_DEFAULT = 1024     # csrc/attention.hip g_attn_fold_min_m
 
 
 def h(t):
@@ -581,12 +582,14 @@ def test_attention_role_offset_kernel(dev, variant):
     def run(q, k, v, heads, occ):
         lib.check(lib.lib.sdmi_debug_set(b"attn_occ", occ))
         lib.check(lib.lib.sdmi_debug_set(b"attn_tau", 0))       # (variant 15's bits as the yardstick: re-based whenever a running maximum moves)
+        lib.check(lib.lib.sdmi_debug_set(b"attn_fold_min_m", 0))     # (15 means 15 here: not handed on to 17 for the long rows)
         try:
             out = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
             torch.cuda.synchronize()
         finally:
             lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
             lib.check(lib.lib.sdmi_debug_set(b"attn_tau", ATTN_TAU_DEFAULT))
+            lib.check(lib.lib.sdmi_debug_set(b"attn_fold_min_m", ATTN_FOLD_MIN_M_DEFAULT))
         return out
 
     for d, heads, n, m in ((40, 8, 512, 512), (40, 2, 256, 256), (40, 1, 300, 333), (40, 2, 1024, 576), (40, 1, 256, 290), (40, 8, 4096, 4096),
@@ -800,12 +803,14 @@ def test_attention_lazy_rebase_slack(dev):
     def run(q, k, v, heads, tau, occ=15):
         lib.check(lib.lib.sdmi_debug_set(b"attn_occ", occ))
         lib.check(lib.lib.sdmi_debug_set(b"attn_tau", tau))
+        lib.check(lib.lib.sdmi_debug_set(b"attn_fold_min_m", 0))     # (15 means 15 here: not handed on to 17 for the long rows)
         try:
             out = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), heads)
             torch.cuda.synchronize()
         finally:
             lib.check(lib.lib.sdmi_debug_set(b"attn_occ", 15))
             lib.check(lib.lib.sdmi_debug_set(b"attn_tau", ATTN_TAU_DEFAULT))
+            lib.check(lib.lib.sdmi_debug_set(b"attn_fold_min_m", ATTN_FOLD_MIN_M_DEFAULT))
         return out.float().cpu()
 
     for heads, n, m in ((8, 512, 512), (2, 200, 77), (1, 130, 333), (2, 1024, 4096), (1, 256, 290)):
@@ -818,6 +823,10 @@ def test_attention_lazy_rebase_slack(dev):
         assert rel_l2(new, old) < 6e-4, (heads, n, m, rel_l2(new, old))
         fold = run(q, k, v, heads, ATTN_TAU_DEFAULT, occ=17)       # the folded-shift form (hires default): shift raised with the same slack
         assert rel_l2(fold, ref) < 5e-4, (heads, n, m, rel_l2(fold, ref))
+    # the production dispatch at the level-0 shape (form 17 from 1024 keys on, with the slack)
+    q, k, v = seeded((1, 4096, 320), 161), seeded((1, 4096, 320), 162), seeded((1, 4096, 320), 163)
+    got = ops.attention(q.half().to(dev), k.half().to(dev), v.half().to(dev), 8).float().cpu()
+    assert rel_l2(got, _attn_ref(h(q), h(k), h(v), 8)) < 5e-4
     d, n, m = 40, 256, 640                               # 10 KV tiles of 64 keys
     q = torch.zeros(1, n, d)
     q[..., 0] = 1.0

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 
 PKG = "stable-diffusion-webui_amd"
-DEFAULTS = {"attn_occ": 15, "attn_kvt": 0, "attn_lds_pad": 0, "attn_tau": 8}
+DEFAULTS = {"attn_occ": 15, "attn_kvt": 0, "attn_lds_pad": 0, "attn_tau": 8, "attn_fold_min_m": 1024}
 # name, images B, heads H, queries N, keys M, head size D
 SHAPES = {
     "c1": [("c1 self level 0", 16, 8, 4096, 4096, 40), ("c1 self level 1", 16, 8, 1024, 1024, 80), ("c1 self level 2", 16, 8, 256, 256, 160),

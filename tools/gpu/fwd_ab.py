@@ -35,7 +35,7 @@ hipmem = None                   # tools/gpu/hipmem.py, imported by main(): tools
 PKG = "stable-diffusion-webui_amd"
 FUSE_ROWS_DEFAULT = 2           # the engine's default for option "fuse_rows" (engine.h)
 ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse", "cfg_pairs", "uniform_t", "gn_cat", "fuse_rows", "residual_fp32")
-DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "attn_tau": 8,
+DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "attn_tau": 8, "attn_fold_min_m": 1024,
             "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1, "gemm_split": 0, "gemm_pipe": -1, "gemm_lin": 1, "gn_fuse": 1, "gn_small": 1, "ep_wide": 1,
             "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0, "cfg_pairs": 1, "uniform_t": 1, "gn_cat": 0, "fuse_rows": FUSE_ROWS_DEFAULT, "residual_fp32": 0}
 assert all(k in DEFAULTS for k in ENGINE_OPTS if k in ("gn_cat", "cfg_pairs", "uniform_t", "ln_fold", "streams", "arena_reuse"))     # every option a setting may switch is reset by the next one
