@@ -385,7 +385,9 @@ int sdmi_engine_tap_info(sdmi_engine* e, int index, char* name_out, int capacity
 int sdmi_engine_tap_read(sdmi_engine* e, int index, void* out_f16_nhwc, void* stream);
 
 /* Tuning knobs for benchmarks: "gemm_cfg" (-1 heuristic, 0..7 force a tile configuration when it fits the shape),
- * "attn_kvt" (0 heuristic, 64 force 64-key tiles). */
+ * "attn_kvt" (0 heuristic, 64 force 64-key tiles), "attn_tau" (slack of the flash kernels' lazy exponent re-basing in log2 units:
+ * default 8; 0 = re-base whenever a running maximum moves, -1 = also rescale O in every tile — both give the round-2 bits),
+ * "attn_fold_min_m" (shortest d = 40 self-attention that takes the folded-shift form: default 1024, 0 = never). */
 int sdmi_debug_set(const char* name, int value);
 /* String-valued knob: "gemm_override" = "M,N,K,taps,kind:cfg:split;..." forces a tile configuration / split-K factor for exact GEMM
  * shapes (kind 0 plain epilogue, 1 GEGLU, 2 transposed output; "" clears) — the in-engine shape autotuner tools/gpu/shape_tune.py. */

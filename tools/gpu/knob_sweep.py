@@ -21,10 +21,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PKG = "stable-diffusion-webui_amd"
-KNOBS = ("tile_order", "conv_korder", "small_linear_lds", "gemm_cfg", "gemm_shortk_cfg", "gemm_shortk_maxk", "gemm_geglu_cfg", "vt_mode", "attn_kvt", "attn_occ", "gemm_split", "gemm_pipe", "gemm_lin", "gn_fuse", "gn_small", "ep_wide", "gemm_dbgflags",
+KNOBS = ("tile_order", "conv_korder", "small_linear_lds", "gemm_cfg", "gemm_shortk_cfg", "gemm_shortk_maxk", "gemm_geglu_cfg", "vt_mode", "attn_kvt", "attn_occ", "attn_tau", "attn_fold_min_m", "gemm_split", "gemm_pipe", "gemm_lin", "gn_fuse", "gn_small", "ep_wide", "gemm_dbgflags",
          )
 ENGINE_OPTS = ("ln_fold", "streams", "arena_reuse")
-DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1, "cfg_pairs": 1,
+DEFAULTS = {"gemm_cfg": -1, "gemm_shortk_cfg": -1, "gemm_shortk_maxk": 448, "gemm_geglu_cfg": -1, "vt_mode": 1, "attn_kvt": 0, "attn_occ": 15, "attn_tau": 8, "attn_fold_min_m": 1024, "tile_order": -1, "conv_korder": -1, "small_linear_lds": 1, "cfg_pairs": 1,
             "gemm_split": 0, "gemm_pipe": -1, "gemm_lin": 1, "gn_fuse": 1, "gn_small": 1, "ep_wide": 1, "gemm_dbgflags": 0, "ln_fold": 0, "streams": 1, "arena_reuse": 0}
 
 
