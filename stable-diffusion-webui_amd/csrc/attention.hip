@@ -52,7 +52,8 @@ __device__ __forceinline__ float tree_max(const f16v (&sc)[NKB]) {
 }
 
 // VAR = forms of the d = 40 level-0 self-attention loop (docs/DESIGN_experiments.md, profiles/r02_attention_experiments.md); selected
-// with SDMI_ATTN_OCC=<VAR> / sdmi_debug_set("attn_occ", VAR); 15 is the default for d = 40 (see g_attn_occ):
+// with SDMI_ATTN_OCC=<VAR> / sdmi_debug_set("attn_occ", VAR); 15 is the default for d = 40 (see g_attn_occ), handed on to 17 for key
+// sequences of g_attn_fold_min_m (1024) and more since round 6:
 //   0  round-1 kernel: register budget for 2 workgroups per CU (D <= 80) or 1; one ds_read -> wait -> MFMA chain per MFMA
 //   5  128 VGPRs (4 workgroups per CU) + lazy rescale: the O accumulators are multiplied by alpha only when some lane's running
 //      max moved (alpha == 1 otherwise: the result is unchanged; after the first few KV tiles the max rarely moves)

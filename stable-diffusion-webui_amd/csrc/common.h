@@ -214,7 +214,7 @@ struct AttnP {
     int causal;            // 1: key j is visible to query i only if j <= i (CLIP text encoder; requires N == M)
     long long* dbg;        // tuning only (SDMI_ATTN_PARTS builds, attn_occ = 18): per-wave section cycle sums, 8 x int64 per wave
     float tau;             // set by launch_attention from g_attn_tau: slack (log2 units) a score may exceed the exponent base by before
-                           // the lazy-rescale forms re-base (0: re-base whenever some query's running maximum moves)
+                           // the kernels re-base (0: re-base whenever some query's running maximum moves; -1: the round-1 form also rescales O^T in every tile)
 };
 int launch_attention(const AttnP& p, bool force_generic, hipStream_t s);
 // v [B, M, ldv] (head h at h*D) -> vt [B, H*D, Mpad] (zero padded)
